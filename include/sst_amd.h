@@ -1,0 +1,218 @@
+/*
+ * sst_amd.h — C ABI of libsst_amd.so: the MI355X (gfx950) implementation of the SST / FSD sparse
+ * hot path (dynamic voxelization -> point->voxel scatter -> window bucketing -> Sparse Regional
+ * Attention core -> SIR segmented max).
+ *
+ * Conventions
+ *   - Every pointer named d_* is a DEVICE pointer (HBM). h_* pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream). All work is
+ *     enqueued on that stream; no entry point synchronises the device unless its comment says so.
+ *   - All buffers are owned by the caller (reference contract: tensors are caller/allocator owned,
+ *     SURVEY.md §8b "Ownership"). Workspaces are sized with the matching *_workspace_bytes().
+ *   - Return value: 0 on success, a positive hipError_t value if the HIP runtime reported an error,
+ *     or a negative SST_ERR_* code for an argument the library refuses.
+ *   - Row-major, contiguous unless a stride argument (in elements) is given.
+ *
+ * Each entry point cites the reference interface (file:line under the reference tree) it replaces.
+ */
+#ifndef SST_AMD_H
+#define SST_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SST_OK 0
+#define SST_ERR_ARG (-1)          /* invalid argument (null pointer, negative size, bad mode)        */
+#define SST_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels are built for                    */
+#define SST_ERR_KEYSPACE (-3)     /* coordinates do not pack into 63 bits                             */
+
+typedef enum { SST_REDUCE_SUM = 0, SST_REDUCE_MEAN = 1, SST_REDUCE_MAX = 2 } sst_reduce_t;
+
+/* Library self-description: returns a static string "sst_amd <version> gfx950". */
+const char* sst_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a1) dynamic voxelization.
+ * Replaces voxel_layer.dynamic_voxelize (mmdet3d/ops/voxel/src/voxelization.h:71-83 ->
+ * dynamic_voxelize_gpu, voxelization_cuda.cu:332-375, kernel :24-65).
+ *   c[d] = clamp((int)floorf((p[d] - range[d]) / voxel_size[d]), 0, grid[d]-1), fp32 subtract then
+ *   fp32 IEEE divide; grid[d] = ceil((range[d+3]-range[d]) / voxel_size[d]) in fp32 (cuda.cu:355-357);
+ *   THIS FORK clamps out-of-range points into the border voxel (cuda.cu:37-59).
+ * d_points: [n, row_stride] fp32, columns 0..2 = x,y,z.  d_coors: [n, coors_stride] int32; columns
+ * coors_col0..coors_col0+2 receive (z, y, x).  If batch_idx >= 0 and coors_col0 == 1, column 0 is
+ * filled with batch_idx (fuses DynamicVoxelNet.voxelize's F.pad, detectors/dynamic_voxelnet.py:49-71).
+ * ---------------------------------------------------------------------------------------------- */
+int sst_dynamic_voxelize_f32(const float* d_points, int64_t n, int64_t row_stride,
+                             const float voxel_size[3], const float coors_range[6],
+                             int32_t* d_coors, int64_t coors_stride, int coors_col0, int batch_idx,
+                             void* stream);
+/* Host helper: the grid the kernel clamps to (fp32 ceil, as voxelization_cuda.cu:355-357). */
+void sst_dynamic_voxelize_grid(const float voxel_size[3], const float coors_range[6], int32_t grid_xyz[3]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device primitives shared by the unique / bucketing steps (exported so they can be tested alone).
+ * ---------------------------------------------------------------------------------------------- */
+/* Exclusive prefix sum of int32.  d_out may alias d_in.  d_total (optional, device int32) receives
+ * the grand total.  Workspace: sst_scan_workspace_bytes(n). */
+int64_t sst_scan_workspace_bytes(int64_t n);
+int sst_exclusive_scan_i32(const int32_t* d_in, int32_t* d_out, int64_t n, int32_t* d_total,
+                           void* d_workspace, void* stream);
+
+/* Stable LSD radix sort of (key, index) pairs on the low `key_bits` bits of 64-bit keys.
+ * On return d_keys_out is sorted ascending and d_perm_out[i] is the original position of the i-th
+ * smallest key (ties in ascending original position).  d_keys_in is clobbered (used as ping-pong).
+ * Workspace: sst_sort_workspace_bytes(n). */
+int64_t sst_sort_workspace_bytes(int64_t n);
+int sst_sort_pairs_u64(uint64_t* d_keys_in, uint64_t* d_keys_out, uint32_t* d_perm_out, int64_t n,
+                       int key_bits, void* d_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a3/a5) sorted-unique of integer coordinate rows — the part of
+ *   dynamic_point_to_voxel_forward_gpu that calls at::unique_dim (scatter_points_cuda.cu:202-205) and of
+ *   scatter_v2 that calls torch.unique(dim=0) (ops/sst/sst_ops.py:151-165).
+ * Rows are packed into one 64-bit key  key = 1 + sum_j (c_j - mins[j]) * stride_j  (last column fastest),
+ * so ascending key order == lexicographic row order.  With invalid_if_negative != 0, any row with a
+ * negative entry gets key 0 (the reference's coors.masked_fill(any(<0), -1): all such rows collapse
+ * into ONE group that sorts first, scatter_points_cuda.cu:200).
+ * invalid_if_negative == 2 is the batched form (DynamicScatter.forward's per-sample loop,
+ * ops/voxel/scatter_points.py:85-99, done in one pass): column 0 is the batch index, the validity test
+ * looks at columns 1.., and an invalid row becomes (b,-1,-1,...) — pass mins[j>=1] = -1 so that it sorts
+ * first inside its own sample.
+ * coor_is_i64: 0 -> int32 rows, 1 -> int64 rows.   extents[j] = (max_j - mins[j] + 1) upper bound.
+ * Outputs (all device, caller allocated):
+ *   d_perm   [n]   uint32  row indices grouped by unique row, ascending row index inside a group
+ *   d_inverse[n]   int32   group id of every input row (== torch.unique's inverse)
+ *   d_offsets[n+1] int32   CSR offsets into d_perm; entries 0..M valid
+ *   d_ukeys  [n]   uint64  packed key of each group; entries 0..M-1 valid
+ *   d_num_unique   int32   M
+ * Workspace: sst_unique_workspace_bytes(n).  No host synchronisation.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_unique_workspace_bytes(int64_t n);
+int sst_unique_rows(const void* d_coors, int coor_is_i64, int64_t n, int ncols, int64_t row_stride,
+                    const int64_t* h_mins, const int64_t* h_extents, int invalid_if_negative,
+                    uint32_t* d_perm, int32_t* d_inverse, int32_t* d_offsets, uint64_t* d_ukeys,
+                    int32_t* d_num_unique, void* d_workspace, void* stream);
+/* Decode packed keys back into rows (int32 or int64 output); key 0 decodes to all -1. */
+int sst_unpack_keys(const uint64_t* d_ukeys, int64_t m, int ncols, const int64_t* h_mins,
+                    const int64_t* h_extents, void* d_rows_out, int out_is_i64, int64_t out_stride,
+                    int out_col0, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a3/a5/a15) segmented reduce over the CSR produced above: one output row per group.
+ * Replaces feats_reduce_kernel (scatter_points_cuda.cu:80-103, float-CAS atomics) and
+ * torch_scatter.scatter_max / scatter(reduce=sum|mean) (call sites ops/sst/sst_ops.py:172-177).
+ *   d_feats [n, c] fp32; group g reduces rows d_perm[d_offsets[g] .. d_offsets[g+1]).
+ *   MAX of an empty group is -inf, SUM/MEAN is 0.  MEAN = sum / (float)count (cuda.cu:228-229).
+ *   d_argmax (optional, [m, c] int32): row index of the FIRST (smallest index) row attaining the max
+ *   (the tie rule of max_reduce_traceback_scatter_idx_kernel, cuda.cu:135-160); n for empty groups.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
+                               const int32_t* d_offsets, int64_t m, int mode, float* d_out,
+                               int32_t* d_argmax, void* stream);
+/* Backward (scatter_points_cuda.cu:236-303).  d_grad_feats [n, c] is fully written (zero where no
+ * gradient flows).  SUM/MEAN: g[i] = G[inv[i]] (/count); rows with d_inverse[i] < 0 get 0.
+ * MAX: gradient goes to d_argmax[g, ch] only.  d_inverse may be shifted by the caller
+ * (inverse_shift is added before use; the DynamicScatter "first row" quirk uses -1). */
+int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const int32_t* d_inverse,
+                               int inverse_shift, const int32_t* d_offsets, const int32_t* d_argmax,
+                               int64_t n, int mode, float* d_grad_feats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a7) in-group rank.  Replaces TorchEx ingroup_indices.forward(group_inds, out_inds)
+ * (call site ops/sst/sst_ops.py:244-264).  d_rank[i] = number of j < i with group[j] == group[i]
+ * (the stable choice; the reference leaves the order unspecified).  group ids must lie in [0, 2^key_bits).
+ * Workspace: sst_ingroup_rank_workspace_bytes(n).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_ingroup_rank_workspace_bytes(int64_t n);
+int sst_ingroup_rank_i64(const int64_t* d_group, int64_t n, int key_bits, int64_t* d_rank,
+                         void* d_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a6) window coordinates, both shifts in one launch.  Replaces get_window_coors
+ * (ops/sst/sst_ops.py:266-314) called twice by SSTInputLayerV2.window_partition
+ * (middle_encoders/sst_input_layer_v2.py:229-236).
+ *   d_coors [m, 4] (b,z,y,x) int32 or int64.  sparse_shape = (sx,sy,sz), window_shape = (wx,wy,wz).
+ *   d_win[s]   [m] int32     batch_win_inds for shift s (0: no shift, 1: half-window shift)
+ *   d_ciw[s]   [m,3] int32   coors_in_win (z,y,x)
+ * ---------------------------------------------------------------------------------------------- */
+int sst_window_coors(const void* d_coors, int coor_is_i64, int64_t m, const int32_t sparse_shape[3],
+                     const int32_t window_shape[3], int32_t* d_win0, int32_t* d_ciw0,
+                     int32_t* d_win1, int32_t* d_ciw1, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a7-a9) region batching for both shifts: drop levels, voxel drop, in-window order, and the
+ * window CSR ("plan") the SRA kernels consume.  Replaces SSTInputLayerV2.drop_voxel /
+ * drop_single_shift (sst_input_layer_v2.py:128-226) and get_flat2win_inds (sst_ops.py:26-64).
+ *   levels: n_levels rows of (max_tokens, lower, upper): level l applies when lower <= count < upper.
+ *   Inputs d_win0/d_win1 [m] from sst_window_coors; win ids must be < 2^win_bits.
+ * Outputs (device, caller allocated, sizes in elements):
+ *   d_keep     [m] int32   1 if the voxel survives both shifts
+ *   d_newidx   [m] int32   index among survivors (exclusive scan of keep)
+ *   d_level[s] [m] int32   drop level of the voxel's window in shift s (-1 if no range matches)
+ *   d_inner[s] [m] int32   rank among SURVIVORS of its window (valid where keep)
+ *   d_flat2win[s] [m] int32  contiguous-window-id-within-level * max_tokens + inner (valid where keep)
+ *   d_tok[s]   [m] int32   survivor indices (NEW numbering) grouped by window, ascending window id,
+ *                           ascending inner; first M' entries valid
+ *   d_winoff[s][m+1] int32 CSR offsets into d_tok[s] per non-empty window; first W_s+1 entries valid
+ *   d_winlevel[s][m] int32 level of each non-empty window; first W_s valid
+ *   d_counts   [8] int32   {M', W_0, W_1, 0...}
+ * Semantics follow the reference exactly: shift-1 levels are computed on the survivors of shift 0,
+ * shift-0 levels are NOT recomputed after the second filter (sst_input_layer_v2.py:186-194).
+ * Workspace: sst_region_batching_workspace_bytes(m).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_region_batching_workspace_bytes(int64_t m);
+int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m, int win_bits,
+                        const int32_t* h_levels /*[n_levels,3]*/, int n_levels,
+                        int32_t* d_keep, int32_t* d_newidx,
+                        int32_t* d_level0, int32_t* d_level1, int32_t* d_inner0, int32_t* d_inner1,
+                        int32_t* d_flat2win0, int32_t* d_flat2win1,
+                        int32_t* d_tok0, int32_t* d_tok1, int32_t* d_winoff0, int32_t* d_winoff1,
+                        int32_t* d_winlevel0, int32_t* d_winlevel1, int32_t* d_counts,
+                        void* d_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a12) Sparse Regional Attention core over variable-length windows (no padding, no key mask):
+ *   for every window w (tokens tok[winoff[w] .. winoff[w+1])), every head h:
+ *       S = (Q_h * scale) K_h^T ; P = softmax_rows(S) ; O_h = P V_h
+ * Replaces the per-drop-level  flat2window -> nn.MultiheadAttention bmm/softmax/bmm -> window2flat
+ * of WindowAttention.forward (models/sst/sst_basic_block_v2.py:41-75); the in/out projections stay
+ * GEMM-library calls in the host layer, and the cosine variant (cosine_msa.py:159-170) normalises and
+ * rescales Q,K in the host layer before calling this with scale = 1.  head_dim is 16 (d_model/nhead =
+ * 128/8, 192/12 in every SST config); n_heads must be a multiple of 4.
+ * Q,K,V,O: [M, n_heads*16] fp32 with row strides ldq/ldk/ldv/ldo (elements, multiples of 4; base
+ * pointers 16-byte aligned).  d_lse [M, n_heads] fp32: log-sum-exp of each softmax row (for backward).
+ *   max_tokens: upper bound on tokens per window the caller guarantees (0 = unknown).
+ *   impl: 0 = auto (MFMA tiles for windows <= 144 tokens, generic VALU kernel above that),
+ *         1 = generic VALU kernel for every window (validation path).
+ * ---------------------------------------------------------------------------------------------- */
+int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk,
+                         int64_t ldv, const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows,
+                         int n_heads, float scale, int max_tokens, int impl, float* d_o, int64_t ldo,
+                         float* d_lse, void* stream);
+/* Backward: given dO, recomputes P from (Q,K,LSE) and writes dQ, dK, dV for every token row listed in
+ * d_tok (other rows untouched).  n_tokens = number of rows of the [M, *] tensors. */
+int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o,
+                         const float* d_do, const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv,
+                         int64_t ldo, int64_t lddo, const int32_t* d_tok, const int32_t* d_winoff,
+                         int64_t n_windows, int64_t n_tokens, int n_heads, float scale, int max_tokens,
+                         int impl, float* d_dq, float* d_dk, float* d_dv, int64_t lddq, int64_t lddk,
+                         int64_t lddv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a10/a14) row gather / scatter used by flat2window / window2flat / recover_bev.
+ *   gather:  d_out[i, :] = idx[i] >= 0 ? d_src[idx[i], :] : fill
+ *   scatter: d_out[idx[i], :] = d_src[i, :]      (idx unique; rows with idx < 0 skipped)
+ * Replaces feat_3d[this_inds] = feat / feat[inds] (ops/sst/sst_ops.py:98, 124-125).
+ * ---------------------------------------------------------------------------------------------- */
+int sst_gather_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_idx, int64_t n_out, int c,
+                        float fill, float* d_out, int64_t ld_out, void* stream);
+int sst_scatter_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_idx, int64_t n_src, int c,
+                         float* d_out, int64_t ld_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SST_AMD_H */

@@ -1,0 +1,139 @@
+"""ctypes binding of libsst_amd.so (the C ABI declared in include/sst_amd.h).
+
+PyTorch is used here only as the owner of device memory and of the HIP stream: every entry point
+receives raw device pointers (``tensor.data_ptr()``), sizes and ``torch.cuda.current_stream()``.
+There is no CPU fallback: if the library is missing, or a tensor is not on the GPU, the call raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # must be imported before the CDLL so that libamdhip64.so.7 resolves to torch's copy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_CSRC, 'libsst_amd.so')
+
+_lib = None
+
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/sst_amd.h one to one
+_SIGNATURES = {
+    'sst_version': (ctypes.c_char_p, []),
+    'sst_dynamic_voxelize_f32': (c_i32, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
+    'sst_dynamic_voxelize_grid': (None, [c_ptr, c_ptr, c_ptr]),
+    'sst_scan_workspace_bytes': (c_i64, [c_i64]),
+    'sst_exclusive_scan_i32': (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sst_sort_workspace_bytes': (c_i64, [c_i64]),
+    'sst_sort_pairs_u64': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
+    'sst_unique_workspace_bytes': (c_i64, [c_i64]),
+    'sst_unique_rows': (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_i32,
+                                c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_unpack_keys': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr]),
+    'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr]),
+    'sst_segment_reduce_bwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32,
+                                           c_ptr, c_ptr]),
+    'sst_ingroup_rank_workspace_bytes': (c_i64, [c_i64]),
+    'sst_ingroup_rank_i64': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr]),
+    'sst_window_coors': (c_i32, [c_ptr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_region_batching_workspace_bytes': (c_i64, [c_i64]),
+    'sst_region_batching': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32] + [c_ptr] * 15 + [c_ptr, c_ptr]),
+    'sst_sra_attn_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32,
+                                     c_f32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_sra_attn_bwd_f32': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_f32,
+                                                                 c_i32, c_i32, c_ptr, c_ptr, c_ptr,
+                                                                 c_i64, c_i64, c_i64, c_ptr]),
+    'sst_gather_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_i64, c_ptr]),
+    'sst_scatter_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def build(force=False, verbose=False):
+    """Compile libsst_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(['make', '-C', _CSRC, 'clean'], check=True, capture_output=not verbose)
+    r = subprocess.run(['make', '-C', _CSRC, '-j8'], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('building libsst_amd.so failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or `make -C sst_amd/csrc`). sst_amd has no CPU / eager fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def version():
+    return load().sst_version().decode()
+
+
+class SSTError(RuntimeError):
+    pass
+
+
+_ERR = {-1: 'SST_ERR_ARG (invalid argument)', -2: 'SST_ERR_UNSUPPORTED', -3: 'SST_ERR_KEYSPACE'}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERR.get(rc, f'hipError_t {rc}' if rc > 0 else f'error {rc}')
+        raise SSTError(f'{what} failed: {msg}')
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    """CHECK_INPUT of the reference (scatter_points_cuda.cu:9-15): device + contiguous, else RuntimeError."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('sst_amd: tensor must be a CUDA/HIP tensor (no CPU path in this library)')
+        if not t.is_contiguous():
+            raise RuntimeError('sst_amd: tensor must be contiguous')
+
+
+def farray(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def i32array(vals):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def i64array(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

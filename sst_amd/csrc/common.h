@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels of libsst_amd.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sst_amd.h"
+
+#define SST_WAVE 64
+
+#define SST_LAUNCH_CHECK()                          \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+#define SST_HIP(call)                               \
+  do {                                              \
+    hipError_t e__ = (call);                        \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+static inline int64_t sst_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t sst_align_up(int64_t a, int64_t b) { return sst_div_up(a, b) * b; }
+
+// Memory-bound 1-D launches: cap the grid at 256 CUs x 8 blocks and grid-stride the rest.
+static inline int sst_grid_1d(int64_t work_items, int block) {
+  int64_t g = sst_div_up(work_items, block);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ int sst_lane() { return (int)(threadIdx.x & 63); }
+
+// Inclusive scan across the 64 lanes of a wave.
+__device__ __forceinline__ int sst_wave_incl_scan(int v) {
+  const int lane = sst_lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Workspace carving on the host side (256-byte aligned slices of one caller-owned buffer).
+struct sst_carver {
+  char* base;
+  int64_t off;
+  explicit sst_carver(void* p) : base((char*)p), off(0) {}
+  template <typename T>
+  T* take(int64_t count) {
+    T* r = (T*)(base + off);
+    off += sst_align_up((int64_t)sizeof(T) * (count > 0 ? count : 1), 256);
+    return r;
+  }
+};

@@ -1,0 +1,511 @@
+// Sparse Regional Attention (SRA) core for gfx950: softmax(Q K^T * scale) V inside every window of
+// non-empty voxels, variable window length, no padding and no key mask.
+//
+// Reference semantics: WindowAttention.forward, mmdet3d/models/sst/sst_basic_block_v2.py:41-75 —
+// per drop level: flat2window (scatter to a padded [W,T,C] tensor) -> nn.MultiheadAttention
+// (q = k = x + pos, v = x; scores/4; key_padding_mask -> -inf; softmax; bmm) -> window2flat.
+// The padded tensors, the mask and the head-averaged attention map the reference materialises and
+// throws away do not exist here: the kernel walks the window CSR (tok, winoff) built by window.hip and
+// reads / writes token rows in their flat [M, C] layout.
+//
+// Mapping to the hardware (MI355X, CDNA4):
+//   * one workgroup (4 waves) = one window x one group of 4 heads (64 channels); K and V rows of the
+//     window are gathered once (coalesced 256 B per row) into LDS, row stride 68 floats so that the
+//     b32 column-fragment reads are bank-conflict free and the b128 row-fragment reads are <= 2-way;
+//   * each wave owns (head, 16-query tile) tasks; S^T = K Q^T and O^T = V^T P^T run on the exact-fp32
+//     MFMA v_mfma_f32_16x16x4_f32: the D layout of S^T (row = key, col = query) is directly the B
+//     operand layout of the second product, so P never leaves registers; the softmax is two-pass in
+//     registers over the whole row (<= 144 keys -> <= 36 VGPRs), cross-lane only for 2 xor-shuffles;
+//   * windows are bucketed by ceil(tokens/16) into 4 compile-time tile counts {2,4,7,9} that mirror the
+//     reference's region-batching levels (30/60/100/144 tokens): each variant is launched over all
+//     windows and blocks of the wrong class exit at once (no host sync to count classes).
+// Arithmetic intensity ~0.25*T flop/B puts the fp32 kernel near the HBM/fp32-MFMA ridge.
+//
+// A plain VALU kernel (one thread per (query, head), online softmax, K/V straight from L2) handles
+// windows above 144 tokens and serves as the in-library cross-check (impl = 1).
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHD = 16;     // head dim
+constexpr int kGH = 4;      // heads per workgroup
+constexpr int kGC = 64;     // channels per workgroup (kGH * kHD)
+constexpr int kRS = 68;     // LDS row stride (floats)
+constexpr int kMaxTilesMfma = 9;
+
+__device__ __forceinline__ f32x4 mfma4(const float4 a, const float4 b, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic VALU kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sra_fwd_generic_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                         const float* __restrict__ V, int64_t ldq, int64_t ldk,
+                                                         int64_t ldv, const int32_t* __restrict__ tok,
+                                                         const int32_t* __restrict__ winoff, int H, float scale,
+                                                         int min_tokens_excl, float* __restrict__ O, int64_t ldo,
+                                                         float* __restrict__ LSE) {
+  const int w = blockIdx.x;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  if (t <= min_tokens_excl) return;
+  for (int p = threadIdx.x; p < t * H; p += blockDim.x) {
+    const int qi = p / H, h = p - qi * H;
+    const int64_t row = tok[beg + qi];
+    float q[kHD], acc[kHD];
+#pragma unroll
+    for (int d = 0; d < kHD; ++d) {
+      q[d] = Q[row * ldq + h * kHD + d] * scale;
+      acc[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int kk = 0; kk < t; ++kk) {
+      const int64_t kr = tok[beg + kk];
+      const float* kp = K + kr * ldk + h * kHD;
+      const float* vp = V + kr * ldv + h * kHD;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < kHD; ++d) s = fmaf(q[d], kp[d], s);
+      const float mn = fmaxf(m, s);
+      const float a = expf(m - mn);
+      const float pe = expf(s - mn);
+      l = l * a + pe;
+#pragma unroll
+      for (int d = 0; d < kHD; ++d) acc[d] = acc[d] * a + pe * vp[d];
+      m = mn;
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < kHD; ++d) O[row * ldo + h * kHD + d] = acc[d] * inv;
+    LSE[row * H + h] = m + logf(l);
+  }
+}
+
+// dK / dV rows of the windows this kernel touches must be zero on entry (float atomics).
+__global__ __launch_bounds__(256) void sra_bwd_generic_k(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE, int64_t ldq,
+    int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* __restrict__ tok,
+    const int32_t* __restrict__ winoff, int H, float scale, int min_tokens_excl, float* __restrict__ dQ,
+    float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv) {
+  const int w = blockIdx.x;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  if (t <= min_tokens_excl) return;
+  for (int p = threadIdx.x; p < t * H; p += blockDim.x) {
+    const int qi = p / H, h = p - qi * H;
+    const int64_t row = tok[beg + qi];
+    float q[kHD], go[kHD], dq[kHD];
+    float D = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHD; ++d) {
+      q[d] = Q[row * ldq + h * kHD + d];
+      go[d] = dO[row * lddo + h * kHD + d];
+      D = fmaf(go[d], O[row * ldo + h * kHD + d], D);
+      dq[d] = 0.f;
+    }
+    const float lse = LSE[row * H + h];
+    for (int kk = 0; kk < t; ++kk) {
+      const int64_t kr = tok[beg + kk];
+      const float* kp = K + kr * ldk + h * kHD;
+      const float* vp = V + kr * ldv + h * kHD;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < kHD; ++d) {
+        s = fmaf(q[d], kp[d], s);
+        dp = fmaf(go[d], vp[d], dp);
+      }
+      const float pe = expf(s * scale - lse);
+      const float ds = pe * (dp - D) * scale;
+#pragma unroll
+      for (int d = 0; d < kHD; ++d) {
+        dq[d] = fmaf(ds, kp[d], dq[d]);
+        atomicAdd(dK + kr * lddk + h * kHD + d, ds * q[d]);
+        atomicAdd(dV + kr * lddv + h * kHD + d, pe * go[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < kHD; ++d) dQ[row * lddq + h * kHD + d] = dq[d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA forward.  Fragment vocabulary (lane = 16*g + c, g = 0..3, c = 0..15):
+//   row-frag  X[base + c][h*16 + 4g .. 4g+3]  (float4)  -> A or B operand of a product contracted over d
+//   col-frag  X[base + 4g + r][h*16 + c], r = 0..3      -> operand of a product contracted over tokens
+//   D layout  value r of lane (g,c) = D[row 4g + r][col c]
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void sra_fwd_mfma_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                      const float* __restrict__ V, int64_t ldq, int64_t ldk,
+                                                      int64_t ldv, const int32_t* __restrict__ tok,
+                                                      const int32_t* __restrict__ winoff, int n_groups, int H,
+                                                      float scale, int nt_lo, float* __restrict__ O, int64_t ldo,
+                                                      float* __restrict__ LSE) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x / n_groups;
+  const int hg = blockIdx.x - w * n_groups;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  const int nt = (t + 15) >> 4;
+  if (nt <= nt_lo || nt > NT) return;  // another variant owns this window
+
+  float* Ks = smem;
+  float* Vs = Ks + NT * 16 * kRS;
+  int* toks = (int*)(Vs + NT * 16 * kRS);
+  const int tid = threadIdx.x;
+  {
+    const int c4 = tid & 15;
+    for (int r = tid >> 4; r < nt * 16; r += 16) {
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      int row = -1;
+      if (r < t) {
+        row = tok[beg + r];
+        kv = *(const float4*)(K + (int64_t)row * ldk + hg * kGC + c4 * 4);
+        vv = *(const float4*)(V + (int64_t)row * ldv + hg * kGC + c4 * 4);
+      }
+      *(float4*)(Ks + r * kRS + c4 * 4) = kv;
+      *(float4*)(Vs + r * kRS + c4 * 4) = vv;
+      if (c4 == 0) toks[r] = row;
+    }
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  for (int task = wave; task < kGH * nt; task += 4) {
+    const int h = task & 3, i = task >> 2;
+    const int qrow = toks[i * 16 + c];
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qrow >= 0) {
+      qf = *(const float4*)(Q + (int64_t)qrow * ldq + hg * kGC + h * kHD + 4 * g);
+      qf.x *= scale;
+      qf.y *= scale;
+      qf.z *= scale;
+      qf.w *= scale;
+    }
+    // S^T tiles: st[j][r] = S[query i*16+c][key j*16+4g+r]
+    f32x4 st[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (j < nt) {
+        const float4 kf = *(const float4*)(Ks + (j * 16 + c) * kRS + h * kHD + 4 * g);
+        acc = mfma4(kf, qf, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (j * 16 + 4 * g + r) < t ? acc[r] : -INFINITY;
+          acc[r] = v;
+          mx = fmaxf(mx, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = -INFINITY;
+      }
+      st[j] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = __expf(st[j][r] - mx);
+        st[j][r] = pe;
+        sum += pe;
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // O^T[d][query] += V^T[d][key] P^T[key][query]
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = Vs[(j * 16 + 4 * g + r) * kRS + h * kHD + c];
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, st[j][r], o, 0, 0, 0);
+        }
+      }
+    }
+    if (qrow >= 0) {
+      const float inv = 1.f / sum;
+      const float4 ov = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      *(float4*)(O + (int64_t)qrow * ldo + hg * kGC + h * kHD + 4 * g) = ov;
+      if (g == 0) LSE[(int64_t)qrow * H + hg * kGH + h] = mx + __logf(sum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA backward.  Phase A: a wave owns (head, key tile) and accumulates dK, dV over query tiles.
+// Phase B: a wave owns (head, query tile) and accumulates dQ over key tiles (S is recomputed in the
+// transposed orientation so that dS lands in the A-operand layout of dS K).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void sra_bwd_mfma_k(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE, int64_t ldq,
+    int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* __restrict__ tok,
+    const int32_t* __restrict__ winoff, int n_groups, int H, float scale, int nt_lo, float* __restrict__ dQ,
+    float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x / n_groups;
+  const int hg = blockIdx.x - w * n_groups;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  const int nt = (t + 15) >> 4;
+  if (nt <= nt_lo || nt > NT) return;
+
+  constexpr int kTile = NT * 16 * kRS;
+  float* Qs = smem;
+  float* Ks = Qs + kTile;
+  float* Vs = Ks + kTile;
+  float* Gs = Vs + kTile;              // dO
+  float* Ls = Gs + kTile;              // [NT*16][4] log-sum-exp
+  float* Ds = Ls + NT * 16 * kGH;      // [NT*16][4] rowsum(dO * O)
+  int* toks = (int*)(Ds + NT * 16 * kGH);
+  const int tid = threadIdx.x;
+  {
+    const int c4 = tid & 15;
+    const int hh = c4 >> 2;  // head of this float4
+    for (int r = tid >> 4; r < nt * 16; r += 16) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 qv = z, kv = z, vv = z, gv = z, ov = z;
+      int row = -1;
+      if (r < t) {
+        row = tok[beg + r];
+        const int co = hg * kGC + c4 * 4;
+        qv = *(const float4*)(Q + (int64_t)row * ldq + co);
+        kv = *(const float4*)(K + (int64_t)row * ldk + co);
+        vv = *(const float4*)(V + (int64_t)row * ldv + co);
+        gv = *(const float4*)(dO + (int64_t)row * lddo + co);
+        ov = *(const float4*)(O + (int64_t)row * ldo + co);
+      }
+      *(float4*)(Qs + r * kRS + c4 * 4) = qv;
+      *(float4*)(Ks + r * kRS + c4 * 4) = kv;
+      *(float4*)(Vs + r * kRS + c4 * 4) = vv;
+      *(float4*)(Gs + r * kRS + c4 * 4) = gv;
+      float dpart = gv.x * ov.x + gv.y * ov.y + gv.z * ov.z + gv.w * ov.w;
+      dpart += __shfl_xor(dpart, 1, 64);
+      dpart += __shfl_xor(dpart, 2, 64);
+      if ((c4 & 3) == 0) {
+        Ds[r * kGH + hh] = dpart;
+        Ls[r * kGH + hh] = (row >= 0) ? LSE[(int64_t)row * H + hg * kGH + hh] : 0.f;
+      }
+      if (c4 == 0) toks[r] = row;
+    }
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+
+  // ---- phase A: dK, dV ----
+  for (int task = wave; task < kGH * nt; task += 4) {
+    const int h = task & 3, j = task >> 2;
+    const float4 kf = *(const float4*)(Ks + (j * 16 + c) * kRS + h * kHD + 4 * g);
+    const float4 vf = *(const float4*)(Vs + (j * 16 + c) * kRS + h * kHD + 4 * g);
+    const bool key_ok = (j * 16 + c) < t;
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < nt; ++i) {
+      const float4 qf = *(const float4*)(Qs + (i * 16 + c) * kRS + h * kHD + 4 * g);
+      const float4 gf = *(const float4*)(Gs + (i * 16 + c) * kRS + h * kHD + 4 * g);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = mfma4(qf, kf, s);    // S[query i*16+4g+r][key j*16+c]
+      dp = mfma4(gf, vf, dp);  // dP same layout
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = i * 16 + 4 * g + r;
+        const bool ok = key_ok && (qi < t);
+        const float pe = ok ? __expf(s[r] * scale - Ls[qi * kGH + h]) : 0.f;
+        const float ds = pe * (dp[r] - Ds[qi * kGH + h]) * scale;
+        const float gcol = Gs[qi * kRS + h * kHD + c];  // dO[query qi][d = c]
+        const float qcol = Qs[qi * kRS + h * kHD + c];  // Q[query qi][d = c]
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(pe, gcol, dv, 0, 0, 0);  // dV[key c][d] += P^T dO
+        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, qcol, dk, 0, 0, 0);  // dK[key c][d] += dS^T Q
+      }
+    }
+    // D layout: value r = d{K,V}[key j*16 + 4g + r][d = c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int krow = toks[j * 16 + 4 * g + r];
+      if (krow >= 0) {
+        dK[(int64_t)krow * lddk + hg * kGC + h * kHD + c] = dk[r];
+        dV[(int64_t)krow * lddv + hg * kGC + h * kHD + c] = dv[r];
+      }
+    }
+  }
+
+  // ---- phase B: dQ ----
+  for (int task = wave; task < kGH * nt; task += 4) {
+    const int h = task & 3, i = task >> 2;
+    const float4 qf = *(const float4*)(Qs + (i * 16 + c) * kRS + h * kHD + 4 * g);
+    const float4 gf = *(const float4*)(Gs + (i * 16 + c) * kRS + h * kHD + 4 * g);
+    const int qi = i * 16 + c;
+    const bool q_ok = qi < t;
+    const float lse = Ls[qi * kGH + h];
+    const float dd = Ds[qi * kGH + h];
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nt; ++j) {
+      const float4 kf = *(const float4*)(Ks + (j * 16 + c) * kRS + h * kHD + 4 * g);
+      const float4 vf = *(const float4*)(Vs + (j * 16 + c) * kRS + h * kHD + 4 * g);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = mfma4(kf, qf, s);    // S^T[key j*16+4g+r][query i*16+c]
+      dp = mfma4(vf, gf, dp);  // dP^T same layout
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = j * 16 + 4 * g + r;
+        const bool ok = q_ok && (kj < t);
+        const float pe = ok ? __expf(s[r] * scale - lse) : 0.f;
+        const float ds = pe * (dp[r] - dd) * scale;
+        const float kcol = Ks[kj * kRS + h * kHD + c];  // K[key kj][d = c]
+        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kcol, dq, 0, 0, 0);  // dQ[query c][d] += dS K
+      }
+    }
+    // D layout: value r = dQ[query i*16 + 4g + r][d = c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = toks[i * 16 + 4 * g + r];
+      if (qrow >= 0) dQ[(int64_t)qrow * lddq + hg * kGC + h * kHD + c] = dq[r];
+    }
+  }
+}
+
+template <int NT>
+int launch_fwd_variant(const float* Q, const float* K, const float* V, int64_t ldq, int64_t ldk, int64_t ldv,
+                       const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, int nt_lo,
+                       float* O, int64_t ldo, float* LSE, hipStream_t st) {
+  const int n_groups = H / kGH;
+  const size_t lds = (size_t)(2 * NT * 16 * kRS) * sizeof(float) + (size_t)NT * 16 * sizeof(int);
+  SST_HIP(hipFuncSetAttribute((const void*)sra_fwd_mfma_k<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(sra_fwd_mfma_k<NT>, dim3((unsigned)(n_windows * n_groups)), dim3(256), lds, st, Q, K, V, ldq, ldk,
+                     ldv, tok, winoff, n_groups, H, scale, nt_lo, O, ldo, LSE);
+  return SST_OK;
+}
+
+template <int NT>
+int launch_bwd_variant(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                       const float* LSE, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                       const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, int nt_lo,
+                       float* dQ, float* dK, float* dV, int64_t lddq, int64_t lddk, int64_t lddv, hipStream_t st) {
+  const int n_groups = H / kGH;
+  const size_t lds =
+      (size_t)(4 * NT * 16 * kRS + 2 * NT * 16 * kGH) * sizeof(float) + (size_t)NT * 16 * sizeof(int);
+  SST_HIP(hipFuncSetAttribute((const void*)sra_bwd_mfma_k<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(sra_bwd_mfma_k<NT>, dim3((unsigned)(n_windows * n_groups)), dim3(256), lds, st, Q, K, V, O, dO, LSE,
+                     ldq, ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, nt_lo, dQ, dK, dV, lddq, lddk, lddv);
+  return SST_OK;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk,
+                         int64_t ldv, const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int n_heads,
+                         float scale, int max_tokens, int impl, float* d_o, int64_t ldo, float* d_lse,
+                         void* stream) {
+  if (n_windows < 0 || n_heads < 1 || impl < 0 || impl > 1) return SST_ERR_ARG;
+  if (n_windows == 0) return SST_OK;
+  if (!d_q || !d_k || !d_v || !d_tok || !d_winoff || !d_o || !d_lse) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const bool mfma_ok = (n_heads % kGH == 0) && ((ldq | ldk | ldv | ldo) % 4 == 0) && aligned16(d_q) &&
+                       aligned16(d_k) && aligned16(d_v) && aligned16(d_o);
+  if (impl == 1 || !mfma_ok) {
+    hipLaunchKernelGGL(sra_fwd_generic_k, dim3((unsigned)n_windows), dim3(256), 0, st, d_q, d_k, d_v, ldq, ldk, ldv,
+                       d_tok, d_winoff, n_heads, scale, 0, d_o, ldo, d_lse);
+    SST_LAUNCH_CHECK();
+    return SST_OK;
+  }
+  int rc;
+  const int cap_tiles = max_tokens > 0 ? (max_tokens + 15) / 16 : 1 << 30;
+  rc = launch_fwd_variant<2>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 0, d_o, ldo,
+                             d_lse, st);
+  if (rc) return rc;
+  if (cap_tiles > 2) {
+    rc = launch_fwd_variant<4>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 2, d_o, ldo,
+                               d_lse, st);
+    if (rc) return rc;
+  }
+  if (cap_tiles > 4) {
+    rc = launch_fwd_variant<7>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 4, d_o, ldo,
+                               d_lse, st);
+    if (rc) return rc;
+  }
+  if (cap_tiles > 7) {
+    rc = launch_fwd_variant<9>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 7, d_o, ldo,
+                               d_lse, st);
+    if (rc) return rc;
+  }
+  if (cap_tiles > kMaxTilesMfma) {
+    hipLaunchKernelGGL(sra_fwd_generic_k, dim3((unsigned)n_windows), dim3(256), 0, st, d_q, d_k, d_v, ldq, ldk, ldv,
+                       d_tok, d_winoff, n_heads, scale, kMaxTilesMfma * 16, d_o, ldo, d_lse);
+  }
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o, const float* d_do,
+                         const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                         const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int64_t n_tokens,
+                         int n_heads, float scale, int max_tokens, int impl, float* d_dq, float* d_dk, float* d_dv,
+                         int64_t lddq, int64_t lddk, int64_t lddv, void* stream) {
+  if (n_windows < 0 || n_tokens < 0 || n_heads < 1 || impl < 0 || impl > 1) return SST_ERR_ARG;
+  if (n_windows == 0) return SST_OK;
+  if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_tok || !d_winoff || !d_dq || !d_dk || !d_dv)
+    return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const bool mfma_ok = (n_heads % kGH == 0) && ((ldq | ldk | ldv | ldo | lddo) % 4 == 0) && aligned16(d_q) &&
+                       aligned16(d_k) && aligned16(d_v) && aligned16(d_o) && aligned16(d_do);
+  const int cap_tiles = max_tokens > 0 ? (max_tokens + 15) / 16 : 1 << 30;
+  const bool all_generic = (impl == 1) || !mfma_ok;
+  const bool need_generic = all_generic || cap_tiles > kMaxTilesMfma;
+  if (need_generic) {
+    // the generic kernel accumulates dK/dV with float atomics
+    const size_t width = (size_t)n_heads * kHD * sizeof(float);
+    SST_HIP(hipMemset2DAsync(d_dk, (size_t)lddk * sizeof(float), 0, width, (size_t)n_tokens, st));
+    SST_HIP(hipMemset2DAsync(d_dv, (size_t)lddv * sizeof(float), 0, width, (size_t)n_tokens, st));
+  }
+  if (!all_generic) {
+    int rc;
+    rc = launch_bwd_variant<2>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
+                               n_heads, scale, 0, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+    if (rc) return rc;
+    if (cap_tiles > 2) {
+      rc = launch_bwd_variant<4>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
+                                 n_windows, n_heads, scale, 2, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+      if (rc) return rc;
+    }
+    if (cap_tiles > 4) {
+      rc = launch_bwd_variant<7>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
+                                 n_windows, n_heads, scale, 4, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+      if (rc) return rc;
+    }
+    if (cap_tiles > 7) {
+      rc = launch_bwd_variant<9>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
+                                 n_windows, n_heads, scale, 7, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+      if (rc) return rc;
+    }
+  }
+  if (need_generic) {
+    hipLaunchKernelGGL(sra_bwd_generic_k, dim3((unsigned)n_windows), dim3(256), 0, st, d_q, d_k, d_v, d_o, d_do,
+                       d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_heads, scale,
+                       all_generic ? 0 : kMaxTilesMfma * 16, d_dq, d_dk, d_dv, lddq, lddk, lddv);
+  }
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+}  // extern "C"

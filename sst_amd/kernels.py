@@ -1,0 +1,418 @@
+"""Tensor-level wrappers around the C ABI (include/sst_amd.h) + the autograd Functions of the path.
+
+Every function here launches HIP kernels through libsst_amd.so on the current torch stream.
+Nothing in this module computes on the CPU or through ATen eager kernels, except for allocating
+output tensors and (where the reference API itself needs a host-side size) one ``.item()`` readback.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+REDUCE = {'sum': 0, 'mean': 1, 'avg': 1, 'max': 2}
+
+
+# ----------------------------------------------------------------------------------------------
+# (a1) dynamic voxelization
+# ----------------------------------------------------------------------------------------------
+def voxel_grid(voxel_size, coors_range):
+    """grid (x, y, z) the kernel clamps to: fp32 ceil((max-min)/v), voxelization_cuda.cu:355-357."""
+    import ctypes
+    g = (ctypes.c_int32 * 3)()
+    _lib.load().sst_dynamic_voxelize_grid(_lib.farray(voxel_size), _lib.farray(coors_range), g)
+    return [int(g[0]), int(g[1]), int(g[2])]
+
+
+def dynamic_voxelize(points, voxel_size, coors_range, coors=None, batch_idx=-1):
+    """points [N, C>=3] fp32 (cuda) -> coors [N,3] int32 (z,y,x), or [N,4] (b,z,y,x) if batch_idx >= 0."""
+    if points.dtype != torch.float32:
+        raise RuntimeError('sst_amd.dynamic_voxelize: points must be float32')
+    _lib.require_cuda(points)
+    n = points.size(0)
+    ncol = 4 if batch_idx >= 0 else 3
+    if coors is None:
+        coors = torch.empty((n, ncol), dtype=torch.int32, device=points.device)
+    else:
+        _lib.require_cuda(coors)
+        if coors.dtype != torch.int32 or coors.size(0) != n or coors.size(1) != ncol:
+            raise RuntimeError('sst_amd.dynamic_voxelize: coors must be int32 [N,%d]' % ncol)
+    rc = _lib.load().sst_dynamic_voxelize_f32(
+        _lib.ptr(points), n, points.stride(0), _lib.farray(voxel_size), _lib.farray(coors_range),
+        _lib.ptr(coors), coors.stride(0) if n > 0 else ncol, ncol - 3, batch_idx, _lib.stream_ptr())
+    _lib.check(rc, 'sst_dynamic_voxelize_f32')
+    return coors
+
+
+# ----------------------------------------------------------------------------------------------
+# device primitives (exposed for tests)
+# ----------------------------------------------------------------------------------------------
+def exclusive_scan_i32(x):
+    _lib.require_cuda(x)
+    assert x.dtype == torch.int32 and x.dim() == 1
+    n = x.numel()
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    total = torch.zeros(1, dtype=torch.int32, device=x.device)
+    ws = _lib.workspace(lib.sst_scan_workspace_bytes(n), x.device)
+    rc = lib.sst_exclusive_scan_i32(_lib.ptr(x), _lib.ptr(out), n, _lib.ptr(total), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, 'sst_exclusive_scan_i32')
+    return out, total
+
+
+def sort_pairs_u64(keys, key_bits):
+    """keys: int64 tensor holding non-negative values < 2**key_bits. Returns (sorted_keys, perm int32)."""
+    _lib.require_cuda(keys)
+    assert keys.dtype == torch.int64 and keys.dim() == 1
+    n = keys.numel()
+    lib = _lib.load()
+    kin = keys.clone()
+    kout = torch.empty_like(keys)
+    perm = torch.empty(n, dtype=torch.int32, device=keys.device)
+    ws = _lib.workspace(lib.sst_sort_workspace_bytes(n), keys.device)
+    rc = lib.sst_sort_pairs_u64(_lib.ptr(kin), _lib.ptr(kout), _lib.ptr(perm), n, int(key_bits), _lib.ptr(ws),
+                                _lib.stream_ptr())
+    _lib.check(rc, 'sst_sort_pairs_u64')
+    return kout, perm
+
+
+class UniquePlan(object):
+    """Result of unique_rows: the grouping of N rows into M sorted-unique rows (all device int32)."""
+    __slots__ = ('n', 'm', 'perm', 'inverse', 'offsets', 'ukeys', 'mins', 'extents', 'ncols', 'has_invalid_group')
+
+    def counts(self):
+        return self.offsets[1:self.m + 1] - self.offsets[:self.m]
+
+
+def unique_rows(coors, mins=None, extents=None, invalid_if_negative=False):
+    """Sorted-unique of integer rows (torch.unique(dim=0, return_inverse) / at::unique_dim semantics).
+
+    coors: [N, k] int32 or int64 (cuda, contiguous).  mins/extents: per-column lower bound and extent;
+    computed from the data (one host sync, like torch.unique itself) when not given.
+    invalid_if_negative: 0 = plain lexicographic unique; 1 = rows containing a negative entry form ONE group
+    that sorts first; 2 = batched form (column 0 = batch index, see include/sst_amd.h).
+    """
+    _lib.require_cuda(coors)
+    if coors.dtype not in (torch.int32, torch.int64) or coors.dim() != 2:
+        raise RuntimeError('sst_amd.unique_rows: coors must be a 2-D int32/int64 tensor')
+    n, k = coors.shape
+    dev = coors.device
+    lib = _lib.load()
+    if n > 0 and (mins is None or extents is None):
+        lo = coors.amin(0)
+        hi = coors.amax(0)
+        lohi = torch.stack([lo, hi]).tolist()  # host sync
+        mins = [int(v) for v in lohi[0]]
+        if int(invalid_if_negative) == 1:
+            mins = [max(v, 0) for v in mins]
+        extents = [max(int(h) - int(l) + 1, 1) for l, h in zip(mins, lohi[1])]
+    elif n == 0:
+        mins = [0] * k
+        extents = [1] * k
+    plan = UniquePlan()
+    plan.n, plan.ncols = n, k
+    plan.mins, plan.extents = list(mins), list(extents)
+    plan.perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    plan.inverse = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    plan.offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    plan.ukeys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.sst_unique_workspace_bytes(n), dev)
+    rc = lib.sst_unique_rows(_lib.ptr(coors), 1 if coors.dtype == torch.int64 else 0, n, k,
+                             coors.stride(0) if n > 0 else k, _lib.i64array(mins), _lib.i64array(extents),
+                             int(invalid_if_negative), _lib.ptr(plan.perm), _lib.ptr(plan.inverse),
+                             _lib.ptr(plan.offsets), _lib.ptr(plan.ukeys), _lib.ptr(num), _lib.ptr(ws),
+                             _lib.stream_ptr())
+    _lib.check(rc, 'sst_unique_rows')
+    plan.m = int(num.item())  # the one host sync the reference API forces (output shape [M, ...])
+    plan.inverse = plan.inverse[:n]
+    plan.perm = plan.perm[:n]
+    return plan
+
+
+def unpack_unique_rows(plan, dtype, first=0, count=None, out_cols=None, col0=0, out=None):
+    """Decode the packed keys of groups [first, first+count) back into coordinate rows."""
+    lib = _lib.load()
+    m = plan.m - first if count is None else count
+    k = plan.ncols
+    dev = plan.ukeys.device
+    width = k if out_cols is None else out_cols
+    if out is None:
+        out = torch.empty((m, width), dtype=dtype, device=dev)
+    if m > 0:
+        keys = plan.ukeys[first:first + m]
+        rc = lib.sst_unpack_keys(_lib.ptr(keys), m, k, _lib.i64array(plan.mins), _lib.i64array(plan.extents),
+                                 _lib.ptr(out), 1 if dtype == torch.int64 else 0, out.stride(0), col0,
+                                 _lib.stream_ptr())
+        _lib.check(rc, 'sst_unpack_keys')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# (a3/a5/a15) segmented reduce with autograd
+# ----------------------------------------------------------------------------------------------
+def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax):
+    n, c = feats.shape
+    out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
+    argmax = torch.empty((m, c), dtype=torch.int32, device=feats.device) if want_argmax else None
+    rc = _lib.load().sst_segment_reduce_fwd_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets), m, mode,
+                                                _lib.ptr(out), _lib.ptr(argmax), _lib.stream_ptr())
+    _lib.check(rc, 'sst_segment_reduce_fwd_f32')
+    return out, argmax
+
+
+class SegmentReduce(Function):
+    """out[g] = reduce(feats[perm[offsets[g]:offsets[g+1]]]) for groups first..first+m-1 of a plan.
+
+    ``inverse_shift`` is added to plan.inverse to obtain the output row of a point (used by the
+    DynamicScatter "first row" quirk, where group 0 is discarded: shift = -1).
+    """
+
+    @staticmethod
+    def forward(ctx, feats, perm, offsets, inverse, m, mode, inverse_shift):
+        if feats.dtype != torch.float32:
+            raise RuntimeError('sst_amd: features must be float32')
+        feats = feats.contiguous()
+        _lib.require_cuda(feats, perm, offsets)
+        out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2)
+        ctx.mode, ctx.m, ctx.shift = mode, m, inverse_shift
+        ctx.shape = feats.shape
+        ctx.save_for_backward(offsets, inverse, argmax if argmax is not None else offsets)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        offsets, inverse, argmax = ctx.saved_tensors
+        n, c = ctx.shape
+        grad_out = grad_out.contiguous()
+        grad_feats = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+        rc = _lib.load().sst_segment_reduce_bwd_f32(
+            _lib.ptr(grad_out), ctx.m, c, _lib.ptr(inverse), ctx.shift, _lib.ptr(offsets),
+            _lib.ptr(argmax) if ctx.mode == 2 else None, n, ctx.mode, _lib.ptr(grad_feats), _lib.stream_ptr())
+        _lib.check(rc, 'sst_segment_reduce_bwd_f32')
+        return grad_feats, None, None, None, None, None, None
+
+
+def segment_reduce(feats, plan, mode, first=0):
+    """Reduce rows of feats over groups [first, plan.m) of a UniquePlan; mode in 'sum'|'mean'|'max'."""
+    m = plan.m - first
+    offsets = plan.offsets[first:]
+    return SegmentReduce.apply(feats, plan.perm, offsets, plan.inverse, m, REDUCE[mode], -first)
+
+
+def segment_argmax(feats, plan, first=0):
+    """(max, argmax row index) per group — torch_scatter.scatter_max's second output."""
+    feats = feats.contiguous()
+    return _segment_reduce_fwd(feats, plan.perm, plan.offsets[first:], plan.m - first, 2, True)
+
+
+# ----------------------------------------------------------------------------------------------
+# (a7) in-group rank
+# ----------------------------------------------------------------------------------------------
+def ingroup_rank(group_inds, key_bits=None):
+    _lib.require_cuda(group_inds)
+    if group_inds.dtype != torch.int64 or group_inds.dim() != 1:
+        raise RuntimeError('sst_amd.ingroup_rank: group_inds must be a 1-D int64 tensor')
+    n = group_inds.numel()
+    out = torch.empty_like(group_inds)
+    if n == 0:
+        return out
+    if key_bits is None:
+        mx = int(group_inds.max().item())
+        if int(group_inds.min().item()) < 0:
+            raise RuntimeError('sst_amd.ingroup_rank: negative group index')
+        key_bits = max(1, int(mx).bit_length())
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_ingroup_rank_workspace_bytes(n), group_inds.device)
+    rc = lib.sst_ingroup_rank_i64(_lib.ptr(group_inds), n, int(key_bits), _lib.ptr(out), _lib.ptr(ws),
+                                  _lib.stream_ptr())
+    _lib.check(rc, 'sst_ingroup_rank_i64')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# (a6, a7-a9) window coordinates and region batching
+# ----------------------------------------------------------------------------------------------
+def window_coors(coors, sparse_shape, window_shape):
+    """coors [M,4] (b,z,y,x) int32/int64 -> (win0, ciw0, win1, ciw1), all int32."""
+    _lib.require_cuda(coors)
+    if coors.dtype not in (torch.int32, torch.int64) or coors.dim() != 2 or coors.size(1) != 4:
+        raise RuntimeError('sst_amd.window_coors: coors must be [M,4] int32/int64')
+    m = coors.size(0)
+    dev = coors.device
+    win0 = torch.empty(m, dtype=torch.int32, device=dev)
+    win1 = torch.empty(m, dtype=torch.int32, device=dev)
+    ciw0 = torch.empty((m, 3), dtype=torch.int32, device=dev)
+    ciw1 = torch.empty((m, 3), dtype=torch.int32, device=dev)
+    rc = _lib.load().sst_window_coors(_lib.ptr(coors), 1 if coors.dtype == torch.int64 else 0, m,
+                                      _lib.i32array(sparse_shape), _lib.i32array(window_shape), _lib.ptr(win0),
+                                      _lib.ptr(ciw0), _lib.ptr(win1), _lib.ptr(ciw1), _lib.stream_ptr())
+    _lib.check(rc, 'sst_window_coors')
+    return win0, ciw0, win1, ciw1
+
+
+def region_batching(win0, win1, win_bits, levels):
+    """levels: list of (max_tokens, lower, upper).  Returns a dict of device int32 tensors + counts."""
+    _lib.require_cuda(win0, win1)
+    m = win0.numel()
+    dev = win0.device
+    lib = _lib.load()
+
+    def e(n):
+        return torch.empty(n, dtype=torch.int32, device=dev)
+
+    r = dict(keep=e(m), newidx=e(m), level0=e(m), level1=e(m), inner0=e(m), inner1=e(m), flat2win0=e(m),
+             flat2win1=e(m), tok0=e(m), tok1=e(m), winoff0=e(m + 1), winoff1=e(m + 1), winlevel0=e(max(m, 1)),
+             winlevel1=e(max(m, 1)))
+    counts = torch.zeros(8, dtype=torch.int32, device=dev)
+    flat = []
+    for (cap, lo, hi) in levels:
+        flat += [int(cap), int(lo), int(min(hi, 2 ** 31 - 1))]
+    ws = _lib.workspace(lib.sst_region_batching_workspace_bytes(m), dev)
+    rc = lib.sst_region_batching(
+        _lib.ptr(win0), _lib.ptr(win1), m, int(win_bits), _lib.i32array(flat), len(levels), _lib.ptr(r['keep']),
+        _lib.ptr(r['newidx']), _lib.ptr(r['level0']), _lib.ptr(r['level1']), _lib.ptr(r['inner0']),
+        _lib.ptr(r['inner1']), _lib.ptr(r['flat2win0']), _lib.ptr(r['flat2win1']), _lib.ptr(r['tok0']),
+        _lib.ptr(r['tok1']), _lib.ptr(r['winoff0']), _lib.ptr(r['winoff1']), _lib.ptr(r['winlevel0']),
+        _lib.ptr(r['winlevel1']), _lib.ptr(counts), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, 'sst_region_batching')
+    r['counts'] = counts
+    return r
+
+
+# ----------------------------------------------------------------------------------------------
+# (a12) SRA attention core with autograd
+# ----------------------------------------------------------------------------------------------
+class WindowPlan(object):
+    """Window CSR consumed by the SRA kernels: tokens of window w are tok[winoff[w]:winoff[w+1]]."""
+    __slots__ = ('tok', 'winoff', 'n_windows', 'n_tokens', 'max_tokens')
+
+    def __init__(self, tok, winoff, n_windows, n_tokens, max_tokens):
+        self.tok, self.winoff = tok, winoff
+        self.n_windows, self.n_tokens, self.max_tokens = int(n_windows), int(n_tokens), int(max_tokens)
+
+
+def _row_stride(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError('sst_amd.sra_attention: q/k/v must be 2-D with unit inner stride')
+    return t.stride(0)
+
+
+def _sra_fwd(q, k, v, plan, n_heads, scale, impl):
+    for t in (q, k, v):
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise RuntimeError('sst_amd.sra_attention: q, k, v must be float32 CUDA tensors')
+    m, c = q.shape
+    if c != n_heads * 16:
+        raise RuntimeError('sst_amd.sra_attention: head_dim must be 16')
+    if plan.n_tokens < m:
+        o = torch.zeros((m, c), dtype=torch.float32, device=q.device)
+    else:
+        o = torch.empty((m, c), dtype=torch.float32, device=q.device)
+    lse = torch.empty((m, n_heads), dtype=torch.float32, device=q.device)
+    rc = _lib.load().sst_sra_attn_fwd_f32(
+        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _row_stride(q), _row_stride(k), _row_stride(v),
+        _lib.ptr(plan.tok), _lib.ptr(plan.winoff), plan.n_windows, n_heads, float(scale), plan.max_tokens,
+        impl, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr())
+    _lib.check(rc, 'sst_sra_attn_fwd_f32')
+    return o, lse
+
+
+def _sra_bwd(q, k, v, o, lse, grad_o, plan, n_heads, scale, impl, dq, dk, dv):
+    m = q.size(0)
+    rc = _lib.load().sst_sra_attn_bwd_f32(
+        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(grad_o), _lib.ptr(lse), _row_stride(q),
+        _row_stride(k), _row_stride(v), o.stride(0), grad_o.stride(0), _lib.ptr(plan.tok),
+        _lib.ptr(plan.winoff), plan.n_windows, m, n_heads, scale, plan.max_tokens, impl,
+        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk), _row_stride(dv),
+        _lib.stream_ptr())
+    _lib.check(rc, 'sst_sra_attn_bwd_f32')
+
+
+def _grad_buf(shape, device, full):
+    return (torch.empty if full else torch.zeros)(shape, dtype=torch.float32, device=device)
+
+
+class SRAAttention(Function):
+    """q, k, v given as three tensors (each [M, C], row-strided views allowed)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, plan, n_heads, scale, impl):
+        o, lse = _sra_fwd(q, k, v, plan, n_heads, scale, impl)
+        ctx.plan, ctx.n_heads, ctx.scale, ctx.impl = plan, n_heads, float(scale), impl
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, grad_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        grad_o = grad_o.contiguous()
+        full = ctx.plan.n_tokens == q.size(0)
+        dq = _grad_buf(q.shape, q.device, full)
+        dk = _grad_buf(q.shape, q.device, full)
+        dv = _grad_buf(q.shape, q.device, full)
+        _sra_bwd(q, k, v, o, lse, grad_o, ctx.plan, ctx.n_heads, ctx.scale, ctx.impl, dq, dk, dv)
+        return dq, dk, dv, None, None, None, None
+
+
+class SRAAttentionQKV(Function):
+    """q|k packed as one [M, 2C] tensor (the q = k = x + pos projection) and v [M, C]: the gradients come
+    back as one contiguous [M, 2C] and one [M, C] tensor, so the projection backward needs no re-packing."""
+
+    @staticmethod
+    def forward(ctx, qk, v, plan, n_heads, scale, impl):
+        c = v.size(1)
+        q, k = qk[:, :c], qk[:, c:]
+        o, lse = _sra_fwd(q, k, v, plan, n_heads, scale, impl)
+        ctx.plan, ctx.n_heads, ctx.scale, ctx.impl = plan, n_heads, float(scale), impl
+        ctx.save_for_backward(qk, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, grad_o):
+        qk, v, o, lse = ctx.saved_tensors
+        c = v.size(1)
+        grad_o = grad_o.contiguous()
+        full = ctx.plan.n_tokens == v.size(0)
+        dqk = _grad_buf(qk.shape, qk.device, full)
+        dv = _grad_buf(v.shape, v.device, full)
+        _sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, grad_o, ctx.plan, ctx.n_heads, ctx.scale, ctx.impl,
+                 dqk[:, :c], dqk[:, c:], dv)
+        return dqk, dv, None, None, None, None
+
+
+def sra_attention(q, k, v, plan, n_heads, scale=None, impl=0):
+    """softmax(q k^T * scale) v inside each window of ``plan``; q,k,v: [M, n_heads*16] fp32 (row-strided ok)."""
+    if scale is None:
+        scale = 1.0 / math.sqrt(16.0)
+    return SRAAttention.apply(q, k, v, plan, n_heads, scale, impl)
+
+
+def sra_attention_qk_v(qk, v, plan, n_heads, scale=None, impl=0):
+    if scale is None:
+        scale = 1.0 / math.sqrt(16.0)
+    return SRAAttentionQKV.apply(qk, v, plan, n_heads, scale, impl)
+
+
+# ----------------------------------------------------------------------------------------------
+# (a10) row gather / scatter
+# ----------------------------------------------------------------------------------------------
+def gather_rows(src, idx, fill=0.0):
+    _lib.require_cuda(src, idx)
+    assert src.dtype == torch.float32 and idx.dtype == torch.int32 and src.dim() == 2
+    n, c = idx.numel(), src.size(1)
+    out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    rc = _lib.load().sst_gather_rows_f32(_lib.ptr(src), src.stride(0), _lib.ptr(idx), n, c, float(fill),
+                                         _lib.ptr(out), c, _lib.stream_ptr())
+    _lib.check(rc, 'sst_gather_rows_f32')
+    return out
+
+
+def scatter_rows(src, idx, out):
+    _lib.require_cuda(src, idx, out)
+    assert src.dtype == torch.float32 and idx.dtype == torch.int32 and src.dim() == 2
+    rc = _lib.load().sst_scatter_rows_f32(_lib.ptr(src), src.stride(0), _lib.ptr(idx), idx.numel(), src.size(1),
+                                          _lib.ptr(out), out.stride(0), _lib.stream_ptr())
+    _lib.check(rc, 'sst_scatter_rows_f32')
+    return out

@@ -1,0 +1,210 @@
+"""Sparse Regional Attention block: WindowAttention -> EncoderLayer -> BasicShiftBlockV2.
+
+Mirror of mmdet3d/models/sst/sst_basic_block_v2.py:14-178 (constructor kwargs, forward signatures and
+state_dict keys: ``win_attn.self_attn.{in_proj_weight,in_proj_bias,out_proj.weight,out_proj.bias[,tau]}``,
+``linear1``, ``linear2``, ``norm1``, ``norm2``) and of the cosine variant's core
+(mmdet3d/models/sst/cosine_msa.py:123-185, 449-466).
+
+The reference scatters the flat features into padded per-level [W,T,C] tensors, calls
+nn.MultiheadAttention (3 in-proj GEMMs on padded tokens, bmm / masked softmax / bmm, averaged attention
+map discarded) and gathers back.  Here the projections run on the M real tokens only and the attention
+core is one HIP launch sequence over the window CSR (sra_attn.hip); nothing is padded or masked.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+from . import kernels as K
+from .norm import build_norm_layer
+
+
+class CosineMultiheadAttention(nn.MultiheadAttention):
+    """Parameter container with the reference's extra ``tau`` (cosine_msa.py:449-466)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, batch_first=False, tau_min=0.01, cosine=True,
+                 non_shared_tau=False):
+        super().__init__(embed_dim, num_heads, dropout=dropout)
+        self.tau_min = tau_min
+        self.cosine = cosine
+        if cosine:
+            if non_shared_tau:
+                self.tau = nn.Parameter(torch.ones(1, num_heads, 1, 1))
+            else:
+                self.tau = nn.Parameter(torch.ones(1, 1, 1))
+
+
+def plan_from_reference_dicts(ind_dict, num_voxels, device):
+    """Build the window CSR from a reference-style flat2win dict {level: (flat2win, (flat_pos,)), ...}
+    (the output of get_flat2win_inds_v2), so a voxel_info produced by reference code can drive this block."""
+    info = ind_dict['batching_info']
+    wkeys, inner, toks = [], [], []
+    wbase, tmax = 0, 1
+    for dl in info:
+        if dl not in ind_dict:
+            continue
+        f2w, (flat_pos,) = ind_dict[dl][0].long(), ind_dict[dl][1]
+        if f2w.numel() == 0:
+            continue
+        t = int(info[dl]['max_tokens'])
+        tmax = max(tmax, t)
+        w = torch.div(f2w, t, rounding_mode='floor')
+        wkeys.append(w + wbase)       # windows of different levels get disjoint id ranges
+        inner.append(f2w - w * t)
+        toks.append(flat_pos.long())
+        wbase += int(w.max().item()) + 1
+    wkeys, inner, toks = torch.cat(wkeys), torch.cat(inner), torch.cat(toks)
+    order = torch.argsort(wkeys * tmax + inner)
+    _, counts = torch.unique_consecutive(wkeys[order], return_counts=True)
+    winoff = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=device)
+    winoff[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return K.WindowPlan(toks[order].to(torch.int32).contiguous(), winoff, counts.numel(), num_voxels, tmax)
+
+
+def flat_pos_from_reference_dict(pos_dict, ind_dict, num_voxels):
+    from .sst_ops import window2flat_v2
+    if pos_dict is None or any(v is None for v in pos_dict.values()):
+        return None
+    return window2flat_v2(pos_dict, ind_dict)
+
+
+class WindowAttention(nn.Module):
+
+    def __init__(self, d_model, nhead, dropout, batch_first=False, layer_id=None, layer_cfg=dict()):
+        super().__init__()
+        self.nhead = nhead
+        self.d_model = d_model
+        if d_model % nhead != 0 or d_model // nhead != 16:
+            raise NotImplementedError('the SRA kernels are built for head_dim 16 (every SST config: 128/8, 192/12)')
+        self.cosine = layer_cfg.get('cosine', False)
+        if self.cosine:
+            tau_min = layer_cfg.get('tau_min', 0.01)
+            self.self_attn = CosineMultiheadAttention(
+                d_model, nhead, dropout=dropout, batch_first=False, tau_min=tau_min, cosine=True,
+                non_shared_tau=layer_cfg.get('non_shared_tau', False))
+        elif layer_cfg.get('linear', False):
+            raise NotImplementedError
+        else:
+            self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.attn_dropout = dropout
+        self.exe_counter = 0
+        self.layer_id = layer_id
+        self.impl = 0  # 0: MFMA kernels, 1: generic VALU kernels (validation)
+
+    def forward(self, feat_2d, pos_dict, ind_dict, key_padding_dict=None):
+        '''
+        Args:
+            feat_2d: [M, C] flat voxel features.
+            pos_dict: flat positional embedding [M, C] (or the reference's per-level dict, or None).
+            ind_dict: kernels.WindowPlan (or the reference's flat2win dict).
+            key_padding_dict: unused (there is no padding); accepted for signature parity.
+        '''
+        if self.attn_dropout > 0 and self.training:
+            raise NotImplementedError('attention-weight dropout is not implemented in the SRA kernels '
+                                      '(every SST/FSD config uses dropout=0)')
+        if isinstance(ind_dict, K.WindowPlan):
+            plan, pos = ind_dict, pos_dict
+        else:
+            plan = plan_from_reference_dicts(ind_dict, feat_2d.size(0), feat_2d.device)
+            pos = flat_pos_from_reference_dict(pos_dict, ind_dict, feat_2d.size(0)) if isinstance(pos_dict, dict) \
+                else pos_dict
+        attn = self.self_attn
+        c = self.d_model
+        x = feat_2d.float()
+        w, b = attn.in_proj_weight, attn.in_proj_bias
+        xp = x + pos if pos is not None else x          # q = k = feat + pos ; v = feat
+        qk = F.linear(xp, w[:2 * c], b[:2 * c])
+        v = F.linear(x, w[2 * c:], b[2 * c:])
+        if self.cosine:
+            h = self.nhead
+            q = F.normalize(qk[:, :c].reshape(-1, h, 16), dim=2)
+            k = F.normalize(qk[:, c:].reshape(-1, h, 16), dim=2)
+            tau = attn.tau.clamp(min=attn.tau_min).reshape(1, -1, 1)  # [1,1,1] or [1,h,1]
+            q = (q / tau).reshape(-1, c)
+            o = K.sra_attention(q, k.reshape(-1, c), v, plan, h, scale=1.0, impl=self.impl)
+        else:
+            o = K.sra_attention_qk_v(qk, v, plan, self.nhead, scale=1.0 / math.sqrt(16.0), impl=self.impl)
+        return F.linear(o, attn.out_proj.weight, attn.out_proj.bias)
+
+
+class EncoderLayer(nn.Module):
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
+                 layer_id=None, mlp_dropout=0, layer_cfg=dict()):
+        super().__init__()
+        assert not batch_first
+        self.batch_first = batch_first
+        self.win_attn = WindowAttention(d_model, nhead, dropout, layer_id=layer_id, layer_cfg=layer_cfg)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(mlp_dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        use_bn = layer_cfg.get('use_bn', False)
+        if use_bn:
+            self.norm1 = build_norm_layer(dict(type='naiveSyncBN1d', momentum=layer_cfg.get('mom', 0.1)), d_model)[1]
+            self.norm2 = build_norm_layer(dict(type='naiveSyncBN1d', momentum=layer_cfg.get('mom', 0.1)), d_model)[1]
+        else:
+            self.norm1 = nn.LayerNorm(d_model)
+            self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(mlp_dropout)
+        self.dropout2 = nn.Dropout(mlp_dropout)
+        self.activation = _get_activation_fn(activation)
+        self.post_norm = layer_cfg.get('post_norm', True)
+        self.fp16_enabled = False
+
+    def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict=None):
+        if self.post_norm:
+            src2 = self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)  # [N, d_model]
+            src = src + self.dropout1(src2)
+            src = self.norm1(src)
+            src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+            src = src + self.dropout2(src2)
+            src = self.norm2(src)
+        else:
+            src2 = self.norm1(src)
+            src2 = self.win_attn(src2, pos_dict, ind_dict, key_padding_mask_dict)
+            src = src + self.dropout1(src2)
+            src2 = self.norm2(src)
+            src2 = self.linear2(self.dropout(self.activation(self.linear1(src2))))
+            src = src + self.dropout2(src2)
+        return src
+
+
+class BasicShiftBlockV2(nn.Module):
+    '''Two encoder layers: regular windows, then shifted windows.'''
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
+                 block_id=-100, layer_cfg=dict()):
+        super().__init__()
+        encoder_1 = EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first,
+                                 layer_id=block_id * 2 + 0, layer_cfg=layer_cfg)
+        encoder_2 = EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first,
+                                 layer_id=block_id * 2 + 1, layer_cfg=layer_cfg)
+        self.encoder_list = nn.ModuleList([encoder_1, encoder_2])
+
+    def forward(self, src, pos_dict_list, ind_dict_list, key_mask_dict_list=None, using_checkpoint=False):
+        num_shifts = len(pos_dict_list)
+        assert num_shifts in (1, 2)
+        output = src
+        for i in range(2):
+            this_id = i % num_shifts
+            pos_dict = pos_dict_list[this_id]
+            ind_dict = ind_dict_list[this_id]
+            key_mask_dict = key_mask_dict_list[this_id] if key_mask_dict_list is not None else None
+            layer = self.encoder_list[i]
+            if using_checkpoint and self.training:
+                output = checkpoint(layer, output, pos_dict, ind_dict, key_mask_dict, use_reentrant=False)
+            else:
+                output = layer(output, pos_dict, ind_dict, key_mask_dict)
+        return output
+
+
+def _get_activation_fn(activation):
+    if activation == "relu":
+        return F.relu
+    if activation == "gelu":
+        return F.gelu
+    if activation == "glu":
+        return F.glu
+    raise RuntimeError(F"activation should be relu/gelu, not {activation}.")

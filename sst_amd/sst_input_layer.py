@@ -1,0 +1,258 @@
+"""SSTInputLayerV2: regional grouping, voxel drop / region batching, flat<->window index precompute.
+
+Mirror of mmdet3d/models/middle_encoders/sst_input_layer_v2.py:40-330 (same constructor kwargs, same
+``forward(voxel_feats, voxel_coors, batch_size=None)``, same keys in the returned ``voxel_info`` dict).
+
+What differs underneath: the reference runs ~100 small ATen launches with a dozen host syncs (bincount,
+boolean-mask compaction x6, per-level unique/sort, padded pos/mask tensors).  Here two calls into
+libsst_amd.so (sst_window_coors + sst_region_batching) produce every index on the device in int32, one
+8-int readback gives the sizes, and the SRA kernels consume the resulting window CSR ("plan") directly.
+The per-level padded dictionaries of the reference API (flat2win_inds / pos_dict / key_mask) are still
+produced when ``reference_outputs=True`` (default) so reference-style consumers keep working; the SST
+backbone of this package only needs ``voxel_info['sra_plan_shift{i}']`` and
+``voxel_info['pos_embed_shift{i}']`` (flat [M, C]).
+
+In-window order: ascending voxel index (stable); the reference's TorchEx kernel leaves it unspecified
+(SURVEY.md §7 "hard parts").  With ``shuffle_voxels=True`` the drop is uniform, as in the reference.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import kernels as K
+from .registry import MIDDLE_ENCODERS
+from .sst_ops import flat2window_v2, window2flat_v2
+
+
+@MIDDLE_ENCODERS.register_module()
+class PseudoMiddleEncoderForSpconvFSD(nn.Module):
+    """sst_input_layer_v2.py:15-37: identity wrapper used by the spconv FSD configs."""
+
+    def __init__(self, ):
+        super().__init__()
+
+    def forward(self, voxel_feats, voxel_coors, batch_size=None):
+        return {'voxel_feats': voxel_feats, 'voxel_coors': voxel_coors}
+
+
+@MIDDLE_ENCODERS.register_module()
+class SSTInputLayerV2(nn.Module):
+
+    def __init__(self,
+                 drop_info,
+                 window_shape,
+                 sparse_shape,
+                 shuffle_voxels=True,
+                 debug=True,
+                 normalize_pos=False,
+                 pos_temperature=10000,
+                 mute=False,
+                 reference_outputs=True,
+                 ):
+        super().__init__()
+        self.fp16_enabled = False
+        self.meta_drop_info = drop_info
+        self.sparse_shape = sparse_shape
+        self.shuffle_voxels = shuffle_voxels
+        self.debug = debug
+        self.window_shape = window_shape
+        self.normalize_pos = normalize_pos
+        self.pos_temperature = pos_temperature
+        self.mute = mute
+        self.reference_outputs = reference_outputs
+
+    # ---------------------------------------------------------------------------------------
+    def set_drop_info(self):
+        if hasattr(self, 'drop_info'):
+            return
+        meta = self.meta_drop_info
+        if isinstance(meta, tuple):
+            self.drop_info = meta[0] if self.training else meta[1]
+        else:
+            self.drop_info = meta
+        if not self.mute:
+            print(f'drop_info is set to {self.drop_info}, in input_layer')
+
+    def _window_shape3(self):
+        ws = tuple(self.window_shape)
+        if len(ws) == 2:
+            return (ws[0], ws[1], self.sparse_shape[-1])
+        return ws
+
+    def _levels(self):
+        keys = list(self.drop_info.keys())
+        levels = []
+        for dl in keys:
+            lo, hi = self.drop_info[dl]['drop_range']
+            levels.append((self.drop_info[dl]['max_tokens'], lo, hi))
+        return keys, levels
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, voxel_feats, voxel_coors, batch_size=None):
+        '''
+        Args:
+            voxel_feats: shape=[N, C], N is the voxel num in the batch.
+            voxel_coors: shape=[N, 4], [b, z, y, x]
+        Returns:
+            voxel_info: dict, same keys as the reference (sst_input_layer_v2.py:99-126) plus
+                        'sra_plan_shift{i}', 'pos_embed_shift{i}'.
+        '''
+        self.set_drop_info()
+        if voxel_coors.dim() != 2 or voxel_coors.size(1) != 4:
+            raise RuntimeError('voxel_coors must be [N,4] (b,z,y,x)')
+        voxel_coors = voxel_coors.long()
+
+        shuffle_inds = None
+        if self.shuffle_voxels:
+            shuffle_inds = torch.randperm(len(voxel_feats), device=voxel_feats.device)
+            voxel_feats = voxel_feats[shuffle_inds]
+            voxel_coors = voxel_coors[shuffle_inds]
+        voxel_coors = voxel_coors.contiguous()
+
+        m = voxel_coors.size(0)
+        sx, sy, sz = self.sparse_shape
+        wx, wy, wz = self._window_shape3()
+        assert sz < sx, 'Usually holds... in case of wrong order'
+        level_keys, levels = self._levels()
+
+        with torch.no_grad():
+            win0, ciw0, win1, ciw1 = K.window_coors(voxel_coors, [sx, sy, sz], [wx, wy, wz])
+            per_sample = (math.ceil(sx / wx) + 1) * (math.ceil(sy / wy) + 1) * (math.ceil(sz / wz) + 1)
+            if batch_size is None:
+                batch_size = int(voxel_coors[:, 0].max().item()) + 1 if m > 0 else 1
+            win_bits = max(1, int(per_sample * int(batch_size)).bit_length())
+            rb = K.region_batching(win0, win1, win_bits, levels)
+            counts = rb['counts'].tolist()  # the single readback: M', W0, W1
+        m_keep, n_win = counts[0], (counts[1], counts[2])
+        max_tokens_cap = max(l[0] for l in levels)
+
+        voxel_info = {}
+        keep_all = (m_keep == m)
+        if keep_all:
+            keep_idx = torch.arange(m, device=voxel_coors.device, dtype=torch.long)
+
+            def sel(t):
+                return t
+        else:
+            keep_idx = torch.nonzero(rb['keep']).squeeze(1)
+
+            def sel(t):
+                return t.index_select(0, keep_idx)
+
+        voxel_feats = sel(voxel_feats)
+        voxel_coors = sel(voxel_coors)
+        wins = (sel(win0), sel(win1))
+        ciws = (sel(ciw0), sel(ciw1))
+        lvls = (sel(rb['level0']), sel(rb['level1']))
+        f2ws = (sel(rb['flat2win0']), sel(rb['flat2win1']))
+        key_map = torch.tensor(level_keys, device=voxel_coors.device, dtype=torch.long)
+
+        voxel_info['voxel_feats'] = voxel_feats
+        voxel_info['voxel_coors'] = voxel_coors
+        voxel_info['voxel_keep_inds'] = keep_idx
+        for i in range(2):
+            voxel_info[f'batch_win_inds_shift{i}'] = wins[i].long()
+            voxel_info[f'coors_in_win_shift{i}'] = ciws[i].long()
+            lv = lvls[i].long()
+            voxel_info[f'voxel_drop_level_shift{i}'] = key_map[lv.clamp(min=0)] if len(level_keys) else lv
+            voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(rb[f'tok{i}'], rb[f'winoff{i}'], n_win[i], m_keep,
+                                                            max_tokens_cap)
+            voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], voxel_feats.size(1),
+                                                                        voxel_feats.dtype)
+
+        if self.debug:
+            for i in range(2):
+                assert (lvls[i] >= 0).all(), 'a window population matched no drop_range'
+
+        if self.reference_outputs:
+            for i in range(2):
+                lvl_key = voxel_info[f'voxel_drop_level_shift{i}']
+                inds_dict = {}
+                for li, dl in enumerate(level_keys):
+                    mask = lvls[i] == li
+                    if not mask.any():
+                        continue
+                    inds_dict[dl] = (f2ws[i][mask].long(), torch.where(mask))
+                inds_dict['voxel_drop_level'] = lvl_key
+                inds_dict['batching_info'] = self.drop_info
+                voxel_info[f'flat2win_inds_shift{i}'] = inds_dict
+                voxel_info[f'pos_dict_shift{i}'] = flat2window_v2(voxel_info[f'pos_embed_shift{i}'], inds_dict)
+                voxel_info[f'key_mask_shift{i}'] = self.get_key_padding_mask(inds_dict)
+            if self.debug:
+                coors_3d_dict_shift0 = flat2window_v2(voxel_coors, voxel_info['flat2win_inds_shift0'])
+                coors_2d = window2flat_v2(coors_3d_dict_shift0, voxel_info['flat2win_inds_shift0'])
+                assert (coors_2d == voxel_coors).all()
+
+        if self.shuffle_voxels:
+            voxel_info['shuffle_inds'] = shuffle_inds
+        return voxel_info
+
+    # ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def pos_table(self, feat_dim, dtype, device):
+        """All distinct positional embeddings: one row per in-window coordinate, row index
+        (z * wy + y) * wx + x.  Same arithmetic as get_pos_embed (sst_input_layer_v2.py:238-305)."""
+        wx, wy, wz3 = self._window_shape3()
+        window_shape = self.window_shape
+        if len(window_shape) == 2 or window_shape[-1] == 1:
+            ndim = 2
+            win_x, win_y = window_shape[:2]
+            win_z = 0
+            nz = wz3
+        else:
+            win_x, win_y, win_z = window_shape
+            ndim = 3
+            nz = win_z
+        zz, yy, xx = torch.meshgrid(torch.arange(nz, device=device), torch.arange(wy, device=device),
+                                    torch.arange(wx, device=device), indexing='ij')
+        z = zz.reshape(-1) - win_z / 2
+        y = yy.reshape(-1) - win_y / 2
+        x = xx.reshape(-1) - win_x / 2
+        if self.normalize_pos:
+            x = x / win_x * 2 * 3.1415  # [-pi, pi]
+            y = y / win_y * 2 * 3.1415
+            z = z / win_z * 2 * 3.1415
+        pos_length = feat_dim // ndim
+        inv_freq = torch.arange(pos_length, dtype=torch.float32, device=device)
+        inv_freq = self.pos_temperature ** (2 * (inv_freq // 2) / pos_length)
+        embed_x = x[:, None] / inv_freq[None, :]
+        embed_y = y[:, None] / inv_freq[None, :]
+        embed_x = torch.stack([embed_x[:, ::2].sin(), embed_x[:, 1::2].cos()], dim=-1).flatten(1)
+        embed_y = torch.stack([embed_y[:, ::2].sin(), embed_y[:, 1::2].cos()], dim=-1).flatten(1)
+        if ndim == 3:
+            embed_z = z[:, None] / inv_freq[None, :]
+            embed_z = torch.stack([embed_z[:, ::2].sin(), embed_z[:, 1::2].cos()], dim=-1).flatten(1)
+            pos = torch.cat([embed_x, embed_y, embed_z], dim=-1).to(dtype)
+        else:
+            pos = torch.cat([embed_x, embed_y], dim=-1).to(dtype)
+        gap = feat_dim - pos.size(1)
+        assert gap >= 0
+        if gap > 0:
+            assert ndim == 3
+            pos = torch.cat([pos, torch.zeros((pos.size(0), gap), dtype=dtype, device=device)], dim=1)
+        return pos
+
+    @torch.no_grad()
+    def get_pos_embed_flat(self, coors_in_win, feat_dim, dtype):
+        """[M, feat_dim] positional embedding of every voxel (flat layout)."""
+        wx, wy, _ = self._window_shape3()
+        table = self.pos_table(feat_dim, dtype, coors_in_win.device)
+        c = coors_in_win.long()
+        idx = (c[:, 0] * wy + c[:, 1]) * wx + c[:, 2]
+        return table.index_select(0, idx)
+
+    @torch.no_grad()
+    def get_pos_embed(self, inds_dict, coors_in_win, feat_dim, dtype):
+        """Reference signature: per-level padded dict of positional embeddings."""
+        return flat2window_v2(self.get_pos_embed_flat(coors_in_win, feat_dim, dtype), inds_dict)
+
+    @torch.no_grad()
+    def get_key_padding_mask(self, ind_dict):
+        num_all_voxel = len(ind_dict['voxel_drop_level'])
+        key_padding = torch.ones((num_all_voxel, 1), device=ind_dict['voxel_drop_level'].device).bool()
+        window_key_padding_dict = flat2window_v2(key_padding, ind_dict)
+        for key, value in window_key_padding_dict.items():  # True = padded slot
+            window_key_padding_dict[key] = value.logical_not().squeeze(2)
+        return window_key_padding_dict
