@@ -1,0 +1,82 @@
+"""TEST INFRASTRUCTURE ONLY — compiles the reference's own CPU voxelization extension from the sources
+where they lie under /root/reference (nothing is copied into this repo), straight with g++ (the
+reference's setup.py / build system is not run).  Output: oracle/_ref/voxel_layer_ref.so (git-ignored;
+it travels to the GPU box with the snapshot like our own built .so).
+
+Sources (3 files, torch + pybind11 headers only):
+  mmdet3d/ops/voxel/src/voxelization.cpp       pybind module: hard_voxelize, dynamic_voxelize, ...
+  mmdet3d/ops/voxel/src/voxelization_cpu.cpp   dynamic_voxelize_cpu / hard_voxelize_cpu
+  mmdet3d/ops/voxel/src/scatter_points_cpu.cpp dynamic_point_to_voxel_cpu (legacy, unused by the bindings)
+The reference's DynamicScatter (dynamic_point_to_voxel_forward/backward) has NO CPU implementation
+(voxelization.h:106,127 "do not support cpu yet"): only dynamic_voxelize / hard_voxelize are usable from
+this build; DynamicScatter is restated in oracle/voxel_oracle.py.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.path.join(HERE, '_ref')
+OUT = os.path.join(OUT_DIR, 'voxel_layer_ref.so')
+REF_ROOT = os.environ.get('SST_REFERENCE_ROOT', '/root/reference')
+SRC_DIR = os.path.join(REF_ROOT, 'mmdet3d', 'ops', 'voxel', 'src')
+SOURCES = ['voxelization.cpp', 'voxelization_cpu.cpp', 'scatter_points_cpu.cpp']
+
+
+def reference_available():
+    return all(os.path.exists(os.path.join(SRC_DIR, s)) for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    """Returns the path of the built module, or None when the reference tree is not present."""
+    if os.path.exists(OUT) and not force:
+        return OUT
+    if not reference_available():
+        return None
+    import torch
+    from torch.utils import cpp_extension
+    os.makedirs(OUT_DIR, exist_ok=True)
+    incs = cpp_extension.include_paths() + [sysconfig.get_paths()['include']]
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(OUT_DIR, s.replace('.cpp', '.o'))
+        objs.append(o)
+        cmd = ['g++', '-O2', '-fPIC', '-std=c++17', '-w', f'-D_GLIBCXX_USE_CXX11_ABI={abi}',
+               '-DTORCH_EXTENSION_NAME=voxel_layer_ref', '-DTORCH_API_INCLUDE_EXTENSION_H']
+        cmd += [f'-I{i}' for i in incs] + ['-c', os.path.join(SRC_DIR, s), '-o', o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('oracle/_ref build failed:\n' + ' '.join(cmd) + '\n' + out[-3000:])
+    link = ['g++', '-shared', '-o', OUT] + objs + [f'-L{torch_lib}', '-ltorch', '-ltorch_cpu', '-lc10',
+                                                   '-ltorch_python', f'-Wl,-rpath,{torch_lib}']
+    r = subprocess.run(link, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('oracle/_ref link failed:\n' + r.stdout + r.stderr)
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print('built', OUT)
+    return OUT
+
+
+def load():
+    """Imports oracle/_ref/voxel_layer_ref.so (must have been built); returns the module or None."""
+    if not os.path.exists(OUT):
+        return None
+    import importlib.util
+    import torch  # noqa: F401  (libtorch must be loaded first)
+    spec = importlib.util.spec_from_file_location('voxel_layer_ref', OUT)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+if __name__ == '__main__':
+    p = build(force='--force' in sys.argv, verbose=True)
+    print(p if p else 'reference tree not present; nothing built')

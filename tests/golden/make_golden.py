@@ -1,0 +1,238 @@
+"""Generates the golden fixtures in this directory by EXECUTING THE REFERENCE (build container only):
+
+  * the reference's own C++ dynamic_voxelize (oracle/_ref/voxel_layer_ref.so, compiled from
+    /root/reference/mmdet3d/ops/voxel/src by oracle/build_ref.py);
+  * the reference's own Python for SSTInputLayerV2 / SSTv2 blocks / DynamicVFE / SIR, loaded unmodified by
+    file path under stubs (oracle/ref_loader.py: TorchEx ingroup_indices -> stable rank, torch_scatter ->
+    scatter_reduce, DynamicScatter -> oracle restatement of scatter_points_cuda.cu).
+
+Run:  python tests/golden/make_golden.py          (from the repo root; needs /root/reference)
+The fixtures are small (< 1.5 MB each) .npz files committed next to this script; the GPU box only reads them.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from oracle import build_ref, ref_loader  # noqa: E402
+
+VOXEL_SIZE = (0.32, 0.32, 6)
+PC_RANGE = [-74.88, -74.88, -2, 74.88, 74.88, 4]
+DROP_TRAIN = {
+    0: {'max_tokens': 30, 'drop_range': (0, 30)},
+    1: {'max_tokens': 60, 'drop_range': (30, 60)},
+    2: {'max_tokens': 100, 'drop_range': (60, 100000)},
+}
+DROP_TEST = {
+    0: {'max_tokens': 30, 'drop_range': (0, 30)},
+    1: {'max_tokens': 60, 'drop_range': (30, 60)},
+    2: {'max_tokens': 100, 'drop_range': (60, 100)},
+    3: {'max_tokens': 144, 'drop_range': (100, 100000)},
+}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def state_to_np(sd, prefix='w::'):
+    return {prefix + k: t2n(v) for k, v in sd.items()}
+
+
+def gen_voxelize():
+    mod = build_ref.load()
+    assert mod is not None, 'build oracle/_ref first (python oracle/build_ref.py)'
+    g = torch.Generator().manual_seed(0)
+    cases = {}
+    # SST Waymo grid, with 8 % of the points outside the range (exercises the clamp) and points ON the borders
+    pts = torch.rand(4000, 5, generator=g) * torch.tensor([170.0, 170.0, 8.0, 1, 1]) + torch.tensor(
+        [-85.0, -85.0, -3.0, 0, 0])
+    pts[:8, :3] = torch.tensor([[-74.88, -74.88, -2.0], [74.88, 74.88, 4.0], [74.8799, 0, 0], [-74.8801, 0, 0],
+                                [0, 74.56, 3.999], [0.32, 0.32, 0], [-0.32, -0.32, 0], [1e6, -1e6, 50.0]])
+    cases['sst'] = (pts, list(VOXEL_SIZE), PC_RANGE)
+    # FSD segmentor grid (3-D voxels)
+    pts2 = torch.rand(3000, 4, generator=g) * torch.tensor([160.0, 160.0, 7.0, 1]) + torch.tensor(
+        [-80.0, -80.0, -2.5, 0])
+    cases['fsd'] = (pts2, [0.25, 0.25, 0.2], [-80, -80, -2, 80, 80, 4])
+    # FSDv2 nuScenes grid
+    pts3 = torch.rand(3000, 3, generator=g) * torch.tensor([110.0, 110.0, 9.0]) + torch.tensor([-55.0, -55.0, -5.5])
+    cases['fsdv2'] = (pts3, [0.2, 0.2, 0.2], [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0])
+    out = {}
+    for name, (p, vs, rng) in cases.items():
+        coors = torch.zeros((p.size(0), 3), dtype=torch.int32)
+        mod.dynamic_voxelize(p.contiguous(), coors, vs, rng, 3)
+        out[f'{name}::points'] = t2n(p)
+        out[f'{name}::voxel_size'] = np.asarray(vs, dtype=np.float64)
+        out[f'{name}::range'] = np.asarray(rng, dtype=np.float64)
+        out[f'{name}::coors'] = t2n(coors)
+    save('voxelize.npz', **out)
+
+
+def make_voxel_coors(g, n_pts, batch, crowded=False):
+    """unique (b,z,y,x) voxel coordinates, sorted lexicographically like the voxel encoder emits them."""
+    rows = []
+    for b in range(batch):
+        if crowded:  # concentrate points so that some 12x12 windows hold > 100 voxels
+            xy = (torch.randn(n_pts, 2, generator=g) * 14 + 234).clamp(0, 467).long()
+        else:
+            xy = torch.randint(0, 468, (n_pts, 2), generator=g)
+        c = torch.cat([torch.full((n_pts, 1), b), torch.zeros(n_pts, 1, dtype=torch.long), xy[:, 1:2], xy[:, 0:1]], 1)
+        rows.append(torch.unique(c, dim=0))
+    return torch.cat(rows, 0)
+
+
+def gen_input_layer(ref):
+    cls = ref.input_layer_v2.SSTInputLayerV2
+    g = torch.Generator().manual_seed(1)
+    for tag, training, crowded, n_pts in (('eval', False, False, 2500), ('train', True, True, 2500)):
+        coors = make_voxel_coors(g, n_pts, 2, crowded)
+        feats = torch.randn(coors.size(0), 128, generator=g)
+        layer = cls(drop_info=(DROP_TRAIN, DROP_TEST), window_shape=(12, 12, 1), sparse_shape=(468, 468, 1),
+                    shuffle_voxels=False, debug=True, pos_temperature=10000, normalize_pos=False, mute=True)
+        layer.train(training)
+        info = layer(feats, coors.int(), 2)
+        out = {'in::voxel_coors': t2n(coors).astype(np.int32), 'in::training': np.asarray(int(training))}
+        for k in ('voxel_coors', 'voxel_keep_inds'):
+            out['out::' + k] = t2n(info[k])
+        for s in range(2):
+            for k in (f'batch_win_inds_shift{s}', f'coors_in_win_shift{s}', f'voxel_drop_level_shift{s}'):
+                out['out::' + k] = t2n(info[k])
+            inds = info[f'flat2win_inds_shift{s}']
+            m = info['voxel_coors'].size(0)
+            f2w = -np.ones(m, dtype=np.int64)
+            for dl in inds:
+                if isinstance(dl, str):
+                    continue
+                f2w[t2n(inds[dl][1][0])] = t2n(inds[dl][0])
+            out[f'out::flat2win_shift{s}'] = f2w
+            pos_flat = ref.sst_ops.window2flat_v2(info[f'pos_dict_shift{s}'], inds)
+            out[f'out::pos_flat_shift{s}'] = t2n(pos_flat).astype(np.float32)
+            n_pad = sum(int(v.numel()) for v in info[f'key_mask_shift{s}'].values())
+            n_true = sum(int(v.sum()) for v in info[f'key_mask_shift{s}'].values())
+            out[f'out::key_mask_stats_shift{s}'] = np.asarray([n_pad, n_true])
+        print(tag, 'voxels in/out', coors.size(0), info['voxel_coors'].size(0))
+        save(f'input_layer_{tag}.npz', **out)
+
+
+def gen_sst_block(ref):
+    """One BasicShiftBlockV2 (2 encoder layers) through the reference SSTv2, fp32, with gradients.
+    'std' is the real SST-base geometry (d=128, 8 heads, FFN 256); the variants use d=64 / 4 heads to keep
+    the fixtures small."""
+    layer = ref.input_layer_v2.SSTInputLayerV2(drop_info=(DROP_TRAIN, DROP_TEST), window_shape=(12, 12, 1),
+                                               sparse_shape=(468, 468, 1), shuffle_voxels=False, debug=True,
+                                               mute=True)
+    layer.eval()
+    variants = (('std', 128, 8, 256, dict()), ('cosine', 64, 4, 128, dict(cosine=True, tau_min=0.01)),
+                ('cosine_ns', 64, 4, 128, dict(cosine=True, tau_min=0.01, non_shared_tau=True)),
+                ('prenorm', 64, 4, 128, dict(post_norm=False)))
+    for tag, d, h, ffn, layer_cfg in variants:
+        g = torch.Generator().manual_seed(2)
+        coors = make_voxel_coors(g, 170, 2, crowded=True)
+        m = coors.size(0)
+        torch.manual_seed(3)
+        net = ref.sst_v2.SSTv2(d_model=[d], nhead=[h], num_blocks=1, dim_feedforward=[ffn], output_shape=[468, 468],
+                               num_attached_conv=0, to_bev=False, debug=True, layer_cfg=layer_cfg)
+        # biases default to zero in nn.MultiheadAttention: randomise so that the test sees them
+        with torch.no_grad():
+            for n_, p_ in net.named_parameters():
+                if p_.dim() == 1:
+                    p_.add_(torch.randn(p_.shape, generator=g) * 0.1)
+                if n_.endswith('tau'):
+                    p_.copy_(0.5 + torch.rand(p_.shape, generator=g))
+        net.train()
+        feats = torch.randn(m, d, generator=g).requires_grad_(True)
+        info = layer(feats, coors.int(), 2)
+        out_feats = net(info)[0]['voxel_feats']
+        gout = torch.randn(out_feats.shape, generator=g)
+        (out_feats * gout).sum().backward()
+        arrays = {'in::voxel_coors': t2n(coors).astype(np.int32), 'in::voxel_feats': t2n(feats),
+                  'in::grad_out': t2n(gout), 'out::voxel_feats': t2n(out_feats), 'out::grad_in': t2n(feats.grad),
+                  'cfg::d_model': np.asarray(d), 'cfg::nhead': np.asarray(h), 'cfg::ffn': np.asarray(ffn)}
+        arrays.update(state_to_np(net.state_dict()))
+        for n_, p_ in net.named_parameters():
+            if 'encoder_list.0.win_attn.self_attn.in_proj' in n_ or 'encoder_list.1.linear1.weight' in n_ \
+                    or n_.endswith('tau'):
+                arrays['grad::' + n_] = t2n(p_.grad)
+        print(tag, 'voxels', m)
+        save(f'sst_block_{tag}.npz', **arrays)
+
+
+def gen_dynamic_vfe(ref):
+    g = torch.Generator().manual_seed(4)
+    pts_list, coors_list = [], []
+    mod = build_ref.load()
+    for b in range(2):
+        p = torch.rand(700, 3, generator=g) * torch.tensor([7.0, 7.0, 6.0]) + torch.tensor([-3.0 + 40 * b, -3.0, -2.0])
+        c = torch.zeros((700, 3), dtype=torch.int32)
+        mod.dynamic_voxelize(p.contiguous(), c, list(VOXEL_SIZE), PC_RANGE, 3)
+        pts_list.append(p)
+        coors_list.append(torch.nn.functional.pad(c, (1, 0), value=b))
+    pts, coors = torch.cat(pts_list), torch.cat(coors_list)
+    torch.manual_seed(5)
+    vfe = ref.voxel_encoder.DynamicVFE(in_channels=3, feat_channels=[64, 128], with_distance=False,
+                                       voxel_size=VOXEL_SIZE, with_cluster_center=True, with_voxel_center=True,
+                                       point_cloud_range=PC_RANGE,
+                                       norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01))
+    vfe.train()
+    pts.requires_grad_(True)
+    vf, vc = vfe(pts, coors)
+    gout = torch.randn(vf.shape, generator=g)
+    (vf * gout).sum().backward()
+    arrays = {'in::points': t2n(pts), 'in::coors': t2n(coors), 'in::grad_out': t2n(gout),
+              'out::voxel_feats': t2n(vf), 'out::voxel_coors': t2n(vc), 'out::grad_points': t2n(pts.grad)}
+    arrays.update(state_to_np(vfe.state_dict()))
+    save('dynamic_vfe.npz', **arrays)
+
+
+def gen_sir(ref):
+    g = torch.Generator().manual_seed(6)
+    p = 320
+    cluster = torch.randint(0, 24, (p,), generator=g)
+    coors = torch.stack([torch.randint(0, 3, (p,), generator=g), torch.randint(0, 2, (p,), generator=g), cluster], 1)
+    centers = torch.randn(24, 3, generator=g) * 20
+    xyz = centers[cluster] + torch.randn(p, 3, generator=g)
+    points = torch.cat([xyz, torch.rand(p, 2, generator=g)], 1)
+    features = torch.randn(p, 79, generator=g)
+    torch.manual_seed(7)
+    sir = ref.sir.SIR(num_blocks=3, in_channels=[84, 133, 133], feat_channels=[[128, 128]] * 3,
+                      rel_mlp_hidden_dims=[[16, 32], [16, 32], [16, 32]], norm_cfg=dict(type='LN', eps=1e-3),
+                      mode='max', xyz_normalizer=[20, 20, 4], act='gelu', unique_once=True)
+    sir.train()
+    features.requires_grad_(True)
+    f_cluster = xyz - centers[cluster]
+    pts_feats, cluster_feats, cluster_coors = sir(points, features, coors, f_cluster)
+    g1 = torch.randn(pts_feats.shape, generator=g)
+    g2 = torch.randn(cluster_feats.shape, generator=g)
+    ((pts_feats * g1).sum() + (cluster_feats * g2).sum()).backward()
+    arrays = {'in::points': t2n(points), 'in::features': t2n(features), 'in::coors': t2n(coors),
+              'in::f_cluster': t2n(f_cluster), 'in::g_pts': t2n(g1), 'in::g_cluster': t2n(g2),
+              'out::pts_feats': t2n(pts_feats), 'out::cluster_feats': t2n(cluster_feats),
+              'out::cluster_coors': t2n(cluster_coors), 'out::grad_features': t2n(features.grad)}
+    arrays.update(state_to_np(sir.state_dict()))
+    save('sir.npz', **arrays)
+
+
+def main():
+    assert ref_loader.available(), 'the reference tree is required'
+    build_ref.build()
+    ref = ref_loader.load_reference()
+    gen_voxelize()
+    gen_input_layer(ref)
+    gen_sst_block(ref)
+    gen_dynamic_vfe(ref)
+    gen_sir(ref)
+
+
+if __name__ == '__main__':
+    main()

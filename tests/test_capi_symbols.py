@@ -1,0 +1,56 @@
+"""The C-ABI library builds, loads, and exports every symbol include/sst_amd.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'sst_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(sst_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_path():
+    names = _declared_symbols()
+    for required in ('sst_dynamic_voxelize_f32', 'sst_unique_rows', 'sst_segment_reduce_fwd_f32',
+                     'sst_segment_reduce_bwd_f32', 'sst_window_coors', 'sst_region_batching',
+                     'sst_sra_attn_fwd_f32', 'sst_sra_attn_bwd_f32', 'sst_ingroup_rank_i64'):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol():
+    from sst_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared_symbols() if not hasattr(lib, n)]
+    assert not missing, f'declared in include/sst_amd.h but not exported: {missing}'
+
+
+def test_python_binding_covers_every_declared_symbol():
+    from sst_amd import _lib
+    assert sorted(_lib.EXPORTED_SYMBOLS) == _declared_symbols()
+    lib = _lib.load()
+    assert _lib.version().startswith('sst_amd')
+    assert lib.sst_scan_workspace_bytes(1000) > 0
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    import pytest
+    import torch
+    import sst_amd
+    pts = torch.zeros(10, 3)
+    with pytest.raises(RuntimeError):
+        sst_amd.voxelization(pts, [0.32, 0.32, 6], [-74.88, -74.88, -2, 74.88, 74.88, 4], -1, -1)
+    with pytest.raises(RuntimeError):
+        sst_amd.dynamic_point_to_voxel_forward(torch.zeros(4, 3), torch.zeros(4, 3, dtype=torch.int32), 'max')
+    with pytest.raises(RuntimeError):
+        sst_amd.get_inner_win_inds(torch.zeros(4, dtype=torch.long))
+
+
+def test_grid_helper_matches_reference_ceil():
+    from sst_amd import kernels as K
+    assert K.voxel_grid([0.32, 0.32, 6], [-74.88, -74.88, -2, 74.88, 74.88, 4]) == [468, 468, 1]
+    assert K.voxel_grid([0.25, 0.25, 0.2], [-80, -80, -2, 80, 80, 4]) == [640, 640, 30]

@@ -1,0 +1,86 @@
+"""GPU: scatter_v2 / SIRLayer / SIR (FSD point-group MLP + scatter-max) vs the oracle and golden tensors
+from the reference's own Python."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('mode', ['max', 'mean', 'sum', 'avg'])
+def test_scatter_v2_matches_oracle(mode):
+    import sst_amd
+    from oracle import sst_oracle
+    g = torch.Generator().manual_seed(3)
+    n = 30000
+    coors = torch.stack([torch.randint(0, 3, (n,), generator=g), torch.randint(0, 2, (n,), generator=g),
+                         torch.randint(0, 600, (n,), generator=g)], 1)
+    feat = torch.randn(n, 67, generator=g)
+    fg = feat.to(DEV).requires_grad_(True)
+    new_feat, new_coors, inv = sst_amd.scatter_v2(fg, coors.to(DEV), mode)
+    uniq, rinv, cnt = sst_oracle.unique_rows(coors.numpy())
+    np.testing.assert_array_equal(new_coors.cpu().numpy(), uniq)
+    np.testing.assert_array_equal(inv.cpu().numpy(), rinv)
+    assert inv.dtype == torch.int64 and new_coors.dtype == torch.int64
+    ref = sst_oracle.segment_reduce(feat.numpy(), rinv, len(uniq), mode)
+    np.testing.assert_allclose(new_feat.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    # reuse of the grouping (unique_once) gives the same result, and gradients match autograd on the oracle form
+    again, _, _ = sst_amd.scatter_v2(fg, coors.to(DEV), mode, unq_inv=inv, new_coors=new_coors)
+    assert torch.equal(again, new_feat)
+    gout = torch.randn(new_feat.shape, generator=g)
+    (new_feat * gout.to(DEV)).sum().backward()
+    f2 = feat.clone().double().requires_grad_(True)
+    idx = torch.from_numpy(rinv).view(-1, 1).expand(-1, 67)
+    red = {'max': 'amax', 'mean': 'mean', 'avg': 'mean', 'sum': 'sum'}[mode]
+    base = torch.zeros(len(uniq), 67, dtype=torch.float64)
+    out2 = base.scatter_reduce(0, idx, f2, reduce=red, include_self=False)
+    (out2 * gout.double()).sum().backward()
+    if mode == 'max':   # random floats: no ties, so amax's tie rule is irrelevant
+        np.testing.assert_allclose(fg.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-6)
+    else:
+        np.testing.assert_allclose(fg.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_scatter_v2_min_points_and_foreign_inverse():
+    import sst_amd
+    g = torch.Generator().manual_seed(4)
+    n = 5000
+    coors = torch.randint(0, 40, (n, 3), generator=g)
+    feat = torch.randn(n, 8, generator=g)
+    nf, nc, inv = sst_amd.scatter_v2(feat.to(DEV), coors.to(DEV), 'avg', min_points=3)
+    uniq, rinv, cnt = torch.unique(coors, dim=0, return_inverse=True, return_counts=True)
+    valid = cnt[rinv] >= 3
+    u2, i2 = torch.unique(coors[valid], dim=0, return_inverse=True)
+    assert torch.equal(nc.cpu(), u2) and torch.equal(inv.cpu(), i2)
+    # an inverse that did not come from this library (plain torch.unique) still works
+    u3, i3 = torch.unique(coors, dim=0, return_inverse=True)
+    nf3, _, _ = sst_amd.scatter_v2(feat.to(DEV), coors.to(DEV), 'max', unq_inv=i3.to(DEV), new_coors=u3.to(DEV))
+    ref = torch.full((u3.size(0), 8), float('-inf')).scatter_reduce(0, i3.view(-1, 1).expand(-1, 8), feat, 'amax')
+    assert torch.equal(nf3.cpu(), ref)
+
+
+def test_sir_matches_reference_golden():
+    import sst_amd
+    g = load_golden('sir.npz')
+    hidden = [[16, 32]] * 3   # one shared list on purpose: the layer must not mutate its argument
+    sir = sst_amd.build_backbone(dict(type='SIR', num_blocks=3, in_channels=[84, 133, 133],
+                                      feat_channels=[[128, 128]] * 3, rel_mlp_hidden_dims=hidden,
+                                      norm_cfg=dict(type='LN', eps=1e-3), mode='max', xyz_normalizer=[20, 20, 4],
+                                      act='gelu', unique_once=True))
+    assert hidden == [[16, 32]] * 3
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}
+    sir.load_state_dict(sd, strict=True)
+    sir.to(DEV).train()
+    feats = torch.from_numpy(g['in::features']).to(DEV).requires_grad_(True)
+    pts_feats, cluster_feats, cluster_coors = sir(torch.from_numpy(g['in::points']).to(DEV), feats,
+                                                  torch.from_numpy(g['in::coors']).to(DEV),
+                                                  torch.from_numpy(g['in::f_cluster']).to(DEV))
+    np.testing.assert_array_equal(cluster_coors.cpu().numpy(), g['out::cluster_coors'])
+    np.testing.assert_allclose(pts_feats.detach().cpu().numpy(), g['out::pts_feats'], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(cluster_feats.detach().cpu().numpy(), g['out::cluster_feats'], rtol=1e-3, atol=1e-3)
+    ((pts_feats * torch.from_numpy(g['in::g_pts']).to(DEV)).sum()
+     + (cluster_feats * torch.from_numpy(g['in::g_cluster']).to(DEV)).sum()).backward()
+    np.testing.assert_allclose(feats.grad.cpu().numpy(), g['out::grad_features'], rtol=2e-3, atol=2e-3)

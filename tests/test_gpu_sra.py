@@ -1,0 +1,172 @@
+"""GPU: Sparse Regional Attention core (MFMA and generic kernels), forward and backward, against the float64
+oracle; encoder layers / SSTv2 block against golden tensors from the reference's own Python.
+Tolerance: 1e-3 absolute on fp32 features (BASELINE.json north_star), in practice ~1e-5."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DROP_TEST, DROP_TRAIN, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = 1e-3
+
+
+def _plan_from_sizes(sizes, seed):
+    from sst_amd import kernels as K
+    rng = np.random.default_rng(seed)
+    m = int(sum(sizes))
+    tok = rng.permutation(m).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    plan = K.WindowPlan(torch.from_numpy(tok).to(DEV), torch.from_numpy(off).to(DEV), len(sizes), m, max(sizes))
+    return plan, tok, off, m
+
+
+SIZE_SETS = {
+    'tiny': [1, 2, 3, 15, 16, 17],
+    'levels': [30, 31, 32, 33, 47, 48, 49, 60, 63, 64, 65],
+    'big': [96, 100, 111, 112, 113, 128, 143, 144],
+    'mixed': [1, 144, 7, 100, 64, 30, 16, 59, 81, 12, 5, 133],
+    'over_cap': [150, 20, 200, 144, 145],
+}
+
+
+@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('heads', [8, 12])
+@pytest.mark.parametrize('name', list(SIZE_SETS))
+def test_sra_core_forward_backward_vs_oracle(name, heads, impl):
+    from sst_amd import kernels as K
+    from oracle import sst_oracle
+    sizes = SIZE_SETS[name]
+    plan, tok, off, m = _plan_from_sizes(sizes, len(sizes) + heads)
+    c = heads * 16
+    g = torch.Generator().manual_seed(m + heads)
+    q = torch.randn(m, c, generator=g) * 1.5
+    k = torch.randn(m, c, generator=g) * 1.5
+    v = torch.randn(m, c, generator=g)
+    do = torch.randn(m, c, generator=g)
+    qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    o = K.sra_attention(qg, kg, vg, plan, heads, impl=impl)
+    ref = sst_oracle.sra_core(q.numpy(), k.numpy(), v.numpy(), tok, off, heads)
+    err = np.abs(o.detach().cpu().numpy() - ref).max()
+    assert err < TOL, f'forward max abs err {err}'
+    (o * do.to(DEV)).sum().backward()
+    rdq, rdk, rdv = sst_oracle.sra_core_backward(q.numpy(), k.numpy(), v.numpy(), do.numpy(), tok, off, heads)
+    for name_, got, want in (('dq', qg.grad, rdq), ('dk', kg.grad, rdk), ('dv', vg.grad, rdv)):
+        e = np.abs(got.cpu().numpy() - want).max()
+        assert e < TOL, f'{name_} max abs err {e}'
+
+
+def test_sra_core_packed_qk_and_strided_inputs():
+    from sst_amd import kernels as K
+    from oracle import sst_oracle
+    plan, tok, off, m = _plan_from_sizes([33, 70, 5, 120], 9)
+    g = torch.Generator().manual_seed(1)
+    qk = torch.randn(m, 256, generator=g)
+    v = torch.randn(m, 128, generator=g)
+    do = torch.randn(m, 128, generator=g)
+    qkg, vg = qk.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+    o = K.sra_attention_qk_v(qkg, vg, plan, 8)
+    ref = sst_oracle.sra_core(qk[:, :128].numpy(), qk[:, 128:].numpy(), v.numpy(), tok, off, 8)
+    assert np.abs(o.detach().cpu().numpy() - ref).max() < TOL
+    (o * do.to(DEV)).sum().backward()
+    rdq, rdk, rdv = sst_oracle.sra_core_backward(qk[:, :128].numpy(), qk[:, 128:].numpy(), v.numpy(), do.numpy(), tok,
+                                                 off, 8)
+    assert np.abs(qkg.grad[:, :128].cpu().numpy() - rdq).max() < TOL
+    assert np.abs(qkg.grad[:, 128:].cpu().numpy() - rdk).max() < TOL
+    assert np.abs(vg.grad.cpu().numpy() - rdv).max() < TOL
+
+
+def test_sra_core_properties_full_size():
+    """M ~ 90k tokens: rows of softmax sum to one (V = 1 -> O = 1), linearity in V, MFMA == generic."""
+    from sst_amd import kernels as K
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(20, 101, size=1500).tolist()
+    plan, tok, off, m = _plan_from_sizes(sizes, 4)
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(m, 128, generator=g).to(DEV)
+    k = torch.randn(m, 128, generator=g).to(DEV)
+    v1 = torch.randn(m, 128, generator=g).to(DEV)
+    v2 = torch.randn(m, 128, generator=g).to(DEV)
+    ones = K.sra_attention(q, k, torch.ones_like(v1), plan, 8)
+    assert float((ones - 1).abs().max()) < 1e-5
+    o1 = K.sra_attention(q, k, v1, plan, 8)
+    o2 = K.sra_attention(q, k, v2, plan, 8)
+    o12 = K.sra_attention(q, k, v1 + 2 * v2, plan, 8)
+    assert float((o12 - (o1 + 2 * o2)).abs().max()) < 1e-4
+    og = K.sra_attention(q, k, v1, plan, 8, impl=1)
+    assert float((og - o1).abs().max()) < 1e-4
+
+
+def _load_block(g, layer_cfg):
+    import sst_amd
+    d, h, ffn = int(g['cfg::d_model']), int(g['cfg::nhead']), int(g['cfg::ffn'])
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[d], nhead=[h], num_blocks=1, dim_feedforward=[ffn],
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=True,
+                                      layer_cfg=layer_cfg))
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}
+    net.load_state_dict(sd, strict=True)   # same state_dict keys as the reference
+    return net.to(DEV).train(), d
+
+
+@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('tag,layer_cfg', [('std', dict()), ('cosine', dict(cosine=True, tau_min=0.01)),
+                                           ('cosine_ns', dict(cosine=True, tau_min=0.01, non_shared_tau=True)),
+                                           ('prenorm', dict(post_norm=False))])
+def test_sst_block_matches_reference_golden(tag, layer_cfg, impl):
+    import sst_amd
+    g = load_golden(f'sst_block_{tag}.npz')
+    net, d = _load_block(g, layer_cfg)
+    net.set_impl(impl)
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
+                                    debug=True, mute=True)
+    layer.eval()
+    feats = torch.from_numpy(g['in::voxel_feats']).to(DEV).requires_grad_(True)
+    coors = torch.from_numpy(g['in::voxel_coors']).to(DEV)
+    info = layer(feats, coors, 2)
+    out = net(info)[0]['voxel_feats']
+    err = np.abs(out.detach().cpu().numpy() - g['out::voxel_feats']).max()
+    assert err < TOL, f'block output max abs err {err}'
+    (out * torch.from_numpy(g['in::grad_out']).to(DEV)).sum().backward()
+    e = np.abs(feats.grad.cpu().numpy() - g['out::grad_in']).max()
+    assert e < TOL * 5, f'input gradient max abs err {e}'
+    params = dict(net.named_parameters())
+    for key in [k for k in g if k.startswith('grad::')]:
+        got = params[key[6:]].grad.cpu().numpy()
+        scale = max(1.0, float(np.abs(g[key]).max()))
+        assert np.abs(got - g[key]).max() < TOL * 5 * scale, key
+
+
+def test_sst_block_accepts_reference_style_dicts():
+    """A voxel_info that only carries the reference's per-level dictionaries drives the same kernels."""
+    import sst_amd
+    g = load_golden('sst_block_std.npz')
+    net, d = _load_block(g, dict())
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
+                                    debug=True, mute=True)
+    layer.eval()
+    info = layer(torch.from_numpy(g['in::voxel_feats']).to(DEV), torch.from_numpy(g['in::voxel_coors']).to(DEV), 2)
+    ref_style = {k: v for k, v in info.items() if not k.startswith('sra_plan') and not k.startswith('pos_embed')}
+    with torch.no_grad():
+        out = net(ref_style)[0]['voxel_feats']
+    assert np.abs(out.cpu().numpy() - g['out::voxel_feats']).max() < TOL
+
+
+def test_recover_bev_matches_loop_semantics():
+    import sst_amd
+    net = sst_amd.SSTv2(d_model=[128], nhead=[8], num_blocks=1, dim_feedforward=[256], output_shape=[468, 468],
+                        num_attached_conv=0, to_bev=True).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    coors = torch.unique(torch.stack([torch.randint(0, 2, (3000,), generator=g), torch.zeros(3000, dtype=torch.long),
+                                      torch.randint(0, 468, (3000,), generator=g),
+                                      torch.randint(0, 468, (3000,), generator=g)], 1), dim=0).to(DEV)
+    feat = torch.randn(coors.size(0), 128, device=DEV)
+    bev = net.recover_bev(feat, coors, 2)
+    assert bev.shape == (2, 128, 468, 468)
+    ref = torch.zeros(2, 128, 468 * 468, device=DEV)
+    for b in range(2):
+        msk = coors[:, 0] == b
+        ref[b][:, coors[msk, 2] * 468 + coors[msk, 3]] = feat[msk].t()
+    assert torch.equal(bev, ref.view(2, 128, 468, 468))

