@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py — LiDAR frames/s of the SST backbone hot path (fwd+bwd) at Waymo 0.32 m voxels on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic frames resident in HBM:
+    dynamic voxelize -> DynamicVFE (3 segmented scatters) -> SSTInputLayerV2 (window bucketing / region
+    batching) -> 6 SRA blocks (12 encoder layers), forward + backward; with --gpus N > 1 the gradients are
+    all-reduced over RCCL (one flat bucket) inside the step.
+Workload at N=1 (BASELINE.json configs[1]): uniform synthetic cloud, 116 000 points/frame ->
+~90 k non-empty voxels, 1 frame per GPU; frames shard data-parallel across ranks (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel group = the SRA attention core forward (sra_fwd_mfma_k<NT> launch group):
+                achieved = 2056 B/token x tokens / mean HIP-event duration of the group over the timed region,
+                vs the 8 TB/s HBM peak.
+  cpu_baseline  the CPU port of the reference path (oracle/cpu_pipeline.py) timed on the host cores for one
+                frame of the same workload, fwd+bwd (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+VOXEL_SIZE = (0.32, 0.32, 6)
+PC_RANGE = [-74.88, -74.88, -2, 74.88, 74.88, 4]
+DROP_TRAIN = {0: {'max_tokens': 30, 'drop_range': (0, 30)}, 1: {'max_tokens': 60, 'drop_range': (30, 60)},
+              2: {'max_tokens': 100, 'drop_range': (60, 100000)}}
+DROP_TEST = {0: {'max_tokens': 30, 'drop_range': (0, 30)}, 1: {'max_tokens': 60, 'drop_range': (30, 60)},
+             2: {'max_tokens': 100, 'drop_range': (60, 100)}, 3: {'max_tokens': 144, 'drop_range': (100, 100000)}}
+HBM_PEAK_GBS = 8000.0
+SRA_BYTES_PER_TOKEN = 4 * 128 * 4 + 8   # Q,K,V read + O write (fp32, d=128) + index: SURVEY.md §8d(5)
+
+
+def make_cloud(n, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(n, 3, generator=g) * torch.tensor([149.76, 149.76, 6.0]) + torch.tensor([-74.88, -74.88, -2.0])
+    return xyz.to(device)
+
+
+class Pipeline(torch.nn.Module):
+    """The SST-base hot path behind the reference's registry names (configs/sst_refactor/
+    sst_waymoD5_1x_3class_8heads_v2.py:26-79), without the dense BEV neck/head."""
+
+    def __init__(self, num_blocks=6):
+        super().__init__()
+        import sst_amd
+        self.voxel_layer = sst_amd.Voxelization(VOXEL_SIZE, PC_RANGE, -1, (-1, -1))
+        self.voxel_encoder = sst_amd.build_voxel_encoder(dict(
+            type='DynamicVFE', in_channels=3, feat_channels=[64, 128], with_distance=False, voxel_size=VOXEL_SIZE,
+            with_cluster_center=True, with_voxel_center=True, point_cloud_range=PC_RANGE,
+            norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01)))
+        self.middle_encoder = sst_amd.build_middle_encoder(dict(
+            type='SSTInputLayerV2', window_shape=(12, 12, 1), sparse_shape=(468, 468, 1), shuffle_voxels=True,
+            debug=False, drop_info=(DROP_TRAIN, DROP_TEST), pos_temperature=10000, normalize_pos=False, mute=True,
+            reference_outputs=False))
+        self.backbone = sst_amd.build_backbone(dict(
+            type='SSTv2', d_model=[128] * num_blocks, nhead=[8] * num_blocks, num_blocks=num_blocks,
+            dim_feedforward=[256] * num_blocks, output_shape=[468, 468], num_attached_conv=0, to_bev=False,
+            debug=False))
+
+    def forward(self, points_list):
+        points, coors = self.voxel_layer.voxelize_batch(points_list)
+        voxel_feats, voxel_coors = self.voxel_encoder(points, coors)
+        info = self.middle_encoder(voxel_feats, voxel_coors, len(points_list))
+        return self.backbone(info)[0]['voxel_feats']
+
+
+def flatten_grads(model):
+    """One flat fp32 gradient bucket (views as .grad) so the data-parallel exchange is a single all-reduce."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    total = sum(p.numel() for p in params)
+    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    return flat
+
+
+def cpu_baseline(points_per_frame, num_blocks):
+    from oracle.cpu_pipeline import CpuSSTBackbone
+    torch.manual_seed(0)
+    net = CpuSSTBackbone(VOXEL_SIZE, PC_RANGE, DROP_TRAIN, num_blocks=num_blocks)
+    pts = make_cloud(points_per_frame, 0, 'cpu')
+    t0 = time.perf_counter()
+    out = net([pts])
+    out.sum().backward()
+    dt = time.perf_counter() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 frame ({points_per_frame} points -> {out.size(0)} voxels), {num_blocks} SRA blocks, '
+                      f'fwd+bwd once, {dt:.1f} s; CPU port of the reference path (padded windows + '
+                      'nn.MultiheadAttention, oracle/cpu_pipeline.py)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--frames-per-gpu', type=int, default=1)
+    ap.add_argument('--points', type=int, default=116000)
+    ap.add_argument('--blocks', type=int, default=6)
+    ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from sst_amd import kernels as K
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    model = Pipeline(args.blocks).to(dev)
+    model.train()
+    model.backbone.set_impl(args.impl)
+    flat_grad = flatten_grads(model)
+    frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
+    torch.manual_seed(1234 + rank)            # per-rank voxel shuffles
+
+    def step():
+        if args.fwd_only:
+            with torch.no_grad():
+                return model(frames)
+        flat_grad.zero_()
+        out = model(frames)
+        out.sum().backward()
+        if world > 1:
+            dist.all_reduce(flat_grad)
+            flat_grad.div_(world)
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    n_voxels = int(out.size(0))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sink = []
+    K.EVENT_SINK = sink
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    K.EVENT_SINK = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline of the dominant kernel group (SRA attention core, forward)
+    def group_stats(kind):
+        ev = [(e0.elapsed_time(e1), n) for k_, e0, e1, n in sink if k_ == kind]
+        if not ev:
+            return None
+        ms = sum(t for t, _ in ev) / len(ev)
+        tokens = sum(n for _, n in ev) / len(ev)
+        return ms, tokens, len(ev)
+
+    fwd = group_stats('sra_fwd')
+    bwd = group_stats('sra_bwd')
+    roofline = None
+    if fwd is not None:
+        ms, tokens, launches = fwd
+        achieved = SRA_BYTES_PER_TOKEN * tokens / (ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'sra_fwd_mfma_k<NT> launch group (sst_sra_attn_fwd_f32)',
+                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'algorithmic_bytes_per_launch': int(SRA_BYTES_PER_TOKEN * tokens),
+                    'avg_launch_ms': round(ms, 4), 'launches': launches}
+        if bwd is not None:
+            roofline['sra_bwd_avg_launch_ms'] = round(bwd[0], 4)
+
+    if rank == 0:
+        total_frames = world * args.frames_per_gpu * args.steps
+        res = {
+            'metric': 'LiDAR frames/sec (SST backbone fwd+bwd) at Waymo 0.32m voxels' if not args.fwd_only
+            else 'LiDAR frames/sec (SST backbone fwd-only) at Waymo 0.32m voxels',
+            'value': round(total_frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SST-base Waymo single-frame, 0.32 m voxel: uniform synthetic cloud '
+                                   f'{args.points} points/frame -> {n_voxels // args.frames_per_gpu} non-empty '
+                                   'voxels/frame; dynamic voxelize + DynamicVFE + SSTInputLayerV2 + '
+                                   f'{args.blocks} SRA blocks, ' + ('fwd only' if args.fwd_only else 'fwd+bwd'),
+                       'frames_per_gpu': args.frames_per_gpu, 'points_per_frame': args.points,
+                       'voxels_per_gpu': n_voxels, 'parallelism': f'dp{world}',
+                       'grad_sync': 'one flat RCCL all-reduce' if world > 1 else 'none'},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.points, args.blocks)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

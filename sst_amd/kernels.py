@@ -299,6 +299,23 @@ def _row_stride(t):
     return t.stride(0)
 
 
+# bench.py hooks: when a list is installed here every SRA launch group is bracketed by a pair of HIP events
+# recorded on the launch stream (torch's current stream) and (kind, start, end, n_tokens) is appended.
+EVENT_SINK = None
+
+
+def _bracket(kind, n_tokens, fn):
+    if EVENT_SINK is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    EVENT_SINK.append((kind, e0, e1, n_tokens))
+    return r
+
+
 def _sra_fwd(q, k, v, plan, n_heads, scale, impl):
     for t in (q, k, v):
         if t.dtype != torch.float32 or not t.is_cuda:
@@ -311,22 +328,22 @@ def _sra_fwd(q, k, v, plan, n_heads, scale, impl):
     else:
         o = torch.empty((m, c), dtype=torch.float32, device=q.device)
     lse = torch.empty((m, n_heads), dtype=torch.float32, device=q.device)
-    rc = _lib.load().sst_sra_attn_fwd_f32(
+    rc = _bracket('sra_fwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_fwd_f32(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _row_stride(q), _row_stride(k), _row_stride(v),
         _lib.ptr(plan.tok), _lib.ptr(plan.winoff), plan.n_windows, n_heads, float(scale), plan.max_tokens,
-        impl, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr())
+        impl, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr()))
     _lib.check(rc, 'sst_sra_attn_fwd_f32')
     return o, lse
 
 
 def _sra_bwd(q, k, v, o, lse, grad_o, plan, n_heads, scale, impl, dq, dk, dv):
     m = q.size(0)
-    rc = _lib.load().sst_sra_attn_bwd_f32(
+    rc = _bracket('sra_bwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_bwd_f32(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(grad_o), _lib.ptr(lse), _row_stride(q),
         _row_stride(k), _row_stride(v), o.stride(0), grad_o.stride(0), _lib.ptr(plan.tok),
         _lib.ptr(plan.winoff), plan.n_windows, m, n_heads, scale, plan.max_tokens, impl,
         _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk), _row_stride(dv),
-        _lib.stream_ptr())
+        _lib.stream_ptr()))
     _lib.check(rc, 'sst_sra_attn_bwd_f32')
 
 
