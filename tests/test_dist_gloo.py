@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size 2 over gloo.  Covers the only collectives of the path:
+naiveSyncBN's all_gather(forward)/all_reduce(backward) and the flat-bucket gradient all-reduce of bench.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sst_amd.norm import NaiveSyncBatchNorm1d
+        import bench
+        torch.manual_seed(0)
+        full = torch.randn(64, 8)
+        sizes = [40, 24]                      # ranks hold different numbers of points, as in LiDAR frames
+        start = sum(sizes[:rank])
+        x = full[start:start + sizes[rank]].clone().requires_grad_(True)
+        bn = NaiveSyncBatchNorm1d(8, eps=1e-3, momentum=0.01)
+        lin = torch.nn.Linear(8, 4)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, 8))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, 8))
+        model = torch.nn.Sequential(bn, lin)
+        model.train()
+        flat = bench.flatten_grads(model)
+        y = model(x)
+        (y ** 2).sum().backward()
+        dist.all_reduce(flat)
+        flat.div_(world)
+        ret[rank] = dict(y=y.detach(), gx=x.grad.detach(), flat=flat.clone(), mean=bn.running_mean.clone(),
+                         gw=bn.weight.grad.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_bn_and_flat_grad_allreduce_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == 2
+    # the flat gradient bucket is identical on both ranks after the all-reduce
+    assert torch.equal(ret[0]['flat'], ret[1]['flat'])
+    assert torch.equal(ret[0]['gw'], ret[1]['gw'])
+    # naiveSyncBN semantics (ops/norm.py:54-86): statistics = plain average over ranks of the per-rank
+    # mean / mean-of-squares (NOT weighted by point count)
+    torch.manual_seed(0)
+    full = torch.randn(64, 8)
+    parts = [full[:40], full[40:]]
+    mean = sum(p.mean(0) for p in parts) / 2
+    meansqr = sum((p * p).mean(0) for p in parts) / 2
+    var = meansqr - mean * mean
+    w, b = torch.linspace(0.5, 1.5, 8), torch.linspace(-0.2, 0.2, 8)
+    lin = None
+    for r, p in enumerate(parts):
+        ref = (p - mean) * torch.rsqrt(var + 1e-3) * w + b
+        torch.manual_seed(0)
+        _ = torch.randn(64, 8)
+        if lin is None:
+            # same construction order as the worker: bn first, then the Linear draws its init from the RNG
+            from sst_amd.norm import NaiveSyncBatchNorm1d
+            NaiveSyncBatchNorm1d(8)
+            lin = torch.nn.Linear(8, 4)
+        assert torch.allclose(ret[r]['y'], lin(ref), atol=1e-5)
+    assert torch.allclose(ret[0]['mean'], 0.01 * mean, atol=1e-6)
+    assert torch.isfinite(ret[0]['gx']).all() and ret[0]['gx'].shape == (40, 8)
