@@ -185,21 +185,25 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
  * Q,K,V,O: [M, n_heads*16] fp32 with row strides ldq/ldk/ldv/ldo (elements, multiples of 4; base
  * pointers 16-byte aligned).  d_lse [M, n_heads] fp32: log-sum-exp of each softmax row (for backward).
  *   max_tokens: upper bound on tokens per window the caller guarantees (0 = unknown).
- *   impl: 0 = auto (MFMA tiles for windows <= 144 tokens, generic VALU kernel above that),
- *         1 = generic VALU kernel for every window (validation path).
+ *   impl: 0 = auto: register-resident MFMA kernels (wave = window x head, no LDS) for windows <= 144
+ *             tokens, generic VALU kernel above that;
+ *         1 = generic VALU kernel for every window (validation path);
+ *         2 = LDS-staged MFMA kernels (K,V of a 4-head group in LDS; the first implementation).
  * ---------------------------------------------------------------------------------------------- */
 int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk,
                          int64_t ldv, const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows,
                          int n_heads, float scale, int max_tokens, int impl, float* d_o, int64_t ldo,
                          float* d_lse, void* stream);
 /* Backward: given dO, recomputes P from (Q,K,LSE) and writes dQ, dK, dV for every token row listed in
- * d_tok (other rows untouched).  n_tokens = number of rows of the [M, *] tensors. */
+ * d_tok (other rows untouched).  n_tokens = number of rows of the [M, *] tensors.
+ * Workspace: sst_sra_attn_bwd_workspace_bytes(n_tokens, n_heads) (holds rowsum(dO*O) per token, head). */
+int64_t sst_sra_attn_bwd_workspace_bytes(int64_t n_tokens, int n_heads);
 int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o,
                          const float* d_do, const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv,
                          int64_t ldo, int64_t lddo, const int32_t* d_tok, const int32_t* d_winoff,
                          int64_t n_windows, int64_t n_tokens, int n_heads, float scale, int max_tokens,
                          int impl, float* d_dq, float* d_dk, float* d_dv, int64_t lddq, int64_t lddk,
-                         int64_t lddv, void* stream);
+                         int64_t lddv, void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a10/a14) row gather / scatter used by flat2window / window2flat / recover_bev.
@@ -211,6 +215,26 @@ int sst_gather_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_idx
                         float fill, float* d_out, int64_t ld_out, void* stream);
 int sst_scatter_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_idx, int64_t n_src, int c,
                          float* d_out, int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a13, §8 f1) row-wise pieces of an encoder layer around the attention core.
+ *   sst_add_layernorm_fwd_f32: y = LayerNorm(x + res) * weight + bias per row (res may be NULL);
+ *     replaces `src = self.norm1(src + src2)` (models/sst/sst_basic_block_v2.py:113-118).  d_sum (optional)
+ *     receives x + res (saved for backward), d_stats [m,2] receives (mean, rstd).  c % 4 == 0, c <= 512.
+ *   sst_add_layernorm_bwd_f32: d_dx = gradient w.r.t. (x + res) (same tensor for both addends);
+ *     d_dweight / d_dbias [c] are overwritten with the column reductions.
+ *   sst_colsum_f32: out[c] = sum over rows of x[m, c] (row stride ld) — bias gradients of the
+ *     projections / FFN.  c % 4 == 0, c <= 1024.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
+                              int64_t m, int c, float eps, float* d_y, float* d_sum, float* d_stats,
+                              void* stream);
+int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c);
+int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats,
+                              const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight,
+                              float* d_dbias, void* d_workspace, void* stream);
+int64_t sst_colsum_workspace_bytes(int64_t m, int c);
+int sst_colsum_f32(const float* d_x, int64_t m, int c, int64_t ld, float* d_out, void* d_workspace, void* stream);
 
 #ifdef __cplusplus
 }

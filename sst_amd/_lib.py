@@ -46,9 +46,17 @@ _SIGNATURES = {
                                      c_f32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     'sst_sra_attn_bwd_f32': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_f32,
                                                                  c_i32, c_i32, c_ptr, c_ptr, c_ptr,
-                                                                 c_i64, c_i64, c_i64, c_ptr]),
+                                                                 c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'sst_sra_attn_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_gather_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_i64, c_ptr]),
     'sst_scatter_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
+    'sst_add_layernorm_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr,
+                                          c_ptr]),
+    'sst_add_layernorm_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
+    'sst_add_layernorm_bwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                          c_ptr]),
+    'sst_colsum_workspace_bytes': (c_i64, [c_i64, c_i32]),
+    'sst_colsum_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

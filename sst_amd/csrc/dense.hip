@@ -1,0 +1,303 @@
+// Row-wise fp32 kernels either side of the SRA core inside an encoder layer:
+//   fused residual-add + LayerNorm forward / backward   (sst_basic_block_v2.py:113-118: src = norm(src + src2))
+//   column sum of a tall matrix                          (bias gradients of the projections / FFN)
+// All HBM-bound: 1 read + 1 write of 4C B/token forward (+ the residual read), row = one 32-lane group.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int kLnThreads = 256;
+constexpr int kLnRowsPerBlock = kLnThreads / 32;  // one row per 32-lane half-wave
+constexpr int kLnMaxVec = 4;                      // up to 4 float4 per lane -> C <= 512
+
+__device__ __forceinline__ float group32_sum(float v) {
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// y = LN(x + r) * w + b ; stats[row] = (mean, rstd).  r may be null.
+__global__ __launch_bounds__(kLnThreads) void add_ln_fwd_k(const float* __restrict__ x, const float* __restrict__ r,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           int64_t m, int c, float eps, float* __restrict__ y,
+                                                           float* __restrict__ sum_out, float2* __restrict__ stats) {
+  const int lane = threadIdx.x & 31;
+  const int sub = threadIdx.x >> 5;
+  const int nvec = (c + 127) / 128;
+  for (int64_t row = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row < m; row += (int64_t)gridDim.x * kLnRowsPerBlock) {
+    float4 v[kLnMaxVec];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < nvec && col < c) {
+        v[k] = *(const float4*)(x + row * c + col);
+        if (r != nullptr) {
+          const float4 rv = *(const float4*)(r + row * c + col);
+          v[k].x += rv.x;
+          v[k].y += rv.y;
+          v[k].z += rv.z;
+          v[k].w += rv.w;
+        }
+        if (sum_out != nullptr) *(float4*)(sum_out + row * c + col) = v[k];
+        s += v[k].x + v[k].y + v[k].z + v[k].w;
+      }
+    }
+    const float mean = group32_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      if (k < nvec && col < c) {
+        const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+        q += dx * dx + dy * dy + dz * dz + dw * dw;
+      }
+    }
+    const float var = group32_sum(q) / (float)c;
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      if (k < nvec && col < c) {
+        const float4 wv = *(const float4*)(w + col);
+        const float4 bv = *(const float4*)(b + col);
+        float4 o;
+        o.x = (v[k].x - mean) * rstd * wv.x + bv.x;
+        o.y = (v[k].y - mean) * rstd * wv.y + bv.y;
+        o.z = (v[k].z - mean) * rstd * wv.z + bv.z;
+        o.w = (v[k].w - mean) * rstd * wv.w + bv.w;
+        *(float4*)(y + row * c + col) = o;
+      }
+    }
+    if (lane == 0) stats[row] = make_float2(mean, rstd);
+  }
+}
+
+// Given s = x + r (saved), stats, dy:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w
+// dw += sum_rows dy * xhat ; db += sum_rows dy   (block partials in LDS, then one atomic per column per block)
+__global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restrict__ dy, const float* __restrict__ s,
+                                                           const float2* __restrict__ stats,
+                                                           const float* __restrict__ w, int64_t m, int c,
+                                                           float* __restrict__ dx,
+                                                           float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [2][c]
+  for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) part[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 31;
+  const int sub = threadIdx.x >> 5;
+  const int nvec = (c + 127) / 128;
+  float4 aw[kLnMaxVec], ab[kLnMaxVec];
+#pragma unroll
+  for (int k = 0; k < kLnMaxVec; ++k) aw[k] = ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t row = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row < m; row += (int64_t)gridDim.x * kLnRowsPerBlock) {
+    const float2 st = stats[row];
+    float4 g[kLnMaxVec], xh[kLnMaxVec];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      g[k] = xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < nvec && col < c) {
+        const float4 d = *(const float4*)(dy + row * c + col);
+        const float4 sv = *(const float4*)(s + row * c + col);
+        const float4 wv = *(const float4*)(w + col);
+        xh[k] = make_float4((sv.x - st.x) * st.y, (sv.y - st.x) * st.y, (sv.z - st.x) * st.y, (sv.w - st.x) * st.y);
+        g[k] = make_float4(d.x * wv.x, d.y * wv.y, d.z * wv.z, d.w * wv.w);
+        sg += g[k].x + g[k].y + g[k].z + g[k].w;
+        sgx += g[k].x * xh[k].x + g[k].y * xh[k].y + g[k].z * xh[k].z + g[k].w * xh[k].w;
+        aw[k].x += d.x * xh[k].x;
+        aw[k].y += d.y * xh[k].y;
+        aw[k].z += d.z * xh[k].z;
+        aw[k].w += d.w * xh[k].w;
+        ab[k].x += d.x;
+        ab[k].y += d.y;
+        ab[k].z += d.z;
+        ab[k].w += d.w;
+      }
+    }
+    const float mg = group32_sum(sg) / (float)c;
+    const float mgx = group32_sum(sgx) / (float)c;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      if (k < nvec && col < c) {
+        float4 o;
+        o.x = st.y * (g[k].x - mg - xh[k].x * mgx);
+        o.y = st.y * (g[k].y - mg - xh[k].y * mgx);
+        o.z = st.y * (g[k].z - mg - xh[k].z * mgx);
+        o.w = st.y * (g[k].w - mg - xh[k].w * mgx);
+        *(float4*)(dx + row * c + col) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kLnMaxVec; ++k) {
+    const int col = k * 128 + lane * 4;
+    if (k < nvec && col < c) {
+      atomicAdd(&part[col + 0], aw[k].x);
+      atomicAdd(&part[col + 1], aw[k].y);
+      atomicAdd(&part[col + 2], aw[k].z);
+      atomicAdd(&part[col + 3], aw[k].w);
+      atomicAdd(&part[c + col + 0], ab[k].x);
+      atomicAdd(&part[c + col + 1], ab[k].y);
+      atomicAdd(&part[c + col + 2], ab[k].z);
+      atomicAdd(&part[c + col + 3], ab[k].w);
+    }
+  }
+  __syncthreads();
+  // block partials [gridDim.x][2c]; reduced by colsum_partials_k (no global atomics, deterministic)
+  float* dst = partials + (int64_t)blockIdx.x * 2 * c;
+  for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
+}
+
+// out[i] = sum_b partials[b][i], i < width.  Block = 32 columns x 8 slices of the nb partial rows.
+__global__ __launch_bounds__(256) void colsum_partials_k(const float* __restrict__ partials, int nb, int width,
+                                                         float* __restrict__ out0, float* __restrict__ out1,
+                                                         int split) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cx;
+  float acc = 0.f;
+  if (i < width)
+    for (int b = gy; b < nb; b += 8) acc += partials[(int64_t)b * width + i];
+  red[gy][cx] = acc;
+  __syncthreads();
+  if (gy == 0 && i < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    if (i < split)
+      out0[i] = t;
+    else
+      out1[i - split] = t;
+  }
+}
+
+// out[col] += sum over rows of x[row, col]; out must be zero on entry.  c % 4 == 0, c <= 1024.
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int64_t m, int c, int64_t ld,
+                                                int64_t rows_per_block, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [c]
+  for (int i = threadIdx.x; i < c; i += 256) part[i] = 0.f;
+  __syncthreads();
+  const int c4 = c >> 2;
+  const int rpi = 256 / c4 > 0 ? 256 / c4 : 1;  // rows per iteration
+  const int ry = threadIdx.x / c4, cx = threadIdx.x - ry * c4;
+  const int64_t beg = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t end = beg + rows_per_block < m ? beg + rows_per_block : m;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ry < rpi) {
+    for (int64_t row = beg + ry; row < end; row += rpi) {
+      for (int cc = cx; cc < c4; cc += 256) {  // c4 <= 256: single trip
+        const float4 v = *(const float4*)(x + row * ld + cc * 4);
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+      }
+    }
+    atomicAdd(&part[cx * 4 + 0], acc.x);
+    atomicAdd(&part[cx * 4 + 1], acc.y);
+    atomicAdd(&part[cx * 4 + 2], acc.z);
+    atomicAdd(&part[cx * 4 + 3], acc.w);
+  }
+  __syncthreads();
+  float* dst = out + (int64_t)blockIdx.x * c;  // block partials, reduced by colsum_partials2d_k
+  for (int i = threadIdx.x; i < c; i += 256) dst[i] = part[i];
+}
+
+// out[i] += sum over a 64-row slice of partials[nb][width]; grid = (ceil(width/32), ceil(nb/64)); out zeroed before
+__global__ __launch_bounds__(256) void colsum_partials2d_k(const float* __restrict__ partials, int nb, int width,
+                                                           float* __restrict__ out) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cx;
+  const int b0 = blockIdx.y * 64;
+  const int b1 = b0 + 64 < nb ? b0 + 64 : nb;
+  float acc = 0.f;
+  if (i < width)
+    for (int b = b0 + gy; b < b1; b += 8) acc += partials[(int64_t)b * width + i];
+  red[gy][cx] = acc;
+  __syncthreads();
+  if (gy == 0 && i < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    atomicAdd(out + i, t);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
+                              int64_t m, int c, float eps, float* d_y, float* d_sum, float* d_stats, void* stream) {
+  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_weight || !d_bias || !d_y || !d_stats) return SST_ERR_ARG;
+  const int grid = sst_grid_1d(m, kLnRowsPerBlock);
+  hipLaunchKernelGGL(add_ln_fwd_k, dim3(grid), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res, d_weight, d_bias,
+                     m, c, eps, d_y, d_sum, (float2*)d_stats);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c) {
+  (void)m;
+  return (int64_t)1024 * 2 * c * sizeof(float) + 256;
+}
+
+int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats, const float* d_weight,
+                              int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias, void* d_workspace,
+                              void* stream) {
+  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (!d_dweight || !d_dbias) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (m == 0) {
+    SST_HIP(hipMemsetAsync(d_dweight, 0, sizeof(float) * c, st));
+    SST_HIP(hipMemsetAsync(d_dbias, 0, sizeof(float) * c, st));
+    return SST_OK;
+  }
+  if (!d_dy || !d_sum || !d_stats || !d_weight || !d_dx || !d_workspace) return SST_ERR_ARG;
+  int grid = (int)sst_div_up(m, kLnRowsPerBlock * 4);
+  if (grid > 512) grid = 512;
+  float* partials = (float*)d_workspace;
+  hipLaunchKernelGGL(add_ln_bwd_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
+                     (const float2*)d_stats, d_weight, m, c, d_dx, partials);
+  hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(256), 0, st, partials, grid, 2 * c, d_dweight,
+                     d_dbias, c);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int64_t sst_colsum_workspace_bytes(int64_t m, int c) {
+  (void)m;
+  return (int64_t)2048 * c * sizeof(float) + 256;
+}
+
+int sst_colsum_f32(const float* d_x, int64_t m, int c, int64_t ld, float* d_out, void* d_workspace, void* stream) {
+  if (m < 0 || c < 4 || (c & 3) || c > 1024 || ld < c) return SST_ERR_UNSUPPORTED;
+  if (!d_out) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  SST_HIP(hipMemsetAsync(d_out, 0, sizeof(float) * c, st));
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_workspace) return SST_ERR_ARG;
+  int64_t rows_per_block = 64;
+  int64_t grid = sst_div_up(m, rows_per_block);
+  if (grid > 2048) {
+    grid = 2048;
+    rows_per_block = sst_div_up(m, grid);
+    grid = sst_div_up(m, rows_per_block);
+  }
+  float* partials = (float*)d_workspace;
+  hipLaunchKernelGGL(colsum_k, dim3((unsigned)grid), dim3(256), c * sizeof(float), st, d_x, m, c, ld, rows_per_block,
+                     partials);
+  hipLaunchKernelGGL(colsum_partials2d_k, dim3((c + 31) / 32, (unsigned)((grid + 63) / 64)), dim3(256), 0, st, partials,
+                     (int)grid, c, d_out);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+}  // extern "C"

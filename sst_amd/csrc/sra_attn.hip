@@ -248,6 +248,154 @@ __global__ __launch_bounds__(256) void sra_fwd_mfma_k(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFMA forward, register-resident variant ("wave = window x head"): no LDS, no barrier.
+// A workgroup is still (window, 4-head group) but each of its 4 waves owns ONE head: it loads that head's
+// K row-fragments (one float4 per 16-key tile) and V column-fragments (4 dwords per tile) straight from
+// HBM/L2 into the MFMA operand layout and keeps them in VGPRs for all query tiles of the window
+// (<= 36 + 36 VGPRs at 144 tokens).  The 4 waves of a block touch adjacent 64 B segments of the same token
+// rows at the same time, so every 128 B line is fetched once per CU.  Token row ids are held 64 per
+// register and broadcast with ds_bpermute (__shfl).  Q tiles are prefetched one iteration ahead.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, const float* __restrict__ K,
+                                                  const float* __restrict__ V, int64_t ldq, int64_t ldk, int64_t ldv,
+                                                  const int32_t* __restrict__ tok, int beg, int t, int nt, int hg,
+                                                  int H, float scale, float* __restrict__ O, int64_t ldo,
+                                                  float* __restrict__ LSE) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int head = hg * kGH + (threadIdx.x >> 6);
+  const int hoff = head * kHD;
+  constexpr int NTK = (NT * 16 + 63) / 64;
+  int tk[NTK];
+#pragma unroll
+  for (int i = 0; i < NTK; ++i) {
+    const int p = i * 64 + lane;
+    tk[i] = p < t ? tok[beg + p] : -1;
+  }
+  // K row-fragments and V column-fragments of this head for the whole window
+  float4 kf[NT];
+  float vf[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    kf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vf[j][r] = 0.f;
+    if (j < nt) {
+      const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      if (krow >= 0) kf[j] = *(const float4*)(K + (int64_t)krow * ldk + hoff + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int vrow = __shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
+        if (vrow >= 0) vf[j][r] = V[(int64_t)vrow * ldv + hoff + c];
+      }
+    }
+  }
+  auto q_row = [&](int i) -> int {
+    int sel = tk[0];
+#pragma unroll
+    for (int u = 1; u < NTK; ++u) sel = ((i >> 2) == u) ? tk[u] : sel;
+    return __shfl(sel, (i & 3) * 16 + c, 64);
+  };
+  auto q_load = [&](int qrow) -> float4 {
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qrow >= 0) {
+      qf = *(const float4*)(Q + (int64_t)qrow * ldq + hoff + 4 * g);
+      qf.x *= scale;
+      qf.y *= scale;
+      qf.z *= scale;
+      qf.w *= scale;
+    }
+    return qf;
+  };
+  int qrow = q_row(0);
+  float4 qf = q_load(qrow);
+  for (int i = 0; i < nt; ++i) {
+    const int qrow_next = (i + 1 < nt) ? q_row(i + 1) : -1;
+    const float4 qf_next = q_load(qrow_next);  // prefetch
+    f32x4 st[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (j < nt) {
+        acc = mfma4(kf[j], qf, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (j * 16 + 4 * g + r) < t ? acc[r] : -INFINITY;
+          acc[r] = v;
+          mx = fmaxf(mx, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = -INFINITY;
+      }
+      st[j] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = __expf(st[j][r] - mx);
+        st[j][r] = pe;
+        sum += pe;
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the MFMA dependent latency
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (j & 1)
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][r], st[j][r], o1, 0, 0, 0);
+          else
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][r], st[j][r], o0, 0, 0, 0);
+        }
+      }
+    }
+    if (qrow >= 0) {
+      const float inv = 1.f / sum;
+      const float4 ov = make_float4((o0[0] + o1[0]) * inv, (o0[1] + o1[1]) * inv, (o0[2] + o1[2]) * inv,
+                                    (o0[3] + o1[3]) * inv);
+      *(float4*)(O + (int64_t)qrow * ldo + hoff + 4 * g) = ov;
+      if (g == 0) LSE[(int64_t)qrow * H + head] = mx + __logf(sum);
+    }
+    qrow = qrow_next;
+    qf = qf_next;
+  }
+}
+
+// One launch for every window: the tile class is picked per workgroup, so all classes run concurrently
+// (separate per-class launches serialise on the stream and the sparse classes run at very low occupancy).
+template <int NTMAX>
+__global__ __launch_bounds__(256) void sra_fwd_wave_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                      const float* __restrict__ V, int64_t ldq, int64_t ldk,
+                                                      int64_t ldv, const int32_t* __restrict__ tok,
+                                                      const int32_t* __restrict__ winoff, int n_groups, int H,
+                                                      float scale, float* __restrict__ O, int64_t ldo,
+                                                      float* __restrict__ LSE) {
+  const int w = blockIdx.x / n_groups;
+  const int hg = blockIdx.x - w * n_groups;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  const int nt = (t + 15) >> 4;
+  if (nt < 1 || nt > NTMAX) return;  // > NTMAX: the generic kernel owns this window
+  if (nt <= 2)
+    sra_fwd_wave_body<2>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+  else if (nt <= 4)
+    sra_fwd_wave_body<4>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+  else if (nt <= 7 || NTMAX <= 7)
+    sra_fwd_wave_body<(NTMAX < 7 ? NTMAX : 7)>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+  else
+    sra_fwd_wave_body<NTMAX>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+}
+
+// ------------------------------------------------------------------------------------------------
 // MFMA backward.  Phase A: a wave owns (head, key tile) and accumulates dK, dV over query tiles.
 // Phase B: a wave owns (head, query tile) and accumulates dQ over key tiles (S is recomputed in the
 // transposed orientation so that dS lands in the A-operand layout of dS K).
@@ -381,6 +529,264 @@ __global__ __launch_bounds__(256) void sra_bwd_mfma_k(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA backward, register-resident ("wave = window x head"), two launches:
+//   sra_bwd_dq_k   : per query tile, S^T = K Q^T and dP^T = V dO^T (row = key, col = query), dS^T, then
+//                    dQ += dS K with the K column-fragments held in registers; also emits
+//                    D[token, head] = rowsum(dO * O) for the second kernel.
+//   sra_bwd_dkv_k  : per query tile, S = Q K^T and dP = dO V^T (row = query, col = key); P and dS are then
+//                    directly the A operands of dV += P^T dO and dK += dS^T Q, accumulated in registers
+//                    over all query tiles of the window.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void sra_bwd_dq_body(const float* __restrict__ Q, const float* __restrict__ K,
+                                                const float* __restrict__ V, const float* __restrict__ O,
+                                                const float* __restrict__ dO, const float* __restrict__ LSE,
+                                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                                                const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H,
+                                                float scale, float* __restrict__ dQ, int64_t lddq,
+                                                float* __restrict__ Dbuf) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int head = hg * kGH + (threadIdx.x >> 6);
+  const int hoff = head * kHD;
+  constexpr int NTK = (NT * 16 + 63) / 64;
+  int tk[NTK];
+#pragma unroll
+  for (int i = 0; i < NTK; ++i) {
+    const int p = i * 64 + lane;
+    tk[i] = p < t ? tok[beg + p] : -1;
+  }
+  float4 kf[NT], vf[NT];
+  float kc[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    kf[j] = vf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kc[j][r] = 0.f;
+    if (j < nt) {
+      const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      if (krow >= 0) {
+        kf[j] = *(const float4*)(K + (int64_t)krow * ldk + hoff + 4 * g);
+        vf[j] = *(const float4*)(V + (int64_t)krow * ldv + hoff + 4 * g);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int crow = __shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
+        if (crow >= 0) kc[j][r] = K[(int64_t)crow * ldk + hoff + c];
+      }
+    }
+  }
+  auto tok_at = [&](int i, int within) -> int {  // token id of window position 16*i + within (within: per lane)
+    int sel = tk[0];
+#pragma unroll
+    for (int u = 1; u < NTK; ++u) sel = ((i >> 2) == u) ? tk[u] : sel;
+    return __shfl(sel, (i & 3) * 16 + within, 64);
+  };
+  for (int i = 0; i < nt; ++i) {
+    const int qrow = tok_at(i, c);
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), gf = qf, of = qf;
+    float lse = 0.f;
+    if (qrow >= 0) {
+      qf = *(const float4*)(Q + (int64_t)qrow * ldq + hoff + 4 * g);
+      gf = *(const float4*)(dO + (int64_t)qrow * lddo + hoff + 4 * g);
+      of = *(const float4*)(O + (int64_t)qrow * ldo + hoff + 4 * g);
+      lse = LSE[(int64_t)qrow * H + head];
+    }
+    float dd = gf.x * of.x + gf.y * of.y + gf.z * of.z + gf.w * of.w;
+    dd += __shfl_xor(dd, 16, 64);
+    dd += __shfl_xor(dd, 32, 64);
+    if (qrow >= 0 && g == 0) Dbuf[(int64_t)qrow * H + head] = dd;
+    const bool q_ok = qrow >= 0;
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma4(kf[j], qf, s);    // S^T[key 16j+4g+r][query 16i+c]
+        dp = mfma4(vf[j], gf, dp);  // dP^T, same layout
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = q_ok && (j * 16 + 4 * g + r) < t;
+          const float pe = ok ? __expf(s[r] * scale - lse) : 0.f;
+          const float ds = pe * (dp[r] - dd) * scale;
+          if (j & 1)
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kc[j][r], dq1, 0, 0, 0);
+          else
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kc[j][r], dq0, 0, 0, 0);
+        }
+      }
+    }
+    // D layout: value r = dQ[query 16i + 4g + r][d = c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = tok_at(i, 4 * g + r);
+      if (orow >= 0) dQ[(int64_t)orow * lddq + hoff + c] = dq0[r] + dq1[r];
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void sra_bwd_dkv_body(const float* __restrict__ Q, const float* __restrict__ K,
+                                                 const float* __restrict__ V, const float* __restrict__ dO,
+                                                 const float* __restrict__ LSE, const float* __restrict__ Dbuf,
+                                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo,
+                                                 const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H,
+                                                 float scale, float* __restrict__ dK, float* __restrict__ dV,
+                                                 int64_t lddk, int64_t lddv) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int head = hg * kGH + (threadIdx.x >> 6);
+  const int hoff = head * kHD;
+  constexpr int NTK = (NT * 16 + 63) / 64;
+  int tk[NTK];
+#pragma unroll
+  for (int i = 0; i < NTK; ++i) {
+    const int p = i * 64 + lane;
+    tk[i] = p < t ? tok[beg + p] : -1;
+  }
+  float4 kf[NT], vf[NT];
+  f32x4 dk[NT], dv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    kf[j] = vf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (j < nt) {
+      const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      if (krow >= 0) {
+        kf[j] = *(const float4*)(K + (int64_t)krow * ldk + hoff + 4 * g);
+        vf[j] = *(const float4*)(V + (int64_t)krow * ldv + hoff + 4 * g);
+      }
+    }
+  }
+  auto tok_at = [&](int i, int within) -> int {
+    int sel = tk[0];
+#pragma unroll
+    for (int u = 1; u < NTK; ++u) sel = ((i >> 2) == u) ? tk[u] : sel;
+    return __shfl(sel, (i & 3) * 16 + within, 64);
+  };
+  for (int i = 0; i < nt; ++i) {
+    const int arow = tok_at(i, c);  // row-fragment row: query 16i + c
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), gf = qf;
+    if (arow >= 0) {
+      qf = *(const float4*)(Q + (int64_t)arow * ldq + hoff + 4 * g);
+      gf = *(const float4*)(dO + (int64_t)arow * lddo + hoff + 4 * g);
+    }
+    float qc[4], gc[4], lse4[4], dd4[4];
+    bool qok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // column-fragment rows: queries 16i + 4g + r
+      const int crow = tok_at(i, 4 * g + r);
+      qok[r] = crow >= 0;
+      qc[r] = gc[r] = lse4[r] = dd4[r] = 0.f;
+      if (crow >= 0) {
+        qc[r] = Q[(int64_t)crow * ldq + hoff + c];
+        gc[r] = dO[(int64_t)crow * lddo + hoff + c];
+        lse4[r] = LSE[(int64_t)crow * H + head];
+        dd4[r] = Dbuf[(int64_t)crow * H + head];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
+        const bool key_ok = (j * 16 + c) < t;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma4(qf, kf[j], s);    // S[query 16i+4g+r][key 16j+c]
+        dp = mfma4(gf, vf[j], dp);  // dP, same layout
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = key_ok && qok[r];
+          const float pe = ok ? __expf(s[r] * scale - lse4[r]) : 0.f;
+          const float ds = pe * (dp[r] - dd4[r]) * scale;
+          dv[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pe, gc[r], dv[j], 0, 0, 0);  // dV[key c][d] += P^T dO
+          dk[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, qc[r], dk[j], 0, 0, 0);  // dK[key c][d] += dS^T Q
+        }
+      }
+    }
+  }
+  // D layout: value r = d{K,V}[key 16j + 4g + r][d = c]
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (j < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
+        if (krow >= 0) {
+          dK[(int64_t)krow * lddk + hoff + c] = dk[j][r];
+          dV[(int64_t)krow * lddv + hoff + c] = dv[j][r];
+        }
+      }
+    }
+  }
+}
+
+template <int NTMAX>
+__global__ __launch_bounds__(256) void sra_bwd_dq_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                    const float* __restrict__ V, const float* __restrict__ O,
+                                                    const float* __restrict__ dO, const float* __restrict__ LSE,
+                                                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                                                    const int32_t* __restrict__ tok,
+                                                    const int32_t* __restrict__ winoff, int n_groups, int H,
+                                                    float scale, float* __restrict__ dQ, int64_t lddq,
+                                                    float* __restrict__ Dbuf) {
+  const int w = blockIdx.x / n_groups;
+  const int hg = blockIdx.x - w * n_groups;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  const int nt = (t + 15) >> 4;
+  if (nt < 1 || nt > NTMAX) return;
+#define SST_DQ_ARGS Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo, tok, beg, t, nt, hg, H, scale, dQ, lddq, Dbuf
+  if (nt <= 2)
+    sra_bwd_dq_body<2>(SST_DQ_ARGS);
+  else if (nt <= 4)
+    sra_bwd_dq_body<4>(SST_DQ_ARGS);
+  else if (nt <= 7 || NTMAX <= 7)
+    sra_bwd_dq_body<(NTMAX < 7 ? NTMAX : 7)>(SST_DQ_ARGS);
+  else
+    sra_bwd_dq_body<NTMAX>(SST_DQ_ARGS);
+#undef SST_DQ_ARGS
+}
+
+template <int NTMAX>
+__global__ __launch_bounds__(256) void sra_bwd_dkv_k(const float* __restrict__ Q, const float* __restrict__ K,
+                                                     const float* __restrict__ V, const float* __restrict__ dO,
+                                                     const float* __restrict__ LSE, const float* __restrict__ Dbuf,
+                                                     int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo,
+                                                     const int32_t* __restrict__ tok,
+                                                     const int32_t* __restrict__ winoff, int n_groups, int H,
+                                                     float scale, float* __restrict__ dK, float* __restrict__ dV,
+                                                     int64_t lddk, int64_t lddv) {
+  const int w = blockIdx.x / n_groups;
+  const int hg = blockIdx.x - w * n_groups;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  const int nt = (t + 15) >> 4;
+  if (nt < 1 || nt > NTMAX) return;
+#define SST_DKV_ARGS Q, K, V, dO, LSE, Dbuf, ldq, ldk, ldv, lddo, tok, beg, t, nt, hg, H, scale, dK, dV, lddk, lddv
+  if (nt <= 2)
+    sra_bwd_dkv_body<2>(SST_DKV_ARGS);
+  else if (nt <= 4)
+    sra_bwd_dkv_body<4>(SST_DKV_ARGS);
+  else if (nt <= 7 || NTMAX <= 7)
+    sra_bwd_dkv_body<(NTMAX < 7 ? NTMAX : 7)>(SST_DKV_ARGS);
+  else
+    sra_bwd_dkv_body<NTMAX>(SST_DKV_ARGS);
+#undef SST_DKV_ARGS
+}
+
+template <int NTMAX>
+int launch_bwd_wave(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* tok,
+                    const int32_t* winoff, int64_t n_windows, int H, float scale, float* dQ, float* dK, float* dV,
+                    int64_t lddq, int64_t lddk, int64_t lddv, float* Dbuf, hipStream_t st) {
+  const int n_groups = H / kGH;
+  const dim3 grid((unsigned)(n_windows * n_groups));
+  hipLaunchKernelGGL(sra_bwd_dq_k<NTMAX>, grid, dim3(256), 0, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo, tok,
+                     winoff, n_groups, H, scale, dQ, lddq, Dbuf);
+  hipLaunchKernelGGL(sra_bwd_dkv_k<NTMAX>, grid, dim3(256), 0, st, Q, K, V, dO, LSE, Dbuf, ldq, ldk, ldv, lddo, tok,
+                     winoff, n_groups, H, scale, dK, dV, lddk, lddv);
+  return SST_OK;
+}
+
 template <int NT>
 int launch_fwd_variant(const float* Q, const float* K, const float* V, int64_t ldq, int64_t ldk, int64_t ldv,
                        const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, int nt_lo,
@@ -390,6 +796,16 @@ int launch_fwd_variant(const float* Q, const float* K, const float* V, int64_t l
   SST_HIP(hipFuncSetAttribute((const void*)sra_fwd_mfma_k<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(sra_fwd_mfma_k<NT>, dim3((unsigned)(n_windows * n_groups)), dim3(256), lds, st, Q, K, V, ldq, ldk,
                      ldv, tok, winoff, n_groups, H, scale, nt_lo, O, ldo, LSE);
+  return SST_OK;
+}
+
+template <int NTMAX>
+int launch_fwd_wave(const float* Q, const float* K, const float* V, int64_t ldq, int64_t ldk, int64_t ldv,
+                    const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, float* O,
+                    int64_t ldo, float* LSE, hipStream_t st) {
+  const int n_groups = H / kGH;
+  hipLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(256), 0, st, Q, K, V, ldq, ldk,
+                     ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE);
   return SST_OK;
 }
 
@@ -417,7 +833,7 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
                          int64_t ldv, const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int n_heads,
                          float scale, int max_tokens, int impl, float* d_o, int64_t ldo, float* d_lse,
                          void* stream) {
-  if (n_windows < 0 || n_heads < 1 || impl < 0 || impl > 1) return SST_ERR_ARG;
+  if (n_windows < 0 || n_heads < 1 || impl < 0 || impl > 2) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
   if (!d_q || !d_k || !d_v || !d_tok || !d_winoff || !d_o || !d_lse) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -431,24 +847,23 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
   }
   int rc;
   const int cap_tiles = max_tokens > 0 ? (max_tokens + 15) / 16 : 1 << 30;
-  rc = launch_fwd_variant<2>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 0, d_o, ldo,
-                             d_lse, st);
-  if (rc) return rc;
-  if (cap_tiles > 2) {
-    rc = launch_fwd_variant<4>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 2, d_o, ldo,
-                               d_lse, st);
+#define SST_FWD_ARGS(lo) d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, lo, d_o, ldo, d_lse, st
+  if (impl == 2) {  // LDS-staged kernels
+    rc = launch_fwd_variant<2>(SST_FWD_ARGS(0));
+    if (rc) return rc;
+    if (cap_tiles > 2 && (rc = launch_fwd_variant<4>(SST_FWD_ARGS(2)))) return rc;
+    if (cap_tiles > 4 && (rc = launch_fwd_variant<7>(SST_FWD_ARGS(4)))) return rc;
+    if (cap_tiles > 7 && (rc = launch_fwd_variant<9>(SST_FWD_ARGS(7)))) return rc;
+  } else {          // register-resident kernels (default): ONE launch, tile class chosen per workgroup
+    if (cap_tiles <= 7)
+      rc = launch_fwd_wave<7>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, d_o, ldo,
+                              d_lse, st);
+    else
+      rc = launch_fwd_wave<9>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, d_o, ldo,
+                              d_lse, st);
     if (rc) return rc;
   }
-  if (cap_tiles > 4) {
-    rc = launch_fwd_variant<7>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 4, d_o, ldo,
-                               d_lse, st);
-    if (rc) return rc;
-  }
-  if (cap_tiles > 7) {
-    rc = launch_fwd_variant<9>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, 7, d_o, ldo,
-                               d_lse, st);
-    if (rc) return rc;
-  }
+#undef SST_FWD_ARGS
   if (cap_tiles > kMaxTilesMfma) {
     hipLaunchKernelGGL(sra_fwd_generic_k, dim3((unsigned)n_windows), dim3(256), 0, st, d_q, d_k, d_v, ldq, ldk, ldv,
                        d_tok, d_winoff, n_heads, scale, kMaxTilesMfma * 16, d_o, ldo, d_lse);
@@ -457,12 +872,16 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
   return SST_OK;
 }
 
+int64_t sst_sra_attn_bwd_workspace_bytes(int64_t n_tokens, int n_heads) {
+  return sst_align_up((n_tokens > 0 ? n_tokens : 1) * (int64_t)n_heads * sizeof(float), 256);
+}
+
 int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o, const float* d_do,
                          const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                          const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int64_t n_tokens,
                          int n_heads, float scale, int max_tokens, int impl, float* d_dq, float* d_dk, float* d_dv,
-                         int64_t lddq, int64_t lddk, int64_t lddv, void* stream) {
-  if (n_windows < 0 || n_tokens < 0 || n_heads < 1 || impl < 0 || impl > 1) return SST_ERR_ARG;
+                         int64_t lddq, int64_t lddk, int64_t lddv, void* d_workspace, void* stream) {
+  if (n_windows < 0 || n_tokens < 0 || n_heads < 1 || impl < 0 || impl > 2) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
   if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_tok || !d_winoff || !d_dq || !d_dk || !d_dv)
     return SST_ERR_ARG;
@@ -479,25 +898,25 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
     SST_HIP(hipMemset2DAsync(d_dv, (size_t)lddv * sizeof(float), 0, width, (size_t)n_tokens, st));
   }
   if (!all_generic) {
-    int rc;
-    rc = launch_bwd_variant<2>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
-                               n_heads, scale, 0, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
-    if (rc) return rc;
-    if (cap_tiles > 2) {
-      rc = launch_bwd_variant<4>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
-                                 n_windows, n_heads, scale, 2, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+    int rc = SST_OK;
+#define SST_BWD_ARGS(lo) d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows, n_heads, scale, lo, d_dq, d_dk, d_dv, lddq, lddk, lddv, st
+    if (impl == 2) {  // LDS-staged kernels
+      rc = launch_bwd_variant<2>(SST_BWD_ARGS(0));
+      if (rc) return rc;
+      if (cap_tiles > 2 && (rc = launch_bwd_variant<4>(SST_BWD_ARGS(2)))) return rc;
+      if (cap_tiles > 4 && (rc = launch_bwd_variant<7>(SST_BWD_ARGS(4)))) return rc;
+      if (cap_tiles > 7 && (rc = launch_bwd_variant<9>(SST_BWD_ARGS(7)))) return rc;
+    } else {          // register-resident kernels (default): two launches, tile class chosen per workgroup
+      if (!d_workspace) return SST_ERR_ARG;
+      if (cap_tiles <= 7)
+        rc = launch_bwd_wave<7>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
+                                n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, (float*)d_workspace, st);
+      else
+        rc = launch_bwd_wave<9>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
+                                n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, (float*)d_workspace, st);
       if (rc) return rc;
     }
-    if (cap_tiles > 4) {
-      rc = launch_bwd_variant<7>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
-                                 n_windows, n_heads, scale, 4, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
-      if (rc) return rc;
-    }
-    if (cap_tiles > 7) {
-      rc = launch_bwd_variant<9>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
-                                 n_windows, n_heads, scale, 7, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
-      if (rc) return rc;
-    }
+#undef SST_BWD_ARGS
   }
   if (need_generic) {
     hipLaunchKernelGGL(sra_bwd_generic_k, dim3((unsigned)n_windows), dim3(256), 0, st, d_q, d_k, d_v, d_o, d_do,

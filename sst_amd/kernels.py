@@ -338,12 +338,14 @@ def _sra_fwd(q, k, v, plan, n_heads, scale, impl):
 
 def _sra_bwd(q, k, v, o, lse, grad_o, plan, n_heads, scale, impl, dq, dk, dv):
     m = q.size(0)
-    rc = _bracket('sra_bwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_bwd_f32(
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_sra_attn_bwd_workspace_bytes(m, n_heads), q.device)
+    rc = _bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_sra_attn_bwd_f32(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(grad_o), _lib.ptr(lse), _row_stride(q),
         _row_stride(k), _row_stride(v), o.stride(0), grad_o.stride(0), _lib.ptr(plan.tok),
         _lib.ptr(plan.winoff), plan.n_windows, m, n_heads, scale, plan.max_tokens, impl,
         _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk), _row_stride(dv),
-        _lib.stream_ptr()))
+        _lib.ptr(ws), _lib.stream_ptr()))
     _lib.check(rc, 'sst_sra_attn_bwd_f32')
 
 

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
+from .dense import add_layer_norm, tall_linear
 from .norm import build_norm_layer
 
 
@@ -115,8 +116,8 @@ class WindowAttention(nn.Module):
         x = feat_2d.float()
         w, b = attn.in_proj_weight, attn.in_proj_bias
         xp = x + pos if pos is not None else x          # q = k = feat + pos ; v = feat
-        qk = F.linear(xp, w[:2 * c], b[:2 * c])
-        v = F.linear(x, w[2 * c:], b[2 * c:])
+        qk = tall_linear(xp, w[:2 * c], b[:2 * c])
+        v = tall_linear(x, w[2 * c:], b[2 * c:])
         if self.cosine:
             h = self.nhead
             q = F.normalize(qk[:, :c].reshape(-1, h, 16), dim=2)
@@ -126,7 +127,7 @@ class WindowAttention(nn.Module):
             o = K.sra_attention(q, k.reshape(-1, c), v, plan, h, scale=1.0, impl=self.impl)
         else:
             o = K.sra_attention_qk_v(qk, v, plan, self.nhead, scale=1.0 / math.sqrt(16.0), impl=self.impl)
-        return F.linear(o, attn.out_proj.weight, attn.out_proj.bias)
+        return tall_linear(o, attn.out_proj.weight, attn.out_proj.bias)
 
 
 class EncoderLayer(nn.Module):
@@ -153,20 +154,22 @@ class EncoderLayer(nn.Module):
         self.post_norm = layer_cfg.get('post_norm', True)
         self.fp16_enabled = False
 
+    def _ffn(self, x):
+        h = self.activation(tall_linear(x, self.linear1.weight, self.linear1.bias))
+        return tall_linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
+
     def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict=None):
         if self.post_norm:
             src2 = self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)  # [N, d_model]
-            src = src + self.dropout1(src2)
-            src = self.norm1(src)
-            src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
-            src = src + self.dropout2(src2)
-            src = self.norm2(src)
+            src = add_layer_norm(src, self.dropout1(src2), self.norm1)     # norm1(src + src2), one kernel
+            src2 = self._ffn(src)
+            src = add_layer_norm(src, self.dropout2(src2), self.norm2)
         else:
-            src2 = self.norm1(src)
+            src2 = add_layer_norm(src, None, self.norm1)
             src2 = self.win_attn(src2, pos_dict, ind_dict, key_padding_mask_dict)
             src = src + self.dropout1(src2)
-            src2 = self.norm2(src)
-            src2 = self.linear2(self.dropout(self.activation(self.linear1(src2))))
+            src2 = add_layer_norm(src, None, self.norm2)
+            src2 = self._ffn(src2)
             src = src + self.dropout2(src2)
         return src
 

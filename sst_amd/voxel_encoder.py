@@ -15,6 +15,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .dense import tall_linear
 from .norm import build_norm_layer
 from .registry import VOXEL_ENCODERS
 from .sst_ops import build_mlp, get_activation_layer, scatter_v2, unique_with_plan
@@ -31,7 +32,7 @@ class DynamicVFELayer(nn.Module):
         self.linear = nn.Linear(in_channels, out_channels, bias=False)
 
     def forward(self, inputs):
-        x = self.linear(inputs)
+        x = tall_linear(inputs, self.linear.weight, None)
         x = self.norm(x)
         return F.relu(x)
 
@@ -51,7 +52,7 @@ class DynamicVFELayerV2(nn.Module):
     def forward(self, inputs):
         if self.dropout is not None:
             inputs = self.dropout(inputs)
-        x = self.linear(inputs)
+        x = tall_linear(inputs, self.linear.weight, None)
         x = self.norm(x)
         return self.act(x)
 

@@ -1,0 +1,74 @@
+"""GPU: the row-wise / dense pieces of an encoder layer against a plain PyTorch fp32 reference of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('m,c', [(1, 128), (77, 128), (5000, 192), (90107, 128), (1000, 64), (300, 512)])
+@pytest.mark.parametrize('with_res', [True, False])
+def test_add_layer_norm_matches_torch(m, c, with_res):
+    from sst_amd.dense import add_layer_norm
+    g = torch.Generator().manual_seed(m + c)
+    x = (torch.randn(m, c, generator=g) * 2 + 0.5).to(DEV)
+    r = torch.randn(m, c, generator=g).to(DEV) if with_res else None
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(c, generator=g) * 0.1)
+    gout = torch.randn(m, c, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ra = r.clone().requires_grad_(True) if with_res else None
+    rb = r.clone().requires_grad_(True) if with_res else None
+    y = add_layer_norm(xa, ra, norm)
+    (y * gout).sum().backward()
+    gw, gb = norm.weight.grad.clone(), norm.bias.grad.clone()
+    norm.zero_grad()
+    y_ref = F.layer_norm(xb + rb if with_res else xb, (c,), norm.weight, norm.bias, norm.eps)
+    (y_ref * gout).sum().backward()
+    assert torch.allclose(y, y_ref, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(xa.grad, xb.grad, atol=2e-4, rtol=1e-4)
+    if with_res:
+        assert torch.allclose(ra.grad, rb.grad, atol=2e-4, rtol=1e-4)
+    scale = max(1.0, float(norm.weight.grad.abs().max()))
+    assert torch.allclose(gw, norm.weight.grad, atol=2e-4 * scale, rtol=1e-3)
+    assert torch.allclose(gb, norm.bias.grad, atol=2e-4 * scale, rtol=1e-3)
+
+
+@pytest.mark.parametrize('m,cin,cout,bias', [(90107, 128, 384, True), (4097, 256, 128, True), (116000, 9, 64, False),
+                                             (100, 128, 128, True), (50000, 128, 256, True)])
+def test_tall_linear_matches_torch(m, cin, cout, bias):
+    from sst_amd.dense import tall_linear
+    g = torch.Generator().manual_seed(m)
+    x = torch.randn(m, cin, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, generator=g) * 0.1).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV) if bias else None
+    gout = (torch.randn(m, cout, generator=g) * 0.1).to(DEV)
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ba = b.clone().requires_grad_(True) if bias else None
+    xb, wb = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bb = b.clone().requires_grad_(True) if bias else None
+    y = tall_linear(xa, wa, ba)
+    (y * gout).sum().backward()
+    y_ref = F.linear(xb.double(), wb.double(), bb.double() if bias else None)
+    (y_ref * gout.double()).sum().backward()
+    assert torch.allclose(y.double(), y_ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(xa.grad.double(), xb.grad.double(), atol=1e-4, rtol=1e-4)
+    gs = float(wb.grad.abs().max())
+    assert float((wa.grad.double() - wb.grad.double()).abs().max()) < 2e-4 * max(1.0, gs)
+    if bias:
+        assert float((ba.grad.double() - bb.grad.double()).abs().max()) < 2e-4 * max(1.0, float(bb.grad.abs().max()))
+
+
+@pytest.mark.parametrize('m,c', [(1, 4), (1000, 128), (90107, 384), (33333, 256), (5000, 1024)])
+def test_colsum(m, c):
+    from sst_amd.dense import colsum
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(m, c, generator=g).to(DEV)
+    ref = x.double().sum(0)
+    out = colsum(x)
+    assert float((out.double() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+    xs = torch.randn(m, 2 * c, generator=g).to(DEV)[:, c:]   # row-strided view
+    assert float((colsum(xs).double() - xs.double().sum(0)).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))

@@ -33,7 +33,7 @@ SIZE_SETS = {
 }
 
 
-@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('impl', [0, 1, 2])
 @pytest.mark.parametrize('heads', [8, 12])
 @pytest.mark.parametrize('name', list(SIZE_SETS))
 def test_sra_core_forward_backward_vs_oracle(name, heads, impl):
@@ -98,6 +98,8 @@ def test_sra_core_properties_full_size():
     assert float((o12 - (o1 + 2 * o2)).abs().max()) < 1e-4
     og = K.sra_attention(q, k, v1, plan, 8, impl=1)
     assert float((og - o1).abs().max()) < 1e-4
+    ol = K.sra_attention(q, k, v1, plan, 8, impl=2)
+    assert float((ol - o1).abs().max()) < 1e-4
 
 
 def _load_block(g, layer_cfg):

@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Developer microbenchmark (GPU box): times individual kernels of the path on the bench workload with HIP
+events (interleaved rounds, median) and prints achieved GB/s against their algorithmic bytes.
+Usage: python tools/microbench.py [sra|ln|unique|all]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import sst_amd  # noqa: E402
+from sst_amd import kernels as K  # noqa: E402
+
+DEV = torch.device('cuda:0')
+
+
+def timeit(fn, iters=30, warmup=5):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def frame_plan(train=True):
+    pts = bench.make_cloud(116000, 0, DEV)
+    vox = sst_amd.Voxelization(bench.VOXEL_SIZE, bench.PC_RANGE, -1, (-1, -1))
+    _, coors = vox.voxelize_batch([pts])
+    sp = sst_amd.build_scatter_plan(coors, grid_zyx=[1, 468, 468])
+    layer = sst_amd.SSTInputLayerV2((bench.DROP_TRAIN, bench.DROP_TEST), (12, 12, 1), (468, 468, 1),
+                                    shuffle_voxels=False, mute=True, reference_outputs=False, debug=False)
+    layer.train(train)
+    feats = torch.randn(sp.num_voxels, 128, device=DEV)
+    return pts, coors, layer(feats, sp.voxel_coors, 1)
+
+
+def bench_sra():
+    _, _, info = frame_plan()
+    m = info['voxel_feats'].size(0)
+    for s in range(2):
+        plan = info[f'sra_plan_shift{s}']
+        off = plan.winoff[:plan.n_windows + 1].cpu().numpy()
+        sizes = np.diff(off)
+        print(f'shift{s}: {plan.n_windows} windows, tokens {m}, size min/mean/max {sizes.min()}/{sizes.mean():.1f}/'
+              f'{sizes.max()}, tiles hist {np.bincount((sizes + 15) // 16).tolist()}')
+        qk = torch.randn(m, 256, device=DEV)
+        v = torch.randn(m, 128, device=DEV)
+        do = torch.randn(m, 128, device=DEV)
+        for impl in (0, 2, 1):
+            med, mn = timeit(lambda: K._sra_fwd(qk[:, :128], qk[:, 128:], v, plan, 8, 0.25, impl))
+            gbs = bench.SRA_BYTES_PER_TOKEN * m / (med * 1e-3) / 1e9
+            print(f'  fwd impl={impl}: median {med * 1e3:.1f} us (min {mn * 1e3:.1f}) -> {gbs:.0f} GB/s '
+                  f'({gbs / 80:.1f} % of 8 TB/s)')
+        o, lse = K._sra_fwd(qk[:, :128], qk[:, 128:], v, plan, 8, 0.25, 0)
+        dqk = torch.empty_like(qk)
+        dv = torch.empty_like(v)
+        for impl in (0, 2):
+            med, mn = timeit(lambda: K._sra_bwd(qk[:, :128], qk[:, 128:], v, o, lse, do, plan, 8, 0.25, impl,
+                                                dqk[:, :128], dqk[:, 128:], dv))
+            print(f'  bwd impl={impl}: median {med * 1e3:.1f} us (min {mn * 1e3:.1f})')
+
+
+def bench_ln():
+    from sst_amd.dense import add_layer_norm, colsum, weight_grad_splitk
+    m, c = 90107, 128
+    x = torch.randn(m, c, device=DEV, requires_grad=True)
+    r = torch.randn(m, c, device=DEV, requires_grad=True)
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    g = torch.randn(m, c, device=DEV)
+    med, _ = timeit(lambda: add_layer_norm(x, r, norm))
+    print(f'add+LN fwd: {med * 1e3:.1f} us -> {(3 * m * c * 4 + m * 8) / med / 1e6:.0f} GB/s')
+    y = add_layer_norm(x, r, norm)
+    med, _ = timeit(lambda: torch.autograd.grad(y, (x, r), g, retain_graph=True))
+    print(f'add+LN bwd: {med * 1e3:.1f} us -> {(3 * m * c * 4) / med / 1e6:.0f} GB/s')
+    med, _ = timeit(lambda: torch.nn.functional.layer_norm(x + r, (c,), norm.weight, norm.bias))
+    print(f'torch add + layer_norm fwd: {med * 1e3:.1f} us')
+    dy = torch.randn(m, 384, device=DEV)
+    xx = torch.randn(m, 128, device=DEV)
+    med, _ = timeit(lambda: dy.t() @ xx)
+    print(f'dW plain  [384x{m}]x[{m}x128]: {med * 1e3:.1f} us')
+    for chunk in (512, 1024, 2048, 4096):
+        med, _ = timeit(lambda: weight_grad_splitk(dy, xx, chunk))
+        print(f'dW split-K chunk {chunk}: {med * 1e3:.1f} us')
+    med, _ = timeit(lambda: colsum(dy))
+    print(f'colsum [{m},384]: {med * 1e3:.1f} us; torch sum(0): {timeit(lambda: dy.sum(0))[0] * 1e3:.1f} us')
+    w = torch.randn(384, 128, device=DEV)
+    med, _ = timeit(lambda: xx @ w.t())
+    print(f'fwd GEMM [{m}x128]x[128x384]: {med * 1e3:.1f} us -> {2 * m * 128 * 384 / med / 1e9:.1f} TFLOP/s')
+
+
+def bench_unique():
+    pts, coors, info = frame_plan()
+    med, _ = timeit(lambda: K.dynamic_voxelize(pts, bench.VOXEL_SIZE, bench.PC_RANGE), iters=50)
+    print(f'dynamic_voxelize 116k: {med * 1e3:.1f} us -> {24 * 116000 / med / 1e6:.1f} GB/s')
+    med, _ = timeit(lambda: K.unique_rows(coors, [0, -1, -1, -1], [1, 2, 469, 469], invalid_if_negative=2))
+    print(f'unique_rows (incl. host readback): {med * 1e3:.1f} us')
+    vc = info['voxel_coors'].contiguous()
+    w0, c0, w1, c1 = K.window_coors(vc, [468, 468, 1], [12, 12, 1])
+    levels = [(30, 0, 30), (60, 30, 60), (100, 60, 100000)]
+    med, _ = timeit(lambda: K.region_batching(w0, w1, 13, levels))
+    print(f'region_batching: {med * 1e3:.1f} us')
+    layer = sst_amd.SSTInputLayerV2((bench.DROP_TRAIN, bench.DROP_TEST), (12, 12, 1), (468, 468, 1),
+                                    shuffle_voxels=True, mute=True, reference_outputs=False, debug=False)
+    layer.train()
+    feats = torch.randn(vc.size(0), 128, device=DEV)
+    med, _ = timeit(lambda: layer(feats, vc, 1))
+    print(f'SSTInputLayerV2 forward (shuffle, no reference dicts): {med * 1e3:.1f} us')
+
+
+def bench_gemm():
+    """Alternatives for the tall weight-gradient GEMM dW[out,in] = dY[M,out]^T X[M,in] and for column sums."""
+    from sst_amd.dense import colsum
+    m = 90107
+    for out, inn in ((384, 128), (256, 128), (128, 128), (256, 128), (128, 256)):
+        dy = torch.randn(m, out, device=DEV)
+        x = torch.randn(m, inn, device=DEV)
+        ref = dy.double().t() @ x.double()
+        flops = 2.0 * m * out * inn
+
+        def report(name, fn):
+            med, _ = timeit(fn, iters=15, warmup=3)
+            err = float((fn().double() - ref).abs().max() / ref.abs().max())
+            print(f'  dW[{out}x{inn}] {name:34s} {med * 1e3:7.1f} us  {flops / med / 1e9:6.1f} TF/s  rel.err {err:.1e}')
+
+        report('dy.t() @ x', lambda: dy.t() @ x)
+        report('(x.t() @ dy).t()', lambda: (x.t() @ dy).t())
+        for chunk in (1024, 4096, 8192):
+            s_ = m // chunk
+            body = s_ * chunk
+
+            def splitk(chunk=chunk, s_=s_, body=body):
+                dw = torch.bmm(dy[:body].view(s_, chunk, out).transpose(1, 2), x[:body].view(s_, chunk, inn)).sum(0)
+                return dw + dy[body:].t() @ x[body:]
+
+            def splitk_t(chunk=chunk, s_=s_, body=body):
+                dw = torch.bmm(x[:body].view(s_, chunk, inn).transpose(1, 2), dy[:body].view(s_, chunk, out)).sum(0)
+                return (dw + x[body:].t() @ dy[body:]).t()
+            report(f'bmm split-K chunk {chunk}', splitk)
+            report(f'bmm split-K (x^T dy) chunk {chunk}', splitk_t)
+        dyt = dy.t().contiguous()
+        report('dy^T contiguous @ x (copy excluded)', lambda: dyt @ x)
+    dy = torch.randn(m, 384, device=DEV)
+    ones = torch.ones(m, device=DEV)
+    for name, fn in (('colsum kernel', lambda: colsum(dy)), ('dy.sum(0)', lambda: dy.sum(0)),
+                     ('torch.mv(dy.t(), ones)', lambda: torch.mv(dy.t(), ones)),
+                     ('ones[None] @ dy', lambda: ones[None] @ dy)):
+        med, _ = timeit(fn, iters=15, warmup=3)
+        print(f'  colsum[{m}x384] {name:28s} {med * 1e3:7.1f} us  {m * 384 * 4 / med / 1e6:7.0f} GB/s')
+    # forward-shaped GEMMs
+    x = torch.randn(m, 128, device=DEV)
+    for out in (128, 256, 384):
+        w = torch.randn(out, 128, device=DEV)
+        b = torch.randn(out, device=DEV)
+        med, _ = timeit(lambda: torch.addmm(b, x, w.t()), iters=15, warmup=3)
+        print(f'  fwd addmm [{m}x128]x[128x{out}]: {med * 1e3:7.1f} us  {2.0 * m * 128 * out / med / 1e9:6.1f} TF/s')
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if what in ('sra', 'all'):
+        bench_sra()
+    if what in ('ln', 'all'):
+        bench_ln()
+    if what in ('unique', 'all'):
+        bench_unique()
+    if what in ('gemm',):
+        bench_gemm()
