@@ -256,114 +256,124 @@ __global__ __launch_bounds__(256) void sra_fwd_mfma_k(const float* __restrict__ 
 // rows at the same time, so every 128 B line is fetched once per CU.  Token row ids are held 64 per
 // register and broadcast with ds_bpermute (__shfl).  Q tiles are prefetched one iteration ahead.
 // ------------------------------------------------------------------------------------------------
+// 32-bit element offsets off a uniform base pointer (saddr + voffset addressing, no 64-bit VALU math);
+// the host checks that every tensor spans < 2^31 elements before choosing these kernels.
+__device__ __forceinline__ float4 ldg4(const float* __restrict__ base, uint32_t off) {
+  return *(const float4*)(base + off);
+}
+__device__ __forceinline__ float ldg1(const float* __restrict__ base, uint32_t off) { return base[off]; }
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
 template <int NT>
 __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, const float* __restrict__ K,
-                                                  const float* __restrict__ V, int64_t ldq, int64_t ldk, int64_t ldv,
-                                                  const int32_t* __restrict__ tok, int beg, int t, int nt, int hg,
-                                                  int H, float scale, float* __restrict__ O, int64_t ldo,
+                                                  const float* __restrict__ V, uint32_t ldq, uint32_t ldk,
+                                                  uint32_t ldv, const int32_t* __restrict__ tok, int beg, int t, int nt,
+                                                  int hg, int H, float scale, float* __restrict__ O, uint32_t ldo,
                                                   float* __restrict__ LSE) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kGH + (threadIdx.x >> 6);
-  const int hoff = head * kHD;
+  const uint32_t hoff = head * kHD;
   constexpr int NTK = (NT * 16 + 63) / 64;
+  // token ids, 64 window positions per register; positions past the window repeat its last token so that
+  // every load below is unconditional (padded keys are masked, padded queries are never stored)
   int tk[NTK];
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = p < t ? tok[beg + p] : -1;
+    tk[i] = tok[beg + (p < t ? p : t - 1)];
   }
-  // K row-fragments and V column-fragments of this head for the whole window
   float4 kf[NT];
   float vf[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    kf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) vf[j][r] = 0.f;
     if (j < nt) {
-      const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
-      if (krow >= 0) kf[j] = *(const float4*)(K + (int64_t)krow * ldk + hoff + 4 * g);
+      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      kf[j] = ldg4(K, krow * ldk + hoff + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int vrow = __shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
-        if (vrow >= 0) vf[j][r] = V[(int64_t)vrow * ldv + hoff + c];
+        const uint32_t vrow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
+        vf[j][r] = ldg1(V, vrow * ldv + hoff + c);
       }
+    } else {
+      kf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vf[j][r] = 0.f;
     }
   }
-  auto q_row = [&](int i) -> int {
+  auto q_row = [&](int i) -> uint32_t {
     int sel = tk[0];
 #pragma unroll
     for (int u = 1; u < NTK; ++u) sel = ((i >> 2) == u) ? tk[u] : sel;
-    return __shfl(sel, (i & 3) * 16 + c, 64);
+    return (uint32_t)__shfl(sel, (i & 3) * 16 + c, 64);
   };
-  auto q_load = [&](int qrow) -> float4 {
-    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qrow >= 0) {
-      qf = *(const float4*)(Q + (int64_t)qrow * ldq + hoff + 4 * g);
-      qf.x *= scale;
-      qf.y *= scale;
-      qf.z *= scale;
-      qf.w *= scale;
-    }
-    return qf;
-  };
-  int qrow = q_row(0);
-  float4 qf = q_load(qrow);
+  const float qscale = scale * kLog2e;  // scores in the log2 domain: softmax via v_exp_f32 directly
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  uint32_t qrow = q_row(0);
+  float4 qf = ldg4(Q, qrow * ldq + hoff + 4 * g);
   for (int i = 0; i < nt; ++i) {
-    const int qrow_next = (i + 1 < nt) ? q_row(i + 1) : -1;
-    const float4 qf_next = q_load(qrow_next);  // prefetch
+    const uint32_t qrow_next = q_row(i + 1 < nt ? i + 1 : i);
+    const float4 qf_next = ldg4(Q, qrow_next * ldq + hoff + 4 * g);  // prefetch
+    const float qx = qf.x * qscale, qy = qf.y * qscale, qz = qf.z * qscale, qw = qf.w * qscale;
+    // S^T tiles: st[j][r] = S[query 16i+c][key 16j+4g+r]; k-step major so consecutive MFMAs are independent
     f32x4 st[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      if (j < nt) st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].x, qx, zero4, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      if (j < nt) st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].y, qy, st[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      if (j < nt) st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].z, qz, st[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      if (j < nt) st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].w, qw, st[j], 0, 0, 0);
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (j < nt) {
-        acc = mfma4(kf[j], qf, acc);
+        if (j == nt - 1) {  // only the last tile can hold padded keys
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = (j * 16 + 4 * g + r) < t ? acc[r] : -INFINITY;
-          acc[r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) st[j][r] = (j * 16 + 4 * g + r) < t ? st[j][r] : -INFINITY;
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = -INFINITY;
+        mx = fmaxf(mx, fmaxf(fmaxf(st[j][0], st[j][1]), fmaxf(st[j][2], st[j][3])));
       }
-      st[j] = acc;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pe = __expf(st[j][r] - mx);
-        st[j][r] = pe;
-        sum += pe;
+        for (int r = 0; r < 4; ++r) {
+          const float pe = __builtin_amdgcn_exp2f(st[j][r] - mx);
+          st[j][r] = pe;
+          sum += pe;
+        }
       }
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the MFMA dependent latency
+    // O^T[d][query] += V^T[d][key] P^T[key][query]; one accumulator per k-step -> no dependent back-to-back MFMAs
+    f32x4 o0 = zero4, o1 = zero4, o2 = zero4, o3 = zero4;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if (j < nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (j & 1)
-            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][r], st[j][r], o1, 0, 0, 0);
-          else
-            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][r], st[j][r], o0, 0, 0, 0);
-        }
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][0], st[j][0], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][1], st[j][1], o1, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][2], st[j][2], o2, 0, 0, 0);
+        o3 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][3], st[j][3], o3, 0, 0, 0);
       }
     }
-    if (qrow >= 0) {
-      const float inv = 1.f / sum;
-      const float4 ov = make_float4((o0[0] + o1[0]) * inv, (o0[1] + o1[1]) * inv, (o0[2] + o1[2]) * inv,
-                                    (o0[3] + o1[3]) * inv);
-      *(float4*)(O + (int64_t)qrow * ldo + hoff + 4 * g) = ov;
-      if (g == 0) LSE[(int64_t)qrow * H + head] = mx + __logf(sum);
+    if (i * 16 + c < t) {
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      const float4 ov = make_float4((o0[0] + o1[0] + o2[0] + o3[0]) * inv, (o0[1] + o1[1] + o2[1] + o3[1]) * inv,
+                                    (o0[2] + o1[2] + o2[2] + o3[2]) * inv, (o0[3] + o1[3] + o2[3] + o3[3]) * inv);
+      *(float4*)(O + (qrow * ldo + hoff + 4 * g)) = ov;
+      if (g == 0) LSE[qrow * (uint32_t)H + head] = (mx + __builtin_amdgcn_logf(sum)) * kLn2;
     }
     qrow = qrow_next;
     qf = qf_next;
@@ -385,14 +395,15 @@ __global__ __launch_bounds__(256) void sra_fwd_wave_k(const float* __restrict__ 
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;  // > NTMAX: the generic kernel owns this window
+  const uint32_t q_ld = (uint32_t)ldq, k_ld = (uint32_t)ldk, v_ld = (uint32_t)ldv, o_ld = (uint32_t)ldo;
   if (nt <= 2)
-    sra_fwd_wave_body<2>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+    sra_fwd_wave_body<2>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
   else if (nt <= 4)
-    sra_fwd_wave_body<4>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+    sra_fwd_wave_body<4>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
   else if (nt <= 7 || NTMAX <= 7)
-    sra_fwd_wave_body<(NTMAX < 7 ? NTMAX : 7)>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+    sra_fwd_wave_body<(NTMAX < 7 ? NTMAX : 7)>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
   else
-    sra_fwd_wave_body<NTMAX>(Q, K, V, ldq, ldk, ldv, tok, beg, t, nt, hg, H, scale, O, ldo, LSE);
+    sra_fwd_wave_body<NTMAX>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,181 +549,216 @@ __global__ __launch_bounds__(256) void sra_bwd_mfma_k(
 //                    directly the A operands of dV += P^T dO and dK += dS^T Q, accumulated in registers
 //                    over all query tiles of the window.
 // ------------------------------------------------------------------------------------------------
+// two independent 4-step MFMA chains interleaved (S and dP of one tile pair)
+__device__ __forceinline__ void mfma4x2(const float4 a0, const float4 b0, f32x4& d0, const float4 a1, const float4 b1,
+                                        f32x4& d1) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, z, 0, 0, 0);
+  d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, z, 0, 0, 0);
+  d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, d0, 0, 0, 0);
+  d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, d1, 0, 0, 0);
+  d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, d0, 0, 0, 0);
+  d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, d1, 0, 0, 0);
+  d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, d0, 0, 0, 0);
+  d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, d1, 0, 0, 0);
+}
+
 template <int NT>
 __device__ __forceinline__ void sra_bwd_dq_body(const float* __restrict__ Q, const float* __restrict__ K,
                                                 const float* __restrict__ V, const float* __restrict__ O,
                                                 const float* __restrict__ dO, const float* __restrict__ LSE,
-                                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                                                uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t ldo, uint32_t lddo,
                                                 const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H,
-                                                float scale, float* __restrict__ dQ, int64_t lddq,
+                                                float scale, float* __restrict__ dQ, uint32_t lddq,
                                                 float* __restrict__ Dbuf) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kGH + (threadIdx.x >> 6);
-  const int hoff = head * kHD;
+  const uint32_t hoff = head * kHD;
   constexpr int NTK = (NT * 16 + 63) / 64;
   int tk[NTK];
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = p < t ? tok[beg + p] : -1;
+    tk[i] = tok[beg + (p < t ? p : t - 1)];  // padded positions repeat the last token: loads are unconditional
   }
   float4 kf[NT], vf[NT];
   float kc[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    kf[j] = vf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) kc[j][r] = 0.f;
     if (j < nt) {
-      const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
-      if (krow >= 0) {
-        kf[j] = *(const float4*)(K + (int64_t)krow * ldk + hoff + 4 * g);
-        vf[j] = *(const float4*)(V + (int64_t)krow * ldv + hoff + 4 * g);
-      }
+      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      kf[j] = ldg4(K, krow * ldk + hoff + 4 * g);
+      vf[j] = ldg4(V, krow * ldv + hoff + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int crow = __shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
-        if (crow >= 0) kc[j][r] = K[(int64_t)crow * ldk + hoff + c];
+        const uint32_t crow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
+        kc[j][r] = ldg1(K, crow * ldk + hoff + c);
       }
+    } else {
+      kf[j] = vf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kc[j][r] = 0.f;
     }
   }
-  auto tok_at = [&](int i, int within) -> int {  // token id of window position 16*i + within (within: per lane)
+  auto tok_at = [&](int i, int within) -> uint32_t {  // token id of window position 16*i + within
     int sel = tk[0];
 #pragma unroll
     for (int u = 1; u < NTK; ++u) sel = ((i >> 2) == u) ? tk[u] : sel;
-    return __shfl(sel, (i & 3) * 16 + within, 64);
+    return (uint32_t)__shfl(sel, (i & 3) * 16 + within, 64);
   };
+  const float s2 = scale * kLog2e;
   for (int i = 0; i < nt; ++i) {
-    const int qrow = tok_at(i, c);
-    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), gf = qf, of = qf;
-    float lse = 0.f;
-    if (qrow >= 0) {
-      qf = *(const float4*)(Q + (int64_t)qrow * ldq + hoff + 4 * g);
-      gf = *(const float4*)(dO + (int64_t)qrow * lddo + hoff + 4 * g);
-      of = *(const float4*)(O + (int64_t)qrow * ldo + hoff + 4 * g);
-      lse = LSE[(int64_t)qrow * H + head];
-    }
+    const uint32_t qrow = tok_at(i, c);
+    const float4 qf = ldg4(Q, qrow * ldq + hoff + 4 * g);
+    const float4 gf = ldg4(dO, qrow * lddo + hoff + 4 * g);
+    const float4 of = ldg4(O, qrow * ldo + hoff + 4 * g);
+    const float lse2 = LSE[qrow * (uint32_t)H + head] * kLog2e;
+    const bool q_ok = (i * 16 + c) < t;
     float dd = gf.x * of.x + gf.y * of.y + gf.z * of.z + gf.w * of.w;
     dd += __shfl_xor(dd, 16, 64);
     dd += __shfl_xor(dd, 32, 64);
-    if (qrow >= 0 && g == 0) Dbuf[(int64_t)qrow * H + head] = dd;
-    const bool q_ok = qrow >= 0;
-    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+    if (q_ok && g == 0) Dbuf[qrow * (uint32_t)H + head] = dd;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dq0 = zero4, dq1 = zero4, dq2 = zero4, dq3 = zero4;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if (j < nt) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = mfma4(kf[j], qf, s);    // S^T[key 16j+4g+r][query 16i+c]
-        dp = mfma4(vf[j], gf, dp);  // dP^T, same layout
+        f32x4 s, dp;
+        mfma4x2(kf[j], qf, s, vf[j], gf, dp);  // S^T / dP^T [key 16j+4g+r][query 16i+c]
+        float ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = q_ok && (j * 16 + 4 * g + r) < t;
-          const float pe = ok ? __expf(s[r] * scale - lse) : 0.f;
-          const float ds = pe * (dp[r] - dd) * scale;
-          if (j & 1)
-            dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kc[j][r], dq1, 0, 0, 0);
-          else
-            dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, kc[j][r], dq0, 0, 0, 0);
+          float pe = __builtin_amdgcn_exp2f(fmaf(s[r], s2, -lse2));
+          if (j == nt - 1) pe = (j * 16 + 4 * g + r) < t ? pe : 0.f;  // padded keys
+          ds[r] = pe * (dp[r] - dd) * scale;
         }
+        dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[0], kc[j][0], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[1], kc[j][1], dq1, 0, 0, 0);
+        dq2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[2], kc[j][2], dq2, 0, 0, 0);
+        dq3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[3], kc[j][3], dq3, 0, 0, 0);
       }
     }
-    // D layout: value r = dQ[query 16i + 4g + r][d = c]
+    // D layout: value r = dQ[query 16i + 4g + r][d = c]   (rows of padded queries are never stored)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int orow = tok_at(i, 4 * g + r);
-      if (orow >= 0) dQ[(int64_t)orow * lddq + hoff + c] = dq0[r] + dq1[r];
+      const uint32_t orow = tok_at(i, 4 * g + r);  // cross-lane read: must run with all lanes active
+      if (i * 16 + 4 * g + r < t) dQ[orow * lddq + hoff + c] = (dq0[r] + dq1[r]) + (dq2[r] + dq3[r]);
     }
   }
 }
 
-template <int NT>
+// dK/dV of up to 4 key tiles (j0 .. j0+3) of one head, accumulated over ALL query tiles of the window.
+// Windows with more than 4 key tiles are covered by several workgroups (key tiles are independent), which
+// keeps the accumulators + fragments at 64 VGPRs and the occupancy at 4 waves/SIMD.
+template <int NTW>  // NTW: compile-time bound on the window's tile count (sizes the token-id registers)
 __device__ __forceinline__ void sra_bwd_dkv_body(const float* __restrict__ Q, const float* __restrict__ K,
                                                  const float* __restrict__ V, const float* __restrict__ dO,
                                                  const float* __restrict__ LSE, const float* __restrict__ Dbuf,
-                                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo,
-                                                 const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H,
-                                                 float scale, float* __restrict__ dK, float* __restrict__ dV,
-                                                 int64_t lddk, int64_t lddv) {
+                                                 uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t lddo,
+                                                 const int32_t* __restrict__ tok, int beg, int t, int nt, int j0,
+                                                 int hg, int H, float scale, float* __restrict__ dK,
+                                                 float* __restrict__ dV, uint32_t lddk, uint32_t lddv) {
+  constexpr int NJ = 4;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kGH + (threadIdx.x >> 6);
-  const int hoff = head * kHD;
-  constexpr int NTK = (NT * 16 + 63) / 64;
+  const uint32_t hoff = head * kHD;
+  constexpr int NTK = (NTW * 16 + 63) / 64;
   int tk[NTK];
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = p < t ? tok[beg + p] : -1;
+    tk[i] = tok[beg + (p < t ? p : t - 1)];
   }
-  float4 kf[NT], vf[NT];
-  f32x4 dk[NT], dv[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    kf[j] = vf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    dk[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    dv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (j < nt) {
-      const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
-      if (krow >= 0) {
-        kf[j] = *(const float4*)(K + (int64_t)krow * ldk + hoff + 4 * g);
-        vf[j] = *(const float4*)(V + (int64_t)krow * ldv + hoff + 4 * g);
-      }
-    }
-  }
-  auto tok_at = [&](int i, int within) -> int {
+  auto tok_at = [&](int i, int within) -> uint32_t {
     int sel = tk[0];
 #pragma unroll
     for (int u = 1; u < NTK; ++u) sel = ((i >> 2) == u) ? tk[u] : sel;
-    return __shfl(sel, (i & 3) * 16 + within, 64);
+    return (uint32_t)__shfl(sel, (i & 3) * 16 + within, 64);
   };
+  const int nj = (nt - j0) < NJ ? (nt - j0) : NJ;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float4 kf[NJ], vf[NJ];
+  f32x4 dk[NJ], dv[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    dk[jj] = zero4;
+    dv[jj] = zero4;
+    if (jj < nj) {
+      const uint32_t krow = tok_at(j0 + jj, c);
+      kf[jj] = ldg4(K, krow * ldk + hoff + 4 * g);
+      vf[jj] = ldg4(V, krow * ldv + hoff + 4 * g);
+    } else {
+      kf[jj] = vf[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float s2 = scale * kLog2e;
+  // operands of one query tile: row fragments for query 16i+c, column fragments for queries 16i+4g+r;
+  // LSE / D are loaded once per query (lane c) and redistributed with cross-lane reads
+  struct qtile {
+    float4 qf, gf;
+    float qc[4], gc[4];
+    float lse_c, dd_c;
+  };
+  auto load_tile = [&](int i) -> qtile {
+    qtile q;
+    const uint32_t arow = tok_at(i, c);
+    q.qf = ldg4(Q, arow * ldq + hoff + 4 * g);
+    q.gf = ldg4(dO, arow * lddo + hoff + 4 * g);
+    q.lse_c = LSE[arow * (uint32_t)H + head];
+    q.dd_c = Dbuf[arow * (uint32_t)H + head];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t crow = tok_at(i, 4 * g + r);
+      q.qc[r] = ldg1(Q, crow * ldq + hoff + c);
+      q.gc[r] = ldg1(dO, crow * lddo + hoff + c);
+    }
+    return q;
+  };
+  qtile cur = load_tile(0);
   for (int i = 0; i < nt; ++i) {
-    const int arow = tok_at(i, c);  // row-fragment row: query 16i + c
-    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), gf = qf;
-    if (arow >= 0) {
-      qf = *(const float4*)(Q + (int64_t)arow * ldq + hoff + 4 * g);
-      gf = *(const float4*)(dO + (int64_t)arow * lddo + hoff + 4 * g);
-    }
-    float qc[4], gc[4], lse4[4], dd4[4];
-    bool qok[4];
+    const qtile nxt = load_tile(i + 1 < nt ? i + 1 : i);  // software prefetch of the next query tile
+    const float4 qf = cur.qf, gf = cur.gf;
+    float qc[4], gc[4], lse2[4], dd4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {  // column-fragment rows: queries 16i + 4g + r
-      const int crow = tok_at(i, 4 * g + r);
-      qok[r] = crow >= 0;
-      qc[r] = gc[r] = lse4[r] = dd4[r] = 0.f;
-      if (crow >= 0) {
-        qc[r] = Q[(int64_t)crow * ldq + hoff + c];
-        gc[r] = dO[(int64_t)crow * lddo + hoff + c];
-        lse4[r] = LSE[(int64_t)crow * H + head];
-        dd4[r] = Dbuf[(int64_t)crow * H + head];
-      }
+    for (int r = 0; r < 4; ++r) {
+      qc[r] = cur.qc[r];
+      gc[r] = cur.gc[r];
+      lse2[r] = __shfl(cur.lse_c, 4 * g + r, 64) * kLog2e;  // lane 4g+r holds query 16i+4g+r
+      dd4[r] = __shfl(cur.dd_c, 4 * g + r, 64);
     }
+    const bool last_q = (i == nt - 1);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (j < nt) {
-        const bool key_ok = (j * 16 + c) < t;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = mfma4(qf, kf[j], s);    // S[query 16i+4g+r][key 16j+c]
-        dp = mfma4(gf, vf[j], dp);  // dP, same layout
+    for (int jj = 0; jj < NJ; ++jj) {
+      if (jj < nj) {
+        f32x4 s, dp;
+        mfma4x2(qf, kf[jj], s, gf, vf[jj], dp);  // S / dP [query 16i+4g+r][key 16(j0+jj)+c]
+        float pe[4], ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = key_ok && qok[r];
-          const float pe = ok ? __expf(s[r] * scale - lse4[r]) : 0.f;
-          const float ds = pe * (dp[r] - dd4[r]) * scale;
-          dv[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pe, gc[r], dv[j], 0, 0, 0);  // dV[key c][d] += P^T dO
-          dk[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, qc[r], dk[j], 0, 0, 0);  // dK[key c][d] += dS^T Q
+          pe[r] = __builtin_amdgcn_exp2f(fmaf(s[r], s2, -lse2[r]));
+          if (last_q) pe[r] = (i * 16 + 4 * g + r) < t ? pe[r] : 0.f;           // padded queries
+          if (j0 + jj == nt - 1) pe[r] = ((j0 + jj) * 16 + c) < t ? pe[r] : 0.f;  // padded keys
+          ds[r] = pe[r] * (dp[r] - dd4[r]) * scale;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dv[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(pe[r], gc[r], dv[jj], 0, 0, 0);  // dV += P^T dO
+          dk[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], qc[r], dk[jj], 0, 0, 0);  // dK += dS^T Q
         }
       }
     }
+    cur = nxt;
   }
-  // D layout: value r = d{K,V}[key 16j + 4g + r][d = c]
+  // D layout: value r = d{K,V}[key 16(j0+jj) + 4g + r][d = c]
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    if (j < nt) {
+  for (int jj = 0; jj < NJ; ++jj) {
+    if (jj < nj) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int krow = __shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
-        if (krow >= 0) {
-          dK[(int64_t)krow * lddk + hoff + c] = dk[j][r];
-          dV[(int64_t)krow * lddv + hoff + c] = dv[j][r];
+        const uint32_t krow = tok_at(j0 + jj, 4 * g + r);  // cross-lane read: all lanes active
+        if ((j0 + jj) * 16 + 4 * g + r < t) {
+          dK[krow * lddk + hoff + c] = dk[jj][r];
+          dV[krow * lddv + hoff + c] = dv[jj][r];
         }
       }
     }
@@ -734,7 +780,7 @@ __global__ __launch_bounds__(256) void sra_bwd_dq_k(const float* __restrict__ Q,
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;
-#define SST_DQ_ARGS Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo, tok, beg, t, nt, hg, H, scale, dQ, lddq, Dbuf
+#define SST_DQ_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, (uint32_t)lddq, Dbuf
   if (nt <= 2)
     sra_bwd_dq_body<2>(SST_DQ_ARGS);
   else if (nt <= 4)
@@ -755,19 +801,18 @@ __global__ __launch_bounds__(256) void sra_bwd_dkv_k(const float* __restrict__ Q
                                                      const int32_t* __restrict__ winoff, int n_groups, int H,
                                                      float scale, float* __restrict__ dK, float* __restrict__ dV,
                                                      int64_t lddk, int64_t lddv) {
-  const int w = blockIdx.x / n_groups;
-  const int hg = blockIdx.x - w * n_groups;
+  constexpr int KSPLIT = (NTMAX + 3) / 4;  // workgroups per (window, head group): 4 key tiles each
+  const int ks = blockIdx.x % KSPLIT;
+  const int rest = blockIdx.x / KSPLIT;
+  const int w = rest / n_groups;
+  const int hg = rest - w * n_groups;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
-  if (nt < 1 || nt > NTMAX) return;
-#define SST_DKV_ARGS Q, K, V, dO, LSE, Dbuf, ldq, ldk, ldv, lddo, tok, beg, t, nt, hg, H, scale, dK, dV, lddk, lddv
-  if (nt <= 2)
-    sra_bwd_dkv_body<2>(SST_DKV_ARGS);
-  else if (nt <= 4)
+  if (nt < 1 || nt > NTMAX || ks * 4 >= nt) return;
+#define SST_DKV_ARGS Q, K, V, dO, LSE, Dbuf, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)lddo, tok, beg, t, nt, ks * 4, hg, H, scale, dK, dV, (uint32_t)lddk, (uint32_t)lddv
+  if (nt <= 4)
     sra_bwd_dkv_body<4>(SST_DKV_ARGS);
-  else if (nt <= 7 || NTMAX <= 7)
-    sra_bwd_dkv_body<(NTMAX < 7 ? NTMAX : 7)>(SST_DKV_ARGS);
   else
     sra_bwd_dkv_body<NTMAX>(SST_DKV_ARGS);
 #undef SST_DKV_ARGS
@@ -782,7 +827,8 @@ int launch_bwd_wave(const float* Q, const float* K, const float* V, const float*
   const dim3 grid((unsigned)(n_windows * n_groups));
   hipLaunchKernelGGL(sra_bwd_dq_k<NTMAX>, grid, dim3(256), 0, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo, tok,
                      winoff, n_groups, H, scale, dQ, lddq, Dbuf);
-  hipLaunchKernelGGL(sra_bwd_dkv_k<NTMAX>, grid, dim3(256), 0, st, Q, K, V, dO, LSE, Dbuf, ldq, ldk, ldv, lddo, tok,
+  const dim3 grid_kv((unsigned)(n_windows * n_groups * ((NTMAX + 3) / 4)));
+  hipLaunchKernelGGL(sra_bwd_dkv_k<NTMAX>, grid_kv, dim3(256), 0, st, Q, K, V, dO, LSE, Dbuf, ldq, ldk, ldv, lddo, tok,
                      winoff, n_groups, H, scale, dK, dV, lddk, lddv);
   return SST_OK;
 }
@@ -839,6 +885,7 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
   hipStream_t st = (hipStream_t)stream;
   const bool mfma_ok = (n_heads % kGH == 0) && ((ldq | ldk | ldv | ldo) % 4 == 0) && aligned16(d_q) &&
                        aligned16(d_k) && aligned16(d_v) && aligned16(d_o);
+  // (the register-resident kernels use 32-bit element offsets: callers keep n_tokens * ld < 2^31)
   if (impl == 1 || !mfma_ok) {
     hipLaunchKernelGGL(sra_fwd_generic_k, dim3((unsigned)n_windows), dim3(256), 0, st, d_q, d_k, d_v, ldq, ldk, ldv,
                        d_tok, d_winoff, n_heads, scale, 0, d_o, ldo, d_lse);
