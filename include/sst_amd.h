@@ -236,6 +236,16 @@ int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float
 int64_t sst_colsum_workspace_bytes(int64_t m, int c);
 int sst_colsum_f32(const float* d_x, int64_t m, int c, int64_t ld, float* d_out, void* d_workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Weight / bias gradient of a tall linear layer y = x W^T + b (projections and FFN of an encoder layer,
+ * models/sst/sst_basic_block_v2.py:104-126; VFE / SIR linears): dW[out,in] = dY[M,out]^T X[M,in] as a
+ * split-K fp32 MFMA kernel, d_db[out] = column sums of dY (optional, NULL to skip).  out, in multiples of 32.
+ * Row strides ld_dy / ld_x in elements.  Workspace: sst_weight_grad_workspace_bytes(m, out, in).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in);
+int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out, int in, int64_t ld_dy,
+                        int64_t ld_x, float* d_dw, float* d_db, void* d_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

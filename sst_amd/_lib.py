@@ -55,6 +55,8 @@ _SIGNATURES = {
     'sst_add_layernorm_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_add_layernorm_bwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                           c_ptr]),
+    'sst_weight_grad_workspace_bytes': (c_i64, [c_i64, c_i32, c_i32]),
+    'sst_weight_grad_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_colsum_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_colsum_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr]),
 }

@@ -87,6 +87,12 @@ class SSTv2(nn.Module):
             for enc in block.encoder_list:
                 enc.win_attn.impl = impl
 
+    def set_fused(self, fused):
+        """True (default): each encoder layer is one autograd node; False: modular path (same arithmetic)."""
+        for block in self.block_list:
+            for enc in block.encoder_list:
+                enc.fused = fused
+
     def forward(self, voxel_info):
         num_shifts = 2
         assert voxel_info['voxel_coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'

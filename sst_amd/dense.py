@@ -40,6 +40,37 @@ def weight_grad_splitk(dy, x, chunk=1024):
     return dw
 
 
+def weight_bias_grad(dy, x, want_bias, out_w=None, out_b=None):
+    """(dW, db) of y = x W^T + b for tall dy [M, out], x [M, in] through the split-K MFMA kernel
+    (csrc/wgrad.hip); shapes it is not built for go through the batched library GEMM.
+    out_w / out_b: optional contiguous destinations (e.g. row slices of a packed in_proj gradient)."""
+    m, out = dy.shape
+    inn = x.size(1)
+    ok = (out % 32 == 0 and inn % 32 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and m >= 4096
+          and dy.dtype == torch.float32 and x.dtype == torch.float32)
+    if not ok:
+        dw = weight_grad_splitk(dy, x.contiguous())
+        db = colsum(dy) if want_bias else None
+        if out_w is not None:
+            out_w.copy_(dw)
+            dw = out_w
+        if out_b is not None and db is not None:
+            out_b.copy_(db)
+            db = out_b
+        return dw, db
+    lib = _lib.load()
+    dw = out_w if out_w is not None else torch.empty((out, inn), dtype=torch.float32, device=dy.device)
+    db = None
+    if want_bias:
+        db = out_b if out_b is not None else torch.empty(out, dtype=torch.float32, device=dy.device)
+    assert dw.is_contiguous() and (db is None or db.is_contiguous())
+    ws = _lib.workspace(lib.sst_weight_grad_workspace_bytes(m, out, inn), dy.device)
+    rc = lib.sst_weight_grad_f32(_lib.ptr(dy), _lib.ptr(x), m, out, inn, dy.stride(0), x.stride(0), _lib.ptr(dw),
+                                 _lib.ptr(db), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, 'sst_weight_grad_f32')
+    return dw, db
+
+
 class TallLinear(Function):
 
     @staticmethod
@@ -57,9 +88,10 @@ class TallLinear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = dy @ weight
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = weight_grad_splitk(dy, x.contiguous())
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw, db = weight_bias_grad(dy, x, want_b)
+        elif want_b:
             db = colsum(dy)
         return dx, dw, db
 
@@ -70,23 +102,43 @@ def tall_linear(x, weight, bias=None):
     return TallLinear.apply(x, weight, bias)
 
 
+def add_ln_fwd(x, res, weight, bias, eps):
+    """-> (y, s, stats) with s = x + res (== x when res is None), stats [M,2] = (mean, rstd)."""
+    x = x.contiguous()
+    m, c = x.shape
+    if res is not None:
+        res = res.contiguous()
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if res is not None else x
+    stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
+    rc = _lib.load().sst_add_layernorm_fwd_f32(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), m, c,
+                                               float(eps), _lib.ptr(y), _lib.ptr(s) if res is not None else None,
+                                               _lib.ptr(stats), _lib.stream_ptr())
+    _lib.check(rc, 'sst_add_layernorm_fwd_f32')
+    return y, s, stats
+
+
+def add_ln_bwd(dy, s, stats, weight):
+    """-> (d(x + res), dweight, dbias)."""
+    dy = dy.contiguous()
+    m, c = s.shape
+    dx = torch.empty_like(s)
+    dw = torch.empty(c, dtype=torch.float32, device=s.device)
+    db = torch.empty(c, dtype=torch.float32, device=s.device)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_add_layernorm_bwd_workspace_bytes(m, c), s.device)
+    rc = lib.sst_add_layernorm_bwd_f32(_lib.ptr(dy), _lib.ptr(s), _lib.ptr(stats), _lib.ptr(weight), m, c,
+                                       _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, 'sst_add_layernorm_bwd_f32')
+    return dx, dw, db
+
+
 class AddLayerNorm(Function):
     """y = LayerNorm(x + res); the gradient w.r.t. x and res is the same tensor."""
 
     @staticmethod
     def forward(ctx, x, res, weight, bias, eps):
-        x = x.contiguous()
-        m, c = x.shape
-        if res is not None:
-            res = res.contiguous()
-        y = torch.empty_like(x)
-        need_sum = res is not None
-        s = torch.empty_like(x) if need_sum else x
-        stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
-        rc = _lib.load().sst_add_layernorm_fwd_f32(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), m, c,
-                                                   float(eps), _lib.ptr(y), _lib.ptr(s) if need_sum else None,
-                                                   _lib.ptr(stats), _lib.stream_ptr())
-        _lib.check(rc, 'sst_add_layernorm_fwd_f32')
+        y, s, stats = add_ln_fwd(x, res, weight, bias, eps)
         ctx.save_for_backward(s, stats, weight)
         ctx.has_res = res is not None
         return y
@@ -94,16 +146,7 @@ class AddLayerNorm(Function):
     @staticmethod
     def backward(ctx, dy):
         s, stats, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        m, c = s.shape
-        dx = torch.empty_like(s)
-        dw = torch.empty(c, dtype=torch.float32, device=s.device)
-        db = torch.empty(c, dtype=torch.float32, device=s.device)
-        lib = _lib.load()
-        ws = _lib.workspace(lib.sst_add_layernorm_bwd_workspace_bytes(m, c), s.device)
-        rc = lib.sst_add_layernorm_bwd_f32(_lib.ptr(dy), _lib.ptr(s), _lib.ptr(stats), _lib.ptr(weight), m, c,
-                                           _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream_ptr())
-        _lib.check(rc, 'sst_add_layernorm_bwd_f32')
+        dx, dw, db = add_ln_bwd(dy, s, stats, weight)
         return dx, (dx if ctx.has_res else None), dw, db, None
 
 

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
-from .dense import add_layer_norm, tall_linear
+from .dense import add_layer_norm, add_ln_bwd, add_ln_fwd, tall_linear, weight_bias_grad
 from .norm import build_norm_layer
 
 
@@ -130,6 +130,63 @@ class WindowAttention(nn.Module):
         return tall_linear(o, attn.out_proj.weight, attn.out_proj.bias)
 
 
+class FusedEncoderLayerFn(torch.autograd.Function):
+    """One post-norm SRA encoder layer (sst_basic_block_v2.py:104-119) as a single autograd node.
+
+    Same arithmetic as the modular path (WindowAttention -> add+LN -> FFN -> add+LN), but the backward is
+    written out so that every gradient accumulation rides on a GEMM's beta = 1 (``addmm``) instead of separate
+    [M, C] add kernels, and weight + bias gradients come from the split-K MFMA kernel in one pass.
+    """
+
+    @staticmethod
+    def forward(ctx, x, pos, plan, nhead, impl, act, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps):
+        c = x.size(1)
+        x = x.contiguous()
+        xp = x + pos if pos is not None else x
+        qk = torch.addmm(b_in[:2 * c], xp, w_in[:2 * c].t())
+        v = torch.addmm(b_in[2 * c:], x, w_in[2 * c:].t())
+        scale = 1.0 / math.sqrt(16.0)
+        o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
+        a = torch.addmm(b_out, o, w_out.t())
+        y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps)
+        pre = torch.addmm(b1, y1, w1.t())
+        h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
+        f = torch.addmm(b2, h, w2.t())
+        y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps)
+        ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
+        ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
+        c = x.size(1)
+        ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w)               # = d(y1 residual) = d(f)
+        dw2, db2 = weight_bias_grad(ds2, h, True)
+        dh = ds2 @ w2
+        if ctx.act == 'gelu':
+            dpre = torch.ops.aten.gelu_backward(dh, pre)
+        else:
+            dpre = dh * (pre > 0).to(dh.dtype)
+        dw1, db1 = weight_bias_grad(dpre, y1, True)
+        dy1 = ds2.addmm_(dpre, w1)                                    # residual + FFN branch: GEMM with beta = 1
+        ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
+        dwo, dbo = weight_bias_grad(ds1, o, True)
+        do = ds1 @ w_out
+        dqk = torch.empty_like(qk)
+        dv = torch.empty_like(v)
+        K._sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, ctx.impl, dqk[:, :c],
+                   dqk[:, c:], dv)
+        dw_in = torch.empty_like(w_in)
+        db_in = torch.empty(3 * c, dtype=torch.float32, device=x.device)
+        weight_bias_grad(dqk, xp, True, out_w=dw_in[:2 * c], out_b=db_in[:2 * c])
+        weight_bias_grad(dv, x, True, out_w=dw_in[2 * c:], out_b=db_in[2 * c:])
+        dx = ds1.addmm_(dqk, w_in[:2 * c])                            # residual + q,k branch (in place)
+        dx.addmm_(dv, w_in[2 * c:])                                   # + v branch
+        return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
+                None)
+
+
 class EncoderLayer(nn.Module):
 
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
@@ -151,6 +208,8 @@ class EncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(mlp_dropout)
         self.dropout2 = nn.Dropout(mlp_dropout)
         self.activation = _get_activation_fn(activation)
+        self.act_name = activation
+        self.fused = True   # single-node forward/backward (FusedEncoderLayerFn) when the configuration allows
         self.post_norm = layer_cfg.get('post_norm', True)
         self.fp16_enabled = False
 
@@ -158,7 +217,24 @@ class EncoderLayer(nn.Module):
         h = self.activation(tall_linear(x, self.linear1.weight, self.linear1.bias))
         return tall_linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
 
+    def _can_fuse(self, src, pos_dict, ind_dict):
+        wa = self.win_attn
+        return (self.fused and self.post_norm and isinstance(ind_dict, K.WindowPlan)
+                and ind_dict.n_tokens == src.size(0)
+                and (pos_dict is None or torch.is_tensor(pos_dict)) and not wa.cosine
+                and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
+                and self.act_name in ('gelu', 'relu') and src.dtype == torch.float32 and src.is_cuda
+                and src.size(1) % 32 == 0 and self.linear1.out_features % 32 == 0
+                and not (self.training and (wa.attn_dropout > 0 or self.dropout.p > 0 or self.dropout1.p > 0)))
+
     def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict=None):
+        if self._can_fuse(src, pos_dict, ind_dict):
+            attn = self.win_attn.self_attn
+            return FusedEncoderLayerFn.apply(
+                src, pos_dict, ind_dict, self.win_attn.nhead, self.win_attn.impl, self.act_name, attn.in_proj_weight,
+                attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, self.linear1.weight, self.linear1.bias,
+                self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias, self.norm2.weight,
+                self.norm2.bias, self.norm1.eps)
         if self.post_norm:
             src2 = self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)  # [N, d_model]
             src = add_layer_norm(src, self.dropout1(src2), self.norm1)     # norm1(src + src2), one kernel

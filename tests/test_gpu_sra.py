@@ -113,15 +113,17 @@ def _load_block(g, layer_cfg):
     return net.to(DEV).train(), d
 
 
+@pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('impl', [0, 1])
 @pytest.mark.parametrize('tag,layer_cfg', [('std', dict()), ('cosine', dict(cosine=True, tau_min=0.01)),
                                            ('cosine_ns', dict(cosine=True, tau_min=0.01, non_shared_tau=True)),
                                            ('prenorm', dict(post_norm=False))])
-def test_sst_block_matches_reference_golden(tag, layer_cfg, impl):
+def test_sst_block_matches_reference_golden(tag, layer_cfg, impl, fused):
     import sst_amd
     g = load_golden(f'sst_block_{tag}.npz')
     net, d = _load_block(g, layer_cfg)
     net.set_impl(impl)
+    net.set_fused(fused)
     layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
                                     debug=True, mute=True)
     layer.eval()

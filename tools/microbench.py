@@ -145,8 +145,8 @@ def bench_gemm():
                 return (dw + x[body:].t() @ dy[body:]).t()
             report(f'bmm split-K chunk {chunk}', splitk)
             report(f'bmm split-K (x^T dy) chunk {chunk}', splitk_t)
-        dyt = dy.t().contiguous()
-        report('dy^T contiguous @ x (copy excluded)', lambda: dyt @ x)
+        from sst_amd.dense import weight_bias_grad
+        report('wgrad kernel (+ bias grad)', lambda: weight_bias_grad(dy, x, True)[0])
     dy = torch.randn(m, 384, device=DEV)
     ones = torch.ones(m, device=DEV)
     for name, fn in (('colsum kernel', lambda: colsum(dy)), ('dy.sum(0)', lambda: dy.sum(0)),
