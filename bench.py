@@ -109,6 +109,8 @@ def main():
     ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
+    ap.add_argument('--no-gemm-tuning', action='store_true',
+                    help='do not let PyTorch TunableOp pick the hipBLASLt/rocBLAS solution of each dense GEMM shape')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -123,6 +125,18 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from sst_amd import kernels as K
+    if not args.no_gemm_tuning:
+        # the dense projections / FFN are library GEMMs (plumbing): let TunableOp choose the fastest
+        # hipBLASLt / rocBLAS solution per shape during warm-up (seeded from the committed results file)
+        import shutil
+        import torch.cuda.tunable as tunable
+        seed_file = os.path.join(ROOT, 'sst_amd', 'tunableop_gfx950_fp32.csv')
+        work_file = f'/tmp/sst_amd_tunableop_rank{rank}.csv'
+        if os.path.exists(seed_file):
+            shutil.copyfile(seed_file, work_file)
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_filename(work_file)
     torch.manual_seed(0)                      # identical initial weights on every rank
     model = Pipeline(args.blocks).to(dev)
     model.train()
@@ -198,6 +212,7 @@ def main():
             'value': round(total_frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'gemm_tuning': 'off' if args.no_gemm_tuning else 'torch TunableOp (hipBLASLt/rocBLAS solution per shape)',
             'config': {'workload': 'SST-base Waymo single-frame, 0.32 m voxel: uniform synthetic cloud '
                                    f'{args.points} points/frame -> {n_voxels // args.frames_per_gpu} non-empty '
                                    'voxels/frame; dynamic voxelize + DynamicVFE + SSTInputLayerV2 + '
