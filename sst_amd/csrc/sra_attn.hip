@@ -825,9 +825,12 @@ __global__ __launch_bounds__(256) void sra_bwd_dkv_k(const float* __restrict__ Q
                                                      const int32_t* __restrict__ winoff, int n_groups, int H,
                                                      float scale, float* __restrict__ dK, float* __restrict__ dV,
                                                      int64_t lddk, int64_t lddv) {
-  constexpr int KSPLIT = (NTMAX + 3) / 4;  // workgroups per (window, head group): 4 key tiles each
-  const int ks = blockIdx.x % KSPLIT;
-  const int rest = blockIdx.x / KSPLIT;
+  // workgroups per (window, head group): 4 key tiles each.  The key-group index is the SLOWEST block
+  // coordinate: block b runs on XCD b % 8, and most windows only have key group 0, so a fastest-varying ks
+  // would park all the real work on the even XCDs (measured: 1.36 waves/SIMD average, 169 us).
+  const int per_ks = gridDim.x / ((NTMAX + 3) / 4);
+  const int ks = blockIdx.x / per_ks;
+  const int rest = blockIdx.x - ks * per_ks;
   const int w = rest / n_groups;
   const int hg = rest - w * n_groups;
   const int beg = winoff[w];

@@ -17,31 +17,49 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ __forceinline__ int64_t sst_dev_align_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
 constexpr int kWgTileO = 128, kWgTileI = 64;
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-template <int U>  // k-steps (of 2 rows) per unrolled group
-__global__ __launch_bounds__(256) void wgrad_k(const float* __restrict__ dy, const float* __restrict__ x, int64_t m,
+template <int U, int KW>  // U: k-steps (of 2 rows) per unrolled group; KW: K-slices inside one workgroup
+__global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy, const float* __restrict__ x, int64_t m,
                                                int out, int in, int64_t ld_dy, int64_t ld_x, int64_t rows_per_split,
                                                float* __restrict__ part_w, float* __restrict__ part_b) {
   const int o_tiles = (out + kWgTileO - 1) / kWgTileO;
   const int i_tiles = (in + kWgTileI - 1) / kWgTileI;
   const int tiles = o_tiles * i_tiles;
-  const int s = blockIdx.x / tiles;
-  const int tt = blockIdx.x - s * tiles;
+  // XCD-aware mapping: workgroup b runs on XCD b % 8 (8 XCDs, private L2s).  All tiles of one K-slice read the
+  // same rows of dY / X, so they are given block ids that are congruent mod 8: the slice is fetched from HBM
+  // once and the other tiles hit in that XCD's L2.  (gridDim.x = nsplit8 * tiles, nsplit8 a multiple of 8.)
+  const int xcd = blockIdx.x & 7;
+  const int rest = blockIdx.x >> 3;
+  const int tt = rest % tiles;
+  const int s = (rest / tiles) * 8 + xcd;
   const int ot = tt / i_tiles, it = tt - ot * i_tiles;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // 4*KW waves: wave = kw*4 + tile-wave.  The KW wave groups split this workgroup's K range (more waves per
+  // SIMD to hide the HBM latency of the fragment loads without multiplying the split-K partials); their
+  // accumulators are combined through LDS at the end.
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [(KW-1)][4 waves][34 values][64 lanes]
+  const int wave_all = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kw = wave_all >> 2, wave = wave_all & 3;
   const int wo = wave >> 1, wi = wave & 1;
   const int o0 = ot * kWgTileO + wo * 64;
   const int i0 = it * kWgTileI + wi * 32;
-  if (o0 >= out || i0 >= in) return;  // no barriers in this kernel: waves may leave independently
+  const bool active = (o0 < out) && (i0 < in);  // inactive waves still reach the barrier; empty K slices write zeros
   const bool has_o1 = (o0 + 32) < out;
   const int col = lane & 31, kk = lane >> 5;
-  const int64_t k0 = (int64_t)s * rows_per_split;
-  const int64_t k1 = k0 + rows_per_split < m ? k0 + rows_per_split : m;
+  const int64_t ks0 = (int64_t)s * rows_per_split < m ? (int64_t)s * rows_per_split : m;
+  const int64_t ks1 = ks0 + rows_per_split < m ? ks0 + rows_per_split : m;
+  // this wave group's slice of [ks0, ks1), boundaries on multiples of 2*U rows
+  const int64_t per = sst_dev_align_up((ks1 - ks0 + KW - 1) / KW, 2 * U);
+  int64_t k0 = ks0 + (int64_t)kw * per;
+  int64_t k1 = k0 + per < ks1 ? k0 + per : ks1;
+  if (k0 > ks1) k0 = ks1;
+  if (!active) k1 = k0;
 
   f32x16 acc0, acc1;
 #pragma unroll
@@ -97,6 +115,33 @@ __global__ __launch_bounds__(256) void wgrad_k(const float* __restrict__ dy, con
     pa += 2 * ld_dy;
     pb += 2 * ld_x;
   }
+  if (KW > 1) {  // combine the K-slices of this workgroup: groups 1.. hand their accumulators to group 0
+    if (kw > 0) {
+      float* dst = red + ((size_t)((kw - 1) * 4 + wave) * 34) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dst[r * 64] = acc0[r];
+        dst[(16 + r) * 64] = acc1[r];
+      }
+      dst[32 * 64] = bs0;
+      dst[33 * 64] = bs1;
+    }
+    __syncthreads();
+    if (kw > 0 || !active) return;
+#pragma unroll
+    for (int g2 = 1; g2 < KW; ++g2) {
+      const float* src = red + ((size_t)((g2 - 1) * 4 + wave) * 34) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] += src[r * 64];
+        acc1[r] += src[(16 + r) * 64];
+      }
+      bs0 += src[32 * 64];
+      bs1 += src[33 * 64];
+    }
+  } else if (!active) {
+    return;
+  }
   // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int64_t pstride = (int64_t)out * in + (part_b != nullptr ? out : 0);  // per-split record: [dW | db]
   float* pw = part_w + (int64_t)s * pstride;
@@ -116,26 +161,192 @@ __global__ __launch_bounds__(256) void wgrad_k(const float* __restrict__ dy, con
   }
 }
 
-// record e of every split summed: e < n_w -> dw[e], else db[e - n_w]
+// ------------------------------------------------------------------------------------------------
+// Wide variant (out % 128 == 0, in % 64 == 0, out/128 * in/64 <= 4): ONE workgroup covers the whole dW for its
+// K-slice, so every row of dY and X is read exactly once from L2 (the narrow kernel above re-reads X per
+// out-tile and dY per in-tile and is bound by L2->L1 traffic at ~10 flop/B).  A wave owns a 128(out) x 64(in)
+// tile = 4 x 2 MFMA tiles with INTERLEAVED columns: lane l loads dY[row][4*(l&31) .. +3] as one float4 and
+// X[row][2*(l&31) .. +1] as one float2; component q of the float4 feeds MFMA tile q, whose row i = l&31
+// therefore means output row 4*i + q (and column 2*j + p for the X tiles).  2 wide loads feed 8 MFMAs.
+// Waves not needed to cover the output split the K range (KW groups), combined through LDS.
+// ------------------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy, const float* __restrict__ x,
+                                                    int64_t m, int out, int in, int64_t ld_dy, int64_t ld_x,
+                                                    int64_t rows_per_split, float* __restrict__ part_w,
+                                                    float* __restrict__ part_b) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [(KW-1) * ntile][130 values][64 lanes]
+  const int o_w = out / 128, i_w = in / 64;  // wave tiles along out / in
+  const int ntile = o_w * i_w;               // 1, 2 or 4
+  const int kwn = 4 / ntile;                 // K groups inside the workgroup
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kw = wave / ntile, tw = wave - kw * ntile;
+  const int ow = tw / i_w, iw = tw - ow * i_w;
+  const int o0 = ow * 128, i0 = iw * 64;
+  const int col = lane & 31, kk = lane >> 5;
+  const int s = blockIdx.x;
+  const int64_t ks0 = (int64_t)s * rows_per_split < m ? (int64_t)s * rows_per_split : m;
+  const int64_t ks1 = ks0 + rows_per_split < m ? ks0 + rows_per_split : m;
+  const int64_t per = sst_dev_align_up((ks1 - ks0 + kwn - 1) / kwn, 2 * U);
+  int64_t k0 = ks0 + (int64_t)kw * per;
+  if (k0 > ks1) k0 = ks1;
+  const int64_t k1 = k0 + per < ks1 ? k0 + per : ks1;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][p][r] = 0.f;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* pa = dy + (k0 + kk) * ld_dy + o0 + 4 * col;
+  const float* pb = x + (k0 + kk) * ld_x + i0 + 2 * col;
+
+  auto load = [&](float4 (&a)[U], float2 (&b)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = *(const float4*)(pa + (int64_t)u * 2 * ld_dy);
+      b[u] = *(const float2*)(pb + (int64_t)u * 2 * ld_x);
+    }
+    pa += (int64_t)2 * U * ld_dy;
+    pb += (int64_t)2 * U * ld_x;
+  };
+  auto comp = [&](const float4 (&a)[U], const float2 (&b)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0][0] = mfma32(a[u].x, b[u].x, acc[0][0]);
+      acc[1][0] = mfma32(a[u].y, b[u].x, acc[1][0]);
+      acc[2][0] = mfma32(a[u].z, b[u].x, acc[2][0]);
+      acc[3][0] = mfma32(a[u].w, b[u].x, acc[3][0]);
+      acc[0][1] = mfma32(a[u].x, b[u].y, acc[0][1]);
+      acc[1][1] = mfma32(a[u].y, b[u].y, acc[1][1]);
+      acc[2][1] = mfma32(a[u].z, b[u].y, acc[2][1]);
+      acc[3][1] = mfma32(a[u].w, b[u].y, acc[3][1]);
+      bsum.x += a[u].x;
+      bsum.y += a[u].y;
+      bsum.z += a[u].z;
+      bsum.w += a[u].w;
+    }
+  };
+  const int64_t ng = (k1 - k0) / (2 * U);
+  float4 A0[U], C0[U];
+  float2 B0[U], D0[U];
+  if (ng > 0) load(A0, B0);
+  int64_t gi = 0;
+  while (gi < ng) {
+    bool more = gi + 1 < ng;
+    if (more) load(C0, D0);
+    comp(A0, B0);
+    ++gi;
+    if (!more) break;
+    more = gi + 1 < ng;
+    if (more) load(A0, B0);
+    comp(C0, D0);
+    ++gi;
+  }
+  for (int64_t k = k0 + ng * 2 * U; k < k1; k += 2) {  // ragged tail, row-guarded
+    const bool ok = (k + kk) < k1;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 b = make_float2(0.f, 0.f);
+    if (ok) {
+      a = *(const float4*)pa;
+      b = *(const float2*)pb;
+    }
+    acc[0][0] = mfma32(a.x, b.x, acc[0][0]);
+    acc[1][0] = mfma32(a.y, b.x, acc[1][0]);
+    acc[2][0] = mfma32(a.z, b.x, acc[2][0]);
+    acc[3][0] = mfma32(a.w, b.x, acc[3][0]);
+    acc[0][1] = mfma32(a.x, b.y, acc[0][1]);
+    acc[1][1] = mfma32(a.y, b.y, acc[1][1]);
+    acc[2][1] = mfma32(a.z, b.y, acc[2][1]);
+    acc[3][1] = mfma32(a.w, b.y, acc[3][1]);
+    bsum.x += a.x;
+    bsum.y += a.y;
+    bsum.z += a.z;
+    bsum.w += a.w;
+    pa += 2 * ld_dy;
+    pb += 2 * ld_x;
+  }
+  if (kwn > 1) {  // K groups 1.. hand their accumulators to group 0 of the same wave tile
+    if (kw > 0) {
+      float* dst = red + ((size_t)((kw - 1) * ntile + tw) * 132) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((q * 2 + p) * 16 + r) * 64] = acc[q][p][r];
+      dst[128 * 64] = bsum.x;
+      dst[129 * 64] = bsum.y;
+      dst[130 * 64] = bsum.z;
+      dst[131 * 64] = bsum.w;
+    }
+    __syncthreads();
+    if (kw > 0) return;
+    for (int g2 = 1; g2 < kwn; ++g2) {
+      const float* src = red + ((size_t)((g2 - 1) * ntile + tw) * 132) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q][p][r] += src[((q * 2 + p) * 16 + r) * 64];
+      bsum.x += src[128 * 64];
+      bsum.y += src[129 * 64];
+      bsum.z += src[130 * 64];
+      bsum.w += src[131 * 64];
+    }
+  }
+  // MFMA tile (q,p): D value r of lane (col, kk) = tile[row = (r&3) + 8*(r>>2) + 4*kk][col]
+  //   -> dW[o0 + 4*row + q][i0 + 2*col + p]
+  const int64_t pstride = (int64_t)out * in + (part_b != nullptr ? out : 0);
+  float* pw = part_w + (int64_t)s * pstride;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+      *(float2*)(pw + (int64_t)(o0 + 4 * row + q) * in + i0 + 2 * col) = make_float2(acc[q][0][r], acc[q][1][r]);
+    }
+  }
+  if (part_b != nullptr && iw == 0) {
+    bsum.x += __shfl_xor(bsum.x, 32, 64);
+    bsum.y += __shfl_xor(bsum.y, 32, 64);
+    bsum.z += __shfl_xor(bsum.z, 32, 64);
+    bsum.w += __shfl_xor(bsum.w, 32, 64);
+    if (lane < 32) *(float4*)(part_b + (int64_t)s * pstride + o0 + 4 * lane) = bsum;
+  }
+}
+
+// record e of every split summed: e < n_w -> dw[e], else db[e - n_w].
+// Block = 32 consecutive elements x 8 interleaved slices of the splits, combined through LDS (deterministic).
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ part, int nsplit, int64_t n_w,
                                                       int64_t n_b, float* __restrict__ dw, float* __restrict__ db) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + cx;
   const int64_t n = n_w + n_b;
-  if (e >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int s = 0;
-  for (; s + 4 <= nsplit; s += 4) {
-    a0 += part[(int64_t)s * n + e];
-    a1 += part[(int64_t)(s + 1) * n + e];
-    a2 += part[(int64_t)(s + 2) * n + e];
-    a3 += part[(int64_t)(s + 3) * n + e];
+  float a0 = 0.f, a1 = 0.f;
+  if (e < n) {
+    int s = gy;
+    for (; s + 8 < nsplit; s += 16) {
+      a0 += part[(int64_t)s * n + e];
+      a1 += part[(int64_t)(s + 8) * n + e];
+    }
+    if (s < nsplit) a0 += part[(int64_t)s * n + e];
   }
-  for (; s < nsplit; ++s) a0 += part[(int64_t)s * n + e];
-  const float r = (a0 + a1) + (a2 + a3);
-  if (e < n_w)
-    dw[e] = r;
-  else
-    db[e - n_w] = r;
+  red[gy][cx] = a0 + a1;
+  __syncthreads();
+  if (gy == 0 && e < n) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += red[k][cx];
+    if (e < n_w)
+      dw[e] = r;
+    else
+      db[e - n_w] = r;
+  }
 }
 
 int pick_splits(int64_t m, int out, int in, int64_t* rows_per_split) {
@@ -147,10 +358,24 @@ int pick_splits(int64_t m, int out, int in, int64_t* rows_per_split) {
     if (target < 1) target = 256;
   }
   int s = target / tiles;
-  if (s < 1) s = 1;
+  s = (s + 7) / 8 * 8;  // multiple of the XCD count
+  if (s < 8) s = 8;
   if (s > 512) s = 512;
   int64_t rps = sst_div_up(m > 0 ? m : 1, s);
   rps = sst_align_up(rps, 16);
+  if (rps < 64) rps = 64;
+  *rows_per_split = rps;
+  return s;  // some trailing slices may be empty (they write zero partials)
+}
+
+int wide_splits(int64_t m, int64_t* rows_per_split) {
+  static int target = 0;
+  if (target == 0) {
+    const char* e = getenv("SST_WGRAD_WIDE_WGS");
+    target = e ? atoi(e) : 256;
+    if (target < 1) target = 256;
+  }
+  int64_t rps = sst_align_up(sst_div_up(m > 0 ? m : 1, target), 16);
   if (rps < 64) rps = 64;
   *rows_per_split = rps;
   return (int)sst_div_up(m > 0 ? m : 1, rps);
@@ -162,7 +387,9 @@ extern "C" {
 
 int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in) {
   int64_t rps;
-  const int s = pick_splits(m, out, in, &rps);
+  int s = pick_splits(m, out, in, &rps);
+  const int sw = wide_splits(m, &rps);
+  if (sw > s) s = sw;
   return sst_align_up((int64_t)s * ((int64_t)out * in + out) * sizeof(float), 256) + 256;
 }
 
@@ -177,16 +404,32 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
     return SST_OK;
   }
   if (!d_dy || !d_x) return SST_ERR_ARG;
-  int64_t rps;
-  const int s = pick_splits(m, out, in, &rps);
-  const int tiles = ((out + kWgTileO - 1) / kWgTileO) * ((in + kWgTileI - 1) / kWgTileI);
   const int64_t nw = (int64_t)out * in;
   float* part_w = (float*)d_workspace;
   float* part_b = d_db ? part_w + nw : nullptr;  // bias sums sit behind the dW block of each split record
-  hipLaunchKernelGGL(wgrad_k<8>, dim3((unsigned)(s * tiles)), dim3(256), 0, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
-                     part_w, part_b);
+  int64_t rps;
+  int s;
+  const bool wide = (out % 128 == 0) && (in % 64 == 0) && ((out / 128) * (in / 64) <= 4) &&
+                    ((out / 128) * (in / 64) != 3) && (ld_dy % 4 == 0) && (ld_x % 2 == 0) &&
+                    (((uintptr_t)d_dy & 15) == 0) && (((uintptr_t)d_x & 7) == 0);
+  if (wide) {
+    s = wide_splits(m, &rps);
+    const int ntile = (out / 128) * (in / 64);
+    const size_t lds = (size_t)(4 / ntile - 1) * ntile * 132 * 64 * sizeof(float);
+    SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(wgrad_wide_k<4>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
+                       part_w, part_b);
+  } else {
+    s = pick_splits(m, out, in, &rps);
+    const int tiles = ((out + kWgTileO - 1) / kWgTileO) * ((in + kWgTileI - 1) / kWgTileI);
+    constexpr int KW = 2;
+    const size_t lds = (size_t)(KW - 1) * 4 * 34 * 64 * sizeof(float);
+    SST_HIP(hipFuncSetAttribute((const void*)wgrad_k<8, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((wgrad_k<8, KW>), dim3((unsigned)(s * tiles)), dim3(256 * KW), lds, st, d_dy, d_x, m, out, in,
+                       ld_dy, ld_x, rps, part_w, part_b);
+  }
   const int64_t nb = d_db ? out : 0;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)sst_div_up(nw + nb, 256)), dim3(256), 0, st, part_w, s, nw, nb, d_dw,
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)sst_div_up(nw + nb, 32)), dim3(256), 0, st, part_w, s, nw, nb, d_dw,
                      d_db);
   SST_LAUNCH_CHECK();
   return SST_OK;
