@@ -109,6 +109,8 @@ def main():
     ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
+    ap.add_argument('--backend', default='nccl', help='nccl (= RCCL, default) | gloo (dev check of the N>1 path on one GPU)')
+    ap.add_argument('--share-device', action='store_true', help='dev only: every rank uses cuda:0')
     ap.add_argument('--no-gemm-tuning', action='store_true',
                     help='do not let PyTorch TunableOp pick the hipBLASLt/rocBLAS solution of each dense GEMM shape')
     args = ap.parse_args()
@@ -117,11 +119,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from sst_amd import kernels as K
@@ -196,13 +200,23 @@ def main():
     if fwd is not None:
         ms, tokens, launches = fwd
         achieved = SRA_BYTES_PER_TOKEN * tokens / (ms * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': 'sra_fwd_mfma_k<NT> launch group (sst_sra_attn_fwd_f32)',
+        roofline = {'bound': 'hbm', 'kernel': 'sra_fwd_wave_k<NTMAX> (one launch per sst_sra_attn_fwd_f32 call)',
                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'algorithmic_bytes_per_launch': int(SRA_BYTES_PER_TOKEN * tokens),
                     'avg_launch_ms': round(ms, 4), 'launches': launches}
         if bwd is not None:
             roofline['sra_bwd_avg_launch_ms'] = round(bwd[0], 4)
+        # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately by
+        # tools/collect_sra_traffic.sh on the same workload and committed under profiles/): per launch, like `achieved`
+        tpath = os.path.join(ROOT, 'profiles', 'latest_sra_traffic.json')
+        if os.path.exists(tpath) and args.points == 116000 and args.frames_per_gpu == 1:
+            try:
+                tr = json.load(open(tpath))['sra_fwd_wave_k']
+                roofline['traffic'] = int(tr['hbm_bytes_per_launch'])
+                roofline['traffic_source'] = 'profiles/latest_sra_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
+            except Exception:
+                pass
 
     if rank == 0:
         total_frames = world * args.frames_per_gpu * args.steps

@@ -33,6 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHD = 16;     // head dim
 constexpr int kGH = 4;      // heads per workgroup
 constexpr int kGC = 64;     // channels per workgroup (kGH * kHD)
+#ifndef SST_WAVE_HEADS
+#define SST_WAVE_HEADS 4
+#endif
+constexpr int kWH = SST_WAVE_HEADS;  // heads (= waves) per workgroup of the register-resident kernels
 constexpr int kRS = 68;     // LDS row stride (floats)
 constexpr int kMaxTilesMfma = 9;
 
@@ -289,7 +293,7 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
                                                   int hg, int H, float scale, float* __restrict__ O, uint32_t ldo,
                                                   float* __restrict__ LSE) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int head = hg * kGH + (threadIdx.x >> 6);
+  const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
   constexpr int NTK = (NT * 16 + 63) / 64;
   // token ids, 64 window positions per register; positions past the window repeat its last token so that
@@ -408,7 +412,7 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
 // One launch for every window: the tile class is picked per workgroup, so all classes run concurrently
 // (separate per-class launches serialise on the stream and the sparse classes run at very low occupancy).
 template <int NTMAX>
-__global__ __launch_bounds__(256) void sra_fwd_wave_k(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(64 * kWH) void sra_fwd_wave_k(const float* __restrict__ Q, const float* __restrict__ K,
                                                       const float* __restrict__ V, int64_t ldq, int64_t ldk,
                                                       int64_t ldv, const int32_t* __restrict__ tok,
                                                       const int32_t* __restrict__ winoff, int n_groups, int H,
@@ -597,7 +601,7 @@ __device__ __forceinline__ void sra_bwd_dq_body(const float* __restrict__ Q, con
                                                 float scale, float* __restrict__ dQ, uint32_t lddq,
                                                 float* __restrict__ Dbuf) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int head = hg * kGH + (threadIdx.x >> 6);
+  const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
   constexpr int NTK = (NT * 16 + 63) / 64;
   int tk[NTK];
@@ -684,7 +688,7 @@ __device__ __forceinline__ void sra_bwd_dkv_body(const float* __restrict__ Q, co
                                                  float* __restrict__ dV, uint32_t lddk, uint32_t lddv) {
   constexpr int NJ = 4;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int head = hg * kGH + (threadIdx.x >> 6);
+  const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
   constexpr int NTK = (NTW * 16 + 63) / 64;
   int tk[NTK];
@@ -790,7 +794,7 @@ __device__ __forceinline__ void sra_bwd_dkv_body(const float* __restrict__ Q, co
 }
 
 template <int NTMAX>
-__global__ __launch_bounds__(256) void sra_bwd_dq_k(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(64 * kWH) void sra_bwd_dq_k(const float* __restrict__ Q, const float* __restrict__ K,
                                                     const float* __restrict__ V, const float* __restrict__ O,
                                                     const float* __restrict__ dO, const float* __restrict__ LSE,
                                                     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
@@ -817,7 +821,7 @@ __global__ __launch_bounds__(256) void sra_bwd_dq_k(const float* __restrict__ Q,
 }
 
 template <int NTMAX>
-__global__ __launch_bounds__(256) void sra_bwd_dkv_k(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(64 * kWH) void sra_bwd_dkv_k(const float* __restrict__ Q, const float* __restrict__ K,
                                                      const float* __restrict__ V, const float* __restrict__ dO,
                                                      const float* __restrict__ LSE, const float* __restrict__ Dbuf,
                                                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo,
@@ -850,12 +854,12 @@ int launch_bwd_wave(const float* Q, const float* K, const float* V, const float*
                     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* tok,
                     const int32_t* winoff, int64_t n_windows, int H, float scale, float* dQ, float* dK, float* dV,
                     int64_t lddq, int64_t lddk, int64_t lddv, float* Dbuf, hipStream_t st) {
-  const int n_groups = H / kGH;
+  const int n_groups = H / kWH;
   const dim3 grid((unsigned)(n_windows * n_groups));
-  hipLaunchKernelGGL(sra_bwd_dq_k<NTMAX>, grid, dim3(256), 0, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo, tok,
+  hipLaunchKernelGGL(sra_bwd_dq_k<NTMAX>, grid, dim3(64 * kWH), 0, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo, tok,
                      winoff, n_groups, H, scale, dQ, lddq, Dbuf);
   const dim3 grid_kv((unsigned)(n_windows * n_groups * ((NTMAX + 3) / 4)));
-  hipLaunchKernelGGL(sra_bwd_dkv_k<NTMAX>, grid_kv, dim3(256), 0, st, Q, K, V, dO, LSE, Dbuf, ldq, ldk, ldv, lddo, tok,
+  hipLaunchKernelGGL(sra_bwd_dkv_k<NTMAX>, grid_kv, dim3(64 * kWH), 0, st, Q, K, V, dO, LSE, Dbuf, ldq, ldk, ldv, lddo, tok,
                      winoff, n_groups, H, scale, dK, dV, lddk, lddv);
   return SST_OK;
 }
@@ -876,8 +880,8 @@ template <int NTMAX>
 int launch_fwd_wave(const float* Q, const float* K, const float* V, int64_t ldq, int64_t ldk, int64_t ldv,
                     const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, float* O,
                     int64_t ldo, float* LSE, hipStream_t st) {
-  const int n_groups = H / kGH;
-  hipLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(256), 0, st, Q, K, V, ldq, ldk,
+  const int n_groups = H / kWH;
+  hipLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st, Q, K, V, ldq, ldk,
                      ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE);
   return SST_OK;
 }
