@@ -173,16 +173,16 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
         dwo, dbo = weight_bias_grad(ds1, o, True)
         do = ds1 @ w_out
-        dqk = torch.empty_like(qk)
-        dv = torch.empty_like(v)
-        K._sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, ctx.impl, dqk[:, :c],
-                   dqk[:, c:], dv)
+        # dq | dk | dv in ONE [M, 3C] buffer: d(x) of the whole in-projection is then a single GEMM
+        dqkv = torch.empty((x.size(0), 3 * c), dtype=torch.float32, device=x.device)
+        dqk, dv = dqkv[:, :2 * c], dqkv[:, 2 * c:]
+        K._sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, ctx.impl, dqkv[:, :c],
+                   dqkv[:, c:2 * c], dv)
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * c, dtype=torch.float32, device=x.device)
         weight_bias_grad(dqk, xp, True, out_w=dw_in[:2 * c], out_b=db_in[:2 * c])
         weight_bias_grad(dv, x, True, out_w=dw_in[2 * c:], out_b=db_in[2 * c:])
-        dx = ds1.addmm_(dqk, w_in[:2 * c])                            # residual + q,k branch (in place)
-        dx.addmm_(dv, w_in[2 * c:])                                   # + v branch
+        dx = ds1.addmm_(dqkv, w_in)                                   # residual + q,k,v branches (in place)
         return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
                 None)
 
