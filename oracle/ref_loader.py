@@ -186,6 +186,10 @@ def load_reference():
     ns.norm = norm
     ns.input_layer_v2 = _load('mmdet3d.models.middle_encoders.sst_input_layer_v2',
                               'mmdet3d/models/middle_encoders/sst_input_layer_v2.py')
+    ns.input_layer_v1 = _load('mmdet3d.models.middle_encoders.sst_input_layer',
+                              'mmdet3d/models/middle_encoders/sst_input_layer.py')
+    ns.block_v1 = _load('mmdet3d.models.sst.sst_basic_block', 'mmdet3d/models/sst/sst_basic_block.py')
+    ns.sst_v1 = _load('mmdet3d.models.backbones.sst_v1', 'mmdet3d/models/backbones/sst_v1.py')
     ns.cosine_msa = _load('mmdet3d.models.sst.cosine_msa', 'mmdet3d/models/sst/cosine_msa.py')
     ns.block_v2 = _load('mmdet3d.models.sst.sst_basic_block_v2', 'mmdet3d/models/sst/sst_basic_block_v2.py')
     ns.sst_v2 = _load('mmdet3d.models.backbones.sst_v2', 'mmdet3d/models/backbones/sst_v2.py')

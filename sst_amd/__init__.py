@@ -16,9 +16,9 @@ from .sst_ops import (build_mlp, flat2window, flat2window_v2, get_activation, ge
                       get_flat2win_inds, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors,
                       make_continuous_inds, scatter_v2, window2flat, window2flat_v2)
 from .voxel_encoder import DynamicScatterVFE, DynamicVFE, DynamicVFELayer, DynamicVFELayerV2, SIRLayer
-from .sst_input_layer import PseudoMiddleEncoderForSpconvFSD, SSTInputLayerV2
+from .sst_input_layer import PseudoMiddleEncoderForSpconvFSD, SSTInputLayer, SSTInputLayerV2
 from .sst_basic_block import BasicShiftBlockV2, EncoderLayer, WindowAttention
-from .backbones import SIR, SSTv2
+from .backbones import SIR, SSTv1, SSTv2
 
 __version__ = '0.1.0'
 
@@ -28,8 +28,8 @@ __all__ = [
     'get_inner_win_inds', 'make_continuous_inds', 'flat2window_v2', 'window2flat_v2', 'get_flat2win_inds_v2',
     'get_window_coors', 'scatter_v2', 'build_mlp', 'get_activation', 'get_activation_layer',
     'NaiveSyncBatchNorm1d', 'NaiveSyncBatchNorm2d', 'build_norm_layer', 'build_conv_layer', 'DynamicVFE',
-    'DynamicScatterVFE', 'SIRLayer', 'DynamicVFELayer', 'DynamicVFELayerV2', 'SSTInputLayerV2',
-    'PseudoMiddleEncoderForSpconvFSD', 'WindowAttention', 'EncoderLayer', 'BasicShiftBlockV2', 'SSTv2', 'SIR',
+    'DynamicScatterVFE', 'SIRLayer', 'DynamicVFELayer', 'DynamicVFELayerV2', 'SSTInputLayer', 'SSTInputLayerV2',
+    'PseudoMiddleEncoderForSpconvFSD', 'WindowAttention', 'EncoderLayer', 'BasicShiftBlockV2', 'SSTv1', 'SSTv2', 'SIR',
     'MODELS', 'VOXEL_ENCODERS', 'MIDDLE_ENCODERS', 'BACKBONES', 'build_voxel_encoder', 'build_middle_encoder',
     'build_backbone', 'WindowPlan', 'sra_attention', 'sra_attention_qk_v',
 ]

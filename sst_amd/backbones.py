@@ -10,7 +10,7 @@ import torch.nn as nn
 from . import kernels as K
 from .norm import build_conv_layer, build_norm_layer
 from .registry import BACKBONES, build_voxel_encoder
-from .sst_basic_block import BasicShiftBlockV2
+from .sst_basic_block import BasicShiftBlockV2, plan_from_reference_dicts
 from .sst_ops import unique_with_plan
 
 
@@ -147,6 +147,105 @@ class SSTv2(nn.Module):
         flat = coors[:, 0] * (ny * nx) + coors[:, 2] * nx + coors[:, 3]
         canvas = canvas.index_put((flat.long(),), voxel_feat)
         return canvas.view(batch_size, ny, nx, feat_dim).permute(0, 3, 1, 2)
+
+
+@BACKBONES.register_module()
+class SSTv1(nn.Module):
+    """First-generation backbone (mmdet3d/models/backbones/sst_v1.py:17-270): consumes the 3-tuple of
+    SSTInputLayer, computes positional embedding itself (:221-259), always recovers the BEV canvas.
+    Same constructor kwargs, forward signature and state_dict keys; the encoder layers are the same modules as
+    SSTv2's (the v1 blocks have identical parameters, mmdet3d/models/sst/sst_basic_block.py:62-99)."""
+
+    def __init__(self, d_model=[], nhead=[], num_blocks=6, dim_feedforward=[], dropout=0.0, activation="gelu",
+                 output_shape=None, num_attached_conv=2, conv_in_channel=64, conv_out_channel=64,
+                 norm_cfg=dict(type='naiveSyncBN2d', eps=1e-3, momentum=0.01),
+                 conv_cfg=dict(type='Conv2d', bias=False), debug=True, drop_info=None, normalize_pos=False,
+                 pos_temperature=10000, window_shape=None, in_channel=None,
+                 conv_kwargs=dict(kernel_size=3, dilation=2, padding=2, stride=1), checkpoint_blocks=[]):
+        super().__init__()
+        assert drop_info is not None
+        self.meta_drop_info = drop_info
+        self.pos_temperature = pos_temperature
+        self.d_model = d_model
+        self.window_shape = window_shape
+        self.normalize_pos = normalize_pos
+        self.nhead = nhead
+        self.checkpoint_blocks = checkpoint_blocks
+        if in_channel is not None:
+            self.linear0 = nn.Linear(in_channel, d_model[0])
+        self.block_list = nn.ModuleList([
+            BasicShiftBlockV2(d_model[i], nhead[i], dim_feedforward[i], dropout, activation, batch_first=False,
+                              block_id=i) for i in range(num_blocks)])
+        for name, p in self.named_parameters():
+            if p.dim() > 1 and 'scaler' not in name:
+                nn.init.xavier_uniform_(p)
+        self.output_shape = output_shape
+        self.debug = debug
+        self.num_attached_conv = num_attached_conv
+        if num_attached_conv > 0:
+            conv_list = []
+            for i in range(num_attached_conv):
+                conv_kwargs_i = conv_kwargs if isinstance(conv_kwargs, dict) else conv_kwargs[i]
+                if i > 0:
+                    conv_in_channel = conv_out_channel
+                conv = build_conv_layer(conv_cfg, in_channels=conv_in_channel, out_channels=conv_out_channel,
+                                        **conv_kwargs_i)
+                layers = [conv] if norm_cfg is None else [conv, build_norm_layer(norm_cfg, conv_out_channel)[1]]
+                conv_list.append(nn.Sequential(*layers, nn.ReLU(inplace=True)))
+            self.conv_layer = nn.ModuleList(conv_list)
+
+    def set_drop_info(self):
+        if hasattr(self, 'drop_info'):
+            return
+        meta = self.meta_drop_info
+        if isinstance(meta, tuple):
+            self.drop_info = meta[0] if self.training else meta[1]
+        else:
+            self.drop_info = meta
+
+    @torch.no_grad()
+    def get_pos_embed_flat(self, coors_in_win, dtype):
+        """[M, d_model] embedding from v1 in-window coordinates (x, y); arithmetic of sst_v1.py:221-259."""
+        win_x, win_y = self.window_shape
+        x, y = coors_in_win[:, 0] - win_x / 2, coors_in_win[:, 1] - win_y / 2
+        if self.normalize_pos:
+            x = x / win_x * 2 * 3.1415
+            y = y / win_y * 2 * 3.1415
+        pos_length = self.d_model[0] // 2
+        inv_freq = torch.arange(pos_length, dtype=torch.float32, device=coors_in_win.device)
+        inv_freq = self.pos_temperature ** (2 * (inv_freq // 2) / pos_length)
+        embed_x = x[:, None] / inv_freq[None, :]
+        embed_y = y[:, None] / inv_freq[None, :]
+        embed_x = torch.stack([embed_x[:, ::2].sin(), embed_x[:, 1::2].cos()], dim=-1).flatten(1)
+        embed_y = torch.stack([embed_y[:, ::2].sin(), embed_y[:, 1::2].cos()], dim=-1).flatten(1)
+        return torch.cat([embed_x, embed_y], dim=-1).to(dtype)
+
+    def forward(self, input_tuple):
+        voxel_feat, ind_dict_list, voxel_info = input_tuple
+        assert voxel_info['coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'
+        self.set_drop_info()
+        batch_size = voxel_info['coors'][:, 0].max().item() + 1
+        num_shifts = len(ind_dict_list)
+        m = voxel_feat.size(0)
+        plans, pos = [], []
+        for i in range(num_shifts):
+            if f'sra_plan_shift{i}' in voxel_info:
+                plans.append(voxel_info[f'sra_plan_shift{i}'])
+            else:  # a voxel_info produced by the reference's own SSTInputLayer
+                d = dict(ind_dict_list[i])
+                d['batching_info'] = self.drop_info
+                plans.append(plan_from_reference_dicts(d, m, voxel_feat.device))
+            pos.append(self.get_pos_embed_flat(voxel_info[f'coors_in_win_shift{i}'], voxel_feat.dtype))
+        output = voxel_feat
+        if hasattr(self, 'linear0'):
+            output = self.linear0(output)
+        for i, block in enumerate(self.block_list):
+            output = block(output, pos, plans, None, using_checkpoint=i in self.checkpoint_blocks)
+        output = SSTv2.recover_bev(self, output, voxel_info['coors'], batch_size)
+        if self.num_attached_conv > 0:
+            for conv in self.conv_layer:
+                output = conv(output)
+        return [output]
 
 
 @BACKBONES.register_module()

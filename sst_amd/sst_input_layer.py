@@ -23,7 +23,7 @@ from torch import nn
 
 from . import kernels as K
 from .registry import MIDDLE_ENCODERS
-from .sst_ops import flat2window_v2, window2flat_v2
+from .sst_ops import flat2window, flat2window_v2, window2flat, window2flat_v2
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -256,3 +256,108 @@ class SSTInputLayerV2(nn.Module):
         for key, value in window_key_padding_dict.items():  # True = padded slot
             window_key_padding_dict[key] = value.logical_not().squeeze(2)
         return window_key_padding_dict
+
+
+@MIDDLE_ENCODERS.register_module()
+class SSTInputLayer(nn.Module):
+    """First-generation input layer (mmdet3d/models/middle_encoders/sst_input_layer.py:14-364): 2-D windows,
+    ``shifts_list`` instead of a fixed half-window shift, returns ``(voxel_feat, flat2win_inds_list, voxel_info)``
+    and leaves positional embedding / key masks to the SSTv1 backbone.  Same constructor kwargs and outputs;
+    the grouping, drop and index computation run on the same HIP kernels as SSTInputLayerV2 (window ids follow
+    the v1 numbering of sst_input_layer.py:299-330).  Accepts the optional third positional argument that
+    DynamicVoxelNet passes (detectors/dynamic_voxelnet.py:43)."""
+
+    def __init__(self, drop_info, shifts_list, window_shape, point_cloud_range, voxel_size, shuffle_voxels=True,
+                 debug=True):
+        super().__init__()
+        self.fp16_enabled = False
+        self.meta_drop_info = drop_info
+        self.shifts_list = shifts_list
+        self.point_cloud_range = point_cloud_range
+        self.voxel_size = voxel_size
+        self.shuffle_voxels = shuffle_voxels
+        self.debug = debug
+        self.window_shape = window_shape
+
+    def set_drop_info(self):
+        if hasattr(self, 'drop_info'):
+            return
+        meta = self.meta_drop_info
+        if isinstance(meta, tuple):
+            self.drop_info = meta[0] if self.training else meta[1]
+        else:
+            self.drop_info = meta
+
+    @torch.no_grad()
+    def window_partition(self, coors, voxel_info):
+        """v1 window ids / in-window coordinates, exactly sst_input_layer.py:299-330."""
+        win_shape_x, win_shape_y = self.window_shape
+        pc_range, voxel_size = self.point_cloud_range, self.voxel_size
+        bev_shape_x = int(np.ceil((pc_range[3] - pc_range[0]) / voxel_size[0]))
+        bev_shape_y = int(np.ceil((pc_range[4] - pc_range[1]) / voxel_size[1]))
+        max_num_win_x = int(np.ceil((bev_shape_x / win_shape_x)) + 1)
+        max_num_win_y = int(np.ceil((bev_shape_y / win_shape_y)) + 1)
+        max_num_win_per_sample = max_num_win_x * max_num_win_y
+        for i, (shift_x, shift_y) in enumerate(self.shifts_list):
+            assert shift_x == 0 or shift_x == win_shape_x // 2, 'Usually ...'
+            sx = coors[:, 3] + (win_shape_x - shift_x if shift_x > 0 else 0)
+            sy = coors[:, 2] + (win_shape_y - shift_y if shift_y > 0 else 0)
+            wxi = torch.div(sx, win_shape_x, rounding_mode='floor')
+            wyi = torch.div(sy, win_shape_y, rounding_mode='floor')
+            voxel_info[f'batch_win_inds_shift{i}'] = coors[:, 0] * max_num_win_per_sample + wxi * max_num_win_y + wyi
+            voxel_info[f'coors_in_win_shift{i}'] = torch.stack([sx - wxi * win_shape_x, sy - wyi * win_shape_y], dim=-1)
+        self._win_id_bound = max_num_win_per_sample
+        return voxel_info
+
+    def forward(self, voxel_feat, coors, batch_size=None):
+        self.set_drop_info()
+        if len(self.shifts_list) != 2:
+            raise NotImplementedError('SSTInputLayer: two shift layouts are expected (every shipped config)')
+        coors = coors.long()
+        if self.shuffle_voxels:
+            shuffle_inds = torch.randperm(len(voxel_feat), device=voxel_feat.device)
+            voxel_feat = voxel_feat[shuffle_inds]
+            coors = coors[shuffle_inds]
+        voxel_info = self.window_partition(coors, {})
+        m = coors.size(0)
+        keys = list(self.drop_info.keys())
+        levels = [(self.drop_info[k]['max_tokens'],) + tuple(self.drop_info[k]['drop_range']) for k in keys]
+        with torch.no_grad():
+            if batch_size is None:
+                batch_size = int(coors[:, 0].max().item()) + 1 if m > 0 else 1
+            win_bits = max(1, int(self._win_id_bound * int(batch_size)).bit_length())
+            w0 = voxel_info['batch_win_inds_shift0'].int().contiguous()
+            w1 = voxel_info['batch_win_inds_shift1'].int().contiguous()
+            rb = K.region_batching(w0, w1, win_bits, levels)
+            counts = rb['counts'].tolist()
+        m_keep = counts[0]
+        if m_keep == m:
+            keep_idx = torch.arange(m, device=coors.device, dtype=torch.long)
+        else:
+            keep_idx = torch.nonzero(rb['keep']).squeeze(1)
+        sel = (lambda t: t) if m_keep == m else (lambda t: t.index_select(0, keep_idx))
+        voxel_feat = sel(voxel_feat)
+        coors = sel(coors)
+        key_map = torch.tensor(keys, device=coors.device, dtype=torch.long)
+        out_info = {'voxel_keep_inds': keep_idx, 'coors': coors}
+        flat2win_inds_list = []
+        cap = max(l[0] for l in levels)
+        for i in range(2):
+            out_info[f'batch_win_inds_shift{i}'] = sel(voxel_info[f'batch_win_inds_shift{i}'])
+            out_info[f'coors_in_win_shift{i}'] = sel(voxel_info[f'coors_in_win_shift{i}'])
+            lvl_idx = sel(rb[f'level{i}'])
+            if self.debug:
+                assert (lvl_idx >= 0).all()
+            out_info[f'voxel_drop_level_shift{i}'] = key_map[lvl_idx.long().clamp(min=0)]
+            f2w = sel(rb[f'flat2win{i}'])
+            inds = {}
+            for li, dl in enumerate(keys):
+                mask = lvl_idx == li
+                if mask.any():
+                    inds[dl] = (f2w[mask].long(), torch.where(mask))
+            flat2win_inds_list.append(inds)
+            out_info[f'sra_plan_shift{i}'] = K.WindowPlan(rb[f'tok{i}'], rb[f'winoff{i}'], counts[1 + i], m_keep, cap)
+        if self.debug:
+            c3d = flat2window(coors, out_info['voxel_drop_level_shift0'], flat2win_inds_list[0], self.drop_info)
+            assert (window2flat(c3d, flat2win_inds_list[0]) == coors).all()
+        return voxel_feat, flat2win_inds_list, out_info

@@ -168,6 +168,42 @@ def gen_sst_block(ref):
         save(f'sst_block_{tag}.npz', **arrays)
 
 
+def gen_sst_v1(ref):
+    """Reference SSTInputLayer (v1) + SSTv1 (2 blocks of d=64 / 4 heads, no attached conv), eval mode, fp32."""
+    g = torch.Generator().manual_seed(8)
+    coors = make_voxel_coors(g, 200, 2, crowded=True)
+    m = coors.size(0)
+    layer = ref.input_layer_v1.SSTInputLayer(drop_info=(DROP_TRAIN, DROP_TEST), shifts_list=[(0, 0), (6, 6)],
+                                             window_shape=(12, 12), point_cloud_range=PC_RANGE, voxel_size=VOXEL_SIZE,
+                                             shuffle_voxels=False, debug=True)
+    layer.eval()
+    torch.manual_seed(9)
+    net = ref.sst_v1.SSTv1(d_model=[64, 64], nhead=[4, 4], num_blocks=2, dim_feedforward=[128, 128],
+                           output_shape=[468, 468],
+                           num_attached_conv=0, debug=True, drop_info=(DROP_TRAIN, DROP_TEST), pos_temperature=10000,
+                           normalize_pos=False, window_shape=(12, 12))
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn(p_.shape, generator=g) * 0.1)
+    net.eval()
+    feats = torch.randn(m, 64, generator=g)
+    with torch.no_grad():
+        vf, ind_list, info = layer(feats, coors.int())
+        bev = net((vf, ind_list, info))[0]
+    c = info['coors']
+    out_feats = bev[c[:, 0], :, c[:, 2], c[:, 3]]
+    arrays = {'in::voxel_coors': t2n(coors).astype(np.int32), 'in::voxel_feats': t2n(feats),
+              'out::voxel_keep_inds': t2n(info['voxel_keep_inds']), 'out::coors': t2n(c),
+              'out::bev_at_voxels': t2n(out_feats), 'out::bev_abs_sum': np.asarray(float(bev.abs().sum()))}
+    for s_ in range(2):
+        for k in (f'batch_win_inds_shift{s_}', f'coors_in_win_shift{s_}', f'voxel_drop_level_shift{s_}'):
+            arrays['out::' + k] = t2n(info[k])
+    arrays.update(state_to_np(net.state_dict()))
+    print('v1 voxels', m, '->', c.size(0))
+    save('sst_v1.npz', **arrays)
+
+
 def gen_dynamic_vfe(ref):
     g = torch.Generator().manual_seed(4)
     pts_list, coors_list = [], []
@@ -193,6 +229,36 @@ def gen_dynamic_vfe(ref):
               'out::voxel_feats': t2n(vf), 'out::voxel_coors': t2n(vc), 'out::grad_points': t2n(pts.grad)}
     arrays.update(state_to_np(vfe.state_dict()))
     save('dynamic_vfe.npz', **arrays)
+
+
+def gen_scatter_vfe(ref):
+    """Reference DynamicScatterVFE (FSD segmentor voxel encoder, configs/fsd/fsd_waymoD1_1x.py:32-44)."""
+    g = torch.Generator().manual_seed(10)
+    vs, rng = (0.25, 0.25, 0.2), [-80, -80, -2, 80, 80, 4]
+    mod = build_ref.load()
+    pts_list, coors_list = [], []
+    for b in range(2):
+        p = torch.rand(500, 5, generator=g) * torch.tensor([4.0, 4.0, 3.0, 1, 1]) + torch.tensor([10.0 * b, -2.0, -1.5, 0, 0])
+        c = torch.zeros((500, 3), dtype=torch.int32)
+        mod.dynamic_voxelize(p.contiguous(), c, list(vs), rng, 3)
+        pts_list.append(p)
+        coors_list.append(torch.nn.functional.pad(c, (1, 0), value=b))
+    pts, coors = torch.cat(pts_list), torch.cat(coors_list).long()
+    torch.manual_seed(11)
+    vfe = ref.voxel_encoder.DynamicScatterVFE(in_channels=5, feat_channels=[64, 64], voxel_size=vs,
+                                              with_cluster_center=True, with_voxel_center=True,
+                                              point_cloud_range=rng,
+                                              norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01),
+                                              unique_once=True)
+    vfe.train()
+    pts.requires_grad_(True)
+    vf, vc, inv = vfe(pts, coors, return_inv=True)
+    gout = torch.randn(vf.shape, generator=g)
+    (vf * gout).sum().backward()
+    arrays = {'in::points': t2n(pts), 'in::coors': t2n(coors), 'in::grad_out': t2n(gout), 'out::voxel_feats': t2n(vf),
+              'out::voxel_coors': t2n(vc), 'out::inv': t2n(inv), 'out::grad_points': t2n(pts.grad)}
+    arrays.update(state_to_np(vfe.state_dict()))
+    save('scatter_vfe.npz', **arrays)
 
 
 def gen_sir(ref):
@@ -230,7 +296,9 @@ def main():
     gen_voxelize()
     gen_input_layer(ref)
     gen_sst_block(ref)
+    gen_sst_v1(ref)
     gen_dynamic_vfe(ref)
+    gen_scatter_vfe(ref)
     gen_sir(ref)
 
 

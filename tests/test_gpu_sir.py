@@ -84,3 +84,21 @@ def test_sir_matches_reference_golden():
     ((pts_feats * torch.from_numpy(g['in::g_pts']).to(DEV)).sum()
      + (cluster_feats * torch.from_numpy(g['in::g_cluster']).to(DEV)).sum()).backward()
     np.testing.assert_allclose(feats.grad.cpu().numpy(), g['out::grad_features'], rtol=2e-3, atol=2e-3)
+
+
+def test_dynamic_scatter_vfe_matches_reference_golden():
+    import sst_amd
+    g = load_golden('scatter_vfe.npz')
+    vfe = sst_amd.build_voxel_encoder(dict(
+        type='DynamicScatterVFE', in_channels=5, feat_channels=[64, 64], voxel_size=(0.25, 0.25, 0.2),
+        with_cluster_center=True, with_voxel_center=True, point_cloud_range=[-80, -80, -2, 80, 80, 4],
+        norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01), unique_once=True))
+    vfe.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}, strict=True)
+    vfe.to(DEV).train()
+    pts = torch.from_numpy(g['in::points']).to(DEV).requires_grad_(True)
+    vf, vc, inv = vfe(pts, torch.from_numpy(g['in::coors']).to(DEV), return_inv=True)
+    np.testing.assert_array_equal(vc.cpu().numpy(), g['out::voxel_coors'])
+    np.testing.assert_array_equal(inv.cpu().numpy(), g['out::inv'])
+    np.testing.assert_allclose(vf.detach().cpu().numpy(), g['out::voxel_feats'], rtol=1e-3, atol=1e-3)
+    (vf * torch.from_numpy(g['in::grad_out']).to(DEV)).sum().backward()
+    np.testing.assert_allclose(pts.grad.cpu().numpy(), g['out::grad_points'], rtol=2e-3, atol=2e-3)

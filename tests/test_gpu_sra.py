@@ -174,3 +174,40 @@ def test_recover_bev_matches_loop_semantics():
         msk = coors[:, 0] == b
         ref[b][:, coors[msk, 2] * 468 + coors[msk, 3]] = feat[msk].t()
     assert torch.equal(bev, ref.view(2, 128, 468, 468))
+
+
+def test_sst_v1_matches_reference_golden():
+    """First-generation twins: SSTInputLayer + SSTv1 vs the reference's own classes (eval mode, no drop)."""
+    import sst_amd
+    from conftest import PC_RANGE, VOXEL_SIZE
+    g = load_golden('sst_v1.npz')
+    layer = sst_amd.build_middle_encoder(dict(
+        type='SSTInputLayer', drop_info=(DROP_TRAIN, DROP_TEST), shifts_list=[(0, 0), (6, 6)], window_shape=(12, 12),
+        point_cloud_range=PC_RANGE, voxel_size=VOXEL_SIZE, shuffle_voxels=False, debug=True))
+    layer.eval()
+    net = sst_amd.build_backbone(dict(
+        type='SSTv1', d_model=[64, 64], nhead=[4, 4], num_blocks=2, dim_feedforward=[128, 128],
+        output_shape=[468, 468], num_attached_conv=0, debug=True, drop_info=(DROP_TRAIN, DROP_TEST),
+        pos_temperature=10000, normalize_pos=False, window_shape=(12, 12)))
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}
+    net.load_state_dict(sd, strict=True)
+    net.to(DEV).eval()
+    feats = torch.from_numpy(g['in::voxel_feats']).to(DEV)
+    coors = torch.from_numpy(g['in::voxel_coors']).to(DEV)
+    with torch.no_grad():
+        vf, ind_list, info = layer(feats, coors, 2)     # third positional argument accepted
+        bev = net((vf, ind_list, info))[0]
+    np.testing.assert_array_equal(info['voxel_keep_inds'].cpu().numpy(), g['out::voxel_keep_inds'])
+    np.testing.assert_array_equal(info['coors'].cpu().numpy(), g['out::coors'])
+    for s in range(2):
+        for k in (f'batch_win_inds_shift{s}', f'coors_in_win_shift{s}', f'voxel_drop_level_shift{s}'):
+            np.testing.assert_array_equal(info[k].cpu().numpy(), g['out::' + k])
+    assert bev.shape == (2, 64, 468, 468)
+    c = info['coors']
+    got = bev[c[:, 0], :, c[:, 2], c[:, 3]].cpu().numpy()
+    assert np.abs(got - g['out::bev_at_voxels']).max() < TOL
+    assert abs(float(bev.abs().sum()) - float(g['out::bev_abs_sum'])) < 1e-2 * max(1.0, float(g['out::bev_abs_sum']))
+    # the reference's own index dictionaries drive the same kernels
+    with torch.no_grad():
+        bev2 = net((vf, ind_list, {k: v for k, v in info.items() if not k.startswith('sra_plan')}))[0]
+    assert float((bev2 - bev).abs().max()) < 1e-5
