@@ -147,7 +147,7 @@ class SSTInputLayerV2(nn.Module):
         ciws = (sel(ciw0), sel(ciw1))
         lvls = (sel(rb['level0']), sel(rb['level1']))
         f2ws = (sel(rb['flat2win0']), sel(rb['flat2win1']))
-        key_map = torch.tensor(level_keys, device=voxel_coors.device, dtype=torch.long)
+        identity_keys = list(level_keys) == list(range(len(level_keys)))
 
         voxel_info['voxel_feats'] = voxel_feats
         voxel_info['voxel_coors'] = voxel_coors
@@ -156,7 +156,9 @@ class SSTInputLayerV2(nn.Module):
             voxel_info[f'batch_win_inds_shift{i}'] = wins[i].long()
             voxel_info[f'coors_in_win_shift{i}'] = ciws[i].long()
             lv = lvls[i].long()
-            voxel_info[f'voxel_drop_level_shift{i}'] = key_map[lv.clamp(min=0)] if len(level_keys) else lv
+            if not identity_keys:  # drop_info keyed by something else than 0..n-1
+                lv = torch.tensor(level_keys, device=lv.device, dtype=torch.long)[lv.clamp(min=0)]
+            voxel_info[f'voxel_drop_level_shift{i}'] = lv
             voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(rb[f'tok{i}'], rb[f'winoff{i}'], n_win[i], m_keep,
                                                             max_tokens_cap)
             voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], voxel_feats.size(1),
@@ -238,7 +240,11 @@ class SSTInputLayerV2(nn.Module):
     def get_pos_embed_flat(self, coors_in_win, feat_dim, dtype):
         """[M, feat_dim] positional embedding of every voxel (flat layout)."""
         wx, wy, _ = self._window_shape3()
-        table = self.pos_table(feat_dim, dtype, coors_in_win.device)
+        key = (feat_dim, dtype, str(coors_in_win.device), self.pos_temperature, self.normalize_pos)
+        cache = self.__dict__.setdefault('_pos_table_cache', {})
+        table = cache.get(key)
+        if table is None:  # the table only depends on the configuration: build it once
+            table = cache[key] = self.pos_table(feat_dim, dtype, coors_in_win.device)
         c = coors_in_win.long()
         idx = (c[:, 0] * wy + c[:, 1]) * wx + c[:, 2]
         return table.index_select(0, idx)
