@@ -81,11 +81,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('SST_AMD_LIB', LIB_PATH)  # developer override: A/B builds of the same library
+    if not os.path.exists(path):
         raise RuntimeError(
-            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'{path} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(or `make -C sst_amd/csrc`). sst_amd has no CPU / eager fallback.')
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

@@ -36,6 +36,17 @@ constexpr int kGC = 64;     // channels per workgroup (kGH * kHD)
 #ifndef SST_WAVE_HEADS
 #define SST_WAVE_HEADS 4
 #endif
+// Block -> window order of the register-resident kernels.  Region batching lays the windows out level by level,
+// smallest token class first; reversed, the largest windows are dispatched first (longest-processing-time
+// first), which shortens the tail of the launch.
+#ifndef SST_SRA_REVERSE
+#define SST_SRA_REVERSE 1
+#endif
+#if SST_SRA_REVERSE
+#define SST_SRA_BLOCK(b, n) ((int)(n) - 1 - (int)(b))
+#else
+#define SST_SRA_BLOCK(b, n) ((int)(b))
+#endif
 constexpr int kWH = SST_WAVE_HEADS;  // heads (= waves) per workgroup of the register-resident kernels
 constexpr int kRS = 68;     // LDS row stride (floats)
 constexpr int kMaxTilesMfma = 9;
@@ -418,8 +429,9 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_wave_k(const float* __restri
                                                       const int32_t* __restrict__ winoff, int n_groups, int H,
                                                       float scale, float* __restrict__ O, int64_t ldo,
                                                       float* __restrict__ LSE) {
-  const int w = blockIdx.x / n_groups;
-  const int hg = blockIdx.x - w * n_groups;
+  const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
+  const int w = bid / n_groups;
+  const int hg = bid - w * n_groups;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
@@ -802,8 +814,9 @@ __global__ __launch_bounds__(64 * kWH) void sra_bwd_dq_k(const float* __restrict
                                                     const int32_t* __restrict__ winoff, int n_groups, int H,
                                                     float scale, float* __restrict__ dQ, int64_t lddq,
                                                     float* __restrict__ Dbuf) {
-  const int w = blockIdx.x / n_groups;
-  const int hg = blockIdx.x - w * n_groups;
+  const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
+  const int w = bid / n_groups;
+  const int hg = bid - w * n_groups;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
@@ -834,7 +847,7 @@ __global__ __launch_bounds__(64 * kWH) void sra_bwd_dkv_k(const float* __restric
   // would park all the real work on the even XCDs (measured: 1.36 waves/SIMD average, 169 us).
   const int per_ks = gridDim.x / ((NTMAX + 3) / 4);
   const int ks = blockIdx.x / per_ks;
-  const int rest = blockIdx.x - ks * per_ks;
+  const int rest = SST_SRA_BLOCK(blockIdx.x - ks * per_ks, per_ks);
   const int w = rest / n_groups;
   const int hg = rest - w * n_groups;
   const int beg = winoff[w];

@@ -16,6 +16,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int64_t sst_dev_align_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
   const int64_t ks0 = (int64_t)s * rows_per_split < m ? (int64_t)s * rows_per_split : m;
   const int64_t ks1 = ks0 + rows_per_split < m ? ks0 + rows_per_split : m;
   // this wave group's slice of [ks0, ks1), boundaries on multiples of 2*U rows
-  const int64_t per = sst_dev_align_up((ks1 - ks0 + KW - 1) / KW, 2 * U);
+  const int64_t per = sst_dev_align_up((ks1 - ks0 + KW - 1) / KW, 4 * U);
   int64_t k0 = ks0 + (int64_t)kw * per;
   int64_t k1 = k0 + per < ks1 ? k0 + per : ks1;
   if (k0 > ks1) k0 = ks1;
@@ -65,18 +67,21 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   float bs0 = 0.f, bs1 = 0.f;
+  const int o1off = has_o1 ? 32 : 0;  // without a second out tile the first one is read twice (its product is never stored)
   const float* pa = dy + (k0 + kk) * ld_dy + o0 + col;
   const float* pb = x + (k0 + kk) * ld_x + i0 + col;
-  // software pipeline: the loads of group g+1 are in flight while the MFMAs of group g issue
+  // software pipeline: the loads of group g+1 are in flight while the MFMAs of group g issue.  The prefetch is
+  // UNCONDITIONAL (past the last group the pointers simply stop advancing and the group is re-read): a
+  // conditional prefetch puts a branch between the loads and their first use, and the waitcnt insertion then
+  // waits at the join for (almost) every outstanding load, the fresh prefetch included (vmcnt(1) instead of
+  // vmcnt(#prefetch) — measured: no overlap at all).
   auto load = [&](float (&a0)[U], float (&a1)[U], float (&b)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       a0[u] = pa[(int64_t)u * 2 * ld_dy];
-      a1[u] = has_o1 ? pa[(int64_t)u * 2 * ld_dy + 32] : 0.f;
+      a1[u] = pa[(int64_t)u * 2 * ld_dy + o1off];
       b[u] = pb[(int64_t)u * 2 * ld_x];
     }
-    pa += (int64_t)2 * U * ld_dy;
-    pb += (int64_t)2 * U * ld_x;
   };
   auto comp = [&](const float (&a0)[U], const float (&a1)[U], const float (&b)[U]) {
 #pragma unroll
@@ -87,20 +92,30 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
       bs1 += a1[u];
     }
   };
-  const int64_t ng = (k1 - k0) / (2 * U);
+  // An EVEN number of groups goes through the pipeline (no exit test between a prefetch and its use — LLVM would
+  // sink the loads below the exit branch); rows left over are handled by the tail loop.
+  const int64_t ng = ((k1 - k0) / (4 * U)) * 2;
   float A0[U], A1[U], B0[U], C0[U], C1[U], D0[U];
-  if (ng > 0) load(A0, A1, B0);
-  int64_t gi = 0;
-  while (gi < ng) {
-    bool more = gi + 1 < ng;
-    if (more) load(C0, C1, D0);
-    comp(A0, A1, B0);
-    ++gi;
-    if (!more) break;
-    more = gi + 1 < ng;
-    if (more) load(A0, A1, B0);
-    comp(C0, C1, D0);
-    ++gi;
+  if (ng > 0) {
+    load(A0, A1, B0);
+    for (int64_t gi = 0; gi < ng; gi += 2) {
+      pa += (int64_t)2 * U * ld_dy;
+      pb += (int64_t)2 * U * ld_x;
+      load(C0, C1, D0);
+      comp(A0, A1, B0);
+      const int64_t adv = gi + 2 < ng ? 2 * U : 0;
+      pa += adv * ld_dy;
+      pb += adv * ld_x;
+      load(A0, A1, B0);
+      comp(C0, C1, D0);
+      // scheduling pattern for this block: [prefetch][MFMA group][prefetch][MFMA group]
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * U, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * U, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * U, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * U, 0);
+    }
+    pa += (int64_t)2 * U * ld_dy;
+    pb += (int64_t)2 * U * ld_x;
   }
   int64_t k = k0 + ng * 2 * U;
   for (; k < k1; k += 2) {  // ragged tail, row-guarded
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy
   const int s = blockIdx.x;
   const int64_t ks0 = (int64_t)s * rows_per_split < m ? (int64_t)s * rows_per_split : m;
   const int64_t ks1 = ks0 + rows_per_split < m ? ks0 + rows_per_split : m;
-  const int64_t per = sst_dev_align_up((ks1 - ks0 + kwn - 1) / kwn, 2 * U);
+  const int64_t per = sst_dev_align_up((ks1 - ks0 + kwn - 1) / kwn, 4 * U);
   int64_t k0 = ks0 + (int64_t)kw * per;
   if (k0 > ks1) k0 = ks1;
   const int64_t k1 = k0 + per < ks1 ? k0 + per : ks1;
@@ -203,47 +218,91 @@ __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy
   const float* pa = dy + (k0 + kk) * ld_dy + o0 + 4 * col;
   const float* pb = x + (k0 + kk) * ld_x + i0 + 2 * col;
 
-  auto load = [&](float4 (&a)[U], float2 (&b)[U]) {
+  // Software pipeline with a prefetch distance of one group (2*U rows): the loads of group g+1 are in flight while
+  // the 8*U MFMAs of group g issue.  The compiler cannot express this: its scheduler sinks the prefetch next to
+  // the first use (register pressure) and its waitcnt insertion then waits for everything, so with one wave per
+  // SIMD every group paid a full memory latency (measured 54 % of the fp32 MFMA rate).  The loads are therefore
+  // issued from inline asm (invisible to the waitcnt pass) and the wait is explicit: `s_waitcnt vmcnt(2*U)`
+  // leaves exactly the fresh prefetch outstanding.  The wait statement takes the group's registers as in/out
+  // operands, so every MFMA that consumes them is ordered after it by data dependence.
+  float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+  auto load = [&](f32x4 (&a)[U], f32x2 (&b)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      a[u] = *(const float4*)(pa + (int64_t)u * 2 * ld_dy);
-      b[u] = *(const float2*)(pb + (int64_t)u * 2 * ld_x);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[u]) : "v"(pa + (int64_t)u * 2 * ld_dy));
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b[u]) : "v"(pb + (int64_t)u * 2 * ld_x));
     }
+  };
+  auto wait_prev = [&](f32x4 (&a)[U], f32x2 (&b)[U]) {  // all but the newest 2*U loads have landed
+    static_assert(U == 2 || U == 4, "operand list below");
+    if constexpr (U == 4)
+      asm volatile("s_waitcnt vmcnt(8)"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+  };
+  // The MFMAs of the pipelined loop are asm statements as well: volatile asm keeps program order, so the previous
+  // contents of a register group are dead before the next prefetch into it is issued (with builtin MFMAs, which
+  // may float below the load statements, the allocator would have to copy the still-in-flight registers).
+  // No MFMA -> MFMA hazard arises inside the loop: an accumulator is revisited after 7 other 16-pass MFMAs.
+  auto comp = [&](const f32x4 (&a)[U], const f32x2 (&b)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#define SST_MFMA(Q, P, AV, BV) \
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[Q][P]) : "v"(AV), "v"(BV))
+      SST_MFMA(0, 0, a[u].x, b[u].x);
+      SST_MFMA(1, 0, a[u].y, b[u].x);
+      SST_MFMA(2, 0, a[u].z, b[u].x);
+      SST_MFMA(3, 0, a[u].w, b[u].x);
+      SST_MFMA(0, 1, a[u].x, b[u].y);
+      SST_MFMA(1, 1, a[u].y, b[u].y);
+      SST_MFMA(2, 1, a[u].z, b[u].y);
+      SST_MFMA(3, 1, a[u].w, b[u].y);
+#undef SST_MFMA
+      // (asm for the same reason: a floating v_add would keep the old registers alive across the next prefetch)
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bs0) : "v"(a[u].x));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bs1) : "v"(a[u].y));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bs2) : "v"(a[u].z));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bs3) : "v"(a[u].w));
+    }
+  };
+  // An even number of groups goes through the pipeline; rows left over are handled by the tail loop.
+  const int64_t ng = ((k1 - k0) / (4 * U)) * 2;
+  f32x4 A0[U], C0[U];
+  f32x2 B0[U], D0[U];
+  if (ng > 0) {
+    load(A0, B0);
+    for (int64_t gi = 0; gi < ng; gi += 2) {
+      pa += (int64_t)2 * U * ld_dy;
+      pb += (int64_t)2 * U * ld_x;
+      load(C0, D0);
+      wait_prev(A0, B0);
+      comp(A0, B0);
+      const int64_t adv = gi + 2 < ng ? 2 * U : 0;  // past the end the last group is simply read again
+      pa += adv * ld_dy;
+      pb += adv * ld_x;
+      load(A0, B0);
+      wait_prev(C0, D0);
+      comp(C0, D0);
+    }
+    // The redundant last prefetch must land before its registers are reused: the statement names them as in/out
+    // operands, which keeps them allocated until here (otherwise the allocator hands them out right after the
+    // loop and the late load overwrites e.g. a pointer).  The last MFMAs (16 passes, opaque to the hazard
+    // recognizer) must have written their accumulators before anything reads them.
+    if constexpr (U == 4)
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                   : "+v"(A0[0]), "+v"(A0[1]), "+v"(A0[2]), "+v"(A0[3]), "+v"(B0[0]), "+v"(B0[1]), "+v"(B0[2]),
+                     "+v"(B0[3])
+                   :
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                   : "+v"(A0[0]), "+v"(A0[1]), "+v"(B0[0]), "+v"(B0[1])
+                   :
+                   : "memory");
     pa += (int64_t)2 * U * ld_dy;
     pb += (int64_t)2 * U * ld_x;
-  };
-  auto comp = [&](const float4 (&a)[U], const float2 (&b)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc[0][0] = mfma32(a[u].x, b[u].x, acc[0][0]);
-      acc[1][0] = mfma32(a[u].y, b[u].x, acc[1][0]);
-      acc[2][0] = mfma32(a[u].z, b[u].x, acc[2][0]);
-      acc[3][0] = mfma32(a[u].w, b[u].x, acc[3][0]);
-      acc[0][1] = mfma32(a[u].x, b[u].y, acc[0][1]);
-      acc[1][1] = mfma32(a[u].y, b[u].y, acc[1][1]);
-      acc[2][1] = mfma32(a[u].z, b[u].y, acc[2][1]);
-      acc[3][1] = mfma32(a[u].w, b[u].y, acc[3][1]);
-      bsum.x += a[u].x;
-      bsum.y += a[u].y;
-      bsum.z += a[u].z;
-      bsum.w += a[u].w;
-    }
-  };
-  const int64_t ng = (k1 - k0) / (2 * U);
-  float4 A0[U], C0[U];
-  float2 B0[U], D0[U];
-  if (ng > 0) load(A0, B0);
-  int64_t gi = 0;
-  while (gi < ng) {
-    bool more = gi + 1 < ng;
-    if (more) load(C0, D0);
-    comp(A0, B0);
-    ++gi;
-    if (!more) break;
-    more = gi + 1 < ng;
-    if (more) load(A0, B0);
-    comp(C0, D0);
-    ++gi;
+    bsum = make_float4(bs0, bs1, bs2, bs3);
   }
   for (int64_t k = k0 + ng * 2 * U; k < k1; k += 2) {  // ragged tail, row-guarded
     const bool ok = (k + kk) < k1;
@@ -416,9 +475,20 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
     s = wide_splits(m, &rps);
     const int ntile = (out / 128) * (in / 64);
     const size_t lds = (size_t)(4 / ntile - 1) * ntile * 132 * 64 * sizeof(float);
-    SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(wgrad_wide_k<4>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
-                       part_w, part_b);
+    static int wide_u = 0;
+    if (wide_u == 0) {
+      const char* e = getenv("SST_WGRAD_U");
+      wide_u = e ? atoi(e) : 4;
+    }
+    if (wide_u == 2) {
+      SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(wgrad_wide_k<2>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
+                         part_w, part_b);
+    } else {
+      SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(wgrad_wide_k<4>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
+                         part_w, part_b);
+    }
   } else {
     s = pick_splits(m, out, in, &rps);
     const int tiles = ((out + kWgTileO - 1) / kWgTileO) * ((in + kWgTileI - 1) / kWgTileI);

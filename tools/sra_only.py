@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Runs only the SRA attention-core kernels on the bench workload (for rocprofv3 --pmc passes)."""
+"""Runs only the SRA attention-core kernels on the bench workload (for rocprofv3 --pmc passes).
+Usage: sra_only.py [iters] [sorted]   ('sorted': token rows laid out in window order, i.e. tok = arange)"""
 import os
 import sys
 
@@ -14,13 +15,16 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 _, _, info = mb.frame_plan()
 m = info['voxel_feats'].size(0)
 plan = info['sra_plan_shift0']
-qk = torch.randn(m, 256, device=mb.DEV)
-v = torch.randn(m, 128, device=mb.DEV)
+if len(sys.argv) > 2 and sys.argv[2] == 'sorted':
+    assert plan.n_tokens == m
+    plan = K.WindowPlan(torch.arange(m, dtype=torch.int32, device=mb.DEV), plan.winoff, plan.n_windows, m,
+                        plan.max_tokens)
+qkv = torch.randn(m, 384, device=mb.DEV)
 do = torch.randn(m, 128, device=mb.DEV)
-dqk = torch.empty_like(qk)
-dv = torch.empty_like(v)
+dqkv = torch.empty_like(qkv)
+q, k, v = qkv[:, :128], qkv[:, 128:256], qkv[:, 256:]
 for _ in range(iters):
-    o, lse = K._sra_fwd(qk[:, :128], qk[:, 128:], v, plan, 8, 0.25, 0)
-    K._sra_bwd(qk[:, :128], qk[:, 128:], v, o, lse, do, plan, 8, 0.25, 0, dqk[:, :128], dqk[:, 128:], dv)
+    o, lse = K._sra_fwd(q, k, v, plan, 8, 0.25, 0)
+    K._sra_bwd(q, k, v, o, lse, do, plan, 8, 0.25, 0, dqkv[:, :128], dqkv[:, 128:256], dqkv[:, 256:])
 torch.cuda.synchronize()
 print('tokens', m, 'windows', plan.n_windows)
