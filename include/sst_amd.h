@@ -246,6 +246,35 @@ int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in);
 int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out, int in, int64_t ld_dy,
                         int64_t ld_x, float* d_dw, float* d_db, void* d_workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (a11/a12, §8 f1) BatchNorm1d (+ ReLU) of the point-wise "Linear -> norm -> ReLU" layers of DynamicVFE / SIR
+ * (models/voxel_encoders/utils.py:107-144; norm = BN1d or naiveSyncBN1d, ops/norm.py:28-86) over tall
+ * x[n, c] (row strides in elements, c % 4 == 0, c <= 1024, 16-byte aligned rows).  Replaces the library's
+ * batch_norm statistics / backward-reduce kernels and the separate ReLU passes.
+ *   sst_bn_stats_f32: d_mean[c], d_var[c] = column mean and BIASED variance E[x^2] - mean^2 (fp64 sums).
+ *   sst_bn_act_fwd_f32: y = act(x * scale[c] + shift[c]); act 0 = identity, 1 = ReLU
+ *     (scale = weight * rsqrt(var + eps), shift = bias - mean * scale; the [c]-sized algebra, running
+ *      statistics and the cross-rank averaging of naiveSyncBN stay on the host side).
+ *   sst_bn_act_bwd_reduce_f32: d_sum_g[c] = sum g, d_sum_gxhat[c] = sum g * xhat with g = dy masked by the
+ *     activation and xhat = (x - mean) * invstd  (= dbias, dweight of the affine norm).
+ *   sst_bn_act_bwd_apply_f32: dx = scale * (g - coef_a[c] - xhat * coef_b[c])
+ *     (training: coef_a = sum_g / count, coef_b = sum_gxhat / count; eval: zeros).
+ * Workspace: sst_bn_workspace_bytes(n, c) for the stats / reduce calls.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_bn_workspace_bytes(int64_t n, int c);
+int sst_bn_stats_f32(const float* d_x, int64_t n, int c, int64_t ld, float* d_mean, float* d_var,
+                     void* d_workspace, void* stream);
+int sst_bn_act_fwd_f32(const float* d_x, int64_t n, int c, int64_t ldx, const float* d_scale,
+                       const float* d_shift, int act, float* d_y, int64_t ldy, void* stream);
+int sst_bn_act_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                              const float* d_mean, const float* d_invstd, const float* d_scale,
+                              const float* d_shift, int act, float* d_sum_g, float* d_sum_gxhat,
+                              void* d_workspace, void* stream);
+int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                             const float* d_mean, const float* d_invstd, const float* d_scale,
+                             const float* d_shift, const float* d_coef_a, const float* d_coef_b, int act,
+                             float* d_dx, int64_t lddx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,138 @@ def _sync_bn_forward(self, input, reduce_dims):
     return scale, bias
 
 
+def _dist_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+class _BatchNormActFn(Function):
+    """y = act(x * scale + shift) with scale = weight * invstd, shift = bias - mean * scale, through
+    csrc/bn.hip.  ``batch_stats``: mean / invstd were computed from this batch (training), so the gradient
+    flows through them: dx = scale * (g - (G1 + xhat * G2) / count), G1 = sum g, G2 = sum g * xhat taken over
+    every rank when ``sync`` (naiveSyncBN averages the per-rank means, ops/norm.py:53-58, hence
+    count = world_size * N_local; its AllReduce backward sums the statistic gradients, :20-24)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean, invstd, act, batch_stats, count, sync):
+        from . import _lib
+        n, c = x.shape
+        scale = invstd if weight is None else weight.detach() * invstd
+        shift = -mean * scale if bias is None else bias.detach() - mean * scale
+        scale, shift = scale.contiguous(), shift.contiguous()
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        rc = _lib.load().sst_bn_act_fwd_f32(_lib.ptr(x), n, c, x.stride(0), _lib.ptr(scale), _lib.ptr(shift),
+                                            int(act), _lib.ptr(y), y.stride(0), _lib.stream_ptr())
+        _lib.check(rc, 'sst_bn_act_fwd_f32')
+        ctx.save_for_backward(x, mean, invstd, scale, shift)
+        ctx.cfg = (int(act), bool(batch_stats), float(count), bool(sync), weight is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        x, mean, invstd, scale, shift = ctx.saved_tensors
+        act, batch_stats, count, sync, has_w, has_b = ctx.cfg
+        n, c = x.shape
+        dy = dy.contiguous()
+        lib = _lib.load()
+        sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
+        rc = lib.sst_bn_act_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(x), n, c, dy.stride(0), x.stride(0), _lib.ptr(mean),
+                                           _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), act, _lib.ptr(sums[0]),
+                                           _lib.ptr(sums[1]), _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, 'sst_bn_act_bwd_reduce_f32')
+        dweight = sums[1].clone() if has_w else None
+        dbias = sums[0].clone() if has_b else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if batch_stats:
+                if sync:
+                    dist.all_reduce(sums, async_op=False)
+                coef = sums * (1.0 / count)
+            else:
+                coef = torch.zeros_like(sums)
+            dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+            rc = lib.sst_bn_act_bwd_apply_f32(_lib.ptr(dy), _lib.ptr(x), n, c, dy.stride(0), x.stride(0),
+                                              _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift),
+                                              _lib.ptr(coef[0]), _lib.ptr(coef[1]), act, _lib.ptr(dx), dx.stride(0),
+                                              _lib.stream_ptr())
+            _lib.check(rc, 'sst_bn_act_bwd_apply_f32')
+        return dx, dweight, dbias, None, None, None, None, None, None
+
+
+def _bn_kernel_ok(bn, x):
+    return (isinstance(bn, nn.BatchNorm1d) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+            and x.size(0) > 0 and x.size(1) % 4 == 0 and x.size(1) <= 1024 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def batch_norm_act(bn, x, relu=False):
+    """``relu(bn(x))`` / ``bn(x)`` for a BatchNorm1d-family module on [N, C] point features.
+
+    CUDA float32 inputs go through the fused kernels (csrc/bn.hip) with the module's exact bookkeeping:
+    nn.BatchNorm1d (torch/nn/modules/batchnorm.py: biased batch variance for the output, unbiased for
+    running_var, num_batches_tracked) or, for NaiveSyncBatchNorm1d in distributed training, the reference's
+    averaging of per-rank [mean || meansqr] and its ``running += momentum * (stat - running)`` update
+    (mmdet3d/ops/norm.py:50-66).  Anything else (CPU tensors, 3-D inputs) takes the module's own forward."""
+    if not _bn_kernel_ok(bn, x):
+        y = bn(x)
+        return torch.relu(y) if relu else y
+    from . import _lib
+    n, c = x.shape
+    world = _dist_world()
+    sync = isinstance(bn, NaiveSyncBatchNorm1d) and world > 1 and bn.training
+    batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
+    count = 1.0
+    if batch_stats:
+        lib = _lib.load()
+        xd = x.detach()
+        stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
+        rc = lib.sst_bn_stats_f32(_lib.ptr(xd), n, c, xd.stride(0), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(ws),
+                                  _lib.stream_ptr())
+        _lib.check(rc, 'sst_bn_stats_f32')
+        mean, var = stats[0], stats[1]
+        if sync:
+            vec = torch.cat([mean, var + mean * mean], dim=0)  # [mean || meansqr], ops/norm.py:53
+            dist.all_reduce(vec, async_op=False)
+            vec = vec * (1.0 / world)
+            mean, meansqr = vec[:c], vec[c:]
+            var = (meansqr - mean * mean).clamp_(min=0)
+            with torch.no_grad():
+                bn.running_mean += bn.momentum * (mean - bn.running_mean)
+                bn.running_var += bn.momentum * (var - bn.running_var)
+            count = float(world * n)
+        else:
+            count = float(n)
+            if bn.training and bn.track_running_stats:
+                with torch.no_grad():
+                    factor = 0.0 if bn.momentum is None else bn.momentum
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                        if bn.momentum is None:
+                            factor = 1.0 / float(bn.num_batches_tracked)
+                    unbiased = var * (n / (n - 1.0)) if n > 1 else var
+                    bn.running_mean.mul_(1.0 - factor).add_(mean, alpha=factor)
+                    bn.running_var.mul_(1.0 - factor).add_(unbiased, alpha=factor)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    invstd = torch.rsqrt(var + bn.eps)
+    return _BatchNormActFn.apply(x, bn.weight, bn.bias, mean.contiguous(), invstd.contiguous(), bool(relu),
+                                 batch_stats, count, sync)
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters / buffers / state_dict) whose [N, C] CUDA forward and backward run through
+    csrc/bn.hip; what ``build_norm_layer(dict(type='BN1d'))`` returns."""
+
+    def forward(self, input):
+        if _bn_kernel_ok(self, input):
+            return batch_norm_act(self, input, relu=False)
+        return super().forward(input)
+
+
 class NaiveSyncBatchNorm1d(nn.BatchNorm1d):
     """mmdet3d/ops/norm.py:28-86."""
 
@@ -53,6 +185,8 @@ class NaiveSyncBatchNorm1d(nn.BatchNorm1d):
 
     def forward(self, input):
         input = input.float()
+        if _bn_kernel_ok(self, input):
+            return batch_norm_act(self, input, relu=False)
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1 or not self.training:
             return super().forward(input)
         assert input.shape[0] > 0, 'SyncBN does not support empty inputs'
@@ -84,7 +218,7 @@ class NaiveSyncBatchNorm2d(nn.BatchNorm2d):
 
 NORM_LAYERS = {
     'BN': nn.BatchNorm2d,
-    'BN1d': nn.BatchNorm1d,
+    'BN1d': BatchNorm1d,
     'BN2d': nn.BatchNorm2d,
     'BN3d': nn.BatchNorm3d,
     'SyncBN': nn.SyncBatchNorm,

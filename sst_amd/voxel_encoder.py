@@ -16,7 +16,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .dense import tall_linear
-from .norm import build_norm_layer
+from .norm import batch_norm_act, build_norm_layer
 from .registry import VOXEL_ENCODERS
 from .sst_ops import build_mlp, get_activation_layer, scatter_v2, unique_with_plan
 from .voxel import DynamicScatter, build_scatter_plan
@@ -33,8 +33,9 @@ class DynamicVFELayer(nn.Module):
 
     def forward(self, inputs):
         x = tall_linear(inputs, self.linear.weight, None)
-        x = self.norm(x)
-        return F.relu(x)
+        if isinstance(self.norm, nn.BatchNorm1d):
+            return batch_norm_act(self.norm, x, relu=True)  # fused norm + ReLU (csrc/bn.hip)
+        return F.relu(self.norm(x))
 
 
 class DynamicVFELayerV2(nn.Module):
@@ -53,8 +54,11 @@ class DynamicVFELayerV2(nn.Module):
         if self.dropout is not None:
             inputs = self.dropout(inputs)
         x = tall_linear(inputs, self.linear.weight, None)
-        x = self.norm(x)
-        return self.act(x)
+        if isinstance(self.norm, nn.BatchNorm1d):
+            if isinstance(self.act, nn.ReLU):
+                return batch_norm_act(self.norm, x, relu=True)
+            return self.act(batch_norm_act(self.norm, x, relu=False))
+        return self.act(self.norm(x))
 
 
 @VOXEL_ENCODERS.register_module()
