@@ -71,11 +71,13 @@ class Pipeline(torch.nn.Module):
         return self.backbone(info)[0]['voxel_feats']
 
 
-def flatten_grads(model):
-    """One flat fp32 gradient bucket (views as .grad) so the data-parallel exchange is a single all-reduce."""
-    params = [p for p in model.parameters() if p.requires_grad]
-    total = sum(p.numel() for p in params)
-    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+def allreduce_grads(params, world):
+    """Data-parallel gradient exchange: ONE all-reduce over a flat fp32 bucket (RCCL ring over xGMI), after which
+    every ``p.grad`` is a view of the averaged bucket.  Gradients are produced with ``p.grad = None`` before the
+    backward pass, so autograd assigns them (no per-parameter accumulate kernels, no bucket memset)."""
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat)
+    flat.div_(world)
     off = 0
     for p in params:
         p.grad = flat[off:off + p.numel()].view_as(p)
@@ -145,7 +147,7 @@ def main():
     model = Pipeline(args.blocks).to(dev)
     model.train()
     model.backbone.set_impl(args.impl)
-    flat_grad = flatten_grads(model)
+    params = [p for p in model.parameters() if p.requires_grad]
     frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
     torch.manual_seed(1234 + rank)            # per-rank voxel shuffles
 
@@ -153,12 +155,12 @@ def main():
         if args.fwd_only:
             with torch.no_grad():
                 return model(frames)
-        flat_grad.zero_()
+        for p in params:
+            p.grad = None
         out = model(frames)
         out.sum().backward()
         if world > 1:
-            dist.all_reduce(flat_grad)
-            flat_grad.div_(world)
+            allreduce_grads(params, world)
         return out
 
     for _ in range(args.warmup):

@@ -152,22 +152,22 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restri
   for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
 }
 
-// out[i] = sum_b partials[b][i], i < width.  Block = 32 columns x 8 slices of the nb partial rows.
-__global__ __launch_bounds__(256) void colsum_partials_k(const float* __restrict__ partials, int nb, int width,
-                                                         float* __restrict__ out0, float* __restrict__ out1,
-                                                         int split) {
-  __shared__ float red[8][33];
+// out[i] = sum_b partials[b][i], i < width.  Block = 32 columns x 32 slices of the nb partial rows.
+__global__ __launch_bounds__(1024) void colsum_partials_k(const float* __restrict__ partials, int nb, int width,
+                                                          float* __restrict__ out0, float* __restrict__ out1,
+                                                          int split) {
+  __shared__ float red[32][33];
   const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + cx;
   float acc = 0.f;
   if (i < width)
-    for (int b = gy; b < nb; b += 8) acc += partials[(int64_t)b * width + i];
+    for (int b = gy; b < nb; b += 32) acc += partials[(int64_t)b * width + i];
   red[gy][cx] = acc;
   __syncthreads();
   if (gy == 0 && i < width) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    for (int k = 0; k < 32; ++k) t += red[k][cx];
     if (i < split)
       out0[i] = t;
     else
@@ -266,7 +266,7 @@ int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float
   float* partials = (float*)d_workspace;
   hipLaunchKernelGGL(add_ln_bwd_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
                      (const float2*)d_stats, d_weight, m, c, d_dx, partials);
-  hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(256), 0, st, partials, grid, 2 * c, d_dweight,
+  hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
                      d_dbias, c);
   SST_LAUNCH_CHECK();
   return SST_OK;

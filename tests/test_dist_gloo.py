@@ -36,11 +36,15 @@ def _worker(rank, world, port, ret):
             bn.bias.copy_(torch.linspace(-0.2, 0.2, 8))
         model = torch.nn.Sequential(bn, lin)
         model.train()
-        flat = bench.flatten_grads(model)
         y = model(x)
         (y ** 2).sum().backward()
-        dist.all_reduce(flat)
-        flat.div_(world)
+        params = [p for p in model.parameters() if p.requires_grad]
+        local = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+        flat = bench.allreduce_grads(params, world)
+        assert all(p.grad.data_ptr() >= flat.data_ptr() for p in params)  # .grad are views of the bucket
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(flat, sum(gathered) / world, atol=1e-6)
         ret[rank] = dict(y=y.detach(), gx=x.grad.detach(), flat=flat.clone(), mean=bn.running_mean.clone(),
                          gw=bn.weight.grad.clone())
     finally:

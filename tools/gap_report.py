@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""GPU idle analysis of a rocprofv3 --kernel-trace CSV: busy time vs wall span and the largest gaps
+(with the kernels on either side).  Usage: gap_report.py <kernel_trace.csv> [skip_fraction]"""
+import csv
+import re
+import sys
+
+
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'^void ', '', n)
+    n = re.sub(r'at::native::', '', n)
+    return n[:70]
+
+
+def main(path, skip=0.5):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    rows.sort()
+    rows = rows[int(len(rows) * skip):]  # steady state only
+    span = rows[-1][1] - rows[0][0]
+    busy = 0
+    cur_end = rows[0][0]
+    gaps = []
+    for i, (s, e, n) in enumerate(rows):
+        if s > cur_end:
+            gaps.append((s - cur_end, rows[i - 1][2], n))
+            busy += e - s
+        else:
+            busy += max(0, e - max(s, cur_end))
+        cur_end = max(cur_end, e)
+    print(f'kernels {len(rows)}  span {span / 1e6:.3f} ms  busy {busy / 1e6:.3f} ms  idle {100 * (1 - busy / span):.1f} %')
+    per = {}
+    for st, en, n in rows:
+        m = re.match(r'(Cijk_\w+?_MT\d+x\d+x\d+)', n)
+        k = ('hipBLASLt ' + m.group(1)) if m else short(n)
+        t = per.setdefault(k, [0, 0])
+        t[0] += en - st
+        t[1] += 1
+    nsteps = sum(1 for r in rows if 'dynamic_voxelize_k' in r[2]) or 1
+    print(f'steady-state steps (dynamic_voxelize_k launches): {nsteps};  busy {busy / 1e6 / nsteps:.3f} ms/step')
+    for k, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
+        print(f'  {t / 1e6 / nsteps:8.3f} ms/step  {c / nsteps:6.1f} calls/step  avg {t / c / 1e3:7.1f} us  {k}')
+    hist = {}
+    for g, a, b in gaps:
+        k = (short(a), short(b))
+        t = hist.setdefault(k, [0, 0])
+        t[0] += g
+        t[1] += 1
+    print('largest idle contributors (total us, count, after -> before):')
+    for k, (t, c) in sorted(hist.items(), key=lambda kv: -kv[1][0])[:8]:
+        print(f'  {t / 1e3:9.1f} us  x{c:<4d} {k[0]}  ->  {k[1]}')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)
