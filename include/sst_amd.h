@@ -275,6 +275,20 @@ int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int
                              const float* d_shift, const float* d_coef_a, const float* d_coef_b, int act,
                              float* d_dx, int64_t lddx, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tall fp32 linear layer  y[m, n] (+)= x[m, k] W^T + bias  on the fp32 MFMA pipe with W resident in LDS
+ * (projections / FFN of an encoder layer and their data gradients, models/sst/sst_basic_block_v2.py:41-75,
+ * :104-126; replaces the library GEMM behind nn.Linear / F.linear for these shapes).
+ *   trans_w = 0: d_w is [n][k] row-major (nn.Linear weight, forward).
+ *   trans_w = 1: d_w is [k][n] row-major (data gradient dx = dy W of a layer whose weight is [out = k][in = n]).
+ *   accumulate = 1: y += ... (residual / gradient accumulation rides on the product).
+ * Supported: n == 128, k in {128, 256}; row strides in elements (multiples of 4, 16-byte aligned rows);
+ * d_bias may be NULL.  Other shapes return SST_ERR_UNSUPPORTED (callers use the library GEMM for them).
+ * ---------------------------------------------------------------------------------------------- */
+int sst_tall_linear_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias,
+                        int64_t m, int n, int k, int trans_w, int accumulate, float* d_y, int64_t ldy,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,8 @@ _SIGNATURES = {
     'sst_weight_grad_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_colsum_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_colsum_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sst_tall_linear_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64,
+                                    c_ptr]),
     'sst_bn_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_bn_stats_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_bn_act_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),

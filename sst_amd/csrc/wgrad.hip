@@ -480,12 +480,17 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
       const char* e = getenv("SST_WGRAD_U");
       wide_u = e ? atoi(e) : 4;
     }
+    static bool configured = false;  // once: the attribute call costs tens of microseconds on the host
+    if (!configured) {
+      const int lds_max = 3 * 132 * 64 * (int)sizeof(float);
+      SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      configured = true;
+    }
     if (wide_u == 2) {
-      SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(wgrad_wide_k<2>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
                          part_w, part_b);
     } else {
-      SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(wgrad_wide_k<4>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
                          part_w, part_b);
     }
@@ -494,7 +499,11 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
     const int tiles = ((out + kWgTileO - 1) / kWgTileO) * ((in + kWgTileI - 1) / kWgTileI);
     constexpr int KW = 2;
     const size_t lds = (size_t)(KW - 1) * 4 * 34 * 64 * sizeof(float);
-    SST_HIP(hipFuncSetAttribute((const void*)wgrad_k<8, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static bool configured_narrow = false;
+    if (!configured_narrow) {
+      SST_HIP(hipFuncSetAttribute((const void*)wgrad_k<8, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured_narrow = true;
+    }
     hipLaunchKernelGGL((wgrad_k<8, KW>), dim3((unsigned)(s * tiles)), dim3(256 * KW), lds, st, d_dy, d_x, m, out, in,
                        ld_dy, ld_x, rps, part_w, part_b);
   }

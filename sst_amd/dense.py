@@ -71,6 +71,26 @@ def weight_bias_grad(dy, x, want_bias, out_w=None, out_b=None):
     return dw, db
 
 
+def tall_gemm(x, w, bias=None, trans_w=False, out=None, accumulate=False):
+    """out (+)= x @ (w if trans_w else w.t()) + bias through csrc/tall_gemm.hip (W resident in LDS, fp32 MFMA);
+    returns None when the shape is not one the kernel is built for (the caller then uses the library GEMM)."""
+    m, k = x.shape
+    n = w.size(1) if trans_w else w.size(0)
+    kw = w.size(0) if trans_w else w.size(1)
+    if (n != 128 or k not in (128, 256) or kw != k or x.dtype != torch.float32 or not x.is_cuda
+            or x.stride(1) != 1 or w.stride(1) != 1 or x.stride(0) % 4 or w.stride(0) % 4
+            or x.data_ptr() % 16 or w.data_ptr() % 16):
+        return None
+    if out is None:
+        assert not accumulate
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    assert out.stride(1) == 1 and out.size(0) == m and out.size(1) == n
+    rc = _lib.load().sst_tall_linear_f32(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), m, n, k,
+                                         int(trans_w), int(accumulate), _lib.ptr(out), out.stride(0), _lib.stream_ptr())
+    _lib.check(rc, 'sst_tall_linear_f32')
+    return out
+
+
 class TallLinear(Function):
 
     @staticmethod

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
-from .dense import add_layer_norm, add_ln_bwd, add_ln_fwd, tall_linear, weight_bias_grad
+from .dense import tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, tall_linear, weight_bias_grad
 from .norm import build_norm_layer
 
 
@@ -130,6 +130,33 @@ class WindowAttention(nn.Module):
         return tall_linear(o, attn.out_proj.weight, attn.out_proj.bias)
 
 
+# Square (128 -> 128) projections of an encoder layer go through the LDS-resident-weight kernel (csrc/tall_gemm.hip):
+# 41 us against 47 us for the best library solution at 90 k tokens.  The K = 256 shapes stay with the library
+# (62 us vs 54 us); SST_AMD_TALL_GEMM=0 switches the kernel off, =2 also routes the K = 256 shapes through it.
+import os as _os
+_TALL_GEMM = int(_os.environ.get('SST_AMD_TALL_GEMM', '1'))
+
+
+def _linear_fwd(x, w, b):
+    """x @ w.t() + b"""
+    if _TALL_GEMM and w.size(0) == 128 and (w.size(1) == 128 or _TALL_GEMM > 1):
+        y = tall_gemm(x, w, b)
+        if y is not None:
+            return y
+    return torch.addmm(b, x, w.t())
+
+
+def _linear_dgrad(dy, w, out=None):
+    """dy @ w (w: [out_features, in_features]); ``out`` given: out += dy @ w in place."""
+    if _TALL_GEMM and w.size(1) == 128 and (w.size(0) == 128 or _TALL_GEMM > 1):
+        y = tall_gemm(dy, w, None, trans_w=True, out=out, accumulate=out is not None)
+        if y is not None:
+            return y
+    if out is not None:
+        return out.addmm_(dy, w)
+    return dy @ w
+
+
 class FusedEncoderLayerFn(torch.autograd.Function):
     """One post-norm SRA encoder layer (sst_basic_block_v2.py:104-119) as a single autograd node.
 
@@ -144,14 +171,14 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         x = x.contiguous()
         xp = x + pos if pos is not None else x
         qk = torch.addmm(b_in[:2 * c], xp, w_in[:2 * c].t())
-        v = torch.addmm(b_in[2 * c:], x, w_in[2 * c:].t())
+        v = _linear_fwd(x, w_in[2 * c:], b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
         o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
-        a = torch.addmm(b_out, o, w_out.t())
+        a = _linear_fwd(o, w_out, b_out)
         y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps)
         pre = torch.addmm(b1, y1, w1.t())
         h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
-        f = torch.addmm(b2, h, w2.t())
+        f = _linear_fwd(h, w2, b2)
         y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps)
         ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
         ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
@@ -169,10 +196,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         else:
             dpre = dh * (pre > 0).to(dh.dtype)
         dw1, db1 = weight_bias_grad(dpre, y1, True)
-        dy1 = ds2.addmm_(dpre, w1)                                    # residual + FFN branch: GEMM with beta = 1
+        dy1 = _linear_dgrad(dpre, w1, out=ds2)                        # residual + FFN branch: GEMM with beta = 1
         ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
         dwo, dbo = weight_bias_grad(ds1, o, True)
-        do = ds1 @ w_out
+        do = _linear_dgrad(ds1, w_out)
         # dq | dk | dv in ONE [M, 3C] buffer: d(x) of the whole in-projection is then a single GEMM
         dqkv = torch.empty((x.size(0), 3 * c), dtype=torch.float32, device=x.device)
         dqk, dv = dqkv[:, :2 * c], dqkv[:, 2 * c:]

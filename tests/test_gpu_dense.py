@@ -73,3 +73,43 @@ def test_colsum(m, c):
     assert float((out.double() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
     xs = torch.randn(m, 2 * c, generator=g).to(DEV)[:, c:]   # row-strided view
     assert float((colsum(xs).double() - xs.double().sum(0)).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('m', [1, 31, 32, 33, 1000, 8192, 90107, 262144])
+@pytest.mark.parametrize('k,trans,acc', [(128, False, False), (256, False, False), (128, True, True), (256, True, True),
+                                         (256, True, False)])
+def test_tall_gemm_matches_float64(m, k, trans, acc):
+    """csrc/tall_gemm.hip (hand-pipelined: asm-issued loads with explicit waits) against a float64 product.
+    Repeated launches: a register touched while its load is still in flight would show up as run-to-run noise."""
+    from sst_amd.dense import tall_gemm
+    dev = torch.device('cuda:0')
+    torch.manual_seed(m + k)
+    x = torch.randn(m, k, device=dev)
+    w = torch.randn(k, 128, device=dev) if trans else torch.randn(128, k, device=dev)
+    b = torch.randn(128, device=dev)
+    y0 = torch.randn(m, 128, device=dev)
+    wt = w if trans else w.t()
+    ref = x.double() @ wt.double() + b.double() + (y0.double() if acc else 0)
+    first = None
+    for rep in range(4):
+        out = y0.clone() if acc else torch.full((m, 128), float('nan'), device=dev)
+        got = tall_gemm(x, w, b, trans_w=trans, out=out, accumulate=acc)
+        assert got is out
+        assert (out.double() - ref).abs().max().item() < 1e-3
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(first, out)  # deterministic, bit for bit
+
+
+def test_tall_gemm_strided_operands_and_unsupported_shapes():
+    from sst_amd.dense import tall_gemm
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    big = torch.randn(5000, 384, device=dev)
+    w_in = torch.randn(384, 128, device=dev)
+    x = big[:, 128:256]                      # row stride 384
+    y = tall_gemm(x, w_in[256:], None)       # row slice of a packed in-projection weight
+    assert (y.double() - x.double() @ w_in[256:].double().t()).abs().max().item() < 1e-3
+    assert tall_gemm(torch.randn(100, 64, device=dev), torch.randn(128, 64, device=dev)) is None   # K = 64
+    assert tall_gemm(torch.randn(100, 128, device=dev), torch.randn(256, 128, device=dev)) is None  # N = 256
