@@ -187,6 +187,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Outside the timed region: the forward-only rate of the same workload (BASELINE.json configs[1] is quoted
+    # forward-only, the metric forward + backward; `value` is the harder one, this is reported beside it).
+    fwd_only = None
+    if not args.fwd_only:
+        with torch.no_grad():
+            for _ in range(2):
+                model(frames)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                model(frames)
+            sync()
+            el = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        fwd_only = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                    'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
+                    'note': 'same pipeline under torch.no_grad(), training-mode drop/shuffle; not part of `value`'}
+
     # roofline of the dominant kernel group (SRA attention core, forward)
     def group_stats(kind):
         ev = [(e0.elapsed_time(e1), n) for k_, e0, e1, n in sink if k_ == kind]
@@ -238,6 +259,8 @@ def main():
                        'grad_sync': 'one flat RCCL all-reduce' if world > 1 else 'none'},
             'roofline': roofline,
         }
+        if fwd_only is not None:
+            res['forward_only'] = fwd_only
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.points, args.blocks)
         else:
