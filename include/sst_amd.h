@@ -289,6 +289,17 @@ int sst_tall_linear_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t
                         int64_t m, int n, int k, int trans_w, int accumulate, float* d_y, int64_t ldy,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py `roofline`): HIP events attached to ONE launch of the register-resident SRA forward
+ * kernel.  sst_sra_attn_profile_next_fwd(start, stop) arms the next sst_sra_attn_fwd_f32 call (impl 0, windows
+ * <= 144 tokens): the kernel is launched with hipExtLaunchKernelGGL so that `start` / `stop` carry the kernel's own
+ * begin / end timestamps on the launch stream.  Events come from sst_event_create (plain hipEventCreate).
+ * ---------------------------------------------------------------------------------------------- */
+void* sst_event_create(void);
+void sst_event_destroy(void* ev);
+float sst_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop`; < 0 on error */
+int sst_sra_attn_profile_next_fwd(void* start, void* stop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@
 // A plain VALU kernel (one thread per (query, head), online softmax, K/V straight from L2) handles
 // windows above 144 tokens and serves as the in-library cross-check (impl = 1).
 #include <math.h>
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace {
@@ -47,6 +48,7 @@ constexpr int kGC = 64;     // channels per workgroup (kGH * kHD)
 #else
 #define SST_SRA_BLOCK(b, n) ((int)(b))
 #endif
+hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // sst_sra_attn_profile_next_fwd
 constexpr int kWH = SST_WAVE_HEADS;  // heads (= waves) per workgroup of the register-resident kernels
 constexpr int kRS = 68;     // LDS row stride (floats)
 constexpr int kMaxTilesMfma = 9;
@@ -894,6 +896,15 @@ int launch_fwd_wave(const float* Q, const float* K, const float* V, int64_t ldq,
                     const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, float* O,
                     int64_t ldo, float* LSE, hipStream_t st) {
   const int n_groups = H / kWH;
+  if (g_prof_start != nullptr && g_prof_stop != nullptr) {
+    // one-shot: kernel-exact start / stop timestamps on the launch stream (no barrier packets, no cache flush
+    // between the marks and the kernel, unlike a pair of hipEventRecord calls around the launch)
+    hipExtLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st,
+                          g_prof_start, g_prof_stop, 0, Q, K, V, ldq, ldk, ldv, tok, winoff, n_groups, H, scale, O, ldo,
+                          LSE);
+    g_prof_start = g_prof_stop = nullptr;
+    return SST_OK;
+  }
   hipLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st, Q, K, V, ldq, ldk,
                      ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE);
   return SST_OK;
@@ -1015,6 +1026,31 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
                        all_generic ? 0 : kMaxTilesMfma * 16, d_dq, d_dk, d_dv, lddq, lddk, lddv);
   }
   SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+// ---- measurement hooks (bench.py): HIP events bound to ONE kernel launch ------------------------------------
+void* sst_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return (void*)e;
+}
+
+void sst_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+
+float sst_event_elapsed_ms(void* start, void* stop) {
+  float ms = -1.f;
+  if (!start || !stop) return ms;
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+  return ms;
+}
+
+int sst_sra_attn_profile_next_fwd(void* start, void* stop) {
+  g_prof_start = (hipEvent_t)start;
+  g_prof_stop = (hipEvent_t)stop;
   return SST_OK;
 }
 

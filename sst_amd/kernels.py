@@ -304,9 +304,37 @@ def _row_stride(t):
 EVENT_SINK = None
 
 
+class _KernelEvents(object):
+    """A pair of HIP events bound to one kernel launch (sst_sra_attn_profile_next_fwd): elapsed_time = the kernel's
+    own begin -> end on its launch stream."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.start, self.stop = lib.sst_event_create(), lib.sst_event_create()
+
+    def elapsed_time(self, _other=None):
+        return float(self.lib.sst_event_elapsed_ms(self.start, self.stop))
+
+    def __del__(self):
+        try:
+            self.lib.sst_event_destroy(self.start)
+            self.lib.sst_event_destroy(self.stop)
+        except Exception:
+            pass
+
+
 def _bracket(kind, n_tokens, fn):
     if EVENT_SINK is None:
         return fn()
+    if kind == 'sra_fwd':
+        # kernel-exact events attached to the launch itself
+        lib = _lib.load()
+        ke = _KernelEvents(lib)
+        lib.sst_sra_attn_profile_next_fwd(ke.start, ke.stop)
+        r = fn()
+        lib.sst_sra_attn_profile_next_fwd(None, None)  # disarm if the call took another kernel path
+        EVENT_SINK.append((kind, ke, ke, n_tokens))
+        return r
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

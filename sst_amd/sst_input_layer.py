@@ -50,6 +50,7 @@ class SSTInputLayerV2(nn.Module):
                  pos_temperature=10000,
                  mute=False,
                  reference_outputs=True,
+                 window_major=False,
                  ):
         super().__init__()
         self.fp16_enabled = False
@@ -62,6 +63,12 @@ class SSTInputLayerV2(nn.Module):
         self.pos_temperature = pos_temperature
         self.mute = mute
         self.reference_outputs = reference_outputs
+        # window_major: emit the kept voxels ordered by their regular (shift-0) window instead of the (shuffled)
+        # input order.  The order of the voxel list carries no meaning downstream (features travel with their
+        # coordinates; the reference's own order is a random permutation in training), but the attention kernels
+        # then read every window as one contiguous run of rows instead of 30-100 scattered ones.  Costs nothing:
+        # the permutation is folded into the gather that removes the dropped voxels.
+        self.window_major = window_major and not reference_outputs
 
     # ---------------------------------------------------------------------------------------
     def set_drop_info(self):
@@ -130,7 +137,17 @@ class SSTInputLayerV2(nn.Module):
 
         voxel_info = {}
         keep_all = (m_keep == m)
-        if keep_all:
+        tok = [rb['tok0'], rb['tok1']]
+        if self.window_major and m_keep > 0:
+            perm = rb['tok0'][:m_keep].long()                      # kept-voxel index at every shift-0 window slot
+            keep_idx = perm if keep_all else torch.nonzero(rb['keep']).squeeze(1).index_select(0, perm)
+            inv = torch.empty(m_keep, dtype=torch.int32, device=perm.device)
+            inv[perm] = torch.arange(m_keep, dtype=torch.int32, device=perm.device)
+            tok = [torch.arange(m_keep, dtype=torch.int32, device=perm.device), inv[rb['tok1'][:m_keep].long()]]
+
+            def sel(t):
+                return t.index_select(0, keep_idx)
+        elif keep_all:
             keep_idx = torch.arange(m, device=voxel_coors.device, dtype=torch.long)
 
             def sel(t):
@@ -159,7 +176,7 @@ class SSTInputLayerV2(nn.Module):
             if not identity_keys:  # drop_info keyed by something else than 0..n-1
                 lv = torch.tensor(level_keys, device=lv.device, dtype=torch.long)[lv.clamp(min=0)]
             voxel_info[f'voxel_drop_level_shift{i}'] = lv
-            voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(rb[f'tok{i}'], rb[f'winoff{i}'], n_win[i], m_keep,
+            voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep,
                                                             max_tokens_cap)
             voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], voxel_feats.size(1),
                                                                         voxel_feats.dtype)

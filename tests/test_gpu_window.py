@@ -152,3 +152,35 @@ def test_input_layer_shuffle_and_full_size_properties():
         # constant window id inside every CSR segment
         seg = torch.repeat_interleave(torch.arange(plan.n_windows, device=DEV), sizes)
         assert torch.equal(wins, wins[off[:-1]][seg])
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_window_major_order_gives_the_same_voxel_features(training):
+    """window_major=True only re-orders the kept voxel list (rows travel with their coordinates): the backbone
+    output, matched by coordinate, is the same as with the input order."""
+    import sst_amd
+    coors = _random_voxels(11, 6000, 2, True).to(DEV)
+    feats = torch.randn(coors.size(0), 128, device=DEV)
+    torch.manual_seed(0)
+    backbone = sst_amd.SSTv2(d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2,
+                             output_shape=[468, 468], num_attached_conv=0, debug=False, to_bev=False,
+                             layer_cfg=dict(use_bn=False, cosine=False, tau_min=0.01), checkpoint_blocks=[]).to(DEV)
+    backbone.train(training)
+    outs = []
+    for wm in (False, True):
+        layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
+                                        mute=True, debug=False, reference_outputs=False, window_major=wm)
+        layer.train(training)
+        info = layer(feats, coors, 2)
+        if wm:  # every regular window is one contiguous run of rows
+            plan = info['sra_plan_shift0']
+            assert torch.equal(plan.tok.long(), torch.arange(plan.n_tokens, device=DEV))
+        keep = info['voxel_keep_inds']
+        assert torch.equal(info['voxel_coors'], coors.long()[keep])
+        out = backbone(info)[0]
+        c = out['voxel_coors'].long()
+        key = ((c[:, 0] * 2 + c[:, 1]) * 468 + c[:, 2]) * 468 + c[:, 3]
+        order = torch.argsort(key)
+        outs.append((key[order], out['voxel_feats'][order]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-4

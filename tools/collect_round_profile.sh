@@ -12,7 +12,7 @@ python bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || tai
 tail -1 $OUT/bench.json | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pb
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/bench.py --steps 16 --warmup 6 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1 || tail -5 $OUT/bench_under_rocprof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/bench.py --steps 16 --warmup 6 --no-cpu-baseline --no-forward-only-leg > $OUT/bench_under_rocprof.log 2>&1 || tail -5 $OUT/bench_under_rocprof.log
 cp /tmp/pb/b_kernel_stats.csv $OUT/kernel_stats.csv
 python $R/tools/gap_report.py /tmp/pb/b_kernel_trace.csv 0.65 60 > $OUT/steady_state_trace_report.txt
 head -12 $OUT/steady_state_trace_report.txt

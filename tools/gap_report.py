@@ -19,6 +19,10 @@ def main(path, skip=0.5):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
     rows = rows[int(len(rows) * skip):]  # steady state only
+    # whole steps only: from the first voxelize launch of the window up to (not including) the last one
+    vox = [i for i, r in enumerate(rows) if 'dynamic_voxelize_k' in r[2]]
+    if len(vox) >= 2:
+        rows = rows[vox[0]:vox[-1]]
     span = rows[-1][1] - rows[0][0]
     busy = 0
     cur_end = rows[0][0]
