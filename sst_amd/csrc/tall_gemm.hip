@@ -38,18 +38,10 @@ constexpr int kTgWaves = 8;     // per workgroup: 2 per SIMD, each with a 256-VG
 constexpr int kTgGrid = 256;    // persistent: one workgroup per CU
 constexpr int kTgImage = 4096;  // bytes of a wave's X image in LDS: 32 rows x 32 k
 
-#ifdef SST_TG_EXP_NOLOAD  /* experiment builds only (tools/gemm_probe.py): drop one stage of the pipeline */
-#define SST_TG_LOAD(DST, PTR, OFF) asm volatile("" : "=v"(DST) : "v"(PTR), "n"(OFF))
-#else
 #define SST_TG_LOAD(DST, PTR, OFF) \
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(DST) : "v"(PTR), "n"(OFF))
-#endif
 #define SST_TG_MFMA(ACC, AV, BV) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(AV), "v"(BV))
-#ifdef SST_TG_EXP_NOLDS
-#define SST_TG_DSR(DST, ADDR, OFF) asm volatile("" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-#else
 #define SST_TG_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-#endif
 #define SST_TG_DSW(ADDR, SRC, OFF) \
   asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(ADDR), "v"(SRC), "n"(OFF) : "memory")
 
@@ -148,9 +140,6 @@ __global__ __launch_bounds__(64 * kTgWaves) void tall_gemm_n128_k(const float* _
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
   };
   auto store = [&](int c) {
-#ifdef SST_TG_EXP_NOSTORE
-    if (bias != (const float*)0x10) return;
-#endif
     // the last MFMAs (16 passes, opaque to the hazard recognizer) must have landed before acc is read
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
     const int64_t row0 = (int64_t)(t0 + tstep * (c / KH)) * 32;
@@ -252,11 +241,7 @@ __global__ __launch_bounds__(64 * kTgWaves) void tall_gemm_n128_k(const float* _
     zero();
     if (KH == 1) {
       // every load this tile waits for was issued before the previous tile's store burst
-#ifdef SST_TG_EXP_NOSTORE
-      SST_TG_CHUNK("s_waitcnt vmcnt(12)", "s_waitcnt vmcnt(12)", c + 1)
-#else
       SST_TG_CHUNK("s_waitcnt vmcnt(63)", "s_waitcnt vmcnt(63)", c + 1)
-#endif
     } else {
       // first chunk of the tile: its pieces 1..3 and the second chunk's piece 0 were requested before the burst;
       // second chunk: everything it waits for was requested after it
