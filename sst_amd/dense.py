@@ -177,5 +177,6 @@ def add_layer_norm(x, res, norm):
     ok = (isinstance(norm, torch.nn.LayerNorm) and x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda
           and norm.elementwise_affine and norm.bias is not None and c % 4 == 0 and c <= 512)
     if not ok:
-        return norm(x + res if res is not None else x)
+        y = x + res if res is not None else x
+        return torch.nn.functional.layer_norm(y, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
     return AddLayerNorm.apply(x, res, norm.weight, norm.bias, norm.eps)

@@ -176,6 +176,17 @@ class BatchNorm1d(nn.BatchNorm1d):
         return super().forward(input)
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict) whose [N, C] CUDA float32 forward / backward run through the row
+    kernels of csrc/dense.hip; what ``build_norm_layer(dict(type='LN'))`` returns (FSD's SIR / rel_mlp layers)."""
+
+    def forward(self, input):
+        if input.dim() == 2 and input.is_cuda and input.dtype == torch.float32:
+            from .dense import add_layer_norm
+            return add_layer_norm(input, None, self)  # falls back to torch for shapes the kernel is not built for
+        return super().forward(input)
+
+
 class NaiveSyncBatchNorm1d(nn.BatchNorm1d):
     """mmdet3d/ops/norm.py:28-86."""
 
@@ -222,7 +233,7 @@ NORM_LAYERS = {
     'BN2d': nn.BatchNorm2d,
     'BN3d': nn.BatchNorm3d,
     'SyncBN': nn.SyncBatchNorm,
-    'LN': nn.LayerNorm,
+    'LN': LayerNorm,
     'GN': nn.GroupNorm,
     'naiveSyncBN1d': NaiveSyncBatchNorm1d,
     'naiveSyncBN2d': NaiveSyncBatchNorm2d,

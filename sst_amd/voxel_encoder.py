@@ -15,7 +15,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .dense import tall_linear
+from .dense import add_layer_norm, tall_linear
 from .norm import batch_norm_act, build_norm_layer
 from .registry import VOXEL_ENCODERS
 from .sst_ops import build_mlp, get_activation_layer, scatter_v2, unique_with_plan
@@ -58,6 +58,8 @@ class DynamicVFELayerV2(nn.Module):
             if isinstance(self.act, nn.ReLU):
                 return batch_norm_act(self.norm, x, relu=True)
             return self.act(batch_norm_act(self.norm, x, relu=False))
+        if isinstance(self.norm, nn.LayerNorm):  # FSD's SIR layers: norm_cfg = LN (row kernel of csrc/dense.hip)
+            return self.act(add_layer_norm(x, None, self.norm))
         return self.act(self.norm(x))
 
 

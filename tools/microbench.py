@@ -163,6 +163,43 @@ def bench_gemm():
         print(f'  fwd addmm [{m}x128]x[128x{out}]: {med * 1e3:7.1f} us  {2.0 * m * 128 * out / med / 1e9:6.1f} TF/s')
 
 
+def bench_sir():
+    """FSD's SIR point-group backbone (configs/fsd: 3 SIRLayer blocks, LN + GELU, max pooling) on a synthetic
+    foreground set: 30 000 points in ~3 000 clusters.  Times forward + backward and the
+    segmented-max kernel against its algorithmic bytes."""
+    torch.manual_seed(0)
+    n, n_clusters = 30000, 3000
+    sir = sst_amd.build_backbone(dict(type='SIR', num_blocks=3, in_channels=[84, 133, 133],
+                                      feat_channels=[[128, 128]] * 3, rel_mlp_hidden_dims=[[16, 32]] * 3,
+                                      norm_cfg=dict(type='LN', eps=1e-3), mode='max', xyz_normalizer=[20, 20, 4],
+                                      act='gelu', unique_once=True)).to(DEV).train()
+    cluster = torch.randint(0, n_clusters, (n,), device=DEV)
+    coors = torch.stack([torch.zeros_like(cluster), torch.zeros_like(cluster), cluster], 1)  # int64 (cls, batch, id)
+    points = torch.randn(n, 5, device=DEV) * 3
+    feats = torch.randn(n, 79, device=DEV).requires_grad_(True)  # 79 + xyz + 2 = in_channels 84 as in the golden case
+    f_cluster = torch.randn(n, 3, device=DEV)
+
+    def fwd_bwd():
+        feats.grad = None
+        p, c, _ = sir(points, feats, coors, f_cluster)
+        (p.sum() + c.sum()).backward()
+
+    med, _ = timeit(fwd_bwd, iters=20, warmup=3)
+    print(f'SIR x3 (30k points, {n_clusters} clusters) fwd+bwd: {med * 1e3:.1f} us')
+    with torch.no_grad():
+        med, _ = timeit(lambda: sir(points, feats, coors, f_cluster), iters=20, warmup=3)
+    print(f'SIR x3 forward: {med * 1e3:.1f} us')
+    # the pooling kernel alone, at FSD size and at the VFE size of the SST bench
+    for npts, c, groups in ((30000, 128, 3000), (116000, 128, 90000), (300000, 128, 60000)):
+        idx = torch.randint(0, groups, (npts,), device=DEV)
+        plan = K.unique_rows(idx[:, None].int().contiguous(), [0], [groups])
+        x = torch.randn(npts, c, device=DEV)
+        med, _ = timeit(lambda: K.segment_reduce(x, plan, 'max'), iters=30, warmup=3)
+        byt = npts * (4 * c + 4) + plan.m * 4 * c
+        print(f'segment max [{npts} x {c}] -> {plan.m} groups: {med * 1e3:.1f} us -> {byt / med / 1e6:.0f} GB/s '
+              f'({100 * byt / med / 1e6 / 8000:.1f} % of 8 TB/s)')
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('sra', 'all'):
@@ -173,3 +210,5 @@ if __name__ == '__main__':
         bench_unique()
     if what in ('gemm',):
         bench_gemm()
+    if what in ('sir',):
+        bench_sir()
