@@ -175,11 +175,14 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(16.0)
         o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
         a = _linear_fwd(o, w_out, b_out)
-        y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps)
+        need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
+        y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
         pre = torch.addmm(b1, y1, w1.t())
         h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
         f = _linear_fwd(h, w2, b2)
-        y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps)
+        y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd)
+        if not need_bwd:
+            return y2
         ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
         ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
         return y2
