@@ -239,7 +239,7 @@ int sst_colsum_f32(const float* d_x, int64_t m, int c, int64_t ld, float* d_out,
 /* ------------------------------------------------------------------------------------------------
  * Weight / bias gradient of a tall linear layer y = x W^T + b (projections and FFN of an encoder layer,
  * models/sst/sst_basic_block_v2.py:104-126; VFE / SIR linears): dW[out,in] = dY[M,out]^T X[M,in] as a
- * split-K fp32 MFMA kernel, d_db[out] = column sums of dY (optional, NULL to skip).  out, in multiples of 32.
+ * split-K fp32 MFMA kernel, d_db[out] = column sums of dY (optional, NULL to skip).  1 <= out, in <= 4096.
  * Row strides ld_dy / ld_x in elements.  Workspace: sst_weight_grad_workspace_bytes(m, out, in).
  * ---------------------------------------------------------------------------------------------- */
 int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in);

@@ -52,7 +52,6 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
   const int o0 = ot * kWgTileO + wo * 64;
   const int i0 = it * kWgTileI + wi * 32;
   const bool active = (o0 < out) && (i0 < in);  // inactive waves still reach the barrier; empty K slices write zeros
-  const bool has_o1 = (o0 + 32) < out;
   const int col = lane & 31, kk = lane >> 5;
   const int64_t ks0 = (int64_t)s * rows_per_split < m ? (int64_t)s * rows_per_split : m;
   const int64_t ks1 = ks0 + rows_per_split < m ? ks0 + rows_per_split : m;
@@ -67,9 +66,14 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   float bs0 = 0.f, bs1 = 0.f;
-  const int o1off = has_o1 ? 32 : 0;  // without a second out tile the first one is read twice (its product is never stored)
-  const float* pa = dy + (k0 + kk) * ld_dy + o0 + col;
-  const float* pb = x + (k0 + kk) * ld_x + i0 + col;
+  // ragged dims (out, in not multiples of 32: SIR / VFE layers with 84, 133, 11 ... channels): columns past the
+  // matrix are read from its last column (in bounds) and multiplied by zero; their products are never stored
+  const bool a0ok = (o0 + col) < out, a1ok = (o0 + 32 + col) < out, bok = (i0 + col) < in;
+  const float a0m = a0ok ? 1.f : 0.f, a1m = a1ok ? 1.f : 0.f, bm = bok ? 1.f : 0.f;
+  const int ca0 = a0ok ? o0 + col : out - 1, ca1 = a1ok ? o0 + 32 + col : out - 1, cb = bok ? i0 + col : in - 1;
+  const int o1off = ca1 - ca0;
+  const float* pa = dy + (k0 + kk) * ld_dy + ca0;
+  const float* pb = x + (k0 + kk) * ld_x + cb;
   // software pipeline: the loads of group g+1 are in flight while the MFMAs of group g issue.  The prefetch is
   // UNCONDITIONAL (past the last group the pointers simply stop advancing and the group is re-read): a
   // conditional prefetch puts a branch between the loads and their first use, and the waitcnt insertion then
@@ -78,9 +82,9 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
   auto load = [&](float (&a0)[U], float (&a1)[U], float (&b)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      a0[u] = pa[(int64_t)u * 2 * ld_dy];
-      a1[u] = pa[(int64_t)u * 2 * ld_dy + o1off];
-      b[u] = pb[(int64_t)u * 2 * ld_x];
+      a0[u] = pa[(int64_t)u * 2 * ld_dy] * a0m;
+      a1[u] = pa[(int64_t)u * 2 * ld_dy + o1off] * a1m;
+      b[u] = pb[(int64_t)u * 2 * ld_x] * bm;
     }
   };
   auto comp = [&](const float (&a0)[U], const float (&a1)[U], const float (&b)[U]) {
@@ -120,9 +124,9 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
   int64_t k = k0 + ng * 2 * U;
   for (; k < k1; k += 2) {  // ragged tail, row-guarded
     const bool ok = (k + kk) < k1;
-    const float a0 = ok ? pa[0] : 0.f;
-    const float a1 = (ok && has_o1) ? pa[32] : 0.f;
-    const float b = ok ? pb[0] : 0.f;
+    const float a0 = ok ? pa[0] * a0m : 0.f;
+    const float a1 = ok ? pa[o1off] * a1m : 0.f;
+    const float b = ok ? pb[0] * bm : 0.f;
     acc0 = mfma32(a0, b, acc0);
     acc1 = mfma32(a1, b, acc1);
     bs0 += a0;
@@ -163,15 +167,15 @@ __global__ __launch_bounds__(256 * KW) void wgrad_k(const float* __restrict__ dy
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-    pw[(int64_t)(o0 + row) * in + i0 + col] = acc0[r];
-    if (has_o1) pw[(int64_t)(o0 + 32 + row) * in + i0 + col] = acc1[r];
+    if (bok && o0 + row < out) pw[(int64_t)(o0 + row) * in + i0 + col] = acc0[r];
+    if (bok && o0 + 32 + row < out) pw[(int64_t)(o0 + 32 + row) * in + i0 + col] = acc1[r];
   }
   if (part_b != nullptr && it == 0 && wi == 0) {
     bs0 += __shfl_xor(bs0, 32, 64);
     bs1 += __shfl_xor(bs1, 32, 64);
     if (lane < 32) {
-      part_b[(int64_t)s * pstride + o0 + lane] = bs0;
-      if (has_o1) part_b[(int64_t)s * pstride + o0 + 32 + lane] = bs1;
+      if (o0 + lane < out) part_b[(int64_t)s * pstride + o0 + lane] = bs0;
+      if (o0 + 32 + lane < out) part_b[(int64_t)s * pstride + o0 + 32 + lane] = bs1;
     }
   }
 }
@@ -454,7 +458,7 @@ int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in) {
 
 int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out, int in, int64_t ld_dy, int64_t ld_x,
                         float* d_dw, float* d_db, void* d_workspace, void* stream) {
-  if (m < 0 || out < 32 || in < 32 || (out & 31) || (in & 31) || out > 4096 || in > 4096) return SST_ERR_UNSUPPORTED;
+  if (m < 0 || out < 1 || in < 1 || out > 4096 || in > 4096) return SST_ERR_UNSUPPORTED;
   if (!d_dw || !d_workspace || ld_dy < out || ld_x < in) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (m == 0) {

@@ -46,8 +46,8 @@ def weight_bias_grad(dy, x, want_bias, out_w=None, out_b=None):
     out_w / out_b: optional contiguous destinations (e.g. row slices of a packed in_proj gradient)."""
     m, out = dy.shape
     inn = x.size(1)
-    ok = (out % 32 == 0 and inn % 32 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 and m >= 4096
-          and dy.dtype == torch.float32 and x.dtype == torch.float32)
+    ok = (dy.stride(1) == 1 and x.stride(1) == 1 and m >= 4096 and out <= 4096 and inn <= 4096
+          and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.is_cuda)
     if not ok:
         dw = weight_grad_splitk(dy, x.contiguous())
         db = colsum(dy) if want_bias else None

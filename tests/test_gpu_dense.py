@@ -39,7 +39,10 @@ def test_add_layer_norm_matches_torch(m, c, with_res):
 
 @pytest.mark.parametrize('m,cin,cout,bias', [(90107, 128, 384, True), (4097, 256, 128, True), (116000, 9, 64, False),
                                              (100, 128, 128, True), (50000, 128, 256, True), (90107, 128, 128, False),
-                                             (33333, 96, 160, True), (116000, 128, 128, False), (5000, 64, 32, True)])
+                                             (33333, 96, 160, True), (116000, 128, 128, False), (5000, 64, 32, True),
+                                             # ragged channel counts of the SIR / VFE layers (masked columns in the wgrad kernel)
+                                             (30000, 84, 128, True), (30000, 133, 128, False), (30000, 3, 16, True),
+                                             (30001, 32, 84, True), (8000, 1, 1, True), (30000, 261, 130, True)])
 def test_tall_linear_matches_torch(m, cin, cout, bias):
     from sst_amd.dense import tall_linear
     g = torch.Generator().manual_seed(m)
