@@ -65,10 +65,18 @@ class Pipeline(torch.nn.Module):
             dim_feedforward=[256] * num_blocks, output_shape=[468, 468], num_attached_conv=0, to_bev=False,
             debug=False))
 
-    def forward(self, points_list):
+    def prepare(self, points_list):
+        """Index work of one batch - dynamic voxelize, point->voxel grouping, window bucketing / drop / window CSR,
+        positional embeddings: depends on the point clouds only (no parameters, no features)."""
         points, coors = self.voxel_layer.voxelize_batch(points_list)
-        voxel_feats, voxel_coors = self.voxel_encoder(points, coors)
-        info = self.middle_encoder(voxel_feats, voxel_coors, len(points_list))
+        sp = self.voxel_encoder.scatter_plan(coors)
+        wplan = self.middle_encoder.build_plan(sp.voxel_coors, len(points_list), 128, torch.float32)
+        return points, coors, sp, wplan
+
+    def forward(self, points_list, prepared=None):
+        points, coors, sp, wplan = prepared if prepared is not None else self.prepare(points_list)
+        voxel_feats, _ = self.voxel_encoder(points, coors, scatter_plan=sp)
+        info = self.middle_encoder.apply_plan(wplan, voxel_feats)
         return self.backbone(info)[0]['voxel_feats']
 
 

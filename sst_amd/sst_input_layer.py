@@ -106,6 +106,14 @@ class SSTInputLayerV2(nn.Module):
             voxel_info: dict, same keys as the reference (sst_input_layer_v2.py:99-126) plus
                         'sra_plan_shift{i}', 'pos_embed_shift{i}'.
         '''
+        return self.apply_plan(self.build_plan(voxel_coors, batch_size, voxel_feats.size(1), voxel_feats.dtype),
+                               voxel_feats)
+
+    @torch.no_grad()
+    def build_plan(self, voxel_coors, batch_size=None, feat_dim=128, dtype=torch.float32):
+        """Everything of forward() that depends only on the voxel coordinates (window bucketing, drop / shuffle,
+        window CSR, positional embeddings): no voxel features, no parameters.  A caller that pipelines frames can
+        run it ahead of time (another stream, the data loader) and finish with apply_plan(plan, voxel_feats)."""
         self.set_drop_info()
         if voxel_coors.dim() != 2 or voxel_coors.size(1) != 4:
             raise RuntimeError('voxel_coors must be [N,4] (b,z,y,x)')
@@ -113,8 +121,7 @@ class SSTInputLayerV2(nn.Module):
 
         shuffle_inds = None
         if self.shuffle_voxels:
-            shuffle_inds = torch.randperm(len(voxel_feats), device=voxel_feats.device)
-            voxel_feats = voxel_feats[shuffle_inds]
+            shuffle_inds = torch.randperm(len(voxel_coors), device=voxel_coors.device)
             voxel_coors = voxel_coors[shuffle_inds]
         voxel_coors = voxel_coors.contiguous()
 
@@ -124,14 +131,13 @@ class SSTInputLayerV2(nn.Module):
         assert sz < sx, 'Usually holds... in case of wrong order'
         level_keys, levels = self._levels()
 
-        with torch.no_grad():
-            win0, ciw0, win1, ciw1 = K.window_coors(voxel_coors, [sx, sy, sz], [wx, wy, wz])
-            per_sample = (math.ceil(sx / wx) + 1) * (math.ceil(sy / wy) + 1) * (math.ceil(sz / wz) + 1)
-            if batch_size is None:
-                batch_size = int(voxel_coors[:, 0].max().item()) + 1 if m > 0 else 1
-            win_bits = max(1, int(per_sample * int(batch_size)).bit_length())
-            rb = K.region_batching(win0, win1, win_bits, levels)
-            counts = rb['counts'].tolist()  # the single readback: M', W0, W1
+        win0, ciw0, win1, ciw1 = K.window_coors(voxel_coors, [sx, sy, sz], [wx, wy, wz])
+        per_sample = (math.ceil(sx / wx) + 1) * (math.ceil(sy / wy) + 1) * (math.ceil(sz / wz) + 1)
+        if batch_size is None:
+            batch_size = int(voxel_coors[:, 0].max().item()) + 1 if m > 0 else 1
+        win_bits = max(1, int(per_sample * int(batch_size)).bit_length())
+        rb = K.region_batching(win0, win1, win_bits, levels)
+        counts = rb['counts'].tolist()  # the single readback: M', W0, W1
         m_keep, n_win = counts[0], (counts[1], counts[2])
         max_tokens_cap = max(l[0] for l in levels)
 
@@ -158,7 +164,6 @@ class SSTInputLayerV2(nn.Module):
             def sel(t):
                 return t.index_select(0, keep_idx)
 
-        voxel_feats = sel(voxel_feats)
         voxel_coors = sel(voxel_coors)
         wins = (sel(win0), sel(win1))
         ciws = (sel(ciw0), sel(ciw1))
@@ -166,7 +171,14 @@ class SSTInputLayerV2(nn.Module):
         f2ws = (sel(rb['flat2win0']), sel(rb['flat2win1']))
         identity_keys = list(level_keys) == list(range(len(level_keys)))
 
-        voxel_info['voxel_feats'] = voxel_feats
+        # rows of the caller's voxel_feats that survive, in output order (shuffle and drop / re-order folded
+        # into one gather); None = all rows in their own order
+        if shuffle_inds is not None:
+            voxel_info['_feat_index'] = shuffle_inds.index_select(0, keep_idx)
+        elif keep_all and not (self.window_major and m_keep > 0):
+            voxel_info['_feat_index'] = None
+        else:
+            voxel_info['_feat_index'] = keep_idx
         voxel_info['voxel_coors'] = voxel_coors
         voxel_info['voxel_keep_inds'] = keep_idx
         for i in range(2):
@@ -178,8 +190,7 @@ class SSTInputLayerV2(nn.Module):
             voxel_info[f'voxel_drop_level_shift{i}'] = lv
             voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep,
                                                             max_tokens_cap)
-            voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], voxel_feats.size(1),
-                                                                        voxel_feats.dtype)
+            voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], feat_dim, dtype)
 
         if self.debug:
             for i in range(2):
@@ -206,6 +217,13 @@ class SSTInputLayerV2(nn.Module):
 
         if self.shuffle_voxels:
             voxel_info['shuffle_inds'] = shuffle_inds
+        return voxel_info
+
+    def apply_plan(self, plan, voxel_feats):
+        """voxel_info of forward(): the plan plus the surviving voxel features in plan order (one gather)."""
+        voxel_info = dict(plan)
+        idx = voxel_info.pop('_feat_index')
+        voxel_info['voxel_feats'] = voxel_feats if idx is None else voxel_feats.index_select(0, idx)
         return voxel_info
 
     # ---------------------------------------------------------------------------------------

@@ -138,13 +138,18 @@ class DynamicVFE(nn.Module):
         idx = plan.coors_map.long().clamp(min=0)
         return voxel_mean[idx, ...]
 
-    def forward(self, features, coors, points=None, img_feats=None, img_metas=None):
-        features = features.float()  # @force_fp32 (voxel_encoder.py:229)
+    def scatter_plan(self, coors):
+        """The point -> voxel grouping this encoder uses for ``coors`` (index work only, no parameters): callers
+        that pipeline frames can build it ahead of time and hand it to forward(..., scatter_plan=...)."""
         coors = coors.contiguous()
         if coors.size(1) == 4:
-            plan = build_scatter_plan(coors, grid_zyx=self._grid_zyx(), reference_compat=self.reference_compat)
-        else:
-            plan = build_scatter_plan(coors, reference_compat=self.reference_compat)
+            return build_scatter_plan(coors, grid_zyx=self._grid_zyx(), reference_compat=self.reference_compat)
+        return build_scatter_plan(coors, reference_compat=self.reference_compat)
+
+    def forward(self, features, coors, points=None, img_feats=None, img_metas=None, scatter_plan=None):
+        features = features.float()  # @force_fp32 (voxel_encoder.py:229)
+        coors = coors.contiguous()
+        plan = scatter_plan if scatter_plan is not None else self.scatter_plan(coors)
         inv = plan.coors_map.long().clamp(min=0)
 
         features_ls = [features]

@@ -184,3 +184,18 @@ def test_window_major_order_gives_the_same_voxel_features(training):
         outs.append((key[order], out['voxel_feats'][order]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-4
+
+
+
+def test_plan_built_ahead_matches_the_in_step_plan():
+    """Pipeline.prepare (index work only) + forward(prepared) == forward(): the split used to build plans ahead."""
+    import bench
+    torch.manual_seed(0)
+    model = bench.Pipeline(2).to(DEV).train()
+    frames = [bench.make_cloud(20000, 3, torch.device(DEV)), bench.make_cloud(15000, 4, torch.device(DEV))]
+    torch.manual_seed(123)          # the voxel shuffle draws from the device generator
+    ref = model(frames)
+    torch.manual_seed(123)
+    prepared = model.prepare(frames)
+    out = model(frames, prepared)
+    assert torch.equal(out, ref)
