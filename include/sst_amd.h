@@ -108,17 +108,21 @@ int sst_unpack_keys(const uint64_t* d_ukeys, int64_t m, int ncols, const int64_t
  *   MAX of an empty group is -inf, SUM/MEAN is 0.  MEAN = sum / (float)count (cuda.cu:228-229).
  *   d_argmax (optional, [m, c] int32): row index of the FIRST (smallest index) row attaining the max
  *   (the tie rule of max_reduce_traceback_scatter_idx_kernel, cuda.cu:135-160); n for empty groups.
+ *   d_group_index (optional, [m] int32): output row g reduces CSR group d_group_index[g] instead of group g
+ *   (a subset / re-ordering of the groups without gathering the result: the batched DynamicScatter keeps all but
+ *   the first sorted-unique row of every sample).
  * ---------------------------------------------------------------------------------------------- */
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
-                               const int32_t* d_offsets, int64_t m, int mode, float* d_out,
-                               int32_t* d_argmax, void* stream);
+                               const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
+                               float* d_out, int32_t* d_argmax, void* stream);
 /* Backward (scatter_points_cuda.cu:236-303).  d_grad_feats [n, c] is fully written (zero where no
  * gradient flows).  SUM/MEAN: g[i] = G[inv[i]] (/count); rows with d_inverse[i] < 0 get 0.
  * MAX: gradient goes to d_argmax[g, ch] only.  d_inverse may be shifted by the caller
- * (inverse_shift is added before use; the DynamicScatter "first row" quirk uses -1). */
+ * (inverse_shift is added before use; the DynamicScatter "first row" quirk uses -1).  With d_group_index the
+ * inverse map must already address OUTPUT rows; the group index is only used for the MEAN count. */
 int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const int32_t* d_inverse,
-                               int inverse_shift, const int32_t* d_offsets, const int32_t* d_argmax,
-                               int64_t n, int mode, float* d_grad_feats, void* stream);
+                               int inverse_shift, const int32_t* d_offsets, const int32_t* d_group_index,
+                               const int32_t* d_argmax, int64_t n, int mode, float* d_grad_feats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a7) in-group rank.  Replaces TorchEx ingroup_indices.forward(group_inds, out_inds)

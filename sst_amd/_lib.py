@@ -34,8 +34,9 @@ _SIGNATURES = {
     'sst_unique_rows': (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_i32,
                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_unpack_keys': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr]),
-    'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr]),
-    'sst_segment_reduce_bwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i32,
+    'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
+                                           c_ptr]),
+    'sst_segment_reduce_bwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                                            c_ptr, c_ptr]),
     'sst_ingroup_rank_workspace_bytes': (c_i64, [c_i64]),
     'sst_ingroup_rank_i64': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr]),

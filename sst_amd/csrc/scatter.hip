@@ -18,14 +18,16 @@ namespace {
 // one thread per (group, channel) element; consecutive threads -> consecutive channels of one group
 __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict__ feats, int c,
                                                         const uint32_t* __restrict__ perm,
-                                                        const int32_t* __restrict__ offsets, int64_t m, int mode,
+                                                        const int32_t* __restrict__ offsets,
+                                                        const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                         float* __restrict__ out, int32_t* __restrict__ argmax,
                                                         int32_t n_rows) {
   const int64_t total = m * c;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t g = e / c;
     const int ch = (int)(e - g * c);
-    const int beg = offsets[g], end = offsets[g + 1];
+    const int64_t gs = gidx != nullptr ? gidx[g] : g;
+    const int beg = offsets[gs], end = offsets[gs + 1];
     if (mode == SST_REDUCE_MAX) {
       float acc = -INFINITY;
       int32_t arg = n_rows;
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict_
 // id -> value pair per point (the scalar kernel ran at 25-29 % of the HBM roof on 1e5..3e5 points).
 __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restrict__ feats, int c,
                                                            const uint32_t* __restrict__ perm,
-                                                           const int32_t* __restrict__ offsets, int64_t m, int mode,
+                                                           const int32_t* __restrict__ offsets,
+                                                           const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
                                                            int32_t n_rows) {
   const int c4 = c >> 2;
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t g = e / c4;
     const int ch = (int)(e - g * c4) * 4;
-    const int beg = offsets[g], end = offsets[g + 1];
+    const int64_t gs = gidx != nullptr ? gidx[g] : g;
+    const int beg = offsets[gs], end = offsets[gs + 1];
     float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
     int32_t a0 = n_rows, a1 = n_rows, a2 = n_rows, a3 = n_rows;
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
 // SUM / MEAN backward: one thread per (point, channel)
 __global__ __launch_bounds__(256) void seg_reduce_bwd_add_k(const float* __restrict__ gout, int c,
                                                             const int32_t* __restrict__ inverse, int shift,
-                                                            const int32_t* __restrict__ offsets, int64_t m,
+                                                            const int32_t* __restrict__ offsets,
+                                                            const int32_t* __restrict__ gidx, int64_t m,
                                                             int64_t n, int mode, float* __restrict__ gfeats) {
   const int64_t total = n * c;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -111,7 +116,10 @@ __global__ __launch_bounds__(256) void seg_reduce_bwd_add_k(const float* __restr
     float v = 0.f;
     if (g >= 0 && g < m) {
       v = gout[(int64_t)g * c + ch];
-      if (mode == SST_REDUCE_MEAN) v = v / (float)(offsets[g + 1] - offsets[g]);
+      if (mode == SST_REDUCE_MEAN) {
+        const int gs = gidx != nullptr ? gidx[g] : g;
+        v = v / (float)(offsets[gs + 1] - offsets[gs]);
+      }
     }
     gfeats[e] = v;
   }
@@ -158,28 +166,28 @@ __global__ __launch_bounds__(256) void scatter_rows_k(const float* __restrict__ 
 extern "C" {
 
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
-                               const int32_t* d_offsets, int64_t m, int mode, float* d_out, int32_t* d_argmax,
-                               void* stream) {
+                               const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
+                               float* d_out, int32_t* d_argmax, void* stream) {
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_offsets || !d_out || (n > 0 && (!d_feats || !d_perm))) return SST_ERR_ARG;
   if ((c & 3) == 0 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15) == 0 && n > 0) {
     const int grid = sst_grid_1d(m * (c >> 2), 256);
     hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                       d_offsets, m, mode, d_out, d_argmax, (int32_t)n);
+                       d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n);
     SST_LAUNCH_CHECK();
     return SST_OK;
   }
   const int grid = sst_grid_1d(m * c, 256);
   hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                     m, mode, d_out, d_argmax, (int32_t)n);
+                     d_group_index, m, mode, d_out, d_argmax, (int32_t)n);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
 
 int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const int32_t* d_inverse,
-                               int inverse_shift, const int32_t* d_offsets, const int32_t* d_argmax, int64_t n,
-                               int mode, float* d_grad_feats, void* stream) {
+                               int inverse_shift, const int32_t* d_offsets, const int32_t* d_group_index,
+                               const int32_t* d_argmax, int64_t n, int mode, float* d_grad_feats, void* stream) {
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (n == 0) return SST_OK;
   if (!d_grad_feats) return SST_ERR_ARG;
@@ -199,7 +207,7 @@ int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const 
     if (!d_grad_out || !d_inverse || !d_offsets) return SST_ERR_ARG;
     const int grid = sst_grid_1d(n * c, 256);
     hipLaunchKernelGGL(seg_reduce_bwd_add_k, dim3(grid), dim3(256), 0, st, d_grad_out, c, d_inverse, inverse_shift,
-                       d_offsets, m, n, mode, d_grad_feats);
+                       d_offsets, d_group_index, m, n, mode, d_grad_feats);
   }
   SST_LAUNCH_CHECK();
   return SST_OK;

@@ -152,12 +152,13 @@ def unpack_unique_rows(plan, dtype, first=0, count=None, out_cols=None, col0=0, 
 # ----------------------------------------------------------------------------------------------
 # (a3/a5/a15) segmented reduce with autograd
 # ----------------------------------------------------------------------------------------------
-def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax):
+def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=None):
     n, c = feats.shape
     out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
     argmax = torch.empty((m, c), dtype=torch.int32, device=feats.device) if want_argmax else None
-    rc = _lib.load().sst_segment_reduce_fwd_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets), m, mode,
-                                                _lib.ptr(out), _lib.ptr(argmax), _lib.stream_ptr())
+    rc = _lib.load().sst_segment_reduce_fwd_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets),
+                                                _lib.ptr(group_index), m, mode, _lib.ptr(out), _lib.ptr(argmax),
+                                                _lib.stream_ptr())
     _lib.check(rc, 'sst_segment_reduce_fwd_f32')
     return out, argmax
 
@@ -170,32 +171,40 @@ class SegmentReduce(Function):
     """
 
     @staticmethod
-    def forward(ctx, feats, perm, offsets, inverse, m, mode, inverse_shift):
+    def forward(ctx, feats, perm, offsets, inverse, m, mode, inverse_shift, group_index=None):
         if feats.dtype != torch.float32:
             raise RuntimeError('sst_amd: features must be float32')
         feats = feats.contiguous()
         _lib.require_cuda(feats, perm, offsets)
-        out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2)
+        out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2, group_index)
         ctx.mode, ctx.m, ctx.shift = mode, m, inverse_shift
         ctx.shape = feats.shape
-        ctx.save_for_backward(offsets, inverse, argmax if argmax is not None else offsets)
+        ctx.has_gidx = group_index is not None
+        ctx.save_for_backward(offsets, inverse, argmax if argmax is not None else offsets,
+                              group_index if group_index is not None else offsets)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        offsets, inverse, argmax = ctx.saved_tensors
+        offsets, inverse, argmax, gidx = ctx.saved_tensors
         n, c = ctx.shape
         grad_out = grad_out.contiguous()
         grad_feats = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
         rc = _lib.load().sst_segment_reduce_bwd_f32(
             _lib.ptr(grad_out), ctx.m, c, _lib.ptr(inverse), ctx.shift, _lib.ptr(offsets),
-            _lib.ptr(argmax) if ctx.mode == 2 else None, n, ctx.mode, _lib.ptr(grad_feats), _lib.stream_ptr())
+            _lib.ptr(gidx) if ctx.has_gidx else None, _lib.ptr(argmax) if ctx.mode == 2 else None, n, ctx.mode,
+            _lib.ptr(grad_feats), _lib.stream_ptr())
         _lib.check(rc, 'sst_segment_reduce_bwd_f32')
-        return grad_feats, None, None, None, None, None, None
+        return grad_feats, None, None, None, None, None, None, None
 
 
-def segment_reduce(feats, plan, mode, first=0):
-    """Reduce rows of feats over groups [first, plan.m) of a UniquePlan; mode in 'sum'|'mean'|'max'."""
+def segment_reduce(feats, plan, mode, first=0, group_index=None, inverse=None):
+    """Reduce rows of feats over groups [first, plan.m) of a UniquePlan; mode in 'sum'|'mean'|'max'.
+    group_index ([m'] int32, with ``inverse`` = point -> output row map): output row g reduces group
+    group_index[g] (subset / re-ordering of the groups without gathering the result)."""
+    if group_index is not None:
+        return SegmentReduce.apply(feats, plan.perm, plan.offsets, inverse, group_index.numel(), REDUCE[mode], 0,
+                                   group_index)
     m = plan.m - first
     offsets = plan.offsets[first:]
     return SegmentReduce.apply(feats, plan.perm, offsets, plan.inverse, m, REDUCE[mode], -first)

@@ -164,11 +164,15 @@ class SSTInputLayerV2(nn.Module):
             def sel(t):
                 return t.index_select(0, keep_idx)
 
+        # the per-voxel window ids / drop levels / flat2win indices are what reference-style consumers (and the
+        # debug checks) read; the SRA kernels only need the window CSR and the positional embeddings
+        full = self.reference_outputs or self.debug
         voxel_coors = sel(voxel_coors)
-        wins = (sel(win0), sel(win1))
         ciws = (sel(ciw0), sel(ciw1))
-        lvls = (sel(rb['level0']), sel(rb['level1']))
-        f2ws = (sel(rb['flat2win0']), sel(rb['flat2win1']))
+        if full:
+            wins = (sel(win0), sel(win1))
+            lvls = (sel(rb['level0']), sel(rb['level1']))
+            f2ws = (sel(rb['flat2win0']), sel(rb['flat2win1']))
         identity_keys = list(level_keys) == list(range(len(level_keys)))
 
         # rows of the caller's voxel_feats that survive, in output order (shuffle and drop / re-order folded
@@ -182,12 +186,13 @@ class SSTInputLayerV2(nn.Module):
         voxel_info['voxel_coors'] = voxel_coors
         voxel_info['voxel_keep_inds'] = keep_idx
         for i in range(2):
-            voxel_info[f'batch_win_inds_shift{i}'] = wins[i].long()
             voxel_info[f'coors_in_win_shift{i}'] = ciws[i].long()
-            lv = lvls[i].long()
-            if not identity_keys:  # drop_info keyed by something else than 0..n-1
-                lv = torch.tensor(level_keys, device=lv.device, dtype=torch.long)[lv.clamp(min=0)]
-            voxel_info[f'voxel_drop_level_shift{i}'] = lv
+            if full:
+                voxel_info[f'batch_win_inds_shift{i}'] = wins[i].long()
+                lv = lvls[i].long()
+                if not identity_keys:  # drop_info keyed by something else than 0..n-1
+                    lv = torch.tensor(level_keys, device=lv.device, dtype=torch.long)[lv.clamp(min=0)]
+                voxel_info[f'voxel_drop_level_shift{i}'] = lv
             voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep,
                                                             max_tokens_cap)
             voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], feat_dim, dtype)

@@ -47,12 +47,14 @@ class ScatterPlan(object):
         self.coors_map = coors_map      # [N] int32, point -> kept voxel (-1: discarded)
         self.reduce_count = reduce_count  # [M] int32
         self.num_voxels = voxel_coors.size(0)
+        self._keep_i32 = keep_idx.to(torch.int32) if keep_idx is not None else None
 
     def reduce(self, feats, mode):
         if self.keep_idx is None:
             return K.segment_reduce(feats, self.plan, mode, first=self.first)
-        full = K.segment_reduce(feats, self.plan, mode, first=0)
-        return full.index_select(0, self.keep_idx)
+        # kept groups addressed through an index inside the kernel: no gather of the result (and no index_add in
+        # its backward)
+        return K.segment_reduce(feats, self.plan, mode, group_index=self._keep_i32, inverse=self.coors_map)
 
 
 def build_scatter_plan(coors, grid_zyx=None, reference_compat=True):
