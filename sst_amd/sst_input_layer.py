@@ -37,6 +37,13 @@ class PseudoMiddleEncoderForSpconvFSD(nn.Module):
         return {'voxel_feats': voxel_feats, 'voxel_coors': voxel_coors}
 
 
+def _nonzero_known(mask, count):
+    """indices of the set entries of a 1-D mask whose number is already known on the host: no readback"""
+    if hasattr(torch, 'nonzero_static'):
+        return torch.nonzero_static(mask, size=int(count)).squeeze(1)
+    return torch.nonzero(mask).squeeze(1)
+
+
 @MIDDLE_ENCODERS.register_module()
 class SSTInputLayerV2(nn.Module):
 
@@ -146,7 +153,7 @@ class SSTInputLayerV2(nn.Module):
         tok = [rb['tok0'], rb['tok1']]
         if self.window_major and m_keep > 0:
             perm = rb['tok0'][:m_keep].long()                      # kept-voxel index at every shift-0 window slot
-            keep_idx = perm if keep_all else torch.nonzero(rb['keep']).squeeze(1).index_select(0, perm)
+            keep_idx = perm if keep_all else _nonzero_known(rb['keep'], m_keep).index_select(0, perm)
             inv = torch.empty(m_keep, dtype=torch.int32, device=perm.device)
             inv[perm] = torch.arange(m_keep, dtype=torch.int32, device=perm.device)
             tok = [torch.arange(m_keep, dtype=torch.int32, device=perm.device), inv[rb['tok1'][:m_keep].long()]]
@@ -159,7 +166,7 @@ class SSTInputLayerV2(nn.Module):
             def sel(t):
                 return t
         else:
-            keep_idx = torch.nonzero(rb['keep']).squeeze(1)
+            keep_idx = _nonzero_known(rb['keep'], m_keep)
 
             def sel(t):
                 return t.index_select(0, keep_idx)
@@ -380,7 +387,7 @@ class SSTInputLayer(nn.Module):
         if m_keep == m:
             keep_idx = torch.arange(m, device=coors.device, dtype=torch.long)
         else:
-            keep_idx = torch.nonzero(rb['keep']).squeeze(1)
+            keep_idx = _nonzero_known(rb['keep'], m_keep)
         sel = (lambda t: t) if m_keep == m else (lambda t: t.index_select(0, keep_idx))
         voxel_feat = sel(voxel_feat)
         coors = sel(coors)

@@ -67,9 +67,11 @@ def build_scatter_plan(coors, grid_zyx=None, reference_compat=True):
     coors = coors.contiguous()
     n, k = coors.shape
     batched = k == 4
+    bmax_known = None
     if batched:
         if grid_zyx is not None:
             bmax = int(coors[-1, 0].item()) if n > 0 else 0  # the reference reads coors[-1,0] too
+            bmax_known = bmax
             mins = [0, -1, -1, -1]
             extents = [bmax + 1] + [int(g) + 1 for g in grid_zyx]
         elif n > 0:
@@ -100,6 +102,10 @@ def build_scatter_plan(coors, grid_zyx=None, reference_compat=True):
         else:
             first = 1 if bool((plan.ukeys[0] == 0).item()) else 0
         return ScatterPlan(plan, first, None, all_coors[first:], plan.inverse - first, counts[first:].contiguous())
+    if reference_compat and bmax_known == 0:
+        # a single sample: "drop the first row of every sample" is the contiguous first = 1 case (no keep index,
+        # no compaction, no extra readback)
+        return ScatterPlan(plan, 1, None, all_coors[1:], plan.inverse - 1, counts[1:].contiguous())
     # batched: the reference loops over samples, so the "first row" is dropped once PER SAMPLE
     b = all_coors[:, 0]
     is_first = torch.ones_like(b, dtype=torch.bool)
