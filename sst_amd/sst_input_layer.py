@@ -128,7 +128,14 @@ class SSTInputLayerV2(nn.Module):
 
         shuffle_inds = None
         if self.shuffle_voxels:
-            shuffle_inds = torch.randperm(len(voxel_coors), device=voxel_coors.device)
+            # random permutation = order of 24-bit random keys under the library's radix sort (3 passes; torch.randperm
+            # runs a ~25-launch merge sort).  Ties (probability ~M / 2^24 per voxel) keep their input order.
+            m0 = len(voxel_coors)
+            if m0 > 0 and voxel_coors.is_cuda:
+                keys = torch.randint(0, 1 << 24, (m0,), device=voxel_coors.device, dtype=torch.int64)
+                shuffle_inds = K.sort_pairs_u64(keys, 24)[1].long()
+            else:
+                shuffle_inds = torch.randperm(m0, device=voxel_coors.device)
             voxel_coors = voxel_coors[shuffle_inds]
         voxel_coors = voxel_coors.contiguous()
 
