@@ -304,6 +304,21 @@ void sst_event_destroy(void* ev);
 float sst_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop`; < 0 on error */
 int sst_sra_attn_profile_next_fwd(void* start, void* stop);
 
+/* ------------------------------------------------------------------------------------------------
+ * (§8 f2) Connected components of the graph "same sample and xy distance < dist" over n points — FSD's
+ * ClusterAssigner.  Replaces find_connected_componets (models/detectors/single_stage_fsd.py:45-68): dense N x N
+ * distance matrix, `.cpu()`, scipy.sparse.csgraph.connected_components per sample, running label base.
+ *   d_points [n, >= 2] fp32 (x, y first; row stride ld elements), d_batch [n] int32 sample index (samples stored
+ *   one after the other, as the sorted-unique that produces the centres leaves them).
+ *   d_labels [n] int32: components numbered by their smallest point index (scipy's order of first appearance;
+ *   with contiguous samples = the reference's per-sample numbering + running base).  Bit-exact: the edge test
+ *   uses the reference's fp32 operations (sub, mul, add, sqrt, <).  d_num_components (optional, device int32).
+ * Workspace: sst_connected_components_workspace_bytes(n).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_connected_components_workspace_bytes(int64_t n);
+int sst_connected_components_xy_f32(const float* d_points, int64_t ld, const int32_t* d_batch, int64_t n, float dist,
+                                    int32_t* d_labels, int32_t* d_num_components, void* d_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

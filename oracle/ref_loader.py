@@ -201,3 +201,23 @@ def load_reference():
     ns.backbones = backbones
     _LOADED = ns
     return ns
+
+
+def load_reference_function(relpath, name, extra_globals=None):
+    """One module-level function of a reference file, executed from the file's own source text (for files whose
+    imports cannot be satisfied here, e.g. detectors/single_stage_fsd.py needs mmdet / mmseg).  Nothing is copied
+    into the repository."""
+    import ast
+    import textwrap
+    path = os.path.join(REF_ROOT, relpath)
+    src = open(path).read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            code = textwrap.dedent(ast.get_source_segment(src, node))
+            glb = {'torch': torch}
+            glb.update(extra_globals or {})
+            exec(compile(code, path + ':' + name, 'exec'), glb)
+            return glb[name]
+    raise KeyError(name)
+

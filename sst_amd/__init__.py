@@ -19,6 +19,8 @@ from .voxel_encoder import DynamicScatterVFE, DynamicVFE, DynamicVFELayer, Dynam
 from .sst_input_layer import PseudoMiddleEncoderForSpconvFSD, SSTInputLayer, SSTInputLayerV2
 from .sst_basic_block import BasicShiftBlockV2, EncoderLayer, WindowAttention
 from .backbones import SIR, SSTv1, SSTv2
+from .cluster import (ClusterAssigner, connected_components_xy, filter_almost_empty, find_connected_componets,  # noqa: F401
+                      find_connected_componets_single_batch, modify_cluster_by_class)
 
 __version__ = '0.1.0'
 
@@ -31,5 +33,7 @@ __all__ = [
     'DynamicScatterVFE', 'SIRLayer', 'DynamicVFELayer', 'DynamicVFELayerV2', 'SSTInputLayer', 'SSTInputLayerV2',
     'PseudoMiddleEncoderForSpconvFSD', 'WindowAttention', 'EncoderLayer', 'BasicShiftBlockV2', 'SSTv1', 'SSTv2', 'SIR',
     'MODELS', 'VOXEL_ENCODERS', 'MIDDLE_ENCODERS', 'BACKBONES', 'build_voxel_encoder', 'build_middle_encoder',
-    'build_backbone', 'WindowPlan', 'sra_attention', 'sra_attention_qk_v',
+    'build_backbone', 'WindowPlan', 'sra_attention', 'sra_attention_qk_v', 'ClusterAssigner',
+    'find_connected_componets', 'find_connected_componets_single_batch', 'filter_almost_empty',
+    'modify_cluster_by_class', 'connected_components_xy',
 ]

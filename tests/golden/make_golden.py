@@ -289,6 +289,31 @@ def gen_sir(ref):
     save('sir.npz', **arrays)
 
 
+def gen_cluster():
+    """FSD cluster assignment: the reference's find_connected_componets / ..._single_batch executed from their own
+    source text (detectors/single_stage_fsd.py:45-84; the file itself needs mmdet / mmseg to import)."""
+    from scipy.sparse.csgraph import connected_components
+    rel = 'mmdet3d/models/detectors/single_stage_fsd.py'
+    f_train = ref_loader.load_reference_function(rel, 'find_connected_componets',
+                                                 {'connected_components': connected_components})
+    f_test = ref_loader.load_reference_function(rel, 'find_connected_componets_single_batch',
+                                                {'connected_components': connected_components})
+    g = torch.Generator().manual_seed(7)
+    arrays = {}
+    # (class, connected_dist, spread): the three classes of configs/fsd/fsd_waymoD1_1x.py:281-285
+    for tag, dist, sigma, n in (('car', 0.6, 0.7, 1800), ('cyclist', 0.4, 0.35, 900), ('pedestrian', 0.1, 0.06, 1200)):
+        centers = torch.rand(60, 2, generator=g) * 100 - 50
+        pts = centers[torch.randint(0, 60, (n,), generator=g)] + torch.randn(n, 2, generator=g) * sigma
+        pts = torch.cat([pts, torch.rand(n, 1, generator=g) * 4 - 2], 1)
+        batch = torch.sort(torch.randint(0, 3, (n,), generator=g))[0].int()
+        arrays[f'in::{tag}::points'] = t2n(pts)
+        arrays[f'in::{tag}::batch'] = t2n(batch)
+        arrays[f'in::{tag}::dist'] = np.float32(dist)
+        arrays[f'out::{tag}::train'] = t2n(f_train(pts, batch, dist))
+        arrays[f'out::{tag}::test'] = t2n(f_test(pts, batch, dist))
+    save('cluster.npz', **arrays)
+
+
 def main():
     assert ref_loader.available(), 'the reference tree is required'
     build_ref.build()
@@ -300,6 +325,7 @@ def main():
     gen_dynamic_vfe(ref)
     gen_scatter_vfe(ref)
     gen_sir(ref)
+    gen_cluster()
 
 
 if __name__ == '__main__':

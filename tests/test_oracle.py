@@ -175,3 +175,30 @@ def test_sra_core_backward_oracle_numeric():
             fa = (sst_oracle.sra_core(*args_a, tok, off, h) * do).sum()
             fb = (sst_oracle.sra_core(*args_b, tok, off, h) * do).sum()
             assert abs((fa - fb) / (2 * eps) - grad[i, j]) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['car', 'cyclist', 'pedestrian'])
+def test_cluster_oracle_matches_reference_golden(tag):
+    """connected-components restatement against labels produced by the reference's own functions
+    (tests/golden/make_golden.py::gen_cluster)."""
+    from oracle import cluster_oracle
+    g = load_golden('cluster.npz')
+    pts, batch, dist = g[f'in::{tag}::points'], g[f'in::{tag}::batch'], float(g[f'in::{tag}::dist'])
+    np.testing.assert_array_equal(cluster_oracle.find_connected_components(pts, batch, dist), g[f'out::{tag}::train'])
+    np.testing.assert_array_equal(cluster_oracle.find_connected_components_single_batch(pts, dist),
+                                  g[f'out::{tag}::test'])
+
+
+def test_cluster_oracle_matches_reference_function_live():
+    from oracle import cluster_oracle, ref_loader
+    if not ref_loader.available():
+        pytest.skip('reference tree not present')
+    from scipy.sparse.csgraph import connected_components
+    f = ref_loader.load_reference_function('mmdet3d/models/detectors/single_stage_fsd.py', 'find_connected_componets',
+                                           {'connected_components': connected_components})
+    gen = torch.Generator().manual_seed(3)
+    pts = torch.rand(700, 3, generator=gen) * torch.tensor([30.0, 30.0, 2.0])
+    batch = torch.sort(torch.randint(0, 4, (700,), generator=gen))[0].int()
+    for dist in (0.3, 1.0, 2.5):
+        ref = f(pts, batch, dist).numpy()
+        np.testing.assert_array_equal(cluster_oracle.find_connected_components(pts.numpy(), batch.numpy(), dist), ref)

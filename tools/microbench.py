@@ -200,6 +200,41 @@ def bench_sir():
               f'({100 * byt / med / 1e6 / 8000:.1f} % of 8 TB/s)')
 
 
+def bench_cluster():
+    """FSD cluster assignment: the union-find kernel against the reference's data flow on the same box (dense
+    N x N distance matrix on the GPU -> .cpu() -> scipy connected_components -> .to(device)), labels compared."""
+    import time
+    from scipy.sparse.csgraph import connected_components
+    for n, dist, spread in ((2000, 0.6, 60.0), (8000, 0.6, 120.0), (20000, 0.3, 150.0)):
+        g = torch.Generator().manual_seed(n)
+        pts = (torch.rand(n, 3, generator=g) * spread).to(DEV)
+        batch = torch.sort(torch.randint(0, 2, (n,), generator=g))[0].int().to(DEV)
+        med, _ = timeit(lambda: sst_amd.find_connected_componets(pts, batch, dist), iters=20, warmup=3)
+        got = sst_amd.find_connected_componets(pts, batch, dist)
+
+        def reference_flow():
+            out = torch.zeros_like(batch) - 1
+            base = 0
+            for i in range(int(batch.max().item()) + 1):
+                m = batch == i
+                p = pts[m]
+                d = p[:, None, :2] - p[None, :, :2]
+                adj = ((d ** 2).sum(2) ** 0.5 < dist).cpu().numpy()
+                c = torch.from_numpy(connected_components(adj, directed=False)[1]).to(DEV).int() + base
+                base = int(c.max().item()) + 1
+                out[m] = c
+            return out
+        reference_flow()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ref = reference_flow()
+        torch.cuda.synchronize()
+        t_ref = time.perf_counter() - t0
+        same = bool(torch.equal(ref, got))
+        print(f'connected components n={n} dist={dist}: kernel {med * 1e3:.0f} us ({int(got.max()) + 1} components), '
+              f'reference data flow {t_ref * 1e3:.1f} ms, labels identical: {same}')
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('sra', 'all'):
@@ -212,3 +247,5 @@ if __name__ == '__main__':
         bench_gemm()
     if what in ('sir',):
         bench_sir()
+    if what in ('cluster',):
+        bench_cluster()
