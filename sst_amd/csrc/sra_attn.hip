@@ -322,11 +322,14 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (j < nt) {
-      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      // Keys sit in their 16-key tile TRANSPOSED as a 4 x 4 index grid: tile position p holds key (p >> 2) + 4 * (p & 3).
+      // MFMA k-step r of P V then covers the four CONSECUTIVE keys 4r..4r+3 (position 4g + r <-> key g + 4r), so in
+      // the last, partially filled tile the steps that would only see padded keys are skipped altogether.
+      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + (c >> 2) + 4 * (c & 3), 64);
       kf[j] = ldg4(K, krow * ldk + hoff + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint32_t vrow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
+        const uint32_t vrow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + g + 4 * r, 64);
         vf[j][r] = ldg1(V, vrow * ldv + hoff + c);
       }
     } else {
@@ -342,6 +345,7 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
     return (uint32_t)__shfl(sel, (i & 3) * 16 + c, 64);
   };
   const float qscale = scale * kLog2e;  // scores in the log2 domain: softmax via v_exp_f32 directly
+  const int last_steps = (t - 16 * (nt - 1) + 3) >> 2;  // k-steps of the last key tile that contain a real key (1..4)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // S^T tiles of one query tile: st[j][r] = S[query 16i+c][key 16j+4g+r]; k-step major so that consecutive
@@ -369,7 +373,7 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
       if (j < nt) {
         if (j == nt - 1) {  // only the last tile can hold padded keys
 #pragma unroll
-          for (int r = 0; r < 4; ++r) st[j][r] = (j * 16 + 4 * g + r) < t ? st[j][r] : -INFINITY;
+          for (int r = 0; r < 4; ++r) st[j][r] = (j * 16 + g + 4 * r) < t ? st[j][r] : -INFINITY;
         }
         mx = fmaxf(mx, fmaxf(fmaxf(st[j][0], st[j][1]), fmaxf(st[j][2], st[j][3])));
       }
@@ -393,10 +397,11 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if (j < nt) {
+        const int steps = (j == nt - 1) ? last_steps : 4;  // wave-uniform
         o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][0], st[j][0], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][1], st[j][1], o1, 0, 0, 0);
-        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][2], st[j][2], o2, 0, 0, 0);
-        o3 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][3], st[j][3], o3, 0, 0, 0);
+        if (steps > 1) o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][1], st[j][1], o1, 0, 0, 0);
+        if (steps > 2) o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][2], st[j][2], o2, 0, 0, 0);
+        if (steps > 3) o3 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j][3], st[j][3], o3, 0, 0, 0);
       }
     }
     if (i * 16 + c < t) {
