@@ -634,12 +634,14 @@ __device__ __forceinline__ void sra_bwd_dq_body(const float* __restrict__ Q, con
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (j < nt) {
-      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      // keys transposed inside their tile (position p <-> key (p >> 2) + 4 * (p & 3)) as in the forward kernel: k-step r
+      // of dQ += dS K covers the consecutive keys 4r..4r+3, padded steps of the last tile are skipped
+      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + (c >> 2) + 4 * (c & 3), 64);
       kf[j] = ldg4(K, krow * ldk + hoff + 4 * g);
       vf[j] = ldg4(V, krow * ldv + hoff + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint32_t crow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + 4 * g + r, 64);
+        const uint32_t crow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + g + 4 * r, 64);
         kc[j][r] = ldg1(K, crow * ldk + hoff + c);
       }
     } else {
@@ -655,6 +657,7 @@ __device__ __forceinline__ void sra_bwd_dq_body(const float* __restrict__ Q, con
     return (uint32_t)__shfl(sel, (i & 3) * 16 + within, 64);
   };
   const float s2 = scale * kLog2e;
+  const int last_steps = (t - 16 * (nt - 1) + 3) >> 2;  // k-steps of the last key tile that hold a real key
   for (int i = 0; i < nt; ++i) {
     const uint32_t qrow = tok_at(i, c);
     const float4 qf = ldg4(Q, qrow * ldq + hoff + 4 * g);
@@ -676,13 +679,14 @@ __device__ __forceinline__ void sra_bwd_dq_body(const float* __restrict__ Q, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pe = __builtin_amdgcn_exp2f(fmaf(s[r], s2, -lse2));
-          if (j == nt - 1) pe = (j * 16 + 4 * g + r) < t ? pe : 0.f;  // padded keys
+          if (j == nt - 1) pe = (j * 16 + g + 4 * r) < t ? pe : 0.f;  // padded keys
           ds[r] = pe * (dp[r] - dd) * scale;
         }
+        const int steps = (j == nt - 1) ? last_steps : 4;  // wave-uniform
         dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[0], kc[j][0], dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[1], kc[j][1], dq1, 0, 0, 0);
-        dq2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[2], kc[j][2], dq2, 0, 0, 0);
-        dq3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[3], kc[j][3], dq3, 0, 0, 0);
+        if (steps > 1) dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[1], kc[j][1], dq1, 0, 0, 0);
+        if (steps > 2) dq2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[2], kc[j][2], dq2, 0, 0, 0);
+        if (steps > 3) dq3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[3], kc[j][3], dq3, 0, 0, 0);
       }
     }
     // D layout: value r = dQ[query 16i + 4g + r][d = c]   (rows of padded queries are never stored)
