@@ -119,6 +119,7 @@ def main():
     ap.add_argument('--blocks', type=int, default=6)
     ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--time-sra-bwd', action='store_true', help='also bracket the SRA backward launches with events')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
     ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL, default) | gloo (dev check of the N>1 path on one GPU)')
@@ -185,6 +186,10 @@ def main():
 
     sink = []
     K.EVENT_SINK = sink
+    # HIP events bound to every 5th SRA forward launch of the timed region (12 launches per step, both window shifts
+    # get sampled); the backward kernels are timed only on request: every pair of marks drains the queue for ~5 us
+    K.EVENT_STRIDE = 5
+    K.EVENT_KINDS = ('sra_fwd', 'sra_bwd') if args.time_sra_bwd else ('sra_fwd',)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -239,7 +244,8 @@ def main():
                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'algorithmic_bytes_per_launch': int(SRA_BYTES_PER_TOKEN * tokens),
-                    'avg_launch_ms': round(ms, 4), 'launches': launches}
+                    'avg_launch_ms': round(ms, 4), 'launches_timed': launches,
+                    'sampling': 'every 5th forward launch of the timed region'}
         if bwd is not None:
             roofline['sra_bwd_avg_launch_ms'] = round(bwd[0], 4)
         # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately by
