@@ -1,0 +1,83 @@
+"""GPU: the whole bench pipeline (voxelize -> DynamicVFE -> SSTInputLayerV2 -> SRA blocks) against the CPU port of
+the reference's data flow (oracle/cpu_pipeline.py: padded per-level windows + nn.MultiheadAttention with a key
+padding mask), same weights, same cloud, training-mode voxel drop, no shuffle.  Voxel indices bit-exact, features
+and gradients within the north-star tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _copy_weights(gpu, cpu):
+    """bench.Pipeline (reference parameter names) -> oracle.cpu_pipeline.CpuSSTBackbone"""
+    with torch.no_grad():
+        for i, layer in enumerate(gpu.voxel_encoder.vfe_layers):
+            cpu.vfe.linears[i].weight.copy_(layer.linear.weight.cpu())
+            cpu.vfe.norms[i].weight.copy_(layer.norm.weight.cpu())
+            cpu.vfe.norms[i].bias.copy_(layer.norm.bias.cpu())
+        k = 0
+        for block in gpu.backbone.block_list:
+            for enc in block.encoder_list:
+                dst = cpu.layers[k]
+                k += 1
+                dst.self_attn.load_state_dict({n: p.cpu() for n, p in enc.win_attn.self_attn.state_dict().items()})
+                for name in ('linear1', 'linear2', 'norm1', 'norm2'):
+                    getattr(dst, name).load_state_dict({n: p.cpu() for n, p in getattr(enc, name).state_dict().items()})
+        assert k == len(cpu.layers)
+
+
+@pytest.mark.parametrize('n_points,blocks', [(6000, 1), (30000, 2)])
+def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks):
+    import bench
+    from oracle.cpu_pipeline import CpuSSTBackbone
+    torch.manual_seed(0)
+    gpu = bench.Pipeline(blocks).to(DEV).train()
+    gpu.middle_encoder.shuffle_voxels = False        # the CPU port has no shuffle; the drop itself stays on
+    cpu = CpuSSTBackbone(bench.VOXEL_SIZE, bench.PC_RANGE, bench.DROP_TRAIN, num_blocks=blocks).train()
+    _copy_weights(gpu, cpu)
+    # crowd part of the cloud so that windows exceed the 100-token cap and voxels really get dropped
+    g = torch.Generator().manual_seed(1)
+    pts = bench.make_cloud(n_points, 5, 'cpu')
+    dense = torch.rand(n_points // 3, 3, generator=g) * torch.tensor([7.0, 7.0, 6.0]) + torch.tensor([10.0, 10.0, -2.0])
+    frames = [torch.cat([pts, dense]), bench.make_cloud(n_points // 2, 6, 'cpu')]
+
+    info_out = {}
+    orig_apply = gpu.middle_encoder.apply_plan
+
+    def spy(plan, feats):
+        info = orig_apply(plan, feats)
+        info_out['coors'] = info['voxel_coors']
+        return info
+    gpu.middle_encoder.apply_plan = spy
+    out_g = gpu([f.to(DEV) for f in frames])
+    out_c = cpu(frames)
+    # the CPU port keeps the kept voxels in sorted-unique order; the GPU pipeline emits them window-major
+    coors_g = info_out['coors'].cpu().long()
+    key_g = ((coors_g[:, 0] * 2 + coors_g[:, 1]) * 468 + coors_g[:, 2]) * 468 + coors_g[:, 3]
+    order = torch.argsort(key_g)
+    assert out_g.size(0) == out_c.size(0), 'different sets of kept voxels'
+    assert torch.equal(key_g[order], torch.sort(key_g)[0]) and key_g.unique().numel() == key_g.numel()
+    err = (out_g.detach().cpu()[order] - out_c.detach()).abs().max().item()
+    assert err < 1e-3, f'end-to-end feature error {err}'
+
+    # gradients of every parameter through the whole path
+    wsum_g = torch.randn(out_c.shape, generator=g)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel())
+    (out_g * wsum_g[inv].to(DEV)).sum().backward()
+    (out_c * wsum_g).sum().backward()
+    checks = [(gpu.voxel_encoder.vfe_layers[0].linear.weight, cpu.vfe.linears[0].weight),
+              (gpu.voxel_encoder.vfe_layers[1].linear.weight, cpu.vfe.linears[1].weight),
+              (gpu.backbone.block_list[0].encoder_list[0].win_attn.self_attn.in_proj_weight,
+               cpu.layers[0].self_attn.in_proj_weight),
+              (gpu.backbone.block_list[-1].encoder_list[1].linear2.weight, cpu.layers[-1].linear2.weight)]
+    # relative to the largest entry of each gradient.  The looser bound than on the features covers the argmax /
+    # ReLU decisions of the VFE (max pooling over the points of a voxel, BN + ReLU): an activation within rounding
+    # of a tie takes the other branch on the other device and moves whole gradient contributions.
+    errs = []
+    for pg, pc in checks:
+        scale = max(1.0, pc.grad.abs().max().item())
+        errs.append((pg.grad.cpu() - pc.grad).abs().max().item() / scale)
+    assert max(errs) < 1e-2, f'relative parameter gradient errors {errs}'
