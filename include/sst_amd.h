@@ -261,8 +261,8 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
  *      statistics and the cross-rank averaging of naiveSyncBN stay on the host side).
  *   sst_bn_act_bwd_reduce_f32: d_sum_g[c] = sum g, d_sum_gxhat[c] = sum g * xhat with g = dy masked by the
  *     activation and xhat = (x - mean) * invstd  (= dbias, dweight of the affine norm).
- *   sst_bn_act_bwd_apply_f32: dx = scale * (g - coef_a[c] - xhat * coef_b[c])
- *     (training: coef_a = sum_g / count, coef_b = sum_gxhat / count; eval: zeros).
+ *   sst_bn_act_bwd_apply_f32: dx = scale * (g - coef_scale * coef_a[c] - xhat * coef_scale * coef_b[c])
+ *     (training: coef_a = sum_g, coef_b = sum_gxhat, coef_scale = 1 / count; eval: coef_scale = 0).
  * Workspace: sst_bn_workspace_bytes(n, c) for the stats / reduce calls.
  * ---------------------------------------------------------------------------------------------- */
 int64_t sst_bn_workspace_bytes(int64_t n, int c);
@@ -276,8 +276,14 @@ int sst_bn_act_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, in
                               void* d_workspace, void* stream);
 int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
                              const float* d_mean, const float* d_invstd, const float* d_scale,
-                             const float* d_shift, const float* d_coef_a, const float* d_coef_b, int act,
-                             float* d_dx, int64_t lddx, void* stream);
+                             const float* d_shift, const float* d_coef_a, const float* d_coef_b, float coef_scale,
+                             int act, float* d_dx, int64_t lddx, void* stream);
+/* Single-process training forward in one call: column moments of x, then d_out4 [4][c] = mean, invstd,
+ * scale = weight * invstd, shift = bias - mean * scale, and running = (1 - factor) * running + factor * {mean,
+ * var * n / (n - 1)} in place (nn.BatchNorm1d's bookkeeping; d_weight / d_bias / d_running_* may be NULL). */
+int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const float* d_weight, const float* d_bias,
+                       float eps, float* d_running_mean, float* d_running_var, float factor, float* d_out4,
+                       void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tall fp32 linear layer  y[m, n] (+)= x[m, k] W^T + bias  on the fp32 MFMA pipe with W resident in LDS

@@ -109,6 +109,48 @@ __global__ __launch_bounds__(1024) void bn_finish_k(const double* __restrict__ p
   }
 }
 
+// Training-mode "prepare" of one BatchNorm layer from the block partials: mean / biased variance -> invstd,
+// scale = weight * invstd, shift = bias - mean * scale, and the running statistics
+// (running = (1 - f) * running + f * {mean, var * unbiased}) in the same launch: the [C]-sized algebra costs a dozen
+// tiny element-wise launches when it is left to the host framework.
+__global__ __launch_bounds__(1024) void bn_prepare_finish_k(const double* __restrict__ partial, int nb, int c,
+                                                            double inv_n, const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, float eps,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, float factor,
+                                                            float unbiased, float* __restrict__ out) {  // out [4][c]
+  __shared__ double r1[32][33], r2[32][33];
+  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cx;
+  double a1 = 0., a2 = 0.;
+  if (ch < c)
+    for (int b = gy; b < nb; b += 32) {
+      a1 += partial[(int64_t)b * 2 * c + ch];
+      a2 += partial[(int64_t)b * 2 * c + c + ch];
+    }
+  r1[gy][cx] = a1;
+  r2[gy][cx] = a2;
+  __syncthreads();
+  if (gy == 0 && ch < c) {
+    double t1 = 0., t2 = 0.;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t1 += r1[k][cx], t2 += r2[k][cx];
+    const double m = t1 * inv_n;
+    double v = t2 * inv_n - m * m;
+    if (v < 0.) v = 0.;
+    const float mean = (float)m, var = (float)v;
+    const float invstd = rsqrtf(var + eps);
+    const float sc = weight != nullptr ? weight[ch] * invstd : invstd;
+    const float sh = (bias != nullptr ? bias[ch] : 0.f) - mean * sc;
+    out[ch] = mean;
+    out[c + ch] = invstd;
+    out[2 * c + ch] = sc;
+    out[3 * c + ch] = sh;
+    if (running_mean != nullptr) running_mean[ch] = (1.f - factor) * running_mean[ch] + factor * mean;
+    if (running_var != nullptr) running_var[ch] = (1.f - factor) * running_var[ch] + factor * (var * unbiased);
+  }
+}
+
 // y = act(x * scale + shift); one float4 per thread, grid-stride.
 __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_k(const float* __restrict__ x, int64_t n, int c, int64_t ldx,
                                                           const float* __restrict__ scale,
@@ -141,7 +183,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_k(const float* __restri
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ ca, const float* __restrict__ cb,
-                                                          int act, float* __restrict__ dx, int64_t lddx) {
+                                                          float coef_scale, int act, float* __restrict__ dx,
+                                                          int64_t lddx) {
   const int c4 = c >> 2;
   const int64_t total = n * c4;
   for (int64_t i = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBnThreads) {
@@ -153,8 +196,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_k(const float* __restri
     const float4 sh = *(const float4*)(shift + cc * 4);
     const float4 mu = *(const float4*)(mean + cc * 4);
     const float4 is = *(const float4*)(invstd + cc * 4);
-    const float4 a = *(const float4*)(ca + cc * 4);
-    const float4 b = *(const float4*)(cb + cc * 4);
+    float4 a = *(const float4*)(ca + cc * 4);  // sum g, sum g * xhat: scaled to means here (0 in eval mode)
+    float4 b = *(const float4*)(cb + cc * 4);
+    a.x *= coef_scale, a.y *= coef_scale, a.z *= coef_scale, a.w *= coef_scale;
+    b.x *= coef_scale, b.y *= coef_scale, b.z *= coef_scale, b.w *= coef_scale;
     if (act) {
       g.x = (v.x * sc.x + sh.x) > 0.f ? g.x : 0.f;
       g.y = (v.y * sc.y + sh.y) > 0.f ? g.y : 0.f;
@@ -254,8 +299,8 @@ int sst_bn_act_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, in
 
 int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
                              const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
-                             const float* d_coef_a, const float* d_coef_b, int act, float* d_dx, int64_t lddx,
-                             void* stream) {
+                             const float* d_coef_a, const float* d_coef_b, float coef_scale, int act, float* d_dx,
+                             int64_t lddx, void* stream) {
   if (!bn_shape_ok(n, c) || ldx < c || lddy < c || lddx < c || (ldx & 3) || (lddy & 3) || (lddx & 3) || act < 0 ||
       act > 1)
     return SST_ERR_UNSUPPORTED;
@@ -267,7 +312,27 @@ int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int
   int64_t grid = sst_div_up(total, kBnThreads);
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(bn_act_bwd_k, dim3((unsigned)grid), dim3(kBnThreads), 0, (hipStream_t)stream, d_dy, d_x, n, c,
-                     lddy, ldx, d_mean, d_invstd, d_scale, d_shift, d_coef_a, d_coef_b, act, d_dx, lddx);
+                     lddy, ldx, d_mean, d_invstd, d_scale, d_shift, d_coef_a, d_coef_b, coef_scale, act, d_dx, lddx);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const float* d_weight, const float* d_bias,
+                       float eps, float* d_running_mean, float* d_running_var, float factor, float* d_out4,
+                       void* d_workspace, void* stream) {
+  if (!bn_shape_ok(n, c) || ld < c || (ld & 3)) return SST_ERR_UNSUPPORTED;
+  if (n == 0) return SST_ERR_ARG;
+  if (!d_x || !d_out4 || !d_workspace || ((uintptr_t)d_x & 15)) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t rpb;
+  const int grid = moments_grid(n, &rpb);
+  double* partial = (double*)d_workspace;
+  const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
+  hipLaunchKernelGGL(bn_moments_k<0>, dim3(grid), dim3(kBnThreads), lds, st, d_x, nullptr, n, c, ld, 0, nullptr,
+                     nullptr, nullptr, nullptr, 0, rpb, partial);
+  const float unbiased = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_prepare_finish_k, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 1.0 / (double)n,
+                     d_weight, d_bias, eps, d_running_mean, d_running_var, factor, unbiased, d_out4);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -51,58 +51,52 @@ def _dist_world():
 
 
 class _BatchNormActFn(Function):
-    """y = act(x * scale + shift) with scale = weight * invstd, shift = bias - mean * scale, through
-    csrc/bn.hip.  ``batch_stats``: mean / invstd were computed from this batch (training), so the gradient
-    flows through them: dx = scale * (g - (G1 + xhat * G2) / count), G1 = sum g, G2 = sum g * xhat taken over
-    every rank when ``sync`` (naiveSyncBN averages the per-rank means, ops/norm.py:53-58, hence
-    count = world_size * N_local; its AllReduce backward sums the statistic gradients, :20-24)."""
+    """y = act(x * scale + shift) through csrc/bn.hip; ``prep`` [4, C] = mean, invstd, scale, shift.
+    ``batch_stats``: mean / invstd were computed from this batch (training), so the gradient flows through them:
+    dx = scale * (g - (G1 + xhat * G2) / count), G1 = sum g, G2 = sum g * xhat taken over every rank when ``sync``
+    (naiveSyncBN averages the per-rank means, ops/norm.py:53-58, hence count = world_size * N_local; its AllReduce
+    backward sums the statistic gradients, :20-24)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mean, invstd, act, batch_stats, count, sync):
+    def forward(ctx, x, weight, bias, prep, act, batch_stats, count, sync):
         from . import _lib
         n, c = x.shape
-        scale = invstd if weight is None else weight.detach() * invstd
-        shift = -mean * scale if bias is None else bias.detach() - mean * scale
-        scale, shift = scale.contiguous(), shift.contiguous()
         y = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        rc = _lib.load().sst_bn_act_fwd_f32(_lib.ptr(x), n, c, x.stride(0), _lib.ptr(scale), _lib.ptr(shift),
+        rc = _lib.load().sst_bn_act_fwd_f32(_lib.ptr(x), n, c, x.stride(0), _lib.ptr(prep[2]), _lib.ptr(prep[3]),
                                             int(act), _lib.ptr(y), y.stride(0), _lib.stream_ptr())
         _lib.check(rc, 'sst_bn_act_fwd_f32')
-        ctx.save_for_backward(x, mean, invstd, scale, shift)
+        ctx.save_for_backward(x, prep)
         ctx.cfg = (int(act), bool(batch_stats), float(count), bool(sync), weight is not None, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import _lib
-        x, mean, invstd, scale, shift = ctx.saved_tensors
+        x, prep = ctx.saved_tensors
         act, batch_stats, count, sync, has_w, has_b = ctx.cfg
         n, c = x.shape
         dy = dy.contiguous()
         lib = _lib.load()
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
         ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
-        rc = lib.sst_bn_act_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(x), n, c, dy.stride(0), x.stride(0), _lib.ptr(mean),
-                                           _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), act, _lib.ptr(sums[0]),
-                                           _lib.ptr(sums[1]), _lib.ptr(ws), _lib.stream_ptr())
+        rc = lib.sst_bn_act_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(x), n, c, dy.stride(0), x.stride(0), _lib.ptr(prep[0]),
+                                           _lib.ptr(prep[1]), _lib.ptr(prep[2]), _lib.ptr(prep[3]), act,
+                                           _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, 'sst_bn_act_bwd_reduce_f32')
-        dweight = sums[1].clone() if has_w else None
-        dbias = sums[0].clone() if has_b else None
+        total = sums
+        if sync and batch_stats:
+            total = sums.clone()  # the parameter gradients stay the local sums (DDP averages them afterwards)
+            dist.all_reduce(total, async_op=False)
         dx = None
         if ctx.needs_input_grad[0]:
-            if batch_stats:
-                if sync:
-                    dist.all_reduce(sums, async_op=False)
-                coef = sums * (1.0 / count)
-            else:
-                coef = torch.zeros_like(sums)
             dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
             rc = lib.sst_bn_act_bwd_apply_f32(_lib.ptr(dy), _lib.ptr(x), n, c, dy.stride(0), x.stride(0),
-                                              _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift),
-                                              _lib.ptr(coef[0]), _lib.ptr(coef[1]), act, _lib.ptr(dx), dx.stride(0),
+                                              _lib.ptr(prep[0]), _lib.ptr(prep[1]), _lib.ptr(prep[2]), _lib.ptr(prep[3]),
+                                              _lib.ptr(total[0]), _lib.ptr(total[1]),
+                                              (1.0 / count) if batch_stats else 0.0, act, _lib.ptr(dx), dx.stride(0),
                                               _lib.stream_ptr())
             _lib.check(rc, 'sst_bn_act_bwd_apply_f32')
-        return dx, dweight, dbias, None, None, None, None, None, None
+        return dx, (sums[1] if has_w else None), (sums[0] if has_b else None), None, None, None, None, None
 
 
 def _bn_kernel_ok(bn, x):
@@ -128,16 +122,38 @@ def batch_norm_act(bn, x, relu=False):
     sync = isinstance(bn, NaiveSyncBatchNorm1d) and world > 1 and bn.training
     batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
     count = 1.0
-    if batch_stats:
-        lib = _lib.load()
+    lib = _lib.load()
+    prep = torch.empty((4, c), dtype=torch.float32, device=x.device)  # mean, invstd, scale, shift
+    if batch_stats and not sync:
+        # one call: moments, invstd / scale / shift and nn.BatchNorm1d's running-statistics bookkeeping
+        count = float(n)
+        factor = 0.0
+        update = bn.training and bn.track_running_stats and bn.running_mean is not None
+        if update:
+            factor = 0.0 if bn.momentum is None else bn.momentum
+            if bn.num_batches_tracked is not None:
+                with torch.no_grad():
+                    bn.num_batches_tracked.add_(1)
+                if bn.momentum is None:
+                    factor = 1.0 / float(bn.num_batches_tracked)
         xd = x.detach()
-        stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
         ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
-        rc = lib.sst_bn_stats_f32(_lib.ptr(xd), n, c, xd.stride(0), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(ws),
-                                  _lib.stream_ptr())
-        _lib.check(rc, 'sst_bn_stats_f32')
-        mean, var = stats[0], stats[1]
-        if sync:
+        rc = lib.sst_bn_prepare_f32(_lib.ptr(xd), n, c, xd.stride(0),
+                                    _lib.ptr(bn.weight.detach()) if bn.weight is not None else None,
+                                    _lib.ptr(bn.bias.detach()) if bn.bias is not None else None, float(bn.eps),
+                                    _lib.ptr(bn.running_mean) if update else None,
+                                    _lib.ptr(bn.running_var) if update else None, float(factor), _lib.ptr(prep),
+                                    _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, 'sst_bn_prepare_f32')
+    else:
+        if batch_stats:  # naiveSyncBN across ranks
+            xd = x.detach()
+            stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+            ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
+            rc = lib.sst_bn_stats_f32(_lib.ptr(xd), n, c, xd.stride(0), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
+                                      _lib.ptr(ws), _lib.stream_ptr())
+            _lib.check(rc, 'sst_bn_stats_f32')
+            mean, var = stats[0], stats[1]
             vec = torch.cat([mean, var + mean * mean], dim=0)  # [mean || meansqr], ops/norm.py:53
             dist.all_reduce(vec, async_op=False)
             vec = vec * (1.0 / world)
@@ -148,22 +164,13 @@ def batch_norm_act(bn, x, relu=False):
                 bn.running_var += bn.momentum * (var - bn.running_var)
             count = float(world * n)
         else:
-            count = float(n)
-            if bn.training and bn.track_running_stats:
-                with torch.no_grad():
-                    factor = 0.0 if bn.momentum is None else bn.momentum
-                    if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked.add_(1)
-                        if bn.momentum is None:
-                            factor = 1.0 / float(bn.num_batches_tracked)
-                    unbiased = var * (n / (n - 1.0)) if n > 1 else var
-                    bn.running_mean.mul_(1.0 - factor).add_(mean, alpha=factor)
-                    bn.running_var.mul_(1.0 - factor).add_(unbiased, alpha=factor)
-    else:
-        mean, var = bn.running_mean, bn.running_var
-    invstd = torch.rsqrt(var + bn.eps)
-    return _BatchNormActFn.apply(x, bn.weight, bn.bias, mean.contiguous(), invstd.contiguous(), bool(relu),
-                                 batch_stats, count, sync)
+            mean, var = bn.running_mean, bn.running_var
+        with torch.no_grad():
+            invstd = torch.rsqrt(var + bn.eps)
+            scale = invstd if bn.weight is None else bn.weight * invstd
+            shift = -mean * scale if bn.bias is None else bn.bias - mean * scale
+            prep[0], prep[1], prep[2], prep[3] = mean, invstd, scale, shift
+    return _BatchNormActFn.apply(x, bn.weight, bn.bias, prep, bool(relu), batch_stats, count, sync)
 
 
 class BatchNorm1d(nn.BatchNorm1d):

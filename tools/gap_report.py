@@ -46,6 +46,20 @@ def main(path, skip=0.5):
     print(f'steady-state steps (dynamic_voxelize_k launches): {nsteps};  busy {busy / 1e6 / nsteps:.3f} ms/step')
     for k, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
         print(f'  {t / 1e6 / nsteps:8.3f} ms/step  {c / nsteps:6.1f} calls/step  avg {t / c / 1e3:7.1f} us  {k}')
+    # front of the step: voxelize -> first SRA forward launch (index phase + VFE + first projections)
+    starts = [i for i, r in enumerate(rows) if 'dynamic_voxelize_k' in r[2]]
+    fronts = []
+    for a in starts:
+        b = next((i for i in range(a, len(rows)) if 'sra_fwd' in rows[i][2]), None)
+        if b is None:
+            continue
+        span_f = rows[b][0] - rows[a][0]
+        busy_f = sum(e - st for st, e, _ in rows[a:b])
+        fronts.append((span_f, busy_f, b - a))
+    if fronts:
+        n = len(fronts)
+        print(f'front of the step (voxelize .. first SRA launch): span {sum(f[0] for f in fronts) / n / 1e3:.0f} us, '
+              f'busy {sum(f[1] for f in fronts) / n / 1e3:.0f} us, {sum(f[2] for f in fronts) / n:.0f} launches')
     hist = {}
     for g, a, b in gaps:
         k = (short(a), short(b))
