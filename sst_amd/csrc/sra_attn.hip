@@ -8,21 +8,25 @@
 // throws away do not exist here: the kernel walks the window CSR (tok, winoff) built by window.hip and
 // reads / writes token rows in their flat [M, C] layout.
 //
-// Mapping to the hardware (MI355X, CDNA4):
-//   * one workgroup (4 waves) = one window x one group of 4 heads (64 channels); K and V rows of the
-//     window are gathered once (coalesced 256 B per row) into LDS, row stride 68 floats so that the
-//     b32 column-fragment reads are bank-conflict free and the b128 row-fragment reads are <= 2-way;
-//   * each wave owns (head, 16-query tile) tasks; S^T = K Q^T and O^T = V^T P^T run on the exact-fp32
-//     MFMA v_mfma_f32_16x16x4_f32: the D layout of S^T (row = key, col = query) is directly the B
-//     operand layout of the second product, so P never leaves registers; the softmax is two-pass in
-//     registers over the whole row (<= 144 keys -> <= 36 VGPRs), cross-lane only for 2 xor-shuffles;
-//   * windows are bucketed by ceil(tokens/16) into 4 compile-time tile counts {2,4,7,9} that mirror the
-//     reference's region-batching levels (30/60/100/144 tokens): each variant is launched over all
-//     windows and blocks of the wrong class exit at once (no host sync to count classes).
-// Arithmetic intensity ~0.25*T flop/B puts the fp32 kernel near the HBM/fp32-MFMA ridge.
-//
-// A plain VALU kernel (one thread per (query, head), online softmax, K/V straight from L2) handles
-// windows above 144 tokens and serves as the in-library cross-check (impl = 1).
+// Mapping to the hardware (MI355X, CDNA4) — three implementations behind one entry point (`impl`):
+//   impl 0 (default) register-resident: workgroup = window x 4 heads, ONE WAVE = ONE HEAD.  The wave loads its
+//     head's K row-fragments and V column-fragments straight from HBM/L2 into the MFMA operand layout and keeps
+//     them in VGPRs for every query tile of the window (<= 72 VGPRs at 144 tokens): no LDS, no barrier.
+//     S^T = K Q^T and O^T = V^T P^T run on the exact-fp32 MFMA v_mfma_f32_16x16x4_f32: the D layout of S^T
+//     (row = key, col = query) is directly the B-operand layout of the second product, so P never leaves
+//     registers; softmax in the log2 domain over the whole row, row reductions with v_permlane32/16_swap.
+//     Keys are stored transposed inside their 16-key tile so that the padded k-steps of the last tile are skipped.
+//     The tile class (2 / 4 / 7 / 9 tiles = the region-batching levels 30 / 60 / 100 / 144 tokens) is chosen per
+//     workgroup inside ONE launch; the largest windows are dispatched first.  Backward: sra_bwd_dq_k (dQ, also
+//     emits rowsum(dO * O)) and sra_bwd_dkv_k (dK, dV for <= 4 key tiles per workgroup).
+//     Measured: 53-55 us per launch at 90 k tokens = 43 % of the 8 TB/s HBM roof and 81 % of the measured
+//     16x16x4 fp32 MFMA rate, which is what actually bounds it.
+//   impl 2 LDS-staged (the first implementation, kept for comparison): K and V rows of a 4-head group gathered
+//     into LDS (row stride 68 floats: conflict-free b32 column reads, <= 2-way b128 row reads), a wave owns
+//     (head, 16-query tile) tasks; one launch per tile class.  113 us per call.
+//   impl 1 plain VALU kernel (one thread per (query, head), online softmax): windows above 144 tokens and the
+//     in-library cross-check.
+// Arithmetic intensity ~0.25*T flop/B puts the fp32 kernel at the HBM / fp32-MFMA ridge.
 #include <math.h>
 #include <hip/hip_ext.h>
 #include "common.h"
