@@ -152,6 +152,86 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restri
   for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
 }
 
+// C = 128 (every SST config): one float4 per lane, FOUR rows per 32-lane group in flight per iteration (the generic
+// kernel above issues the two loads of a single row, then two dependent 5-step shuffle reductions: latency-bound
+// at two waves per SIMD, 4.2 TB/s).
+__global__ __launch_bounds__(kLnThreads) void add_ln_bwd_c128_k(const float* __restrict__ dy,
+                                                                const float* __restrict__ s,
+                                                                const float2* __restrict__ stats,
+                                                                const float* __restrict__ w, int64_t m,
+                                                                float* __restrict__ dx,
+                                                                float* __restrict__ partials) {
+  constexpr int C = 128, R = 4;
+  __shared__ float part[2 * C];
+  for (int i = threadIdx.x; i < 2 * C; i += kLnThreads) part[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 31;
+  const int sub = threadIdx.x >> 5;
+  const int col = lane * 4;
+  const float4 wv = *(const float4*)(w + col);
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
+  const int64_t stride = (int64_t)gridDim.x * kLnRowsPerBlock;
+  for (int64_t row0 = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row0 < m; row0 += stride * R) {
+    float4 d[R], sv[R];
+    float2 st[R];
+    bool ok[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int64_t row = row0 + u * stride;
+      ok[u] = row < m;
+      const int64_t rr = ok[u] ? row : row0;  // clamped: loads are unconditional
+      d[u] = *(const float4*)(dy + rr * C + col);
+      sv[u] = *(const float4*)(s + rr * C + col);
+      st[u] = stats[rr];
+    }
+    float4 g[R], xh[R];
+    float sg[R], sgx[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      xh[u] = make_float4((sv[u].x - st[u].x) * st[u].y, (sv[u].y - st[u].x) * st[u].y, (sv[u].z - st[u].x) * st[u].y,
+                          (sv[u].w - st[u].x) * st[u].y);
+      g[u] = make_float4(d[u].x * wv.x, d[u].y * wv.y, d[u].z * wv.z, d[u].w * wv.w);
+      sg[u] = g[u].x + g[u].y + g[u].z + g[u].w;
+      sgx[u] = g[u].x * xh[u].x + g[u].y * xh[u].y + g[u].z * xh[u].z + g[u].w * xh[u].w;
+      if (ok[u]) {
+        aw.x += d[u].x * xh[u].x, aw.y += d[u].y * xh[u].y, aw.z += d[u].z * xh[u].z, aw.w += d[u].w * xh[u].w;
+        ab.x += d[u].x, ab.y += d[u].y, ab.z += d[u].z, ab.w += d[u].w;
+      }
+    }
+#pragma unroll
+    for (int dlt = 1; dlt < 32; dlt <<= 1) {  // the 2 * R reductions interleaved
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        sg[u] += __shfl_xor(sg[u], dlt, 64);
+        sgx[u] += __shfl_xor(sgx[u], dlt, 64);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (ok[u]) {
+        const float mg = sg[u] * (1.f / C), mgx = sgx[u] * (1.f / C);
+        float4 o;
+        o.x = st[u].y * (g[u].x - mg - xh[u].x * mgx);
+        o.y = st[u].y * (g[u].y - mg - xh[u].y * mgx);
+        o.z = st[u].y * (g[u].z - mg - xh[u].z * mgx);
+        o.w = st[u].y * (g[u].w - mg - xh[u].w * mgx);
+        *(float4*)(dx + (row0 + u * stride) * C + col) = o;
+      }
+    }
+  }
+  atomicAdd(&part[col + 0], aw.x);
+  atomicAdd(&part[col + 1], aw.y);
+  atomicAdd(&part[col + 2], aw.z);
+  atomicAdd(&part[col + 3], aw.w);
+  atomicAdd(&part[C + col + 0], ab.x);
+  atomicAdd(&part[C + col + 1], ab.y);
+  atomicAdd(&part[C + col + 2], ab.z);
+  atomicAdd(&part[C + col + 3], ab.w);
+  __syncthreads();
+  float* dst = partials + (int64_t)blockIdx.x * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += kLnThreads) dst[i] = part[i];
+}
+
 // out[i] = sum_b partials[b][i], i < width.  Block = 32 columns x 32 slices of the nb partial rows.
 __global__ __launch_bounds__(1024) void colsum_partials_k(const float* __restrict__ partials, int nb, int width,
                                                           float* __restrict__ out0, float* __restrict__ out1,
@@ -264,8 +344,12 @@ int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float
   int grid = (int)sst_div_up(m, kLnRowsPerBlock * 4);
   if (grid > 512) grid = 512;
   float* partials = (float*)d_workspace;
-  hipLaunchKernelGGL(add_ln_bwd_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
-                     (const float2*)d_stats, d_weight, m, c, d_dx, partials);
+  if (c == 128)
+    hipLaunchKernelGGL(add_ln_bwd_c128_k, dim3(grid), dim3(kLnThreads), 0, st, d_dy, d_sum, (const float2*)d_stats,
+                       d_weight, m, d_dx, partials);
+  else
+    hipLaunchKernelGGL(add_ln_bwd_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
+                       (const float2*)d_stats, d_weight, m, c, d_dx, partials);
   hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
                      d_dbias, c);
   SST_LAUNCH_CHECK();
