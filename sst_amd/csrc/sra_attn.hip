@@ -19,8 +19,8 @@
 //     The tile class (2 / 4 / 7 / 9 tiles = the region-batching levels 30 / 60 / 100 / 144 tokens) is chosen per
 //     workgroup inside ONE launch; the largest windows are dispatched first.  Backward: sra_bwd_dq_k (dQ, also
 //     emits rowsum(dO * O)) and sra_bwd_dkv_k (dK, dV for <= 4 key tiles per workgroup).
-//     Measured: 53-55 us per launch at 90 k tokens = 43 % of the 8 TB/s HBM roof and 81 % of the measured
-//     16x16x4 fp32 MFMA rate, which is what actually bounds it.
+//     Measured: 53-55 us per launch at 90 k tokens = 43 % of the 8 TB/s HBM roof; MFMA pipe 36 % busy, 2.5 of 4
+//     waves resident per SIMD on average: bound by instruction issue / the dependent chain of a wave.
 //   impl 2 LDS-staged (the first implementation, kept for comparison): K and V rows of a 4-head group gathered
 //     into LDS (row stride 68 floats: conflict-free b32 column reads, <= 2-way b128 row reads), a wave owns
 //     (head, 16-query tile) tasks; one launch per tile class.  113 us per call.
