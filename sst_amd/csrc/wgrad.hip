@@ -15,6 +15,23 @@
 
 namespace {
 
+// Debug instrumentation (build with -DSST_WGRAD_TIMING, see tools/wgrad_phases.py): per-wave timestamps of the wide
+// kernel's phases, {constant 100 MHz clock, shader clock} pairs.  Compiled out of the product library.
+#ifdef SST_WGRAD_TIMING
+__device__ unsigned long long g_wg_ts[1024 * 4 * 8 * 2];
+#define SST_TS(i)                                                                      \
+  do {                                                                                 \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {                                \
+      if ((i) == 5) __builtin_amdgcn_s_waitcnt(0);                                     \
+      unsigned long long* t_ = g_wg_ts + ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)) * 2; \
+      t_[0] = wall_clock64();                                                          \
+      t_[1] = clock64();                                                               \
+    }                                                                                  \
+  } while (0)
+#else
+#define SST_TS(i)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -193,17 +210,45 @@ template <int U>
 __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy, const float* __restrict__ x,
                                                     int64_t m, int out, int in, int64_t ld_dy, int64_t ld_x,
                                                     int64_t rows_per_split, float* __restrict__ part_w,
-                                                    float* __restrict__ part_b) {
+                                                    float* __restrict__ part_b, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [(KW-1) * ntile][130 values][64 lanes]
+  SST_TS(0);
   const int o_w = out / 128, i_w = in / 64;  // wave tiles along out / in
-  const int ntile = o_w * i_w;               // 1, 2 or 4
-  const int kwn = 4 / ntile;                 // K groups inside the workgroup
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int kw = wave / ntile, tw = wave - kw * ntile;
-  const int ow = tw / i_w, iw = tw - ow * i_w;
-  const int o0 = ow * 128, i0 = iw * 64;
   const int col = lane & 31, kk = lane >> 5;
-  const int s = blockIdx.x;
+  int ntile, kwn, kw, tw, ow, iw, s;
+  if (tiles > 0) {
+    // Tiled mode: the workgroup owns ONE 128 x 64 tile of dW; its four waves split the K slice and meet in LDS.
+    // tiles < 0 would be meaningless; tiles = o_w * i_w.  A K slice is shared by `tiles` workgroups that read the
+    // same rows at the same time: consecutive j below differ in the tile only and blockIdx % 8 (the XCD, hence the
+    // L2) is the same for all of them, so the second reader of a line hits in L2.
+    ntile = 1;
+    kwn = 4;
+    kw = wave;
+    tw = 0;
+    const int b = blockIdx.x;
+    const int nsplit = gridDim.x / tiles;
+    int tile;
+    if ((nsplit & 7) == 0) {
+      const int j = b >> 3;
+      tile = j % tiles;
+      s = (j / tiles) * 8 + (b & 7);
+    } else {
+      tile = b % tiles;
+      s = b / tiles;
+    }
+    ow = tile / i_w;
+    iw = tile - ow * i_w;
+  } else {
+    ntile = o_w * i_w;  // 1, 2 or 4: one workgroup covers all of dW
+    kwn = 4 / ntile;    // K groups inside the workgroup
+    kw = wave / ntile;
+    tw = wave - kw * ntile;
+    ow = tw / i_w;
+    iw = tw - ow * i_w;
+    s = blockIdx.x;
+  }
+  const int o0 = ow * 128, i0 = iw * 64;
   const int64_t ks0 = (int64_t)s * rows_per_split < m ? (int64_t)s * rows_per_split : m;
   const int64_t ks1 = ks0 + rows_per_split < m ? ks0 + rows_per_split : m;
   const int64_t per = sst_dev_align_up((ks1 - ks0 + kwn - 1) / kwn, 4 * U);
@@ -274,6 +319,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy
   const int64_t ng = ((k1 - k0) / (4 * U)) * 2;
   f32x4 A0[U], C0[U];
   f32x2 B0[U], D0[U];
+  SST_TS(1);
   if (ng > 0) {
     load(A0, B0);
     for (int64_t gi = 0; gi < ng; gi += 2) {
@@ -307,6 +353,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy
     pa += (int64_t)2 * U * ld_dy;
     pb += (int64_t)2 * U * ld_x;
     bsum = make_float4(bs0, bs1, bs2, bs3);
+    SST_TS(3);
   }
   for (int64_t k = k0 + ng * 2 * U; k < k1; k += 2) {  // ragged tail, row-guarded
     const bool ok = (k + kk) < k1;
@@ -363,6 +410,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy
   }
   // MFMA tile (q,p): D value r of lane (col, kk) = tile[row = (r&3) + 8*(r>>2) + 4*kk][col]
   //   -> dW[o0 + 4*row + q][i0 + 2*col + p]
+  SST_TS(4);
   const int64_t pstride = (int64_t)out * in + (part_b != nullptr ? out : 0);
   float* pw = part_w + (int64_t)s * pstride;
 #pragma unroll
@@ -380,6 +428,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy
     bsum.w += __shfl_xor(bsum.w, 32, 64);
     if (lane < 32) *(float4*)(part_b + (int64_t)s * pstride + o0 + 4 * lane) = bsum;
   }
+  SST_TS(5);
 }
 
 // record e of every split summed: e < n_w -> dw[e], else db[e - n_w].
@@ -448,6 +497,14 @@ int wide_splits(int64_t m, int64_t* rows_per_split) {
 
 extern "C" {
 
+#ifdef SST_WGRAD_TIMING
+int sst_debug_wgrad_timestamps(void* host_dst, int64_t bytes) {
+  SST_HIP(hipDeviceSynchronize());
+  SST_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wg_ts), (size_t)bytes));
+  return SST_OK;
+}
+#endif
+
 int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in) {
   int64_t rps;
   int s = pick_splits(m, out, in, &rps);
@@ -472,13 +529,34 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
   float* part_b = d_db ? part_w + nw : nullptr;  // bias sums sit behind the dW block of each split record
   int64_t rps;
   int s;
-  const bool wide = (out % 128 == 0) && (in % 64 == 0) && ((out / 128) * (in / 64) <= 4) &&
-                    ((out / 128) * (in / 64) != 3) && (ld_dy % 4 == 0) && (ld_x % 2 == 0) &&
-                    (((uintptr_t)d_dy & 15) == 0) && (((uintptr_t)d_x & 7) == 0);
+  // Tiled mode (default): any out % 128 == 0, in % 64 == 0 with up to 64 tiles; SST_WGRAD_TILED=0 selects the older
+  // form where one workgroup covers all of dW (at most 4 wave tiles).
+  static int tiled_env = -1;
+  if (tiled_env < 0) {
+    const char* e = getenv("SST_WGRAD_TILED");
+    tiled_env = e ? atoi(e) : 1;
+  }
+  const int ntile = (out % 128 == 0 && in % 64 == 0) ? (out / 128) * (in / 64) : 0;
+  const bool aligned = (ld_dy % 4 == 0) && (ld_x % 2 == 0) && (((uintptr_t)d_dy & 15) == 0) && (((uintptr_t)d_x & 7) == 0);
+  const bool tiled = tiled_env != 0 && aligned && ntile >= 1 && ntile <= 64;
+  const bool wide = tiled || (aligned && ntile >= 1 && ntile <= 4 && ntile != 3);
   if (wide) {
-    s = wide_splits(m, &rps);
-    const int ntile = (out / 128) * (in / 64);
-    const size_t lds = (size_t)(4 / ntile - 1) * ntile * 132 * 64 * sizeof(float);
+    size_t lds;
+    int grid;
+    if (tiled) {
+      // K slices: as many as fill the 256 CUs with `ntile` workgroups each, a multiple of 8 so that the workgroups
+      // sharing a slice sit on one XCD; every wave's chunk (a quarter of the slice) is a multiple of 16 rows.
+      int s0 = (256 / ntile) & ~7;
+      if (s0 < 8) s0 = 8;
+      rps = sst_align_up(sst_div_up(m, s0), 64);
+      s = (int)sst_div_up(m, rps);
+      grid = s * ntile;
+      lds = (size_t)3 * 132 * 64 * sizeof(float);
+    } else {
+      s = wide_splits(m, &rps);
+      grid = s;
+      lds = (size_t)(4 / ntile - 1) * ntile * 132 * 64 * sizeof(float);
+    }
     static int wide_u = 0;
     if (wide_u == 0) {
       const char* e = getenv("SST_WGRAD_U");
@@ -491,12 +569,13 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
       SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
       configured = true;
     }
+    const int tiles_arg = tiled ? ntile : 0;
     if (wide_u == 2) {
-      hipLaunchKernelGGL(wgrad_wide_k<2>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
-                         part_w, part_b);
+      hipLaunchKernelGGL(wgrad_wide_k<2>, dim3((unsigned)grid), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x,
+                         rps, part_w, part_b, tiles_arg);
     } else {
-      hipLaunchKernelGGL(wgrad_wide_k<4>, dim3((unsigned)s), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x, rps,
-                         part_w, part_b);
+      hipLaunchKernelGGL(wgrad_wide_k<4>, dim3((unsigned)grid), dim3(256), lds, st, d_dy, d_x, m, out, in, ld_dy, ld_x,
+                         rps, part_w, part_b, tiles_arg);
     }
   } else {
     s = pick_splits(m, out, in, &rps);

@@ -66,6 +66,29 @@ def test_tall_linear_matches_torch(m, cin, cout, bias):
         assert float((ba.grad.double() - bb.grad.double()).abs().max()) < 2e-4 * max(1.0, float(bb.grad.abs().max()))
 
 
+@pytest.mark.parametrize('m,out,inn', [(90107, 256, 128), (90107, 128, 256), (90107, 384, 128), (4096, 128, 64),
+                                       (5001, 256, 256), (40000, 512, 64), (9000, 1024, 256), (70001, 128, 128)])
+def test_weight_bias_grad_tiled_shapes(m, out, inn):
+    """csrc/wgrad.hip tiled mode: one workgroup per 128 x 64 tile of dW and K slice, any tile count up to 64,
+    ragged K chunks (m not a multiple of the slice length)."""
+    from sst_amd.dense import weight_bias_grad
+    g = torch.Generator().manual_seed(m + out)
+    dy = (torch.randn(m, out, generator=g) * 0.1).to(DEV)
+    x = torch.randn(m, inn, generator=g).to(DEV)
+    dw, db = weight_bias_grad(dy, x, True)
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    assert float((dw.double() - ref_w).abs().max()) < 2e-4 * max(1.0, float(ref_w.abs().max()))
+    assert float((db.double() - ref_b).abs().max()) < 2e-4 * max(1.0, float(ref_b.abs().max()))
+    # views with a row stride (column slices of a packed buffer), no bias
+    big_dy = (torch.randn(m, out + 64, generator=g) * 0.1).to(DEV)
+    big_x = torch.randn(m, inn + 32, generator=g).to(DEV)
+    dw2, db2 = weight_bias_grad(big_dy[:, 64:], big_x[:, :inn], False)
+    ref2 = big_dy[:, 64:].double().t() @ big_x[:, :inn].double()
+    assert db2 is None
+    assert float((dw2.double() - ref2).abs().max()) < 2e-4 * max(1.0, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize('m,c', [(1, 4), (1000, 128), (90107, 384), (33333, 256), (5000, 1024)])
 def test_colsum(m, c):
     from sst_amd.dense import colsum
