@@ -325,6 +325,30 @@ int64_t sst_connected_components_workspace_bytes(int64_t n);
 int sst_connected_components_xy_f32(const float* d_points, int64_t ld, const int32_t* d_batch, int64_t n, float dist,
                                     int32_t* d_labels, int32_t* d_num_components, void* d_workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (§8 f3) Dynamic point pool — the RoI extractor in front of FSD's second-stage SIR layers.  Replaces
+ * dynamic_point_pool_ext.forward(rois, pts, extra_wlh, max_inbox_point, out_pts_idx, out_roi_idx, out_pts_feats)
+ * (mmdet3d/ops/dynamic_point_pool_op.py:36) and dynamic_point_pool_ext.dynamic_point_pool_mixed_gpu (:86-88); that
+ * extension (TorchEx) is not in the reference tree: PARITY UNPINNED beyond the box convention of
+ * ops/roiaware_pool3d/src/points_in_boxes_cuda.cu:24-50 and the invariants asserted in
+ * models/roi_heads/roi_extractors/dynamic_point_roi_extractor.py:96-105.
+ *   d_rois [n_rois, 7] fp32 (x, y, z of the bottom centre, w, l, h, rz); d_pts [n_pts, >= 3] fp32, row stride ld_pts.
+ *   d_rois_batch / d_pts_batch: both NULL (one sample) or int32 sample indices (a pair needs equal indices).
+ *   extra_wlh: HOST pointer to 3 floats added to (w, l, h) for the membership test.
+ *   Outputs (caller-allocated, max_all_pts rows; rows >= *d_num_out are left untouched): d_out_pts_idx,
+ *   d_out_roi_idx int64; d_out_feats [max_all_pts, 13] = point xyz, box-frame xyz, distances to the six faces of the
+ *   un-enlarged box (+x, +y, +z side sums give l, w, h), 1.0 if the point lies only in the enlarged margin.
+ *   Deterministic: pairs sorted by (RoI, point index); a RoI keeps its first max_inbox_point points, the output
+ *   its first max_all_pts pairs (the reference's atomics make the surviving subset and the order race-dependent).
+ *   d_num_out: device int64.  Workspace: sst_dynamic_point_pool_workspace_bytes(n_rois, n_pts).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_dynamic_point_pool_workspace_bytes(int64_t n_rois, int64_t n_pts);
+int sst_dynamic_point_pool_f32(const float* d_rois, const int32_t* d_rois_batch, int64_t n_rois, const float* d_pts,
+                               int64_t ld_pts, const int32_t* d_pts_batch, int64_t n_pts, const float* extra_wlh,
+                               int max_inbox_point, int64_t max_all_pts, int64_t* d_out_pts_idx,
+                               int64_t* d_out_roi_idx, float* d_out_feats, int64_t* d_num_out, void* d_workspace,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,62 @@ def load():
     return m
 
 
+# ---- second target: the reference's CPU points-in-boxes routine (box convention pin for the dynamic point pool) ----
+PIB_OUT = os.path.join(OUT_DIR, 'points_in_boxes_ref.so')
+PIB_SRC = os.path.join(REF_ROOT, 'mmdet3d', 'ops', 'roiaware_pool3d', 'src', 'points_in_boxes_cpu.cpp')
+PIB_BINDING = os.path.join(HERE, 'ref_points_in_boxes_binding.cpp')
+
+
+def build_points_in_boxes(force=False, verbose=False):
+    """oracle/_ref/points_in_boxes_ref.so = the reference's points_in_boxes_cpu.cpp (compiled where it lies) +
+    oracle/ref_points_in_boxes_binding.cpp (our pybind shim).  None when the reference tree is absent."""
+    if os.path.exists(PIB_OUT) and not force:
+        return PIB_OUT
+    if not os.path.exists(PIB_SRC):
+        return None
+    import torch
+    from torch.utils import cpp_extension
+    os.makedirs(OUT_DIR, exist_ok=True)
+    incs = cpp_extension.include_paths() + [sysconfig.get_paths()['include']]
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    objs, procs = [], []
+    for src in (PIB_SRC, PIB_BINDING):
+        o = os.path.join(OUT_DIR, 'pib_' + os.path.basename(src).replace('.cpp', '.o'))
+        objs.append(o)
+        cmd = ['g++', '-O2', '-fPIC', '-std=c++17', '-w', f'-D_GLIBCXX_USE_CXX11_ABI={abi}',
+               '-DTORCH_EXTENSION_NAME=points_in_boxes_ref', '-DTORCH_API_INCLUDE_EXTENSION_H']
+        cmd += [f'-I{i}' for i in incs] + ['-c', src, '-o', o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('oracle/_ref build failed:\n' + ' '.join(cmd) + '\n' + out[-3000:])
+    link = ['g++', '-shared', '-o', PIB_OUT] + objs + [f'-L{torch_lib}', '-ltorch', '-ltorch_cpu', '-lc10',
+                                                       '-ltorch_python', f'-Wl,-rpath,{torch_lib}']
+    r = subprocess.run(link, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('oracle/_ref link failed:\n' + r.stdout + r.stderr)
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print('built', PIB_OUT)
+    return PIB_OUT
+
+
+def load_points_in_boxes():
+    if not os.path.exists(PIB_OUT):
+        return None
+    import importlib.util
+    import torch  # noqa: F401
+    spec = importlib.util.spec_from_file_location('points_in_boxes_ref', PIB_OUT)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
 if __name__ == '__main__':
     p = build(force='--force' in sys.argv, verbose=True)
     print(p if p else 'reference tree not present; nothing built')
+    p = build_points_in_boxes(force='--force' in sys.argv, verbose=True)
+    print(p if p else 'reference tree not present; points_in_boxes not built')

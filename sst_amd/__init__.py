@@ -8,8 +8,8 @@ tensor, the ops raise.
 from . import _lib
 from .kernels import WindowPlan, sra_attention, sra_attention_qk_v
 from .norm import NaiveSyncBatchNorm1d, NaiveSyncBatchNorm2d, build_conv_layer, build_norm_layer
-from .registry import (BACKBONES, MIDDLE_ENCODERS, MODELS, VOXEL_ENCODERS, build_backbone, build_middle_encoder,
-                       build_voxel_encoder)
+from .registry import (BACKBONES, MIDDLE_ENCODERS, MODELS, ROI_EXTRACTORS, VOXEL_ENCODERS, build_backbone,
+                       build_middle_encoder, build_voxel_encoder)
 from .voxel import (DynamicScatter, Voxelization, build_scatter_plan, dynamic_point_to_voxel_forward,
                     dynamic_scatter, dynamic_voxelize, voxelization)
 from .sst_ops import (build_mlp, flat2window, flat2window_v2, get_activation, get_activation_layer,
@@ -21,6 +21,7 @@ from .sst_basic_block import BasicShiftBlockV2, EncoderLayer, WindowAttention
 from .backbones import SIR, SSTv1, SSTv2
 from .cluster import (ClusterAssigner, connected_components_xy, filter_almost_empty, find_connected_componets,  # noqa: F401
                       find_connected_componets_single_batch, modify_cluster_by_class)
+from .dynamic_point_pool import DynamicPointROIExtractor, dynamic_point_pool, dynamic_point_pool_mixed
 
 __version__ = '0.1.0'
 
@@ -35,5 +36,6 @@ __all__ = [
     'MODELS', 'VOXEL_ENCODERS', 'MIDDLE_ENCODERS', 'BACKBONES', 'build_voxel_encoder', 'build_middle_encoder',
     'build_backbone', 'WindowPlan', 'sra_attention', 'sra_attention_qk_v', 'ClusterAssigner',
     'find_connected_componets', 'find_connected_componets_single_batch', 'filter_almost_empty',
-    'modify_cluster_by_class', 'connected_components_xy',
+    'modify_cluster_by_class', 'connected_components_xy', 'ROI_EXTRACTORS', 'DynamicPointROIExtractor',
+    'dynamic_point_pool', 'dynamic_point_pool_mixed',
 ]

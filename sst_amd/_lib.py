@@ -64,6 +64,9 @@ _SIGNATURES = {
                                     c_ptr]),
     'sst_connected_components_workspace_bytes': (c_i64, [c_i64]),
     'sst_connected_components_xy_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_dynamic_point_pool_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sst_dynamic_point_pool_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i32, c_i64, c_ptr,
+                                           c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_event_create': (c_ptr, []),
     'sst_event_destroy': (None, [c_ptr]),
     'sst_event_elapsed_ms': (ctypes.c_float, [c_ptr, c_ptr]),

@@ -1,0 +1,179 @@
+"""Dynamic point pool and its RoI extractor on the GPU.
+
+Mirrors mmdet3d/ops/dynamic_point_pool_op.py (``dynamic_point_pool`` :9-58, ``dynamic_point_pool_mixed`` :61-113)
+and mmdet3d/models/roi_heads/roi_extractors/dynamic_point_roi_extractor.py:9-136 (``DynamicPointROIExtractor``):
+same names, arguments, return values, "fake non-empty" result and non-differentiable outputs.
+
+The CUDA extension those wrappers call belongs to TorchEx and is not in the reference tree, so the per-pair
+arithmetic is a restatement (see csrc/point_pool.hip): PARITY UNPINNED beyond the reference's box convention and the
+invariants its extractor asserts in debug mode, which ``debug=True`` checks here too.  Differences by design: the
+output is deterministic (sorted by RoI, then point index; above the caps the lowest point indices survive) where the
+reference's atomics leave order and survivors to the race; the valid rows are sliced off with one read-back of
+their count instead of a boolean mask over ``max_all_pts`` rows.
+"""
+import torch
+from torch import nn
+
+from . import _lib
+from .registry import ROI_EXTRACTORS
+
+
+def _pool(rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_pts):
+    if not (rois.is_cuda and pts.is_cuda):
+        raise RuntimeError('sst_amd.dynamic_point_pool: CUDA tensors required (no CPU fallback)')
+    assert len(rois) > 0  # dynamic_point_pool_op.py:35
+    assert rois.size(1) == 7 and pts.size(1) >= 3 and len(extra_wlh) == 3
+    dev = pts.device
+    rois_f = rois.float().contiguous()
+    pts_f = pts.float()
+    if pts_f.dim() != 2 or pts_f.stride(1) != 1:
+        pts_f = pts_f.contiguous()
+    n_rois, n_pts = rois_f.size(0), pts_f.size(0)
+    rb = pb = None
+    if rois_batch is not None:
+        rb = rois_batch.to(torch.int32).contiguous()
+        pb = pts_batch.to(torch.int32).contiguous()
+        assert rb.numel() == n_rois and pb.numel() == n_pts
+    out_pts_idx = torch.full((max_all_pts,), -1, dtype=torch.long, device=dev)
+    out_roi_idx = torch.full((max_all_pts,), -1, dtype=torch.long, device=dev)
+    out_pts_feats = torch.zeros((max_all_pts, 13), dtype=torch.float, device=dev)
+    num_out = torch.zeros(1, dtype=torch.long, device=dev)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_dynamic_point_pool_workspace_bytes(n_rois, n_pts), dev)
+    extra = _lib.farray(extra_wlh)  # host array, read during the call
+    rc = lib.sst_dynamic_point_pool_f32(_lib.ptr(rois_f), _lib.ptr(rb), n_rois, _lib.ptr(pts_f),
+                                        pts_f.stride(0) if n_pts > 0 else 3, _lib.ptr(pb), n_pts,
+                                        extra, int(max_inbox_point),
+                                        int(max_all_pts), _lib.ptr(out_pts_idx), _lib.ptr(out_roi_idx),
+                                        _lib.ptr(out_pts_feats), _lib.ptr(num_out), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, 'sst_dynamic_point_pool_f32')
+    n = int(num_out.item())
+    if n == 0:
+        # "fake a non-empty input" (dynamic_point_pool_op.py:41-45): one row of (-1, -1, zeros)
+        return out_pts_idx[0:1], out_roi_idx[0:1], out_pts_feats[0:1, :]
+    return out_pts_idx[:n], out_roi_idx[:n], out_pts_feats[:n]
+
+
+class DynamicPointPoolFunction(torch.autograd.Function):
+    """dynamic_point_pool_op.py:9-56."""
+
+    @staticmethod
+    def forward(ctx, rois, pts, extra_wlh, max_inbox_point, max_all_pts=50000):
+        out = _pool(rois, None, pts, None, extra_wlh, max_inbox_point, max_all_pts)
+        ctx.mark_non_differentiable(*out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        return None, None, None, None, None
+
+
+dynamic_point_pool = DynamicPointPoolFunction.apply
+
+
+class DynamicPointPoolMixedFunction(torch.autograd.Function):
+    """dynamic_point_pool_op.py:61-111: all samples in one call, a pair needs equal sample indices."""
+
+    @staticmethod
+    def forward(ctx, rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_pts=200000):
+        out = _pool(rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_pts)
+        ctx.mark_non_differentiable(*out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        return None, None, None, None, None, None, None
+
+
+dynamic_point_pool_mixed = DynamicPointPoolMixedFunction.apply
+
+
+@ROI_EXTRACTORS.register_module()
+class DynamicPointROIExtractor(nn.Module):
+    """Point-wise RoI extractor (dynamic_point_roi_extractor.py:9-136).
+
+    forward(pts_xyz [P,3], batch_inds [P] (sorted), rois [R,8] = (sample, x, y, z, w, l, h, rz)) ->
+    (point indices, RoI indices, dict(local_xyz, boundary_offset, is_in_margin))."""
+
+    def __init__(self, init_cfg=None, debug=True, extra_wlh=[0, 0, 0], max_inbox_point=512, max_all_pts=50000):
+        super().__init__()
+        self.init_cfg = init_cfg
+        self.debug = debug
+        self.extra_wlh = extra_wlh
+        self.max_inbox_point = max_inbox_point
+        self.max_all_pts = max_all_pts
+
+    def forward(self, pts_xyz, batch_inds, rois, max_inbox_point=None, batch_size=None):
+        if batch_size == 1:
+            return self.fast_single_sample_forward(pts_xyz, rois, max_inbox_point)
+        assert len(pts_xyz) > 0
+        assert len(batch_inds) > 0
+        assert len(rois) > 0
+        if not (batch_inds == 0).all():
+            assert (batch_inds.sort()[0] == batch_inds).all()
+        all_inds, all_pts_info, all_roi_inds = [], [], []
+        roi_inds_base = 0
+        pts_inds_base = 0
+        if max_inbox_point is None:
+            max_inbox_point = self.max_inbox_point
+        # one pool call per sample, as the reference does (:51-80): max_all_pts caps every sample separately
+        for batch_idx in range(int(batch_inds.max()) + 1):
+            roi_batch_mask = (rois[..., 0].int() == batch_idx)
+            pts_batch_mask = (batch_inds.int() == batch_idx)
+            num_roi_this_batch = roi_batch_mask.sum().item()
+            num_pts_this_batch = pts_batch_mask.sum().item()
+            assert num_roi_this_batch > 0
+            assert num_pts_this_batch > 0
+            ext_pts_inds, roi_inds, ext_pts_info = dynamic_point_pool(
+                rois[..., 1:][roi_batch_mask], pts_xyz[pts_batch_mask], self.extra_wlh, max_inbox_point,
+                self.max_all_pts)
+            if len(ext_pts_inds) == 1 and ext_pts_inds[0].item() == -1:
+                assert roi_inds[0].item() == -1
+                all_inds.append(ext_pts_inds)  # keep -1 and do not plus the base
+                all_pts_info.append(ext_pts_info)
+                all_roi_inds.append(roi_inds)
+            else:
+                all_inds.append(ext_pts_inds + pts_inds_base)
+                all_pts_info.append(ext_pts_info)
+                all_roi_inds.append(roi_inds + roi_inds_base)
+            pts_inds_base += num_pts_this_batch
+            roi_inds_base += num_roi_this_batch
+        all_inds = torch.cat(all_inds, dim=0)
+        all_pts_info = torch.cat(all_pts_info, dim=0)
+        all_roi_inds = torch.cat(all_roi_inds, dim=0)
+        all_out_xyz = all_pts_info[:, :3]
+        all_local_xyz = all_pts_info[:, 3:6]
+        all_offset = all_pts_info[:, 6:-1]
+        is_in_margin = all_pts_info[:, -1]
+        if self.debug:
+            self.check_invariants(pts_xyz, rois[..., 1:], all_inds, all_roi_inds, all_out_xyz, all_local_xyz,
+                                  all_offset)
+        ext_pts_info = dict(local_xyz=all_local_xyz, boundary_offset=all_offset, is_in_margin=is_in_margin)
+        return all_inds, all_roi_inds, ext_pts_info
+
+    def check_invariants(self, pts_xyz, rois7, inds, roi_inds, out_xyz, local_xyz, offset):
+        """the reference's debug block (:96-105); pairs of the fake row (-1) are skipped"""
+        ok = inds >= 0
+        if not bool(ok.any()):
+            return
+        roi_per_pts = rois7[roi_inds[ok]]
+        out_xyz, local_xyz, offset = out_xyz[ok], local_xyz[ok], offset[ok]
+        assert torch.isclose(pts_xyz[inds[ok]], out_xyz).all()
+        assert torch.isclose(offset[:, 0] + offset[:, 3], roi_per_pts[:, 4]).all()
+        assert torch.isclose(offset[:, 1] + offset[:, 4], roi_per_pts[:, 3]).all()
+        assert torch.isclose(offset[:, 2] + offset[:, 5], roi_per_pts[:, 5]).all()
+        assert (local_xyz[:, 0].abs() < roi_per_pts[:, 4] + self.extra_wlh[0] + 1e-5).all()
+        assert (local_xyz[:, 1].abs() < roi_per_pts[:, 3] + self.extra_wlh[1] + 1e-5).all()
+        assert (local_xyz[:, 2].abs() < roi_per_pts[:, 5] + self.extra_wlh[2] + 1e-5).all()
+
+    def fast_single_sample_forward(self, pts_xyz, rois, max_inbox_point=None):
+        """:107-133 (the reference passes no max_all_pts here: the op's default of 50000 applies)"""
+        if max_inbox_point is None:
+            max_inbox_point = self.max_inbox_point
+        ext_pts_inds, roi_inds, ext_pts_info = dynamic_point_pool(
+            rois[..., 1:].contiguous(), pts_xyz.contiguous(), self.extra_wlh, max_inbox_point)
+        all_local_xyz = ext_pts_info[:, 3:6]
+        all_offset = ext_pts_info[:, 6:-1]
+        is_in_margin = ext_pts_info[:, -1]
+        ext_pts_info = dict(local_xyz=all_local_xyz, boundary_offset=all_offset, is_in_margin=is_in_margin)
+        return ext_pts_inds, roi_inds, ext_pts_info

@@ -53,6 +53,7 @@ MODELS = Registry('models')
 VOXEL_ENCODERS = MODELS
 MIDDLE_ENCODERS = MODELS
 BACKBONES = Registry('backbone')
+ROI_EXTRACTORS = Registry('roi_extractor')  # mmdet.models.builder.ROI_EXTRACTORS
 
 
 def build_voxel_encoder(cfg):

@@ -314,6 +314,42 @@ def gen_cluster():
     save('cluster.npz', **arrays)
 
 
+def gen_point_pool():
+    """Dynamic point pool (f3): the membership part is pinned with the reference's own CPU points-in-boxes routine
+    (ops/roiaware_pool3d/src/points_in_boxes_cpu.cpp, compiled by oracle/build_ref.build_points_in_boxes) on the
+    boxes themselves and on the boxes enlarged by extra_wlh (w, l, h grown, bottom z lowered by half the growth).
+    Stored sparsely: the (roi, point) pairs that are inside."""
+    mod = build_ref.load_points_in_boxes()
+    assert mod is not None, 'build oracle/_ref first (python oracle/build_ref.py)'
+    rng = np.random.default_rng(11)
+    arrays = {}
+    for tag, n_rois, n_pts, extra in (('veh', 150, 12000, (0.5, 0.5, 0.5)), ('ped', 300, 6000, (0.25, 0.5, 1.0))):
+        big = tag == 'veh'
+        rois = np.concatenate([rng.uniform(-40, 40, (n_rois, 2)), rng.uniform(-2, 1, (n_rois, 1)),
+                               rng.uniform(1.5 if big else 0.4, 5.0 if big else 1.2, (n_rois, 3)),
+                               rng.uniform(-4, 4, (n_rois, 1))], 1).astype(np.float32)
+        pts = np.concatenate([rng.uniform(-45, 45, (n_pts, 2)), rng.uniform(-3, 4, (n_pts, 1))], 1).astype(np.float32)
+        near = n_pts * 3 // 4  # most points are scattered around boxes so that many pairs exist
+        k = rng.integers(0, n_rois, near)
+        pts[:near, :2] = rois[k, :2] + rng.normal(0, 1.2 if big else 0.5, (near, 2)).astype(np.float32)
+        pts[:near, 2] = rois[k, 2] + rng.uniform(-0.6, 1.2, near).astype(np.float32) * rois[k, 5]
+        e = np.asarray(extra, dtype=np.float32)
+        large = rois.copy()
+        large[:, 3:6] += e[None, :]
+        large[:, 2] -= e[2] * np.float32(0.5)
+        pairs = {}
+        for name, boxes in (('small', rois), ('large', large)):
+            flags = torch.zeros(n_rois, n_pts, dtype=torch.int32)
+            mod.points_in_boxes_cpu(torch.from_numpy(np.ascontiguousarray(boxes)), torch.from_numpy(pts), flags)
+            pairs[name] = np.stack(np.nonzero(flags.numpy()), 1).astype(np.int32)
+        arrays[f'in::{tag}::rois'] = rois
+        arrays[f'in::{tag}::pts'] = pts
+        arrays[f'in::{tag}::extra_wlh'] = e
+        arrays[f'out::{tag}::pairs_in_box'] = pairs['small']
+        arrays[f'out::{tag}::pairs_in_enlarged_box'] = pairs['large']
+    save('point_pool.npz', **arrays)
+
+
 def main():
     assert ref_loader.available(), 'the reference tree is required'
     build_ref.build()
@@ -326,6 +362,8 @@ def main():
     gen_scatter_vfe(ref)
     gen_sir(ref)
     gen_cluster()
+    build_ref.build_points_in_boxes()
+    gen_point_pool()
 
 
 if __name__ == '__main__':

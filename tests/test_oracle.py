@@ -202,3 +202,71 @@ def test_cluster_oracle_matches_reference_function_live():
     for dist in (0.3, 1.0, 2.5):
         ref = f(pts, batch, dist).numpy()
         np.testing.assert_array_equal(cluster_oracle.find_connected_components(pts.numpy(), batch.numpy(), dist), ref)
+
+
+def _pairs_set(pairs):
+    return set(map(tuple, np.asarray(pairs).tolist()))
+
+
+@pytest.mark.parametrize('tag', ['veh', 'ped'])
+def test_point_pool_oracle_membership_matches_reference_golden(tag):
+    """box convention / membership of the dynamic-point-pool restatement against pairs produced by the reference's own
+    points_in_boxes_cpu (tests/golden/make_golden.py::gen_point_pool): exact for the boxes themselves; for the
+    enlarged boxes up to pairs that sit within 1e-5 of a face (the enlarged centre is formed differently)."""
+    from oracle import point_pool_oracle as O
+    g = load_golden('point_pool.npz')
+    rois, pts, extra = g[f'in::{tag}::rois'], g[f'in::{tag}::pts'], g[f'in::{tag}::extra_wlh']
+    lx, ly, lz = O.local_coords(rois, pts)
+    small = O.inside(lx, ly, lz, rois[:, 3], rois[:, 4], rois[:, 5])
+    assert _pairs_set(np.stack(np.nonzero(small), 1)) == _pairs_set(g[f'out::{tag}::pairs_in_box'])
+    pts_idx, roi_idx, feats = O.dynamic_point_pool(rois, pts, extra, 1 << 30, 1 << 30)
+    got = _pairs_set(np.stack([roi_idx, pts_idx], 1))
+    want = _pairs_set(g[f'out::{tag}::pairs_in_enlarged_box'])
+    clear = O.face_clearance(rois, pts, extra)
+    assert all(clear[r, p] < 1e-5 for r, p in got ^ want)
+    assert len(got & want) > 500
+    # is_in_margin <=> in the enlarged box but not in the box
+    in_box = _pairs_set(g[f'out::{tag}::pairs_in_box'])
+    for (r, p), m in zip(zip(roi_idx.tolist(), pts_idx.tolist()), feats[:, 12].tolist()):
+        assert (m == 0.0) == ((r, p) in in_box)
+    O.check_invariants(rois, pts, extra, pts_idx, roi_idx, feats)
+    assert (np.diff(roi_idx * (len(pts) + 1) + pts_idx) > 0).all()  # sorted by (roi, point)
+
+
+def test_point_pool_oracle_caps_and_batches():
+    from oracle import point_pool_oracle as O
+    g = load_golden('point_pool.npz')
+    rois, pts, extra = g['in::veh::rois'], g['in::veh::pts'], g['in::veh::extra_wlh']
+    full_p, full_r, full_f = O.dynamic_point_pool(rois, pts, extra, 1 << 30, 1 << 30)
+    p8, r8, f8 = O.dynamic_point_pool(rois, pts, extra, 8, 1 << 30)
+    assert np.bincount(r8).max() == 8
+    for r in np.unique(full_r):
+        np.testing.assert_array_equal(p8[r8 == r], full_p[full_r == r][:8])
+    pc, rc, fc = O.dynamic_point_pool(rois, pts, extra, 8, 100)
+    np.testing.assert_array_equal(pc, p8[:100])
+    np.testing.assert_array_equal(fc, f8[:100])
+    rb = (np.arange(len(rois)) % 2).astype(np.int32)
+    pb = (np.arange(len(pts)) % 2).astype(np.int32)
+    pm, rm, fm = O.dynamic_point_pool(rois, pts, extra, 1 << 30, 1 << 30, rb, pb)
+    sel = rb[full_r] == pb[full_p]
+    np.testing.assert_array_equal(pm, full_p[sel])
+    np.testing.assert_array_equal(fm, full_f[sel])
+
+
+def test_point_pool_oracle_matches_compiled_reference_live():
+    from oracle import point_pool_oracle as O
+    mod = build_ref.load_points_in_boxes()
+    if mod is None:
+        pytest.skip('oracle/_ref/points_in_boxes_ref.so not built (reference tree absent)')
+    rng = np.random.default_rng(5)
+    n_rois, n_pts = 120, 9000
+    rois = np.concatenate([rng.uniform(-30, 30, (n_rois, 2)), rng.uniform(-2, 1, (n_rois, 1)),
+                           rng.uniform(0.5, 6, (n_rois, 3)), rng.uniform(-7, 7, (n_rois, 1))], 1).astype(np.float32)
+    k = rng.integers(0, n_rois, n_pts)
+    pts = (rois[k, :3] + rng.normal(0, 1.5, (n_pts, 3))).astype(np.float32)
+    flags = torch.zeros(n_rois, n_pts, dtype=torch.int32)
+    mod.points_in_boxes_cpu(torch.from_numpy(rois), torch.from_numpy(pts), flags)
+    lx, ly, lz = O.local_coords(rois, pts)
+    mine = O.inside(lx, ly, lz, rois[:, 3], rois[:, 4], rois[:, 5])
+    assert flags.sum() > 1000
+    np.testing.assert_array_equal(mine, flags.numpy().astype(bool))

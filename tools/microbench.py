@@ -235,6 +235,23 @@ def bench_cluster():
               f'reference data flow {t_ref * 1e3:.1f} ms, labels identical: {same}')
 
 
+def bench_pointpool():
+    """dynamic point pool at FSD second-stage sizes: whole op (3 passes + scans + the count read-back) and the pair
+    tests per second it amounts to (the reference's kernel is the same R x P brute force, one thread per pair)."""
+    import numpy as np
+    for n_rois, n_pts, max_all in ((300, 50000, 50000), (1000, 100000, 100000), (2000, 200000, 100000)):
+        rng = np.random.default_rng(n_rois)
+        rois = np.concatenate([rng.uniform(-70, 70, (n_rois, 2)), rng.uniform(-2, 1, (n_rois, 1)),
+                               rng.uniform(0.5, 5, (n_rois, 3)), rng.uniform(-4, 4, (n_rois, 1))], 1).astype(np.float32)
+        k = rng.integers(0, n_rois, n_pts)
+        pts = (rois[k, :3] + rng.normal(0, 1.0, (n_pts, 3)) + np.array([0, 0, 1.0])).astype(np.float32)
+        r, p = torch.from_numpy(rois).to(DEV), torch.from_numpy(pts).to(DEV)
+        med, _ = timeit(lambda: sst_amd.dynamic_point_pool(r, p, [0.5, 0.5, 0.5], 256, max_all), iters=20, warmup=3)
+        n_out = len(sst_amd.dynamic_point_pool(r, p, [0.5, 0.5, 0.5], 256, max_all)[0])
+        print(f'dynamic point pool {n_rois} RoIs x {n_pts} points -> {n_out} pairs: {med * 1e3:.0f} us '
+              f'({2 * n_rois * n_pts / med / 1e6:.1f} G pair tests/s over the two passes)')
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('sra', 'all'):
@@ -249,3 +266,5 @@ if __name__ == '__main__':
         bench_sir()
     if what in ('cluster',):
         bench_cluster()
+    if what in ('pointpool',):
+        bench_pointpool()
