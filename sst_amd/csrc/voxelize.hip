@@ -44,6 +44,37 @@ __global__ __launch_bounds__(256) void dynamic_voxelize_k(const float* __restric
   }
 }
 
+// Streaming form for the usual layout (points rows of STRIDE <= 8 floats, coors rows of 4 int32 with the batch index
+// in column 0, 16-byte aligned): a workgroup copies the contiguous 256 x STRIDE floats of its points into LDS with
+// fully coalesced dword loads (every fetched byte of a line is used once, instead of three strided dword loads per
+// thread), each thread then takes its x, y, z from LDS and writes its row as ONE 16-byte store.  Same arithmetic.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dynamic_voxelize_rows_k(const float* __restrict__ pts, int64_t n, vox_params vp,
+                                                               int4* __restrict__ coors, int batch_idx) {
+  __shared__ float tile[256 * STRIDE];
+  const int64_t nblk = (n + 255) / 256;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t i0 = blk * 256;
+    const int64_t rows = n - i0 < 256 ? n - i0 : 256;
+    const float* src = pts + i0 * STRIDE;
+    const int nflt = (int)rows * STRIDE;
+#pragma unroll
+    for (int k = 0; k < STRIDE; ++k) {
+      const int e = k * 256 + threadIdx.x;
+      if (e < nflt) tile[e] = src[e];
+    }
+    __syncthreads();
+    if ((int64_t)threadIdx.x < rows) {
+      const float* p = tile + threadIdx.x * STRIDE;
+      const int cx = vox_coord(p[0], vp.x0, vp.vx, vp.gx);
+      const int cy = vox_coord(p[1], vp.y0, vp.vy, vp.gy);
+      const int cz = vox_coord(p[2], vp.z0, vp.vz, vp.gz);
+      coors[i0 + threadIdx.x] = make_int4(batch_idx, cz, cy, cx);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -78,8 +109,28 @@ int sst_dynamic_voxelize_f32(const float* d_points, int64_t n, int64_t row_strid
   vp.gy = g[1];
   vp.gz = g[2];
   const int grid = sst_grid_1d(n, 256);
-  hipLaunchKernelGGL(dynamic_voxelize_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_points, n, row_stride, vp,
-                     d_coors, coors_stride, coors_col0, batch_idx);
+  const bool rows16 = coors_stride == 4 && coors_col0 == 1 && batch_idx >= 0 && (((uintptr_t)d_coors) & 15) == 0 &&
+                      row_stride >= 3 && row_stride <= 8 && n >= 4096;
+  hipStream_t st = (hipStream_t)stream;
+#define SST_VOX_ROWS(S)                                                                                         \
+  case S:                                                                                                       \
+    hipLaunchKernelGGL(dynamic_voxelize_rows_k<S>, dim3(grid), dim3(256), 0, st, d_points, n, vp, (int4*)d_coors, \
+                       batch_idx);                                                                              \
+    break;
+  if (rows16) {
+    switch ((int)row_stride) {
+      SST_VOX_ROWS(3)
+      SST_VOX_ROWS(4)
+      SST_VOX_ROWS(5)
+      SST_VOX_ROWS(6)
+      SST_VOX_ROWS(7)
+      SST_VOX_ROWS(8)
+    }
+  } else {
+    hipLaunchKernelGGL(dynamic_voxelize_k, dim3(grid), dim3(256), 0, st, d_points, n, row_stride, vp, d_coors,
+                       coors_stride, coors_col0, batch_idx);
+  }
+#undef SST_VOX_ROWS
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -39,6 +39,26 @@ def test_voxelize_module_and_empty_and_strided():
     np.testing.assert_array_equal(coors.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('ncol', [3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize('n', [4096, 4097, 20000, 116001])
+def test_voxelize_streaming_rows_kernel_bit_exact(n, ncol):
+    """the LDS-staged (b, z, y, x)-row kernel taken by voxelize_batch for rows of up to 8 floats and n >= 4096, the
+    plain kernel beyond (9 columns) and for the 3-column output of Voxelization.forward: all bit-exact vs the oracle,
+    including out-of-range points (clamped) and a second sample (batch column, unaligned sample offset)."""
+    import sst_amd
+    from oracle import voxel_oracle
+    g = torch.Generator().manual_seed(n * 16 + ncol)
+    pts = torch.rand(n, ncol, generator=g) * 200 - 100
+    pts[:, 2] = torch.rand(n, generator=g) * 10 - 4
+    pts2 = torch.rand(4099, ncol, generator=g) * 160 - 80
+    vox = sst_amd.Voxelization(VOXEL_SIZE, PC_RANGE, -1, (-1, -1))
+    _, coors = vox.voxelize_batch([pts.to(DEV), pts2.to(DEV)])
+    ref = np.concatenate([np.pad(voxel_oracle.dynamic_voxelize(p.numpy(), VOXEL_SIZE, PC_RANGE), ((0, 0), (1, 0)),
+                                 constant_values=b) for b, p in enumerate((pts, pts2))])
+    np.testing.assert_array_equal(coors.cpu().numpy(), ref)
+    np.testing.assert_array_equal(vox(pts.to(DEV)).cpu().numpy(), ref[:n, 1:])
+
+
 def test_voxelize_full_size_bit_exact_and_idempotent():
     import sst_amd
     from oracle import voxel_oracle

@@ -235,6 +235,18 @@ def bench_cluster():
               f'reference data flow {t_ref * 1e3:.1f} ms, labels identical: {same}')
 
 
+def bench_voxelize():
+    """dynamic_voxelize at sizes where the HBM roof matters (a frame is 2.8 MB: launch-bound): algorithmic 24 B/point
+    (SURVEY.md §8d); the bytes really moved are 4*C read + 16 written per point for [N, C] points and (b, z, y, x) rows."""
+    vox = sst_amd.Voxelization(bench.VOXEL_SIZE, bench.PC_RANGE, -1, (-1, -1))
+    for n, c in ((116000, 5), (1160000, 5), (16000000, 5), (16000000, 4), (16000000, 3)):
+        pts = torch.rand(n, c, device=DEV) * 150 - 75
+        med, mn = timeit(lambda: vox.voxelize_batch([pts]), iters=20, warmup=3)
+        print(f'dynamic_voxelize {n} points x {c} floats: {med * 1e3:.1f} us (min {mn * 1e3:.1f}) -> algorithmic '
+              f'{24 * n / med / 1e6:.0f} GB/s ({100 * 24 * n / med / 1e6 / 8000:.1f} % of 8 TB/s), moved '
+              f'{(4 * c + 16) * n / med / 1e6:.0f} GB/s')
+
+
 def bench_pointpool():
     """dynamic point pool at FSD second-stage sizes: whole op (3 passes + scans + the count read-back) and the pair
     tests per second it amounts to (the reference's kernel is the same R x P brute force, one thread per pair)."""
@@ -266,5 +278,7 @@ if __name__ == '__main__':
         bench_sir()
     if what in ('cluster',):
         bench_cluster()
+    if what in ('voxelize',):
+        bench_voxelize()
     if what in ('pointpool',):
         bench_pointpool()
