@@ -378,6 +378,48 @@ __global__ __launch_bounds__(256) void wgrad_wide_k(const float* __restrict__ dy
     pa += 2 * ld_dy;
     pb += 2 * ld_x;
   }
+  if (tiles > 0) {
+    // Tiled mode: all four waves (the four K quarters of one 128 x 64 tile) take part in the reduction.  Every wave
+    // writes its 8 MFMA tiles to LDS; wave w then sums, in the fixed order of the K quarters, the tile pair
+    // (q = w, p = 0 / 1) = output rows o0 + 4*row + w, and stores that quarter of the partial record.
+    float* dst = red + (size_t)wave * 132 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((q * 2 + p) * 16 + r) * 64] = acc[q][p][r];
+    dst[128 * 64] = bsum.x;
+    dst[129 * 64] = bsum.y;
+    dst[130 * 64] = bsum.z;
+    dst[131 * 64] = bsum.w;
+    __syncthreads();
+    SST_TS(4);
+    const int q = wave;
+    const int64_t pstride = (int64_t)out * in + (part_b != nullptr ? out : 0);
+    float* pw = part_w + (int64_t)s * pstride;
+    const float* src = red + ((size_t)q * 2 * 16) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < 4; ++g2) {
+        v0 += src[((size_t)g2 * 132 + r) * 64];
+        v1 += src[((size_t)g2 * 132 + 16 + r) * 64];
+      }
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+      *(float2*)(pw + (int64_t)(o0 + 4 * row + q) * in + i0 + 2 * col) = make_float2(v0, v1);
+    }
+    if (part_b != nullptr && iw == 0) {
+      float b = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < 4; ++g2) b += red[((size_t)g2 * 132 + 128 + q) * 64 + lane];
+      b += __shfl_xor(b, 32, 64);
+      if (lane < 32) part_b[(int64_t)s * pstride + o0 + 4 * lane + q] = b;
+    }
+    SST_TS(5);
+    return;
+  }
   if (kwn > 1) {  // K groups 1.. hand their accumulators to group 0 of the same wave tile
     if (kw > 0) {
       float* dst = red + ((size_t)((kw - 1) * ntile + tw) * 132) * 64 + lane;
@@ -551,7 +593,7 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
       rps = sst_align_up(sst_div_up(m, s0), 64);
       s = (int)sst_div_up(m, rps);
       grid = s * ntile;
-      lds = (size_t)3 * 132 * 64 * sizeof(float);
+      lds = (size_t)4 * 132 * 64 * sizeof(float);
     } else {
       s = wide_splits(m, &rps);
       grid = s;
@@ -564,7 +606,7 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
     }
     static bool configured = false;  // once: the attribute call costs tens of microseconds on the host
     if (!configured) {
-      const int lds_max = 3 * 132 * 64 * (int)sizeof(float);
+      const int lds_max = 4 * 132 * 64 * (int)sizeof(float);
       SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
       SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
       configured = true;
