@@ -15,6 +15,7 @@ rm -rf /tmp/pb
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/bench.py --steps 16 --warmup 6 --no-cpu-baseline --no-forward-only-leg > $OUT/bench_under_rocprof.log 2>&1 || tail -5 $OUT/bench_under_rocprof.log
 cp /tmp/pb/b_kernel_stats.csv $OUT/kernel_stats.csv
 python $R/tools/gap_report.py /tmp/pb/b_kernel_trace.csv 0.65 60 > $OUT/steady_state_trace_report.txt
+gzip -c /tmp/pb/b_kernel_trace.csv > $OUT/kernel_trace.csv.gz
 head -12 $OUT/steady_state_trace_report.txt
 bash $R/tools/collect_sra_traffic.sh gpurun_out/$TAG/traffic > $OUT/traffic.log 2>&1 || tail -5 $OUT/traffic.log
 tail -30 $OUT/traffic.log | head -12

@@ -20,7 +20,7 @@ def main(path, skip=0.5):
     rows.sort()
     rows = rows[int(len(rows) * skip):]  # steady state only
     # whole steps only: from the first voxelize launch of the window up to (not including) the last one
-    vox = [i for i, r in enumerate(rows) if 'dynamic_voxelize_k' in r[2]]
+    vox = [i for i, r in enumerate(rows) if 'dynamic_voxelize_' in r[2]]
     if len(vox) >= 2:
         rows = rows[vox[0]:vox[-1]]
     span = rows[-1][1] - rows[0][0]
@@ -42,12 +42,12 @@ def main(path, skip=0.5):
         t = per.setdefault(k, [0, 0])
         t[0] += en - st
         t[1] += 1
-    nsteps = sum(1 for r in rows if 'dynamic_voxelize_k' in r[2]) or 1
-    print(f'steady-state steps (dynamic_voxelize_k launches): {nsteps};  busy {busy / 1e6 / nsteps:.3f} ms/step')
+    nsteps = sum(1 for r in rows if 'dynamic_voxelize_' in r[2]) or 1
+    print(f'steady-state steps (dynamic_voxelize_* launches): {nsteps};  busy {busy / 1e6 / nsteps:.3f} ms/step')
     for k, (t, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
         print(f'  {t / 1e6 / nsteps:8.3f} ms/step  {c / nsteps:6.1f} calls/step  avg {t / c / 1e3:7.1f} us  {k}')
     # front of the step: voxelize -> first SRA forward launch (index phase + VFE + first projections)
-    starts = [i for i, r in enumerate(rows) if 'dynamic_voxelize_k' in r[2]]
+    starts = [i for i, r in enumerate(rows) if 'dynamic_voxelize_' in r[2]]
     fronts = []
     for a in starts:
         b = next((i for i in range(a, len(rows)) if 'sra_fwd' in rows[i][2]), None)
