@@ -349,6 +349,51 @@ int sst_dynamic_point_pool_f32(const float* d_rois, const int32_t* d_rois_batch,
                                int64_t* d_out_roi_idx, float* d_out_feats, int64_t* d_num_out, void* d_workspace,
                                void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (§8 f4, first part) Sparse 3-D convolution: rulebook + convolution.  Replaces the reference's vendored spconv for
+ * 3-D int32 indices: getIndicePair<3> (mmdet3d/ops/spconv/include/spconv/spconv_ops.h:26-150; kernel-offset and
+ * position arithmetic include/spconv/geometry.h:24-151) and indiceConv / indiceConvBackward (spconv_ops.h:256-446).
+ * All index tensors are int32; d_coors rows are (batch, z, y, x), contiguous, 16-byte aligned; shapes / ksize /
+ * stride / padding / dilation are HOST arrays of 3 int32 (z, y, x).  Kernel offset k = (kz * ksize_y + ky) * ksize_x
+ * + kx (the `offset` of geometry.h:66-70); K = ksize_z * ksize_y * ksize_x <= 4096.
+ *
+ * The rulebook is two dense maps, in2out [K, n] and out2in [K, m] (-1 = no partner), plus the reference's pair lists
+ * (indice_pairs [K, 2, n] filled with -1 behind the valid entries, indice_num [K]; pairs ordered by input row).
+ *   sst_spconv_candidates_i32: regular / transposed convolution, rows [K * n + 1, 4] = output voxel (b, z, y, x) touched
+ *     by (offset k, input row j) at row k * n + j, or four -1; the last row is always invalid.  Feed them to
+ *     sst_unique_rows(invalid_if_negative = 1): the sorted groups 1.. are the output voxels in ascending (b, z, y, x)
+ *     order (the order of the reference's GPU path, torch::_unique of the linear indices, spconv_ops.h:128), and
+ *     sst_spconv_inverse_to_map_i32 turns its inverse into in2out (group - 1).
+ *   sst_spconv_subm_map_i32: submanifold convolution (stride 1, padding ksize / 2, spconv_ops.h:74-77): outputs =
+ *     inputs.  d_sorted_keys / d_perm: ukeys and perm of sst_unique_rows over the n input rows with mins = 0,
+ *     extents = (batch, shape) and invalid_if_negative = 0 (key = 1 + linear index).
+ *   sst_spconv_invert_map_i32: out2in from in2out.   sst_spconv_pair_lists_i32: pair lists from in2out.
+ *   sst_spconv_gather_gemm_f32: Y[r, :] = sum_k X[map[k][r], :] W[k] (+ bias), r < m; W[k] is [cin, cout] row-major, or
+ *     [cout, cin] with trans_w (data gradient on the forward weights).  Forward: map = out2in; data gradient and
+ *     inverse convolution: map = in2out.  Every row of Y is written.
+ *   sst_spconv_wgrad_f32: dW[k] = sum over the pairs p < num[k] of X[pairs[k][x_side][p]]^T dY[pairs[k][1 - x_side][p]];
+ *     pair_ld = row length of the pair lists (n).  Workspace: sst_spconv_wgrad_workspace_bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_spconv_candidates_i32(const int32_t* d_coors, int64_t n, const int32_t* in_shape, const int32_t* out_shape,
+                              const int32_t* ksize, const int32_t* stride, const int32_t* padding,
+                              const int32_t* dilation, int transpose, int32_t* d_rows, void* stream);
+int sst_spconv_inverse_to_map_i32(const int32_t* d_inverse, int64_t total, int32_t* d_in2out, void* stream);
+int sst_spconv_subm_map_i32(const int32_t* d_coors, int64_t n, const int32_t* shape, const int32_t* ksize,
+                            const int32_t* dilation, const uint64_t* d_sorted_keys, const uint32_t* d_perm,
+                            int32_t* d_in2out, void* stream);
+int sst_spconv_invert_map_i32(const int32_t* d_in2out, int kvol, int64_t n, int64_t m, int32_t* d_out2in,
+                              void* stream);
+int64_t sst_spconv_pair_lists_workspace_bytes(int kvol, int64_t n);
+int sst_spconv_pair_lists_i32(const int32_t* d_in2out, int kvol, int64_t n, int32_t* d_pairs, int32_t* d_num,
+                              void* d_workspace, void* stream);
+int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol,
+                               const float* d_w, int cin, int cout, int trans_w, const float* d_bias, float* d_y,
+                               int64_t ldy, void* stream);
+int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout);
+int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+                         int64_t pair_ld, int x_side, const int32_t* d_num, int kvol, int cin, int cout, float* d_dw,
+                         void* d_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,8 +131,59 @@ def load_points_in_boxes():
     return m
 
 
+# ---- third target: the CPU rulebook templates of the reference's vendored spconv (header-only, geometry.h) ----
+SRB_OUT = os.path.join(OUT_DIR, 'spconv_rulebook_ref.so')
+SRB_INC = os.path.join(REF_ROOT, 'mmdet3d', 'ops', 'spconv', 'include')
+SRB_BINDING = os.path.join(HERE, 'ref_spconv_rulebook_binding.cpp')
+SRB_STUBS = os.path.join(HERE, 'ref_stubs')  # an empty cuda_runtime_api.h: tensorview.h includes it unconditionally
+
+
+def build_spconv_rulebook(force=False, verbose=False):
+    """oracle/_ref/spconv_rulebook_ref.so = oracle/ref_spconv_rulebook_binding.cpp instantiating getIndicePairsConv /
+    SubM / DeConv <int, int, 3> from the reference's include/spconv/geometry.h (compiled where it lies)."""
+    if os.path.exists(SRB_OUT) and not force:
+        return SRB_OUT
+    if not os.path.exists(os.path.join(SRB_INC, 'spconv', 'geometry.h')):
+        return None
+    import torch
+    from torch.utils import cpp_extension
+    os.makedirs(OUT_DIR, exist_ok=True)
+    incs = cpp_extension.include_paths() + [sysconfig.get_paths()['include'], SRB_STUBS, SRB_INC]
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    obj = os.path.join(OUT_DIR, 'srb_binding.o')
+    cmd = ['g++', '-O2', '-fPIC', '-std=c++17', '-w', f'-D_GLIBCXX_USE_CXX11_ABI={abi}',
+           '-DTORCH_EXTENSION_NAME=spconv_rulebook_ref', '-DTORCH_API_INCLUDE_EXTENSION_H']
+    cmd += [f'-I{i}' for i in incs] + ['-c', SRB_BINDING, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('oracle/_ref build failed:\n' + ' '.join(cmd) + '\n' + (r.stdout + r.stderr)[-3000:])
+    link = ['g++', '-shared', '-o', SRB_OUT, obj, f'-L{torch_lib}', '-ltorch', '-ltorch_cpu', '-lc10', '-ltorch_python',
+            f'-Wl,-rpath,{torch_lib}']
+    r = subprocess.run(link, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('oracle/_ref link failed:\n' + r.stdout + r.stderr)
+    os.remove(obj)
+    if verbose:
+        print('built', SRB_OUT)
+    return SRB_OUT
+
+
+def load_spconv_rulebook():
+    if not os.path.exists(SRB_OUT):
+        return None
+    import importlib.util
+    import torch  # noqa: F401
+    spec = importlib.util.spec_from_file_location('spconv_rulebook_ref', SRB_OUT)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
 if __name__ == '__main__':
     p = build(force='--force' in sys.argv, verbose=True)
     print(p if p else 'reference tree not present; nothing built')
     p = build_points_in_boxes(force='--force' in sys.argv, verbose=True)
     print(p if p else 'reference tree not present; points_in_boxes not built')
+    p = build_spconv_rulebook(force='--force' in sys.argv, verbose=True)
+    print(p if p else 'reference tree not present; spconv rulebook not built')

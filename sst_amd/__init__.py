@@ -22,6 +22,9 @@ from .backbones import SIR, SSTv1, SSTv2
 from .cluster import (ClusterAssigner, connected_components_xy, filter_almost_empty, find_connected_componets,  # noqa: F401
                       find_connected_componets_single_batch, modify_cluster_by_class)
 from .dynamic_point_pool import DynamicPointROIExtractor, dynamic_point_pool, dynamic_point_pool_mixed
+from . import spconv  # noqa: F401  (sst_amd.spconv mirrors mmdet3d.ops.spconv)
+from .spconv import (SparseConv3d, SparseConvTensor, SparseConvTranspose3d, SparseInverseConv3d,  # noqa: F401
+                     SparseModule, SparseSequential, SubMConv3d)
 
 __version__ = '0.1.0'
 
@@ -37,5 +40,6 @@ __all__ = [
     'build_backbone', 'WindowPlan', 'sra_attention', 'sra_attention_qk_v', 'ClusterAssigner',
     'find_connected_componets', 'find_connected_componets_single_batch', 'filter_almost_empty',
     'modify_cluster_by_class', 'connected_components_xy', 'ROI_EXTRACTORS', 'DynamicPointROIExtractor',
-    'dynamic_point_pool', 'dynamic_point_pool_mixed',
+    'dynamic_point_pool', 'dynamic_point_pool_mixed', 'spconv', 'SparseConvTensor', 'SparseSequential', 'SparseModule',
+    'SubMConv3d', 'SparseConv3d', 'SparseConvTranspose3d', 'SparseInverseConv3d',
 ]

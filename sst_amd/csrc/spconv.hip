@@ -1,0 +1,486 @@
+// (§8 f4, first part) sparse 3-D convolution: rulebook construction and the convolution itself.
+//
+// Replaces, for 3-D int32 indices, the vendored spconv of the reference:
+//   * getIndicePair<3> (mmdet3d/ops/spconv/include/spconv/spconv_ops.h:26-150) with its functors
+//     CreateSubMIndicePairFunctor / CreateConvIndicePairFunctorP1/P2 (src/indice_cuda.cu, include/spconv/indice.cu.h)
+//     and the position / kernel-offset arithmetic of include/spconv/geometry.h:24-151;
+//   * indiceConv / indiceConvBackward (spconv_ops.h:256-446): per kernel offset gather -> mm -> scatter-add.
+//
+// Design.  A sparse convolution maps every output row i and kernel offset k to AT MOST ONE input row (and every
+// input row j and offset k to at most one output row).  The rulebook is therefore stored as two dense int32 maps,
+//   out2in[k][i] = j or -1        in2out[k][j] = i or -1,
+// next to the reference's pair lists (indice_pairs [K, 2, N], indice_num [K]; pairs of an offset ordered by input
+// row, the order of the reference's CPU path -- its GPU path leaves it to atomics).  With the maps the convolution is
+// ONE output-stationary kernel, Y[r] = sum_k X[map[k][r]] W[k]: a tall GEMM whose A rows are gathered on the fly,
+// fp32 MFMA (v_mfma_f32_32x32x2_f32), no atomics, no [nnz, C] gather / scatter buffers, deterministic.  The same
+// kernel is the data gradient (map = in2out, W transposed) and the inverse convolution (map = in2out of the coupled
+// convolution).  Offsets for which none of a workgroup's 64 rows has a neighbour are skipped.  The weight gradient
+// walks the pair lists (exactly the non-zero work), split over the pairs, partial sums reduced in a fixed order.
+//
+// Output rows of a regular (strided / transposed) convolution are numbered by ascending (batch, z, y, x), the order
+// of the reference's GPU path (torch::_unique of the linear indices, spconv_ops.h:128); they come from the
+// sorted-unique of sort_scan.hip applied to the candidate positions produced here.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SpGeom {
+  int in_shape[3], out_shape[3], ks[3], st[3], pd[3], dl[3];
+  int kvol;
+};
+
+// kernel offset k -> (kz, ky, kx), row-major as geometry.h:66-70 composes `offset`
+__device__ __forceinline__ void sp_koff(const SpGeom& g, int k, int (&ko)[3]) {
+  ko[2] = k % g.ks[2];
+  k /= g.ks[2];
+  ko[1] = k % g.ks[1];
+  ko[0] = k / g.ks[1];
+}
+
+// Candidate output position of input voxel `in` under offset ko.  Regular: in = out * st - pd + ko * dl
+// (geometry.h:41-47 enumerates the same set); transposed: out = in * st - pd + ko * dl (geometry.h:101-104).
+__device__ __forceinline__ bool sp_out_pos(const SpGeom& g, const int* in, const int (&ko)[3], bool transpose,
+                                           int (&out)[3]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int v;
+    if (transpose) {
+      v = in[d] * g.st[d] - g.pd[d] + ko[d] * g.dl[d];
+    } else {
+      const int num = in[d] + g.pd[d] - ko[d] * g.dl[d];
+      if (num < 0 || num % g.st[d] != 0) return false;
+      v = num / g.st[d];
+    }
+    if (v < 0 || v >= g.out_shape[d]) return false;
+    out[d] = v;
+  }
+  return true;
+}
+
+// rows [kvol * n + 1, 4]: (b, z, y, x) of the output voxel touched by (k, j), or -1 x 4; the extra last row is
+// always invalid so that the sorted-unique's group 0 is always the "invalid" group.
+__global__ __launch_bounds__(256) void sp_candidates_k(const int32_t* __restrict__ coors, int64_t n, SpGeom g,
+                                                       int transpose, int4* __restrict__ rows) {
+  const int64_t total = (int64_t)g.kvol * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= total; e += (int64_t)gridDim.x * blockDim.x) {
+    int4 r = make_int4(-1, -1, -1, -1);
+    if (e < total) {
+      const int k = (int)(e / n);
+      const int64_t j = e - (int64_t)k * n;
+      const int4 c = ((const int4*)coors)[j];
+      const int in[3] = {c.y, c.z, c.w};
+      int ko[3], out[3];
+      sp_koff(g, k, ko);
+      if (sp_out_pos(g, in, ko, transpose != 0, out)) r = make_int4(c.x, out[0], out[1], out[2]);
+    }
+    rows[e] = r;
+  }
+}
+
+// in2out[k][j] = inverse[k * n + j] - 1  (group 0 = invalid)
+__global__ __launch_bounds__(256) void sp_inverse_to_map_k(const int32_t* __restrict__ inverse, int64_t total,
+                                                           int32_t* __restrict__ in2out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    in2out[e] = inverse[e] - 1;
+}
+
+// Submanifold: output voxels = input voxels (same numbering).  sorted_keys[g] = 1 + linear index of the g-th voxel
+// in ascending order, perm[g] = its row; binary search for the neighbour position.
+__global__ __launch_bounds__(256) void sp_subm_map_k(const int32_t* __restrict__ coors, int64_t n, SpGeom g,
+                                                     const uint64_t* __restrict__ sorted_keys,
+                                                     const uint32_t* __restrict__ perm, int32_t* __restrict__ in2out) {
+  const int64_t total = (int64_t)g.kvol * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e / n);
+    const int64_t j = e - (int64_t)k * n;
+    const int4 c = ((const int4*)coors)[j];
+    const int in[3] = {c.y, c.z, c.w};
+    int ko[3], out[3];
+    sp_koff(g, k, ko);
+    int res = -1;
+    if (sp_out_pos(g, in, ko, false, out)) {
+      const uint64_t key =
+          1ull + (((uint64_t)c.x * g.out_shape[0] + out[0]) * g.out_shape[1] + out[1]) * g.out_shape[2] + out[2];
+      int64_t lo = 0, hi = n;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sorted_keys[mid] < key)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (lo < n && sorted_keys[lo] == key) res = (int)perm[lo];
+    }
+    in2out[e] = res;
+  }
+}
+
+__global__ __launch_bounds__(256) void sp_fill_i32_k(int32_t* __restrict__ p, int64_t n, int32_t v) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
+}
+
+// out2in[k][in2out[k][j]] = j
+__global__ __launch_bounds__(256) void sp_invert_map_k(const int32_t* __restrict__ in2out, int kvol, int64_t n,
+                                                       int64_t m, int32_t* __restrict__ out2in) {
+  const int64_t total = (int64_t)kvol * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = in2out[e];
+    if (i >= 0) {
+      const int64_t k = e / n;
+      out2in[k * m + i] = (int32_t)(e - k * n);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sp_pair_flags_k(const int32_t* __restrict__ in2out, int64_t total,
+                                                       int32_t* __restrict__ flags) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    flags[e] = in2out[e] >= 0 ? 1 : 0;
+}
+
+// pairs[k][0][p] = j, pairs[k][1][p] = in2out[k][j] for the p-th valid j of offset k (ascending j); num[k]
+__global__ __launch_bounds__(256) void sp_pair_write_k(const int32_t* __restrict__ in2out,
+                                                       const int32_t* __restrict__ pos, const int32_t* __restrict__ tot,
+                                                       int kvol, int64_t n, int32_t* __restrict__ pairs,
+                                                       int32_t* __restrict__ num) {
+  const int64_t total = (int64_t)kvol * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = e / n;
+    const int64_t j = e - k * n;
+    const int i = in2out[e];
+    const int base = pos[k * n];
+    if (i >= 0) {
+      const int p = pos[e] - base;
+      pairs[(k * 2 + 0) * n + p] = (int32_t)j;
+      pairs[(k * 2 + 1) * n + p] = i;
+    }
+    if (j == 0) num[k] = ((k + 1 < kvol) ? pos[(k + 1) * n] : tot[0]) - base;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Y[r, :] = sum_k X[map[k][r], :] @ W[k]  (+ bias).  Workgroup = 64 rows x up to 128 columns, 4 waves:
+// wave w -> rows 32 * (w & 1) .. +31, column tiles {2 * (w >> 1), 2 * (w >> 1) + 1} of 32.
+// Per (offset, 32-channel chunk): gathered A tile [64][32] and the weight slab B [32][128] staged in LDS, then
+// 16 k-steps of v_mfma_f32_32x32x2_f32 per column tile.  trans_w: W[k] is stored [cout_of_this_op][cin_of_this_op]
+// (the data gradient reads the forward weights [K, Cin, Cout] with the roles swapped).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSpRows = 64;
+constexpr int kSpCols = 128;
+
+__global__ __launch_bounds__(256) void sp_gather_gemm_k(const float* __restrict__ x, int64_t ldx,
+                                                        const int32_t* __restrict__ map, int64_t m, int kvol,
+                                                        const float* __restrict__ w, int cin, int cout, int trans_w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int64_t ldy) {
+  __shared__ float As[kSpRows][33];
+  __shared__ float Bs[32][kSpCols + 4];
+  __shared__ int idx[kSpRows];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kSpRows;
+  const int col0 = blockIdx.y * kSpCols;  // first output column of this workgroup
+  const int rhalf = wave & 1, chalf = wave >> 1;
+  const int l31 = lane & 31, kk = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const bool wave_cols = col0 + chalf * 64 < cout;  // this wave has at least one live column tile
+  for (int k = 0; k < kvol; ++k) {
+    int v = -1;
+    if (tid < kSpRows && r0 + tid < m) v = map[(int64_t)k * m + r0 + tid];
+    const int any = __syncthreads_or(v >= 0);  // also orders the previous offset's readers of idx
+    if (!any) continue;
+    if (tid < kSpRows) idx[tid] = v;
+    __syncthreads();
+    // does this wave's row half have a neighbour for this offset?  (uniform per wave)
+    const bool half_live = __any(idx[rhalf * 32 + l31] >= 0);
+    const float* wk = w + (int64_t)k * cin * cout;
+    for (int c0 = 0; c0 < cin; c0 += 32) {
+      {  // A: thread -> row tid >> 2, 8 channels at (tid & 3) * 8
+        const int row = tid >> 2, seg = (tid & 3) * 8;
+        const int src = idx[row];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + seg + u;
+          As[row][seg + u] = (src >= 0 && c < cin) ? x[(int64_t)src * ldx + c] : 0.f;
+        }
+      }
+      if (!trans_w) {  // B[c][n] = W[k][c0 + c][col0 + n]: thread -> channel tid >> 3, 16 columns at (tid & 7) * 16
+        const int c = tid >> 3, seg = (tid & 7) * 16;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int n = col0 + seg + u;
+          Bs[c][seg + u] = (c0 + c < cin && n < cout) ? wk[(int64_t)(c0 + c) * cout + n] : 0.f;
+        }
+      } else {  // W[k] stored [cout][cin]: thread -> column tid >> 1, 16 channels at (tid & 1) * 16
+        const int nloc = tid >> 1, seg = (tid & 1) * 16;
+        const int n = col0 + nloc;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int c = c0 + seg + u;
+          Bs[seg + u][nloc] = (c < cin && n < cout) ? wk[(int64_t)n * cin + c] : 0.f;
+        }
+      }
+      __syncthreads();
+      if (half_live && wave_cols) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float a = As[rhalf * 32 + l31][2 * s + kk];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float b = Bs[2 * s + kk][chalf * 64 + q * 32 + l31];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // D layout of 32x32: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int n = col0 + chalf * 64 + q * 32 + l31;
+    if (n >= cout) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = r0 + rhalf * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (row < m) y[row * ldy + n] = acc[q][r] + bv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dW[k] (cin x cout) = sum over the pairs p of offset k of  X[pa[p], :]^T  dY[pb[p], :].
+// grid = (kvol, splits, strips / 4): a wave owns a strip = 32 input channels x up to 128 output columns (4 MFMA
+// tiles); two pairs per v_mfma_f32_32x32x2_f32 step; fragments straight from global memory (a half-wave reads 128
+// contiguous bytes of one row).  Partials [split][k][cin][cout] are summed by sp_wgrad_reduce_k in split order.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_wgrad_k(const float* __restrict__ x, int64_t ldx,
+                                                  const float* __restrict__ dy, int64_t lddy,
+                                                  const int32_t* __restrict__ pairs, int64_t pair_ld, int x_side,
+                                                  const int32_t* __restrict__ num, int cin, int cout,
+                                                  float* __restrict__ part) {
+  const int k = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, kk = lane >> 5;
+  const int n_cog = (cout + 127) / 128;  // column groups of 128
+  const int strip = blockIdx.z * 4 + wave;
+  const int n_ci = (cin + 31) / 32;
+  const int ci = strip / n_cog, cog = strip - ci * n_cog;
+  const bool live = ci < n_ci;
+  const int np = num[k];
+  const int per = ((np + nsplit - 1) / nsplit + 1) & ~1;
+  const int p0 = split * per < np ? split * per : np;
+  const int p1 = p0 + per < np ? p0 + per : np;
+  const int32_t* pa = pairs + ((int64_t)k * 2 + x_side) * pair_ld;
+  const int32_t* pb = pairs + ((int64_t)k * 2 + (1 - x_side)) * pair_ld;
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int ca = ci * 32 + l31;
+  if (live) {
+    for (int p = p0; p < p1; p += 2) {
+      const bool ok = p + kk < p1;
+      const int ia = ok ? pa[p + kk] : 0, ib = ok ? pb[p + kk] : 0;
+      const float a = (ok && ca < cin) ? x[(int64_t)ia * ldx + ca] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = cog * 128 + q * 32 + l31;
+        const float b = (ok && n < cout) ? dy[(int64_t)ib * lddy + n] : 0.f;
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+      }
+    }
+    float* dst = part + ((int64_t)split * gridDim.x + k) * cin * cout;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = cog * 128 + q * 32 + l31;
+      if (n >= cout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (c < cin) dst[(int64_t)c * cout + n] = acc[q][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sp_wgrad_reduce_k(const float* __restrict__ part, int nsplit, int64_t elems,
+                                                         float* __restrict__ dw) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  float s = 0.f;
+  for (int i = 0; i < nsplit; ++i) s += part[(int64_t)i * elems + e];
+  dw[e] = s;
+}
+
+bool sp_geom(const int32_t* in_shape, const int32_t* out_shape, const int32_t* ks, const int32_t* st,
+             const int32_t* pd, const int32_t* dl, SpGeom* g) {
+  if (!in_shape || !out_shape || !ks || !st || !pd || !dl) return false;
+  g->kvol = 1;
+  for (int d = 0; d < 3; ++d) {
+    g->in_shape[d] = in_shape[d];
+    g->out_shape[d] = out_shape[d];
+    g->ks[d] = ks[d];
+    g->st[d] = st[d];
+    g->pd[d] = pd[d];
+    g->dl[d] = dl[d];
+    if (ks[d] < 1 || st[d] < 1 || dl[d] < 1 || pd[d] < 0 || in_shape[d] < 1 || out_shape[d] < 1) return false;
+    g->kvol *= ks[d];
+  }
+  return g->kvol <= 4096;  // spconv_ops.h:49
+}
+
+int sp_wgrad_splits(int kvol) {
+  int s = 512 / (kvol > 0 ? kvol : 1);
+  if (s < 1) s = 1;
+  if (s > 32) s = 32;
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sst_spconv_candidates_i32(const int32_t* d_coors, int64_t n, const int32_t* in_shape, const int32_t* out_shape,
+                              const int32_t* ksize, const int32_t* stride, const int32_t* padding,
+                              const int32_t* dilation, int transpose, int32_t* d_rows, void* stream) {
+  SpGeom g;
+  if (n < 0 || !sp_geom(in_shape, out_shape, ksize, stride, padding, dilation, &g)) return SST_ERR_ARG;
+  if ((int64_t)g.kvol * n > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
+  if (!d_rows || (n > 0 && !d_coors) || (((uintptr_t)d_coors | (uintptr_t)d_rows) & 15)) return SST_ERR_ARG;
+  const int64_t total = (int64_t)g.kvol * n + 1;
+  hipLaunchKernelGGL(sp_candidates_k, dim3(sst_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, d_coors, n, g,
+                     transpose, (int4*)d_rows);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_spconv_inverse_to_map_i32(const int32_t* d_inverse, int64_t total, int32_t* d_in2out, void* stream) {
+  if (total < 0) return SST_ERR_ARG;
+  if (total == 0) return SST_OK;
+  if (!d_inverse || !d_in2out) return SST_ERR_ARG;
+  hipLaunchKernelGGL(sp_inverse_to_map_k, dim3(sst_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, d_inverse,
+                     total, d_in2out);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_spconv_subm_map_i32(const int32_t* d_coors, int64_t n, const int32_t* shape, const int32_t* ksize,
+                            const int32_t* dilation, const uint64_t* d_sorted_keys, const uint32_t* d_perm,
+                            int32_t* d_in2out, void* stream) {
+  // spconv_ops.h:74-77: a submanifold convolution always uses stride 1 and padding = ksize / 2
+  int32_t st[3] = {1, 1, 1}, pd[3];
+  if (!ksize) return SST_ERR_ARG;
+  for (int d = 0; d < 3; ++d) pd[d] = ksize[d] / 2;
+  SpGeom g;
+  if (n < 0 || !sp_geom(shape, shape, ksize, st, pd, dilation, &g)) return SST_ERR_ARG;
+  if ((int64_t)g.kvol * n > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
+  if (n == 0) return SST_OK;
+  if (!d_coors || !d_sorted_keys || !d_perm || !d_in2out || (((uintptr_t)d_coors) & 15)) return SST_ERR_ARG;
+  hipLaunchKernelGGL(sp_subm_map_k, dim3(sst_grid_1d((int64_t)g.kvol * n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_coors, n, g, d_sorted_keys, d_perm, d_in2out);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_spconv_invert_map_i32(const int32_t* d_in2out, int kvol, int64_t n, int64_t m, int32_t* d_out2in,
+                              void* stream) {
+  if (kvol < 1 || n < 0 || m < 0) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (m > 0) {
+    if (!d_out2in) return SST_ERR_ARG;
+    hipLaunchKernelGGL(sp_fill_i32_k, dim3(sst_grid_1d((int64_t)kvol * m, 256)), dim3(256), 0, st, d_out2in,
+                       (int64_t)kvol * m, -1);
+  }
+  if (n > 0 && m > 0) {
+    if (!d_in2out) return SST_ERR_ARG;
+    hipLaunchKernelGGL(sp_invert_map_k, dim3(sst_grid_1d((int64_t)kvol * n, 256)), dim3(256), 0, st, d_in2out, kvol, n,
+                       m, d_out2in);
+  }
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int64_t sst_spconv_pair_lists_workspace_bytes(int kvol, int64_t n) {
+  const int64_t total = (int64_t)(kvol > 0 ? kvol : 1) * (n > 0 ? n : 1);
+  return 2 * sst_align_up(total * (int64_t)sizeof(int32_t), 256) + sst_align_up(sst_scan_workspace_bytes(total), 256) +
+         512;
+}
+
+int sst_spconv_pair_lists_i32(const int32_t* d_in2out, int kvol, int64_t n, int32_t* d_pairs, int32_t* d_num,
+                              void* d_workspace, void* stream) {
+  if (kvol < 1 || n < 0 || !d_num) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    SST_HIP(hipMemsetAsync(d_num, 0, sizeof(int32_t) * kvol, st));
+    return SST_OK;
+  }
+  if (!d_in2out || !d_pairs || !d_workspace) return SST_ERR_ARG;
+  const int64_t total = (int64_t)kvol * n;
+  if (total > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
+  const int64_t seg = sst_align_up(total * (int64_t)sizeof(int32_t), 256);
+  char* ws = (char*)d_workspace;
+  int32_t* flags = (int32_t*)ws;
+  int32_t* pos = (int32_t*)(ws + seg);
+  void* scan_ws = ws + 2 * seg;
+  int32_t* tot = (int32_t*)(ws + 2 * seg + sst_align_up(sst_scan_workspace_bytes(total), 256));
+  const int grid = sst_grid_1d(total, 256);
+  hipLaunchKernelGGL(sp_fill_i32_k, dim3(sst_grid_1d(2 * total, 256)), dim3(256), 0, st, d_pairs, 2 * total, -1);
+  hipLaunchKernelGGL(sp_pair_flags_k, dim3(grid), dim3(256), 0, st, d_in2out, total, flags);
+  const int rc = sst_exclusive_scan_i32(flags, pos, total, tot, scan_ws, stream);
+  if (rc != SST_OK) return rc;
+  hipLaunchKernelGGL(sp_pair_write_k, dim3(grid), dim3(256), 0, st, d_in2out, pos, tot, kvol, n, d_pairs, d_num);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol,
+                               const float* d_w, int cin, int cout, int trans_w, const float* d_bias, float* d_y,
+                               int64_t ldy, void* stream) {
+  if (m < 0 || kvol < 1 || cin < 1 || cout < 1 || ldx < cin || ldy < cout) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_map || !d_w || !d_y) return SST_ERR_ARG;
+  if (sst_div_up(m, kSpRows) > 0x7fffffff || sst_div_up(cout, kSpCols) > 65535) return SST_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sp_gather_gemm_k, dim3((unsigned)sst_div_up(m, kSpRows), (unsigned)sst_div_up(cout, kSpCols)),
+                     dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w, cin, cout, trans_w, d_bias, d_y,
+                     ldy);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout) {
+  return (int64_t)sp_wgrad_splits(kvol) * (kvol > 0 ? kvol : 1) * cin * cout * (int64_t)sizeof(float) + 256;
+}
+
+int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+                         int64_t pair_ld, int x_side, const int32_t* d_num, int kvol, int cin, int cout, float* d_dw,
+                         void* d_workspace, void* stream) {
+  if (kvol < 1 || cin < 1 || cout < 1 || ldx < cin || lddy < cout || pair_ld < 0 || (x_side != 0 && x_side != 1))
+    return SST_ERR_ARG;
+  if (!d_pairs || !d_num || !d_dw || !d_workspace) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t elems = (int64_t)kvol * cin * cout;
+  if (pair_ld == 0 || !d_x || !d_dy) {
+    SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * elems, st));
+    return SST_OK;
+  }
+  const int splits = sp_wgrad_splits(kvol);
+  const int strips = (int)(sst_div_up(cin, 32) * sst_div_up(cout, 128));
+  if (kvol > 65535 || sst_div_up(strips, 4) > 65535) return SST_ERR_UNSUPPORTED;
+  float* part = (float*)d_workspace;
+  hipLaunchKernelGGL(sp_wgrad_k, dim3((unsigned)kvol, (unsigned)splits, (unsigned)sst_div_up(strips, 4)), dim3(256), 0,
+                     st, d_x, ldx, d_dy, lddy, d_pairs, pair_ld, x_side, d_num, cin, cout, part);
+  hipLaunchKernelGGL(sp_wgrad_reduce_k, dim3((unsigned)sst_div_up(elems, 256)), dim3(256), 0, st, part, splits, elems,
+                     d_dw);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,532 @@
+"""Sparse 3-D convolution on the GPU (first part): rulebook, SubM / strided / transposed / inverse
+convolution with forward, data gradient and weight gradient.
+
+Mirrors the Python surface of the reference's vendored spconv (mmdet3d/ops/spconv): ``SparseConvTensor``
+(structure.py:21-73), ``SparseModule`` / ``SparseSequential`` / ``ToDense`` (modules.py:36-215), ``get_conv_output_size``
+/ ``get_deconv_output_size`` / ``get_indice_pairs`` / ``indice_conv`` / ``indice_conv_backward`` (ops.py:20-160), the
+autograd functions ``indice_conv`` / ``indice_inverse_conv`` / ``indice_subm_conv`` (functional.py:20-75) and
+``SparseConvolution`` with its 3-D subclasses (conv.py:37-480): same names, constructor arguments, ``weight`` layout
+``[kz, ky, kx, Cin, Cout]`` and ``indice_dict`` entries, so checkpoints and the reference's backbones
+(middle_encoders/sparse_unet.py) see the same objects.
+
+What differs underneath (csrc/spconv.hip): the rulebook is kept as two dense int32 maps next to the reference's pair
+lists; a convolution is ONE gathered-GEMM launch (fp32 MFMA, no atomics) instead of K x (gather, mm, scatter-add);
+output voxels of a strided / transposed convolution are numbered by ascending (b, z, y, x) -- the order of the
+reference's GPU path (``torch::_unique`` of the linear indices, spconv_ops.h:128); pairs of an offset are ordered by
+input row (the reference's CPU order; its GPU order is left to atomics).  3-D int32 indices and fp32 features only.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import init
+from torch.nn.parameter import Parameter
+
+from . import _lib
+from . import kernels as K
+from .registry import Registry
+
+CONV_LAYERS = Registry('conv layer')  # mmcv.cnn.CONV_LAYERS
+
+
+# ------------------------------------------------------------------------------------------------ structure.py
+def scatter_nd(indices, updates, shape):
+    """structure.py:5-18 (no repeated indices)"""
+    ret = torch.zeros(*shape, dtype=updates.dtype, device=updates.device)
+    ndim = indices.shape[-1]
+    output_shape = list(indices.shape[:-1]) + shape[indices.shape[-1]:]
+    flat = indices.view(-1, ndim)
+    slices = [flat[:, i] for i in range(ndim)] + [Ellipsis]
+    ret[tuple(slices)] = updates.view(*output_shape)
+    return ret
+
+
+class SparseConvTensor(object):
+    """features [N, C] fp32, indices [N, 4] int32 (batch, z, y, x), spatial_shape (z, y, x), batch_size."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.spatial_shape = spatial_shape
+        self.batch_size = batch_size
+        self.indice_dict = {}
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return np.prod(self.spatial_shape)
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        output_shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
+        res = scatter_nd(self.indices.long(), self.features, output_shape)
+        if not channels_first:
+            return res
+        ndim = len(self.spatial_shape)
+        order = list(range(0, ndim + 1))
+        order.insert(1, ndim + 1)
+        return res.permute(*order).contiguous()
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+
+
+# ------------------------------------------------------------------------------------------------ ops.py
+def _triple(v, ndim=3):
+    return [int(e) for e in v] if isinstance(v, (list, tuple)) else [int(v)] * ndim
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """ops.py:20-30"""
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(1 if kernel_size[i] == -1 else size)
+    return out
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    """ops.py:33-43"""
+    out = []
+    for i in range(len(input_size)):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        out.append((input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i])
+    return out
+
+
+class Rulebook(object):
+    """in2out [K, n], out2in [K, m] int32 maps (-1 = no partner) + the reference's pair lists."""
+    __slots__ = ('in2out', 'out2in', 'pairs', 'num', 'n', 'm', 'kvol')
+
+
+def _i32(vals):
+    return _lib.i32array([int(v) for v in vals])
+
+
+def _finish_rulebook(in2out, kvol, n, m, dev):
+    lib = _lib.load()
+    rb = Rulebook()
+    rb.in2out, rb.kvol, rb.n, rb.m = in2out, kvol, n, m
+    rb.out2in = torch.empty((kvol, m), dtype=torch.int32, device=dev)
+    _lib.check(lib.sst_spconv_invert_map_i32(_lib.ptr(in2out), kvol, n, m, _lib.ptr(rb.out2in), _lib.stream_ptr()),
+               'sst_spconv_invert_map_i32')
+    rb.pairs = torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
+    rb.num = torch.zeros(kvol, dtype=torch.int32, device=dev)
+    ws = _lib.workspace(lib.sst_spconv_pair_lists_workspace_bytes(kvol, n), dev)
+    _lib.check(lib.sst_spconv_pair_lists_i32(_lib.ptr(in2out), kvol, n, _lib.ptr(rb.pairs), _lib.ptr(rb.num),
+                                             _lib.ptr(ws), _lib.stream_ptr()), 'sst_spconv_pair_lists_i32')
+    rb.pairs._sst_rulebook = rb  # rides along wherever the reference passes indice_pairs around
+    return rb
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
+                     subm=False, transpose=False, grid=None):
+    """ops.py:46-102 -> (outids [M, 4] int32, indice_pairs [K, 2, N] int32, indice_pair_num [K] int32)."""
+    if not indices.is_cuda:
+        raise RuntimeError('sst_amd.spconv: CUDA tensors required (no CPU fallback)')
+    if indices.dim() != 2 or indices.shape[1] != 4:
+        raise NotImplementedError('sst_amd.spconv: 3-D indices (batch, z, y, x) only')
+    ndim = 3
+    ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
+    dilation, out_padding = _triple(dilation), _triple(out_padding)
+    for d, s in zip(dilation, stride):
+        assert any([s == 1, d == 1]), "don't support this."
+    spatial_shape = [int(s) for s in spatial_shape]
+    if not subm:
+        if transpose:
+            out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, out_padding)
+        else:
+            out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    else:
+        out_shape = spatial_shape
+    indices = indices.int().contiguous()
+    n, dev = indices.size(0), indices.device
+    kvol = int(np.prod(ksize))
+    lib = _lib.load()
+    in2out = torch.empty((kvol, n), dtype=torch.int32, device=dev)
+    if n == 0:
+        rb = _finish_rulebook(in2out, kvol, 0, 0, dev)
+        return indices, rb.pairs, rb.num
+    if subm:
+        plan = K.unique_rows(indices, [0, 0, 0, 0], [int(batch_size)] + out_shape, invalid_if_negative=0)
+        if plan.m != n:
+            raise RuntimeError('sst_amd.spconv: a SparseConvTensor must not contain a voxel twice')
+        rc = lib.sst_spconv_subm_map_i32(_lib.ptr(indices), n, _i32(out_shape), _i32(ksize), _i32(dilation),
+                                         _lib.ptr(plan.ukeys), _lib.ptr(plan.perm), _lib.ptr(in2out),
+                                         _lib.stream_ptr())
+        _lib.check(rc, 'sst_spconv_subm_map_i32')
+        rb = _finish_rulebook(in2out, kvol, n, n, dev)
+        return indices, rb.pairs, rb.num
+    rows = torch.empty((kvol * n + 1, 4), dtype=torch.int32, device=dev)
+    rc = lib.sst_spconv_candidates_i32(_lib.ptr(indices), n, _i32(spatial_shape), _i32(out_shape), _i32(ksize),
+                                       _i32(stride), _i32(padding), _i32(dilation), int(bool(transpose)),
+                                       _lib.ptr(rows), _lib.stream_ptr())
+    _lib.check(rc, 'sst_spconv_candidates_i32')
+    plan = K.unique_rows(rows, [0, 0, 0, 0], [int(batch_size)] + out_shape, invalid_if_negative=1)
+    m = plan.m - 1  # group 0 collects the invalid candidates (the extra last row guarantees that it exists)
+    outids = K.unpack_unique_rows(plan, torch.int32, first=1, count=m)
+    _lib.check(lib.sst_spconv_inverse_to_map_i32(_lib.ptr(plan.inverse), kvol * n, _lib.ptr(in2out),
+                                                 _lib.stream_ptr()), 'sst_spconv_inverse_to_map_i32')
+    rb = _finish_rulebook(in2out, kvol, n, m, dev)
+    return outids, rb.pairs, rb.num
+
+
+def rulebook_of(indice_pairs, indice_pair_num, num_out):
+    """the dense maps behind a pair-list tensor; rebuilt from the lists when they did not come from get_indice_pairs"""
+    rb = getattr(indice_pairs, '_sst_rulebook', None)
+    if rb is not None:
+        return rb
+    kvol, _, n = indice_pairs.shape
+    dev = indice_pairs.device
+    valid = torch.arange(n, device=dev)[None, :] < indice_pair_num[:, None].to(dev)
+    koff = torch.arange(kvol, device=dev)[:, None].expand(kvol, n)[valid]
+    src, dst = indice_pairs[:, 0][valid].long(), indice_pairs[:, 1][valid]
+    in2out = torch.full((kvol, n), -1, dtype=torch.int32, device=dev)
+    in2out[koff, src] = dst
+    return _finish_rulebook(in2out, kvol, n, int(num_out), dev)
+
+
+def _gather_gemm(x, mapping, rows, weight3, trans_w, cout):
+    lib = _lib.load()
+    x = x if x.stride(1) == 1 else x.contiguous()
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    if rows > 0:
+        rc = lib.sst_spconv_gather_gemm_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, weight3.size(0),
+                                            _lib.ptr(weight3), x.size(1), cout, int(trans_w), None, _lib.ptr(y),
+                                            y.stride(0), _lib.stream_ptr())
+        _lib.check(rc, 'sst_spconv_gather_gemm_f32')
+    return y
+
+
+def _wgrad(x, dy, rb, x_side, shape):
+    lib = _lib.load()
+    kvol, cin, cout = rb.kvol, x.size(1), dy.size(1)
+    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, cin, cout), x.device)
+    x = x if x.stride(1) == 1 else x.contiguous()
+    dy = dy if dy.stride(1) == 1 else dy.contiguous()
+    rc = lib.sst_spconv_wgrad_f32(_lib.ptr(x), x.stride(0) if x.size(0) else cin, _lib.ptr(dy),
+                                  dy.stride(0) if dy.size(0) else cout, _lib.ptr(rb.pairs), rb.n, x_side,
+                                  _lib.ptr(rb.num), kvol, cin, cout, _lib.ptr(dw), _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, 'sst_spconv_wgrad_f32')
+    return dw.view(shape)
+
+
+def _check(features, filters):
+    if not features.is_cuda:
+        raise RuntimeError('sst_amd.spconv: CUDA tensors required (no CPU fallback)')
+    if features.dtype != torch.float32 or filters.dtype != torch.float32:
+        raise NotImplementedError('sst_amd.spconv: fp32 only')
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
+    """ops.py:105-124: out[pairs[k][1 - inverse]] += features[pairs[k][inverse]] @ filters[k]"""
+    _check(features, filters)
+    rb = rulebook_of(indice_pairs, indice_pair_num, features.size(0) if inverse else num_activate_out)
+    w3 = filters.reshape(-1, filters.shape[-2], filters.shape[-1])
+    if inverse:
+        return _gather_gemm(features, rb.in2out, rb.n, w3, False, w3.size(2))
+    return _gather_gemm(features, rb.out2in, rb.m, w3, False, w3.size(2))
+
+
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
+    """ops.py:139-156 -> (input gradient, filter gradient)"""
+    _check(features, filters)
+    rb = rulebook_of(indice_pairs, indice_pair_num, features.size(0) if inverse else out_bp.size(0))
+    w3 = filters.reshape(-1, filters.shape[-2], filters.shape[-1])
+    out_bp = out_bp.contiguous()
+    if inverse:
+        input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3, True, w3.size(1))
+        filters_bp = _wgrad(features, out_bp, rb, 1, filters.shape)
+    else:
+        input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3, True, w3.size(1))
+        filters_bp = _wgrad(features, out_bp, rb, 0, filters.shape)
+    return input_bp, filters_bp
+
+
+# ------------------------------------------------------------------------------------------------ functional.py
+class SparseConvFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters)
+        ctx.rulebook = getattr(indice_pairs, '_sst_rulebook', None)
+        return indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, False)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, filters = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            indice_pairs._sst_rulebook = ctx.rulebook
+        input_bp, filters_bp = indice_conv_backward(features, filters, grad_output, indice_pairs, indice_pair_num, False)
+        return input_bp, filters_bp, None, None, None
+
+
+class SparseInverseConvFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters)
+        ctx.rulebook = getattr(indice_pairs, '_sst_rulebook', None)
+        return indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, True, False)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, filters = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            indice_pairs._sst_rulebook = ctx.rulebook
+        input_bp, filters_bp = indice_conv_backward(features, filters, grad_output, indice_pairs, indice_pair_num, True,
+                                                    False)
+        return input_bp, filters_bp, None, None, None
+
+
+class SubMConvFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters)
+        ctx.rulebook = getattr(indice_pairs, '_sst_rulebook', None)
+        return indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, False, True)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, filters = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            indice_pairs._sst_rulebook = ctx.rulebook
+        input_bp, filters_bp = indice_conv_backward(features, filters, grad_output, indice_pairs, indice_pair_num, False,
+                                                    True)
+        return input_bp, filters_bp, None, None, None
+
+
+indice_conv_fn = SparseConvFunction.apply
+indice_inverse_conv = SparseInverseConvFunction.apply
+indice_subm_conv = SubMConvFunction.apply
+
+
+# ------------------------------------------------------------------------------------------------ modules.py
+class SparseModule(nn.Module):
+    """marker: modules deriving from it receive the SparseConvTensor itself inside a SparseSequential"""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+def is_sparse_conv(module):
+    return isinstance(module, SparseConvolution)
+
+
+class SparseSequential(SparseModule):
+    """modules.py:42-140: sparse modules get the tensor, everything else its features."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError('name exists.')
+            self.add_module(name, module)
+        self._sparity_dict = {}
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError('index {} is out of range'.format(idx))
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    @property
+    def sparity_dict(self):
+        return self._sparity_dict
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError('name exists')
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                self._sparity_dict[k] = input.sparity
+                input = module(input)
+            else:
+                if isinstance(input, SparseConvTensor):
+                    if input.indices.shape[0] != 0:
+                        input.features = module(input.features)
+                else:
+                    input = module(input)
+        return input
+
+
+class ToDense(SparseModule):
+
+    def forward(self, x):
+        return x.dense()
+
+
+class RemoveGrid(SparseModule):
+
+    def forward(self, x):
+        x.grid = None
+        return x
+
+
+# ------------------------------------------------------------------------------------------------ conv.py
+def _calculate_fan_in_and_fan_out_hwio(tensor):
+    """conv.py:28-46: the weight is [*kernel, Cin, Cout]"""
+    dimensions = tensor.ndimension()
+    if dimensions < 2:
+        raise ValueError('fan in and fan out can not be computed for tensor with fewer than 2 dimensions')
+    if dimensions == 2:
+        return tensor.size(-2), tensor.size(-1)
+    receptive = 1
+    if tensor.dim() > 2:
+        receptive = tensor[..., 0, 0].numel()
+    return tensor.size(-2) * receptive, tensor.size(-1) * receptive
+
+
+class SparseConvolution(SparseModule):
+    """conv.py:49-230.  fused_bn is accepted and ignored (the reference marks it "don't use")."""
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 fused_bn=False):
+        super().__init__()
+        assert groups == 1
+        if ndim != 3:
+            raise NotImplementedError('sst_amd.spconv: 3-D convolutions only')
+        kernel_size, stride, padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        dilation, output_padding = _triple(dilation), _triple(output_padding)
+        for d, s in zip(dilation, stride):
+            assert any([s == 1, d == 1]), "don't support this."
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.conv1x1 = np.prod(kernel_size) == 1
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.transposed = transposed
+        self.inverse = inverse
+        self.output_padding = output_padding
+        self.groups = groups
+        self.subm = subm
+        self.indice_key = indice_key
+        self.fused_bn = fused_bn
+        self.weight = Parameter(torch.Tensor(*kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = _calculate_fan_in_and_fan_out_hwio(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        features = input.features
+        indices = input.indices
+        spatial_shape = input.spatial_shape
+        batch_size = input.batch_size
+        if not self.subm:
+            if self.transposed:
+                out_spatial_shape = get_deconv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
+                                                           self.dilation, self.output_padding)
+            else:
+                out_spatial_shape = get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
+                                                         self.dilation)
+        else:
+            out_spatial_shape = spatial_shape
+        if self.conv1x1:
+            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                features += self.bias
+            out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
+            out_tensor.indice_dict = input.indice_dict
+            out_tensor.grid = input.grid
+            return out_tensor
+        datas = input.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert datas is not None and self.indice_key is not None
+            _, outids, indice_pairs, indice_pair_num, out_spatial_shape = datas
+            assert indice_pairs.shape[0] == np.prod(self.kernel_size), \
+                'inverse conv must have same kernel size as its couple conv'
+        else:
+            if self.indice_key is not None and datas is not None:
+                outids, _, indice_pairs, indice_pair_num, _ = datas
+            else:
+                outids, indice_pairs, indice_pair_num = get_indice_pairs(
+                    indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation,
+                    self.output_padding, self.subm, self.transposed, grid=input.grid)
+                input.indice_dict[self.indice_key] = (outids, indices, indice_pairs, indice_pair_num, spatial_shape)
+        if self.subm:
+            out_features = indice_subm_conv(features, self.weight, indice_pairs, indice_pair_num, outids.shape[0])
+        elif self.inverse:
+            out_features = indice_inverse_conv(features, self.weight, indice_pairs, indice_pair_num, outids.shape[0])
+        else:
+            out_features = indice_conv_fn(features, self.weight, indice_pairs, indice_pair_num, outids.shape[0])
+        if self.bias is not None:
+            out_features += self.bias
+        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+        out_tensor.indice_dict = input.indice_dict
+        out_tensor.grid = input.grid
+        return out_tensor
+
+
+@CONV_LAYERS.register_module()
+class SparseConv3d(SparseConvolution):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+@CONV_LAYERS.register_module()
+class SparseConvTranspose3d(SparseConvolution):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         transposed=True, indice_key=indice_key)
+
+
+@CONV_LAYERS.register_module()
+class SparseInverseConv3d(SparseConvolution):
+
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+
+
+@CONV_LAYERS.register_module()
+class SubMConv3d(SparseConvolution):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)

@@ -350,6 +350,49 @@ def gen_point_pool():
     save('point_pool.npz', **arrays)
 
 
+SPCONV_CASES = {
+    # tag: (n, batch, spatial_shape, ksize, stride, padding, dilation, subm, transpose)
+    'subm3': (1500, 2, [12, 40, 40], [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], True, False),
+    'down3s2': (1500, 2, [12, 40, 40], [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], False, False),
+    'down_k313': (1200, 1, [9, 33, 31], [3, 1, 3], [2, 1, 2], [0, 0, 1], [1, 1, 1], False, False),
+    'down2s2': (1200, 2, [8, 20, 20], [2, 2, 2], [2, 2, 2], [0, 0, 0], [1, 1, 1], False, False),
+    'transposed': (600, 2, [6, 16, 16], [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], False, True),
+    'subm_dil2': (1500, 1, [10, 30, 30], [3, 3, 3], [1, 1, 1], [0, 0, 0], [2, 2, 2], True, False),
+}
+
+
+def gen_spconv():
+    """Sparse-convolution rulebooks (f4) from the reference's own CPU templates (include/spconv/geometry.h, compiled
+    by oracle/build_ref.build_spconv_rulebook): output indices in the CPU path's first-appearance order, pair lists,
+    pair counts.  Consumers compare through coordinates (the GPU path and this repo number outputs in sorted order)."""
+    mod = build_ref.load_spconv_rulebook()
+    assert mod is not None, 'build oracle/_ref first (python oracle/build_ref.py)'
+    from oracle import spconv_oracle
+    rng = np.random.default_rng(21)
+    arrays = {}
+    for tag, (n, batch, shape, ks, st, pd, dl, subm, tr) in SPCONV_CASES.items():
+        vol = int(np.prod(shape))
+        lin = rng.choice(batch * vol, n, replace=False)
+        b, r = lin // vol, lin % vol
+        ind = np.stack([b, r // (shape[1] * shape[2]), (r // shape[2]) % shape[1], r % shape[2]], 1).astype(np.int32)
+        if subm:
+            out_shape, st_ref, pd_ref = shape, [1, 1, 1], [k // 2 for k in ks]  # spconv_ops.h:74-77
+        elif tr:
+            out_shape, st_ref, pd_ref = spconv_oracle.deconv_output_size(shape, ks, st, pd, dl, [0, 0, 0]), st, pd
+        else:
+            out_shape, st_ref, pd_ref = spconv_oracle.conv_output_size(shape, ks, st, pd, dl), st, pd
+        outids, pairs, num = mod.get_indice_pairs_3d(torch.from_numpy(ind), batch, out_shape, ks, st_ref, pd_ref, dl,
+                                                     subm, tr)
+        arrays[f'in::{tag}::indices'] = ind
+        # batch, spatial_shape, ksize, stride, padding, dilation, subm, transpose
+        arrays[f'in::{tag}::params'] = np.asarray([batch] + shape + ks + st + pd + dl + [int(subm), int(tr)], dtype=np.int32)
+        arrays[f'out::{tag}::out_shape'] = np.asarray(out_shape, dtype=np.int32)
+        arrays[f'out::{tag}::outids'] = outids.numpy()
+        arrays[f'out::{tag}::pairs'] = pairs.numpy()
+        arrays[f'out::{tag}::num'] = num.numpy()
+    save('spconv.npz', **arrays)
+
+
 def main():
     assert ref_loader.available(), 'the reference tree is required'
     build_ref.build()
@@ -364,6 +407,8 @@ def main():
     gen_cluster()
     build_ref.build_points_in_boxes()
     gen_point_pool()
+    build_ref.build_spconv_rulebook()
+    gen_spconv()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,178 @@
+"""GPU: sparse 3-D convolution (csrc/spconv.hip, sst_amd/spconv.py).  Rulebooks: bit-exact against the oracle
+(oracle/spconv_oracle.py) and, through coordinates, against the output of the reference's own CPU templates
+(tests/golden/spconv.npz).  Convolution forward / data gradient / weight gradient: against the float64 restatement
+of indiceConv / indiceConvBackward, relative 1e-4 (fp32 MFMA accumulation)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_oracle import _rulebook_equal_by_coordinates, spconv_case
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TAGS = ['subm3', 'down3s2', 'down_k313', 'down2s2', 'transposed', 'subm_dil2']
+
+
+def _cloud(rng, n, batch, shape):
+    vol = int(np.prod(shape))
+    lin = rng.choice(batch * vol, n, replace=False)
+    b, r = lin // vol, lin % vol
+    return np.stack([b, r // (shape[1] * shape[2]), (r // shape[2]) % shape[1], r % shape[2]], 1).astype(np.int32)
+
+
+def _rulebook(ind, batch, shape, ks, st, pd, dl, subm, tr):
+    from sst_amd import spconv
+    outids, pairs, num = spconv.get_indice_pairs(torch.from_numpy(ind).to(DEV), batch, shape, ks, st, pd, dl, 0, subm, tr)
+    return outids, pairs, num, pairs._sst_rulebook
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_rulebook_matches_oracle_and_reference_golden(tag):
+    from oracle import spconv_oracle as O
+    g = load_golden('spconv.npz')
+    ind, batch, shape, ks, st, pd, dl, subm, tr = spconv_case(g, tag)
+    outids, pairs, num, rb = _rulebook(ind, batch, shape, ks, st, pd, dl, subm, tr)
+    w_out, w_pairs, w_num, _ = O.indice_pairs(ind, batch, shape, ks, st, pd, dl, (0, 0, 0), subm, tr)
+    assert outids.dtype == torch.int32 and pairs.dtype == torch.int32 and num.dtype == torch.int32
+    np.testing.assert_array_equal(outids.cpu().numpy(), w_out)       # sorted (b, z, y, x) / the inputs for subm
+    np.testing.assert_array_equal(num.cpu().numpy(), w_num)
+    np.testing.assert_array_equal(pairs.cpu().numpy(), w_pairs)      # pairs by ascending input row, -1 behind
+    in2out, out2in = O.maps_from_pairs(w_pairs, w_num, len(ind), len(w_out))
+    np.testing.assert_array_equal(rb.in2out.cpu().numpy(), in2out)
+    np.testing.assert_array_equal(rb.out2in.cpu().numpy(), out2in)
+    _rulebook_equal_by_coordinates(g[f'out::{tag}::outids'], g[f'out::{tag}::pairs'], g[f'out::{tag}::num'],
+                                   outids.cpu().numpy(), pairs.cpu().numpy(), num.cpu().numpy())
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('cin,cout', [(16, 32), (5, 7), (64, 64), (67, 128), (128, 160)])
+def test_conv_forward_backward_match_oracle(tag, cin, cout):
+    from oracle import spconv_oracle as O
+    from sst_amd import spconv
+    g = load_golden('spconv.npz')
+    ind, batch, shape, ks, st, pd, dl, subm, tr = spconv_case(g, tag)
+    outids, pairs, num, rb = _rulebook(ind, batch, shape, ks, st, pd, dl, subm, tr)
+    gen = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(len(ind), cin, generator=gen)
+    w = torch.randn(*ks, cin, cout, generator=gen) * 0.2
+    gy = torch.randn(len(outids), cout, generator=gen)
+    fn = spconv.indice_subm_conv if subm else spconv.indice_conv_fn
+    xa, wa = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = fn(xa, wa, pairs, num, len(outids))
+    y.backward(gy.to(DEV))
+    p_np, n_np = pairs.cpu().numpy(), num.cpu().numpy()
+    y_ref = O.indice_conv(x.numpy(), w.numpy(), p_np, n_np, len(outids))
+    dx_ref, dw_ref = O.indice_conv_backward(x.numpy(), w.numpy(), gy.numpy(), p_np, n_np)
+    for got, want in ((y, y_ref), (xa.grad, dx_ref), (wa.grad, dw_ref)):
+        err = np.abs(got.detach().cpu().numpy().astype(np.float64) - want).max()
+        assert err < 1e-4 * max(1.0, np.abs(want).max()), err
+
+
+def test_inverse_conv_matches_oracle_and_modules_chain():
+    """SubMConv3d -> SparseConv3d (stride 2, indice_key) -> SubMConv3d -> SparseInverseConv3d back to the input voxels
+    (the down / up pattern of middle_encoders/sparse_unet.py), forward and all gradients against the oracle."""
+    from oracle import spconv_oracle as O
+    from sst_amd import spconv
+    rng = np.random.default_rng(4)
+    batch, shape, n = 2, [9, 28, 30], 2200
+    ind = _cloud(rng, n, batch, shape)
+    torch.manual_seed(0)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(6, 16, 3, padding=1, bias=False, indice_key='subm1'),
+        torch.nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=True, indice_key='down1'),
+        spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key='subm2'),
+        spconv.SparseInverseConv3d(32, 8, 3, indice_key='down1', bias=False)).to(DEV)
+    x = torch.randn(n, 6)
+    xa = x.to(DEV).requires_grad_(True)
+    t = spconv.SparseConvTensor(xa, torch.from_numpy(ind).to(DEV), shape, batch)
+    out = net(t)
+    assert out.features.shape == (n, 8) and torch.equal(out.indices.cpu(), torch.from_numpy(ind))
+    assert list(out.spatial_shape) == shape
+    gy = torch.randn(n, 8)
+    out.features.backward(gy.to(DEV))
+    # oracle chain in float64
+    w = [p.detach().cpu().numpy().astype(np.float64) for p in (net[0].weight, net[2].weight, net[3].weight, net[4].weight)]
+    bias = net[2].bias.detach().cpu().numpy().astype(np.float64)
+    _, p1, n1, _ = O.indice_pairs(ind, batch, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+    o2, p2, n2, shape2 = O.indice_pairs(ind, batch, shape, [3] * 3, [2] * 3, [1] * 3, [1] * 3)
+    _, p3, n3, _ = O.indice_pairs(o2, batch, shape2, [3] * 3, [1] * 3, [1] * 3, [1] * 3, subm=True)
+    h1 = O.indice_conv(x.numpy(), w[0], p1, n1, n)
+    a1 = np.maximum(h1, 0)
+    h2 = O.indice_conv(a1, w[1], p2, n2, len(o2)) + bias
+    h3 = O.indice_conv(h2, w[2], p3, n3, len(o2))
+    y = O.indice_conv(h3, w[3], p2, n2, n, inverse=True)
+    assert np.abs(out.features.detach().cpu().numpy() - y).max() < 2e-4 * max(1.0, np.abs(y).max())
+    d3, dw3 = O.indice_conv_backward(h3, w[3], gy.numpy(), p2, n2, inverse=True)
+    d2, dw2 = O.indice_conv_backward(h2, w[2], d3, p3, n3)
+    db = d2.sum(0)
+    d1, dw1 = O.indice_conv_backward(a1, w[1], d2, p2, n2)
+    d1 = d1 * (h1 > 0)
+    dx, dw0 = O.indice_conv_backward(x.numpy(), w[0], d1, p1, n1)
+    for got, want in ((xa.grad, dx), (net[0].weight.grad, dw0), (net[2].weight.grad, dw1), (net[2].bias.grad, db),
+                      (net[3].weight.grad, dw2), (net[4].weight.grad, dw3)):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - want).max()
+        assert err < 5e-4 * max(1.0, np.abs(want).max()), err
+    # the rulebook of 'down1' is shared by the inverse convolution, 'subm1' is reused by a second SubM with the key
+    assert set(t.indice_dict) == {'subm1', 'down1', 'subm2'}
+
+
+def test_spconv_edge_cases():
+    from sst_amd import spconv
+    shape, batch = [5, 8, 8], 1
+    conv = spconv.SubMConv3d(4, 8, 3, padding=1, indice_key='k').to(DEV)
+    empty = spconv.SparseConvTensor(torch.zeros(0, 4, device=DEV), torch.zeros(0, 4, dtype=torch.int32, device=DEV),
+                                    shape, batch)
+    assert conv(empty).features.shape == (0, 8)
+    one = spconv.SparseConvTensor(torch.ones(1, 4, device=DEV), torch.tensor([[0, 2, 3, 4]], dtype=torch.int32, device=DEV),
+                                  shape, batch)
+    y = conv(one)
+    want = torch.ones(1, 4, device=DEV) @ conv.weight[1, 1, 1] + conv.bias
+    assert torch.allclose(y.features, want, atol=1e-5)
+    down = spconv.SparseConv3d(4, 8, 3, stride=2, padding=1, bias=False).to(DEV)
+    z = down(one)
+    assert z.indices.tolist() == [[0, 1, 1, 2], [0, 1, 2, 2]] and list(z.spatial_shape) == [3, 4, 4]
+    with pytest.raises(RuntimeError):
+        spconv.get_indice_pairs(torch.tensor([[0, 1, 1, 1], [0, 1, 1, 1]], dtype=torch.int32, device=DEV), 1, shape, 3,
+                                subm=True)   # duplicate voxel
+    with pytest.raises(RuntimeError):
+        spconv.get_indice_pairs(torch.zeros(3, 4, dtype=torch.int32), 1, shape, 3, subm=True)   # CPU tensor
+    d = one.dense()
+    assert d.shape == (1, 4, 5, 8, 8) and float(d.sum()) == 4.0
+    # pair lists that did not come from get_indice_pairs (no attached maps): rebuilt from the lists
+    ind = torch.tensor([[0, 1, 1, 1], [0, 1, 1, 2], [0, 2, 2, 2]], dtype=torch.int32, device=DEV)
+    outids, pairs, num = spconv.get_indice_pairs(ind, 1, shape, 3, subm=True)
+    x = torch.randn(3, 4, device=DEV)
+    a = spconv.indice_conv(x, conv.weight, pairs, num, 3, False, True)
+    b = spconv.indice_conv(x, conv.weight, pairs.clone(), num, 3, False, True)
+    assert torch.equal(a, b)
+
+
+def test_spconv_full_size_properties():
+    """FSD-scale SubM layer (150 k voxels, 64 -> 64): linearity, agreement of the gathered GEMM with the reference's
+    per-offset gather / mm / index_add formulation in torch, determinism, rulebook symmetry."""
+    from sst_amd import spconv
+    rng = np.random.default_rng(8)
+    batch, shape, n = 2, [41, 400, 400], 150000
+    base = _cloud(rng, n // 4, batch, [shape[0], shape[1] // 2, shape[2] // 2])
+    ind = np.unique(np.concatenate([base * [1, 1, 2, 2] + [0, 0, dy, dx] for dy in (0, 1) for dx in (0, 1)]), axis=0)
+    ind = ind[rng.permutation(len(ind))].astype(np.int32)
+    n = len(ind)
+    outids, pairs, num = spconv.get_indice_pairs(torch.from_numpy(ind).to(DEV), batch, shape, 3, subm=True)
+    rb = pairs._sst_rulebook
+    assert int(num[13]) == n and torch.equal(rb.in2out[13], torch.arange(n, dtype=torch.int32, device=DEV))
+    assert torch.equal(num, num.flip(0))                      # subm pairs come in mirrored offsets
+    x = torch.randn(n, 64, device=DEV)
+    w = torch.randn(3, 3, 3, 64, 64, device=DEV) * 0.05
+    y = spconv.indice_conv(x, w, pairs, num, n, False, True)
+    assert torch.equal(y, spconv.indice_conv(x, w, pairs, num, n, False, True))
+    ref = torch.zeros(n, 64, device=DEV, dtype=torch.float64)
+    w3 = w.view(27, 64, 64).double()
+    for k in range(27):
+        c = int(num[k])
+        src, dst = pairs[k, 0, :c].long(), pairs[k, 1, :c].long()
+        ref.index_add_(0, dst, x[src].double() @ w3[k])
+    assert float((y.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    y2 = spconv.indice_conv(2.5 * x, w, pairs, num, n, False, True)
+    assert float((y2 - 2.5 * y).abs().max()) < 1e-4 * float(y.abs().max())

@@ -270,3 +270,98 @@ def test_point_pool_oracle_matches_compiled_reference_live():
     mine = O.inside(lx, ly, lz, rois[:, 3], rois[:, 4], rois[:, 5])
     assert flags.sum() > 1000
     np.testing.assert_array_equal(mine, flags.numpy().astype(bool))
+
+
+def spconv_case(g, tag):
+    """(indices, batch, shape, ksize, stride, padding, dilation, subm, transpose) of a tests/golden/spconv.npz case"""
+    p = g[f'in::{tag}::params'].tolist()
+    return (g[f'in::{tag}::indices'], p[0], p[1:4], p[4:7], p[7:10], p[10:13], p[13:16], bool(p[16]), bool(p[17]))
+
+
+def _rulebook_equal_by_coordinates(ref_outids, ref_pairs, ref_num, outids, pairs, num):
+    assert (np.asarray(ref_num) == np.asarray(num)).all()
+    assert set(map(tuple, ref_outids.tolist())) == set(map(tuple, outids.tolist())) and len(ref_outids) == len(outids)
+    for k in range(len(num)):
+        a = {(j, tuple(ref_outids[i])) for j, i in zip(ref_pairs[k, 0, :ref_num[k]].tolist(),
+                                                       ref_pairs[k, 1, :ref_num[k]].tolist())}
+        b = {(j, tuple(outids[i])) for j, i in zip(pairs[k, 0, :num[k]].tolist(), pairs[k, 1, :num[k]].tolist())}
+        assert a == b, k
+        assert (pairs[k, :, num[k]:] == -1).all()
+
+
+@pytest.mark.parametrize('tag', ['subm3', 'down3s2', 'down_k313', 'down2s2', 'transposed', 'subm_dil2'])
+def test_spconv_rulebook_oracle_matches_reference_golden(tag):
+    """sparse-convolution rulebook restatement against the output of the reference's own CPU templates
+    (tests/golden/make_golden.py::gen_spconv): same output voxels, same (input row, output voxel) pairs per kernel
+    offset, same counts; outputs sorted by (b, z, y, x), pairs by input row."""
+    from oracle import spconv_oracle as O
+    g = load_golden('spconv.npz')
+    ind, batch, shape, ks, st, pd, dl, subm, tr = spconv_case(g, tag)
+    outids, pairs, num, out_shape = O.indice_pairs(ind, batch, shape, ks, st, pd, dl, (0, 0, 0), subm, tr)
+    assert list(out_shape) == g[f'out::{tag}::out_shape'].tolist()
+    _rulebook_equal_by_coordinates(g[f'out::{tag}::outids'], g[f'out::{tag}::pairs'], g[f'out::{tag}::num'], outids,
+                                   pairs, num)
+    if subm:
+        np.testing.assert_array_equal(outids, ind)
+    else:
+        vol = int(np.prod(out_shape))
+        lin = ((outids[:, 0].astype(np.int64) * out_shape[0] + outids[:, 1]) * out_shape[1] + outids[:, 2]) \
+            * out_shape[2] + outids[:, 3]
+        assert (np.diff(lin) > 0).all() and lin.max() < batch * vol
+    for k in range(len(num)):
+        assert (np.diff(pairs[k, 0, :num[k]]) > 0).all()
+    in2out, out2in = O.maps_from_pairs(pairs, num, len(ind), len(outids))
+    assert ((in2out >= 0).sum(1) == num).all() and ((out2in >= 0).sum(1) == num).all()
+
+
+def test_spconv_rulebook_oracle_matches_compiled_reference_live():
+    from oracle import spconv_oracle as O
+    mod = build_ref.load_spconv_rulebook()
+    if mod is None:
+        pytest.skip('oracle/_ref/spconv_rulebook_ref.so not built (reference tree absent)')
+    rng = np.random.default_rng(77)
+    for n, batch, shape, ks, st, pd, dl, subm, tr in [(2500, 3, [10, 36, 28], [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], True, False),
+                                                      (2500, 3, [10, 36, 28], [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], False, False),
+                                                      (900, 1, [5, 14, 15], [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1], False, True),
+                                                      (1800, 2, [9, 25, 25], [3, 3, 3], [1, 1, 1], [2, 2, 2], [2, 2, 2], False, False)]:
+        vol = int(np.prod(shape))
+        lin = rng.choice(batch * vol, n, replace=False)
+        b, r = lin // vol, lin % vol
+        ind = np.stack([b, r // (shape[1] * shape[2]), (r // shape[2]) % shape[1], r % shape[2]], 1).astype(np.int32)
+        outids, pairs, num, out_shape = O.indice_pairs(ind, batch, shape, ks, st, pd, dl, (0, 0, 0), subm, tr)
+        st_ref, pd_ref = ([1, 1, 1], [k // 2 for k in ks]) if subm else (st, pd)
+        ro, rp, rn = mod.get_indice_pairs_3d(torch.from_numpy(ind), batch, out_shape, ks, st_ref, pd_ref, dl, subm, tr)
+        _rulebook_equal_by_coordinates(ro.numpy(), rp.numpy(), rn.numpy(), outids, pairs, num)
+
+
+def test_spconv_conv_oracle_forward_backward_consistency():
+    """indice_conv restatement: against a dense float64 convolution (scipy-free: explicit loops over offsets on a
+    dense canvas) and its backward against finite differences."""
+    from oracle import spconv_oracle as O
+    rng = np.random.default_rng(3)
+    shape, batch, n, cin, cout = [6, 9, 8], 2, 300, 5, 4
+    vol = int(np.prod(shape))
+    lin = rng.choice(batch * vol, n, replace=False)
+    b, r = lin // vol, lin % vol
+    ind = np.stack([b, r // (shape[1] * shape[2]), (r // shape[2]) % shape[1], r % shape[2]], 1).astype(np.int32)
+    x = rng.normal(size=(n, cin))
+    w = rng.normal(size=(3, 3, 3, cin, cout))
+    outids, pairs, num, out_shape = O.indice_pairs(ind, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1])
+    y = O.indice_conv(x, w, pairs, num, len(outids))
+    dense = np.zeros([batch] + [s + 2 for s in shape] + [cin])
+    dense[ind[:, 0], ind[:, 1] + 1, ind[:, 2] + 1, ind[:, 3] + 1] = x
+    for i, (bb, z, yy, xx) in enumerate(outids.tolist()):
+        patch = dense[bb, 2 * z:2 * z + 3, 2 * yy:2 * yy + 3, 2 * xx:2 * xx + 3]   # in = out * 2 - 1 + k
+        np.testing.assert_allclose(y[i], np.einsum('zyxc,zyxco->o', patch, w), atol=1e-10)
+    g = rng.normal(size=y.shape)
+    dx, dw = O.indice_conv_backward(x, w, g, pairs, num)
+    eps = 1e-6
+    for idx in [(0, 0), (17, 3), (299, 4)]:
+        xp = x.copy()
+        xp[idx] += eps
+        num_grad = ((O.indice_conv(xp, w, pairs, num, len(outids)) - y) * g).sum() / eps
+        assert abs(num_grad - dx[idx]) < 1e-4
+    wp = w.copy()
+    wp[1, 2, 0, 3, 1] += eps
+    num_grad = ((O.indice_conv(x, wp, pairs, num, len(outids)) - y) * g).sum() / eps
+    assert abs(num_grad - dw[1, 2, 0, 3, 1]) < 1e-4

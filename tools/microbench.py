@@ -247,6 +247,50 @@ def bench_voxelize():
               f'{(4 * c + 16) * n / med / 1e6:.0f} GB/s')
 
 
+def bench_spconv():
+    """sparse convolution at FSD scale: rulebook construction, the gathered-GEMM forward / data gradient, the
+    pair-list weight gradient, against the reference's formulation in torch on the same box (per kernel offset:
+    gather, mm, index_add -- spconv_ops.h:305-350).  Useful flops = 2 * pairs * Cin * Cout."""
+    import numpy as np
+    from sst_amd import spconv
+    rng = np.random.default_rng(8)
+    batch, shape = 2, [41, 800, 800]
+    for n_target, cin, cout in ((150000, 64, 64), (150000, 128, 128), (60000, 64, 128)):
+        vol = int(np.prod([shape[0], shape[1] // 2, shape[2] // 2]))
+        lin = rng.choice(batch * vol, n_target // 4, replace=False)
+        b, r = lin // vol, lin % vol
+        hs = [shape[0], shape[1] // 2, shape[2] // 2]
+        base = np.stack([b, r // (hs[1] * hs[2]), (r // hs[2]) % hs[1], r % hs[2]], 1)
+        ind = np.unique(np.concatenate([base * [1, 1, 2, 2] + [0, 0, dy, dx] for dy in (0, 1) for dx in (0, 1)]), axis=0)
+        ind = torch.from_numpy(ind.astype(np.int32)).to(DEV)
+        n = ind.size(0)
+        med_rb, _ = timeit(lambda: spconv.get_indice_pairs(ind, batch, shape, 3, subm=True), iters=10, warmup=2)
+        outids, pairs, num = spconv.get_indice_pairs(ind, batch, shape, 3, subm=True)
+        med_rb2, _ = timeit(lambda: spconv.get_indice_pairs(ind, batch, shape, 3, 2, 1), iters=10, warmup=2)
+        npairs = int(num.sum())
+        x = torch.randn(n, cin, device=DEV)
+        w = torch.randn(3, 3, 3, cin, cout, device=DEV) * 0.05
+        gy = torch.randn(n, cout, device=DEV)
+        med_f, _ = timeit(lambda: spconv.indice_conv(x, w, pairs, num, n, False, True), iters=20, warmup=3)
+        med_b, _ = timeit(lambda: spconv.indice_conv_backward(x, w, gy, pairs, num, False, True), iters=20, warmup=3)
+        w3 = w.view(27, cin, cout)
+        counts = num.tolist()
+
+        def reference_flow():
+            out = torch.zeros(n, cout, device=DEV)
+            for k in range(27):
+                c = counts[k]
+                if c:
+                    out.index_add_(0, pairs[k, 1, :c].long(), x[pairs[k, 0, :c].long()] @ w3[k])
+            return out
+        med_r, _ = timeit(reference_flow, iters=10, warmup=2)
+        fl = 2.0 * npairs * cin * cout
+        print(f'spconv SubM3 {n} voxels {cin}->{cout}, {npairs} pairs ({npairs / n:.1f} per voxel): rulebook {med_rb * 1e3:.0f} us '
+              f'(stride-2 conv rulebook {med_rb2 * 1e3:.0f} us); forward {med_f * 1e3:.0f} us = {fl / med_f / 1e9:.1f} useful TFLOP/s '
+              f'({27 * 2.0 * n * cin * cout / med_f / 1e9:.1f} issued); dgrad + wgrad {med_b * 1e3:.0f} us; '
+              f'per-offset gather/mm/index_add forward in torch {med_r * 1e3:.0f} us')
+
+
 def bench_pointpool():
     """dynamic point pool at FSD second-stage sizes: whole op (3 passes + scans + the count read-back) and the pair
     tests per second it amounts to (the reference's kernel is the same R x P brute force, one thread per pair)."""
@@ -280,5 +324,7 @@ if __name__ == '__main__':
         bench_cluster()
     if what in ('voxelize',):
         bench_voxelize()
+    if what in ('spconv',):
+        bench_spconv()
     if what in ('pointpool',):
         bench_pointpool()
