@@ -389,7 +389,7 @@ int sst_spconv_pair_lists_i32(const int32_t* d_in2out, int kvol, int64_t n, int3
 int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol,
                                const float* d_w, int cin, int cout, int trans_w, const float* d_bias, float* d_y,
                                int64_t ldy, void* stream);
-int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout);
+int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int cin, int cout);
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                          int64_t pair_ld, int x_side, const int32_t* d_num, int kvol, int cin, int cout, float* d_dw,
                          void* d_workspace, void* stream);

@@ -256,27 +256,47 @@ __global__ __launch_bounds__(256) void sp_gather_gemm_k(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------
 // dW[k] (cin x cout) = sum over the pairs p of offset k of  X[pa[p], :]^T  dY[pb[p], :].
-// grid = (kvol, splits, strips / 4): a wave owns a strip = 32 input channels x up to 128 output columns (4 MFMA
-// tiles); two pairs per v_mfma_f32_32x32x2_f32 step; fragments straight from global memory (a half-wave reads 128
-// contiguous bytes of one row).  Partials [split][k][cin][cout] are summed by sp_wgrad_reduce_k in split order.
+// The pairs of all offsets are cut into chunks of kSpChunk pairs (an offset with num[k] pairs owns
+// ceil(num[k] / kSpChunk) consecutive chunks; every workgroup finds its (offset, chunk) by walking num[], K <= 4096),
+// so the load is balanced whatever the spread of the pair counts (the centre offset of a submanifold convolution
+// holds every voxel).  grid = (chunks upper bound, strips / 4): a wave owns a strip = 32 input channels x up to 128
+// output columns (4 MFMA tiles); two pairs per v_mfma_f32_32x32x2_f32 step, four steps in flight (indices, then
+// fragments, then MFMAs); fragments straight from global memory (a half-wave reads 128 contiguous bytes of one row).
+// Partials [chunk][cin][cout] are summed per offset, in chunk order, by sp_wgrad_reduce_k.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kSpChunk = 2048;
+
+__device__ __forceinline__ bool sp_find_chunk(const int32_t* __restrict__ num, int kvol, int chunk, int& k, int& first) {
+  int c0 = 0;
+  for (int i = 0; i < kvol; ++i) {
+    const int nc = (num[i] + kSpChunk - 1) / kSpChunk;
+    if (chunk < c0 + nc) {
+      k = i;
+      first = c0;
+      return true;
+    }
+    c0 += nc;
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(256) void sp_wgrad_k(const float* __restrict__ x, int64_t ldx,
                                                   const float* __restrict__ dy, int64_t lddy,
                                                   const int32_t* __restrict__ pairs, int64_t pair_ld, int x_side,
-                                                  const int32_t* __restrict__ num, int cin, int cout,
+                                                  const int32_t* __restrict__ num, int kvol, int cin, int cout,
                                                   float* __restrict__ part) {
-  const int k = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  int k, first;
+  if (!sp_find_chunk(num, kvol, blockIdx.x, k, first)) return;  // uniform
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, kk = lane >> 5;
   const int n_cog = (cout + 127) / 128;  // column groups of 128
-  const int strip = blockIdx.z * 4 + wave;
+  const int strip = blockIdx.y * 4 + wave;
   const int n_ci = (cin + 31) / 32;
   const int ci = strip / n_cog, cog = strip - ci * n_cog;
-  const bool live = ci < n_ci;
+  if (ci >= n_ci) return;
   const int np = num[k];
-  const int per = ((np + nsplit - 1) / nsplit + 1) & ~1;
-  const int p0 = split * per < np ? split * per : np;
-  const int p1 = p0 + per < np ? p0 + per : np;
+  const int p0 = (blockIdx.x - first) * kSpChunk;
+  const int p1 = p0 + kSpChunk < np ? p0 + kSpChunk : np;
   const int32_t* pa = pairs + ((int64_t)k * 2 + x_side) * pair_ld;
   const int32_t* pb = pairs + ((int64_t)k * 2 + (1 - x_side)) * pair_ld;
   f32x16 acc[4];
@@ -285,39 +305,64 @@ __global__ __launch_bounds__(256) void sp_wgrad_k(const float* __restrict__ x, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   const int ca = ci * 32 + l31;
-  if (live) {
-    for (int p = p0; p < p1; p += 2) {
-      const bool ok = p + kk < p1;
-      const int ia = ok ? pa[p + kk] : 0, ib = ok ? pb[p + kk] : 0;
-      const float a = (ok && ca < cin) ? x[(int64_t)ia * ldx + ca] : 0.f;
+  const bool a_ok = ca < cin;
+  bool b_ok[4];
+  int cb[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = cog * 128 + q * 32 + l31;
-        const float b = (ok && n < cout) ? dy[(int64_t)ib * lddy + n] : 0.f;
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
-      }
+  for (int q = 0; q < 4; ++q) {
+    cb[q] = cog * 128 + q * 32 + l31;
+    b_ok[q] = cb[q] < cout;
+  }
+  for (int p = p0; p < p1; p += 8) {
+    int ia[4], ib[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = p + 2 * u + kk;
+      ok[u] = pp < p1;
+      ia[u] = ok[u] ? pa[pp] : 0;
+      ib[u] = ok[u] ? pb[pp] : 0;
     }
-    float* dst = part + ((int64_t)split * gridDim.x + k) * cin * cout;
+    float a[4], b[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = cog * 128 + q * 32 + l31;
-      if (n >= cout) continue;
+    for (int u = 0; u < 4; ++u) {
+      a[u] = (ok[u] && a_ok) ? x[(int64_t)ia[u] * ldx + ca] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (c < cin) dst[(int64_t)c * cout + n] = acc[q][r];
-      }
+      for (int q = 0; q < 4; ++q) b[u][q] = (ok[u] && b_ok[q]) ? dy[(int64_t)ib[u] * lddy + cb[q]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][q], acc[q], 0, 0, 0);
+  }
+  float* dst = part + (int64_t)blockIdx.x * cin * cout;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!b_ok[q]) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = ci * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (c < cin) dst[(int64_t)c * cout + cb[q]] = acc[q][r];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void sp_wgrad_reduce_k(const float* __restrict__ part, int nsplit, int64_t elems,
-                                                         float* __restrict__ dw) {
+// dw[k][e] = sum over the chunks of offset k, in chunk order
+__global__ __launch_bounds__(256) void sp_wgrad_reduce_k(const float* __restrict__ part, const int32_t* __restrict__ num,
+                                                         int kvol, int64_t per_k, float* __restrict__ dw) {
+  const int k = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
+  if (e >= per_k) return;
+  int first = 0;
+  for (int i = 0; i < k; ++i) first += (num[i] + kSpChunk - 1) / kSpChunk;
+  const int nc = (num[k] + kSpChunk - 1) / kSpChunk;
   float s = 0.f;
-  for (int i = 0; i < nsplit; ++i) s += part[(int64_t)i * elems + e];
-  dw[e] = s;
+  for (int c = 0; c < nc; ++c) s += part[(int64_t)(first + c) * per_k + e];
+  dw[(int64_t)k * per_k + e] = s;
+}
+
+int64_t sp_wgrad_chunks(int kvol, int64_t pair_ld) {  // upper bound on the number of chunks
+  return ((int64_t)kvol * pair_ld) / kSpChunk + kvol;
 }
 
 bool sp_geom(const int32_t* in_shape, const int32_t* out_shape, const int32_t* ks, const int32_t* st,
@@ -335,13 +380,6 @@ bool sp_geom(const int32_t* in_shape, const int32_t* out_shape, const int32_t* k
     g->kvol *= ks[d];
   }
   return g->kvol <= 4096;  // spconv_ops.h:49
-}
-
-int sp_wgrad_splits(int kvol) {
-  int s = 512 / (kvol > 0 ? kvol : 1);
-  if (s < 1) s = 1;
-  if (s > 32) s = 32;
-  return s;
 }
 
 }  // namespace
@@ -455,8 +493,8 @@ int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_m
   return SST_OK;
 }
 
-int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout) {
-  return (int64_t)sp_wgrad_splits(kvol) * (kvol > 0 ? kvol : 1) * cin * cout * (int64_t)sizeof(float) + 256;
+int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int cin, int cout) {
+  return sp_wgrad_chunks(kvol > 0 ? kvol : 1, pair_ld > 0 ? pair_ld : 1) * cin * cout * (int64_t)sizeof(float) + 256;
 }
 
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
@@ -466,19 +504,19 @@ int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64
     return SST_ERR_ARG;
   if (!d_pairs || !d_num || !d_dw || !d_workspace) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t elems = (int64_t)kvol * cin * cout;
+  const int64_t per_k = (int64_t)cin * cout;
   if (pair_ld == 0 || !d_x || !d_dy) {
-    SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * elems, st));
+    SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * kvol * per_k, st));
     return SST_OK;
   }
-  const int splits = sp_wgrad_splits(kvol);
+  const int64_t chunks = sp_wgrad_chunks(kvol, pair_ld);
   const int strips = (int)(sst_div_up(cin, 32) * sst_div_up(cout, 128));
-  if (kvol > 65535 || sst_div_up(strips, 4) > 65535) return SST_ERR_UNSUPPORTED;
+  if (kvol > 65535 || chunks > 0x7fffffff || sst_div_up(strips, 4) > 65535) return SST_ERR_UNSUPPORTED;
   float* part = (float*)d_workspace;
-  hipLaunchKernelGGL(sp_wgrad_k, dim3((unsigned)kvol, (unsigned)splits, (unsigned)sst_div_up(strips, 4)), dim3(256), 0,
-                     st, d_x, ldx, d_dy, lddy, d_pairs, pair_ld, x_side, d_num, cin, cout, part);
-  hipLaunchKernelGGL(sp_wgrad_reduce_k, dim3((unsigned)sst_div_up(elems, 256)), dim3(256), 0, st, part, splits, elems,
-                     d_dw);
+  hipLaunchKernelGGL(sp_wgrad_k, dim3((unsigned)chunks, (unsigned)sst_div_up(strips, 4)), dim3(256), 0, st, d_x, ldx,
+                     d_dy, lddy, d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, part);
+  hipLaunchKernelGGL(sp_wgrad_reduce_k, dim3((unsigned)sst_div_up(per_k, 256), (unsigned)kvol), dim3(256), 0, st, part,
+                     d_num, kvol, per_k, d_dw);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -209,7 +209,7 @@ def _wgrad(x, dy, rb, x_side, shape):
     lib = _lib.load()
     kvol, cin, cout = rb.kvol, x.size(1), dy.size(1)
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
-    ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, cin, cout), x.device)
+    ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, rb.n, cin, cout), x.device)
     x = x if x.stride(1) == 1 else x.contiguous()
     dy = dy if dy.stride(1) == 1 else dy.contiguous()
     rc = lib.sst_spconv_wgrad_f32(_lib.ptr(x), x.stride(0) if x.size(0) else cin, _lib.ptr(dy),

@@ -273,6 +273,12 @@ def bench_spconv():
         gy = torch.randn(n, cout, device=DEV)
         med_f, _ = timeit(lambda: spconv.indice_conv(x, w, pairs, num, n, False, True), iters=20, warmup=3)
         med_b, _ = timeit(lambda: spconv.indice_conv_backward(x, w, gy, pairs, num, False, True), iters=20, warmup=3)
+        rb = pairs._sst_rulebook
+        w3c = w.view(27, cin, cout)
+        med_d, _ = timeit(lambda: spconv._gather_gemm(gy, rb.in2out, n, w3c, True, cin), iters=20, warmup=3)
+        shuf = ind[torch.randperm(n, device=DEV)]
+        _, pairs_s, num_s = spconv.get_indice_pairs(shuf, batch, shape, 3, subm=True)
+        med_fs, _ = timeit(lambda: spconv.indice_conv(x, w, pairs_s, num_s, n, False, True), iters=20, warmup=3)
         w3 = w.view(27, cin, cout)
         counts = num.tolist()
 
@@ -287,7 +293,8 @@ def bench_spconv():
         fl = 2.0 * npairs * cin * cout
         print(f'spconv SubM3 {n} voxels {cin}->{cout}, {npairs} pairs ({npairs / n:.1f} per voxel): rulebook {med_rb * 1e3:.0f} us '
               f'(stride-2 conv rulebook {med_rb2 * 1e3:.0f} us); forward {med_f * 1e3:.0f} us = {fl / med_f / 1e9:.1f} useful TFLOP/s '
-              f'({27 * 2.0 * n * cin * cout / med_f / 1e9:.1f} issued); dgrad + wgrad {med_b * 1e3:.0f} us; '
+              f'({27 * 2.0 * n * cin * cout / med_f / 1e9:.1f} if nothing were skipped; voxels in (b, z, y, x) order; {med_fs * 1e3:.0f} us in random order); '
+              f'dgrad {med_d * 1e3:.0f} us, dgrad + wgrad {med_b * 1e3:.0f} us; '
               f'per-offset gather/mm/index_add forward in torch {med_r * 1e3:.0f} us')
 
 
