@@ -14,7 +14,11 @@ Stubbed third-party modules (absent here):
   ingroup_indices.forward               -> stable-sort rank (TorchEx is un-vendored; the reference's own
                                           fallback get_inner_win_inds_deprecated defines the contract:
                                           a bijection onto 0..cnt-1 per group, order unspecified)
-  mmdet.models.BACKBONES, mmdet3d.ops.spconv / make_sparse_convmodule -> placeholders
+  mmdet.models.BACKBONES, mmdet3d.ops.spconv / make_sparse_convmodule -> placeholders (load_reference);
+  load_reference_spconv() replaces the spconv placeholder by the reference's own vendored spconv Python package
+  (structure / modules / ops / functional / conv .py, unmodified) on top of a stub `sparse_conv_ext` whose rulebook
+  comes from the reference's CPU templates compiled into oracle/_ref and whose indice_conv is oracle/spconv_oracle's
+  arithmetic in torch; mmdet 2.14's resnet.BasicBlock constructor is restated for ops/sparse_block.py
   DynamicScatter (GPU-only in the reference) -> oracle.voxel_oracle restatement
 """
 import importlib.util
@@ -137,12 +141,17 @@ def load_reference():
         cfg.setdefault('eps', 1e-5)
         return ('ln' if t == 'LN' else 'bn') + str(postfix), table[t](num_features, **cfg)
 
+    conv_layers = _Registry('conv layer')
+
     def build_conv_layer(cfg, *args, **kwargs):
         cfg = dict(cfg or dict(type='Conv2d'))
         t = cfg.pop('type')
-        return {'Conv2d': nn.Conv2d, 'Conv1d': nn.Conv1d}[t](*args, **kwargs, **cfg)
+        table = {'Conv2d': nn.Conv2d, 'Conv1d': nn.Conv1d}
+        table.update(conv_layers.module_dict)
+        return table[t](*args, **kwargs, **cfg)
 
-    _mod('mmcv.cnn', build_norm_layer=build_norm_layer, build_conv_layer=build_conv_layer, NORM_LAYERS=norm_layers)
+    _mod('mmcv.cnn', build_norm_layer=build_norm_layer, build_conv_layer=build_conv_layer, NORM_LAYERS=norm_layers,
+         CONV_LAYERS=conv_layers)
     _mod('torch_scatter', scatter_max=_scatter_max, scatter=_scatter)
 
     def _ingroup_forward(group_inds, out_inds):
@@ -201,6 +210,126 @@ def load_reference():
     ns.backbones = backbones
     _LOADED = ns
     return ns
+
+
+_SPCONV = None
+
+
+def load_reference_spconv():
+    """The reference's vendored spconv Python package + ops/sparse_block.py + middle_encoders/sparse_unet.py, executed
+    unmodified on CPU.  Native side (`sparse_conv_ext`, CUDA / extension code in the reference): get_indice_pairs_3d
+    = the reference's CPU rulebook templates compiled by oracle/build_ref.build_spconv_rulebook (subm forces stride 1
+    and padding ksize // 2 as spconv_ops.h:74-77 does); indice_conv(_backward)_fp32 = the per-offset gather / mm /
+    scatter-add of spconv_ops.h:256-446 written with torch CPU ops."""
+    global _SPCONV
+    if _SPCONV is not None:
+        return _SPCONV
+    ns = load_reference()
+    from oracle import build_ref
+    build_ref.build_spconv_rulebook()
+    rule = build_ref.load_spconv_rulebook()
+    assert rule is not None
+
+    def get_indice_pairs_3d(indices, batch_size, out_shape, spatial_shape, ksize, stride, padding, dilation,
+                            out_padding, subm, transpose):
+        if subm:
+            stride, padding = [1] * 3, [k // 2 for k in ksize]
+        outids, pairs, num = rule.get_indice_pairs_3d(indices.int().contiguous(), int(batch_size), list(out_shape),
+                                                      list(ksize), list(stride), list(padding), list(dilation),
+                                                      bool(subm), bool(transpose))
+        return [outids, pairs, num]
+
+    def indice_conv_fp32(features, filters, indice_pairs, indice_pair_num, num_act_out, inverse, subm):
+        w = filters.reshape(-1, filters.shape[-2], filters.shape[-1])
+        out = torch.zeros(num_act_out, w.shape[2], dtype=features.dtype)
+        for k in range(w.shape[0]):
+            c = int(indice_pair_num[k])
+            if c:
+                src, dst = indice_pairs[k, int(inverse), :c].long(), indice_pairs[k, 1 - int(inverse), :c].long()
+                out.index_add_(0, dst, features[src] @ w[k])
+        return out
+
+    def indice_conv_backward_fp32(features, filters, out_bp, indice_pairs, indice_pair_num, inverse, subm):
+        w = filters.reshape(-1, filters.shape[-2], filters.shape[-1])
+        dx = torch.zeros_like(features)
+        dw = torch.zeros_like(w)
+        for k in range(w.shape[0]):
+            c = int(indice_pair_num[k])
+            if c:
+                src, dst = indice_pairs[k, int(inverse), :c].long(), indice_pairs[k, 1 - int(inverse), :c].long()
+                dw[k] = features[src].t() @ out_bp[dst]
+                dx.index_add_(0, src, out_bp[dst] @ w[k].t())
+        return [dx, dw.reshape(filters.shape)]
+
+    pkg = _pkg('mmdet3d.ops.spconv')
+    pkg.IS_SPCONV2_AVAILABLE = False
+    sys.modules['mmdet3d.ops'].spconv = pkg
+    _mod('mmdet3d.ops.spconv.sparse_conv_ext', get_indice_pairs_3d=get_indice_pairs_3d,
+         indice_conv_fp32=indice_conv_fp32, indice_conv_backward_fp32=indice_conv_backward_fp32)
+    pkg.sparse_conv_ext = sys.modules['mmdet3d.ops.spconv.sparse_conv_ext']
+    out = types.SimpleNamespace()
+    for name in ('structure', 'modules', 'ops', 'functional', 'conv'):
+        m = _load('mmdet3d.ops.spconv.' + name, f'mmdet3d/ops/spconv/{name}.py')
+        setattr(pkg, name, m)
+        setattr(out, name, m)
+
+    class SparseConvTensor(out.structure.SparseConvTensor):
+        """+ replace_feature of spconv 2.x, which sparse_unet.py calls (the vendored 1.x class lacks it)"""
+
+        def replace_feature(self, new_features):
+            t = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self.grid)
+            t.indice_dict = self.indice_dict
+            return t
+
+    out.modules.SparseConvTensor = SparseConvTensor   # SparseSequential's isinstance checks
+    out.conv.SparseConvTensor = SparseConvTensor      # tensors created by the convolutions
+    _mod('mmcv.ops', SparseModule=out.modules.SparseModule, SparseSequential=out.modules.SparseSequential,
+         SparseConvTensor=SparseConvTensor)
+    sys.modules['mmcv.runner'].BaseModule = type('BaseModule', (nn.Module,), {
+        '__init__': lambda self, init_cfg=None: nn.Module.__init__(self)})
+
+    # mmdet 2.14.0 (docs/overall_instructions.md:38) resnet.BasicBlock, constructor restated; Bottleneck unused here
+    build_norm_layer = sys.modules['mmcv.cnn'].build_norm_layer
+    build_conv_layer = sys.modules['mmcv.cnn'].build_conv_layer
+
+    class BasicBlock(nn.Module):
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch', with_cp=False,
+                     conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None, init_cfg=None):
+            nn.Module.__init__(self)
+            self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+            self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+            self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 3, stride=stride, padding=dilation,
+                                          dilation=dilation, bias=False)
+            self.add_module(self.norm1_name, norm1)
+            self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, padding=1, bias=False)
+            self.add_module(self.norm2_name, norm2)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = downsample
+            self.stride = stride
+            self.dilation = dilation
+            self.with_cp = with_cp
+
+        @property
+        def norm1(self):
+            return getattr(self, self.norm1_name)
+
+        @property
+        def norm2(self):
+            return getattr(self, self.norm2_name)
+
+    _pkg('mmdet.models.backbones')
+    _mod('mmdet.models.backbones.resnet', BasicBlock=BasicBlock, Bottleneck=BasicBlock)
+    out.sparse_block = _load('mmdet3d.ops.sparse_block', 'mmdet3d/ops/sparse_block.py')
+    ops_pkg = sys.modules['mmdet3d.ops']
+    ops_pkg.SparseBasicBlock = out.sparse_block.SparseBasicBlock
+    ops_pkg.make_sparse_convmodule = out.sparse_block.make_sparse_convmodule
+    out.sparse_unet = _load('mmdet3d.models.middle_encoders.sparse_unet', 'mmdet3d/models/middle_encoders/sparse_unet.py')
+    out.SparseConvTensor = SparseConvTensor
+    out.base = ns
+    _SPCONV = out
+    return out
 
 
 def load_reference_function(relpath, name, extra_globals=None):

@@ -275,5 +275,9 @@ def build_conv_layer(cfg, *args, **kwargs):
     layer_type = cfg_.pop('type')
     convs = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d, 'Conv': nn.Conv2d}
     if layer_type not in convs:
+        from .spconv import CONV_LAYERS  # sparse layers register there as they do in mmcv.cnn.CONV_LAYERS
+        sparse = CONV_LAYERS.get(layer_type)
+        if sparse is not None:
+            return sparse(*args, **kwargs, **cfg_)
         raise KeyError(f'Unrecognized conv type {layer_type}')
     return convs[layer_type](*args, **kwargs, **cfg_)

@@ -62,6 +62,12 @@ class SparseConvTensor(object):
             return None
         return self.indice_dict.get(key)
 
+    def replace_feature(self, new_features):
+        """spconv 2.x API used by the reference's blocks (ops/sparse_block.py:13-18): same voxels, new features"""
+        out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self.grid)
+        out.indice_dict = self.indice_dict
+        return out
+
     def dense(self, channels_first=True):
         output_shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
         res = scatter_nd(self.indices.long(), self.features, output_shape)

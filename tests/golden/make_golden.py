@@ -393,6 +393,60 @@ def gen_spconv():
     save('spconv.npz', **arrays)
 
 
+SPARSE_UNET_CFG = dict(in_channels=8, sparse_shape=[16, 40, 40], order=('conv', 'norm', 'act'),
+                       norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=32,
+                       encoder_channels=((16, ), (16, 16, 16), (32, 32, 32), (32, 32, 32)),
+                       encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+                       decoder_channels=((32, 32, 32), (32, 32, 16), (16, 16, 16), (16, 16, 16)),
+                       decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)))
+
+
+def gen_sparse_unet():
+    """FSD's segmentor backbone (f4): the reference's own SimpleSparseUNet (middle_encoders/sparse_unet.py), its
+    sparse blocks (ops/sparse_block.py) and its vendored spconv Python package executed unmodified on CPU through
+    oracle/ref_loader.load_reference_spconv (rulebook = the reference's compiled CPU templates, convolution
+    arithmetic = the per-offset gather / mm / scatter-add in torch).  Training mode (batch statistics) and eval mode
+    (perturbed running statistics), outputs and gradients."""
+    R = ref_loader.load_reference_spconv()
+    torch.manual_seed(5)
+    net = R.sparse_unet.SimpleSparseUNet(**SPARSE_UNET_CFG)   # fp32: the reference's ops dispatch on float32 / half
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    rng = np.random.default_rng(31)
+    shape, batch, n_cells = SPARSE_UNET_CFG['sparse_shape'], 2, 500
+    hs = [shape[0] // 2, shape[1] // 2, shape[2] // 2]
+    vol = int(np.prod(hs))
+    lin = rng.choice(batch * vol, n_cells, replace=False)
+    b, r = lin // vol, lin % vol
+    base = np.stack([b, r // (hs[1] * hs[2]), (r // hs[2]) % hs[1], r % hs[2]], 1)
+    ind = np.unique(np.concatenate([base * [1, 2, 2, 2] + [0, dz, dy, dx] for dz in (0, 1) for dy in (0, 1)
+                                    for dx in (0, 1) if rng.random() < 0.7]), axis=0).astype(np.int32)
+    ind = ind[rng.permutation(len(ind))]
+    x = torch.randn(len(ind), SPARSE_UNET_CFG['in_channels'])
+    gy = torch.randn(len(ind), SPARSE_UNET_CFG['decoder_channels'][-1][-1])
+    arrays = {'in::indices': ind, 'in::features': t2n(x.float()), 'in::grad_out': t2n(gy.float())}
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    arrays.update(state_to_np({k: v.float() for k, v in state.items()}))
+    for mode in ('train', 'eval'):
+        net.load_state_dict(state)
+        net.train(mode == 'train')
+        net.zero_grad()
+        xa = x.clone().requires_grad_(True)
+        out = net({'voxel_feats': xa, 'voxel_coors': torch.from_numpy(ind)})[0]
+        assert torch.equal(out['voxel_coors'], torch.from_numpy(ind))
+        (out['voxel_feats'] * gy).sum().backward()
+        arrays[f'out::{mode}::voxel_feats'] = t2n(out['voxel_feats'].float())
+        arrays[f'out::{mode}::grad_features'] = t2n(xa.grad.float())
+        for name in ('conv_input.0.weight', 'encoder_layers.encoder_layer3.0.0.weight', 'lateral_layer2.conv2.weight',
+                     'upsample_layer3.0.weight', 'merge_layer1.1.weight'):
+            arrays[f'out::{mode}::grad::{name}'] = t2n(dict(net.named_parameters())[name].grad.float())
+    save('sparse_unet.npz', **arrays)
+
+
 def main():
     assert ref_loader.available(), 'the reference tree is required'
     build_ref.build()
@@ -409,6 +463,7 @@ def main():
     gen_point_pool()
     build_ref.build_spconv_rulebook()
     gen_spconv()
+    gen_sparse_unet()
 
 
 if __name__ == '__main__':
