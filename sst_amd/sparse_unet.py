@@ -265,3 +265,43 @@ class SimpleSparseUNet(SparseUNet):
         ret = {'voxel_feats': x.features, 'voxel_coors': x.indices, 'sparse_shape': x.spatial_shape,
                'batch_size': x.batch_size, 'decoder_features': decode_features}
         return [ret, ]
+
+
+@BACKBONES.register_module()
+class VirtualVoxelMixer(SparseUNet):
+    """FSDv2's backbone over real + virtual voxels (sparse_unet.py:417-504): the U-Net followed by a submanifold
+    output convolution; forward(voxel_features, coors, batch_size) -> (features, indices, spatial_shape)."""
+
+    def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128, ndim=3,
+                 encoder_channels=((16, ), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+                 decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
+                 decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)), keep_coors_dims=None, act_type='relu',
+                 init_cfg=None):
+        super().__init__(in_channels=in_channels, sparse_shape=sparse_shape, order=order, norm_cfg=norm_cfg,
+                         base_channels=base_channels, output_channels=output_channels,
+                         encoder_channels=encoder_channels, encoder_paddings=encoder_paddings,
+                         decoder_channels=decoder_channels, decoder_paddings=decoder_paddings, ndim=ndim,
+                         act_type=act_type, init_cfg=init_cfg)
+        self.ndim = ndim
+        self.keep_coors_dims = keep_coors_dims
+        self.conv_out = make_sparse_convmodule(decoder_channels[-1][-1], self.output_channels, kernel_size=3, stride=1,
+                                               norm_cfg=norm_cfg, padding=0, indice_key='out_conv',
+                                               conv_type=f'SubMConv{self.ndim}d', act_type=act_type)
+
+    def forward(self, voxel_features, coors, batch_size):
+        if self.keep_coors_dims is not None:
+            coors = coors[:, self.keep_coors_dims]
+        coors = coors.int()
+        x = self.conv_input(SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
+        encode_features = []
+        for encoder_layer in self.encoder_layers:
+            x = encoder_layer(x)
+            encode_features.append(x)
+        x = encode_features[-1]
+        for i in range(self.stage_num, 0, -1):
+            x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f'lateral_layer{i}'),
+                                           getattr(self, f'merge_layer{i}'), getattr(self, f'upsample_layer{i}'))
+        x = self.conv_out(x)
+        return x.features, x.indices, x.spatial_shape

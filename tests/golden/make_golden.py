@@ -401,6 +401,13 @@ SPARSE_UNET_CFG = dict(in_channels=8, sparse_shape=[16, 40, 40], order=('conv', 
                        decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)))
 
 
+VOXEL_MIXER_CFG = dict(in_channels=8, sparse_shape=[16, 40, 40], order=('conv', 'norm', 'act'),
+                       norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=24,
+                       encoder_channels=((16, ), (16, 16), (16, 16)), encoder_paddings=((1, ), (1, 1), (1, 1)),
+                       decoder_channels=((16, 16, 16), (16, 16, 16), (16, 16, 16)),
+                       decoder_paddings=((1, 1), (1, 1), (1, 1)))
+
+
 def gen_sparse_unet():
     """FSD's segmentor backbone (f4): the reference's own SimpleSparseUNet (middle_encoders/sparse_unet.py), its
     sparse blocks (ops/sparse_block.py) and its vendored spconv Python package executed unmodified on CPU through
@@ -445,6 +452,22 @@ def gen_sparse_unet():
                      'upsample_layer3.0.weight', 'merge_layer1.1.weight'):
             arrays[f'out::{mode}::grad::{name}'] = t2n(dict(net.named_parameters())[name].grad.float())
     save('sparse_unet.npz', **arrays)
+    # FSDv2's VirtualVoxelMixer (sparse_unet.py:417-504) in the shape of configs/fsdv2/fsdv2_waymo_1x.py:127-139, narrower
+    torch.manual_seed(6)
+    mix = R.sparse_unet.VirtualVoxelMixer(**VOXEL_MIXER_CFG)
+    mix.train()
+    xa = x.clone().requires_grad_(True)
+    feats, out_ind, out_shape = mix(xa, torch.from_numpy(ind), batch)
+    assert torch.equal(out_ind, torch.from_numpy(ind))
+    gy2 = torch.randn(feats.shape)
+    (feats * gy2).sum().backward()
+    arrays2 = {'in::indices': ind, 'in::features': t2n(x), 'in::grad_out': t2n(gy2), 'out::features': t2n(feats),
+               'out::grad_features': t2n(xa.grad),
+               'out::grad::conv_out.0.weight': t2n(mix.conv_out[0].weight.grad),
+               'out::grad::encoder_layers.encoder_layer2.0.0.weight':
+                   t2n(mix.encoder_layers.encoder_layer2[0][0].weight.grad)}
+    arrays2.update(state_to_np(mix.state_dict()))
+    save('voxel_mixer.npz', **arrays2)
 
 
 def main():

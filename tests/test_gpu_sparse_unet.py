@@ -87,3 +87,41 @@ def test_fsd_config_backbone_runs_at_scale():
     out['voxel_feats'].square().mean().backward()
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+MIXER_CFG = dict(in_channels=8, sparse_shape=[16, 40, 40], order=('conv', 'norm', 'act'),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=24,
+                 encoder_channels=((16, ), (16, 16), (16, 16)), encoder_paddings=((1, ), (1, 1), (1, 1)),
+                 decoder_channels=((16, 16, 16), (16, 16, 16), (16, 16, 16)),
+                 decoder_paddings=((1, 1), (1, 1), (1, 1)))
+
+
+def test_voxel_mixer_state_dict_matches_the_reference_module():
+    import sst_amd
+    g = load_golden('voxel_mixer.npz')
+    net = sst_amd.BACKBONES.build(dict(type='VirtualVoxelMixer', **MIXER_CFG))
+    mine, ref = net.state_dict(), _state(g)
+    assert set(mine) == set(ref) and all(tuple(mine[k].shape) == tuple(ref[k].shape) for k in ref)
+
+
+@pytest.mark.gpu
+def test_virtual_voxel_mixer_matches_reference_golden():
+    """FSDv2's backbone (sparse_unet.py:417-504), training mode, against the reference's own class run on CPU"""
+    import sst_amd
+    g = load_golden('voxel_mixer.npz')
+    net = sst_amd.VirtualVoxelMixer(**MIXER_CFG)
+    net.load_state_dict(_state(g), strict=True)
+    net = net.to(DEV).train()
+    x = torch.from_numpy(g['in::features']).to(DEV).requires_grad_(True)
+    ind = torch.from_numpy(g['in::indices']).to(DEV)
+    feats, out_ind, shape = net(x, ind, 2)
+    assert torch.equal(out_ind, ind) and list(shape) == MIXER_CFG['sparse_shape']
+    (feats * torch.from_numpy(g['in::grad_out']).to(DEV)).sum().backward()
+    params = dict(net.named_parameters())
+    for got, key in ((feats, 'out::features'), (x.grad, 'out::grad_features'),
+                     (params['conv_out.0.weight'].grad, 'out::grad::conv_out.0.weight'),
+                     (params['encoder_layers.encoder_layer2.0.0.weight'].grad,
+                      'out::grad::encoder_layers.encoder_layer2.0.0.weight')):
+        want = torch.from_numpy(g[key])
+        err = float((got.detach().cpu() - want).abs().max())
+        assert err < 1e-3 * max(1.0, float(want.abs().max())), (key, err)
