@@ -20,6 +20,8 @@
 // Output rows of a regular (strided / transposed) convolution are numbered by ascending (batch, z, y, x), the order
 // of the reference's GPU path (torch::_unique of the linear indices, spconv_ops.h:128); they come from the
 // sorted-unique of sort_scan.hip applied to the candidate positions produced here.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -255,6 +257,158 @@ __global__ __launch_bounds__(256) void sp_gather_gemm_k(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Second form of the same contraction, used when W is stored [cin, cout] and K <= 32: the MFMAs run over COMPACTED
+// rows and the gathers are prefetched.  A workgroup owns a segment of 128 output rows x 64 output columns whose sums
+// live in LDS (ytile).  First the rows of the segment that have a partner are listed per kernel offset (ballots).
+// Then the workgroup walks the stages (offset, 32 listed rows, 64 input channels) in a fixed order: while the
+// gathered rows of stage i (in LDS) are multiplied with W[k] by v_mfma_f32_16x16x4_f32 -- wave w owns output columns
+// 16 w .. 16 w + 15, fragments of W straight from global memory / L1 -- the rows of stage i + 1 are already on their
+// way into registers (double-buffered LDS, one barrier per stage).  Products are added to the rows' sums with
+// ds_add_f32: a wave is the only writer of its columns and the order is fixed, so the result is deterministic.
+// With LiDAR-like sparsity (4 of 27 offsets populated) this issues ~1/4 of the MFMA work of sp_gather_gemm_k,
+// which multiplies every row of a tile with every offset that has at least one partner in the tile.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kSegRows = 128, kSegCols = 64, kSegStage = 32, kSegChunk = 64, kSegMaxK = 32;
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void sp_conv_seg_k(const float* __restrict__ x, int64_t ldx,
+                                                     const int32_t* __restrict__ map, int64_t m, int kvol,
+                                                     const float* __restrict__ w, int cin, int cout,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     int64_t ldy) {
+  __shared__ float ytile[kSegRows][kSegCols];
+  __shared__ __attribute__((aligned(16))) float abuf[2][kSegStage][kSegChunk + 4];
+  __shared__ int lsrc[kSegMaxK][kSegRows];
+  __shared__ unsigned char lrow[kSegMaxK][kSegRows];
+  __shared__ int cnt_s[kSegMaxK];
+  __shared__ int wave_cnt[kSegMaxK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kSegRows;
+  const int col0 = blockIdx.y * kSegCols;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ncol = col0 + wave * 16 + l15;  // this lane's output column
+  const bool col_ok = ncol < cout;
+  for (int e = tid; e < kSegRows * kSegCols; e += 256) (&ytile[0][0])[e] = 0.f;
+  // ---- per-offset lists of the rows that have a partner (waves 0 / 1 hold rows 0..63 / 64..127) ----
+  int v[kSegMaxK];  // all offsets' partners of this thread's row: independent loads, issued together
+#pragma unroll
+  for (int k = 0; k < kSegMaxK; ++k)
+    v[k] = (wave < 2 && k < kvol && r0 + tid < m) ? map[(int64_t)k * m + r0 + tid] : -1;
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < kSegMaxK; ++k) {
+      const unsigned long long bal = __ballot(v[k] >= 0);
+      if (lane == 0) wave_cnt[k] = __popcll(bal);
+    }
+  }
+  __syncthreads();
+  if (wave < 2) {  // wave 1 appends behind wave 0
+#pragma unroll
+    for (int k = 0; k < kSegMaxK; ++k) {
+      if (k < kvol) {  // uniform
+        const unsigned long long bal = __ballot(v[k] >= 0);
+        const int base = wave == 1 ? wave_cnt[k] : 0;
+        if (wave == 1 && lane == 0) cnt_s[k] = base + __popcll(bal);
+        if (v[k] >= 0) {
+          const int p = base + __popcll(bal & ((1ull << lane) - 1ull));
+          lrow[k][p] = (unsigned char)tid;
+          lsrc[k][p] = v[k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- stages ----
+  const int n_chunk = (cin + kSegChunk - 1) / kSegChunk;
+  const int srow = tid >> 3, sseg = (tid & 7) * 8;  // staging: listed row vb + srow, 8 channels at c0 + sseg
+  float reg[8], bnext[kSegChunk / 4];
+  auto fetch = [&](int k, int vb, int c0) {
+    const float* wk = w + (int64_t)k * cin * cout;
+#pragma unroll
+    for (int s = 0; s < kSegChunk / 4; ++s) {  // this lane's W fragments of the stage: 16 independent loads
+      const int ch = c0 + 4 * s + kq;
+      bnext[s] = (col_ok && ch < cin) ? wk[(int64_t)ch * cout + ncol] : 0.f;
+    }
+    const int e = vb + srow;
+    const int src = e < cnt_s[k] ? lsrc[k][e] : -1;
+    const float* px = x + (int64_t)(src >= 0 ? src : 0) * ldx + c0 + sseg;
+    if (VEC) {
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (src >= 0 && c0 + sseg < cin) lo = *(const float4*)px;
+      if (src >= 0 && c0 + sseg + 4 < cin) hi = *(const float4*)(px + 4);
+      reg[0] = lo.x, reg[1] = lo.y, reg[2] = lo.z, reg[3] = lo.w;
+      reg[4] = hi.x, reg[5] = hi.y, reg[6] = hi.z, reg[7] = hi.w;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) reg[u] = (src >= 0 && c0 + sseg + u < cin) ? px[u] : 0.f;
+    }
+  };
+  // first stage
+  int k = 0;
+  while (k < kvol && cnt_s[k] == 0) ++k;
+  int vb = 0, ci = 0, buf = 0;
+  if (k < kvol) fetch(k, 0, 0);
+  f32x4 acc[2];
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  while (k < kvol) {
+    // next stage in (k, vb, chunk) order
+    int nk = k, nvb = vb, nci = ci + 1;
+    if (nci == n_chunk) {
+      nci = 0;
+      nvb += kSegStage;
+      if (nvb >= cnt_s[k]) {
+        nvb = 0;
+        ++nk;
+        while (nk < kvol && cnt_s[nk] == 0) ++nk;
+      }
+    }
+    float4* dst = (float4*)&abuf[buf][srow][sseg];
+    dst[0] = make_float4(reg[0], reg[1], reg[2], reg[3]);
+    dst[1] = make_float4(reg[4], reg[5], reg[6], reg[7]);
+    float bcur[kSegChunk / 4];
+#pragma unroll
+    for (int s = 0; s < kSegChunk / 4; ++s) bcur[s] = bnext[s];
+    if (nk < kvol) fetch(nk, nvb, nci * kSegChunk);  // in flight during the MFMAs below
+    __syncthreads();
+    const int cnt = cnt_s[k];
+    const int c0 = ci * kSegChunk;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      if (vb + rb * 16 >= cnt) continue;  // uniform
+#pragma unroll
+      for (int s = 0; s < kSegChunk / 4; ++s) {
+        if (c0 + 4 * s < cin) {  // uniform
+          const float a = abuf[buf][rb * 16 + l15][4 * s + kq];
+          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[s], acc[rb], 0, 0, 0);
+        }
+      }
+    }
+    if (ci == n_chunk - 1) {  // all channels of this row block done: D of 16x16: column = lane & 15, rows 4 * (lane >> 4) + r
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = vb + rb * 16 + 4 * kq + r;
+          if (e < cnt) atomicAdd(&ytile[lrow[k][e]][wave * 16 + l15], acc[rb][r]);
+        }
+        acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    k = nk;
+    vb = nvb;
+    ci = nci;
+    buf ^= 1;
+  }
+  __syncthreads();
+  for (int e = tid; e < kSegRows * kSegCols; e += 256) {
+    const int row = e / kSegCols, c = e - row * kSegCols;
+    if (r0 + row < m && col0 + c < cout) y[(r0 + row) * ldy + col0 + c] = ytile[row][c] + (bias ? bias[col0 + c] : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // dW[k] (cin x cout) = sum over the pairs p of offset k of  X[pa[p], :]^T  dY[pb[p], :].
 // The pairs of all offsets are cut into chunks of kSpChunk pairs (an offset with num[k] pairs owns
 // ceil(num[k] / kSpChunk) consecutive chunks; every workgroup finds its (offset, chunk) by walking num[], K <= 4096),
@@ -486,9 +640,25 @@ int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_m
   if (m == 0) return SST_OK;
   if (!d_x || !d_map || !d_w || !d_y) return SST_ERR_ARG;
   if (sst_div_up(m, kSpRows) > 0x7fffffff || sst_div_up(cout, kSpCols) > 65535) return SST_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sp_gather_gemm_k, dim3((unsigned)sst_div_up(m, kSpRows), (unsigned)sst_div_up(cout, kSpCols)),
-                     dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w, cin, cout, trans_w, d_bias, d_y,
-                     ldy);
+  static int form = -1;  // SST_SPCONV_FORM=1 forces the uncompacted kernel (sp_gather_gemm_k) for every call
+  if (form < 0) {
+    const char* e = getenv("SST_SPCONV_FORM");
+    form = e ? atoi(e) : 0;
+  }
+  if (!trans_w && form != 1 && kvol <= kSegMaxK) {
+    const dim3 grid((unsigned)sst_div_up(m, kSegRows), (unsigned)sst_div_up(cout, kSegCols));
+    const bool vec = (ldx % 4 == 0) && (cin % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
+    if (vec)
+      hipLaunchKernelGGL(sp_conv_seg_k<true>, grid, dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w,
+                         cin, cout, d_bias, d_y, ldy);
+    else
+      hipLaunchKernelGGL(sp_conv_seg_k<false>, grid, dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w,
+                         cin, cout, d_bias, d_y, ldy);
+  } else {
+    hipLaunchKernelGGL(sp_gather_gemm_k, dim3((unsigned)sst_div_up(m, kSpRows), (unsigned)sst_div_up(cout, kSpCols)),
+                       dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w, cin, cout, trans_w, d_bias,
+                       d_y, ldy);
+  }
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

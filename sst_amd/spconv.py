@@ -248,11 +248,14 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     rb = rulebook_of(indice_pairs, indice_pair_num, features.size(0) if inverse else out_bp.size(0))
     w3 = filters.reshape(-1, filters.shape[-2], filters.shape[-1])
     out_bp = out_bp.contiguous()
+    # the data gradient is the same contraction with W[k]^T: transposed once (K x Cin x Cout floats) so that it runs
+    # through the compacted-row kernel, which reads W as [cin_of_the_op, cout_of_the_op]
+    w3t = w3.transpose(1, 2).contiguous()
     if inverse:
-        input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3, True, w3.size(1))
+        input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3t, False, w3.size(1))
         filters_bp = _wgrad(features, out_bp, rb, 1, filters.shape)
     else:
-        input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3, True, w3.size(1))
+        input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3t, False, w3.size(1))
         filters_bp = _wgrad(features, out_bp, rb, 0, filters.shape)
     return input_bp, filters_bp
 

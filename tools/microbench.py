@@ -298,6 +298,40 @@ def bench_spconv():
               f'per-offset gather/mm/index_add forward in torch {med_r * 1e3:.0f} us')
 
 
+def bench_unet():
+    """FSD's SimpleSparseUNet (configs/fsd/fsd_waymoD1_1x.py:39-51) forward + backward on a synthetic 2-sample
+    batch of ~120 k voxels."""
+    import numpy as np
+    net = sst_amd.BACKBONES.build(dict(
+        type='SimpleSparseUNet', in_channels=64, sparse_shape=[32, 640, 640], order=('conv', 'norm', 'act'),
+        norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01), base_channels=64, output_channels=128,
+        encoder_channels=((64, ), (64, 64, 64), (64, 64, 64), (128, 128, 128), (256, 256, 256)),
+        encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1), (1, 1, 1)),
+        decoder_channels=((256, 256, 128), (128, 128, 64), (64, 64, 64), (64, 64, 64), (64, 64, 64)),
+        decoder_paddings=((1, 1), (1, 0), (1, 0), (0, 0), (0, 1)))).to(DEV)
+    rng = np.random.default_rng(2)
+    hs = [16, 320, 320]
+    vol = int(np.prod(hs))
+    lin = rng.choice(2 * vol, 30000, replace=False)
+    b, r = lin // vol, lin % vol
+    base = np.stack([b, r // (hs[1] * hs[2]), (r // hs[2]) % hs[1], r % hs[2]], 1)
+    ind = np.unique(np.concatenate([base * [1, 2, 2, 2] + [0, 0, dy, dx] for dy in (0, 1) for dx in (0, 1)]), axis=0)
+    ind = torch.from_numpy(ind.astype(np.int32)).to(DEV)
+    x = torch.randn(ind.size(0), 64, device=DEV, requires_grad=True)
+
+    def fwd_bwd():
+        x.grad = None
+        for p in net.parameters():
+            p.grad = None
+        out = net({'voxel_feats': x, 'voxel_coors': ind})[0]
+        out['voxel_feats'].sum().backward()
+
+    med, _ = timeit(fwd_bwd, iters=10, warmup=3)
+    with torch.no_grad():
+        med_f, _ = timeit(lambda: net({'voxel_feats': x, 'voxel_coors': ind}), iters=10, warmup=3)
+    print(f'SimpleSparseUNet (FSD config) on {ind.size(0)} voxels: forward {med_f:.2f} ms, forward + backward {med:.2f} ms')
+
+
 def bench_pointpool():
     """dynamic point pool at FSD second-stage sizes: whole op (3 passes + scans + the count read-back) and the pair
     tests per second it amounts to (the reference's kernel is the same R x P brute force, one thread per pair)."""
@@ -331,6 +365,8 @@ if __name__ == '__main__':
         bench_cluster()
     if what in ('voxelize',):
         bench_voxelize()
+    if what in ('unet',):
+        bench_unet()
     if what in ('spconv',):
         bench_spconv()
     if what in ('pointpool',):
