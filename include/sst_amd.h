@@ -370,7 +370,9 @@ int sst_dynamic_point_pool_f32(const float* d_rois, const int32_t* d_rois_batch,
  *   sst_spconv_invert_map_i32: out2in from in2out.   sst_spconv_pair_lists_i32: pair lists from in2out.
  *   sst_spconv_gather_gemm_f32: Y[r, :] = sum_k X[map[k][r], :] W[k] (+ bias), r < m; W[k] is [cin, cout] row-major, or
  *     [cout, cin] with trans_w (data gradient on the forward weights).  Forward: map = out2in; data gradient and
- *     inverse convolution: map = in2out.  Every row of Y is written.
+ *     inverse convolution: map = in2out.  Every row of Y is written.  form: 0 = automatic, 1 = every row of a 64 x 128
+ *     tile times every offset present in the tile, 2 = MFMAs over the compacted rows that have a partner (K <= 32,
+ *     W not transposed; best when few of the K offsets are populated).
  *   sst_spconv_wgrad_f32: dW[k] = sum over the pairs p < num[k] of X[pairs[k][x_side][p]]^T dY[pairs[k][1 - x_side][p]];
  *     pair_ld = row length of the pair lists (n).  Workspace: sst_spconv_wgrad_workspace_bytes.
  * ---------------------------------------------------------------------------------------------- */
@@ -388,7 +390,7 @@ int sst_spconv_pair_lists_i32(const int32_t* d_in2out, int kvol, int64_t n, int3
                               void* d_workspace, void* stream);
 int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol,
                                const float* d_w, int cin, int cout, int trans_w, const float* d_bias, float* d_y,
-                               int64_t ldy, void* stream);
+                               int64_t ldy, int form, void* stream);
 int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int cin, int cout);
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                          int64_t pair_ld, int x_side, const int32_t* d_num, int kvol, int cin, int cout, float* d_dw,

@@ -412,13 +412,13 @@ __global__ __launch_bounds__(256) void sp_conv_seg_k(const float* __restrict__ x
 // dW[k] (cin x cout) = sum over the pairs p of offset k of  X[pa[p], :]^T  dY[pb[p], :].
 // The pairs of all offsets are cut into chunks of kSpChunk pairs (an offset with num[k] pairs owns
 // ceil(num[k] / kSpChunk) consecutive chunks; every workgroup finds its (offset, chunk) by walking num[], K <= 4096),
-// so the load is balanced whatever the spread of the pair counts (the centre offset of a submanifold convolution
+// so the load is balanced whatever the spread of the pair counts and there are enough workgroups to overlap their gather latencies (the centre offset of a submanifold convolution
 // holds every voxel).  grid = (chunks upper bound, strips / 4): a wave owns a strip = 32 input channels x up to 128
 // output columns (4 MFMA tiles); two pairs per v_mfma_f32_32x32x2_f32 step, four steps in flight (indices, then
 // fragments, then MFMAs); fragments straight from global memory (a half-wave reads 128 contiguous bytes of one row).
 // Partials [chunk][cin][cout] are summed per offset, in chunk order, by sp_wgrad_reduce_k.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kSpChunk = 2048;
+constexpr int kSpChunk = 512;  // small chunks: many workgroups in flight hide the gather latency of each one
 
 __device__ __forceinline__ bool sp_find_chunk(const int32_t* __restrict__ num, int kvol, int chunk, int& k, int& first) {
   int c0 = 0;
@@ -635,16 +635,20 @@ int sst_spconv_pair_lists_i32(const int32_t* d_in2out, int kvol, int64_t n, int3
 
 int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol,
                                const float* d_w, int cin, int cout, int trans_w, const float* d_bias, float* d_y,
-                               int64_t ldy, void* stream) {
+                               int64_t ldy, int form, void* stream) {
   if (m < 0 || kvol < 1 || cin < 1 || cout < 1 || ldx < cin || ldy < cout) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_x || !d_map || !d_w || !d_y) return SST_ERR_ARG;
   if (sst_div_up(m, kSpRows) > 0x7fffffff || sst_div_up(cout, kSpCols) > 65535) return SST_ERR_UNSUPPORTED;
-  static int form = -1;  // SST_SPCONV_FORM=1 forces the uncompacted kernel (sp_gather_gemm_k) for every call
-  if (form < 0) {
+  // form: 0 = automatic (compacted rows for narrow outputs, where one 64-column group covers the layer), 1 =
+  // uncompacted 64 x 128 tiles, 2 = compacted rows whenever the kernel applies.  SST_SPCONV_FORM overrides the argument.
+  static int env_form = -1;
+  if (env_form < 0) {
     const char* e = getenv("SST_SPCONV_FORM");
-    form = e ? atoi(e) : 0;
+    env_form = e ? atoi(e) : 0;
   }
+  if (env_form != 0) form = env_form;
+  if (form == 0) form = cout <= kSegCols ? 2 : 1;
   if (!trans_w && form != 1 && kvol <= kSegMaxK) {
     const dim3 grid((unsigned)sst_div_up(m, kSegRows), (unsigned)sst_div_up(cout, kSegCols));
     const bool vec = (ldx % 4 == 0) && (cin % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
