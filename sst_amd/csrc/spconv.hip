@@ -256,6 +256,121 @@ __global__ __launch_bounds__(256) void sp_gather_gemm_k(const float* __restrict_
   }
 }
 
+// The same 64 x 128 tile with the gathers prefetched (K <= 32): the partner rows of all offsets are read up front,
+// offsets without any partner in the tile drop out of the stage list, and while stage i (offset, 32-channel chunk) is
+// multiplied out of one LDS buffer the A rows and the W slab of stage i + 1 are already on their way into registers
+// (double-buffered LDS, one barrier per stage).
+__global__ __launch_bounds__(256) void sp_gather_gemm_pf_k(const float* __restrict__ x, int64_t ldx,
+                                                           const int32_t* __restrict__ map, int64_t m, int kvol,
+                                                           const float* __restrict__ w, int cin, int cout, int trans_w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int64_t ldy) {
+  __shared__ float As[2][kSpRows][33];
+  __shared__ float Bs[2][32][kSpCols + 4];
+  __shared__ int idx[32][kSpRows];
+  __shared__ unsigned live_s[3];  // offsets with a partner in: the tile, rows 0..31, rows 32..63
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kSpRows;
+  const int col0 = blockIdx.y * kSpCols;
+  const int rhalf = wave & 1, chalf = wave >> 1;
+  const int l31 = lane & 31, kk = lane >> 5;
+  if (wave == 0) {
+    int v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = (k < kvol && r0 + lane < m) ? map[(int64_t)k * m + r0 + lane] : -1;
+    unsigned any = 0, lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      idx[k][lane] = v[k];
+      const unsigned long long bal = __ballot(v[k] >= 0);
+      any |= (bal != 0 ? 1u : 0u) << k;
+      lo |= ((bal & 0xffffffffull) != 0 ? 1u : 0u) << k;
+      hi |= ((bal >> 32) != 0 ? 1u : 0u) << k;
+    }
+    if (lane == 0) {
+      live_s[0] = any;
+      live_s[1] = lo;
+      live_s[2] = hi;
+    }
+  }
+  __syncthreads();
+  const unsigned live = live_s[0], half_live = live_s[1 + rhalf];
+  const bool wave_cols = col0 + chalf * 64 < cout;
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  const int n_chunk = (cin + 31) / 32;
+  const int arow = tid >> 2, aseg = (tid & 3) * 8;  // A staging: row, 8 channels
+  float ra[8], rbv[16];
+  auto fetch = [&](int k, int c0) {
+    const int src = idx[k][arow];
+    const float* px = x + (int64_t)(src >= 0 ? src : 0) * ldx + c0 + aseg;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ra[u] = (src >= 0 && c0 + aseg + u < cin) ? px[u] : 0.f;
+    const float* wk = w + (int64_t)k * cin * cout;
+    if (!trans_w) {  // B[c][n] = W[k][c0 + c][col0 + n]: thread -> channel tid >> 3, 16 columns at (tid & 7) * 16
+      const int c = c0 + (tid >> 3), seg = col0 + (tid & 7) * 16;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) rbv[u] = (c < cin && seg + u < cout) ? wk[(int64_t)c * cout + seg + u] : 0.f;
+    } else {  // W[k] stored [cout][cin]: thread -> column tid >> 1, 16 channels at (tid & 1) * 16
+      const int n = col0 + (tid >> 1), seg = c0 + (tid & 1) * 16;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) rbv[u] = (seg + u < cin && n < cout) ? wk[(int64_t)n * cin + seg + u] : 0.f;
+    }
+  };
+  auto next_live = [&](int k) {  // first populated offset >= k (32 if none)
+    const unsigned rest = k < 32 ? (live >> k) : 0u;
+    return rest ? k + __builtin_ctz(rest) : 32;
+  };
+  int k = next_live(0), ci = 0, buf = 0;
+  if (k < 32) fetch(k, 0);
+  while (k < 32) {
+    int nk = k, nci = ci + 1;
+    if (nci == n_chunk) {
+      nci = 0;
+      nk = next_live(k + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) As[buf][arow][aseg + u] = ra[u];
+    if (!trans_w) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) Bs[buf][tid >> 3][(tid & 7) * 16 + u] = rbv[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) Bs[buf][(tid & 1) * 16 + u][tid >> 1] = rbv[u];
+    }
+    if (nk < 32) fetch(nk, nci * 32);  // in flight during the MFMAs below
+    __syncthreads();
+    if (((half_live >> k) & 1) && wave_cols) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = As[buf][rhalf * 32 + l31][2 * s + kk];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float b = Bs[buf][2 * s + kk][chalf * 64 + q * 32 + l31];
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    k = nk;
+    ci = nci;
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int n = col0 + chalf * 64 + q * 32 + l31;
+    if (n >= cout) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = r0 + rhalf * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (row < m) y[row * ldy + n] = acc[q][r] + bv;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Second form of the same contraction, used when W is stored [cin, cout] and K <= 32: the MFMAs run over COMPACTED
 // rows and the gathers are prefetched.  A workgroup owns a segment of 128 output rows x 64 output columns whose sums
@@ -374,15 +489,15 @@ __global__ __launch_bounds__(256) void sp_conv_seg_k(const float* __restrict__ x
     __syncthreads();
     const int cnt = cnt_s[k];
     const int c0 = ci * kSegChunk;
+    // the two row blocks are independent accumulation chains: interleaved, so that a dependent MFMA never waits for
+    // its predecessor (a second block without listed rows multiplies zeros: cheaper than a branch per step)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      if (vb + rb * 16 >= cnt) continue;  // uniform
-#pragma unroll
-      for (int s = 0; s < kSegChunk / 4; ++s) {
-        if (c0 + 4 * s < cin) {  // uniform
-          const float a = abuf[buf][rb * 16 + l15][4 * s + kq];
-          acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[s], acc[rb], 0, 0, 0);
-        }
+    for (int s = 0; s < kSegChunk / 4; ++s) {
+      if (c0 + 4 * s < cin) {  // uniform
+        const float a0 = abuf[buf][l15][4 * s + kq];
+        const float a1 = abuf[buf][16 + l15][4 * s + kq];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bcur[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bcur[s], acc[1], 0, 0, 0);
       }
     }
     if (ci == n_chunk - 1) {  // all channels of this row block done: D of 16x16: column = lane & 15, rows 4 * (lane >> 4) + r
@@ -649,7 +764,7 @@ int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_m
   }
   if (env_form != 0) form = env_form;
   if (form == 0) form = cout <= kSegCols ? 2 : 1;
-  if (!trans_w && form != 1 && kvol <= kSegMaxK) {
+  if (!trans_w && form == 2 && kvol <= kSegMaxK) {
     const dim3 grid((unsigned)sst_div_up(m, kSegRows), (unsigned)sst_div_up(cout, kSegCols));
     const bool vec = (ldx % 4 == 0) && (cin % 4 == 0) && (((uintptr_t)d_x & 15) == 0);
     if (vec)
@@ -659,9 +774,13 @@ int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_m
       hipLaunchKernelGGL(sp_conv_seg_k<false>, grid, dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w,
                          cin, cout, d_bias, d_y, ldy);
   } else {
-    hipLaunchKernelGGL(sp_gather_gemm_k, dim3((unsigned)sst_div_up(m, kSpRows), (unsigned)sst_div_up(cout, kSpCols)),
-                       dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w, cin, cout, trans_w, d_bias,
-                       d_y, ldy);
+    const dim3 grid((unsigned)sst_div_up(m, kSpRows), (unsigned)sst_div_up(cout, kSpCols));
+    if (kvol <= 32 && form != 3)
+      hipLaunchKernelGGL(sp_gather_gemm_pf_k, grid, dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w, cin,
+                         cout, trans_w, d_bias, d_y, ldy);
+    else  // form 3: the version without prefetch (kept for comparison; the only one for K > 32)
+      hipLaunchKernelGGL(sp_gather_gemm_k, grid, dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_map, m, kvol, d_w, cin,
+                         cout, trans_w, d_bias, d_y, ldy);
   }
   SST_LAUNCH_CHECK();
   return SST_OK;
