@@ -377,15 +377,26 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        from .norm import batch_norm_act
+        mods = list(self._modules.items())
+        i = 0
+        while i < len(mods):
+            k, module = mods[i]
+            i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity
                 input = module(input)
             else:
+                # BatchNorm1d directly followed by ReLU on the features: one fused kernel pair (csrc/bn.hip) instead
+                # of norm + a separate ReLU pass -- the `conv -> norm -> act` order of make_sparse_convmodule
+                fuse = (isinstance(module, nn.BatchNorm1d) and i < len(mods) and type(mods[i][1]) is nn.ReLU)
                 if isinstance(input, SparseConvTensor):
                     if input.indices.shape[0] != 0:
-                        input.features = module(input.features)
+                        input.features = batch_norm_act(module, input.features, relu=True) if fuse \
+                            else module(input.features)
+                        if fuse:
+                            i += 1
                 else:
                     input = module(input)
         return input
