@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void sp_gather_gemm_pf_k(const float* __restri
 // which multiplies every row of a tile with every offset that has at least one partner in the tile.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kSegRows = 128, kSegCols = 64, kSegStage = 32, kSegChunk = 64, kSegMaxK = 32;
+constexpr int kSegRows = 64, kSegCols = 64, kSegStage = 32, kSegChunk = 64, kSegMaxK = 32;
+static_assert(kSegRows == 64 || kSegRows == 128, "row listing below handles one or two row waves");
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void sp_conv_seg_k(const float* __restrict__ x, int64_t ldx,
@@ -407,24 +408,27 @@ __global__ __launch_bounds__(256) void sp_conv_seg_k(const float* __restrict__ x
   for (int e = tid; e < kSegRows * kSegCols; e += 256) (&ytile[0][0])[e] = 0.f;
   // ---- per-offset lists of the rows that have a partner (waves 0 / 1 hold rows 0..63 / 64..127) ----
   int v[kSegMaxK];  // all offsets' partners of this thread's row: independent loads, issued together
+  constexpr int kRowWaves = kSegRows / 64;  // waves that hold rows (wave w: rows 64 w .. 64 w + 63)
 #pragma unroll
   for (int k = 0; k < kSegMaxK; ++k)
-    v[k] = (wave < 2 && k < kvol && r0 + tid < m) ? map[(int64_t)k * m + r0 + tid] : -1;
-  if (wave == 0) {
+    v[k] = (wave < kRowWaves && k < kvol && r0 + tid < m) ? map[(int64_t)k * m + r0 + tid] : -1;
+  if (kRowWaves > 1) {
+    if (wave == 0) {
 #pragma unroll
-    for (int k = 0; k < kSegMaxK; ++k) {
-      const unsigned long long bal = __ballot(v[k] >= 0);
-      if (lane == 0) wave_cnt[k] = __popcll(bal);
+      for (int k = 0; k < kSegMaxK; ++k) {
+        const unsigned long long bal = __ballot(v[k] >= 0);
+        if (lane == 0) wave_cnt[k] = __popcll(bal);
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave < 2) {  // wave 1 appends behind wave 0
+  if (wave < kRowWaves) {  // wave 1 appends behind wave 0
 #pragma unroll
     for (int k = 0; k < kSegMaxK; ++k) {
       if (k < kvol) {  // uniform
         const unsigned long long bal = __ballot(v[k] >= 0);
         const int base = wave == 1 ? wave_cnt[k] : 0;
-        if (wave == 1 && lane == 0) cnt_s[k] = base + __popcll(bal);
+        if (wave == kRowWaves - 1 && lane == 0) cnt_s[k] = base + __popcll(bal);
         if (v[k] >= 0) {
           const int p = base + __popcll(bal & ((1ull << lane) - 1ull));
           lrow[k][p] = (unsigned char)tid;
