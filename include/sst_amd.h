@@ -374,7 +374,8 @@ int sst_dynamic_point_pool_f32(const float* d_rois, const int32_t* d_rois_batch,
  *     tile times every offset present in the tile, 2 = MFMAs over the compacted rows that have a partner (K <= 32,
  *     W not transposed; best when few of the K offsets are populated).
  *   sst_spconv_wgrad_f32: dW[k] = sum over the pairs p < num[k] of X[pairs[k][x_side][p]]^T dY[pairs[k][1 - x_side][p]];
- *     pair_ld = row length of the pair lists (n).  Workspace: sst_spconv_wgrad_workspace_bytes.
+ *     pair_ld = row length of the pair lists (n); total_pairs = sum of d_num if the caller knows it on the host (it bounds
+ *     the launch and the workspace), -1 otherwise.  Workspace: sst_spconv_wgrad_workspace_bytes (same arguments).
  * ---------------------------------------------------------------------------------------------- */
 int sst_spconv_candidates_i32(const int32_t* d_coors, int64_t n, const int32_t* in_shape, const int32_t* out_shape,
                               const int32_t* ksize, const int32_t* stride, const int32_t* padding,
@@ -391,10 +392,10 @@ int sst_spconv_pair_lists_i32(const int32_t* d_in2out, int kvol, int64_t n, int3
 int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol,
                                const float* d_w, int cin, int cout, int trans_w, const float* d_bias, float* d_y,
                                int64_t ldy, int form, void* stream);
-int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int cin, int cout);
+int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout);
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
-                         int64_t pair_ld, int x_side, const int32_t* d_num, int kvol, int cin, int cout, float* d_dw,
-                         void* d_workspace, void* stream);
+                         int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
+                         int cout, float* d_dw, void* d_workspace, void* stream);
 
 #ifdef __cplusplus
 }

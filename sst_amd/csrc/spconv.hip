@@ -634,8 +634,11 @@ __global__ __launch_bounds__(256) void sp_wgrad_reduce_k(const float* __restrict
   dw[(int64_t)k * per_k + e] = s;
 }
 
-int64_t sp_wgrad_chunks(int kvol, int64_t pair_ld) {  // upper bound on the number of chunks
-  return ((int64_t)kvol * pair_ld) / kSpChunk + kvol;
+// upper bound on the number of chunks: sum_k ceil(num[k] / chunk) <= total / chunk + K; without a known total every
+// slot of the pair lists counts
+int64_t sp_wgrad_chunks(int kvol, int64_t pair_ld, int64_t total_pairs) {
+  const int64_t total = (total_pairs >= 0 && total_pairs <= (int64_t)kvol * pair_ld) ? total_pairs : (int64_t)kvol * pair_ld;
+  return total / kSpChunk + kvol;
 }
 
 bool sp_geom(const int32_t* in_shape, const int32_t* out_shape, const int32_t* ks, const int32_t* st,
@@ -790,13 +793,14 @@ int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_m
   return SST_OK;
 }
 
-int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int cin, int cout) {
-  return sp_wgrad_chunks(kvol > 0 ? kvol : 1, pair_ld > 0 ? pair_ld : 1) * cin * cout * (int64_t)sizeof(float) + 256;
+int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout) {
+  return sp_wgrad_chunks(kvol > 0 ? kvol : 1, pair_ld > 0 ? pair_ld : 1, total_pairs) * cin * cout *
+             (int64_t)sizeof(float) + 256;
 }
 
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
-                         int64_t pair_ld, int x_side, const int32_t* d_num, int kvol, int cin, int cout, float* d_dw,
-                         void* d_workspace, void* stream) {
+                         int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
+                         int cout, float* d_dw, void* d_workspace, void* stream) {
   if (kvol < 1 || cin < 1 || cout < 1 || ldx < cin || lddy < cout || pair_ld < 0 || (x_side != 0 && x_side != 1))
     return SST_ERR_ARG;
   if (!d_pairs || !d_num || !d_dw || !d_workspace) return SST_ERR_ARG;
@@ -806,7 +810,7 @@ int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64
     SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * kvol * per_k, st));
     return SST_OK;
   }
-  const int64_t chunks = sp_wgrad_chunks(kvol, pair_ld);
+  const int64_t chunks = sp_wgrad_chunks(kvol, pair_ld, total_pairs);
   const int strips = (int)(sst_div_up(cin, 32) * sst_div_up(cout, 128));
   if (kvol > 65535 || chunks > 0x7fffffff || sst_div_up(strips, 4) > 65535) return SST_ERR_UNSUPPORTED;
   float* part = (float*)d_workspace;

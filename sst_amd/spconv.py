@@ -109,7 +109,7 @@ def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, o
 
 class Rulebook(object):
     """in2out [K, n], out2in [K, m] int32 maps (-1 = no partner) + the reference's pair lists."""
-    __slots__ = ('in2out', 'out2in', 'pairs', 'num', 'n', 'm', 'kvol', 'density')
+    __slots__ = ('in2out', 'out2in', 'pairs', 'num', 'n', 'm', 'kvol', 'density', 'total_pairs')
 
 
 def _i32(vals):
@@ -130,7 +130,8 @@ def _finish_rulebook(in2out, kvol, n, m, dev):
                                              _lib.ptr(ws), _lib.stream_ptr()), 'sst_spconv_pair_lists_i32')
     rb.pairs._sst_rulebook = rb  # rides along wherever the reference passes indice_pairs around
     # populated share of the (offset, row) slots, read once per rulebook: picks the kernel form of every convolution on it
-    rb.density = float(rb.num.sum().item()) / max(1, kvol * max(n, m)) if n > 0 else 0.0
+    rb.total_pairs = int(rb.num.sum().item()) if n > 0 else 0
+    rb.density = rb.total_pairs / max(1, kvol * max(n, m))
     return rb
 
 
@@ -220,11 +221,11 @@ def _wgrad(x, dy, rb, x_side, shape):
     lib = _lib.load()
     kvol, cin, cout = rb.kvol, x.size(1), dy.size(1)
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
-    ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, rb.n, cin, cout), x.device)
+    ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, rb.n, rb.total_pairs, cin, cout), x.device)
     x = x if x.stride(1) == 1 else x.contiguous()
     dy = dy if dy.stride(1) == 1 else dy.contiguous()
     rc = lib.sst_spconv_wgrad_f32(_lib.ptr(x), x.stride(0) if x.size(0) else cin, _lib.ptr(dy),
-                                  dy.stride(0) if dy.size(0) else cout, _lib.ptr(rb.pairs), rb.n, x_side,
+                                  dy.stride(0) if dy.size(0) else cout, _lib.ptr(rb.pairs), rb.n, rb.total_pairs, x_side,
                                   _lib.ptr(rb.num), kvol, cin, cout, _lib.ptr(dw), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, 'sst_spconv_wgrad_f32')
     return dw.view(shape)
