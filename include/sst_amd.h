@@ -125,6 +125,19 @@ int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const 
                                const int32_t* d_argmax, int64_t n, int mode, float* d_grad_feats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (f1) Decorate step of DynamicVFE / DynamicScatterVFE (voxel_encoders/voxel_encoder.py:252-271, :569-589) in one
+ * launch: d_out[i] = [ point features (c) | xyz - mean xyz of the point's voxel, divided by cluster_div (3, if
+ * with_cluster) | xyz - centre of the point's voxel (3, if with_center) ], bit-identical to the composed torch ops.
+ *   d_inverse [n] int32 voxel of every point (< 0 reads voxel 0, like the reference's zero-initialised canvas);
+ *   d_voxel_mean [m, >= 3] (row stride ldm); d_coors [n, 4] (b, z, y, x) int32 or int64 (row stride ldc);
+ *   voxel_size / offsets: HOST float[3] (vx, vy, vz) and (v / 2 + range_min) per axis.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_vfe_decorate_f32(const float* d_points, int64_t ldp, int64_t n, int c, const int32_t* d_inverse,
+                         const float* d_voxel_mean, int64_t ldm, float cluster_div, const void* d_coors,
+                         int coor_is_i64, int64_t ldc, const float* voxel_size, const float* offsets,
+                         int with_cluster, int with_center, float* d_out, int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (a7) in-group rank.  Replaces TorchEx ingroup_indices.forward(group_inds, out_inds)
  * (call site ops/sst/sst_ops.py:244-264).  d_rank[i] = number of j < i with group[j] == group[i]
  * (the stable choice; the reference leaves the order unspecified).  group ids must lie in [0, 2^key_bits).

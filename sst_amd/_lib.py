@@ -78,6 +78,8 @@ _SIGNATURES = {
     'sst_spconv_wgrad_workspace_bytes': (c_i64, [c_i32, c_i64, c_i64, c_i32, c_i32]),
     'sst_spconv_wgrad_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32,
                                      c_ptr, c_ptr, c_ptr]),
+    'sst_vfe_decorate_f32': (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_i64, ctypes.c_float, c_ptr, c_i32, c_i64,
+                                     c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_event_create': (c_ptr, []),
     'sst_event_destroy': (None, [c_ptr]),
     'sst_event_elapsed_ms': (ctypes.c_float, [c_ptr, c_ptr]),

@@ -161,9 +161,76 @@ __global__ __launch_bounds__(256) void scatter_rows_k(const float* __restrict__ 
   }
 }
 
+// (f1) decorate step of DynamicVFE / DynamicScatterVFE (voxel_encoders/voxel_encoder.py:252-271, 569-589) in one pass:
+// out[i] = [ point features (c) | xyz - mean of its voxel, optionally / cluster_scale (3) | xyz - centre of its voxel (3) ]
+// replacing ~15 element-wise launches, a gather and the `cat`.  Same fp32 operations in the same order
+// (coordinate * voxel + offset with separate roundings), so the result is bit-identical to the composed ops.
+template <typename CT>
+__global__ __launch_bounds__(256) void vfe_decorate_k(const float* __restrict__ pts, int64_t ldp, int64_t n, int c,
+                                                      const int32_t* __restrict__ inv, const float* __restrict__ mean,
+                                                      int64_t ldm, float cluster_div, const CT* __restrict__ coors,
+                                                      int64_t ldc, float vx, float vy, float vz, float ox, float oy,
+                                                      float oz, int with_cluster, int with_center,
+                                                      float* __restrict__ out, int64_t ldo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* p = pts + i * ldp;
+    float* o = out + i * ldo;
+    for (int k = 0; k < c; ++k) o[k] = p[k];
+    int col = c;
+    const float x = p[0], y = p[1], z = p[2];
+    if (with_cluster) {
+      int g = inv[i];
+      if (g < 0) g = 0;  // a point without a voxel reads voxel 0 (the reference's zero-initialised canvas)
+      const float* mu = mean + (int64_t)g * ldm;
+      float fx = __fsub_rn(x, mu[0]), fy = __fsub_rn(y, mu[1]), fz = __fsub_rn(z, mu[2]);
+      if (cluster_div != 1.f) {
+        fx = __fdiv_rn(fx, cluster_div);
+        fy = __fdiv_rn(fy, cluster_div);
+        fz = __fdiv_rn(fz, cluster_div);
+      }
+      o[col] = fx;
+      o[col + 1] = fy;
+      o[col + 2] = fz;
+      col += 3;
+    }
+    if (with_center) {
+      const CT* cc = coors + i * ldc;  // (b, z, y, x)
+      o[col] = __fsub_rn(x, __fadd_rn(__fmul_rn((float)cc[3], vx), ox));
+      o[col + 1] = __fsub_rn(y, __fadd_rn(__fmul_rn((float)cc[2], vy), oy));
+      o[col + 2] = __fsub_rn(z, __fadd_rn(__fmul_rn((float)cc[1], vz), oz));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int sst_vfe_decorate_f32(const float* d_points, int64_t ldp, int64_t n, int c, const int32_t* d_inverse,
+                         const float* d_voxel_mean, int64_t ldm, float cluster_div, const void* d_coors,
+                         int coor_is_i64, int64_t ldc, const float* voxel_size, const float* offsets,
+                         int with_cluster, int with_center, float* d_out, int64_t ldo, void* stream) {
+  if (n < 0 || c < 3 || ldp < c || ldo < c + 3 * (with_cluster != 0) + 3 * (with_center != 0)) return SST_ERR_ARG;
+  if (n == 0) return SST_OK;
+  if (!d_points || !d_out || (with_cluster && (!d_inverse || !d_voxel_mean || ldm < 3 || cluster_div == 0.f)) ||
+      (with_center && (!d_coors || ldc < 4 || !voxel_size || !offsets)))
+    return SST_ERR_ARG;
+  const float vx = with_center ? voxel_size[0] : 0.f, vy = with_center ? voxel_size[1] : 0.f,
+              vz = with_center ? voxel_size[2] : 0.f;
+  const float ox = with_center ? offsets[0] : 0.f, oy = with_center ? offsets[1] : 0.f,
+              oz = with_center ? offsets[2] : 0.f;
+  const int grid = sst_grid_1d(n, 256);
+  if (coor_is_i64)
+    hipLaunchKernelGGL(vfe_decorate_k<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_points, ldp, n, c,
+                       d_inverse, d_voxel_mean, ldm, cluster_div, (const int64_t*)d_coors, ldc, vx, vy, vz, ox, oy, oz,
+                       with_cluster, with_center, d_out, ldo);
+  else
+    hipLaunchKernelGGL(vfe_decorate_k<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_points, ldp, n, c,
+                       d_inverse, d_voxel_mean, ldm, cluster_div, (const int32_t*)d_coors, ldc, vx, vy, vz, ox, oy, oz,
+                       with_cluster, with_center, d_out, ldo);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
 
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,

@@ -480,3 +480,32 @@ def scatter_rows(src, idx, out):
                                           _lib.ptr(out), out.stride(0), _lib.stream_ptr())
     _lib.check(rc, 'sst_scatter_rows_f32')
     return out
+
+
+def vfe_decorate(features, inverse, voxel_mean, cluster_div, coors, voxel_size, offsets, with_cluster, with_center):
+    """[features | xyz - voxel mean (/ cluster_div) | xyz - voxel centre] in one launch (csrc/scatter.hip,
+    sst_vfe_decorate_f32); the decorate step of DynamicVFE / DynamicScatterVFE (voxel_encoder.py:252-271, 569-589)."""
+    _lib.require_cuda(features)
+    n, c = features.shape
+    out = torch.empty((n, c + 3 * int(bool(with_cluster)) + 3 * int(bool(with_center))), dtype=torch.float32,
+                      device=features.device)
+    if n == 0:
+        return out
+    inv = mean = None
+    if with_cluster:
+        inv = inverse if inverse.dtype == torch.int32 else inverse.int()
+        inv = inv.contiguous()
+        mean = voxel_mean if voxel_mean.stride(1) == 1 else voxel_mean.contiguous()
+    cc = None
+    if with_center:
+        cc = coors if coors.stride(1) == 1 else coors.contiguous()
+        if cc.dtype not in (torch.int32, torch.int64):
+            cc = cc.long()
+    lib = _lib.load()
+    rc = lib.sst_vfe_decorate_f32(_lib.ptr(features), features.stride(0), n, c, _lib.ptr(inv), _lib.ptr(mean),
+                                  mean.stride(0) if mean is not None else 3, float(cluster_div), _lib.ptr(cc),
+                                  int(cc is not None and cc.dtype == torch.int64), cc.stride(0) if cc is not None else 4,
+                                  _lib.farray(voxel_size), _lib.farray(offsets), int(bool(with_cluster)),
+                                  int(bool(with_center)), _lib.ptr(out), out.stride(0), _lib.stream_ptr())
+    _lib.check(rc, 'sst_vfe_decorate_f32')
+    return out

@@ -15,6 +15,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import kernels as K
 from .dense import add_layer_norm, tall_linear
 from .norm import batch_norm_act, build_norm_layer
 from .registry import VOXEL_ENCODERS
@@ -152,25 +153,34 @@ class DynamicVFE(nn.Module):
         plan = scatter_plan if scatter_plan is not None else self.scatter_plan(coors)
         inv = plan.coors_map.long().clamp(min=0)
 
-        features_ls = [features]
-        if self._with_cluster_center:
-            voxel_mean = plan.reduce(features, 'mean')
-            points_mean = voxel_mean[inv]
-            f_cluster = features[:, :3] - points_mean[:, :3]
-            features_ls.append(f_cluster)
+        # decorate: [features | xyz - voxel mean | xyz - voxel centre] in one launch (bit-identical to the composed
+        # subtractions / cat of voxel_encoder.py:252-271)
+        if features.is_cuda and features.stride(1) == 1 and coors.size(1) == 4 and not features.requires_grad:
+            voxel_mean = plan.reduce(features, 'mean') if self._with_cluster_center else None
+            decorated = K.vfe_decorate(features, plan.coors_map, voxel_mean, 1.0, coors, (self.vx, self.vy, self.vz),
+                                       (self.x_offset, self.y_offset, self.z_offset), self._with_cluster_center,
+                                       self._with_voxel_center)
+            features_ls = [decorated]
+        else:
+            features_ls = [features]
+            if self._with_cluster_center:
+                voxel_mean = plan.reduce(features, 'mean')
+                points_mean = voxel_mean[inv]
+                f_cluster = features[:, :3] - points_mean[:, :3]
+                features_ls.append(f_cluster)
 
-        if self._with_voxel_center:
-            f_center = features.new_zeros(size=(features.size(0), 3))
-            f_center[:, 0] = features[:, 0] - (coors[:, 3].type_as(features) * self.vx + self.x_offset)
-            f_center[:, 1] = features[:, 1] - (coors[:, 2].type_as(features) * self.vy + self.y_offset)
-            f_center[:, 2] = features[:, 2] - (coors[:, 1].type_as(features) * self.vz + self.z_offset)
-            features_ls.append(f_center)
+            if self._with_voxel_center:
+                f_center = features.new_zeros(size=(features.size(0), 3))
+                f_center[:, 0] = features[:, 0] - (coors[:, 3].type_as(features) * self.vx + self.x_offset)
+                f_center[:, 1] = features[:, 1] - (coors[:, 2].type_as(features) * self.vy + self.y_offset)
+                f_center[:, 2] = features[:, 2] - (coors[:, 1].type_as(features) * self.vz + self.z_offset)
+                features_ls.append(f_center)
 
         if self._with_distance:
             points_dist = torch.norm(features[:, :3], 2, 1, keepdim=True)
             features_ls.append(points_dist)
 
-        features = torch.cat(features_ls, dim=-1)
+        features = torch.cat(features_ls, dim=-1) if len(features_ls) > 1 else features_ls[0]
         reduce_mode = 'max' if self.mode == 'max' else 'mean'
         for i, vfe in enumerate(self.vfe_layers):
             point_feats = vfe(features)
@@ -223,26 +233,36 @@ class DynamicScatterVFE(DynamicVFE):
         else:
             new_coors = unq_inv_once = None
 
-        features_ls = [features]
-        if self._with_cluster_center:
-            voxel_mean, _, unq_inv = scatter_v2(features[:, :3], coors, mode='avg', new_coors=new_coors,
-                                                unq_inv=unq_inv_once)
-            points_mean = self.map_voxel_center_to_point(voxel_mean, unq_inv)
-            f_cluster = features[:, :3] - points_mean[:, :3]
-            features_ls.append(f_cluster / self.rel_dist_scaler)
+        if features.is_cuda and features.stride(1) == 1 and coors.size(1) == 4 and not features.requires_grad:
+            # decorate in one launch (bit-identical to the composed ops of voxel_encoder.py:569-589)
+            voxel_mean = unq_inv = None
+            if self._with_cluster_center:
+                voxel_mean, _, unq_inv = scatter_v2(features[:, :3], coors, mode='avg', new_coors=new_coors,
+                                                    unq_inv=unq_inv_once)
+            features_ls = [K.vfe_decorate(features, unq_inv, voxel_mean, self.rel_dist_scaler, coors,
+                                          (self.vx, self.vy, self.vz), (self.x_offset, self.y_offset, self.z_offset),
+                                          self._with_cluster_center, self._with_voxel_center)]
+        else:
+            features_ls = [features]
+            if self._with_cluster_center:
+                voxel_mean, _, unq_inv = scatter_v2(features[:, :3], coors, mode='avg', new_coors=new_coors,
+                                                    unq_inv=unq_inv_once)
+                points_mean = self.map_voxel_center_to_point(voxel_mean, unq_inv)
+                f_cluster = features[:, :3] - points_mean[:, :3]
+                features_ls.append(f_cluster / self.rel_dist_scaler)
 
-        if self._with_voxel_center:
-            f_center = features.new_zeros(size=(features.size(0), 3))
-            f_center[:, 0] = features[:, 0] - (coors[:, 3].type_as(features) * self.vx + self.x_offset)
-            f_center[:, 1] = features[:, 1] - (coors[:, 2].type_as(features) * self.vy + self.y_offset)
-            f_center[:, 2] = features[:, 2] - (coors[:, 1].type_as(features) * self.vz + self.z_offset)
-            features_ls.append(f_center)
+            if self._with_voxel_center:
+                f_center = features.new_zeros(size=(features.size(0), 3))
+                f_center[:, 0] = features[:, 0] - (coors[:, 3].type_as(features) * self.vx + self.x_offset)
+                f_center[:, 1] = features[:, 1] - (coors[:, 2].type_as(features) * self.vy + self.y_offset)
+                f_center[:, 2] = features[:, 2] - (coors[:, 1].type_as(features) * self.vz + self.z_offset)
+                features_ls.append(f_center)
 
         if self._with_distance:
             points_dist = torch.norm(features[:, :3], 2, 1, keepdim=True)
             features_ls.append(points_dist)
 
-        features = torch.cat(features_ls, dim=-1)
+        features = torch.cat(features_ls, dim=-1) if len(features_ls) > 1 else features_ls[0]
         for i, vfe in enumerate(self.vfe_layers):
             point_feats = vfe(features)
             voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, mode=self.mode, new_coors=new_coors,
