@@ -7,7 +7,6 @@ names 'SSTv2' / 'SIR', constructor kwargs, forward signatures, state_dict keys
 import torch
 import torch.nn as nn
 
-from . import kernels as K
 from .norm import build_conv_layer, build_norm_layer
 from .registry import BACKBONES, build_voxel_encoder
 from .sst_basic_block import BasicShiftBlockV2, plan_from_reference_dicts

@@ -142,7 +142,6 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
         raise RuntimeError('sst_amd.spconv: CUDA tensors required (no CPU fallback)')
     if indices.dim() != 2 or indices.shape[1] != 4:
         raise NotImplementedError('sst_amd.spconv: 3-D indices (batch, z, y, x) only')
-    ndim = 3
     ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
     dilation, out_padding = _triple(dilation), _triple(out_padding)
     for d, s in zip(dilation, stride):

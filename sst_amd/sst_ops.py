@@ -12,7 +12,6 @@ tensors).
 """
 import traceback
 
-import numpy as np
 import torch
 import torch.nn as nn
 

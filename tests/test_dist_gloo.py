@@ -3,7 +3,6 @@ naiveSyncBN's all_gather(forward)/all_reduce(backward) and the flat-bucket gradi
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -2,7 +2,6 @@
 the reference's data flow (oracle/cpu_pipeline.py: padded per-level windows + nn.MultiheadAttention with a key
 padding mask), same weights, same cloud, training-mode voxel drop, no shuffle.  Voxel indices bit-exact, features
 and gradients within the north-star tolerance."""
-import numpy as np
 import pytest
 import torch
 

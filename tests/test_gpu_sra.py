@@ -1,7 +1,6 @@
 """GPU: Sparse Regional Attention core (MFMA and generic kernels), forward and backward, against the float64
 oracle; encoder layers / SSTv2 block against golden tensors from the reference's own Python.
 Tolerance: 1e-3 absolute on fp32 features (BASELINE.json north_star), in practice ~1e-5."""
-import math
 
 import numpy as np
 import pytest
