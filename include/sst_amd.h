@@ -405,6 +405,14 @@ int sst_spconv_pair_lists_i32(const int32_t* d_in2out, int kvol, int64_t n, int3
 int sst_spconv_gather_gemm_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol,
                                const float* d_w, int cin, int cout, int trans_w, const float* d_bias, float* d_y,
                                int64_t ldy, int form, void* stream);
+/*   sst_spconv_maxpool_{fwd,bwd}_f32: indiceMaxPool / indiceMaxPoolBackward (include/spconv/pool_ops.h:24-97,
+ *     src/maxpool.cc:22-63) on the maps: y[i] = max(0, max_k x[out2in[k][i]]) (the reference's zero-filled start);
+ *     dx[j] = sum of dy[i] over the outputs i = in2out[k][j] whose value equals x[j] (ties all receive). */
+int sst_spconv_maxpool_fwd_f32(const float* d_x, int64_t ldx, const int32_t* d_out2in, int64_t m, int kvol, int c,
+                               float* d_y, int64_t ldy, void* stream);
+int sst_spconv_maxpool_bwd_f32(const float* d_x, int64_t ldx, const float* d_y, int64_t ldy, const float* d_dy,
+                               int64_t lddy, const int32_t* d_in2out, int64_t n, int kvol, int c, float* d_dx,
+                               int64_t lddx, void* stream);
 int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout);
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                          int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,

@@ -140,7 +140,8 @@ SRB_STUBS = os.path.join(HERE, 'ref_stubs')  # an empty cuda_runtime_api.h: tens
 
 def build_spconv_rulebook(force=False, verbose=False):
     """oracle/_ref/spconv_rulebook_ref.so = oracle/ref_spconv_rulebook_binding.cpp instantiating getIndicePairsConv /
-    SubM / DeConv <int, int, 3> from the reference's include/spconv/geometry.h (compiled where it lies)."""
+    SubM / DeConv <int, int, 3> from the reference's include/spconv/geometry.h, + the reference's src/maxpool.cc (CPU
+    max-pool functors), both compiled where they lie."""
     if os.path.exists(SRB_OUT) and not force:
         return SRB_OUT
     if not os.path.exists(os.path.join(SRB_INC, 'spconv', 'geometry.h')):
@@ -151,19 +152,23 @@ def build_spconv_rulebook(force=False, verbose=False):
     incs = cpp_extension.include_paths() + [sysconfig.get_paths()['include'], SRB_STUBS, SRB_INC]
     torch_lib = os.path.join(os.path.dirname(torch.__file__), 'lib')
     abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
-    obj = os.path.join(OUT_DIR, 'srb_binding.o')
-    cmd = ['g++', '-O2', '-fPIC', '-std=c++17', '-w', f'-D_GLIBCXX_USE_CXX11_ABI={abi}',
-           '-DTORCH_EXTENSION_NAME=spconv_rulebook_ref', '-DTORCH_API_INCLUDE_EXTENSION_H']
-    cmd += [f'-I{i}' for i in incs] + ['-c', SRB_BINDING, '-o', obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('oracle/_ref build failed:\n' + ' '.join(cmd) + '\n' + (r.stdout + r.stderr)[-3000:])
-    link = ['g++', '-shared', '-o', SRB_OUT, obj, f'-L{torch_lib}', '-ltorch', '-ltorch_cpu', '-lc10', '-ltorch_python',
-            f'-Wl,-rpath,{torch_lib}']
+    objs = []
+    for src in (SRB_BINDING, os.path.join(REF_ROOT, 'mmdet3d', 'ops', 'spconv', 'src', 'maxpool.cc')):
+        obj = os.path.join(OUT_DIR, 'srb_' + os.path.basename(src).rsplit('.', 1)[0] + '.o')
+        objs.append(obj)
+        cmd = ['g++', '-O2', '-fPIC', '-std=c++17', '-w', f'-D_GLIBCXX_USE_CXX11_ABI={abi}',
+               '-DTORCH_EXTENSION_NAME=spconv_rulebook_ref', '-DTORCH_API_INCLUDE_EXTENSION_H']
+        cmd += [f'-I{i}' for i in incs] + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('oracle/_ref build failed:\n' + ' '.join(cmd) + '\n' + (r.stdout + r.stderr)[-3000:])
+    link = ['g++', '-shared', '-o', SRB_OUT] + objs + [f'-L{torch_lib}', '-ltorch', '-ltorch_cpu', '-lc10',
+                                                       '-ltorch_python', f'-Wl,-rpath,{torch_lib}']
     r = subprocess.run(link, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('oracle/_ref link failed:\n' + r.stdout + r.stderr)
-    os.remove(obj)
+    for obj in objs:
+        os.remove(obj)
     if verbose:
         print('built', SRB_OUT)
     return SRB_OUT

@@ -8,6 +8,7 @@
 #include <torch/extension.h>
 
 #include <spconv/geometry.h>
+#include <spconv/maxpool.h>
 #include <tensorview/tensorview.h>
 
 namespace {
@@ -63,6 +64,45 @@ std::vector<at::Tensor> get_indice_pairs_3d(at::Tensor indices, int64_t batch_si
   return {out, pairs, num};
 }
 
+// Sparse max pooling: the per-offset functors are the reference's (src/maxpool.cc, compiled next to this file); the
+// loop over the kernel offsets and the zero-filled start follow include/spconv/pool_ops.h:24-97.
+tv::TensorView<float> fview(at::Tensor t) {
+  tv::Shape shape;
+  for (auto s : t.sizes()) shape.push_back((int)s);
+  return tv::TensorView<float>(t.data_ptr<float>(), shape);
+}
+
+tv::TensorView<const float> cfview(at::Tensor t) {
+  tv::Shape shape;
+  for (auto s : t.sizes()) shape.push_back((int)s);
+  return tv::TensorView<const float>(t.data_ptr<float>(), shape);
+}
+
+at::Tensor indice_maxpool(at::Tensor features, at::Tensor pairs, at::Tensor num, int64_t num_act) {
+  auto out = at::zeros({num_act, features.size(1)}, features.options());
+  spconv::functor::SparseMaxPoolForwardFunctor<tv::CPU, float, int> f;
+  for (int64_t k = 0; k < pairs.size(0); ++k) {
+    const int n = num.data_ptr<int>()[k];
+    if (n > 0) f(tv::CPU(), fview(out), cfview(features), cview(pairs).subview(k), n);
+  }
+  return out;
+}
+
+at::Tensor indice_maxpool_backward(at::Tensor features, at::Tensor out_features, at::Tensor out_grad, at::Tensor pairs,
+                                   at::Tensor num) {
+  auto din = at::zeros_like(features);
+  spconv::functor::SparseMaxPoolBackwardFunctor<tv::CPU, float, int> f;
+  for (int64_t k = 0; k < pairs.size(0); ++k) {
+    const int n = num.data_ptr<int>()[k];
+    if (n > 0) f(tv::CPU(), cfview(out_features), cfview(features), cfview(out_grad), fview(din), cview(pairs).subview(k), n);
+  }
+  return din;
+}
+
 }  // namespace
 
-PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) { m.def("get_indice_pairs_3d", &get_indice_pairs_3d); }
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("get_indice_pairs_3d", &get_indice_pairs_3d);
+  m.def("indice_maxpool", &indice_maxpool);
+  m.def("indice_maxpool_backward", &indice_maxpool_backward);
+}

@@ -127,3 +127,25 @@ def indice_conv_backward(features, filters, out_grad, pairs, num, inverse=False)
         dw[k] = x[src].T @ g[dst]
         np.add.at(dx, src, g[dst] @ w[k].T)
     return dx, dw.reshape(filters.shape)
+
+
+def indice_maxpool(features, pairs, num, n_out):
+    """pool_ops.h:24-58 + maxpool.cc:22-40: output starts at ZERO, then out = max(out, in) per pair"""
+    x = np.asarray(features, dtype=np.float32)
+    out = np.zeros((n_out, x.shape[1]), dtype=np.float32)
+    for k in range(pairs.shape[0]):
+        src, dst = pairs[k, 0, :num[k]], pairs[k, 1, :num[k]]
+        np.maximum.at(out, dst, x[src])
+    return out
+
+
+def indice_maxpool_backward(features, out_features, out_grad, pairs, num):
+    """pool_ops.h:60-96 + maxpool.cc:42-63: every input equal to the pooled value receives the gradient"""
+    x = np.asarray(features, dtype=np.float32)
+    y = np.asarray(out_features, dtype=np.float32)
+    g = np.asarray(out_grad, dtype=np.float32)
+    dx = np.zeros_like(x)
+    for k in range(pairs.shape[0]):
+        src, dst = pairs[k, 0, :num[k]], pairs[k, 1, :num[k]]
+        np.add.at(dx, src, np.where(y[dst] == x[src], g[dst], np.float32(0)))
+    return dx

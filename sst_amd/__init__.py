@@ -24,7 +24,7 @@ from .cluster import (ClusterAssigner, connected_components_xy, filter_almost_em
 from .dynamic_point_pool import DynamicPointROIExtractor, dynamic_point_pool, dynamic_point_pool_mixed
 from . import spconv  # noqa: F401  (sst_amd.spconv mirrors mmdet3d.ops.spconv)
 from .spconv import (SparseConv3d, SparseConvTensor, SparseConvTranspose3d, SparseInverseConv3d,  # noqa: F401
-                     SparseModule, SparseSequential, SubMConv3d)
+                     SparseMaxPool3d, SparseModule, SparseSequential, SubMConv3d)
 from .sparse_unet import (SimpleSparseUNet, SparseBasicBlock, SparseUNet, VirtualVoxelMixer,  # noqa: F401
                           make_sparse_convmodule)
 
@@ -43,6 +43,6 @@ __all__ = [
     'find_connected_componets', 'find_connected_componets_single_batch', 'filter_almost_empty',
     'modify_cluster_by_class', 'connected_components_xy', 'ROI_EXTRACTORS', 'DynamicPointROIExtractor',
     'dynamic_point_pool', 'dynamic_point_pool_mixed', 'spconv', 'SparseConvTensor', 'SparseSequential', 'SparseModule',
-    'SubMConv3d', 'SparseConv3d', 'SparseConvTranspose3d', 'SparseInverseConv3d', 'SparseUNet', 'SimpleSparseUNet', 'VirtualVoxelMixer',
+    'SubMConv3d', 'SparseConv3d', 'SparseConvTranspose3d', 'SparseInverseConv3d', 'SparseMaxPool3d', 'SparseUNet', 'SimpleSparseUNet', 'VirtualVoxelMixer',
     'SparseBasicBlock', 'make_sparse_convmodule',
 ]

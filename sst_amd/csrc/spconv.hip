@@ -641,6 +641,50 @@ int64_t sp_wgrad_chunks(int kvol, int64_t pair_ld, int64_t total_pairs) {
   return total / kSpChunk + kvol;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sparse max pooling (indiceMaxPool / indiceMaxPoolBackward, include/spconv/pool_ops.h:24-97, src/maxpool.cc:22-63) on
+// the dense maps: out[i][c] = max(0, max_k in[out2in[k][i]][c]) -- the reference starts from a zero-filled output, so
+// negative maxima clip to 0 -- and din[j][c] = sum over the outputs i = in2out[k][j] with out[i][c] == in[j][c] of
+// dout[i][c] (every input that equals the maximum receives the gradient, as in the reference).  Gathers, no atomics.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_maxpool_fwd_k(const float* __restrict__ x, int64_t ldx,
+                                                        const int32_t* __restrict__ out2in, int64_t m, int kvol, int c,
+                                                        float* __restrict__ y, int64_t ldy) {
+  const int64_t total = m * c;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / c;
+    const int ch = (int)(e - i * c);
+    float best = 0.f;
+    for (int k = 0; k < kvol; ++k) {
+      const int j = out2in[(int64_t)k * m + i];
+      if (j >= 0) {
+        const float v = x[(int64_t)j * ldx + ch];
+        if (best < v) best = v;
+      }
+    }
+    y[i * ldy + ch] = best;
+  }
+}
+
+__global__ __launch_bounds__(256) void sp_maxpool_bwd_k(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ y, int64_t ldy,
+                                                        const float* __restrict__ dy, int64_t lddy,
+                                                        const int32_t* __restrict__ in2out, int64_t n, int kvol, int c,
+                                                        float* __restrict__ dx, int64_t lddx) {
+  const int64_t total = n * c;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / c;
+    const int ch = (int)(e - j * c);
+    const float v = x[j * ldx + ch];
+    float g = 0.f;
+    for (int k = 0; k < kvol; ++k) {
+      const int i = in2out[(int64_t)k * n + j];
+      if (i >= 0 && y[(int64_t)i * ldy + ch] == v) g += dy[(int64_t)i * lddy + ch];
+    }
+    dx[j * lddx + ch] = g;
+  }
+}
+
 bool sp_geom(const int32_t* in_shape, const int32_t* out_shape, const int32_t* ks, const int32_t* st,
              const int32_t* pd, const int32_t* dl, SpGeom* g) {
   if (!in_shape || !out_shape || !ks || !st || !pd || !dl) return false;
@@ -818,6 +862,29 @@ int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64
                      d_dy, lddy, d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, part);
   hipLaunchKernelGGL(sp_wgrad_reduce_k, dim3((unsigned)sst_div_up(per_k, 256), (unsigned)kvol), dim3(256), 0, st, part,
                      d_num, kvol, per_k, d_dw);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_spconv_maxpool_fwd_f32(const float* d_x, int64_t ldx, const int32_t* d_out2in, int64_t m, int kvol, int c,
+                               float* d_y, int64_t ldy, void* stream) {
+  if (m < 0 || kvol < 1 || c < 1 || ldx < c || ldy < c) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_out2in || !d_y) return SST_ERR_ARG;
+  hipLaunchKernelGGL(sp_maxpool_fwd_k, dim3(sst_grid_1d(m * c, 256)), dim3(256), 0, (hipStream_t)stream, d_x, ldx,
+                     d_out2in, m, kvol, c, d_y, ldy);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_spconv_maxpool_bwd_f32(const float* d_x, int64_t ldx, const float* d_y, int64_t ldy, const float* d_dy,
+                               int64_t lddy, const int32_t* d_in2out, int64_t n, int kvol, int c, float* d_dx,
+                               int64_t lddx, void* stream) {
+  if (n < 0 || kvol < 1 || c < 1 || ldx < c || ldy < c || lddy < c || lddx < c) return SST_ERR_ARG;
+  if (n == 0) return SST_OK;
+  if (!d_x || !d_in2out || !d_dx || !d_y || !d_dy) return SST_ERR_ARG;
+  hipLaunchKernelGGL(sp_maxpool_bwd_k, dim3(sst_grid_1d(n * c, 256)), dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_y,
+                     ldy, d_dy, lddy, d_in2out, n, kvol, c, d_dx, lddx);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -265,7 +265,59 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     return input_bp, filters_bp
 
 
+def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    """ops.py:162-171 / pool_ops.h:24-58: out = max(0, max over the paired inputs)"""
+    if not features.is_cuda:
+        raise RuntimeError('sst_amd.spconv: CUDA tensors required (no CPU fallback)')
+    if features.dtype != torch.float32:
+        raise NotImplementedError('sst_amd.spconv: fp32 only')
+    rb = rulebook_of(indice_pairs, indice_pair_num, num_activate_out)
+    x = features if features.stride(1) == 1 else features.contiguous()
+    y = torch.empty((rb.m, x.size(1)), dtype=torch.float32, device=x.device)
+    rc = _lib.load().sst_spconv_maxpool_fwd_f32(_lib.ptr(x), x.stride(0) if x.size(0) else x.size(1), _lib.ptr(rb.out2in),
+                                                rb.m, rb.kvol, x.size(1), _lib.ptr(y), y.stride(0), _lib.stream_ptr())
+    _lib.check(rc, 'sst_spconv_maxpool_fwd_f32')
+    return y
+
+
+def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
+    """ops.py:174-183 / pool_ops.h:60-96"""
+    rb = rulebook_of(indice_pairs, indice_pair_num, out_features.size(0))
+    x = features if features.stride(1) == 1 else features.contiguous()
+    y = out_features if out_features.stride(1) == 1 else out_features.contiguous()
+    dy = out_bp if out_bp.stride(1) == 1 else out_bp.contiguous()
+    dx = torch.empty_like(x)
+    c = x.size(1)
+    rc = _lib.load().sst_spconv_maxpool_bwd_f32(_lib.ptr(x), x.stride(0) if x.size(0) else c, _lib.ptr(y),
+                                                y.stride(0) if y.size(0) else c, _lib.ptr(dy),
+                                                dy.stride(0) if dy.size(0) else c, _lib.ptr(rb.in2out), rb.n, rb.kvol, c,
+                                                _lib.ptr(dx), dx.stride(0) if dx.size(0) else c, _lib.stream_ptr())
+    _lib.check(rc, 'sst_spconv_maxpool_bwd_f32')
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------ functional.py
+class SparseMaxPoolFunction(torch.autograd.Function):
+    """functional.py:78-96"""
+
+    @staticmethod
+    def forward(ctx, features, indice_pairs, indice_pair_num, num_activate_out):
+        out = indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out)
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, out)
+        ctx.rulebook = getattr(indice_pairs, '_sst_rulebook', None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, out = ctx.saved_tensors
+        if ctx.rulebook is not None:
+            indice_pairs._sst_rulebook = ctx.rulebook
+        return indice_maxpool_backward(features, out, grad_output, indice_pairs, indice_pair_num), None, None, None
+
+
+indice_maxpool_fn = SparseMaxPoolFunction.apply
+
+
 class SparseConvFunction(torch.autograd.Function):
 
     @staticmethod
@@ -555,3 +607,41 @@ class SubMConv3d(SparseConvolution):
                  indice_key=None):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
                          indice_key=indice_key)
+
+
+# ------------------------------------------------------------------------------------------------ pool.py
+class SparseMaxPool(SparseModule):
+    """pool.py:20-72"""
+
+    def __init__(self, ndim, kernel_size, stride=1, padding=0, dilation=1, subm=False):
+        super().__init__()
+        if ndim != 3:
+            raise NotImplementedError('sst_amd.spconv: 3-D pooling only')
+        self.ndim = ndim
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.subm = subm
+        self.dilation = _triple(dilation)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        if not self.subm:
+            out_spatial_shape = get_conv_output_size(input.spatial_shape, self.kernel_size, self.stride, self.padding,
+                                                     self.dilation)
+        else:
+            out_spatial_shape = input.spatial_shape
+        outids, indice_pairs, indice_pairs_num = get_indice_pairs(input.indices, input.batch_size, input.spatial_shape,
+                                                                  self.kernel_size, self.stride, self.padding,
+                                                                  self.dilation, 0, self.subm)
+        out_features = indice_maxpool_fn(input.features, indice_pairs, indice_pairs_num, outids.shape[0])
+        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, input.batch_size)
+        out_tensor.indice_dict = input.indice_dict
+        out_tensor.grid = input.grid
+        return out_tensor
+
+
+class SparseMaxPool3d(SparseMaxPool):
+
+    def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__(3, kernel_size, stride, padding, dilation)

@@ -390,6 +390,16 @@ def gen_spconv():
         arrays[f'out::{tag}::outids'] = outids.numpy()
         arrays[f'out::{tag}::pairs'] = pairs.numpy()
         arrays[f'out::{tag}::num'] = num.numpy()
+        if tag in ('down3s2', 'down2s2', 'subm3'):
+            # max pooling over the same pairs with the reference's own CPU functors (src/maxpool.cc); some features are
+            # made equal on purpose (ties all receive the gradient) and many are negative (the zero-filled start clips)
+            feats = torch.from_numpy(rng.normal(size=(n, 6)).round(1).astype(np.float32))
+            gout = torch.from_numpy(rng.normal(size=(len(outids), 6)).astype(np.float32))
+            pooled = mod.indice_maxpool(feats, pairs, num, len(outids))
+            arrays[f'in::{tag}::pool_features'] = feats.numpy()
+            arrays[f'in::{tag}::pool_grad_out'] = gout.numpy()
+            arrays[f'out::{tag}::pooled'] = pooled.numpy()
+            arrays[f'out::{tag}::pool_grad_in'] = mod.indice_maxpool_backward(feats, pooled, gout, pairs, num).numpy()
     save('spconv.npz', **arrays)
 
 

@@ -176,3 +176,33 @@ def test_spconv_full_size_properties():
     assert float((y.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
     y2 = spconv.indice_conv(2.5 * x, w, pairs, num, n, False, True)
     assert float((y2 - 2.5 * y).abs().max()) < 1e-4 * float(y.abs().max())
+
+
+@pytest.mark.parametrize('tag', ['down3s2', 'down2s2', 'subm3'])
+def test_sparse_maxpool_matches_reference_golden(tag):
+    """indice_maxpool forward / backward (bit-exact: max and exact-equality selections, sums of at most K terms in the
+    reference's offset order differ only by association -> 1e-6) against the reference's CPU functors (golden)"""
+    from sst_amd import spconv
+    g = load_golden('spconv.npz')
+    ind, batch, shape, ks, st, pd, dl, subm, tr = spconv_case(g, tag)
+    outids, pairs, num, rb = _rulebook(ind, batch, shape, ks, st, pd, dl, subm, tr)
+    pos = {tuple(c): i for i, c in enumerate(g[f'out::{tag}::outids'].tolist())}
+    perm = np.array([pos[tuple(c)] for c in outids.cpu().tolist()])
+    x = torch.from_numpy(g[f'in::{tag}::pool_features']).to(DEV).requires_grad_(True)
+    y = spconv.indice_maxpool_fn(x, pairs, num, len(outids))
+    np.testing.assert_array_equal(y.detach().cpu().numpy(), g[f'out::{tag}::pooled'][perm])
+    y.backward(torch.from_numpy(g[f'in::{tag}::pool_grad_out'][perm]).to(DEV))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f'out::{tag}::pool_grad_in'], atol=1e-6)
+
+
+def test_sparse_maxpool_module():
+    from sst_amd import spconv
+    rng = np.random.default_rng(12)
+    ind = _cloud(rng, 800, 2, [8, 20, 20])
+    t = spconv.SparseConvTensor(torch.randn(800, 5, device=DEV), torch.from_numpy(ind).to(DEV), [8, 20, 20], 2)
+    out = spconv.SparseMaxPool3d(3, stride=2, padding=1)(t)
+    assert list(out.spatial_shape) == [4, 10, 10] and out.features.shape[1] == 5 and (out.features >= 0).all()
+    dense_in = t.dense().clamp(min=0)
+    want = torch.nn.functional.max_pool3d(dense_in, 3, 2, 1)       # zeros where nothing is active, like the sparse op
+    got = out.dense()
+    assert torch.equal(got, want * (got != 0)) or torch.allclose(got[got != 0], want[got != 0])

@@ -365,3 +365,23 @@ def test_spconv_conv_oracle_forward_backward_consistency():
     wp[1, 2, 0, 3, 1] += eps
     num_grad = ((O.indice_conv(x, wp, pairs, num, len(outids)) - y) * g).sum() / eps
     assert abs(num_grad - dw[1, 2, 0, 3, 1]) < 1e-4
+
+
+@pytest.mark.parametrize('tag', ['down3s2', 'down2s2', 'subm3'])
+def test_spconv_maxpool_oracle_matches_reference_golden(tag):
+    """sparse max pooling restatement against the reference's own CPU functors (src/maxpool.cc, golden): zero-filled
+    start (negative maxima clip to 0), ties all receive the gradient.  Golden outputs are indexed by the CPU path's
+    output numbering: compared through the output coordinates."""
+    from oracle import spconv_oracle as O
+    g = load_golden('spconv.npz')
+    ind, batch, shape, ks, st, pd, dl, subm, tr = spconv_case(g, tag)
+    outids, pairs, num, _ = O.indice_pairs(ind, batch, shape, ks, st, pd, dl, (0, 0, 0), subm, tr)
+    x, gout_ref = g[f'in::{tag}::pool_features'], g[f'in::{tag}::pool_grad_out']
+    ref_ids = g[f'out::{tag}::outids']
+    pos = {tuple(c): i for i, c in enumerate(ref_ids.tolist())}
+    perm = np.array([pos[tuple(c)] for c in outids.tolist()])      # my output row -> reference output row
+    y = O.indice_maxpool(x, pairs, num, len(outids))
+    np.testing.assert_array_equal(y, g[f'out::{tag}::pooled'][perm])
+    assert (y >= 0).all() and (y == 0).any()
+    dx = O.indice_maxpool_backward(x, y, gout_ref[perm], pairs, num)
+    np.testing.assert_allclose(dx, g[f'out::{tag}::pool_grad_in'], atol=1e-5)
