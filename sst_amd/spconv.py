@@ -138,10 +138,10 @@ def _finish_rulebook(in2out, kvol, n, m, dev):
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
                      subm=False, transpose=False, grid=None):
     """ops.py:46-102 -> (outids [M, 4] int32, indice_pairs [K, 2, N] int32, indice_pair_num [K] int32)."""
-    if not indices.is_cuda:
-        raise RuntimeError('sst_amd.spconv: CUDA tensors required (no CPU fallback)')
     if indices.dim() != 2 or indices.shape[1] != 4:
         raise NotImplementedError('sst_amd.spconv: 3-D indices (batch, z, y, x) only')
+    if not indices.is_cuda:
+        raise RuntimeError('sst_amd.spconv: CUDA tensors required (no CPU fallback)')
     ksize, stride, padding = _triple(ksize), _triple(stride), _triple(padding)
     dilation, out_padding = _triple(dilation), _triple(out_padding)
     for d, s in zip(dilation, stride):
