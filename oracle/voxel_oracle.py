@@ -134,3 +134,34 @@ class DynamicScatterOracle(nn.Module):
             voxel_coors.append(nn.functional.pad(voxel_coor, (1, 0), mode='constant', value=i))
             voxels.append(voxel)
         return torch.cat(voxels, dim=0), torch.cat(voxel_coors, dim=0)
+
+
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    """voxelization_cpu.cpp:43-100 + 102-142 without the sequential loop (the formulation the GPU path uses): dynamic
+    voxelization clamped to the round() grid of :127-130, voxels numbered by the first appearance of one of their
+    points and cut at max_voxels, the first max_points points of a voxel kept in input order.
+    -> (voxels [V, max_points, C] zero padded, coors [V, 3] int32 (z, y, x), num_points [V] int32)."""
+    p = np.asarray(points, dtype=np.float32)
+    c = dynamic_voxelize(p, voxel_size, coors_range).astype(np.int64)
+    v = np.asarray(voxel_size, dtype=np.float32)
+    r = np.asarray(coors_range, dtype=np.float32)
+    # C round(): halves away from zero (numpy / Python round to even), on the float32 quotient
+    grid = np.floor(((r[3:] - r[:3]) / v).astype(np.float32) + np.float32(0.5)).astype(np.int64)   # (gx, gy, gz)
+    c = np.minimum(c, grid[::-1][None, :] - 1)
+    uniq, first, inv, counts = np.unique(c, axis=0, return_index=True, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(first, kind='stable')
+    vrank = np.empty(len(uniq), dtype=np.int64)
+    vrank[order] = np.arange(len(uniq))
+    num = len(uniq) if max_voxels == -1 else min(len(uniq), max_voxels)
+    # rank of every point inside its voxel, in input order
+    by_voxel = np.argsort(inv, kind='stable')
+    start = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    rank = np.empty(len(p), dtype=np.int64)
+    rank[by_voxel] = np.arange(len(p)) - start[inv[by_voxel]]
+    keep = (vrank[inv] < num) & ((rank < max_points) if max_points != -1 else True)
+    width = max_points if max_points != -1 else int(counts.max())
+    voxels = np.zeros((num, width, p.shape[1]), dtype=np.float32)
+    voxels[vrank[inv][keep], rank[keep]] = p[keep]
+    npts = counts if max_points == -1 else np.minimum(counts, max_points)
+    return voxels, uniq[order[:num]].astype(np.int32), npts[order[:num]].astype(np.int32)

@@ -29,10 +29,52 @@ def dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3):
     K.dynamic_voxelize(points.contiguous(), list(voxel_size), list(coors_range), coors=coors)
 
 
-def hard_voxelize(*args, **kwargs):
-    raise NotImplementedError(
-        'hard voxelization (max_num_points != -1) is outside the SST/FSD hot path: every SST/FSD config uses '
-        'dynamic voxelization (max_num_points=-1), see SURVEY.md §2.2')
+def hard_voxelize(points, voxels, coors, num_points_per_voxel, voxel_size, coors_range, max_points, max_voxels,
+                  NDim=3):
+    """voxel_layer.hard_voxelize (voxelization.h:51-69; algorithm voxelization_cpu.cpp:43-100): fills the
+    caller-allocated ``voxels`` [max_voxels, max_points, C], ``coors`` [max_voxels, 3] int32 (z, y, x) and
+    ``num_points_per_voxel`` [max_voxels] int32, returns the number of voxels.
+
+    Same result as the reference's sequential loop: voxels numbered by the first appearance of one of their points,
+    at most ``max_voxels`` of them (later voxels are dropped), inside a voxel the first ``max_points`` points in
+    input order.  Here without a sequential pass: dynamic voxelization (this fork clamps, grid = round(), :127-130),
+    sorted-unique of the coordinates, voxels ordered by their smallest point index, in-voxel rank from the CSR
+    position.  No SST / FSD config uses it (they all set max_num_points = -1); composed of the existing kernels."""
+    if NDim != 3:
+        raise RuntimeError('sst_amd.hard_voxelize supports NDim == 3 only')
+    K._lib.require_cuda(points)
+    n = points.size(0)
+    if n == 0:
+        return 0
+    with torch.no_grad():
+        c = K.dynamic_voxelize(points.contiguous(), list(voxel_size), list(coors_range))           # [N, 3] (z, y, x)
+        # C round() on the float32 quotient (halves away from zero; Python's round() goes to even)
+        f32 = torch.tensor(list(coors_range) + list(voxel_size), dtype=torch.float32)
+        grid = [int(g) for g in torch.floor((f32[3:6] - f32[0:3]) / f32[6:9] + 0.5).tolist()]         # x, y, z
+        c = torch.minimum(c, torch.tensor([grid[2] - 1, grid[1] - 1, grid[0] - 1], dtype=torch.int32, device=c.device))
+        plan = K.unique_rows(c.contiguous(), [0, 0, 0], [grid[2], grid[1], grid[0]])
+        m = plan.m
+        perm, offsets, inv = plan.perm.long(), plan.offsets[:m + 1].long(), plan.inverse.long()
+        first_point = perm[offsets[:m]]                       # smallest point index of every voxel (perm is ascending in a group)
+        order = torch.argsort(first_point)                    # voxels in order of first appearance
+        vrank = torch.empty(m, dtype=torch.long, device=c.device)
+        vrank[order] = torch.arange(m, device=c.device)
+        pos = torch.empty(n, dtype=torch.long, device=c.device)
+        pos[perm] = torch.arange(n, device=c.device)
+        rank = pos - offsets[inv]                             # position of the point inside its voxel, input order
+        num = min(m, int(max_voxels)) if max_voxels != -1 else m
+        v_of_point = vrank[inv]
+        keep = v_of_point < num
+        if max_points != -1:
+            keep &= rank < max_points
+        voxels[v_of_point[keep], rank[keep]] = points[keep].to(voxels.dtype)
+        counts = plan.counts().long()
+        if max_points != -1:
+            counts = counts.clamp(max=max_points)
+        sel = order[:num]
+        num_points_per_voxel[:num] = counts[sel].to(num_points_per_voxel.dtype)
+        coors[:num] = K.unpack_unique_rows(plan, torch.int32)[sel].to(coors.dtype)
+    return num
 
 
 class ScatterPlan(object):
@@ -158,7 +200,13 @@ class _VoxelizationFn(object):
         if max_points == -1 or max_voxels == -1:
             with torch.no_grad():
                 return K.dynamic_voxelize(points.contiguous(), list(voxel_size), list(coors_range))
-        return hard_voxelize()
+        # voxelize.py:47-58
+        voxels = points.new_zeros(size=(max_voxels, max_points, points.size(1)))
+        coors = points.new_zeros(size=(max_voxels, 3), dtype=torch.int)
+        num_points_per_voxel = points.new_zeros(size=(max_voxels, ), dtype=torch.int)
+        voxel_num = hard_voxelize(points, voxels, coors, num_points_per_voxel, voxel_size, coors_range, max_points,
+                                  max_voxels, 3)
+        return voxels[:voxel_num], coors[:voxel_num], num_points_per_voxel[:voxel_num]
 
 
 voxelization = _VoxelizationFn.apply

@@ -480,11 +480,37 @@ def gen_sparse_unet():
     save('voxel_mixer.npz', **arrays2)
 
 
+def gen_hard_voxelize():
+    """Hard voxelization (max_num_points / max_voxels set) from the reference's own compiled C++
+    (voxelization_cpu.cpp:43-142 through oracle/_ref/voxel_layer_ref.so): more voxels than max_voxels (later ones
+    dropped), more points per voxel than max_points, points outside the range (clamped in this fork)."""
+    mod = build_ref.load()
+    assert mod is not None
+    g = torch.Generator().manual_seed(17)
+    arrays = {}
+    for tag, n, vs, rng, max_points, max_voxels in (('dense', 6000, [0.5, 0.5, 4.0], [0, -10, -3, 20, 10, 1], 5, 800),
+                                                    ('all_kept', 3000, [0.32, 0.32, 6.0], [-10, -10, -2, 10, 10, 4], 32, 20000)):
+        lo = torch.tensor(rng[:3]) - 1.0
+        hi = torch.tensor(rng[3:]) + 1.0
+        pts = torch.rand(n, 4, generator=g) * torch.cat([hi - lo, torch.ones(1)]) + torch.cat([lo, torch.zeros(1)])
+        voxels = torch.zeros(max_voxels, max_points, 4)
+        coors = torch.zeros(max_voxels, 3, dtype=torch.int32)
+        num = torch.zeros(max_voxels, dtype=torch.int32)
+        nv = mod.hard_voxelize(pts, voxels, coors, num, vs, rng, max_points, max_voxels, 3)
+        arrays[f'in::{tag}::points'] = t2n(pts)
+        arrays[f'in::{tag}::params'] = np.asarray(vs + rng + [max_points, max_voxels], dtype=np.float64)
+        arrays[f'out::{tag}::voxels'] = t2n(voxels[:nv])
+        arrays[f'out::{tag}::coors'] = t2n(coors[:nv])
+        arrays[f'out::{tag}::num_points'] = t2n(num[:nv])
+    save('hard_voxelize.npz', **arrays)
+
+
 def main():
     assert ref_loader.available(), 'the reference tree is required'
     build_ref.build()
     ref = ref_loader.load_reference()
     gen_voxelize()
+    gen_hard_voxelize()
     gen_input_layer(ref)
     gen_sst_block(ref)
     gen_sst_v1(ref)

@@ -199,3 +199,22 @@ def test_scatter_full_size_properties():
     mx = plan.reduce(feats, 'max')
     assert bool((mx[plan.coors_map.long()] >= feats).all())
     assert 85000 < plan.num_voxels < 95000
+
+
+@pytest.mark.parametrize('tag', ['dense', 'all_kept'])
+def test_hard_voxelize_matches_reference_golden(tag):
+    """Voxelization with max_num_points / max_voxels set (voxelize.py:47-58): bit-exact against the reference's
+    compiled C++ (tests/golden/hard_voxelize.npz)"""
+    import sst_amd
+    g = load_golden('hard_voxelize.npz')
+    prm = g[f'in::{tag}::params']
+    vs, rng, mp, mv = prm[:3].tolist(), prm[3:9].tolist(), int(prm[9]), int(prm[10])
+    pts = torch.from_numpy(g[f'in::{tag}::points']).to(DEV)
+    voxels, coors, num = sst_amd.voxelization(pts, vs, rng, mp, mv)
+    assert coors.dtype == torch.int32 and num.dtype == torch.int32 and voxels.shape[1:] == (mp, 4)
+    np.testing.assert_array_equal(coors.cpu().numpy(), g[f'out::{tag}::coors'])
+    np.testing.assert_array_equal(num.cpu().numpy(), g[f'out::{tag}::num_points'])
+    np.testing.assert_array_equal(voxels.cpu().numpy(), g[f'out::{tag}::voxels'])
+    layer = sst_amd.Voxelization(vs, rng, mp, (mv, mv)).eval()
+    v2, c2, n2 = layer(pts)
+    assert torch.equal(v2, voxels) and torch.equal(c2, coors) and torch.equal(n2, num)

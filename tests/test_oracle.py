@@ -385,3 +385,16 @@ def test_spconv_maxpool_oracle_matches_reference_golden(tag):
     assert (y >= 0).all() and (y == 0).any()
     dx = O.indice_maxpool_backward(x, y, gout_ref[perm], pairs, num)
     np.testing.assert_allclose(dx, g[f'out::{tag}::pool_grad_in'], atol=1e-5)
+
+
+@pytest.mark.parametrize('tag', ['dense', 'all_kept'])
+def test_hard_voxelize_oracle_matches_reference_golden(tag):
+    """hard voxelization restated without the sequential loop against the reference's compiled C++ (golden):
+    voxel order by first appearance, max_voxels cut, first max_points points per voxel."""
+    g = load_golden('hard_voxelize.npz')
+    prm = g[f'in::{tag}::params']
+    vs, rng, mp, mv = prm[:3].tolist(), prm[3:9].tolist(), int(prm[9]), int(prm[10])
+    voxels, coors, num = voxel_oracle.hard_voxelize(g[f'in::{tag}::points'], vs, rng, mp, mv)
+    np.testing.assert_array_equal(coors, g[f'out::{tag}::coors'])
+    np.testing.assert_array_equal(num, g[f'out::{tag}::num_points'])
+    np.testing.assert_array_equal(voxels, g[f'out::{tag}::voxels'])
