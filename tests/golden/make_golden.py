@@ -168,6 +168,41 @@ def gen_sst_block(ref):
         save(f'sst_block_{tag}.npz', **arrays)
 
 
+def gen_sst_bev(ref):
+    """The output side of SSTv2 (a14): recover_bev + attached dilated convolutions + BN2d + ReLU (sst_v2.py:86-92,
+    139-197), with a 48 x 48 canvas so that the dense output stays a small fixture; also with conv_shortcut."""
+    layer = ref.input_layer_v2.SSTInputLayerV2(drop_info=(DROP_TRAIN, DROP_TEST), window_shape=(12, 12, 1),
+                                               sparse_shape=(48, 48, 1), shuffle_voxels=False, debug=True, mute=True)
+    layer.eval()
+    for tag, shortcut in (('plain', False), ('shortcut', True)):
+        g = torch.Generator().manual_seed(4)
+        rows = []
+        for b in range(2):
+            xy = torch.randint(0, 48, (500, 2), generator=g)
+            c = torch.cat([torch.full((500, 1), b), torch.zeros(500, 1, dtype=torch.long), xy[:, 1:2], xy[:, 0:1]], 1)
+            rows.append(torch.unique(c, dim=0))
+        coors = torch.cat(rows, 0)
+        m = coors.size(0)
+        torch.manual_seed(5)
+        net = ref.sst_v2.SSTv2(d_model=[32], nhead=[2], num_blocks=1, dim_feedforward=[64], output_shape=[48, 48],
+                               num_attached_conv=2, conv_in_channel=32, conv_out_channel=32, debug=True, to_bev=True,
+                               conv_shortcut=shortcut)
+        net.train()
+        feats = torch.randn(m, 32, generator=g).requires_grad_(True)
+        info = layer(feats, coors.int(), 2)
+        bev = net(info)[0]
+        gout = torch.randn(bev.shape, generator=g)
+        (bev * gout).sum().backward()
+        arrays = {'in::voxel_coors': t2n(coors).astype(np.int32), 'in::voxel_feats': t2n(feats),
+                  'in::grad_out': t2n(gout), 'out::bev': t2n(bev), 'out::grad_in': t2n(feats.grad)}
+        arrays.update(state_to_np(net.state_dict()))   # after the step: BN running statistics updated once
+        for n_, p_ in net.named_parameters():
+            if n_.startswith('conv_layer'):
+                arrays['grad::' + n_] = t2n(p_.grad)
+        print(tag, 'voxels', m, 'bev', tuple(bev.shape))
+        save(f'sst_bev_{tag}.npz', **arrays)
+
+
 def gen_sst_v1(ref):
     """Reference SSTInputLayer (v1) + SSTv1 (2 blocks of d=64 / 4 heads, no attached conv), eval mode, fp32."""
     g = torch.Generator().manual_seed(8)
@@ -513,6 +548,7 @@ def main():
     gen_hard_voxelize()
     gen_input_layer(ref)
     gen_sst_block(ref)
+    gen_sst_bev(ref)
     gen_sst_v1(ref)
     gen_dynamic_vfe(ref)
     gen_scatter_vfe(ref)

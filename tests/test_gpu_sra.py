@@ -210,3 +210,34 @@ def test_sst_v1_matches_reference_golden():
     with torch.no_grad():
         bev2 = net((vf, ind_list, {k: v for k, v in info.items() if not k.startswith('sra_plan')}))[0]
     assert float((bev2 - bev).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('tag,shortcut', [('plain', False), ('shortcut', True)])
+def test_sstv2_bev_and_attached_convs_match_reference_golden(tag, shortcut):
+    """the output side of SSTv2 (a14): recover_bev + two attached dilated convolutions with naiveSyncBN2d + ReLU
+    (sst_v2.py:86-92, 139-197), training mode, against the reference's own SSTv2 (tests/golden/sst_bev_*.npz):
+    dense canvas, input gradient, convolution weight gradients."""
+    import sst_amd
+    g = load_golden(f'sst_bev_{tag}.npz')
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[32], nhead=[2], num_blocks=1, dim_feedforward=[64],
+                                      output_shape=[48, 48], num_attached_conv=2, conv_in_channel=32,
+                                      conv_out_channel=32, debug=True, to_bev=True, conv_shortcut=shortcut))
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (48, 48, 1), shuffle_voxels=False, debug=True,
+                                    mute=True)
+    layer.eval()
+    feats = torch.from_numpy(g['in::voxel_feats']).to(DEV).requires_grad_(True)
+    info = layer(feats, torch.from_numpy(g['in::voxel_coors']).to(DEV), 2)
+    bev = net(info)[0]
+    assert tuple(bev.shape) == (2, 32, 48, 48)
+    err = np.abs(bev.detach().cpu().numpy() - g['out::bev']).max()
+    assert err < TOL * max(1.0, float(np.abs(g['out::bev']).max())), err
+    (bev * torch.from_numpy(g['in::grad_out']).to(DEV)).sum().backward()
+    e = np.abs(feats.grad.cpu().numpy() - g['out::grad_in']).max()
+    assert e < TOL * 5 * max(1.0, float(np.abs(g['out::grad_in']).max())), e
+    params = dict(net.named_parameters())
+    for key in [k for k in g if k.startswith('grad::')]:
+        got = params[key[6:]].grad.cpu().numpy()
+        assert np.abs(got - g[key]).max() < TOL * 5 * max(1.0, float(np.abs(g[key]).max())), key
