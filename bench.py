@@ -94,19 +94,117 @@ def allreduce_grads(params, world):
     return flat
 
 
-def cpu_baseline(points_per_frame, num_blocks):
-    from oracle.cpu_pipeline import CpuSSTBackbone
-    torch.manual_seed(0)
-    net = CpuSSTBackbone(VOXEL_SIZE, PC_RANGE, DROP_TRAIN, num_blocks=num_blocks)
-    pts = make_cloud(points_per_frame, 0, 'cpu')
-    t0 = time.perf_counter()
-    out = net([pts])
-    out.sum().backward()
-    dt = time.perf_counter() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 frame ({points_per_frame} points -> {out.size(0)} voxels), {num_blocks} SRA blocks, '
-                      f'fwd+bwd once, {dt:.1f} s; CPU port of the reference path (padded windows + '
-                      'nn.MultiheadAttention, oracle/cpu_pipeline.py)'}
+def gpu_forward_sorted(model, frames):
+    """Forward of the GPU pipeline without the voxel shuffle, rows re-ordered to the reference's sorted-unique voxel
+    order: (features [M, C] on the host, int64 voxel keys [M] ascending)."""
+    from oracle.cpu_pipeline import voxel_sort_key
+    me = model.middle_encoder
+    seen = {}
+    orig_apply, orig_shuffle = me.apply_plan, me.shuffle_voxels
+
+    def spy(plan, feats):
+        info = orig_apply(plan, feats)
+        seen['coors'] = info['voxel_coors']
+        return info
+
+    me.apply_plan, me.shuffle_voxels = spy, False
+    try:
+        with torch.no_grad():
+            out = model(frames)
+    finally:
+        me.apply_plan, me.shuffle_voxels = orig_apply, orig_shuffle
+    key = voxel_sort_key(seen['coors'].cpu())
+    order = torch.argsort(key)
+    return out.detach().cpu()[order], key[order]
+
+
+def _median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def cpu_reference_leg(model, frame_cpu, num_blocks, budget_s=75.0):
+    """The CPU port of the reference data flow (oracle/cpu_pipeline.py) beside the GPU path, on rank 0 at N = 1:
+      * `cpu_baseline`: frames/s of forward + backward on the bench frame itself - one untimed warm-up pass on the
+        20 000-point cloud of BASELINE.json configs[0] (thread pools, allocator), then timed passes on the headline
+        frame until `budget_s` of CPU time is spent (at most 3), median; plus configs[0] itself (20 000 points,
+        voxelize + DynamicScatter VFE + 1 SRA block, forward only; 1 warm-up + 3 timed, median) with all host
+        threads and with one thread;
+      * `parity`: the GPU forward of the SAME network (weights copied) on the SAME frame against the first timed
+        CPU forward: kept-voxel sets equal, max abs feature error (north-star bar: 1e-3)."""
+    from oracle.cpu_pipeline import CpuSSTBackbone, load_pipeline_weights, voxel_sort_key
+    threads = torch.get_num_threads()
+    net = load_pipeline_weights(CpuSSTBackbone(VOXEL_SIZE, PC_RANGE, DROP_TRAIN, num_blocks=num_blocks).train(), model)
+    small = make_cloud(20000, 7, 'cpu')
+    net([small]).sum().backward()                                 # warm-up, untimed
+    times, out_first = [], None
+    spent = 0.0
+    while len(times) < 3 and (not times or spent + times[-1] < budget_s):
+        net.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        out = net([frame_cpu])
+        out.sum().backward()
+        times.append(time.perf_counter() - t0)
+        spent += times[-1]
+        if out_first is None:
+            out_first = out.detach()
+    med = _median(times)
+
+    # parity at the headline configuration
+    out_g, key_g = gpu_forward_sorted(model, [frame_cpu.to(next(model.parameters()).device)])
+    key_c = voxel_sort_key(net.last_voxel_coors)   # rows of the CPU output are in sorted-unique voxel order
+    voxels_equal = bool(key_c.numel() == key_g.numel() and torch.equal(key_c, key_g))
+    parity = {'voxels_equal': voxels_equal, 'voxels': int(key_g.numel()),
+              'max_abs_err': float((out_g - out_first).abs().max()) if voxels_equal else None,
+              'tolerance': 1e-3,
+              'what': 'GPU forward (fp32, no voxel shuffle, training-mode drop + batch-norm statistics) vs the CPU '
+                      'port of the reference data flow with the same weights on the bench frame, all '
+                      f'{num_blocks} SRA blocks; integer side = set of kept voxel coordinates'}
+
+    # BASELINE.json configs[0]: 20k points, DynamicScatter voxelize + 1 SRA block on CPU, forward only
+    net1 = CpuSSTBackbone(VOXEL_SIZE, PC_RANGE, DROP_TRAIN, num_blocks=1).train()
+
+    def config0(nthreads):
+        torch.set_num_threads(nthreads)
+        try:
+            with torch.no_grad():
+                net1([small])
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    net1([small])
+                    ts.append(time.perf_counter() - t0)
+        finally:
+            torch.set_num_threads(threads)
+        return round(1.0 / _median(ts), 4)
+
+    base = {'value': round(1.0 / med, 5), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{len(times)} timed pass(es) of 1 frame ({frame_cpu.size(0)} points -> {out_first.size(0)} '
+                      f'voxels), {num_blocks} SRA blocks, forward + backward, after one untimed warm-up pass on a '
+                      f'20 000-point cloud; median {med:.1f} s (passes: ' + ', '.join(f'{t:.1f}' for t in times) +
+                      ' s); CPU port of the reference path (padded windows + nn.MultiheadAttention, '
+                      'oracle/cpu_pipeline.py)',
+            'config0_20k_points_1_block_fwd': {'frames_per_s_all_threads': config0(threads),
+                                               'frames_per_s_1_thread': config0(1), 'threads': threads,
+                                               'protocol': '1 warm-up + 3 timed, median'}}
+    return base, parity
+
+
+def self_launch(n_ranks):
+    """Re-run this script under torch.distributed.run with one process per GPU of this node."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: needed by RCCL on this driver stack
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_ranks}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -127,6 +225,11 @@ def main():
     ap.add_argument('--no-gemm-tuning', action='store_true',
                     help='do not let PyTorch TunableOp pick the hipBLASLt/rocBLAS solution of each dense GEMM shape')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # launched as plain `python bench.py --gpus N`: start one rank per GPU ourselves, the way the reference's
+        # tools/dist_train.sh:7-9 does (torch.distributed.launch --nproc_per_node=$GPUS); rank 0 prints the JSON line
+        sys.exit(self_launch(args.gpus))
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -274,13 +377,13 @@ def main():
                                    f'{args.blocks} SRA blocks, ' + ('fwd only' if args.fwd_only else 'fwd+bwd'),
                        'frames_per_gpu': args.frames_per_gpu, 'points_per_frame': args.points,
                        'voxels_per_gpu': n_voxels, 'parallelism': f'dp{world}',
-                       'grad_sync': 'one flat RCCL all-reduce' if world > 1 else 'none'},
+                       'grad_sync': ('one flat all-reduce over ' + ('RCCL' if args.backend == 'nccl' else args.backend)) if world > 1 else 'none'},
             'roofline': roofline,
         }
         if fwd_only is not None:
             res['forward_only'] = fwd_only
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(args.points, args.blocks)
+            res['cpu_baseline'], res['parity'] = cpu_reference_leg(model, frames[0].cpu(), args.blocks)
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))

@@ -120,8 +120,35 @@ class CpuSSTBackbone(nn.Module):
         pts = torch.cat(points_list)
         vf, vc = self.vfe(pts, coors)
         keep, shifts = self.plan(vc)
+        self.last_voxel_coors = vc[keep]      # (b, z, y, x) of the rows of the output, sorted-unique order
         x = vf[keep]
         for i, layer in enumerate(self.layers):
             pos, levels = shifts[i % 2]
             x = layer(x, pos, levels)
         return x
+
+
+def load_pipeline_weights(cpu, gpu_pipeline):
+    """Copy the parameters of a bench.Pipeline (reference parameter names: ``vfe_layers.{i}.linear / norm``,
+    ``block_list.{i}.encoder_list.{0,1}.*``) into a CpuSSTBackbone, so both run the same network."""
+    with torch.no_grad():
+        for i, layer in enumerate(gpu_pipeline.voxel_encoder.vfe_layers):
+            cpu.vfe.linears[i].weight.copy_(layer.linear.weight.cpu())
+            cpu.vfe.norms[i].weight.copy_(layer.norm.weight.cpu())
+            cpu.vfe.norms[i].bias.copy_(layer.norm.bias.cpu())
+        k = 0
+        for block in gpu_pipeline.backbone.block_list:
+            for enc in block.encoder_list:
+                dst = cpu.layers[k]
+                k += 1
+                dst.self_attn.load_state_dict({n: p.cpu() for n, p in enc.win_attn.self_attn.state_dict().items()})
+                for name in ('linear1', 'linear2', 'norm1', 'norm2'):
+                    getattr(dst, name).load_state_dict({n: p.cpu() for n, p in getattr(enc, name).state_dict().items()})
+        assert k == len(cpu.layers)
+    return cpu
+
+
+def voxel_sort_key(coors):
+    """(b, z, y, x) -> one int64 key whose order is the sorted-unique voxel order of the reference"""
+    c = coors.long()
+    return ((c[:, 0] * 64 + c[:, 1]) * 4096 + c[:, 2]) * 4096 + c[:, 3]

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict_
           arg = (int32_t)row;
         }
       }
-      out[e] = acc;
+      out[e] = end > beg ? acc : 0.f;  // a group without points reads 0, as torch_scatter.scatter_max fills it
       if (argmax != nullptr) argmax[e] = arg;
     } else {
       float acc = 0.f;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
       const float cnt = (float)(end - beg);
       acc.x = acc.x / cnt, acc.y = acc.y / cnt, acc.z = acc.z / cnt, acc.w = acc.w / cnt;
     }
+    if (end <= beg) acc = make_float4(0.f, 0.f, 0.f, 0.f);  // empty group: 0 (torch_scatter.scatter_max's fill)
     *(float4*)(out + g * c + ch) = acc;
     if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + ch) = make_int4(a0, a1, a2, a3);
   }

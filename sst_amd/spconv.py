@@ -16,6 +16,7 @@ reference's GPU path (``torch::_unique`` of the linear indices, spconv_ops.h:128
 input row (the reference's CPU order; its GPU order is left to atomics).  3-D int32 indices and fp32 features only.
 """
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -108,8 +109,19 @@ def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, o
 
 
 class Rulebook(object):
-    """in2out [K, n], out2in [K, m] int32 maps (-1 = no partner) + the reference's pair lists."""
-    __slots__ = ('in2out', 'out2in', 'pairs', 'num', 'n', 'm', 'kvol', 'density', 'total_pairs')
+    """in2out [K, n], out2in [K, m] int32 maps (-1 = no partner) + the reference's pair lists.
+
+    The pair-list tensor carries its Rulebook as an attribute (it rides along wherever the reference passes
+    ``indice_pairs`` around); the Rulebook refers back to the tensor only weakly, so the pair lists and the two dense
+    maps (~4 K n int32 each) are released by reference counting as soon as the tensor is, not by the cycle collector."""
+    __slots__ = ('in2out', 'out2in', '_pairs_ref', 'num', 'n', 'm', 'kvol', 'density', 'total_pairs')
+
+    @property
+    def pairs(self):
+        t = self._pairs_ref()
+        if t is None:
+            raise RuntimeError('sst_amd.spconv: the indice_pairs tensor of this rulebook has been released')
+        return t
 
 
 def _i32(vals):
@@ -123,16 +135,17 @@ def _finish_rulebook(in2out, kvol, n, m, dev):
     rb.out2in = torch.empty((kvol, m), dtype=torch.int32, device=dev)
     _lib.check(lib.sst_spconv_invert_map_i32(_lib.ptr(in2out), kvol, n, m, _lib.ptr(rb.out2in), _lib.stream_ptr()),
                'sst_spconv_invert_map_i32')
-    rb.pairs = torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
+    pairs = torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
     rb.num = torch.zeros(kvol, dtype=torch.int32, device=dev)
     ws = _lib.workspace(lib.sst_spconv_pair_lists_workspace_bytes(kvol, n), dev)
-    _lib.check(lib.sst_spconv_pair_lists_i32(_lib.ptr(in2out), kvol, n, _lib.ptr(rb.pairs), _lib.ptr(rb.num),
+    _lib.check(lib.sst_spconv_pair_lists_i32(_lib.ptr(in2out), kvol, n, _lib.ptr(pairs), _lib.ptr(rb.num),
                                              _lib.ptr(ws), _lib.stream_ptr()), 'sst_spconv_pair_lists_i32')
-    rb.pairs._sst_rulebook = rb  # rides along wherever the reference passes indice_pairs around
+    rb._pairs_ref = weakref.ref(pairs)
+    pairs._sst_rulebook = rb
     # populated share of the (offset, row) slots, read once per rulebook: picks the kernel form of every convolution on it
     rb.total_pairs = int(rb.num.sum().item()) if n > 0 else 0
     rb.density = rb.total_pairs / max(1, kvol * max(n, m))
-    return rb
+    return rb, pairs
 
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
@@ -160,8 +173,8 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     lib = _lib.load()
     in2out = torch.empty((kvol, n), dtype=torch.int32, device=dev)
     if n == 0:
-        rb = _finish_rulebook(in2out, kvol, 0, 0, dev)
-        return indices, rb.pairs, rb.num
+        rb, pairs = _finish_rulebook(in2out, kvol, 0, 0, dev)
+        return indices, pairs, rb.num
     if subm:
         plan = K.unique_rows(indices, [0, 0, 0, 0], [int(batch_size)] + out_shape, invalid_if_negative=0)
         if plan.m != n:
@@ -170,8 +183,8 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
                                          _lib.ptr(plan.ukeys), _lib.ptr(plan.perm), _lib.ptr(in2out),
                                          _lib.stream_ptr())
         _lib.check(rc, 'sst_spconv_subm_map_i32')
-        rb = _finish_rulebook(in2out, kvol, n, n, dev)
-        return indices, rb.pairs, rb.num
+        rb, pairs = _finish_rulebook(in2out, kvol, n, n, dev)
+        return indices, pairs, rb.num
     rows = torch.empty((kvol * n + 1, 4), dtype=torch.int32, device=dev)
     rc = lib.sst_spconv_candidates_i32(_lib.ptr(indices), n, _i32(spatial_shape), _i32(out_shape), _i32(ksize),
                                        _i32(stride), _i32(padding), _i32(dilation), int(bool(transpose)),
@@ -182,8 +195,8 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     outids = K.unpack_unique_rows(plan, torch.int32, first=1, count=m)
     _lib.check(lib.sst_spconv_inverse_to_map_i32(_lib.ptr(plan.inverse), kvol * n, _lib.ptr(in2out),
                                                  _lib.stream_ptr()), 'sst_spconv_inverse_to_map_i32')
-    rb = _finish_rulebook(in2out, kvol, n, m, dev)
-    return outids, rb.pairs, rb.num
+    rb, pairs = _finish_rulebook(in2out, kvol, n, m, dev)
+    return outids, pairs, rb.num
 
 
 def rulebook_of(indice_pairs, indice_pair_num, num_out):
@@ -198,7 +211,10 @@ def rulebook_of(indice_pairs, indice_pair_num, num_out):
     src, dst = indice_pairs[:, 0][valid].long(), indice_pairs[:, 1][valid]
     in2out = torch.full((kvol, n), -1, dtype=torch.int32, device=dev)
     in2out[koff, src] = dst
-    return _finish_rulebook(in2out, kvol, n, int(num_out), dev)
+    rb, _ = _finish_rulebook(in2out, kvol, n, int(num_out), dev)
+    rb._pairs_ref = weakref.ref(indice_pairs)   # the caller's lists (same pairs per offset, possibly another order)
+    indice_pairs._sst_rulebook = rb
+    return rb
 
 
 def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None):
@@ -207,6 +223,8 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None):
     # U-Net: 64-channel levels 0.29-0.82 ms against 0.39-1.08 ms, 128 / 256-channel levels 1.46 / 0.90 against 0.85 / 0.64)
     form = 2 if (cout <= 64 or (density is not None and density < 0.2)) else 1
     x = x if x.stride(1) == 1 else x.contiguous()
+    if x.size(0) == 0:   # nothing to gather from (e.g. the data gradient of a layer whose output side is empty)
+        return torch.zeros((rows, cout), dtype=torch.float32, device=x.device)
     y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     if rows > 0:
         rc = lib.sst_spconv_gather_gemm_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, weight3.size(0),
@@ -216,7 +234,7 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None):
     return y
 
 
-def _wgrad(x, dy, rb, x_side, shape):
+def _wgrad(x, dy, rb, pairs, x_side, shape):
     lib = _lib.load()
     kvol, cin, cout = rb.kvol, x.size(1), dy.size(1)
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
@@ -224,7 +242,7 @@ def _wgrad(x, dy, rb, x_side, shape):
     x = x if x.stride(1) == 1 else x.contiguous()
     dy = dy if dy.stride(1) == 1 else dy.contiguous()
     rc = lib.sst_spconv_wgrad_f32(_lib.ptr(x), x.stride(0) if x.size(0) else cin, _lib.ptr(dy),
-                                  dy.stride(0) if dy.size(0) else cout, _lib.ptr(rb.pairs), rb.n, rb.total_pairs, x_side,
+                                  dy.stride(0) if dy.size(0) else cout, _lib.ptr(pairs), rb.n, rb.total_pairs, x_side,
                                   _lib.ptr(rb.num), kvol, cin, cout, _lib.ptr(dw), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, 'sst_spconv_wgrad_f32')
     return dw.view(shape)
@@ -258,10 +276,10 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     w3t = w3.transpose(1, 2).contiguous()
     if inverse:
         input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3t, False, w3.size(1), rb.density)
-        filters_bp = _wgrad(features, out_bp, rb, 1, filters.shape)
+        filters_bp = _wgrad(features, out_bp, rb, indice_pairs, 1, filters.shape)
     else:
         input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3t, False, w3.size(1), rb.density)
-        filters_bp = _wgrad(features, out_bp, rb, 0, filters.shape)
+        filters_bp = _wgrad(features, out_bp, rb, indice_pairs, 0, filters.shape)
     return input_bp, filters_bp
 
 
@@ -286,6 +304,8 @@ def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice
     x = features if features.stride(1) == 1 else features.contiguous()
     y = out_features if out_features.stride(1) == 1 else out_features.contiguous()
     dy = out_bp if out_bp.stride(1) == 1 else out_bp.contiguous()
+    if y.size(0) == 0 or x.size(0) == 0:   # empty output side: no input voxel has a partner
+        return torch.zeros_like(x)
     dx = torch.empty_like(x)
     c = x.size(1)
     rc = _lib.load().sst_spconv_maxpool_bwd_f32(_lib.ptr(x), x.stride(0) if x.size(0) else c, _lib.ptr(y),

@@ -150,12 +150,27 @@ def unique_with_plan(coors, return_counts=False):
     return new_coors, unq_inv
 
 
-def _plan_from_inverse(unq_inv):
+def _plan_from_inverse(unq_inv, num_groups):
     plan = getattr(unq_inv, '_sst_plan', None)
-    if plan is not None:
+    if plan is not None and plan.m == num_groups:
         return plan
-    # an inverse produced elsewhere (e.g. torch.unique): regroup by the inverse ids themselves
-    plan = K.unique_rows(unq_inv.reshape(-1, 1).contiguous())
+    # an inverse produced elsewhere (torch.unique, a slice / clone of ours): regroup by the ids themselves.  Like
+    # torch_scatter (output sized by the number of groups, absent ids keep an empty row) every id 0..num_groups-1
+    # gets a group: one sentinel row per id is appended, so the CSR has exactly num_groups groups in id order and
+    # the sentinels (positions >= N) are dropped from the permutation again.
+    n = unq_inv.numel()
+    ids = torch.cat([unq_inv.reshape(-1), torch.arange(num_groups, device=unq_inv.device, dtype=unq_inv.dtype)])
+    full = K.unique_rows(ids.reshape(-1, 1).contiguous(), [0], [max(int(num_groups), 1)])
+    assert full.m == num_groups, 'unq_inv holds an id outside [0, len(new_coors))'
+    keep = full.perm < n                                   # stable sort: a group's sentinel is its last member
+    plan = K.UniquePlan()
+    plan.n, plan.m, plan.ncols = n, num_groups, 1
+    plan.mins, plan.extents = full.mins, full.extents
+    plan.perm = full.perm[keep].contiguous()
+    plan.inverse = full.inverse[:n].contiguous()
+    plan.offsets = (full.offsets[:num_groups + 1]
+                    - torch.arange(num_groups + 1, device=ids.device, dtype=torch.int32)).contiguous()
+    plan.ukeys = full.ukeys
     _attach_plan(unq_inv, plan)
     return plan
 
@@ -175,7 +190,7 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
     else:
         assert new_coors is not None, \
             'please pass new_coors for interface consistency, caller: {}'.format(traceback.extract_stack()[-2][2])
-        plan = _plan_from_inverse(unq_inv)
+        plan = _plan_from_inverse(unq_inv, new_coors.size(0))
         unq_cnt = plan.counts().long() if min_points > 0 else None
 
     if min_points > 0:

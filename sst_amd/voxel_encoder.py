@@ -126,9 +126,13 @@ class DynamicVFE(nn.Module):
             raise NotImplementedError('image fusion layers are outside the LiDAR hot path')
 
     def _grid_zyx(self):
-        # the same round() the reference's canvas uses (voxel_encoder.py:198-203)
+        """Extents of the voxel key space: the grid the voxelizer itself clamps to (fp32 ceil, voxelize.hip), which for
+        ranges that are no multiple of the voxel size is one larger than the round() of the reference's canvas
+        (voxel_encoder.py:198-203); the larger of the two, so that no clamped coordinate can alias another key."""
         r = self.point_cloud_range
-        return [round((r[5] - r[2]) / self.vz), round((r[4] - r[1]) / self.vy), round((r[3] - r[0]) / self.vx)]
+        gx, gy, gz = K.voxel_grid((self.vx, self.vy, self.vz), list(r))
+        return [max(gz, round((r[5] - r[2]) / self.vz)), max(gy, round((r[4] - r[1]) / self.vy)),
+                max(gx, round((r[3] - r[0]) / self.vx))]
 
     def map_voxel_center_to_point(self, pts_coors, voxel_mean, voxel_coors, plan=None):
         """voxel feature of every point.  The reference scatters voxel ids into a dense zero-initialised

@@ -125,7 +125,7 @@ def gen_input_layer(ref):
         save(f'input_layer_{tag}.npz', **out)
 
 
-def gen_sst_block(ref):
+def gen_sst_block(ref, only=None):
     """One BasicShiftBlockV2 (2 encoder layers) through the reference SSTv2, fp32, with gradients.
     'std' is the real SST-base geometry (d=128, 8 heads, FFN 256); the variants use d=64 / 4 heads to keep
     the fixtures small."""
@@ -135,8 +135,12 @@ def gen_sst_block(ref):
     layer.eval()
     variants = (('std', 128, 8, 256, dict()), ('cosine', 64, 4, 128, dict(cosine=True, tau_min=0.01)),
                 ('cosine_ns', 64, 4, 128, dict(cosine=True, tau_min=0.01, non_shared_tau=True)),
-                ('prenorm', 64, 4, 128, dict(post_norm=False)))
+                ('prenorm', 64, 4, 128, dict(post_norm=False)),
+                # FSD's SST encoder (configs/fsd/fsd_waymoD1_1x_sst_encoder.py): batch norm instead of LayerNorm
+                ('bn_cosine', 64, 4, 128, dict(use_bn=True, cosine=True, tau_min=0.01)))
     for tag, d, h, ffn, layer_cfg in variants:
+        if only is not None and tag not in only:
+            continue
         g = torch.Generator().manual_seed(2)
         coors = make_voxel_coors(g, 170, 2, crowded=True)
         m = coors.size(0)
@@ -544,6 +548,9 @@ def main():
     assert ref_loader.available(), 'the reference tree is required'
     build_ref.build()
     ref = ref_loader.load_reference()
+    if len(sys.argv) > 2 and sys.argv[1] == 'sst_block':     # regenerate single block variants only
+        gen_sst_block(ref, only=sys.argv[2:])
+        return
     gen_voxelize()
     gen_hard_voxelize()
     gen_input_layer(ref)

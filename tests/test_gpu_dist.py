@@ -1,0 +1,102 @@
+"""GPU: the N > 1 path of bench.py on ONE device — two ranks (gloo, both on cuda:0) run bench.Pipeline on one frame each,
+naiveSyncBN exchanges its statistics (ops/norm.py:9-24), the gradients go through bench.allreduce_grads; the result
+must equal the single-rank run on the concatenated two-frame batch (frames shard over ranks, the only
+exchanges are the BN statistics and the gradient all-reduce).  Also: `python bench.py --gpus 2` launches its own ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_POINTS = 20000      # the same number of points on both ranks: naiveSyncBN averages per-rank means unweighted
+BLOCKS = 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dev):
+    import bench
+    torch.manual_seed(0)
+    model = bench.Pipeline(BLOCKS).to(dev).train()
+    model.middle_encoder.shuffle_voxels = False
+    return bench, model
+
+
+def _bn_stats(model):
+    return [t.detach().cpu().clone() for layer in model.voxel_encoder.vfe_layers
+            for t in (layer.norm.running_mean, layer.norm.running_var)]
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        bench, model = _build('cuda:0')
+        params = [p for p in model.parameters() if p.requires_grad]
+        frame = bench.make_cloud(N_POINTS, 100 + rank, 'cuda:0')
+        out = model([frame])
+        out.sum().backward()
+        bench.allreduce_grads(params, world)
+        ret[rank] = dict(out_sum=float(out.double().sum()), n=int(out.size(0)),
+                         grads=[p.grad.detach().cpu().clone() for p in params], bn=_bn_stats(model))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_the_concatenated_batch():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == 2
+    # the averaged gradients are bit-identical on both ranks
+    for a, b in zip(ret[0]['grads'], ret[1]['grads']):
+        assert torch.equal(a, b)
+    # single rank, both frames in one batch
+    bench, model = _build('cuda:0')
+    params = [p for p in model.parameters() if p.requires_grad]
+    frames = [bench.make_cloud(N_POINTS, 100 + r, 'cuda:0') for r in range(world)]
+    out = model(frames)
+    out.sum().backward()
+    assert out.size(0) == ret[0]['n'] + ret[1]['n']
+    tot = float(out.double().sum())
+    assert abs(tot - (ret[0]['out_sum'] + ret[1]['out_sum'])) <= 1e-4 * max(1.0, abs(tot))
+    for p, g2 in zip(params, ret[0]['grads']):
+        ref = p.grad.cpu()
+        scale = max(1e-3, float(ref.abs().max()))
+        err = float((world * g2 - ref).abs().max()) / scale     # all-reduce averages, the joint batch sums
+        assert err < 2e-3, f'{tuple(p.shape)}: relative gradient error {err}'
+    for a, b in zip(_bn_stats(model), ret[0]['bn']):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the script starts its ranks itself
+    (the reference: tools/dist_train.sh:7-9) and rank 0 prints the JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-device', '--backend',
+                        'gloo', '--steps', '2', '--warmup', '1', '--points', '20000', '--blocks', '1',
+                        '--no-gemm-tuning', '--no-forward-only-leg'], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['parallelism'] == 'dp2' and res['value'] > 0
+    assert res['config']['grad_sync'].startswith('one flat')

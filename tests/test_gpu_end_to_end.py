@@ -7,24 +7,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+GRAD_TOL_VFE = 1e-2
 
 
 def _copy_weights(gpu, cpu):
-    """bench.Pipeline (reference parameter names) -> oracle.cpu_pipeline.CpuSSTBackbone"""
-    with torch.no_grad():
-        for i, layer in enumerate(gpu.voxel_encoder.vfe_layers):
-            cpu.vfe.linears[i].weight.copy_(layer.linear.weight.cpu())
-            cpu.vfe.norms[i].weight.copy_(layer.norm.weight.cpu())
-            cpu.vfe.norms[i].bias.copy_(layer.norm.bias.cpu())
-        k = 0
-        for block in gpu.backbone.block_list:
-            for enc in block.encoder_list:
-                dst = cpu.layers[k]
-                k += 1
-                dst.self_attn.load_state_dict({n: p.cpu() for n, p in enc.win_attn.self_attn.state_dict().items()})
-                for name in ('linear1', 'linear2', 'norm1', 'norm2'):
-                    getattr(dst, name).load_state_dict({n: p.cpu() for n, p in getattr(enc, name).state_dict().items()})
-        assert k == len(cpu.layers)
+    from oracle.cpu_pipeline import load_pipeline_weights
+    load_pipeline_weights(cpu, gpu)
 
 
 @pytest.mark.parametrize('n_points,blocks', [(6000, 1), (30000, 2)])
@@ -67,19 +55,51 @@ def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks):
     inv[order] = torch.arange(order.numel())
     (out_g * wsum_g[inv].to(DEV)).sum().backward()
     (out_c * wsum_g).sum().backward()
-    checks = [(gpu.voxel_encoder.vfe_layers[0].linear.weight, cpu.vfe.linears[0].weight),
-              (gpu.voxel_encoder.vfe_layers[1].linear.weight, cpu.vfe.linears[1].weight),
-              (gpu.backbone.block_list[0].encoder_list[0].win_attn.self_attn.in_proj_weight,
-               cpu.layers[0].self_attn.in_proj_weight),
-              (gpu.backbone.block_list[-1].encoder_list[1].linear2.weight, cpu.layers[-1].linear2.weight)]
-    # relative to the largest entry of each gradient.  The looser bound than on the features covers the argmax /
-    # ReLU decisions of the VFE (max pooling over the points of a voxel, BN + ReLU): an activation within rounding
-    # of a tie takes the other branch on the other device and moves whole gradient contributions.
-    errs = []
-    for pg, pc in checks:
+    checks = {'vfe0.linear': (gpu.voxel_encoder.vfe_layers[0].linear.weight, cpu.vfe.linears[0].weight),
+              'vfe1.linear': (gpu.voxel_encoder.vfe_layers[1].linear.weight, cpu.vfe.linears[1].weight),
+              'vfe1.norm': (gpu.voxel_encoder.vfe_layers[1].norm.weight, cpu.vfe.norms[1].weight),
+              'layer0.in_proj': (gpu.backbone.block_list[0].encoder_list[0].win_attn.self_attn.in_proj_weight,
+                                 cpu.layers[0].self_attn.in_proj_weight),
+              'layer0.linear1': (gpu.backbone.block_list[0].encoder_list[0].linear1.weight, cpu.layers[0].linear1.weight),
+              'last.norm2': (gpu.backbone.block_list[-1].encoder_list[1].norm2.weight, cpu.layers[-1].norm2.weight),
+              'last.linear2': (gpu.backbone.block_list[-1].encoder_list[1].linear2.weight, cpu.layers[-1].linear2.weight)}
+    # relative to the largest entry of each gradient
+    errs = {}
+    for name, (pg, pc) in checks.items():
         scale = max(1.0, pc.grad.abs().max().item())
-        errs.append((pg.grad.cpu() - pc.grad).abs().max().item() / scale)
-    assert max(errs) < 1e-2, f'relative parameter gradient errors {errs}'
+        errs[name] = (pg.grad.cpu() - pc.grad).abs().max().item() / scale
+    import json
+    import os
+    log_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(log_dir):
+        with open(os.path.join(log_dir, f'e2e_grad_errs_{n_points}.json'), 'w') as f:
+            json.dump({'feature_err': err, 'grad_errs': errs}, f)
+    # the transformer's parameters sit behind smooth functions only: the north-star bar applies as it stands
+    for name in ('layer0.in_proj', 'layer0.linear1', 'last.norm2', 'last.linear2'):
+        assert errs[name] < 1e-3, f'relative parameter gradient errors {errs}'
+    # the VFE's parameters sit behind max pooling over the points of a voxel and BN + ReLU (discontinuous gradients)
+    # and behind batch statistics over 1e5 points (fp64 moments on the GPU, fp32 in the CPU port)
+    for name in ('vfe0.linear', 'vfe1.linear', 'vfe1.norm'):
+        assert errs[name] < GRAD_TOL_VFE, f'relative parameter gradient errors {errs}'
+
+
+def test_headline_config_forward_parity():
+    """BASELINE.json configs[1] itself: 116 000 points -> ~90 k voxels, 6 SRA blocks, forward; the GPU pipeline against
+    the CPU port of the reference data flow with the same weights (what bench.py reports as `parity`)."""
+    import bench
+    from oracle.cpu_pipeline import CpuSSTBackbone, load_pipeline_weights, voxel_sort_key
+    torch.manual_seed(0)
+    gpu = bench.Pipeline(6).to(DEV).train()
+    cpu = load_pipeline_weights(CpuSSTBackbone(bench.VOXEL_SIZE, bench.PC_RANGE, bench.DROP_TRAIN, num_blocks=6).train(), gpu)
+    frame = bench.make_cloud(116000, 0, 'cpu')
+    out_g, key_g = bench.gpu_forward_sorted(gpu, [frame.to(DEV)])
+    with torch.no_grad():
+        out_c = cpu([frame])
+    key_c = voxel_sort_key(cpu.last_voxel_coors)
+    assert out_g.size(0) > 85000
+    assert torch.equal(key_g, key_c), 'different sets of kept voxels'
+    err = float((out_g - out_c).abs().max())
+    assert err < 1e-3, f'headline-config feature error {err}'
 
 
 def test_fsd_path_chain_runs_forward_and_backward():

@@ -60,6 +60,17 @@ def test_scatter_v2_min_points_and_foreign_inverse():
     nf3, _, _ = sst_amd.scatter_v2(feat.to(DEV), coors.to(DEV), 'max', unq_inv=i3.to(DEV), new_coors=u3.to(DEV))
     ref = torch.full((u3.size(0), 8), float('-inf')).scatter_reduce(0, i3.view(-1, 1).expand(-1, 8), feat, 'amax')
     assert torch.equal(nf3.cpu(), ref)
+    # ... also when ids are missing from it (a slice of the points): torch_scatter sizes the output by the number of
+    # groups and leaves the rows of absent ids at 0 (sst_ops.py:172-177)
+    part = (i3 % 3) != 0
+    i4 = i3[part].clone()
+    for mode, red in (('max', 'amax'), ('sum', 'sum')):
+        nf4, nc4, _ = sst_amd.scatter_v2(feat[part].to(DEV), coors[part].to(DEV), mode, unq_inv=i4.to(DEV),
+                                         new_coors=u3.to(DEV))
+        assert nf4.shape == (u3.size(0), 8) and nc4.size(0) == u3.size(0)
+        ref4 = torch.zeros((u3.size(0), 8)).scatter_reduce(0, i4.view(-1, 1).expand(-1, 8), feat[part], red,
+                                                           include_self=False)
+        assert torch.allclose(nf4.cpu(), ref4, atol=1e-5)
 
 
 def test_sir_matches_reference_golden():

@@ -116,7 +116,8 @@ def _load_block(g, layer_cfg):
 @pytest.mark.parametrize('impl', [0, 1])
 @pytest.mark.parametrize('tag,layer_cfg', [('std', dict()), ('cosine', dict(cosine=True, tau_min=0.01)),
                                            ('cosine_ns', dict(cosine=True, tau_min=0.01, non_shared_tau=True)),
-                                           ('prenorm', dict(post_norm=False))])
+                                           ('prenorm', dict(post_norm=False)),
+                                           ('bn_cosine', dict(use_bn=True, cosine=True, tau_min=0.01))])
 def test_sst_block_matches_reference_golden(tag, layer_cfg, impl, fused):
     import sst_amd
     g = load_golden(f'sst_block_{tag}.npz')

@@ -114,16 +114,27 @@ def test_dynamic_scatter_reference_test_construction():
     inv_c = -torch.ones((200, 3), dtype=torch.int32, device=DEV)
     ef, ec = dsmax(torch.rand(200, 3, device=DEV), inv_c)
     assert ef.shape == (0, 3) and ec.shape == (0, 3)
-    # brute-force reference (:56-65), subsampled voxels to keep the CPU side fast
+    # the reference test's brute-force construction (:56-65) for EVERY voxel, vectorised: per-voxel mean in float64
+    # and per-voxel max over the points whose coordinate row equals the voxel's.  Bar: max exact,
+    # mean within 1e-5 relative (to the summands' magnitude, 50, where the mean itself is close to zero)
     fm, cm = dsmean(feats.to(DEV), coors.to(DEV))
     fx, cx = dsmax(feats.to(DEV), coors.to(DEV))
-    ref_coors = coors[coors.min(dim=-1).values >= 0].unique(dim=0, sorted=True)
+    valid = coors.min(dim=-1).values >= 0
+    ref_coors, inv = coors[valid].unique(dim=0, sorted=True, return_inverse=True)
     np.testing.assert_array_equal(cm.cpu().numpy(), ref_coors.numpy())
     np.testing.assert_array_equal(cx.cpu().numpy(), ref_coors.numpy())
+    m = ref_coors.size(0)
+    fv = feats[valid]
+    cnt = torch.zeros(m, dtype=torch.float64).index_add_(0, inv, torch.ones(inv.numel(), dtype=torch.float64))
+    ref_mean = torch.zeros((m, 3), dtype=torch.float64).index_add_(0, inv, fv.double()) / cnt[:, None]
+    ref_max = torch.full((m, 3), -float('inf')).scatter_reduce_(0, inv[:, None].expand(-1, 3), fv, 'amax')
+    assert torch.equal(fx.cpu(), ref_max)
+    np.testing.assert_allclose(fm.cpu().double().numpy(), ref_mean.numpy(), rtol=1e-5, atol=1e-5 * 50)
+    # and the literal per-voxel loop of the reference test on a subsample
     fm, fx = fm.cpu(), fx.cpu()
-    for vi in range(0, ref_coors.size(0), 97):
+    for vi in range(0, m, 397):
         sel = feats[(coors == ref_coors[vi]).all(dim=-1)]
-        assert torch.allclose(fm[vi], sel.mean(0), atol=1e-2)
+        assert torch.allclose(fm[vi], sel.mean(0), rtol=1e-5, atol=5e-4)
         assert torch.equal(fx[vi], sel.max(0).values)
 
 
