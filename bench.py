@@ -35,6 +35,7 @@ DROP_TEST = {0: {'max_tokens': 30, 'drop_range': (0, 30)}, 1: {'max_tokens': 60,
              2: {'max_tokens': 100, 'drop_range': (60, 100)}, 3: {'max_tokens': 144, 'drop_range': (100, 100000)}}
 HBM_PEAK_GBS = 8000.0
 SRA_BYTES_PER_TOKEN = 4 * 128 * 4 + 8   # Q,K,V read + O write (fp32, d=128) + index: SURVEY.md §8d(5)
+SRA_BWD_BYTES_PER_TOKEN = 8 * 128 * 4 + 8   # Q,K,V,O,dO read + dQ,dK,dV written + index
 
 
 def make_cloud(n, seed, device):
@@ -217,7 +218,7 @@ def main():
     ap.add_argument('--blocks', type=int, default=6)
     ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--time-sra-bwd', action='store_true', help='also bracket the SRA backward launches with events')
+    ap.add_argument('--no-time-sra-bwd', action='store_true', help='do not attach events to the SRA backward launches')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
     ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL, default) | gloo (dev check of the N>1 path on one GPU)')
@@ -289,10 +290,10 @@ def main():
 
     sink = []
     K.EVENT_SINK = sink
-    # HIP events bound to every 5th SRA forward launch of the timed region (12 launches per step, both window shifts
-    # get sampled); the backward kernels are timed only on request: every pair of marks drains the queue for ~5 us
+    # HIP events bound to every 5th SRA forward launch and every 5th one-pass SRA backward launch of the timed region
+    # (12 launches of each per step, both window shifts get sampled)
     K.EVENT_STRIDE = 5
-    K.EVENT_KINDS = ('sra_fwd', 'sra_bwd') if args.time_sra_bwd else ('sra_fwd',)
+    K.EVENT_KINDS = ('sra_fwd',) if (args.fwd_only or args.no_time_sra_bwd) else ('sra_fwd', 'sra_bwd')
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -350,15 +351,26 @@ def main():
                     'avg_launch_ms': round(ms, 4), 'launches_timed': launches,
                     'sampling': 'every 5th forward launch of the timed region'}
         if bwd is not None:
-            roofline['sra_bwd_avg_launch_ms'] = round(bwd[0], 4)
+            # the other half of what `value` times: the one-pass backward kernel (dQ, dK, dV from one read of
+            # Q, K, V, O, dO), same event method, and forward + backward of the attention core together
+            bms, btokens, blaunches = bwd
+            bach = SRA_BWD_BYTES_PER_TOKEN * btokens / (bms * 1e-3) / 1e9
+            roofline['sra_bwd'] = {'kernel': 'sra_bwd_fused_k<NTMAX> (one launch per sst_sra_attn_bwd_f32 call)',
+                                   'achieved': round(bach, 1), 'frac': round(bach / HBM_PEAK_GBS, 4), 'traffic': None,
+                                   'algorithmic_bytes_per_launch': int(SRA_BWD_BYTES_PER_TOKEN * btokens),
+                                   'avg_launch_ms': round(bms, 4), 'launches_timed': blaunches}
+            both = (SRA_BYTES_PER_TOKEN * tokens + SRA_BWD_BYTES_PER_TOKEN * btokens) / ((ms + bms) * 1e-3) / 1e9
+            roofline['sra_fwd_plus_bwd'] = {'achieved': round(both, 1), 'frac': round(both / HBM_PEAK_GBS, 4)}
         # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately by
         # tools/collect_sra_traffic.sh on the same workload and committed under profiles/): per launch, like `achieved`
         tpath = os.path.join(ROOT, 'profiles', 'latest_sra_traffic.json')
         if os.path.exists(tpath) and args.points == 116000 and args.frames_per_gpu == 1:
             try:
-                tr = json.load(open(tpath))['sra_fwd_wave_k']
-                roofline['traffic'] = int(tr['hbm_bytes_per_launch'])
+                tj = json.load(open(tpath))
+                roofline['traffic'] = int(tj['sra_fwd_wave_k']['hbm_bytes_per_launch'])
                 roofline['traffic_source'] = 'profiles/latest_sra_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
+                if 'sra_bwd' in roofline and 'sra_bwd_fused_k' in tj:
+                    roofline['sra_bwd']['traffic'] = int(tj['sra_bwd_fused_k']['hbm_bytes_per_launch'])
             except Exception:
                 pass
 

@@ -205,15 +205,18 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
  *   impl: 0 = auto: register-resident MFMA kernels (wave = window x head, no LDS) for windows <= 144
  *             tokens, generic VALU kernel above that;
  *         1 = generic VALU kernel for every window (validation path);
- *         2 = LDS-staged MFMA kernels (K,V of a 4-head group in LDS; the first implementation).
+ *         2 = LDS-staged MFMA kernels (K,V of a 4-head group in LDS; the first implementation);
+ *         3 = forward as 0; backward as two register-resident launches (dQ, then dK / dV), kept for comparison.
  * ---------------------------------------------------------------------------------------------- */
 int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk,
                          int64_t ldv, const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows,
                          int n_heads, float scale, int max_tokens, int impl, float* d_o, int64_t ldo,
                          float* d_lse, void* stream);
 /* Backward: given dO, recomputes P from (Q,K,LSE) and writes dQ, dK, dV for every token row listed in
- * d_tok (other rows untouched).  n_tokens = number of rows of the [M, *] tensors.
- * Workspace: sst_sra_attn_bwd_workspace_bytes(n_tokens, n_heads) (holds rowsum(dO*O) per token, head). */
+ * d_tok (other rows untouched).  n_tokens = number of rows of the [M, *] tensors.  impl 0: ONE pass over
+ * Q, K, V, O, dO per (window, head) wave (dQ, dK and dV from the same S / dP tiles; 8 x 64 B per token and
+ * head of traffic); d_workspace may be NULL for it.
+ * Workspace (impl 3): sst_sra_attn_bwd_workspace_bytes(n_tokens, n_heads) (rowsum(dO*O) per token, head). */
 int64_t sst_sra_attn_bwd_workspace_bytes(int64_t n_tokens, int n_heads);
 int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o,
                          const float* d_do, const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv,
@@ -322,6 +325,9 @@ void* sst_event_create(void);
 void sst_event_destroy(void* ev);
 float sst_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop`; < 0 on error */
 int sst_sra_attn_profile_next_fwd(void* start, void* stop);
+/* the same for the one-pass backward kernel (the next sst_sra_attn_bwd_f32 call with impl 0); both hooks are
+ * one-shot and local to the calling thread */
+int sst_sra_attn_profile_next_bwd(void* start, void* stop);
 
 /* ------------------------------------------------------------------------------------------------
  * (§8 f2) Connected components of the graph "same sample and xy distance < dist" over n points — FSD's

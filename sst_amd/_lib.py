@@ -87,6 +87,7 @@ _SIGNATURES = {
     'sst_event_destroy': (None, [c_ptr]),
     'sst_event_elapsed_ms': (ctypes.c_float, [c_ptr, c_ptr]),
     'sst_sra_attn_profile_next_fwd': (c_i32, [c_ptr, c_ptr]),
+    'sst_sra_attn_profile_next_bwd': (c_i32, [c_ptr, c_ptr]),
     'sst_bn_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_bn_stats_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_bn_act_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),

@@ -52,7 +52,9 @@ constexpr int kGC = 64;     // channels per workgroup (kGH * kHD)
 #else
 #define SST_SRA_BLOCK(b, n) ((int)(b))
 #endif
-hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;  // sst_sra_attn_profile_next_fwd
+// one-shot measurement hooks (sst_sra_attn_profile_next_fwd / _bwd): per calling thread, consumed by the next launch
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+thread_local hipEvent_t g_prof_bwd_start = nullptr, g_prof_bwd_stop = nullptr;
 constexpr int kWH = SST_WAVE_HEADS;  // heads (= waves) per workgroup of the register-resident kernels
 constexpr int kRS = 68;     // LDS row stride (floats)
 constexpr int kMaxTilesMfma = 9;
@@ -877,6 +879,226 @@ __global__ __launch_bounds__(64 * kWH) void sra_bwd_dkv_k(const float* __restric
 #undef SST_DKV_ARGS
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA backward, register-resident, ONE pass ("wave = window x head"): dQ, dK and dV from one read of Q, K, V, O, dO.
+//   S = Q K^T and dP = dO V^T are computed once per (query tile, key tile) pair in the orientation row = query,
+//   col = key.  P and dS in that D layout are directly the A operands of dV += P^T dO and dK += dS^T Q (contraction
+//   over the rows); dQ += dS K contracts over the columns and needs the tile transposed: it makes a round trip
+//   through a wave-private 16 x 16 LDS tile (one ds_write_b128, four ds_read_b32, row stride 20 floats: both
+//   conflict-free), hidden behind the eight dV / dK MFMAs of the pair.  The operands that are contracted over tokens
+//   (K for dQ; Q and dO for dK / dV) are needed as column fragments: they are read from wave-private LDS images of
+//   the row fragments (K once per window, Q / dO once per query tile) instead of being fetched a second time.
+//   20 MFMAs per tile pair (the two-kernel form: 12 + 16), every input row is read once, nothing is recomputed.
+//   K / V row fragments and the dK / dV accumulators of ALL key tiles stay in VGPRs (16 per tile); the kernel is
+//   built for 2 waves per SIMD.  The tile count is a template parameter of the body (exact for 1..7 tiles: the
+//   key-tile loop is straight-line code without guards, so the scheduler can overlap neighbouring pairs).
+//   Tokens sit transposed inside their 16-token tile (slot p <-> token (p >> 2) + 4 (p & 3)) as in the forward kernel:
+//   MFMA k-step r then covers the consecutive tokens 4r..4r+3 and the padded steps of the last key tile are skipped.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTS = 20;  // row stride (floats) of the LDS tiles
+
+__host__ __device__ constexpr int sra_fused_lds_floats_per_wave(int nt) { return (nt * 16 + 3 * 16) * kTS; }
+
+template <int NT, bool EXACT>
+__device__ __forceinline__ void sra_bwd_fused_body(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
+    const float* __restrict__ dO, const float* __restrict__ LSE, uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t ldo,
+    uint32_t lddo, const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H, float scale,
+    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, uint32_t lddq, uint32_t lddk, uint32_t lddv,
+    float* __restrict__ lds) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int sig = (c >> 2) + 4 * (c & 3);  // token held by tile slot c
+  const int head = hg * kWH + (threadIdx.x >> 6);
+  const uint32_t hoff = head * kHD;
+  float* Kimg = lds;                 // [NT * 16][kTS]  K rows, tile slot order
+  float* Qimg = Kimg + NT * 16 * kTS;  // [16][kTS]   Q rows of the current query tile
+  float* Gimg = Qimg + 16 * kTS;       // [16][kTS]   dO rows of the current query tile
+  float* Dimg = Gimg + 16 * kTS;       // [16][kTS]   dS tile, [key slot][query slot]
+  constexpr int NTK = (NT * 16 + 63) / 64;
+  int tk[NTK];
+#pragma unroll
+  for (int i = 0; i < NTK; ++i) {
+    const int p = i * 64 + lane;
+    tk[i] = tok[beg + (p < t ? p : t - 1)];  // padded positions repeat the last token: every load is unconditional
+  }
+  auto tok_at = [&](int i, int within) -> uint32_t {  // token id of window position 16 i + within
+    int sel = tk[0];
+#pragma unroll
+    for (int u = 1; u < NTK; ++u) sel = ((i >> 2) == u) ? tk[u] : sel;
+    return (uint32_t)__shfl(sel, (i & 3) * 16 + within, 64);
+  };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float4 kf[NT], vf[NT];
+  f32x4 dk[NT], dv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    dk[j] = zero4;
+    dv[j] = zero4;
+    if (EXACT || j < nt) {
+      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + sig, 64);
+      kf[j] = ldg4(K, krow * ldk + hoff + 4 * g);
+      vf[j] = ldg4(V, krow * ldv + hoff + 4 * g);
+    } else {
+      kf[j] = vf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // first query tile
+  struct qtile {
+    float4 qf, gf, of;
+    float lse;
+  };
+  auto load_tile = [&](int i) -> qtile {
+    qtile q;
+    const uint32_t row = tok_at(i, sig);
+    q.qf = ldg4(Q, row * ldq + hoff + 4 * g);
+    q.gf = ldg4(dO, row * lddo + hoff + 4 * g);
+    q.of = ldg4(O, row * ldo + hoff + 4 * g);
+    q.lse = LSE[row * (uint32_t)H + head];
+    return q;
+  };
+  qtile cur = load_tile(0);
+  // K image (column fragments of K for dQ += dS K)
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+    if (EXACT || j < nt) *(float4*)(Kimg + (j * 16 + c) * kTS + 4 * g) = kf[j];
+  const float s2 = scale * kLog2e;
+  const int last_steps = (t - 16 * (nt - 1) + 3) >> 2;  // k-steps of the last tile that hold a real token (1..4)
+  const float* kcol = Kimg + (4 * g) * kTS + c;          // + (16 j + r) * kTS : K[key slot 4g + r of tile j][d = c]
+  const float* qcol = Qimg + (4 * g) * kTS + c;
+  const float* gcol = Gimg + (4 * g) * kTS + c;
+  float* drow = Dimg + c * kTS + 4 * g;                  // write: [key slot c][query slots 4g .. 4g+3]
+  const float* dcol = Dimg + (4 * g) * kTS + c;          // read:  [key slot 4g + r][query slot c]
+
+  for (int i = 0; i < nt; ++i) {
+    const float4 qf = cur.qf, gf = cur.gf;
+    float dd = gf.x * cur.of.x + gf.y * cur.of.y + gf.z * cur.of.z + gf.w * cur.of.w;
+    dd = rows4_sum(dd);                       // rowsum(dO * O) of query slot c, on every lane of the column
+    const float lse_c = cur.lse * kLog2e;
+    *(float4*)(Qimg + c * kTS + 4 * g) = qf;
+    *(float4*)(Gimg + c * kTS + 4 * g) = gf;
+    cur = load_tile(i + 1 < nt ? i + 1 : i);  // prefetch of the next query tile
+    float qc[4], gc[4], lse2[4], dd4[4], rmask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      qc[r] = qcol[r * kTS];
+      gc[r] = gcol[r * kTS];
+      lse2[r] = __shfl(lse_c, 4 * g + r, 64);  // lane (0, 4g + r) holds query slot 4g + r
+      dd4[r] = __shfl(dd, 4 * g + r, 64);
+      rmask[r] = (i * 16 + g + 4 * r) < t ? 1.f : 0.f;  // padded queries (last tile only)
+    }
+    f32x4 dq0 = zero4, dq1 = zero4, dq2 = zero4, dq3 = zero4;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (EXACT || j < nt) {
+        f32x4 s, dp;
+        mfma4x2(qf, kf[j], s, gf, vf[j], dp);  // S / dP [query slot 4g+r][key slot c]
+        f32x4 pe, ds;
+        const bool last_j = EXACT ? (j == NT - 1) : (j == nt - 1);
+        const float cmask = (last_j && (j * 16 + sig) >= t) ? 0.f : 1.f;  // padded keys (last tile only)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(s[r], s2, -lse2[r])) * rmask[r];
+          if (!EXACT || j == NT - 1) p *= cmask;
+          pe[r] = p;
+          ds[r] = p * (dp[r] - dd4[r]) * scale;
+        }
+        *(f32x4*)drow = ds;  // transposed hand-over of the dS tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dv[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pe[r], gc[r], dv[j], 0, 0, 0);  // dV += P^T dO
+          dk[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], qc[r], dk[j], 0, 0, 0);  // dK += dS^T Q
+        }
+        float dst[4], kc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[r] = dcol[r * kTS];                  // dS[query slot c][key slot 4g + r]
+          kc[r] = kcol[(j * 16 + r) * kTS];        // K [key slot 4g + r][d = c]
+        }
+        const int steps = last_j ? last_steps : 4;  // wave-uniform; compile-time 4 except in the last tile
+        dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[0], kc[0], dq0, 0, 0, 0);
+        if (steps > 1) dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[1], kc[1], dq1, 0, 0, 0);
+        if (steps > 2) dq2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[2], kc[2], dq2, 0, 0, 0);
+        if (steps > 3) dq3 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[3], kc[3], dq3, 0, 0, 0);
+      }
+    }
+    // D layout: value r = dQ[query slot 4g + r = token 16 i + g + 4 r][d = c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t orow = tok_at(i, g + 4 * r);  // cross-lane read: all lanes active
+      if (i * 16 + g + 4 * r < t) dQ[orow * lddq + hoff + c] = (dq0[r] + dq1[r]) + (dq2[r] + dq3[r]);
+    }
+  }
+  // D layout: value r = d{K,V}[key slot 4g + r = token 16 j + g + 4 r][d = c]
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (EXACT || j < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t krow = tok_at(j, g + 4 * r);
+        if (j * 16 + g + 4 * r < t) {
+          dK[krow * lddk + hoff + c] = dk[j][r];
+          dV[krow * lddv + hoff + c] = dv[j][r];
+        }
+      }
+    }
+  }
+}
+
+template <int NTMAX>
+__global__ __launch_bounds__(64 * kWH, 2) void sra_bwd_fused_k(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
+    const float* __restrict__ dO, const float* __restrict__ LSE, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+    int64_t lddo, const int32_t* __restrict__ tok, const int32_t* __restrict__ winoff, int n_groups, int H, float scale,
+    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
+  const int w = bid / n_groups;
+  const int hg = bid - w * n_groups;
+  const int beg = winoff[w];
+  const int t = winoff[w + 1] - beg;
+  const int nt = (t + 15) >> 4;
+  if (nt < 1 || nt > NTMAX) return;  // > NTMAX: the generic kernel owns this window
+  float* lds = smem + (threadIdx.x >> 6) * sra_fused_lds_floats_per_wave(NTMAX);
+#define SST_FUSED_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, lds
+  switch (nt) {
+    case 1: sra_bwd_fused_body<1, true>(SST_FUSED_ARGS); break;
+    case 2: sra_bwd_fused_body<2, true>(SST_FUSED_ARGS); break;
+    case 3: sra_bwd_fused_body<3, true>(SST_FUSED_ARGS); break;
+    case 4: sra_bwd_fused_body<4, true>(SST_FUSED_ARGS); break;
+    case 5: sra_bwd_fused_body<5, true>(SST_FUSED_ARGS); break;
+    case 6: sra_bwd_fused_body<6, true>(SST_FUSED_ARGS); break;
+    case 7: sra_bwd_fused_body<7, true>(SST_FUSED_ARGS); break;
+    default:
+      if constexpr (NTMAX > 7) sra_bwd_fused_body<NTMAX, false>(SST_FUSED_ARGS);
+      break;
+  }
+#undef SST_FUSED_ARGS
+}
+
+template <int NTMAX>
+int launch_bwd_fused(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* tok,
+                     const int32_t* winoff, int64_t n_windows, int H, float scale, float* dQ, float* dK, float* dV,
+                     int64_t lddq, int64_t lddk, int64_t lddv, hipStream_t st) {
+  const int n_groups = H / kWH;
+  const size_t lds = (size_t)kWH * sra_fused_lds_floats_per_wave(NTMAX) * sizeof(float);
+  SST_HIP(hipFuncSetAttribute((const void*)sra_bwd_fused_k<NTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((unsigned)(n_windows * n_groups));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof_bwd_start != nullptr && g_prof_bwd_stop != nullptr) {
+    e0 = g_prof_bwd_start;
+    e1 = g_prof_bwd_stop;
+    g_prof_bwd_start = g_prof_bwd_stop = nullptr;  // one-shot, as for the forward kernel
+  }
+  if (e0 != nullptr)  // kernel-exact start / stop timestamps on the launch stream
+    hipExtLaunchKernelGGL(sra_bwd_fused_k<NTMAX>, grid, dim3(64 * kWH), lds, st, e0, e1, 0, Q, K, V, O, dO, LSE, ldq, ldk,
+                          ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
+  else
+    hipLaunchKernelGGL(sra_bwd_fused_k<NTMAX>, grid, dim3(64 * kWH), lds, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo,
+                       tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
+  return SST_OK;
+}
+
 template <int NTMAX>
 int launch_bwd_wave(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
                     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* tok,
@@ -947,7 +1169,7 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
                          int64_t ldv, const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int n_heads,
                          float scale, int max_tokens, int impl, float* d_o, int64_t ldo, float* d_lse,
                          void* stream) {
-  if (n_windows < 0 || n_heads < 1 || impl < 0 || impl > 2) return SST_ERR_ARG;
+  if (n_windows < 0 || n_heads < 1 || impl < 0 || impl > 3) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
   if (!d_q || !d_k || !d_v || !d_tok || !d_winoff || !d_o || !d_lse) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -996,7 +1218,7 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
                          const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int64_t n_tokens,
                          int n_heads, float scale, int max_tokens, int impl, float* d_dq, float* d_dk, float* d_dv,
                          int64_t lddq, int64_t lddk, int64_t lddv, void* d_workspace, void* stream) {
-  if (n_windows < 0 || n_tokens < 0 || n_heads < 1 || impl < 0 || impl > 2) return SST_ERR_ARG;
+  if (n_windows < 0 || n_tokens < 0 || n_heads < 1 || impl < 0 || impl > 3) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
   if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_tok || !d_winoff || !d_dq || !d_dk || !d_dv)
     return SST_ERR_ARG;
@@ -1021,7 +1243,7 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
       if (cap_tiles > 2 && (rc = launch_bwd_variant<4>(SST_BWD_ARGS(2)))) return rc;
       if (cap_tiles > 4 && (rc = launch_bwd_variant<7>(SST_BWD_ARGS(4)))) return rc;
       if (cap_tiles > 7 && (rc = launch_bwd_variant<9>(SST_BWD_ARGS(7)))) return rc;
-    } else {          // register-resident kernels (default): two launches, tile class chosen per workgroup
+    } else if (impl == 3) {  // register-resident kernels, two launches (dQ, then dK / dV): kept for comparison
       if (!d_workspace) return SST_ERR_ARG;
       if (cap_tiles <= 7)
         rc = launch_bwd_wave<7>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
@@ -1029,6 +1251,14 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
       else
         rc = launch_bwd_wave<9>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
                                 n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, (float*)d_workspace, st);
+      if (rc) return rc;
+    } else {          // register-resident one-pass kernel (default): one launch, tile count chosen per workgroup
+      if (cap_tiles <= 7)
+        rc = launch_bwd_fused<7>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
+                                 n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+      else
+        rc = launch_bwd_fused<9>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
+                                 n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
       if (rc) return rc;
     }
 #undef SST_BWD_ARGS
@@ -1064,6 +1294,12 @@ float sst_event_elapsed_ms(void* start, void* stop) {
 int sst_sra_attn_profile_next_fwd(void* start, void* stop) {
   g_prof_start = (hipEvent_t)start;
   g_prof_stop = (hipEvent_t)stop;
+  return SST_OK;
+}
+
+int sst_sra_attn_profile_next_bwd(void* start, void* stop) {
+  g_prof_bwd_start = (hipEvent_t)start;
+  g_prof_bwd_stop = (hipEvent_t)stop;
   return SST_OK;
 }
 

@@ -332,32 +332,27 @@ class _KernelEvents(object):
             pass
 
 
-EVENT_STRIDE = 1        # bench.py: time every EVENT_STRIDE-th forward launch (the marks cost ~5 us of queue drain each)
+EVENT_STRIDE = 1        # bench.py: time every EVENT_STRIDE-th launch of a kind (the marks cost a few us of queue drain)
 EVENT_KINDS = ('sra_fwd', 'sra_bwd')
-_event_counter = [0]
+_event_counter = {'sra_fwd': 0, 'sra_bwd': 0}
 
 
 def _bracket(kind, n_tokens, fn):
+    """Run ``fn`` (one C-ABI call that ends in one launch of the register-resident SRA kernel of ``kind``) with HIP
+    events attached to that launch itself (hipExtLaunchKernelGGL start / stop, armed through the library's one-shot
+    hooks): the interval is the kernel's own begin -> end on its stream."""
     if EVENT_SINK is None or kind not in EVENT_KINDS:
         return fn()
-    if kind == 'sra_fwd':
-        _event_counter[0] += 1
-        if (_event_counter[0] - 1) % EVENT_STRIDE != 0:
-            return fn()
-        # kernel-exact events attached to the launch itself
-        lib = _lib.load()
-        ke = _KernelEvents(lib)
-        lib.sst_sra_attn_profile_next_fwd(ke.start, ke.stop)
-        r = fn()
-        lib.sst_sra_attn_profile_next_fwd(None, None)  # disarm if the call took another kernel path
-        EVENT_SINK.append((kind, ke, ke, n_tokens))
-        return r
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
+    _event_counter[kind] += 1
+    if (_event_counter[kind] - 1) % EVENT_STRIDE != 0:
+        return fn()
+    lib = _lib.load()
+    arm = lib.sst_sra_attn_profile_next_fwd if kind == 'sra_fwd' else lib.sst_sra_attn_profile_next_bwd
+    ke = _KernelEvents(lib)
+    arm(ke.start, ke.stop)
     r = fn()
-    e1.record()
-    EVENT_SINK.append((kind, e0, e1, n_tokens))
+    arm(None, None)  # disarm if the call took another kernel path
+    EVENT_SINK.append((kind, ke, ke, n_tokens))
     return r
 
 

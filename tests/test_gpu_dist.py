@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_POINTS = 20000      # the same number of points on both ranks: naiveSyncBN averages per-rank means unweighted
 BLOCKS = 1
+GRAD_TOL = 2e-3
 
 
 def _free_port():
@@ -53,7 +54,7 @@ def _worker(rank, world, port, ret):
         out = model([frame])
         out.sum().backward()
         bench.allreduce_grads(params, world)
-        ret[rank] = dict(out_sum=float(out.double().sum()), n=int(out.size(0)),
+        ret[rank] = dict(out_sum=float(out.detach().abs().double().sum()), n=int(out.size(0)),
                          grads=[p.grad.detach().cpu().clone() for p in params], bn=_bn_stats(model))
     finally:
         dist.destroy_process_group()
@@ -75,13 +76,20 @@ def test_two_ranks_on_one_gpu_equal_the_concatenated_batch():
     out = model(frames)
     out.sum().backward()
     assert out.size(0) == ret[0]['n'] + ret[1]['n']
-    tot = float(out.double().sum())
-    assert abs(tot - (ret[0]['out_sum'] + ret[1]['out_sum'])) <= 1e-4 * max(1.0, abs(tot))
-    for p, g2 in zip(params, ret[0]['grads']):
+    tot = float(out.detach().abs().double().sum())       # (LayerNorm outputs: the plain sum is ~0)
+    assert abs(tot - (ret[0]['out_sum'] + ret[1]['out_sum'])) <= 1e-5 * tot
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    errs = {}
+    for n, p, g2 in zip(names, params, ret[0]['grads']):
         ref = p.grad.cpu()
         scale = max(1e-3, float(ref.abs().max()))
-        err = float((world * g2 - ref).abs().max()) / scale     # all-reduce averages, the joint batch sums
-        assert err < 2e-3, f'{tuple(p.shape)}: relative gradient error {err}'
+        errs[n] = float((world * g2 - ref).abs().max()) / scale     # all-reduce averages, the joint batch sums
+    log_dir = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(log_dir):
+        with open(os.path.join(log_dir, 'dist_grad_errs.json'), 'w') as f:
+            json.dump(errs, f, indent=1)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < GRAD_TOL, f'{worst}: relative gradient error {errs[worst]}'
     for a, b in zip(_bn_stats(model), ret[0]['bn']):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 

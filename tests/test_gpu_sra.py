@@ -32,7 +32,7 @@ SIZE_SETS = {
 }
 
 
-@pytest.mark.parametrize('impl', [0, 1, 2])
+@pytest.mark.parametrize('impl', [0, 1, 2, 3])
 @pytest.mark.parametrize('heads', [8, 12])
 @pytest.mark.parametrize('name', list(SIZE_SETS))
 def test_sra_core_forward_backward_vs_oracle(name, heads, impl):
@@ -76,6 +76,37 @@ def test_sra_core_packed_qk_and_strided_inputs():
     assert np.abs(qkg.grad[:, :128].cpu().numpy() - rdq).max() < TOL
     assert np.abs(qkg.grad[:, 128:].cpu().numpy() - rdk).max() < TOL
     assert np.abs(vg.grad.cpu().numpy() - rdv).max() < TOL
+
+
+def test_sra_core_backward_full_size_vs_oracle():
+    """M ~ 90k tokens (the bench workload's window-size mix): forward and the one-pass backward kernel against the
+    float64 oracle on every 25th window (the oracle walks windows one by one), and against the two-launch and the
+    generic kernels on every row."""
+    from sst_amd import kernels as K
+    from oracle import sst_oracle
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(20, 101, size=1500).tolist()
+    plan, tok, off, m = _plan_from_sizes(sizes, 5)
+    g = torch.Generator().manual_seed(6)
+    q, k, v, do = (torch.randn(m, 128, generator=g) for _ in range(4))
+    grads = {}
+    for impl in (0, 3, 1):
+        qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+        o = K.sra_attention(qg, kg, vg, plan, 8, impl=impl)
+        (o * do.to(DEV)).sum().backward()
+        grads[impl] = (o.detach().cpu().numpy(), qg.grad.cpu().numpy(), kg.grad.cpu().numpy(), vg.grad.cpu().numpy())
+    for impl in (3, 1):
+        for a, b in zip(grads[0], grads[impl]):
+            assert np.abs(a - b).max() < 1e-4
+    sel = np.arange(0, len(sizes), 25)
+    sub_tok = np.concatenate([tok[off[w]:off[w + 1]] for w in sel])
+    sub_off = np.concatenate([[0], np.cumsum([sizes[w] for w in sel])])
+    rows = np.sort(sub_tok)
+    ro = sst_oracle.sra_core(q.numpy(), k.numpy(), v.numpy(), sub_tok, sub_off, 8)
+    rdq, rdk, rdv = sst_oracle.sra_core_backward(q.numpy(), k.numpy(), v.numpy(), do.numpy(), sub_tok, sub_off, 8)
+    for name_, got, want in zip(('o', 'dq', 'dk', 'dv'), grads[0], (ro, rdq, rdk, rdv)):
+        e = np.abs(got[rows] - want[rows]).max()
+        assert e < 1e-4, f'{name_} max abs err {e} against the float64 oracle'
 
 
 def test_sra_core_properties_full_size():

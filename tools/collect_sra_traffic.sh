@@ -22,7 +22,7 @@ def avg(path, counter, pat):
             if r['Counter_Name'] == counter and re.search(pat, r['Kernel_Name'])]
     return sum(vals) / len(vals), len(vals)
 res = {}
-for kern in ('sra_fwd_wave_k', 'sra_bwd_dq_k', 'sra_bwd_dkv_k'):
+for kern in ('sra_fwd_wave_k', 'sra_bwd_fused_k'):
     f, nf = avg(out + '/fetch_counter_collection.csv', 'FETCH_SIZE', kern)
     w, nw = avg(out + '/write_counter_collection.csv', 'WRITE_SIZE', kern)
     res[kern] = {'FETCH_SIZE_KB_raw': f, 'WRITE_SIZE_KB_raw': w, 'launches_averaged': nf,

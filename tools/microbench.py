@@ -62,10 +62,12 @@ def bench_sra():
         o, lse = K._sra_fwd(qk[:, :128], qk[:, 128:], v, plan, 8, 0.25, 0)
         dqk = torch.empty_like(qk)
         dv = torch.empty_like(v)
-        for impl in (0, 2):
+        for impl in (0, 3, 0, 3, 2):   # 0: one-pass kernel, 3: two launches (dQ, dK / dV), 2: LDS-staged
             med, mn = timeit(lambda: K._sra_bwd(qk[:, :128], qk[:, 128:], v, o, lse, do, plan, 8, 0.25, impl,
                                                 dqk[:, :128], dqk[:, 128:], dv))
-            print(f'  bwd impl={impl}: median {med * 1e3:.1f} us (min {mn * 1e3:.1f})')
+            gbs = bench.SRA_BWD_BYTES_PER_TOKEN * m / (med * 1e-3) / 1e9
+            print(f'  bwd impl={impl}: median {med * 1e3:.1f} us (min {mn * 1e3:.1f}) -> {gbs:.0f} GB/s '
+                  f'({gbs / 80:.1f} % of 8 TB/s)')
 
 
 def bench_ln():
