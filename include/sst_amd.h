@@ -175,7 +175,8 @@ int sst_window_coors(const void* d_coors, int coor_is_i64, int64_t m, const int3
  *                           ascending inner; first M' entries valid
  *   d_winoff[s][m+1] int32 CSR offsets into d_tok[s] per non-empty window; first W_s+1 entries valid
  *   d_winlevel[s][m] int32 level of each non-empty window; first W_s valid
- *   d_counts   [8] int32   {M', W_0, W_1, 0...}
+ *   d_counts   [8] int32   {M', W_0, W_1, T_0, T_1, 0...}: survivors, windows per shift, largest surviving window
+ *                            population per shift (lets the caller pick the attention kernels' tile class)
  * Semantics follow the reference exactly: shift-1 levels are computed on the survivors of shift 0,
  * shift-0 levels are NOT recomputed after the second filter (sst_input_layer_v2.py:186-194).
  * Workspace: sst_region_batching_workspace_bytes(m).

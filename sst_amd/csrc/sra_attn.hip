@@ -28,6 +28,7 @@
 //     in-library cross-check.
 // Arithmetic intensity ~0.25*T flop/B puts the fp32 kernel at the HBM / fp32-MFMA ridge.
 #include <math.h>
+#include <stdlib.h>
 #include <hip/hip_ext.h>
 #include "common.h"
 
@@ -899,7 +900,7 @@ constexpr int kTS = 20;  // row stride (floats) of the LDS tiles
 
 __host__ __device__ constexpr int sra_fused_lds_floats_per_wave(int nt) { return (nt * 16 + 3 * 16) * kTS; }
 
-template <int NT, bool EXACT>
+template <int NT, bool EXACT, bool NOHOIST>
 __device__ __forceinline__ void sra_bwd_fused_body(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t ldo,
@@ -946,10 +947,12 @@ __device__ __forceinline__ void sra_bwd_fused_body(
   struct qtile {
     float4 qf, gf, of;
     float lse;
+    uint32_t row;
   };
   auto load_tile = [&](int i) -> qtile {
     qtile q;
     const uint32_t row = tok_at(i, sig);
+    q.row = row;
     q.qf = ldg4(Q, row * ldq + hoff + 4 * g);
     q.gf = ldg4(dO, row * lddo + hoff + 4 * g);
     q.of = ldg4(O, row * ldo + hoff + 4 * g);
@@ -970,10 +973,14 @@ __device__ __forceinline__ void sra_bwd_fused_body(
   const float* dcol = Dimg + (4 * g) * kTS + c;          // read:  [key slot 4g + r][query slot c]
 
   for (int i = 0; i < nt; ++i) {
+    // NOHOIST: the K column fragments are re-read from the LDS image for every tile pair (4 ds_read_b32) instead of
+    // being kept in 4 VGPRs per key tile across the whole loop - the price of a third wave per SIMD
+    if (NOHOIST) asm volatile("" ::: "memory");
     const float4 qf = cur.qf, gf = cur.gf;
     float dd = gf.x * cur.of.x + gf.y * cur.of.y + gf.z * cur.of.z + gf.w * cur.of.w;
     dd = rows4_sum(dd);                       // rowsum(dO * O) of query slot c, on every lane of the column
     const float lse_c = cur.lse * kLog2e;
+    const uint32_t qrow = cur.row;
     *(float4*)(Qimg + c * kTS + 4 * g) = qf;
     *(float4*)(Gimg + c * kTS + 4 * g) = gf;
     cur = load_tile(i + 1 < nt ? i + 1 : i);  // prefetch of the next query tile
@@ -1005,8 +1012,8 @@ __device__ __forceinline__ void sra_bwd_fused_body(
         *(f32x4*)drow = ds;  // transposed hand-over of the dS tile
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dv[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pe[r], gc[r], dv[j], 0, 0, 0);  // dV += P^T dO
-          dk[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], qc[r], dk[j], 0, 0, 0);  // dK += dS^T Q
+          dv[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[r], pe[r], dv[j], 0, 0, 0);  // dV^T += dO^T P
+          dk[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[r], ds[r], dk[j], 0, 0, 0);  // dK^T += Q^T dS
         }
         float dst[4], kc[4];
 #pragma unroll
@@ -1015,42 +1022,44 @@ __device__ __forceinline__ void sra_bwd_fused_body(
           kc[r] = kcol[(j * 16 + r) * kTS];        // K [key slot 4g + r][d = c]
         }
         const int steps = last_j ? last_steps : 4;  // wave-uniform; compile-time 4 except in the last tile
-        dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[0], kc[0], dq0, 0, 0, 0);
-        if (steps > 1) dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[1], kc[1], dq1, 0, 0, 0);
-        if (steps > 2) dq2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[2], kc[2], dq2, 0, 0, 0);
-        if (steps > 3) dq3 = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[3], kc[3], dq3, 0, 0, 0);
+        dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[0], dst[0], dq0, 0, 0, 0);  // dQ^T += K^T dS^T
+        if (steps > 1) dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[1], dst[1], dq1, 0, 0, 0);
+        if (steps > 2) dq2 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[2], dst[2], dq2, 0, 0, 0);
+        if (steps > 3) dq3 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[3], dst[3], dq3, 0, 0, 0);
       }
     }
-    // D layout: value r = dQ[query slot 4g + r = token 16 i + g + 4 r][d = c]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t orow = tok_at(i, g + 4 * r);  // cross-lane read: all lanes active
-      if (i * 16 + g + 4 * r < t) dQ[orow * lddq + hoff + c] = (dq0[r] + dq1[r]) + (dq2[r] + dq3[r]);
+    // The products are formed transposed (dQ^T = K^T dS^T): in the D layout value r of lane (g, c) is
+    // dQ^T[d = 4g + r][query slot c], i.e. the lane holds the ROW fragment dQ[token of slot c][4g .. 4g+3] - one
+    // 16-byte store at the address pattern of the Q loads, no lane exchange.
+    if (i * 16 + sig < t) {
+      const float4 o = make_float4((dq0[0] + dq1[0]) + (dq2[0] + dq3[0]), (dq0[1] + dq1[1]) + (dq2[1] + dq3[1]),
+                                   (dq0[2] + dq1[2]) + (dq2[2] + dq3[2]), (dq0[3] + dq1[3]) + (dq2[3] + dq3[3]));
+      *(float4*)(dQ + (qrow * lddq + hoff + 4 * g)) = o;
     }
   }
-  // D layout: value r = d{K,V}[key slot 4g + r = token 16 j + g + 4 r][d = c]
+  // dK^T / dV^T likewise: lane (g, c) holds d{K,V}[token of key slot c][4g .. 4g+3]
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (EXACT || j < nt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t krow = tok_at(j, g + 4 * r);
-        if (j * 16 + g + 4 * r < t) {
-          dK[krow * lddk + hoff + c] = dk[j][r];
-          dV[krow * lddv + hoff + c] = dv[j][r];
-        }
+      const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + sig, 64);
+      if (j * 16 + sig < t) {
+        *(float4*)(dK + (krow * lddk + hoff + 4 * g)) = make_float4(dk[j][0], dk[j][1], dk[j][2], dk[j][3]);
+        *(float4*)(dV + (krow * lddv + hoff + 4 * g)) = make_float4(dv[j][0], dv[j][1], dv[j][2], dv[j][3]);
       }
     }
   }
 }
 
-template <int NTMAX>
-__global__ __launch_bounds__(64 * kWH, 2) void sra_bwd_fused_k(
+// NTMAX: largest tile count the launch has to handle (the caller knows the largest window); WPS: waves per SIMD the
+// kernel is built for (2: K column fragments stay in registers, <= 256 VGPRs; 3: they are re-read from LDS, <= 168).
+template <int NTMAX, int WPS>
+__global__ __launch_bounds__(64 * kWH, WPS) void sra_bwd_fused_k(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     int64_t lddo, const int32_t* __restrict__ tok, const int32_t* __restrict__ winoff, int n_groups, int H, float scale,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool NH = WPS >= 3;
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
   const int w = bid / n_groups;
   const int hg = bid - w * n_groups;
@@ -1061,28 +1070,33 @@ __global__ __launch_bounds__(64 * kWH, 2) void sra_bwd_fused_k(
   float* lds = smem + (threadIdx.x >> 6) * sra_fused_lds_floats_per_wave(NTMAX);
 #define SST_FUSED_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, lds
   switch (nt) {
-    case 1: sra_bwd_fused_body<1, true>(SST_FUSED_ARGS); break;
-    case 2: sra_bwd_fused_body<2, true>(SST_FUSED_ARGS); break;
-    case 3: sra_bwd_fused_body<3, true>(SST_FUSED_ARGS); break;
-    case 4: sra_bwd_fused_body<4, true>(SST_FUSED_ARGS); break;
-    case 5: sra_bwd_fused_body<5, true>(SST_FUSED_ARGS); break;
-    case 6: sra_bwd_fused_body<6, true>(SST_FUSED_ARGS); break;
-    case 7: sra_bwd_fused_body<7, true>(SST_FUSED_ARGS); break;
+    case 1: sra_bwd_fused_body<1, true, NH>(SST_FUSED_ARGS); break;
+    case 2: sra_bwd_fused_body<2, true, NH>(SST_FUSED_ARGS); break;
+    case 3: sra_bwd_fused_body<3, true, NH>(SST_FUSED_ARGS); break;
+    case 4: sra_bwd_fused_body<4, true, NH>(SST_FUSED_ARGS); break;
+    case 5: if constexpr (NTMAX >= 5) sra_bwd_fused_body<5, true, NH>(SST_FUSED_ARGS); break;
+    case 6: if constexpr (NTMAX >= 6) sra_bwd_fused_body<6, true, NH>(SST_FUSED_ARGS); break;
+    case 7: if constexpr (NTMAX >= 7) sra_bwd_fused_body<7, true, NH>(SST_FUSED_ARGS); break;
     default:
-      if constexpr (NTMAX > 7) sra_bwd_fused_body<NTMAX, false>(SST_FUSED_ARGS);
+      if constexpr (NTMAX > 7) sra_bwd_fused_body<NTMAX, false, NH>(SST_FUSED_ARGS);
       break;
   }
 #undef SST_FUSED_ARGS
 }
 
-template <int NTMAX>
+template <int NTMAX, int WPS>
 int launch_bwd_fused(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
                      int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* tok,
                      const int32_t* winoff, int64_t n_windows, int H, float scale, float* dQ, float* dK, float* dV,
                      int64_t lddq, int64_t lddk, int64_t lddv, hipStream_t st) {
   const int n_groups = H / kWH;
   const size_t lds = (size_t)kWH * sra_fused_lds_floats_per_wave(NTMAX) * sizeof(float);
-  SST_HIP(hipFuncSetAttribute((const void*)sra_bwd_fused_k<NTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    SST_HIP(hipFuncSetAttribute((const void*)sra_bwd_fused_k<NTMAX, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    configured = true;
+  }
   const dim3 grid((unsigned)(n_windows * n_groups));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof_bwd_start != nullptr && g_prof_bwd_stop != nullptr) {
@@ -1091,11 +1105,11 @@ int launch_bwd_fused(const float* Q, const float* K, const float* V, const float
     g_prof_bwd_start = g_prof_bwd_stop = nullptr;  // one-shot, as for the forward kernel
   }
   if (e0 != nullptr)  // kernel-exact start / stop timestamps on the launch stream
-    hipExtLaunchKernelGGL(sra_bwd_fused_k<NTMAX>, grid, dim3(64 * kWH), lds, st, e0, e1, 0, Q, K, V, O, dO, LSE, ldq, ldk,
-                          ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
+    hipExtLaunchKernelGGL((sra_bwd_fused_k<NTMAX, WPS>), grid, dim3(64 * kWH), lds, st, e0, e1, 0, Q, K, V, O, dO, LSE, ldq,
+                          ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
   else
-    hipLaunchKernelGGL(sra_bwd_fused_k<NTMAX>, grid, dim3(64 * kWH), lds, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo, lddo,
-                       tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
+    hipLaunchKernelGGL((sra_bwd_fused_k<NTMAX, WPS>), grid, dim3(64 * kWH), lds, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo,
+                       lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
   return SST_OK;
 }
 
@@ -1192,7 +1206,13 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
     if (cap_tiles > 4 && (rc = launch_fwd_variant<7>(SST_FWD_ARGS(4)))) return rc;
     if (cap_tiles > 7 && (rc = launch_fwd_variant<9>(SST_FWD_ARGS(7)))) return rc;
   } else {          // register-resident kernels (default): ONE launch, tile class chosen per workgroup
-    if (cap_tiles <= 7)
+    if (cap_tiles <= 4)   // the largest window the caller announces picks the register class of the launch
+      rc = launch_fwd_wave<4>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, d_o, ldo,
+                              d_lse, st);
+    else if (cap_tiles <= 5)
+      rc = launch_fwd_wave<5>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, d_o, ldo,
+                              d_lse, st);
+    else if (cap_tiles <= 7)
       rc = launch_fwd_wave<7>(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, d_o, ldo,
                               d_lse, st);
     else
@@ -1225,6 +1245,7 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
   hipStream_t st = (hipStream_t)stream;
   const bool mfma_ok = (n_heads % kGH == 0) && ((ldq | ldk | ldv | ldo | lddo) % 4 == 0) && aligned16(d_q) &&
                        aligned16(d_k) && aligned16(d_v) && aligned16(d_o) && aligned16(d_do);
+  const bool out_vec_ok = ((lddq | lddk | lddv) % 4 == 0) && aligned16(d_dq) && aligned16(d_dk) && aligned16(d_dv);
   const int cap_tiles = max_tokens > 0 ? (max_tokens + 15) / 16 : 1 << 30;
   const bool all_generic = (impl == 1) || !mfma_ok;
   const bool need_generic = all_generic || cap_tiles > kMaxTilesMfma;
@@ -1243,7 +1264,8 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
       if (cap_tiles > 2 && (rc = launch_bwd_variant<4>(SST_BWD_ARGS(2)))) return rc;
       if (cap_tiles > 4 && (rc = launch_bwd_variant<7>(SST_BWD_ARGS(4)))) return rc;
       if (cap_tiles > 7 && (rc = launch_bwd_variant<9>(SST_BWD_ARGS(7)))) return rc;
-    } else if (impl == 3) {  // register-resident kernels, two launches (dQ, then dK / dV): kept for comparison
+    } else if (impl == 3 || !out_vec_ok) {  // register-resident kernels, two launches (dQ, then dK / dV): kept for
+                                            // comparison, and for gradient buffers that are not 16-byte aligned
       if (!d_workspace) return SST_ERR_ARG;
       if (cap_tiles <= 7)
         rc = launch_bwd_wave<7>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
@@ -1253,12 +1275,25 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
                                 n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, (float*)d_workspace, st);
       if (rc) return rc;
     } else {          // register-resident one-pass kernel (default): one launch, tile count chosen per workgroup
-      if (cap_tiles <= 7)
-        rc = launch_bwd_fused<7>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
-                                 n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+#define SST_FUSED_CALL(NTM, WPS)                                                                                      \
+  launch_bwd_fused<NTM, WPS>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows, \
+                             n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, st)
+      // the kernel class follows the largest window the caller announces (max_tokens): up to 5 tiles the three-wave
+      // build fits (SST_SRA_BWD_WPS=2 forces the two-wave build for A/B runs)
+      static int wps_env = -1;
+      if (wps_env < 0) {
+        const char* e = getenv("SST_SRA_BWD_WPS");
+        wps_env = e ? atoi(e) : 0;
+      }
+      if (cap_tiles <= 4)
+        rc = wps_env == 2 ? SST_FUSED_CALL(4, 2) : SST_FUSED_CALL(4, 3);
+      else if (cap_tiles <= 5)
+        rc = wps_env == 2 ? SST_FUSED_CALL(5, 2) : SST_FUSED_CALL(5, 3);
+      else if (cap_tiles <= 7)
+        rc = SST_FUSED_CALL(7, 2);
       else
-        rc = launch_bwd_fused<9>(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
-                                 n_heads, scale, d_dq, d_dk, d_dv, lddq, lddk, lddv, st);
+        rc = SST_FUSED_CALL(9, 2);
+#undef SST_FUSED_CALL
       if (rc) return rc;
     }
 #undef SST_BWD_ARGS

@@ -136,10 +136,13 @@ __global__ __launch_bounds__(256) void seg_plan_k(const int32_t* __restrict__ c,
                                                   const int32_t* __restrict__ seglevel, int n_levels,
                                                   int32_t* __restrict__ tokbase, int32_t* __restrict__ cwl,
                                                   int32_t* __restrict__ winoff, int32_t* __restrict__ winlevel,
-                                                  int32_t* __restrict__ n_windows_out) {
+                                                  int32_t* __restrict__ n_windows_out,
+                                                  int32_t* __restrict__ max_tokens_out) {
   __shared__ int lds[4];
+  __shared__ int lds_max;
+  if (threadIdx.x == 0) lds_max = 0;
   const int nseg = *nseg_p;
-  int carry_tok = 0, carry_win = 0;
+  int carry_tok = 0, carry_win = 0, my_max = 0;
   int carry_lvl[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l) carry_lvl[l] = 0;
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(256) void seg_plan_k(const int32_t* __restrict__ c,
       lv = seglevel[seg];
     }
     const int nonempty = cnt > 0 ? 1 : 0;
+    my_max = cnt > my_max ? cnt : my_max;
     int total;
     const int ex_tok = block_excl_scan_256_w(cnt, total, lds);
     const int tb = carry_tok + ex_tok;
@@ -177,9 +181,12 @@ __global__ __launch_bounds__(256) void seg_plan_k(const int32_t* __restrict__ c,
       }
     }
   }
+  atomicMax(&lds_max, my_max);  // LDS, integer: the largest surviving window population of this shift
+  __syncthreads();
   if (threadIdx.x == 0) {
     winoff[carry_win] = carry_tok;
     *n_windows_out = carry_win;
+    *max_tokens_out = lds_max;
   }
 }
 
@@ -347,7 +354,7 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
     hipLaunchKernelGGL(seg_rank_cnt_k, dim3(grid), dim3(256), 0, st, c, perm[s], inv[s], off[s], m, inner[s],
                        (int32_t*)nullptr);
     hipLaunchKernelGGL(seg_plan_k, dim3(1), dim3(256), 0, st, c, off[s], nseg + s, seglevel[s], n_levels, tokbase, cwl,
-                       winoff[s], winlevel[s], d_counts + 1 + s);
+                       winoff[s], winlevel[s], d_counts + 1 + s, d_counts + 3 + s);
     hipLaunchKernelGGL(plan_fill_k, dim3(grid), dim3(256), 0, st, d_keep, inv[s], inner[s], level[s], d_newidx,
                        tokbase, cwl, lt, m, tok[s], flat2win[s]);
   }

@@ -153,7 +153,10 @@ class SSTInputLayerV2(nn.Module):
         rb = K.region_batching(win0, win1, win_bits, levels)
         counts = rb['counts'].tolist()  # the single readback: M', W0, W1
         m_keep, n_win = counts[0], (counts[1], counts[2])
+        # upper bound on the tokens per window handed to the attention kernels: the largest surviving window of the
+        # shift (read back with the other sizes) - lets them pick the smallest register / LDS class that fits
         max_tokens_cap = max(l[0] for l in levels)
+        win_max = tuple(min(max_tokens_cap, max(1, int(t))) for t in (counts[3], counts[4]))
 
         voxel_info = {}
         keep_all = (m_keep == m)
@@ -207,8 +210,7 @@ class SSTInputLayerV2(nn.Module):
                 if not identity_keys:  # drop_info keyed by something else than 0..n-1
                     lv = torch.tensor(level_keys, device=lv.device, dtype=torch.long)[lv.clamp(min=0)]
                 voxel_info[f'voxel_drop_level_shift{i}'] = lv
-            voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep,
-                                                            max_tokens_cap)
+            voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep, win_max[i])
             voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], feat_dim, dtype)
 
         if self.debug:

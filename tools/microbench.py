@@ -54,7 +54,7 @@ def bench_sra():
         qk = torch.randn(m, 256, device=DEV)
         v = torch.randn(m, 128, device=DEV)
         do = torch.randn(m, 128, device=DEV)
-        for impl in (0, 2, 1):
+        for impl in (0, 2):
             med, mn = timeit(lambda: K._sra_fwd(qk[:, :128], qk[:, 128:], v, plan, 8, 0.25, impl))
             gbs = bench.SRA_BYTES_PER_TOKEN * m / (med * 1e-3) / 1e9
             print(f'  fwd impl={impl}: median {med * 1e3:.1f} us (min {mn * 1e3:.1f}) -> {gbs:.0f} GB/s '
@@ -62,11 +62,15 @@ def bench_sra():
         o, lse = K._sra_fwd(qk[:, :128], qk[:, 128:], v, plan, 8, 0.25, 0)
         dqk = torch.empty_like(qk)
         dv = torch.empty_like(v)
-        for impl in (0, 3, 0, 3, 2):   # 0: one-pass kernel, 3: two launches (dQ, dK / dV), 2: LDS-staged
-            med, mn = timeit(lambda: K._sra_bwd(qk[:, :128], qk[:, 128:], v, o, lse, do, plan, 8, 0.25, impl,
+        plan100 = K.WindowPlan(plan.tok, plan.winoff, plan.n_windows, plan.n_tokens, 100)  # announce the cap only
+        print(f'  plan.max_tokens = {plan.max_tokens} (largest window); second plan announces 100')
+        for impl, pl, tag in ((0, plan, 'one-pass, class by largest window'), (0, plan100, 'one-pass, 7-tile class'),
+                              (3, plan, 'two launches'), (0, plan, 'one-pass, class by largest window'),
+                              (0, plan100, 'one-pass, 7-tile class'), (3, plan, 'two launches')):
+            med, mn = timeit(lambda: K._sra_bwd(qk[:, :128], qk[:, 128:], v, o, lse, do, pl, 8, 0.25, impl,
                                                 dqk[:, :128], dqk[:, 128:], dv))
             gbs = bench.SRA_BWD_BYTES_PER_TOKEN * m / (med * 1e-3) / 1e9
-            print(f'  bwd impl={impl}: median {med * 1e3:.1f} us (min {mn * 1e3:.1f}) -> {gbs:.0f} GB/s '
+            print(f'  bwd impl={impl} ({tag}): median {med * 1e3:.1f} us (min {mn * 1e3:.1f}) -> {gbs:.0f} GB/s '
                   f'({gbs / 80:.1f} % of 8 TB/s)')
 
 
