@@ -65,19 +65,33 @@ class Pipeline(torch.nn.Module):
             type='SSTv2', d_model=[128] * num_blocks, nhead=[8] * num_blocks, num_blocks=num_blocks,
             dim_feedforward=[256] * num_blocks, output_shape=[468, 468], num_attached_conv=0, to_bev=False,
             debug=False))
+        self.fused_index = True     # csrc/frame_plan.hip; False: the piecewise path through the module interfaces
+        self._planner = None
 
     def prepare(self, points_list):
         """Index work of one batch - dynamic voxelize, point->voxel grouping, window bucketing / drop / window CSR,
         positional embeddings: depends on the point clouds only (no parameters, no features)."""
+        if self.fused_index:
+            if self._planner is None:
+                from sst_amd.frame_plan import FramePlanner
+                self._planner = FramePlanner(self.voxel_layer, self.voxel_encoder, self.middle_encoder)
+            if self._planner.supported(len(points_list)):
+                return self._planner.build(points_list)     # no host round trip; sizes are read in forward()
         points, coors = self.voxel_layer.voxelize_batch(points_list)
         sp = self.voxel_encoder.scatter_plan(coors)
         wplan = self.middle_encoder.build_plan(sp.voxel_coors, len(points_list), 128, torch.float32)
         return points, coors, sp, wplan
 
     def forward(self, points_list, prepared=None):
-        points, coors, sp, wplan = prepared if prepared is not None else self.prepare(points_list)
-        voxel_feats, _ = self.voxel_encoder(points, coors, scatter_plan=sp)
-        info = self.middle_encoder.apply_plan(wplan, voxel_feats)
+        prepared = prepared if prepared is not None else self.prepare(points_list)
+        if isinstance(prepared, tuple):     # piecewise index path (one read-back per module boundary)
+            points, coors, sp, wplan = prepared
+            voxel_feats, _ = self.voxel_encoder(points, coors, scatter_plan=sp)
+            info = self.middle_encoder.apply_plan(wplan, voxel_feats)
+        else:                               # fused index plan: the voxel encoder is queued before the sizes are read
+            voxel_feats, _ = self.voxel_encoder(prepared.points, prepared.coors, scatter_plan=prepared)
+            info = prepared.finalize(voxel_feats, self.middle_encoder)
+        self.last_voxel_coors = info['voxel_coors']
         return self.backbone(info)[0]['voxel_feats']
 
 
@@ -100,21 +114,14 @@ def gpu_forward_sorted(model, frames):
     order: (features [M, C] on the host, int64 voxel keys [M] ascending)."""
     from oracle.cpu_pipeline import voxel_sort_key
     me = model.middle_encoder
-    seen = {}
-    orig_apply, orig_shuffle = me.apply_plan, me.shuffle_voxels
-
-    def spy(plan, feats):
-        info = orig_apply(plan, feats)
-        seen['coors'] = info['voxel_coors']
-        return info
-
-    me.apply_plan, me.shuffle_voxels = spy, False
+    orig_shuffle = me.shuffle_voxels
+    me.shuffle_voxels = False
     try:
         with torch.no_grad():
             out = model(frames)
     finally:
-        me.apply_plan, me.shuffle_voxels = orig_apply, orig_shuffle
-    key = voxel_sort_key(seen['coors'].cpu())
+        me.shuffle_voxels = orig_shuffle
+    key = voxel_sort_key(model.last_voxel_coors.cpu())
     order = torch.argsort(key)
     return out.detach().cpu()[order], key[order]
 
@@ -220,6 +227,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-time-sra-bwd', action='store_true', help='do not attach events to the SRA backward launches')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
+    ap.add_argument('--piecewise-index', action='store_true',
+                    help='index plan through the module interfaces (three read-backs) instead of csrc/frame_plan.hip')
     ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL, default) | gloo (dev check of the N>1 path on one GPU)')
     ap.add_argument('--share-device', action='store_true', help='dev only: every rank uses cuda:0')
@@ -262,6 +271,7 @@ def main():
     model = Pipeline(args.blocks).to(dev)
     model.train()
     model.backbone.set_impl(args.impl)
+    model.fused_index = not args.piecewise_index
     params = [p for p in model.parameters() if p.requires_grad]
     frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
     torch.manual_seed(1234 + rank)            # per-rank voxel shuffles

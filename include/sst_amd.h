@@ -114,15 +114,18 @@ int sst_unpack_keys(const uint64_t* d_ukeys, int64_t m, int ncols, const int64_t
  * ---------------------------------------------------------------------------------------------- */
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
-                               float* d_out, int32_t* d_argmax, void* stream);
+                               float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream);
 /* Backward (scatter_points_cuda.cu:236-303).  d_grad_feats [n, c] is fully written (zero where no
  * gradient flows).  SUM/MEAN: g[i] = G[inv[i]] (/count); rows with d_inverse[i] < 0 get 0.
  * MAX: gradient goes to d_argmax[g, ch] only.  d_inverse may be shifted by the caller
  * (inverse_shift is added before use; the DynamicScatter "first row" quirk uses -1).  With d_group_index the
- * inverse map must already address OUTPUT rows; the group index is only used for the MEAN count. */
+ * inverse map must already address OUTPUT rows; the group index is only used for the MEAN count.
+ * d_m_limit (both directions, may be NULL): the number of output rows when it is only known on the device - `m`
+ * is then an upper bound that sizes the launch and rows >= *d_m_limit are neither computed nor read. */
 int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const int32_t* d_inverse,
                                int inverse_shift, const int32_t* d_offsets, const int32_t* d_group_index,
-                               const int32_t* d_argmax, int64_t n, int mode, float* d_grad_feats, void* stream);
+                               const int32_t* d_argmax, int64_t n, int mode, float* d_grad_feats,
+                               const int32_t* d_m_limit, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (f1) Decorate step of DynamicVFE / DynamicScatterVFE (voxel_encoders/voxel_encoder.py:252-271, :569-589) in one
@@ -190,6 +193,43 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
                         int32_t* d_tok0, int32_t* d_tok1, int32_t* d_winoff0, int32_t* d_winoff1,
                         int32_t* d_winlevel0, int32_t* d_winlevel1, int32_t* d_counts,
                         void* d_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a2-a9 in one piece) Index plan of a frame batch without host round trips (csrc/frame_plan.hip): the same voxel
+ * table / window bucketing / voxel drop / window CSR as sst_unique_rows + sst_window_coors + sst_region_batching,
+ * from buffers sized by host-known upper bounds; the counts stay on the device (d_counts) and are read once.
+ * Replaces, for the SST training path, DynamicScatter's per-sample unique bookkeeping (ops/voxel/scatter_points.py:
+ * 85-99, src/scatter_points_cuda.cu:202-210) and SSTInputLayerV2.window_partition / drop_voxel / get_flat2win_inds
+ * (middle_encoders/sst_input_layer_v2.py:128-236, ops/sst/sst_ops.py:26-64, 266-331).
+ *
+ * sst_frame_voxels_i32: from the sorted-unique groups of the point coordinates (sst_unique_rows with
+ *   invalid_if_negative = 2, mins (0,-1,-1,-1), extents (B, gz+1, gy+1, gx+1); d_num_groups = its device count):
+ *   drop_mode 1: the first group of every sample is discarded (the reference's unconditional out_coors[1:]),
+ *   drop_mode 0: only the group of invalid rows.  Kept groups are the voxels v = 0..M-1 (ascending key):
+ *     d_vcoors [n_points, 4] int32 (b,z,y,x), d_gidx [n_points] group of voxel v, d_coors_map [n_points] voxel of every
+ *     point (-1: dropped), d_grid [B*gz*gy*gx] dense cell -> voxel map (-1: empty), d_counts[0] = M.
+ * sst_window_plan_i32: window / shifted-window bucketing, drop levels (h_levels: n_levels x (max_tokens, lo, hi)), the
+ *   three passes of drop_voxel, window CSR.  seed = 0: survivors of an over-full window are its first voxels in
+ *   ascending voxel order; seed != 0: a uniformly random subset (the reference's shuffle_voxels).  Outputs, kept voxels
+ *   numbered window-major (position in the shift-0 CSR):
+ *     d_feat_index / d_feat_index32 [n_upper] voxel v of every output row, d_out_coors [n_upper, 4] int64,
+ *     d_winoff0 / d_winoff1 [n_windows + 1] CSR offsets of the non-empty windows (shift-0 tokens are 0..M'-1 in order),
+ *     d_tok1 [n_upper] output rows grouped by shift-1 window, d_posidx0/1 [n_upper] row of the positional table
+ *     ((z_in * wy + y_in) * wx + x_in); d_counts: [1] M', [2] W_0, [3] W_1, [4] / [5] largest window of each shift.
+ *   n_windows = B * sst_frame_windows_per_sample(grid, window).  Limits: B <= 64, window <= 512 cells,
+ *   B * cells <= 2^28 (otherwise SST_ERR_UNSUPPORTED: callers use the piecewise entry points).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sst_frame_windows_per_sample(const int32_t grid_zyx[3], const int32_t window_shape[3]);
+int sst_frame_voxels_i32(const uint64_t* d_ukeys, const int32_t* d_offsets, const uint32_t* d_perm,
+                         const int32_t* d_num_groups, int64_t n_points, int batch_size, const int32_t grid_zyx[3],
+                         int drop_mode, int32_t* d_vcoors, int32_t* d_gidx, int32_t* d_coors_map, int32_t* d_grid,
+                         int32_t* d_counts, void* stream);
+int64_t sst_window_plan_workspace_bytes(int64_t n_upper, int64_t n_windows);
+int sst_window_plan_i32(const int32_t* d_vcoors, const int32_t* d_grid, int64_t n_upper, int batch_size,
+                        const int32_t grid_zyx[3], const int32_t window_shape[3], const int32_t* h_levels, int n_levels,
+                        uint32_t seed, int64_t* d_feat_index, int32_t* d_feat_index32, int64_t* d_out_coors,
+                        int32_t* d_tok1, int32_t* d_winoff0, int32_t* d_winoff1, int32_t* d_posidx0, int32_t* d_posidx1,
+                        int32_t* d_counts, void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a12) Sparse Regional Attention core over variable-length windows (no padding, no key mask):

@@ -44,8 +44,12 @@ class CpuDynamicVFE(nn.Module):
                                 features[:, 2] - (coors[:, 1].float() * self.vz + self.z_offset)], 1)
         feats = torch.cat([features, f_cluster, f_center], 1)
         scatter_max = voxel_oracle.DynamicScatterOracle(None, None, False)
+        keep = getattr(self, 'keep_point_feats', None)   # tests: per-point features of every layer (with gradients)
         for i, (lin, norm) in enumerate(zip(self.linears, self.norms)):
             pf = F.relu(norm(lin(feats)))
+            if keep is not None:
+                pf.retain_grad()
+                keep.append(pf)
             vf, vcoors = scatter_max(pf, coors)
             if i != len(self.linears) - 1:
                 feats = torch.cat([pf, vf[inv]], 1)
@@ -121,6 +125,7 @@ class CpuSSTBackbone(nn.Module):
         vf, vc = self.vfe(pts, coors)
         keep, shifts = self.plan(vc)
         self.last_voxel_coors = vc[keep]      # (b, z, y, x) of the rows of the output, sorted-unique order
+        self.last_all_voxel_coors = vc        # ... of every voxel before the drop
         x = vf[keep]
         for i, layer in enumerate(self.layers):
             pos, levels = shifts[i % 2]

@@ -35,14 +35,19 @@ _SIGNATURES = {
                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_unpack_keys': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr]),
     'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
-                                           c_ptr]),
-    'sst_segment_reduce_bwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                                            c_ptr, c_ptr]),
+    'sst_segment_reduce_bwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
+                                           c_ptr, c_ptr, c_ptr]),
     'sst_ingroup_rank_workspace_bytes': (c_i64, [c_i64]),
     'sst_ingroup_rank_i64': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr]),
     'sst_window_coors': (c_i32, [c_ptr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_region_batching_workspace_bytes': (c_i64, [c_i64]),
     'sst_region_batching': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32] + [c_ptr] * 15 + [c_ptr, c_ptr]),
+    'sst_frame_windows_per_sample': (c_i64, [c_ptr, c_ptr]),
+    'sst_frame_voxels_i32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                     c_ptr, c_ptr]),
+    'sst_window_plan_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sst_window_plan_i32': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, ctypes.c_uint32] + [c_ptr] * 11),
     'sst_sra_attn_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32,
                                      c_f32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     'sst_sra_attn_bwd_f32': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_f32,

@@ -1,0 +1,445 @@
+// Index plan of one frame batch without host round trips (gfx950): voxel table + window / shifted-window bucketing +
+// voxel drop + window CSR for both shifts in seven launches whose sizes never depend on device-side counts.
+//
+// Reference semantics (the same as sort_scan.hip + window.hip implement piecewise):
+//   DynamicScatter's sorted-unique voxel list with the "first row of every sample" quirk
+//                                         mmdet3d/ops/voxel/src/scatter_points_cuda.cu:202-210, scatter_points.py:85-99
+//   get_window_coors                      mmdet3d/ops/sst/sst_ops.py:266-314
+//   drop_single_shift / drop_voxel        mmdet3d/models/middle_encoders/sst_input_layer_v2.py:128-226
+//   get_flat2win_inds / make_continuous_inds   sst_ops.py:26-64, 316-331  (only what the attention kernels consume:
+//                                         the window CSR; the per-level padded dictionaries stay with window.hip)
+//
+// Why a second implementation: the piecewise path runs ~150 launches of a few microseconds each and reads three sizes
+// back to the host (M after the unique, the survivors and window counts after the bucketing), which drains the
+// queue three times per step: 2.5 ms of a 16 ms step for ~10 MB of traffic (profiles/r01/k_steady_state_trace_report).
+// Here every buffer is sized by a host-known upper bound (points N >= voxels M; B * windows-per-sample), the counts
+// stay on the device and are read once, after the feature kernels of the voxel encoder have been queued.
+//
+// Method: the voxel grid of a frame is small (468 x 468 x 1 cells for Waymo at 0.32 m = 0.9 MB of int32 per sample, L2
+// resident), so the voxel table is also written as a DENSE cell -> voxel map.  A window is then 12 x 12 (x wz) cells
+// of that map: ONE WAVE PER WINDOW reads its cells in (z, y, x) order - which is ascending voxel index, the in-window
+// order this library defines - and a ballot / popcount gives every voxel its rank and the window its population:
+// no sort by window id, no segmented scan.  The three dependent passes of drop_voxel (shift 0 on all voxels, shift 1
+// on the survivors, shift 0 again for the final in-window positions) are three launches of that kernel; one
+// two-block scan turns the per-window survivor counts into CSR offsets; one per-voxel kernel writes the outputs in
+// window-major order (kept voxels numbered by their position in the shift-0 CSR).
+// With a non-zero seed the voxels dropped from an over-full window are a uniformly random subset (a stateless hash
+// per voxel ranks them), which is what the reference's randperm + in-window order amounts to.
+#include "common.h"
+
+namespace {
+
+struct fp_geom {
+  int B, gz, gy, gx;       // samples, voxel grid
+  int wx, wy, wz;          // window shape
+  int nwx, nwy, nwz;       // windows per axis (ceil(s / w) + 1, sst_ops.py:280-283)
+  int sh[2][3];            // (x, y, z) shift of the two partitions
+  int n_levels;
+  int cap[8], lo[8], hi[8];
+};
+
+__device__ __forceinline__ void fp_decode(uint64_t key, const fp_geom& G, int& b, int& z, int& y, int& x) {
+  // key = 1 + ((b * (gz+1) + (z+1)) * (gy+1) + (y+1)) * (gx+1) + (x+1)   (sst_unique_rows, mode 2)
+  uint64_t k = key - 1;
+  x = (int)(k % (uint64_t)(G.gx + 1)) - 1;
+  k /= (uint64_t)(G.gx + 1);
+  y = (int)(k % (uint64_t)(G.gy + 1)) - 1;
+  k /= (uint64_t)(G.gy + 1);
+  z = (int)(k % (uint64_t)(G.gz + 1)) - 1;
+  b = (int)(k / (uint64_t)(G.gz + 1));
+}
+
+// first group index of sample bb (or m_all when the sample has no group): lower bound of its smallest key
+__device__ int fp_lower_bound(const uint64_t* __restrict__ ukeys, int m_all, uint64_t key) {
+  int lo = 0, hi = m_all;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---- 1. voxel table ------------------------------------------------------------------------------------------
+// One thread per sorted-unique group g.  drop_mode 1: the first group of every sample is discarded (the reference's
+// unconditional out_coors[1:], once per sample); drop_mode 0: only the group of the invalid rows (b, -1, -1, -1).
+// Kept group -> voxel v (ascending): vcoors[v], gidx[v] = g, grid[cell] = v, coors_map[point] = v (-1 if dropped).
+__global__ __launch_bounds__(256) void fp_voxels_k(const uint64_t* __restrict__ ukeys, const int32_t* __restrict__ offsets,
+                                                   const uint32_t* __restrict__ perm, const int32_t* __restrict__ d_num,
+                                                   fp_geom G, int drop_mode, int32_t* __restrict__ vcoors,
+                                                   int32_t* __restrict__ gidx, int32_t* __restrict__ coors_map,
+                                                   int32_t* __restrict__ grid, int32_t* __restrict__ d_counts) {
+  __shared__ int dropped_upto[65];  // dropped groups among samples < bb
+  const int m_all = *d_num;
+  const uint64_t sample_stride = (uint64_t)(G.gz + 1) * (G.gy + 1) * (G.gx + 1);
+  if (threadIdx.x < 64) {
+    int d = 0;
+    const int bb = threadIdx.x;
+    if (bb < G.B) {
+      const int p = fp_lower_bound(ukeys, m_all, 1 + (uint64_t)bb * sample_stride);
+      if (p < m_all) {
+        int b, z, y, x;
+        fp_decode(ukeys[p], G, b, z, y, x);
+        if (b == bb) d = drop_mode == 1 ? 1 : (z < 0 ? 1 : 0);
+      }
+    }
+    // inclusive scan over the 64 lanes of wave 0, then shifted to exclusive
+    const int incl = sst_wave_incl_scan(d);
+    dropped_upto[bb + 1] = incl;
+    if (bb == 0) dropped_upto[0] = 0;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) d_counts[0] = m_all - dropped_upto[G.B < 64 ? G.B : 64];
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < m_all; g += gridDim.x * blockDim.x) {
+    int b, z, y, x;
+    fp_decode(ukeys[g], G, b, z, y, x);
+    bool first = true;
+    if (g > 0) {
+      int pb, pz, py, px;
+      fp_decode(ukeys[g - 1], G, pb, pz, py, px);
+      first = pb != b;
+    }
+    const bool dropped = drop_mode == 1 ? first : (z < 0);
+    int v = -1;
+    if (!dropped) {
+      v = g - dropped_upto[b + 1];
+      vcoors[4 * v + 0] = b;
+      vcoors[4 * v + 1] = z;
+      vcoors[4 * v + 2] = y;
+      vcoors[4 * v + 3] = x;
+      gidx[v] = g;
+      if (z >= 0) grid[(((int64_t)b * G.gz + z) * G.gy + y) * G.gx + x] = v;
+    }
+    const int beg = offsets[g], end = offsets[g + 1];
+    for (int p = beg; p < end; ++p) coors_map[perm[p]] = v;
+  }
+}
+
+// ---- 2. window passes ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fp_hash(uint32_t v, uint32_t seed) {  // stateless per-voxel random key (pcg-style mix)
+  uint32_t h = v * 747796405u + seed * 2891336453u + 1u;
+  h = ((h >> ((h >> 28) + 4)) ^ h) * 277803737u;
+  return (h >> 22) ^ h;
+}
+
+// STAGE 0: shift 0 over all voxels          -> keep_a[v] = rank < cap(level of the window population)
+// STAGE 1: shift 1 over the voxels of keep_a -> keep[v], inner1[v] (position among the survivors), cntk1[w]
+// STAGE 2: shift 0 over the voxels of keep   -> inner0[v], cntk0[w]   (levels of shift 0 are NOT recomputed: quirk)
+template <int STAGE>
+__global__ __launch_bounds__(256) void fp_window_pass_k(const int32_t* __restrict__ grid, fp_geom G, uint32_t seed,
+                                                        const int32_t* __restrict__ keep_in,
+                                                        int32_t* __restrict__ keep_out, int32_t* __restrict__ inner,
+                                                        int32_t* __restrict__ cntk) {
+  const int lane = threadIdx.x & 63;
+  const int nw = G.nwx * G.nwy * G.nwz;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= G.B * nw) return;
+  const int s = STAGE == 1 ? 1 : 0;
+  const int b = w / nw;
+  int r = w - b * nw;
+  const int wxi = r / (G.nwy * G.nwz);
+  r -= wxi * (G.nwy * G.nwz);
+  const int wyi = r / G.nwz, wzi = r - wyi * G.nwz;
+  const int ncell = G.wx * G.wy * G.wz;
+  const int x0 = wxi * G.wx - G.sh[s][0], y0 = wyi * G.wy - G.sh[s][1], z0 = wzi * G.wz - G.sh[s][2];
+  constexpr int MAXS = 8;                  // up to 512 cells per window
+  int vox[MAXS];
+  int rank[MAXS];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < MAXS; ++q) {
+    vox[q] = -1;
+    rank[q] = 0;
+    const int ci = q * 64 + lane;
+    if (q * 64 < ncell) {
+      int v = -1;
+      if (ci < ncell) {
+        const int zz = ci / (G.wy * G.wx);
+        const int rr = ci - zz * (G.wy * G.wx);
+        const int yy = rr / G.wx, xx = rr - yy * G.wx;
+        const int x = x0 + xx, y = y0 + yy, z = z0 + zz;
+        if (x >= 0 && x < G.gx && y >= 0 && y < G.gy && z >= 0 && z < G.gz) {
+          v = grid[(((int64_t)b * G.gz + z) * G.gy + y) * G.gx + x];
+          if (STAGE != 0 && v >= 0 && keep_in[v] == 0) v = -1;
+        }
+      }
+      const uint64_t occ = __ballot(v >= 0);
+      vox[q] = v;
+      rank[q] = total + __popcll(occ & lt);
+      total += __popcll(occ);
+    }
+  }
+  if (STAGE == 2) {  // final in-window positions of the survivors
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q)
+      if (vox[q] >= 0) inner[vox[q]] = rank[q];
+    if (lane == 0) cntk[w] = total;
+    return;
+  }
+  // drop level of the window by its population (later levels override earlier ones, as the reference loop does)
+  int cap = 0;
+  for (int l = 0; l < G.n_levels; ++l)
+    if (total >= G.lo[l] && total < G.hi[l]) cap = G.cap[l];
+  if (seed != 0u && total > cap) {
+    // over-full window: the survivors are a uniformly random subset - rank by (hash, voxel) instead of by voxel
+    uint32_t hk[MAXS];
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q) {
+      hk[q] = vox[q] >= 0 ? fp_hash((uint32_t)vox[q], seed + (uint32_t)STAGE) : 0xffffffffu;
+      rank[q] = 0;
+    }
+#pragma unroll
+    for (int qs = 0; qs < MAXS; ++qs) {
+      if (qs * 64 < ncell) {
+        for (int src = 0; src < 64; ++src) {
+          const int ov = __shfl(vox[qs], src, 64);
+          const uint32_t oh = (uint32_t)__shfl((int)hk[qs], src, 64);
+          if (ov >= 0) {
+#pragma unroll
+            for (int q = 0; q < MAXS; ++q)
+              if (vox[q] >= 0 && (oh < hk[q] || (oh == hk[q] && ov < vox[q]))) rank[q] += 1;
+          }
+        }
+      }
+    }
+  }
+  int kept = 0;
+#pragma unroll
+  for (int q = 0; q < MAXS; ++q) {
+    if (q * 64 < ncell) {
+      const bool kp = vox[q] >= 0 && rank[q] < cap;
+      if (vox[q] >= 0) {
+        keep_out[vox[q]] = kp ? 1 : 0;
+        if (STAGE == 1 && kp) inner[vox[q]] = rank[q];
+      }
+      kept += __popcll(__ballot(kp));
+    }
+  }
+  if (STAGE == 1) {
+    // with the random ranking the survivors' ranks are not contiguous: renumber them in voxel order
+    if (seed != 0u && total > cap) {
+      int run = 0;
+#pragma unroll
+      for (int q = 0; q < MAXS; ++q) {
+        if (q * 64 < ncell) {
+          const bool kp = vox[q] >= 0 && rank[q] < cap;
+          const uint64_t bal = __ballot(kp);
+          if (kp) inner[vox[q]] = run + __popcll(bal & lt);
+          run += __popcll(bal);
+        }
+      }
+    }
+    if (lane == 0) cntk[w] = kept;
+  }
+}
+
+// voxels that lie in no window cell that was visited never get a keep flag: none exist (every voxel lies in exactly
+// one window of each partition), but voxels beyond M must read as dropped: the flag arrays are zeroed by a memset.
+
+// ---- 3. scan of the per-window survivor counts: CSR offsets, compact window ids ------------------------------------
+// grid = 2 blocks (one per shift).  counts: [0] M (written by fp_voxels_k), [1] M', [2] W_0, [3] W_1, [4] T_0, [5] T_1
+__global__ __launch_bounds__(1024) void fp_window_scan_k(const int32_t* __restrict__ cntk0,
+                                                         const int32_t* __restrict__ cntk1, int n_win,
+                                                         int32_t* __restrict__ tokbase0, int32_t* __restrict__ tokbase1,
+                                                         int32_t* __restrict__ winoff0, int32_t* __restrict__ winoff1,
+                                                         int32_t* __restrict__ d_counts) {
+  __shared__ int wsum[16], wsum2[16];
+  __shared__ int smax;
+  const int s = blockIdx.x;
+  const int32_t* cnt = s ? cntk1 : cntk0;
+  int32_t* tokbase = s ? tokbase1 : tokbase0;
+  int32_t* winoff = s ? winoff1 : winoff0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) smax = 0;
+  int carry_tok = 0, carry_win = 0, my_max = 0;
+  for (int base = 0; base < n_win; base += 1024) {
+    const int w = base + tid;
+    const int c = w < n_win ? cnt[w] : 0;
+    const int ne = c > 0 ? 1 : 0;
+    my_max = c > my_max ? c : my_max;
+    const int ic = sst_wave_incl_scan(c);
+    const int in = sst_wave_incl_scan(ne);
+    if (lane == 63) {
+      wsum[wave] = ic;
+      wsum2[wave] = in;
+    }
+    __syncthreads();
+    int off_c = 0, off_n = 0, tot_c = 0, tot_n = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int a = wsum[k], bq = wsum2[k];
+      if (k < wave) {
+        off_c += a;
+        off_n += bq;
+      }
+      tot_c += a;
+      tot_n += bq;
+    }
+    __syncthreads();
+    const int tb = carry_tok + off_c + ic - c;
+    const int cw = carry_win + off_n + in - ne;
+    if (w < n_win) {
+      tokbase[w] = tb;
+      if (ne) winoff[cw] = tb;
+    }
+    carry_tok += tot_c;
+    carry_win += tot_n;
+  }
+  atomicMax(&smax, my_max);
+  __syncthreads();
+  if (tid == 0) {
+    winoff[carry_win] = carry_tok;
+    d_counts[2 + s] = carry_win;
+    d_counts[4 + s] = smax;
+    if (s == 0) d_counts[1] = carry_tok;
+  }
+}
+
+// ---- 4. outputs in window-major order ---------------------------------------------------------------------------
+__device__ __forceinline__ void fp_window_of(const fp_geom& G, int s, int b, int z, int y, int x, int& w, int& pos) {
+  const int xs = x + G.sh[s][0], ys = y + G.sh[s][1], zs = z + G.sh[s][2];
+  const int wxi = xs / G.wx, wyi = ys / G.wy, wzi = zs / G.wz;
+  w = b * (G.nwx * G.nwy * G.nwz) + wxi * G.nwy * G.nwz + wyi * G.nwz + wzi;
+  // row of the positional-embedding table: (z_in * wy + y_in) * wx + x_in
+  pos = ((zs - wzi * G.wz) * G.wy + (ys - wyi * G.wy)) * G.wx + (xs - wxi * G.wx);
+}
+
+__global__ __launch_bounds__(256) void fp_fill_k(const int32_t* __restrict__ vcoors, const int32_t* __restrict__ d_counts,
+                                                 fp_geom G, const int32_t* __restrict__ keep,
+                                                 const int32_t* __restrict__ inner0, const int32_t* __restrict__ inner1,
+                                                 const int32_t* __restrict__ tokbase0,
+                                                 const int32_t* __restrict__ tokbase1, int64_t* __restrict__ feat_index,
+                                                 int32_t* __restrict__ feat_index32,
+                                                 int64_t* __restrict__ out_coors, int32_t* __restrict__ tok1,
+                                                 int32_t* __restrict__ posidx0, int32_t* __restrict__ posidx1) {
+  const int m = d_counts[0];
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < m; v += gridDim.x * blockDim.x) {
+    if (keep[v] == 0) continue;
+    const int b = vcoors[4 * v], z = vcoors[4 * v + 1], y = vcoors[4 * v + 2], x = vcoors[4 * v + 3];
+    int w0, p0, w1, p1;
+    fp_window_of(G, 0, b, z, y, x, w0, p0);
+    fp_window_of(G, 1, b, z, y, x, w1, p1);
+    const int ni = tokbase0[w0] + inner0[v];  // position in the shift-0 CSR = row of the voxel in every output
+    feat_index[ni] = v;
+    feat_index32[ni] = v;
+    out_coors[4 * (int64_t)ni + 0] = b;
+    out_coors[4 * (int64_t)ni + 1] = z;
+    out_coors[4 * (int64_t)ni + 2] = y;
+    out_coors[4 * (int64_t)ni + 3] = x;
+    posidx0[ni] = p0;
+    posidx1[ni] = p1;
+    tok1[tokbase1[w1] + inner1[v]] = ni;
+  }
+}
+
+int fill_geom(fp_geom* G, int batch_size, const int32_t grid_zyx[3], const int32_t window_shape[3],
+              const int32_t* h_levels, int n_levels) {
+  if (batch_size < 1 || batch_size > 64 || !grid_zyx || !window_shape) return SST_ERR_ARG;
+  G->B = batch_size;
+  G->gz = grid_zyx[0];
+  G->gy = grid_zyx[1];
+  G->gx = grid_zyx[2];
+  G->wx = window_shape[0];
+  G->wy = window_shape[1];
+  G->wz = window_shape[2];
+  if (G->gz < 1 || G->gy < 1 || G->gx < 1 || G->wx < 1 || G->wy < 1 || G->wz < 1) return SST_ERR_ARG;
+  if ((int64_t)G->wx * G->wy * G->wz > 512) return SST_ERR_UNSUPPORTED;
+  if ((int64_t)G->B * G->gz * G->gy * G->gx > ((int64_t)1 << 28)) return SST_ERR_UNSUPPORTED;
+  G->nwx = (G->gx + G->wx - 1) / G->wx + 1;
+  G->nwy = (G->gy + G->wy - 1) / G->wy + 1;
+  G->nwz = (G->gz + G->wz - 1) / G->wz + 1;
+  G->sh[0][0] = G->wx;
+  G->sh[0][1] = G->wy;
+  G->sh[0][2] = G->wz;
+  G->sh[1][0] = G->wx / 2;
+  G->sh[1][1] = G->wy / 2;
+  G->sh[1][2] = G->wz / 2;
+  if (G->gz == G->wz) G->sh[0][2] = G->sh[1][2] = 0;  // 2-D windows on a flat grid (sst_ops.py:291-293)
+  G->n_levels = n_levels;
+  for (int l = 0; l < 8; ++l) {
+    G->cap[l] = (h_levels && l < n_levels) ? h_levels[3 * l + 0] : 0;
+    G->lo[l] = (h_levels && l < n_levels) ? h_levels[3 * l + 1] : 0;
+    G->hi[l] = (h_levels && l < n_levels) ? h_levels[3 * l + 2] : 0;
+  }
+  return SST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sst_frame_windows_per_sample(const int32_t grid_zyx[3], const int32_t window_shape[3]) {
+  fp_geom G;
+  if (fill_geom(&G, 1, grid_zyx, window_shape, nullptr, 0) != SST_OK) return -1;
+  return (int64_t)G.nwx * G.nwy * G.nwz;
+}
+
+int sst_frame_voxels_i32(const uint64_t* d_ukeys, const int32_t* d_offsets, const uint32_t* d_perm,
+                         const int32_t* d_num_groups, int64_t n_points, int batch_size, const int32_t grid_zyx[3],
+                         int drop_mode, int32_t* d_vcoors, int32_t* d_gidx, int32_t* d_coors_map, int32_t* d_grid,
+                         int32_t* d_counts, void* stream) {
+  if (n_points < 0 || (drop_mode != 0 && drop_mode != 1)) return SST_ERR_ARG;
+  const int32_t win1[3] = {1, 1, 1};
+  fp_geom G;
+  int rc = fill_geom(&G, batch_size, grid_zyx, win1, nullptr, 0);
+  if (rc != SST_OK) return rc;
+  if (!d_counts || !d_grid) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  SST_HIP(hipMemsetAsync(d_counts, 0, 8 * sizeof(int32_t), st));
+  SST_HIP(hipMemsetAsync(d_grid, 0xff, sizeof(int32_t) * (size_t)G.B * G.gz * G.gy * G.gx, st));
+  if (n_points == 0) return SST_OK;
+  if (!d_ukeys || !d_offsets || !d_perm || !d_num_groups || !d_vcoors || !d_gidx || !d_coors_map) return SST_ERR_ARG;
+  hipLaunchKernelGGL(fp_voxels_k, dim3(sst_grid_1d(n_points, 256)), dim3(256), 0, st, d_ukeys, d_offsets, d_perm,
+                     d_num_groups, G, drop_mode, d_vcoors, d_gidx, d_coors_map, d_grid, d_counts);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int64_t sst_window_plan_workspace_bytes(int64_t n_upper, int64_t n_windows) {
+  const int64_t n = n_upper > 0 ? n_upper : 1, w = n_windows > 0 ? n_windows : 1;
+  return 4 * sst_align_up(4 * n, 256) + 4 * sst_align_up(4 * (w + 1), 256);
+}
+
+int sst_window_plan_i32(const int32_t* d_vcoors, const int32_t* d_grid, int64_t n_upper, int batch_size,
+                        const int32_t grid_zyx[3], const int32_t window_shape[3], const int32_t* h_levels, int n_levels,
+                        uint32_t seed, int64_t* d_feat_index, int32_t* d_feat_index32, int64_t* d_out_coors,
+                        int32_t* d_tok1,
+                        int32_t* d_winoff0, int32_t* d_winoff1, int32_t* d_posidx0, int32_t* d_posidx1,
+                        int32_t* d_counts, void* d_workspace, void* stream) {
+  if (n_upper < 0 || n_levels < 1 || n_levels > 8 || !h_levels) return SST_ERR_ARG;
+  fp_geom G;
+  int rc = fill_geom(&G, batch_size, grid_zyx, window_shape, h_levels, n_levels);
+  if (rc != SST_OK) return rc;
+  if (n_upper == 0) return SST_OK;
+  if (!d_vcoors || !d_grid || !d_feat_index || !d_feat_index32 || !d_out_coors || !d_tok1 || !d_winoff0 || !d_winoff1 || !d_posidx0 ||
+      !d_posidx1 || !d_counts || !d_workspace)
+    return SST_ERR_ARG;
+  if (n_upper >= ((int64_t)1 << 30)) return SST_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_win = G.B * G.nwx * G.nwy * G.nwz;
+  sst_carver cv(d_workspace);
+  int32_t* keep_a = cv.take<int32_t>(n_upper);
+  int32_t* keep = cv.take<int32_t>(n_upper);
+  int32_t* inner0 = cv.take<int32_t>(n_upper);
+  int32_t* inner1 = cv.take<int32_t>(n_upper);
+  int32_t* cntk0 = cv.take<int32_t>(n_win + 1);
+  int32_t* cntk1 = cv.take<int32_t>(n_win + 1);
+  int32_t* tokbase0 = cv.take<int32_t>(n_win + 1);
+  int32_t* tokbase1 = cv.take<int32_t>(n_win + 1);
+  // keep flags of rows beyond M (and of voxels outside every visited cell: none) must read as "dropped"
+  SST_HIP(hipMemsetAsync(keep_a, 0, 2 * sst_align_up(4 * n_upper, 256), st));
+  const dim3 wgrid((unsigned)((n_win + 3) / 4));
+  hipLaunchKernelGGL(fp_window_pass_k<0>, wgrid, dim3(256), 0, st, d_grid, G, seed, (const int32_t*)nullptr, keep_a,
+                     (int32_t*)nullptr, (int32_t*)nullptr);
+  hipLaunchKernelGGL(fp_window_pass_k<1>, wgrid, dim3(256), 0, st, d_grid, G, seed, keep_a, keep, inner1, cntk1);
+  hipLaunchKernelGGL(fp_window_pass_k<2>, wgrid, dim3(256), 0, st, d_grid, G, seed, keep, (int32_t*)nullptr, inner0,
+                     cntk0);
+  hipLaunchKernelGGL(fp_window_scan_k, dim3(2), dim3(1024), 0, st, cntk0, cntk1, n_win, tokbase0, tokbase1, d_winoff0,
+                     d_winoff1, d_counts);
+  hipLaunchKernelGGL(fp_fill_k, dim3(sst_grid_1d(n_upper, 256)), dim3(256), 0, st, d_vcoors, d_counts, G, keep, inner0,
+                     inner1, tokbase0, tokbase1, d_feat_index, d_feat_index32, d_out_coors, d_tok1, d_posidx0, d_posidx1);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+}  // extern "C"

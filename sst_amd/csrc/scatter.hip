@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict_
                                                         const int32_t* __restrict__ offsets,
                                                         const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                         float* __restrict__ out, int32_t* __restrict__ argmax,
-                                                        int32_t n_rows) {
+                                                        int32_t n_rows, const int32_t* __restrict__ d_mlim) {
+  if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int64_t total = m * c;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t g = e / c;
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
                                                            const int32_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
-                                                           int32_t n_rows) {
+                                                           int32_t n_rows, const int32_t* __restrict__ d_mlim) {
+  if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int c4 = c >> 2;
   const int64_t total = m * c4;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -108,7 +110,9 @@ __global__ __launch_bounds__(256) void seg_reduce_bwd_add_k(const float* __restr
                                                             const int32_t* __restrict__ inverse, int shift,
                                                             const int32_t* __restrict__ offsets,
                                                             const int32_t* __restrict__ gidx, int64_t m,
-                                                            int64_t n, int mode, float* __restrict__ gfeats) {
+                                                            int64_t n, int mode, float* __restrict__ gfeats,
+                                                            const int32_t* __restrict__ d_mlim) {
+  if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;
   const int64_t total = n * c;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = e / c;
@@ -129,7 +133,9 @@ __global__ __launch_bounds__(256) void seg_reduce_bwd_add_k(const float* __restr
 // MAX backward: one thread per (group, channel) routes its gradient to the recorded argmax row.
 __global__ __launch_bounds__(256) void seg_reduce_bwd_max_k(const float* __restrict__ gout, int c,
                                                             const int32_t* __restrict__ argmax, int64_t m,
-                                                            int64_t n, float* __restrict__ gfeats) {
+                                                            int64_t n, float* __restrict__ gfeats,
+                                                            const int32_t* __restrict__ d_mlim) {
+  if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;
   const int64_t total = m * c;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int ch = (int)(e % c);
@@ -235,27 +241,28 @@ int sst_vfe_decorate_f32(const float* d_points, int64_t ldp, int64_t n, int c, c
 
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
-                               float* d_out, int32_t* d_argmax, void* stream) {
+                               float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream) {
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_offsets || !d_out || (n > 0 && (!d_feats || !d_perm))) return SST_ERR_ARG;
   if ((c & 3) == 0 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15) == 0 && n > 0) {
     const int grid = sst_grid_1d(m * (c >> 2), 256);
     hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                       d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n);
+                       d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
     SST_LAUNCH_CHECK();
     return SST_OK;
   }
   const int grid = sst_grid_1d(m * c, 256);
   hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                     d_group_index, m, mode, d_out, d_argmax, (int32_t)n);
+                     d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
 
 int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const int32_t* d_inverse,
                                int inverse_shift, const int32_t* d_offsets, const int32_t* d_group_index,
-                               const int32_t* d_argmax, int64_t n, int mode, float* d_grad_feats, void* stream) {
+                               const int32_t* d_argmax, int64_t n, int mode, float* d_grad_feats,
+                               const int32_t* d_m_limit, void* stream) {
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (n == 0) return SST_OK;
   if (!d_grad_feats) return SST_ERR_ARG;
@@ -266,7 +273,7 @@ int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const 
     if (!d_grad_out || !d_argmax) return SST_ERR_ARG;
     const int grid = sst_grid_1d(m * c, 256);
     hipLaunchKernelGGL(seg_reduce_bwd_max_k, dim3(grid), dim3(256), 0, st, d_grad_out, c, d_argmax, m, n,
-                       d_grad_feats);
+                       d_grad_feats, d_m_limit);
   } else {
     if (m == 0) {
       SST_HIP(hipMemsetAsync(d_grad_feats, 0, sizeof(float) * n * c, st));
@@ -275,7 +282,7 @@ int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const 
     if (!d_grad_out || !d_inverse || !d_offsets) return SST_ERR_ARG;
     const int grid = sst_grid_1d(n * c, 256);
     hipLaunchKernelGGL(seg_reduce_bwd_add_k, dim3(grid), dim3(256), 0, st, d_grad_out, c, d_inverse, inverse_shift,
-                       d_offsets, d_group_index, m, n, mode, d_grad_feats);
+                       d_offsets, d_group_index, m, n, mode, d_grad_feats, d_m_limit);
   }
   SST_LAUNCH_CHECK();
   return SST_OK;

@@ -1,0 +1,151 @@
+"""Index plan of a frame batch without host round trips (csrc/frame_plan.hip).
+
+The piecewise path (``Voxelization`` -> ``DynamicVFE.scatter_plan`` -> ``SSTInputLayerV2.build_plan``) mirrors the
+reference's module boundaries, and every boundary hands over a tensor whose first dimension is a device-side count
+(voxels after the sorted-unique, survivors and windows after the drop): three read-backs and ~150 small launches per
+step.  ``FramePlan`` builds the same plan - the point -> voxel grouping DynamicVFE reduces over (with the reference's
+"first voxel of every sample" quirk), the kept voxels in window-major order, the window CSR of both partitions, the
+positional-embedding rows - from upper-bound sized buffers, keeps the counts on the device, and reads them ONCE in
+``finalize()``, which the caller invokes after it has queued the voxel encoder's feature kernels.
+
+Semantics: kept-voxel set, window membership and window order are those of ``SSTInputLayerV2`` with
+``window_major=True``; with ``shuffle_voxels=False`` the drop is by ascending voxel index (tests compare the two
+paths bit for bit), with ``shuffle_voxels=True`` a uniformly random subset of every over-full window survives, as
+with the reference's ``randperm`` (sst_input_layer_v2.py:93-97, 128-148).
+"""
+import torch
+
+from . import _lib
+from . import kernels as K
+
+
+class FramePlan(object):
+
+    def __init__(self):
+        self.info = None
+
+    # -- the interface DynamicVFE.forward uses of a scatter plan ------------------------------------------------
+    def reduce(self, feats, mode):
+        """Segmented reduce of point features over the kept voxels: [n_upper, C], rows >= M (device count) are
+        never written or read."""
+        return K.segment_reduce(feats, self.groups, mode, group_index=self.gidx, inverse=self.coors_map,
+                                m_limit=self.d_counts[0:1])
+
+    @property
+    def voxel_coors(self):
+        return self.vcoors
+
+    # -----------------------------------------------------------------------------------------------------------
+    def finalize(self, voxel_feats, input_layer, feat_dim=None):
+        """Read the sizes (the only host synchronisation of the plan) and return the ``voxel_info`` dictionary the
+        SST backbone consumes: surviving voxel features in window-major order, their coordinates, the window CSR and
+        the positional embedding of both partitions."""
+        counts = self.d_counts.tolist()
+        m, m_keep, n_win, t_max = counts[0], counts[1], (counts[2], counts[3]), (counts[4], counts[5])
+        self.num_voxels, self.num_kept = m, m_keep
+        dev = voxel_feats.device
+        feat_index = self.feat_index[:m_keep]
+        info = {'voxel_feats': GatherRows.apply(voxel_feats, feat_index, self.feat_index_i32[:m_keep]),
+                'voxel_coors': self.out_coors[:m_keep], 'voxel_keep_inds': feat_index}
+        cap = self.max_tokens_cap
+        tok0 = torch.arange(m_keep, dtype=torch.int32, device=dev)
+        toks = (tok0, self.tok1)
+        winoffs = (self.winoff0, self.winoff1)
+        dim = voxel_feats.size(1) if feat_dim is None else feat_dim
+        table = input_layer.pos_table_cached(dim, voxel_feats.dtype, dev)
+        for i in range(2):
+            info[f'sra_plan_shift{i}'] = K.WindowPlan(toks[i], winoffs[i], n_win[i], m_keep,
+                                                      min(cap, max(1, t_max[i])))
+            info[f'pos_embed_shift{i}'] = K.gather_rows(table, (self.posidx0, self.posidx1)[i][:m_keep])
+        self.info = info
+        return info
+
+
+class GatherRows(torch.autograd.Function):
+    """rows ``index`` of a [N, C] fp32 tensor (index entries unique); backward = zero-fill + row scatter (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, src, index_i64, index_i32):
+        ctx.save_for_backward(index_i32)
+        ctx.rows = src.size(0)
+        return K.gather_rows(src.contiguous(), index_i32)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        out = torch.zeros((ctx.rows, grad.size(1)), dtype=grad.dtype, device=grad.device)
+        K.scatter_rows(grad.contiguous(), idx, out)
+        return out, None, None
+
+
+class FramePlanner(object):
+    """Builds FramePlans for one (Voxelization, DynamicVFE, SSTInputLayerV2) triple; ``supported()`` tells whether the
+    configuration is one the fused kernels cover (otherwise callers use the piecewise path)."""
+
+    def __init__(self, voxel_layer, voxel_encoder, input_layer):
+        self.voxel_layer, self.vfe, self.layer = voxel_layer, voxel_encoder, input_layer
+        self.grid_zyx = [int(g) for g in voxel_encoder._grid_zyx()]
+        sx, sy, sz = input_layer.sparse_shape
+        self.window = [int(w) for w in input_layer._window_shape3()]
+        self._ok = ([sz, sy, sx] == self.grid_zyx and not input_layer.reference_outputs
+                    and self.window[0] * self.window[1] * self.window[2] <= 512)
+
+    def supported(self, batch_size):
+        cells = batch_size * self.grid_zyx[0] * self.grid_zyx[1] * self.grid_zyx[2]
+        return self._ok and 1 <= batch_size <= 64 and cells <= (1 << 28)
+
+    @torch.no_grad()
+    def build(self, points_list):
+        lib = _lib.load()
+        layer, vfe = self.layer, self.vfe
+        layer.set_drop_info()
+        bsz = len(points_list)
+        points, coors = self.voxel_layer.voxelize_batch(points_list)
+        n = coors.size(0)
+        dev = coors.device
+        gz, gy, gx = self.grid_zyx
+        plan = FramePlan()
+        plan.points, plan.coors, plan.n_points = points, coors, n
+        # 1. sorted-unique voxel keys of the points (count stays on the device)
+        groups = K.unique_rows(coors, [0, -1, -1, -1], [bsz, gz + 1, gy + 1, gx + 1], invalid_if_negative=2,
+                               defer_count=True)
+        plan.groups = groups
+        n_up = max(n, 1)
+        plan.n_upper = n_up
+
+        def e32(k):
+            return torch.empty(k, dtype=torch.int32, device=dev)
+
+        plan.vcoors = torch.empty((n_up, 4), dtype=torch.int32, device=dev)
+        plan.gidx, plan.coors_map = e32(n_up), e32(n_up)
+        plan.d_counts = e32(8)
+        grid = e32(bsz * gz * gy * gx)
+        rc = lib.sst_frame_voxels_i32(_lib.ptr(groups.ukeys), _lib.ptr(groups.offsets), _lib.ptr(groups.perm),
+                                      _lib.ptr(groups.num), n, bsz, _lib.i32array(self.grid_zyx),
+                                      1 if vfe.reference_compat else 0, _lib.ptr(plan.vcoors), _lib.ptr(plan.gidx),
+                                      _lib.ptr(plan.coors_map), _lib.ptr(grid), _lib.ptr(plan.d_counts),
+                                      _lib.stream_ptr())
+        _lib.check(rc, 'sst_frame_voxels_i32')
+        plan.coors_map = plan.coors_map[:n]
+        # 2. window bucketing, drop, window CSR of both partitions
+        _, levels = layer._levels()
+        flat = []
+        for (cap, lo, hi) in levels:
+            flat += [int(cap), int(lo), int(min(hi, 2 ** 31 - 1))]
+        plan.max_tokens_cap = max(l[0] for l in levels)
+        n_win = bsz * int(lib.sst_frame_windows_per_sample(_lib.i32array(self.grid_zyx), _lib.i32array(self.window)))
+        plan.feat_index = torch.empty(n_up, dtype=torch.int64, device=dev)
+        plan.feat_index_i32 = e32(n_up)
+        plan.out_coors = torch.empty((n_up, 4), dtype=torch.int64, device=dev)
+        plan.tok1, plan.posidx0, plan.posidx1 = e32(n_up), e32(n_up), e32(n_up)
+        plan.winoff0, plan.winoff1 = e32(n_win + 1), e32(n_win + 1)
+        seed = int(torch.randint(1, 2 ** 31 - 1, (1,)).item()) if layer.shuffle_voxels else 0   # host RNG, no sync
+        ws = _lib.workspace(lib.sst_window_plan_workspace_bytes(n_up, n_win), dev)
+        rc = lib.sst_window_plan_i32(_lib.ptr(plan.vcoors), _lib.ptr(grid), n_up, bsz, _lib.i32array(self.grid_zyx),
+                                     _lib.i32array(self.window), _lib.i32array(flat), len(levels), seed,
+                                     _lib.ptr(plan.feat_index), _lib.ptr(plan.feat_index_i32), _lib.ptr(plan.out_coors),
+                                     _lib.ptr(plan.tok1),
+                                     _lib.ptr(plan.winoff0), _lib.ptr(plan.winoff1), _lib.ptr(plan.posidx0),
+                                     _lib.ptr(plan.posidx1), _lib.ptr(plan.d_counts), _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, 'sst_window_plan_i32')
+        return plan

@@ -79,13 +79,13 @@ def sort_pairs_u64(keys, key_bits):
 
 class UniquePlan(object):
     """Result of unique_rows: the grouping of N rows into M sorted-unique rows (all device int32)."""
-    __slots__ = ('n', 'm', 'perm', 'inverse', 'offsets', 'ukeys', 'mins', 'extents', 'ncols', 'has_invalid_group')
+    __slots__ = ('n', 'm', 'num', 'perm', 'inverse', 'offsets', 'ukeys', 'mins', 'extents', 'ncols', 'has_invalid_group')
 
     def counts(self):
         return self.offsets[1:self.m + 1] - self.offsets[:self.m]
 
 
-def unique_rows(coors, mins=None, extents=None, invalid_if_negative=False):
+def unique_rows(coors, mins=None, extents=None, invalid_if_negative=False, defer_count=False):
     """Sorted-unique of integer rows (torch.unique(dim=0, return_inverse) / at::unique_dim semantics).
 
     coors: [N, k] int32 or int64 (cuda, contiguous).  mins/extents: per-column lower bound and extent;
@@ -125,7 +125,11 @@ def unique_rows(coors, mins=None, extents=None, invalid_if_negative=False):
                              _lib.ptr(plan.offsets), _lib.ptr(plan.ukeys), _lib.ptr(num), _lib.ptr(ws),
                              _lib.stream_ptr())
     _lib.check(rc, 'sst_unique_rows')
-    plan.m = int(num.item())  # the one host sync the reference API forces (output shape [M, ...])
+    plan.num = num
+    if defer_count:
+        plan.m = None             # stays on the device (plan.num); the caller works with the upper bound n
+    else:
+        plan.m = int(num.item())  # the one host sync the reference API forces (output shape [M, ...])
     plan.inverse = plan.inverse[:n]
     plan.perm = plan.perm[:n]
     return plan
@@ -152,13 +156,13 @@ def unpack_unique_rows(plan, dtype, first=0, count=None, out_cols=None, col0=0, 
 # ----------------------------------------------------------------------------------------------
 # (a3/a5/a15) segmented reduce with autograd
 # ----------------------------------------------------------------------------------------------
-def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=None):
+def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=None, m_limit=None):
     n, c = feats.shape
     out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
     argmax = torch.empty((m, c), dtype=torch.int32, device=feats.device) if want_argmax else None
     rc = _lib.load().sst_segment_reduce_fwd_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets),
                                                 _lib.ptr(group_index), m, mode, _lib.ptr(out), _lib.ptr(argmax),
-                                                _lib.stream_ptr())
+                                                _lib.ptr(m_limit), _lib.stream_ptr())
     _lib.check(rc, 'sst_segment_reduce_fwd_f32')
     return out, argmax
 
@@ -171,15 +175,16 @@ class SegmentReduce(Function):
     """
 
     @staticmethod
-    def forward(ctx, feats, perm, offsets, inverse, m, mode, inverse_shift, group_index=None):
+    def forward(ctx, feats, perm, offsets, inverse, m, mode, inverse_shift, group_index=None, m_limit=None):
         if feats.dtype != torch.float32:
             raise RuntimeError('sst_amd: features must be float32')
         feats = feats.contiguous()
         _lib.require_cuda(feats, perm, offsets)
-        out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2, group_index)
+        out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2, group_index, m_limit)
         ctx.mode, ctx.m, ctx.shift = mode, m, inverse_shift
         ctx.shape = feats.shape
         ctx.has_gidx = group_index is not None
+        ctx.m_limit = m_limit   # device int32 [1]: rows of the output that exist (m is an upper bound), or None
         ctx.save_for_backward(offsets, inverse, argmax if argmax is not None else offsets,
                               group_index if group_index is not None else offsets)
         return out
@@ -193,18 +198,20 @@ class SegmentReduce(Function):
         rc = _lib.load().sst_segment_reduce_bwd_f32(
             _lib.ptr(grad_out), ctx.m, c, _lib.ptr(inverse), ctx.shift, _lib.ptr(offsets),
             _lib.ptr(gidx) if ctx.has_gidx else None, _lib.ptr(argmax) if ctx.mode == 2 else None, n, ctx.mode,
-            _lib.ptr(grad_feats), _lib.stream_ptr())
+            _lib.ptr(grad_feats), _lib.ptr(ctx.m_limit), _lib.stream_ptr())
         _lib.check(rc, 'sst_segment_reduce_bwd_f32')
-        return grad_feats, None, None, None, None, None, None, None
+        return grad_feats, None, None, None, None, None, None, None, None
 
 
-def segment_reduce(feats, plan, mode, first=0, group_index=None, inverse=None):
+def segment_reduce(feats, plan, mode, first=0, group_index=None, inverse=None, m_limit=None):
     """Reduce rows of feats over groups [first, plan.m) of a UniquePlan; mode in 'sum'|'mean'|'max'.
     group_index ([m'] int32, with ``inverse`` = point -> output row map): output row g reduces group
-    group_index[g] (subset / re-ordering of the groups without gathering the result)."""
+    group_index[g] (subset / re-ordering of the groups without gathering the result).
+    m_limit (device int32 [1], with group_index): the number of valid rows of group_index when only the device
+    knows it; the output then has group_index.numel() rows of which the first *m_limit are written."""
     if group_index is not None:
         return SegmentReduce.apply(feats, plan.perm, plan.offsets, inverse, group_index.numel(), REDUCE[mode], 0,
-                                   group_index)
+                                   group_index, m_limit)
     m = plan.m - first
     offsets = plan.offsets[first:]
     return SegmentReduce.apply(feats, plan.perm, offsets, plan.inverse, m, REDUCE[mode], -first)

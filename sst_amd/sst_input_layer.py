@@ -292,15 +292,20 @@ class SSTInputLayerV2(nn.Module):
             pos = torch.cat([pos, torch.zeros((pos.size(0), gap), dtype=dtype, device=device)], dim=1)
         return pos
 
+    def pos_table_cached(self, feat_dim, dtype, device):
+        """pos_table of the current configuration, built once (it only depends on the configuration)"""
+        key = (feat_dim, dtype, str(device), self.pos_temperature, self.normalize_pos)
+        cache = self.__dict__.setdefault('_pos_table_cache', {})
+        table = cache.get(key)
+        if table is None:
+            table = cache[key] = self.pos_table(feat_dim, dtype, device)
+        return table
+
     @torch.no_grad()
     def get_pos_embed_flat(self, coors_in_win, feat_dim, dtype):
         """[M, feat_dim] positional embedding of every voxel (flat layout)."""
         wx, wy, _ = self._window_shape3()
-        key = (feat_dim, dtype, str(coors_in_win.device), self.pos_temperature, self.normalize_pos)
-        cache = self.__dict__.setdefault('_pos_table_cache', {})
-        table = cache.get(key)
-        if table is None:  # the table only depends on the configuration: build it once
-            table = cache[key] = self.pos_table(feat_dim, dtype, coors_in_win.device)
+        table = self.pos_table_cached(feat_dim, dtype, coors_in_win.device)
         c = coors_in_win.long()
         idx = (c[:, 0] * wy + c[:, 1]) * wx + c[:, 2]
         return table.index_select(0, idx)

@@ -15,37 +15,46 @@ def _copy_weights(gpu, cpu):
     load_pipeline_weights(cpu, gpu)
 
 
-@pytest.mark.parametrize('n_points,blocks', [(6000, 1), (30000, 2)])
-def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks):
-    import bench
-    from oracle.cpu_pipeline import CpuSSTBackbone
-    torch.manual_seed(0)
-    gpu = bench.Pipeline(blocks).to(DEV).train()
-    gpu.middle_encoder.shuffle_voxels = False        # the CPU port has no shuffle; the drop itself stays on
-    cpu = CpuSSTBackbone(bench.VOXEL_SIZE, bench.PC_RANGE, bench.DROP_TRAIN, num_blocks=blocks).train()
-    _copy_weights(gpu, cpu)
-    # crowd part of the cloud so that windows exceed the 100-token cap and voxels really get dropped
+def _crowded_frames(bench, n_points):
+    """part of the cloud crowded so that windows exceed the 100-token cap and voxels really get dropped"""
     g = torch.Generator().manual_seed(1)
     pts = bench.make_cloud(n_points, 5, 'cpu')
     dense = torch.rand(n_points // 3, 3, generator=g) * torch.tensor([7.0, 7.0, 6.0]) + torch.tensor([10.0, 10.0, -2.0])
-    frames = [torch.cat([pts, dense]), bench.make_cloud(n_points // 2, 6, 'cpu')]
+    return [torch.cat([pts, dense]), bench.make_cloud(n_points // 2, 6, 'cpu')], g
 
-    info_out = {}
-    orig_apply = gpu.middle_encoder.apply_plan
 
-    def spy(plan, feats):
-        info = orig_apply(plan, feats)
-        info_out['coors'] = info['voxel_coors']
-        return info
-    gpu.middle_encoder.apply_plan = spy
+@pytest.mark.parametrize('fused_index', [True, False])
+@pytest.mark.parametrize('n_points,blocks', [(6000, 1), (30000, 2)])
+def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks, fused_index):
+    import bench
+    from oracle.cpu_pipeline import CpuSSTBackbone, voxel_sort_key
+    torch.manual_seed(0)
+    gpu = bench.Pipeline(blocks).to(DEV).train()
+    gpu.fused_index = fused_index
+    gpu.middle_encoder.shuffle_voxels = False        # the CPU port has no shuffle; the drop itself stays on
+    cpu = CpuSSTBackbone(bench.VOXEL_SIZE, bench.PC_RANGE, bench.DROP_TRAIN, num_blocks=blocks).train()
+    _copy_weights(gpu, cpu)
+    frames, g = _crowded_frames(bench, n_points)
+
+    # per-point gradients at the outputs of the two VFE layers, to count the max-pooling decisions that differ
+    pf_g, pf_c = [], []
+    for layer in gpu.voxel_encoder.vfe_layers:
+        def hooked(x, fwd=layer.forward):
+            y = fwd(x)
+            y.retain_grad()
+            pf_g.append(y)
+            return y
+        layer.forward = hooked
+    cpu.vfe.keep_point_feats = pf_c
+
     out_g = gpu([f.to(DEV) for f in frames])
     out_c = cpu(frames)
     # the CPU port keeps the kept voxels in sorted-unique order; the GPU pipeline emits them window-major
-    coors_g = info_out['coors'].cpu().long()
-    key_g = ((coors_g[:, 0] * 2 + coors_g[:, 1]) * 468 + coors_g[:, 2]) * 468 + coors_g[:, 3]
+    key_g = voxel_sort_key(gpu.last_voxel_coors.cpu())
     order = torch.argsort(key_g)
     assert out_g.size(0) == out_c.size(0), 'different sets of kept voxels'
-    assert torch.equal(key_g[order], torch.sort(key_g)[0]) and key_g.unique().numel() == key_g.numel()
+    assert torch.equal(key_g[order], voxel_sort_key(cpu.last_voxel_coors)), 'different sets of kept voxels'
+    assert out_g.size(0) < voxel_sort_key(cpu.last_all_voxel_coors).numel() or n_points < 10000, 'no voxel was dropped'
     err = (out_g.detach().cpu()[order] - out_c.detach()).abs().max().item()
     assert err < 1e-3, f'end-to-end feature error {err}'
 
@@ -72,15 +81,25 @@ def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks):
     import os
     log_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     if os.path.isdir(log_dir):
-        with open(os.path.join(log_dir, f'e2e_grad_errs_{n_points}.json'), 'w') as f:
+        with open(os.path.join(log_dir, f'e2e_grad_errs_{n_points}_{int(fused_index)}.json'), 'w') as f:
             json.dump({'feature_err': err, 'grad_errs': errs}, f)
     # the transformer's parameters sit behind smooth functions only: the north-star bar applies as it stands
     for name in ('layer0.in_proj', 'layer0.linear1', 'last.norm2', 'last.linear2'):
         assert errs[name] < 1e-3, f'relative parameter gradient errors {errs}'
-    # the VFE's parameters sit behind max pooling over the points of a voxel and BN + ReLU (discontinuous gradients)
-    # and behind batch statistics over 1e5 points (fp64 moments on the GPU, fp32 in the CPU port)
+    # The VFE's parameters sit behind max pooling over the points of a voxel: where two points of a voxel are within
+    # rounding of each other in a channel, the two devices may route the gradient to different points (measured with
+    # tools/diag_vfe_grad.py: forward values equal to 2e-6, 2 of 55 000 point rows receive another gradient).  Count
+    # those rows: without a flipped decision the north-star bar applies, with flips (a handful of rows) the bound is
+    # the one such a row can move the sum by.
+    flips = 0
+    for a, b in zip(pf_g, pf_c):
+        d = (a.grad.cpu() - b.grad).abs().max(1).values
+        flips += int((d > 1e-4 * float(b.grad.abs().max())).sum())
+    n_rows = pf_c[0].size(0)
+    assert flips <= max(4, n_rows // 5000), f'{flips} point rows with a different pooling decision'
+    tol = 1e-3 if flips == 0 else GRAD_TOL_VFE
     for name in ('vfe0.linear', 'vfe1.linear', 'vfe1.norm'):
-        assert errs[name] < GRAD_TOL_VFE, f'relative parameter gradient errors {errs}'
+        assert errs[name] < tol, f'relative parameter gradient errors {errs} ({flips} flipped pooling decisions)'
 
 
 def test_headline_config_forward_parity():

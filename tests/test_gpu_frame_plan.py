@@ -1,0 +1,145 @@
+"""GPU: the fused index plan (csrc/frame_plan.hip: no host round trips) against the piecewise path through the module
+interfaces (Voxelization -> DynamicVFE.scatter_plan -> SSTInputLayerV2.build_plan), which itself is pinned to the
+reference's golden tensors (tests/test_gpu_window.py, test_gpu_voxel.py).  Integer outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import DROP_TEST, DROP_TRAIN, PC_RANGE, VOXEL_SIZE
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _modules(shuffle=False, train=True, window_shape=(12, 12, 1)):
+    import sst_amd
+    vox = sst_amd.Voxelization(VOXEL_SIZE, PC_RANGE, -1, (-1, -1))
+    vfe = sst_amd.DynamicVFE(in_channels=3, feat_channels=[64, 128], voxel_size=VOXEL_SIZE, with_cluster_center=True,
+                             with_voxel_center=True, point_cloud_range=PC_RANGE,
+                             norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01)).to(DEV)
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), window_shape, (468, 468, 1), shuffle_voxels=shuffle,
+                                    debug=False, mute=True, reference_outputs=False, window_major=True)
+    layer.train(train)
+    return vox, vfe, layer
+
+
+def _clouds(kind):
+    g = torch.Generator().manual_seed(7)
+    span = torch.tensor([149.76, 149.76, 6.0])
+    lo = torch.tensor([-74.88, -74.88, -2.0])
+    if kind == 'uniform':
+        return [torch.rand(20000, 3, generator=g) * span + lo]
+    if kind == 'crowded2':     # two samples, windows far above the 100-token cap, points outside the range
+        a = torch.cat([torch.rand(9000, 3, generator=g) * span + lo,
+                       torch.rand(9000, 3, generator=g) * torch.tensor([9.0, 9.0, 6.0]) + torch.tensor([3.0, -20.0, -2.0]),
+                       torch.rand(200, 3, generator=g) * 400 - 200])
+        b = torch.cat([torch.rand(4000, 3, generator=g) * span + lo,
+                       torch.rand(6000, 3, generator=g) * torch.tensor([6.0, 12.0, 6.0]) + torch.tensor([-60.0, 40.0, -2.0])])
+        return [a, b]
+    if kind == 'tiny3':
+        return [torch.rand(5, 3, generator=g) * span + lo, torch.rand(1, 3, generator=g) * span + lo,
+                torch.rand(40, 3, generator=g) * span + lo]
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('kind', ['uniform', 'crowded2', 'tiny3'])
+def test_fused_plan_equals_piecewise_path(kind, train):
+    from sst_amd.frame_plan import FramePlanner
+    vox, vfe, layer = _modules(train=train)
+    clouds = [c.to(DEV) for c in _clouds(kind)]
+    # piecewise
+    points, coors = vox.voxelize_batch(clouds)
+    sp = vfe.scatter_plan(coors)
+    wplan = layer.build_plan(sp.voxel_coors, len(clouds), 128, torch.float32)
+    # fused
+    planner = FramePlanner(vox, vfe, layer)
+    assert planner.supported(len(clouds))
+    plan = planner.build(clouds)
+    n = coors.size(0)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(n, 8, generator=g).to(DEV)
+    red_f = {mode: plan.reduce(feats, mode) for mode in ('max', 'mean')}
+    vfeat = torch.randn(plan.n_upper, 128, generator=g).to(DEV)
+    info_f = plan.finalize(vfeat, layer)
+    m = plan.num_voxels
+    assert m == sp.num_voxels
+    assert torch.equal(plan.coors_map, sp.coors_map)
+    assert torch.equal(plan.vcoors[:m], sp.voxel_coors)
+    for mode in ('max', 'mean'):
+        assert torch.equal(red_f[mode][:m], sp.reduce(feats, mode))
+    info_p = layer.apply_plan(wplan, vfeat[:m])
+    assert torch.equal(info_f['voxel_coors'], info_p['voxel_coors'])
+    assert torch.equal(info_f['voxel_keep_inds'], info_p['voxel_keep_inds'])
+    assert torch.equal(info_f['voxel_feats'], info_p['voxel_feats'])
+    if kind == 'crowded2' and train:
+        assert info_f['voxel_feats'].size(0) < m, 'the crowded cloud must lose voxels to the drop'
+    for i in range(2):
+        pf, pp = info_f[f'sra_plan_shift{i}'], info_p[f'sra_plan_shift{i}']
+        assert (pf.n_windows, pf.n_tokens, pf.max_tokens) == (pp.n_windows, pp.n_tokens, pp.max_tokens)
+        assert torch.equal(pf.winoff[:pf.n_windows + 1], pp.winoff[:pp.n_windows + 1])
+        assert torch.equal(pf.tok[:pf.n_tokens], pp.tok[:pp.n_tokens])
+        assert torch.equal(info_f[f'pos_embed_shift{i}'], info_p[f'pos_embed_shift{i}'])
+
+
+def test_fused_plan_gradient_paths():
+    """segmented max / mean over the upper-bound sized voxel table and the row gather of finalize(): gradients equal to
+    the piecewise path's."""
+    from sst_amd.frame_plan import FramePlanner
+    vox, vfe, layer = _modules()
+    clouds = [c.to(DEV) for c in _clouds('crowded2')]
+    points, coors = vox.voxelize_batch(clouds)
+    sp = vfe.scatter_plan(coors)
+    plan = FramePlanner(vox, vfe, layer).build(clouds)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(coors.size(0), 16, generator=g)
+    for mode in ('max', 'mean'):
+        fa, fb = feats.to(DEV).requires_grad_(True), feats.to(DEV).requires_grad_(True)
+        ra, rb = plan.reduce(fa, mode), sp.reduce(fb, mode)
+        w = torch.randn(rb.shape, generator=g).to(DEV)
+        m = rb.size(0)
+        (ra[:m] * w).sum().backward()
+        (rb * w).sum().backward()
+        assert torch.equal(fa.grad, fb.grad)
+    vfeat = torch.randn(plan.n_upper, 128, generator=g).to(DEV).requires_grad_(True)
+    info = plan.finalize(vfeat, layer)
+    w = torch.randn(info['voxel_feats'].shape, generator=g).to(DEV)
+    (info['voxel_feats'] * w).sum().backward()
+    ref = torch.zeros_like(vfeat)
+    ref[info['voxel_keep_inds']] = w
+    assert torch.equal(vfeat.grad, ref)
+
+
+def test_fused_plan_random_drop_invariants():
+    """shuffle_voxels=True: the survivors of an over-full window are a random subset - every window within its cap,
+    window membership consistent with the coordinates, all tokens distinct, another seed another subset."""
+    from sst_amd.frame_plan import FramePlanner
+    vox, vfe, layer = _modules(shuffle=True)
+    clouds = [c.to(DEV) for c in _clouds('crowded2')]
+    planner = FramePlanner(vox, vfe, layer)
+    kept_sets = []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        plan = planner.build(clouds)
+        vfeat = torch.zeros(plan.n_upper, 128, device=DEV)
+        info = plan.finalize(vfeat, layer)
+        coors = info['voxel_coors'].cpu().numpy()
+        mk = coors.shape[0]
+        assert mk < plan.num_voxels
+        key = ((coors[:, 0] * 2 + coors[:, 1]) * 468 + coors[:, 2]) * 468 + coors[:, 3]
+        assert np.unique(key).size == mk
+        kept_sets.append(set(key.tolist()))
+        for s, shift in ((0, 12), (1, 6)):
+            p = info[f'sra_plan_shift{s}']
+            off = p.winoff[:p.n_windows + 1].cpu().numpy()
+            tok = p.tok[:p.n_tokens].cpu().numpy()
+            sizes = np.diff(off)
+            assert sizes.min() >= 1 and sizes.max() <= 100 and off[-1] == mk
+            assert np.array_equal(np.sort(tok), np.arange(mk))
+            wid = (coors[:, 0] * 40 + (coors[:, 3] + shift) // 12) * 40 + (coors[:, 2] + shift) // 12
+            wid_tok = wid[tok]
+            starts = off[:-1]
+            seg = np.repeat(np.arange(p.n_windows), sizes)
+            assert np.array_equal(wid_tok, wid_tok[starts][seg]), 'a window of the CSR mixes voxels of two windows'
+            assert np.all(np.diff(wid_tok[starts]) > 0), 'windows not in ascending id order'
+    assert kept_sets[0] != kept_sets[1]
