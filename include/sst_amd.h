@@ -128,6 +128,29 @@ int sst_segment_reduce_bwd_f32(const float* d_grad_out, int64_t m, int c, const 
                                const int32_t* d_m_limit, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (a15 / f1) d_out[i] = [ d_x[i, 0:c1] | d_g[d_idx[i], 0:c2] ]  ([n, c1 + c2] contiguous): the gather by the inverse map
+ * + concatenation between the layers of DynamicVFE / DynamicScatterVFE / SIRLayer (voxel_encoders/voxel_encoder.py:
+ * 288-291, 605-607, 745-750) in one coalesced pass.  d_idx[i] < 0 reads row 0.  c1, c2 multiples of 4, 16-byte rows.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_concat_gather_f32(const float* d_x, int64_t ldx, int c1, const float* d_g, int64_t ldg, int c2,
+                          const int32_t* d_idx, int64_t n, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a14) SSTv2.recover_bev (models/backbones/sst_v2.py:161-197): voxel features [m, c] + coordinates (b, z, y, x)
+ * -> dense canvas of batch x ny x nx cells, written ONCE, cell by cell (the voxel's row or zeros), in CHANNELS-LAST
+ * order: d_canvas is [batch, ny, nx, c] contiguous = the channels-last memory of the reference's logical
+ * [batch, c, ny, nx] tensor (the host layer hands it on as that view).  c % 4 == 0, 16-byte aligned rows.
+ *   d_cell_map [batch*ny*nx] int32 scratch (cell -> voxel, -1 empty); d_cell_of_voxel [m] int32 out: the cell each
+ *   voxel was written to (-1: outside the canvas, or another voxel with the same cell was written instead - the
+ *   reference's index assignment keeps one of them too).  Backward: rows of the canvas gradient at those cells.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_recover_bev_f32(const float* d_feats, int64_t ldf, const void* d_coors, int coor_is_i64, int64_t ldc, int64_t m,
+                        int batch, int ny, int nx, int c, int32_t* d_cell_map, int32_t* d_cell_of_voxel, float* d_canvas,
+                        void* stream);
+int sst_recover_bev_bwd_f32(const float* d_grad_canvas, const int32_t* d_cell_of_voxel, int64_t m, int c,
+                            float* d_grad_feats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (f1) Decorate step of DynamicVFE / DynamicScatterVFE (voxel_encoders/voxel_encoder.py:252-271, :569-589) in one
  * launch: d_out[i] = [ point features (c) | xyz - mean xyz of the point's voxel, divided by cluster_div (3, if
  * with_cluster) | xyz - centre of the point's voxel (3, if with_center) ], bit-identical to the composed torch ops.
@@ -355,6 +378,14 @@ int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const flo
 int sst_tall_linear_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias,
                         int64_t m, int n, int k, int trans_w, int accumulate, float* d_y, int64_t ldy,
                         void* stream);
+/* The same product (n == 128, k == 128) with the FFN's GELU (erf form, sst_basic_block_v2.py:116) in the epilogue:
+ *   mode 0: y = x W^T + b and aux = gelu(y)   (linear1 + activation; both kept for the backward pass)
+ *   mode 1: y = (x W [+ b]) * gelu'(aux)      (data gradient through linear2 times the activation's derivative at
+ *                                              the pre-activation aux)
+ * d_aux has the row stride ldy.  A 256-wide FFN is two calls on column halves of W / y / aux. */
+int sst_tall_linear_gelu_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias,
+                             int64_t m, int n, int k, int trans_w, int mode, float* d_aux, float* d_y, int64_t ldy,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py `roofline`): HIP events attached to ONE launch of the register-resident SRA forward

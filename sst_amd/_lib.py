@@ -67,6 +67,8 @@ _SIGNATURES = {
     'sst_colsum_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr]),
     'sst_tall_linear_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i64,
                                     c_ptr]),
+    'sst_tall_linear_gelu_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr,
+                                         c_i64, c_ptr]),
     'sst_connected_components_workspace_bytes': (c_i64, [c_i64]),
     'sst_connected_components_xy_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_dynamic_point_pool_workspace_bytes': (c_i64, [c_i64, c_i64]),
@@ -86,6 +88,10 @@ _SIGNATURES = {
     'sst_spconv_wgrad_workspace_bytes': (c_i64, [c_i32, c_i64, c_i64, c_i32, c_i32]),
     'sst_spconv_wgrad_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32,
                                      c_ptr, c_ptr, c_ptr]),
+    'sst_concat_gather_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_recover_bev_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
+                                    c_ptr]),
+    'sst_recover_bev_bwd_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
     'sst_vfe_decorate_f32': (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_i64, ctypes.c_float, c_ptr, c_i32, c_i64,
                                      c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_event_create': (c_ptr, []),

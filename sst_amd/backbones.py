@@ -1,84 +1,128 @@
-"""SSTv2 and SIR backbones.
+"""SST and SIR backbones on the window-CSR kernels.
 
-Mirrors mmdet3d/models/backbones/sst_v2.py:16-196 and mmdet3d/models/backbones/sir.py:15-87 (registry
-names 'SSTv2' / 'SIR', constructor kwargs, forward signatures, state_dict keys
-``block_list.{i}.encoder_list.{0,1}.*``, ``conv_layer.{j}.{0,1}.*``, ``linear0.*``).
+Drop-in for the reference's registry entries 'SSTv2' (mmdet3d/models/backbones/sst_v2.py:16-196), 'SSTv1'
+(backbones/sst_v1.py:17-270) and 'SIR' (backbones/sir.py:15-87): constructor keywords, forward signatures and
+``state_dict`` keys (``block_list.{i}.encoder_list.{0,1}.*``, ``conv_layer.{j}.{0,1}.*``, ``linear0.*``) are the
+reference's, so its configs and checkpoints load unchanged.  The bodies are organised around this package's plan
+objects instead of the reference's per-level dictionaries:
+
+* both SST generations share one stem (`_WindowTransformer`): a stack of BasicShiftBlockV2 driven by two
+  ``kernels.WindowPlan`` (window CSR of the regular / shifted partition) and two flat [M, C] positional tensors -
+  whatever the input layer handed over (plans of this package, or the reference's flat2win dictionaries, which are
+  converted once per forward);
+* the dense BEV canvas is written by one kernel pass (csrc/scatter.hip, ``sst_recover_bev_f32``: every cell once,
+  channels-last) and handed on as the channels-last view of the reference's [B, C, ny, nx] tensor;
+* SIR groups the points of a cluster ONCE (``UniquePlan``) and every layer's pooling reuses it.
 """
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .norm import build_conv_layer, build_norm_layer
 from .registry import BACKBONES, build_voxel_encoder
 from .sst_basic_block import BasicShiftBlockV2, plan_from_reference_dicts
 from .sst_ops import unique_with_plan
 
 
-@BACKBONES.register_module()
-class SSTv2(nn.Module):
-    '''Single-stride Sparse Transformer (sst_v2.py:16-159).'''
+class _RecoverBEV(torch.autograd.Function):
+    """[M, C] voxel rows -> [B, ny, nx, C] canvas (csrc/scatter.hip); backward gathers the rows back."""
 
-    def __init__(
-        self,
-        d_model=[],
-        nhead=[],
-        num_blocks=6,
-        dim_feedforward=[],
-        dropout=0.0,
-        activation="gelu",
-        output_shape=None,
-        num_attached_conv=2,
-        conv_in_channel=64,
-        conv_out_channel=64,
-        norm_cfg=dict(type='naiveSyncBN2d', eps=1e-3, momentum=0.01),
-        conv_cfg=dict(type='Conv2d', bias=False),
-        debug=True,
-        in_channel=None,
-        to_bev=True,
-        conv_kwargs=dict(kernel_size=3, dilation=2, padding=2, stride=1),
-        checkpoint_blocks=[],
-        layer_cfg=dict(),
-        conv_shortcut=False,
-    ):
-        super().__init__()
-        self.d_model = d_model
-        self.nhead = nhead
-        self.checkpoint_blocks = checkpoint_blocks
-        self.conv_shortcut = conv_shortcut
-        self.to_bev = to_bev
+    @staticmethod
+    def forward(ctx, feats, coors, batch, ny, nx):
+        lib = _lib.load()
+        feats = feats.contiguous()
+        coors = coors.contiguous()
+        m, c = feats.shape
+        dev = feats.device
+        canvas = torch.empty((batch, ny, nx, c), dtype=torch.float32, device=dev)
+        cell_map = torch.empty(batch * ny * nx, dtype=torch.int32, device=dev)
+        cell_of_voxel = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+        rc = lib.sst_recover_bev_f32(_lib.ptr(feats), feats.stride(0), _lib.ptr(coors),
+                                     int(coors.dtype == torch.int64), coors.stride(0), m, batch, ny, nx, c,
+                                     _lib.ptr(cell_map), _lib.ptr(cell_of_voxel), _lib.ptr(canvas), _lib.stream_ptr())
+        _lib.check(rc, 'sst_recover_bev_f32')
+        ctx.save_for_backward(cell_of_voxel)
+        ctx.shape = (m, c)
+        return canvas
 
+    @staticmethod
+    def backward(ctx, grad_canvas):
+        (cell_of_voxel,) = ctx.saved_tensors
+        m, c = ctx.shape
+        grad_canvas = grad_canvas.contiguous()   # [B, ny, nx, C]
+        out = torch.empty((m, c), dtype=torch.float32, device=grad_canvas.device)
+        rc = _lib.load().sst_recover_bev_bwd_f32(_lib.ptr(grad_canvas), _lib.ptr(cell_of_voxel), m, c, _lib.ptr(out),
+                                                 _lib.stream_ptr())
+        _lib.check(rc, 'sst_recover_bev_bwd_f32')
+        return out, None, None, None, None
+
+
+def recover_bev(voxel_feat, coors, batch_size, output_shape):
+    """Dense [B, C, ny, nx] canvas of the voxel features (sst_v2.py:161-197), returned as the channels-last view of that
+    logical shape.  Shapes the kernel is not built for (C % 4 != 0, CPU tensors) take an index assignment in torch."""
+    ny, nx = output_shape
+    c = voxel_feat.shape[-1]
+    if voxel_feat.is_cuda and voxel_feat.dtype == torch.float32 and c % 4 == 0 and coors.dtype in (torch.int32, torch.int64):
+        return _RecoverBEV.apply(voxel_feat, coors, int(batch_size), int(ny), int(nx)).permute(0, 3, 1, 2)
+    flat = (coors[:, 0] * ny + coors[:, 2]) * nx + coors[:, 3]
+    canvas = voxel_feat.new_zeros((batch_size * ny * nx, c)).index_put((flat.long(),), voxel_feat)
+    return canvas.view(batch_size, ny, nx, c).permute(0, 3, 1, 2)
+
+
+def _batch_size_of(info, coors_key):
+    """number of samples: the input layer's own record when it left one, else the last batch index (one read-back, as
+    in the reference: sst_v2.py:136)"""
+    if info.get('batch_size') is not None:
+        return int(info['batch_size'])
+    coors = info[coors_key]
+    return int(coors[:, 0].max().item()) + 1 if coors.size(0) > 0 else 1
+
+
+class _WindowTransformer(nn.Module):
+    """What SSTv1 and SSTv2 have in common: optional input projection, the shift blocks, the attached convolutions."""
+
+    def _build_stem(self, d_model, nhead, num_blocks, dim_feedforward, dropout, activation, in_channel, layer_cfg,
+                    init_skip):
         if in_channel is not None:
             self.linear0 = nn.Linear(in_channel, d_model[0])
+        self.block_list = nn.ModuleList([
+            BasicShiftBlockV2(d_model[i], nhead[i], dim_feedforward[i], dropout, activation, batch_first=False, block_id=i,
+                              layer_cfg=layer_cfg) for i in range(num_blocks)])
+        # sst_v2.py:156-159 / sst_v1.py:216-219: Xavier on every matrix except the attention temperatures / scalers
+        for name, p in self.named_parameters():
+            if p.dim() > 1 and not any(tag in name for tag in init_skip):
+                nn.init.xavier_uniform_(p)
 
-        block_list = []
-        for i in range(num_blocks):
-            block_list.append(
-                BasicShiftBlockV2(d_model[i], nhead[i], dim_feedforward[i], dropout, activation, batch_first=False,
-                                  block_id=i, layer_cfg=layer_cfg))
-        self.block_list = nn.ModuleList(block_list)
-        self._reset_parameters()
-        self.output_shape = output_shape
-        self.debug = debug
-        self.num_attached_conv = num_attached_conv
+    def _build_attached_convs(self, count, conv_in_channel, conv_out_channel, norm_cfg, conv_cfg, conv_kwargs):
+        self.num_attached_conv = count
+        if count <= 0:
+            return
+        if isinstance(conv_kwargs, (list, tuple)):
+            assert len(conv_kwargs) == count
+            per_layer = list(conv_kwargs)
+        else:
+            per_layer = [conv_kwargs] * count
+        stages, width = [], conv_in_channel
+        for kw in per_layer:
+            stage = [build_conv_layer(conv_cfg, in_channels=width, out_channels=conv_out_channel, **kw)]
+            if norm_cfg is not None:
+                stage.append(build_norm_layer(norm_cfg, conv_out_channel)[1])
+            stage.append(nn.ReLU(inplace=True))
+            stages.append(nn.Sequential(*stage))
+            width = conv_out_channel
+        self.conv_layer = nn.ModuleList(stages)
 
-        if num_attached_conv > 0:
-            conv_list = []
-            for i in range(num_attached_conv):
-                if isinstance(conv_kwargs, dict):
-                    conv_kwargs_i = conv_kwargs
-                elif isinstance(conv_kwargs, list):
-                    assert len(conv_kwargs) == num_attached_conv
-                    conv_kwargs_i = conv_kwargs[i]
-                if i > 0:
-                    conv_in_channel = conv_out_channel
-                conv = build_conv_layer(conv_cfg, in_channels=conv_in_channel, out_channels=conv_out_channel,
-                                        **conv_kwargs_i)
-                if norm_cfg is None:
-                    convnormrelu = nn.Sequential(conv, nn.ReLU(inplace=True))
-                else:
-                    convnormrelu = nn.Sequential(conv, build_norm_layer(norm_cfg, conv_out_channel)[1],
-                                                 nn.ReLU(inplace=True))
-                conv_list.append(convnormrelu)
-            self.conv_layer = nn.ModuleList(conv_list)
+    def run_blocks(self, feats, pos, plans, masks=None):
+        x = self.linear0(feats) if hasattr(self, 'linear0') else feats
+        for i, block in enumerate(self.block_list):
+            x = block(x, pos, plans, masks, using_checkpoint=i in self.checkpoint_blocks)
+        return x
+
+    def run_attached_convs(self, canvas, shortcut=False):
+        for stage in getattr(self, 'conv_layer', ()):
+            y = stage(canvas)
+            canvas = y + canvas if (shortcut and y.shape == canvas.shape) else y
+        return canvas
 
     def set_impl(self, impl):
         """0: MFMA SRA kernels (default); 1: generic VALU kernels (in-library cross-check)."""
@@ -92,68 +136,59 @@ class SSTv2(nn.Module):
             for enc in block.encoder_list:
                 enc.fused = fused
 
+
+@BACKBONES.register_module()
+class SSTv2(_WindowTransformer):
+    '''Single-stride Sparse Transformer (sst_v2.py:16-159).'''
+
+    def __init__(self, d_model=[], nhead=[], num_blocks=6, dim_feedforward=[], dropout=0.0, activation="gelu",
+                 output_shape=None, num_attached_conv=2, conv_in_channel=64, conv_out_channel=64,
+                 norm_cfg=dict(type='naiveSyncBN2d', eps=1e-3, momentum=0.01), conv_cfg=dict(type='Conv2d', bias=False),
+                 debug=True, in_channel=None, to_bev=True,
+                 conv_kwargs=dict(kernel_size=3, dilation=2, padding=2, stride=1), checkpoint_blocks=[],
+                 layer_cfg=dict(), conv_shortcut=False):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.checkpoint_blocks = checkpoint_blocks
+        self.conv_shortcut = conv_shortcut
+        self.to_bev = to_bev
+        self.output_shape = output_shape
+        self.debug = debug
+        self._build_stem(d_model, nhead, num_blocks, dim_feedforward, dropout, activation, in_channel, layer_cfg,
+                         init_skip=('scaler', 'tau'))
+        self._build_attached_convs(num_attached_conv, conv_in_channel, conv_out_channel, norm_cfg, conv_cfg, conv_kwargs)
+
+    @staticmethod
+    def _window_inputs(voxel_info, shifts=2):
+        """(plans, positional tensors, key masks) per partition, from either kind of voxel_info"""
+        if 'sra_plan_shift0' in voxel_info:   # produced by this package's input layer / frame plan
+            return ([voxel_info[f'sra_plan_shift{i}'] for i in range(shifts)],
+                    [voxel_info[f'pos_embed_shift{i}'] for i in range(shifts)], None)
+        # the reference's per-level dictionaries (flat2win indices, padded positional tensors, key masks)
+        return ([voxel_info[f'flat2win_inds_shift{i}'] for i in range(shifts)],
+                [voxel_info[f'pos_dict_shift{i}'] for i in range(shifts)],
+                [voxel_info[f'key_mask_shift{i}'] for i in range(shifts)])
+
     def forward(self, voxel_info):
-        num_shifts = 2
-        assert voxel_info['voxel_coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'
-        voxel_feat = voxel_info['voxel_feats']
-        if 'sra_plan_shift0' in voxel_info:   # produced by this package's SSTInputLayerV2
-            ind_dict_list = [voxel_info[f'sra_plan_shift{i}'] for i in range(num_shifts)]
-            pos_embed_list = [voxel_info[f'pos_embed_shift{i}'] for i in range(num_shifts)]
-            padding_mask_list = None
-        else:                                 # reference-style dictionaries
-            ind_dict_list = [voxel_info[f'flat2win_inds_shift{i}'] for i in range(num_shifts)]
-            padding_mask_list = [voxel_info[f'key_mask_shift{i}'] for i in range(num_shifts)]
-            pos_embed_list = [voxel_info[f'pos_dict_shift{i}'] for i in range(num_shifts)]
-
-        output = voxel_feat
-        if hasattr(self, 'linear0'):
-            output = self.linear0(output)
-        for i, block in enumerate(self.block_list):
-            output = block(output, pos_embed_list, ind_dict_list, padding_mask_list,
-                           using_checkpoint=i in self.checkpoint_blocks)
-
-        if self.to_bev:
-            batch_size = voxel_info['voxel_coors'][:, 0].max().item() + 1
-            output = self.recover_bev(output, voxel_info['voxel_coors'], batch_size)
-
-        output_list = []
-        if self.num_attached_conv > 0:
-            assert self.to_bev
-            for conv in self.conv_layer:
-                temp = conv(output)
-                if temp.shape == output.shape and self.conv_shortcut:
-                    output = temp + output
-                else:
-                    output = temp
-
+        coors = voxel_info['voxel_coors']
+        assert coors.dtype == torch.int64, 'data type of coors should be torch.int64!'
+        plans, pos, masks = self._window_inputs(voxel_info)
+        feats = self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks)
         if not self.to_bev:
-            output = {'voxel_feats': output, 'voxel_coors': voxel_info['voxel_coors']}
-        output_list.append(output)
-        return output_list
-
-    def _reset_parameters(self):
-        for name, p in self.named_parameters():
-            if p.dim() > 1 and 'scaler' not in name and 'tau' not in name:
-                nn.init.xavier_uniform_(p)
+            assert self.num_attached_conv <= 0, 'the attached convolutions need the BEV canvas'
+            return [{'voxel_feats': feats, 'voxel_coors': coors}]
+        canvas = self.recover_bev(feats, coors, _batch_size_of(voxel_info, 'voxel_coors'))
+        return [self.run_attached_convs(canvas, self.conv_shortcut)]
 
     def recover_bev(self, voxel_feat, coors, batch_size):
-        '''[N,C] voxel features -> dense [B, C, ny, nx] canvas (sst_v2.py:161-197), one scatter for the whole
-        batch instead of a python loop; rows are written token-major (coalesced) and the result is returned
-        as a channels-last view of logical shape [B,C,ny,nx].'''
-        ny, nx = self.output_shape
-        feat_dim = voxel_feat.shape[-1]
-        canvas = voxel_feat.new_zeros((batch_size * ny * nx, feat_dim))
-        flat = coors[:, 0] * (ny * nx) + coors[:, 2] * nx + coors[:, 3]
-        canvas = canvas.index_put((flat.long(),), voxel_feat)
-        return canvas.view(batch_size, ny, nx, feat_dim).permute(0, 3, 1, 2)
+        return recover_bev(voxel_feat, coors, batch_size, self.output_shape)
 
 
 @BACKBONES.register_module()
-class SSTv1(nn.Module):
-    """First-generation backbone (mmdet3d/models/backbones/sst_v1.py:17-270): consumes the 3-tuple of
-    SSTInputLayer, computes positional embedding itself (:221-259), always recovers the BEV canvas.
-    Same constructor kwargs, forward signature and state_dict keys; the encoder layers are the same modules as
-    SSTv2's (the v1 blocks have identical parameters, mmdet3d/models/sst/sst_basic_block.py:62-99)."""
+class SSTv1(_WindowTransformer):
+    """First-generation backbone (mmdet3d/models/backbones/sst_v1.py:17-270): consumes the 3-tuple of SSTInputLayer,
+    computes the positional embedding itself (:221-259), always recovers the BEV canvas.  The encoder layers are the
+    same modules as SSTv2's (the v1 blocks have identical parameters, mmdet3d/models/sst/sst_basic_block.py:62-99)."""
 
     def __init__(self, d_model=[], nhead=[], num_blocks=6, dim_feedforward=[], dropout=0.0, activation="gelu",
                  output_shape=None, num_attached_conv=2, conv_in_channel=64, conv_out_channel=64,
@@ -164,155 +199,85 @@ class SSTv1(nn.Module):
         super().__init__()
         assert drop_info is not None
         self.meta_drop_info = drop_info
-        self.pos_temperature = pos_temperature
-        self.d_model = d_model
-        self.window_shape = window_shape
-        self.normalize_pos = normalize_pos
-        self.nhead = nhead
+        self.pos_temperature, self.normalize_pos = pos_temperature, normalize_pos
+        self.d_model, self.nhead, self.window_shape = d_model, nhead, window_shape
         self.checkpoint_blocks = checkpoint_blocks
-        if in_channel is not None:
-            self.linear0 = nn.Linear(in_channel, d_model[0])
-        self.block_list = nn.ModuleList([
-            BasicShiftBlockV2(d_model[i], nhead[i], dim_feedforward[i], dropout, activation, batch_first=False,
-                              block_id=i) for i in range(num_blocks)])
-        for name, p in self.named_parameters():
-            if p.dim() > 1 and 'scaler' not in name:
-                nn.init.xavier_uniform_(p)
         self.output_shape = output_shape
         self.debug = debug
-        self.num_attached_conv = num_attached_conv
-        if num_attached_conv > 0:
-            conv_list = []
-            for i in range(num_attached_conv):
-                conv_kwargs_i = conv_kwargs if isinstance(conv_kwargs, dict) else conv_kwargs[i]
-                if i > 0:
-                    conv_in_channel = conv_out_channel
-                conv = build_conv_layer(conv_cfg, in_channels=conv_in_channel, out_channels=conv_out_channel,
-                                        **conv_kwargs_i)
-                layers = [conv] if norm_cfg is None else [conv, build_norm_layer(norm_cfg, conv_out_channel)[1]]
-                conv_list.append(nn.Sequential(*layers, nn.ReLU(inplace=True)))
-            self.conv_layer = nn.ModuleList(conv_list)
+        self._build_stem(d_model, nhead, num_blocks, dim_feedforward, dropout, activation, in_channel, dict(),
+                         init_skip=('scaler',))
+        self._build_attached_convs(num_attached_conv, conv_in_channel, conv_out_channel, norm_cfg, conv_cfg, conv_kwargs)
 
     def set_drop_info(self):
-        if hasattr(self, 'drop_info'):
-            return
-        meta = self.meta_drop_info
-        if isinstance(meta, tuple):
-            self.drop_info = meta[0] if self.training else meta[1]
-        else:
-            self.drop_info = meta
+        if not hasattr(self, 'drop_info'):
+            meta = self.meta_drop_info
+            self.drop_info = (meta[0] if self.training else meta[1]) if isinstance(meta, tuple) else meta
 
     @torch.no_grad()
     def get_pos_embed_flat(self, coors_in_win, dtype):
-        """[M, d_model] embedding from v1 in-window coordinates (x, y); arithmetic of sst_v1.py:221-259."""
-        win_x, win_y = self.window_shape
-        x, y = coors_in_win[:, 0] - win_x / 2, coors_in_win[:, 1] - win_y / 2
-        if self.normalize_pos:
-            x = x / win_x * 2 * 3.1415
-            y = y / win_y * 2 * 3.1415
-        pos_length = self.d_model[0] // 2
-        inv_freq = torch.arange(pos_length, dtype=torch.float32, device=coors_in_win.device)
-        inv_freq = self.pos_temperature ** (2 * (inv_freq // 2) / pos_length)
-        embed_x = x[:, None] / inv_freq[None, :]
-        embed_y = y[:, None] / inv_freq[None, :]
-        embed_x = torch.stack([embed_x[:, ::2].sin(), embed_x[:, 1::2].cos()], dim=-1).flatten(1)
-        embed_y = torch.stack([embed_y[:, ::2].sin(), embed_y[:, 1::2].cos()], dim=-1).flatten(1)
-        return torch.cat([embed_x, embed_y], dim=-1).to(dtype)
+        """[M, d_model] embedding from v1 in-window coordinates (x, y); arithmetic of sst_v1.py:221-259: per axis
+        d_model / 2 values, sin on the even and cos on the odd entries of centred_coordinate / T^(2 (i // 2) / L)."""
+        half = self.d_model[0] // 2
+        idx = torch.arange(half, dtype=torch.float32, device=coors_in_win.device)
+        denom = self.pos_temperature ** (2 * (idx // 2) / half)
+        parts = []
+        for axis, extent in enumerate(self.window_shape):
+            centred = coors_in_win[:, axis] - extent / 2
+            if self.normalize_pos:
+                centred = centred / extent * 2 * 3.1415
+            phase = centred[:, None] / denom[None, :]
+            parts.append(torch.stack([phase[:, ::2].sin(), phase[:, 1::2].cos()], dim=-1).flatten(1))
+        return torch.cat(parts, dim=-1).to(dtype)
 
     def forward(self, input_tuple):
         voxel_feat, ind_dict_list, voxel_info = input_tuple
         assert voxel_info['coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'
         self.set_drop_info()
-        batch_size = voxel_info['coors'][:, 0].max().item() + 1
-        num_shifts = len(ind_dict_list)
-        m = voxel_feat.size(0)
         plans, pos = [], []
-        for i in range(num_shifts):
-            if f'sra_plan_shift{i}' in voxel_info:
-                plans.append(voxel_info[f'sra_plan_shift{i}'])
-            else:  # a voxel_info produced by the reference's own SSTInputLayer
-                d = dict(ind_dict_list[i])
-                d['batching_info'] = self.drop_info
-                plans.append(plan_from_reference_dicts(d, m, voxel_feat.device))
+        for i, ind_dict in enumerate(ind_dict_list):
+            plan = voxel_info.get(f'sra_plan_shift{i}')
+            if plan is None:   # a voxel_info produced by the reference's own SSTInputLayer: convert its dictionaries
+                plan = plan_from_reference_dicts(dict(ind_dict, batching_info=self.drop_info), voxel_feat.size(0),
+                                                 voxel_feat.device)
+            plans.append(plan)
             pos.append(self.get_pos_embed_flat(voxel_info[f'coors_in_win_shift{i}'], voxel_feat.dtype))
-        output = voxel_feat
-        if hasattr(self, 'linear0'):
-            output = self.linear0(output)
-        for i, block in enumerate(self.block_list):
-            output = block(output, pos, plans, None, using_checkpoint=i in self.checkpoint_blocks)
-        output = SSTv2.recover_bev(self, output, voxel_info['coors'], batch_size)
-        if self.num_attached_conv > 0:
-            for conv in self.conv_layer:
-                output = conv(output)
-        return [output]
+        feats = self.run_blocks(voxel_feat, pos, plans)
+        canvas = recover_bev(feats, voxel_info['coors'], _batch_size_of(voxel_info, 'coors'), self.output_shape)
+        return [self.run_attached_convs(canvas)]
 
 
 @BACKBONES.register_module()
 class SIR(nn.Module):
     '''Sparse Instance Recognition backbone: a stack of SIRLayer (sir.py:15-87).'''
 
-    def __init__(
-        self,
-        num_blocks=5,
-        in_channels=[],
-        feat_channels=[],
-        rel_mlp_hidden_dims=[],
-        with_rel_mlp=True,
-        with_distance=False,
-        with_cluster_center=False,
-        norm_cfg=dict(type='LN', eps=1e-3),
-        mode='max',
-        xyz_normalizer=[1.0, 1.0, 1.0],
-        act='relu',
-        dropout=0,
-        unique_once=False,
-    ):
+    def __init__(self, num_blocks=5, in_channels=[], feat_channels=[], rel_mlp_hidden_dims=[], with_rel_mlp=True,
+                 with_distance=False, with_cluster_center=False, norm_cfg=dict(type='LN', eps=1e-3), mode='max',
+                 xyz_normalizer=[1.0, 1.0, 1.0], act='relu', dropout=0, unique_once=False):
         super().__init__()
         self.num_blocks = num_blocks
         self.unique_once = unique_once
-        block_list = []
-        for i in range(num_blocks):
-            return_point_feats = i != num_blocks - 1
-            kwargs = dict(
-                type='SIRLayer',
-                in_channels=in_channels[i],
-                feat_channels=feat_channels[i],
-                with_distance=with_distance,
-                with_cluster_center=with_cluster_center,
-                with_rel_mlp=with_rel_mlp,
-                rel_mlp_hidden_dims=rel_mlp_hidden_dims[i],
-                with_voxel_center=False,
-                voxel_size=[0.1, 0.1, 0.1],  # not used, placeholder
-                point_cloud_range=[-74.88, -74.88, -2, 74.88, 74.88, 4],  # not used, placeholder
-                norm_cfg=norm_cfg,
-                mode=mode,
-                fusion_layer=None,
-                return_point_feats=return_point_feats,
-                return_inv=False,
-                rel_dist_scaler=10.0,
-                xyz_normalizer=xyz_normalizer,
-                act=act,
-                dropout=dropout,
-            )
-            block_list.append(build_voxel_encoder(kwargs))
-        self.block_list = nn.ModuleList(block_list)
+        common = dict(type='SIRLayer', with_distance=with_distance, with_cluster_center=with_cluster_center,
+                      with_rel_mlp=with_rel_mlp, with_voxel_center=False, norm_cfg=norm_cfg, mode=mode, fusion_layer=None,
+                      return_inv=False, rel_dist_scaler=10.0, xyz_normalizer=xyz_normalizer, act=act, dropout=dropout,
+                      # placeholders the layer never reads (sir.py:47-48)
+                      voxel_size=[0.1, 0.1, 0.1], point_cloud_range=[-74.88, -74.88, -2, 74.88, 74.88, 4])
+        self.block_list = nn.ModuleList([
+            build_voxel_encoder(dict(common, in_channels=in_channels[i], feat_channels=feat_channels[i],
+                                     rel_mlp_hidden_dims=rel_mlp_hidden_dims[i],
+                                     return_point_feats=i != num_blocks - 1)) for i in range(num_blocks)])
 
     def forward(self, points, features, coors, f_cluster=None):
-        if self.unique_once:
-            new_coors, unq_inv = unique_with_plan(coors)
-        else:
-            new_coors = unq_inv = None
-        out_feats = features
-        cluster_feat_list = []
+        """-> (point features of the last block, per-cluster features of all blocks side by side, cluster coordinates)."""
+        grouping = dict(new_coors_once=None, unq_inv_once=None)
+        if self.unique_once:   # one sorted-unique of the cluster ids for the whole stack (its CSR rides on unq_inv)
+            grouping['new_coors_once'], grouping['unq_inv_once'] = unique_with_plan(coors)
+        point_feats, per_cluster, cluster_coors = features, [], None
+        last = self.num_blocks - 1
         for i, block in enumerate(self.block_list):
-            in_feats = torch.cat([points, out_feats], 1)
-            if i < self.num_blocks - 1:
-                out_feats, out_cluster_feats = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv,
-                                                     new_coors_once=new_coors)
-                cluster_feat_list.append(out_cluster_feats)
-            if i == self.num_blocks - 1:
-                out_feats, out_cluster_feats, out_coors = block(in_feats, coors, f_cluster, return_both=True,
-                                                                unq_inv_once=unq_inv, new_coors_once=new_coors)
-                cluster_feat_list.append(out_cluster_feats)
-        final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
-        return out_feats, final_cluster_feats, out_coors
+            block_in = torch.cat([points, point_feats], 1)
+            if i < last:
+                point_feats, cluster_feats = block(block_in, coors, f_cluster, **grouping)
+            else:
+                point_feats, cluster_feats, cluster_coors = block(block_in, coors, f_cluster, return_both=True, **grouping)
+            per_cluster.append(cluster_feats)
+        return point_feats, torch.cat(per_cluster, dim=1), cluster_coors

@@ -209,9 +209,148 @@ __global__ __launch_bounds__(256) void vfe_decorate_k(const float* __restrict__ 
   }
 }
 
+// (a15 / f1) "features = cat([point_feats, voxel_feats[point -> voxel]], dim=1)" between the layers of DynamicVFE /
+// DynamicScatterVFE / SIRLayer (voxel_encoders/voxel_encoder.py:288-291, :605-607, :745-750) in one pass: a gather by the
+// inverse map and a concatenation become one coalesced kernel, the gathered [N, C] tensor is never materialised.
+// idx < 0 reads group 0 (the zero-initialised canvas of DynamicVFE.map_voxel_center_to_point).
+__global__ __launch_bounds__(256) void concat_gather_k(const float* __restrict__ x, int64_t ldx, int c1,
+                                                       const float* __restrict__ g, int64_t ldg, int c2,
+                                                       const int32_t* __restrict__ idx, int64_t n,
+                                                       float* __restrict__ out) {
+  const int q1 = c1 >> 2, q = (c1 + c2) >> 2;
+  const int64_t total = n * q;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / q;
+    const int k = (int)(e - i * q);
+    float4 v;
+    if (k < q1) {
+      v = *(const float4*)(x + i * ldx + 4 * k);
+    } else {
+      int r = idx[i];
+      if (r < 0) r = 0;
+      v = *(const float4*)(g + (int64_t)r * ldg + 4 * (k - q1));
+    }
+    *(float4*)(out + e * 4) = v;
+  }
+}
+
+// (a14) recover_bev (mmdet3d/models/backbones/sst_v2.py:161-197): voxel features -> dense bird's-eye-view canvas.
+// The reference loops over the samples, allocates a zero canvas per sample and assigns canvas[:, y * nx + x] = feat^T
+// (a transposed, 4-byte-granular scatter), then stacks.  Here: (1) the voxel index of every occupied cell goes into an
+// int32 cell map (0.9 MB per Waymo sample); (2) ONE pass writes every cell of the canvas exactly once - the voxel's row
+// or zeros - in channels-last order (a cell's C channels are contiguous: 16-byte stores, every row read once), so
+// there is no separate zero-fill of the 112 MB canvas.  The canvas is handed on as the channels-last view of the
+// logical [B, C, ny, nx] tensor.
+template <typename CT>
+__global__ __launch_bounds__(256) void bev_map_k(const CT* __restrict__ coors, int64_t ldc, int64_t m, int ny, int nx,
+                                                 int batch, int32_t* __restrict__ map) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const CT* r = coors + i * ldc;  // (b, z, y, x)
+    const int64_t b = (int64_t)r[0], y = (int64_t)r[2], x = (int64_t)r[3];
+    if (b >= 0 && b < batch && y >= 0 && y < ny && x >= 0 && x < nx) map[(b * ny + y) * nx + x] = (int32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(256) void bev_fill_k(const float* __restrict__ feats, int64_t ldf,
+                                                  const int32_t* __restrict__ map, int64_t cells, int c4,
+                                                  float* __restrict__ out) {
+  const int64_t total = cells * c4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = e / c4;
+    const int q = (int)(e - cell * c4);
+    const int32_t v = map[cell];
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v >= 0) val = *(const float4*)(feats + (int64_t)v * ldf + 4 * q);
+    *(float4*)(out + (cell * c4 + q) * 4) = val;
+  }
+}
+
+// gradient: rows of the canvas gradient (channels-last) at the voxels' cells
+__global__ __launch_bounds__(256) void bev_gather_k(const float* __restrict__ gcanvas, const int32_t* __restrict__ map_of_voxel,
+                                                    int64_t m, int c4, float* __restrict__ gfeats) {
+  const int64_t total = m * c4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / c4;
+    const int q = (int)(e - i * c4);
+    const int32_t cell = map_of_voxel[i];
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cell >= 0) val = *(const float4*)(gcanvas + ((int64_t)cell * c4 + q) * 4);
+    *(float4*)(gfeats + (i * c4 + q) * 4) = val;
+  }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void bev_cell_of_voxel_k(const CT* __restrict__ coors, int64_t ldc, int64_t m, int ny,
+                                                           int nx, int batch, const int32_t* __restrict__ map,
+                                                           int32_t* __restrict__ cell_of_voxel) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const CT* r = coors + i * ldc;
+    const int64_t b = (int64_t)r[0], y = (int64_t)r[2], x = (int64_t)r[3];
+    int32_t cell = -1;
+    if (b >= 0 && b < batch && y >= 0 && y < ny && x >= 0 && x < nx) {
+      const int64_t cidx = (b * ny + y) * nx + x;
+      if (map[cidx] == (int32_t)i) cell = (int32_t)cidx;  // a cell written by several voxels belongs to the one that won
+    }
+    cell_of_voxel[i] = cell;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int sst_concat_gather_f32(const float* d_x, int64_t ldx, int c1, const float* d_g, int64_t ldg, int c2,
+                          const int32_t* d_idx, int64_t n, float* d_out, void* stream) {
+  if (n < 0 || c1 < 4 || c2 < 4 || (c1 & 3) || (c2 & 3) || ldx < c1 || ldg < c2 || (ldx & 3) || (ldg & 3)) return SST_ERR_ARG;
+  if (n == 0) return SST_OK;
+  if (!d_x || !d_g || !d_idx || !d_out) return SST_ERR_ARG;
+  if (((uintptr_t)d_x | (uintptr_t)d_g | (uintptr_t)d_out) & 15) return SST_ERR_ARG;
+  hipLaunchKernelGGL(concat_gather_k, dim3(sst_grid_1d(n * ((c1 + c2) >> 2), 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_x, ldx, c1, d_g, ldg, c2, d_idx, n, d_out);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_recover_bev_f32(const float* d_feats, int64_t ldf, const void* d_coors, int coor_is_i64, int64_t ldc, int64_t m,
+                        int batch, int ny, int nx, int c, int32_t* d_cell_map, int32_t* d_cell_of_voxel, float* d_canvas,
+                        void* stream) {
+  if (m < 0 || batch < 1 || ny < 1 || nx < 1 || c < 4 || (c & 3) || ldf < c) return SST_ERR_ARG;
+  const int64_t cells = (int64_t)batch * ny * nx;
+  if (cells * c >= ((int64_t)1 << 40) || cells >= ((int64_t)1 << 31) || m >= ((int64_t)1 << 31)) return SST_ERR_UNSUPPORTED;
+  if (!d_cell_map || !d_canvas || (m > 0 && (!d_feats || !d_coors || !d_cell_of_voxel))) return SST_ERR_ARG;
+  if ((((uintptr_t)d_feats | (uintptr_t)d_canvas) & 15) || (ldf & 3)) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  SST_HIP(hipMemsetAsync(d_cell_map, 0xff, sizeof(int32_t) * (size_t)cells, st));
+  if (m > 0) {
+    const int g = sst_grid_1d(m, 256);
+    if (coor_is_i64) {
+      hipLaunchKernelGGL(bev_map_k<int64_t>, dim3(g), dim3(256), 0, st, (const int64_t*)d_coors, ldc, m, ny, nx, batch,
+                         d_cell_map);
+      hipLaunchKernelGGL(bev_cell_of_voxel_k<int64_t>, dim3(g), dim3(256), 0, st, (const int64_t*)d_coors, ldc, m, ny, nx,
+                         batch, d_cell_map, d_cell_of_voxel);
+    } else {
+      hipLaunchKernelGGL(bev_map_k<int32_t>, dim3(g), dim3(256), 0, st, (const int32_t*)d_coors, ldc, m, ny, nx, batch,
+                         d_cell_map);
+      hipLaunchKernelGGL(bev_cell_of_voxel_k<int32_t>, dim3(g), dim3(256), 0, st, (const int32_t*)d_coors, ldc, m, ny, nx,
+                         batch, d_cell_map, d_cell_of_voxel);
+    }
+  }
+  hipLaunchKernelGGL(bev_fill_k, dim3(sst_grid_1d(cells * (c >> 2), 256)), dim3(256), 0, st, d_feats, ldf, d_cell_map,
+                     cells, c >> 2, d_canvas);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_recover_bev_bwd_f32(const float* d_grad_canvas, const int32_t* d_cell_of_voxel, int64_t m, int c,
+                            float* d_grad_feats, void* stream) {
+  if (m < 0 || c < 4 || (c & 3)) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_grad_canvas || !d_cell_of_voxel || !d_grad_feats) return SST_ERR_ARG;
+  hipLaunchKernelGGL(bev_gather_k, dim3(sst_grid_1d(m * (c >> 2), 256)), dim3(256), 0, (hipStream_t)stream, d_grad_canvas,
+                     d_cell_of_voxel, m, c >> 2, d_grad_feats);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
 
 int sst_vfe_decorate_f32(const float* d_points, int64_t ldp, int64_t n, int c, const int32_t* d_inverse,
                          const float* d_voxel_mean, int64_t ldm, float cluster_div, const void* d_coors,

@@ -46,13 +46,17 @@ constexpr int kTgImage = 4096;  // bytes of a wave's X image in LDS: 32 rows x 3
   asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(ADDR), "v"(SRC), "n"(OFF) : "memory")
 
 // EPI 0: Y = acc + bias (bias may be null).  EPI 1: Y = Y_old + acc (+ bias): accumulate into the destination.
+// EPI 2: Y = acc + bias and AUX = gelu(Y) (erf form): linear1 + activation of the FFN in one pass (sst_basic_block_v2.py:116),
+//        both tensors are kept for the backward pass.  EPI 3: Y = (acc + bias) * gelu'(AUX): the data gradient through
+//        linear2 with the activation's derivative applied to the pre-activation AUX in the epilogue.
 // TRANS_W 0: W is [N][K] row-major (forward: y = x W^T).  TRANS_W 1: W is [K][N] row-major (data gradient:
 // dx = dy W with the layer's [out = K][in = N] weight) and is transposed while it is staged.
 template <int K, int EPI, int TRANS_W>
 __global__ __launch_bounds__(64 * kTgWaves) void tall_gemm_n128_k(const float* __restrict__ X, int64_t ldx,
                                                                    const float* __restrict__ W, int64_t ldw,
                                                                    const float* __restrict__ bias, int64_t m,
-                                                                   float* __restrict__ Y, int64_t ldy) {
+                                                                   float* __restrict__ Y, int64_t ldy,
+                                                                   float* __restrict__ AUX) {
   constexpr int N = 128;
   constexpr int KH = K / 128;  // chunks per tile
   extern __shared__ __attribute__((aligned(16))) float Ws[];  // [N][K] swizzled, then kTgWaves X images
@@ -155,11 +159,24 @@ __global__ __launch_bounds__(64 * kTgWaves) void tall_gemm_n128_k(const float* _
         for (int nt = 0; nt < 4; ++nt) {
           v[nt] = acc[nt][r] + bv[nt];
           if (EPI == 1) v[nt] += *(const float*)((const char*)Y + yoff + 128 * nt);
+          if (EPI == 3) {
+            const float p = *(const float*)((const char*)AUX + yoff + 128 * nt);
+            // d gelu(p) / dp = Phi(p) + p * phi(p)
+            v[nt] *= 0.5f * (1.f + erff(p * 0.70710678118654752f)) + p * 0.39894228040143268f * __expf(-0.5f * p * p);
+          }
         }
-        // asm: EXACTLY 64 store instructions per full tile (the wait immediates below count them)
+        // asm: EXACTLY 64 store instructions per full tile (the wait immediates below count them; EPI 2 issues 128,
+        // which only makes vmcnt(63) wait for more of the - older - stores, never for less of the loads it guards)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(yoff), "v"(v[nt]), "s"(Y), "n"(128 * nt) : "memory");
+        if (EPI == 2) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float hgelu = 0.5f * v[nt] * (1.f + erff(v[nt] * 0.70710678118654752f));
+            asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(yoff), "v"(hgelu), "s"(AUX), "n"(128 * nt) : "memory");
+          }
+        }
       }
     }
   };
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(64 * kTgWaves) void tall_gemm_n128_k(const float* _
 
 template <int K, int EPI, int TRANS_W>
 int launch_n128(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int64_t m, float* Y,
-                int64_t ldy, hipStream_t st) {
+                int64_t ldy, hipStream_t st, float* aux = nullptr) {
   const size_t lds = (size_t)128 * K * sizeof(float) + (size_t)kTgWaves * kTgImage;
   static bool configured = false;  // per instantiation; the attribute call costs tens of microseconds on the host
   if (!configured) {
@@ -281,7 +298,7 @@ int launch_n128(const float* X, int64_t ldx, const float* W, int64_t ldw, const 
   const int64_t n_tiles = sst_div_up(m, 32);
   const int grid = (int)(n_tiles < kTgGrid ? n_tiles : kTgGrid);
   hipLaunchKernelGGL((tall_gemm_n128_k<K, EPI, TRANS_W>), dim3(grid), dim3(64 * kTgWaves), lds, st, X, ldx, W, ldw,
-                     bias, m, Y, ldy);
+                     bias, m, Y, ldy, aux);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
@@ -312,6 +329,26 @@ int sst_tall_linear_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t
   if (accumulate && !trans_w) SST_TG(256, 1, 0);
   SST_TG(256, 1, 1);
 #undef SST_TG
+}
+
+int sst_tall_linear_gelu_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias,
+                             int64_t m, int n, int k, int trans_w, int mode, float* d_aux, float* d_y, int64_t ldy,
+                             void* stream) {
+  // mode 0: y = x W^T + b, aux = gelu(y) (aux has the row stride of y);  mode 1: y = (x W) * gelu'(aux)
+  if (m < 0 || n != 128 || k != 128 || (mode != 0 && mode != 1)) return SST_ERR_UNSUPPORTED;
+  if ((m + 32) * ldy >= ((int64_t)1 << 30) || (m + 32) * ldx >= ((int64_t)1 << 40)) return SST_ERR_UNSUPPORTED;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_w || !d_y || !d_aux || ldx < k || ldy < n || (ldx & 3) || (ldw & 3) || ((uintptr_t)d_x & 15) ||
+      ((uintptr_t)d_w & 15))
+    return SST_ERR_ARG;
+  if (ldw < (trans_w ? n : k)) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    if (trans_w) return launch_n128<128, 2, 1>(d_x, ldx, d_w, ldw, d_bias, m, d_y, ldy, st, d_aux);
+    return launch_n128<128, 2, 0>(d_x, ldx, d_w, ldw, d_bias, m, d_y, ldy, st, d_aux);
+  }
+  if (trans_w) return launch_n128<128, 3, 1>(d_x, ldx, d_w, ldw, d_bias, m, d_y, ldy, st, d_aux);
+  return launch_n128<128, 3, 0>(d_x, ldx, d_w, ldw, d_bias, m, d_y, ldy, st, d_aux);
 }
 
 }  // extern "C"

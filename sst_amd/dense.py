@@ -91,6 +91,46 @@ def tall_gemm(x, w, bias=None, trans_w=False, out=None, accumulate=False):
     return out
 
 
+def _gelu_gemm_ok(x, w, n, k):
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and k == 128 and n % 128 == 0
+            and x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (x.size(0) + 32) * n < (1 << 30))
+
+
+def linear_gelu(x, w1, b1):
+    """(pre, h) = (x w1^T + b1, gelu(pre)) for the first FFN layer: bias and activation ride on the GEMM's epilogue
+    (csrc/tall_gemm.hip, one launch per 128 output columns); None when the shape is not one the kernel is built for."""
+    m, k = x.shape
+    n = w1.size(0)
+    if w1.size(1) != k or not _gelu_gemm_ok(x, w1, n, k) or b1 is None:
+        return None
+    pre = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    h = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    for j in range(0, n, 128):
+        rc = lib.sst_tall_linear_gelu_f32(_lib.ptr(x), x.stride(0), _lib.ptr(w1[j:j + 128]), w1.stride(0),
+                                          _lib.ptr(b1[j:j + 128]), m, 128, k, 0, 0, _lib.ptr(h[:, j:]),
+                                          _lib.ptr(pre[:, j:]), n, _lib.stream_ptr())
+        _lib.check(rc, 'sst_tall_linear_gelu_f32')
+    return pre, h
+
+
+def dgrad_gelu(dy, w2, pre):
+    """d(pre) = (dy w2) * gelu'(pre) for the second FFN layer (w2: [out = k, in = n]): the activation's derivative is
+    applied in the epilogue of the data-gradient GEMM; None when the shape is not one the kernel is built for."""
+    m, k = dy.shape
+    n = w2.size(1)
+    if w2.size(0) != k or not _gelu_gemm_ok(dy, w2, n, k) or pre.shape != (m, n) or not pre.is_contiguous():
+        return None
+    out = torch.empty((m, n), dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    for j in range(0, n, 128):
+        rc = lib.sst_tall_linear_gelu_f32(_lib.ptr(dy), dy.stride(0), _lib.ptr(w2[:, j:]), w2.stride(0), None, m, 128,
+                                          k, 1, 1, _lib.ptr(pre[:, j:]), _lib.ptr(out[:, j:]), n, _lib.stream_ptr())
+        _lib.check(rc, 'sst_tall_linear_gelu_f32')
+    return out
+
+
 class TallLinear(Function):
 
     @staticmethod

@@ -47,6 +47,11 @@ def _pool(rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_
                                         int(max_all_pts), _lib.ptr(out_pts_idx), _lib.ptr(out_roi_idx),
                                         _lib.ptr(out_pts_feats), _lib.ptr(num_out), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, 'sst_dynamic_point_pool_f32')
+    return out_pts_idx, out_roi_idx, out_pts_feats, num_out
+
+
+def _valid_rows(out_pts_idx, out_roi_idx, out_pts_feats, num_out):
+    """slice the pairs off the max_all_pts-row buffers (one read-back of their count)"""
     n = int(num_out.item())
     if n == 0:
         # "fake a non-empty input" (dynamic_point_pool_op.py:41-45): one row of (-1, -1, zeros)
@@ -59,7 +64,7 @@ class DynamicPointPoolFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rois, pts, extra_wlh, max_inbox_point, max_all_pts=50000):
-        out = _pool(rois, None, pts, None, extra_wlh, max_inbox_point, max_all_pts)
+        out = _valid_rows(*_pool(rois, None, pts, None, extra_wlh, max_inbox_point, max_all_pts))
         ctx.mark_non_differentiable(*out)
         return out
 
@@ -76,7 +81,7 @@ class DynamicPointPoolMixedFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_pts=200000):
-        out = _pool(rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_pts)
+        out = _valid_rows(*_pool(rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_pts))
         ctx.mark_non_differentiable(*out)
         return out
 
@@ -104,52 +109,45 @@ class DynamicPointROIExtractor(nn.Module):
         self.max_all_pts = max_all_pts
 
     def forward(self, pts_xyz, batch_inds, rois, max_inbox_point=None, batch_size=None):
+        """All samples in ONE pool launch (the batched entry point pairs a point only with RoIs of its own sample) and
+        one read-back of the per-sample pair counts; the reference runs one launch and two read-backs per sample
+        (:51-80).  What its loop defines is kept: RoI / point indices are global, the pairs of a sample are capped at
+        ``max_all_pts``, a sample without any pair contributes the fake (-1, -1, zeros) row."""
         if batch_size == 1:
             return self.fast_single_sample_forward(pts_xyz, rois, max_inbox_point)
-        assert len(pts_xyz) > 0
-        assert len(batch_inds) > 0
-        assert len(rois) > 0
-        if not (batch_inds == 0).all():
-            assert (batch_inds.sort()[0] == batch_inds).all()
-        all_inds, all_pts_info, all_roi_inds = [], [], []
-        roi_inds_base = 0
-        pts_inds_base = 0
-        if max_inbox_point is None:
-            max_inbox_point = self.max_inbox_point
-        # one pool call per sample, as the reference does (:51-80): max_all_pts caps every sample separately
-        for batch_idx in range(int(batch_inds.max()) + 1):
-            roi_batch_mask = (rois[..., 0].int() == batch_idx)
-            pts_batch_mask = (batch_inds.int() == batch_idx)
-            num_roi_this_batch = roi_batch_mask.sum().item()
-            num_pts_this_batch = pts_batch_mask.sum().item()
-            assert num_roi_this_batch > 0
-            assert num_pts_this_batch > 0
-            ext_pts_inds, roi_inds, ext_pts_info = dynamic_point_pool(
-                rois[..., 1:][roi_batch_mask], pts_xyz[pts_batch_mask], self.extra_wlh, max_inbox_point,
-                self.max_all_pts)
-            if len(ext_pts_inds) == 1 and ext_pts_inds[0].item() == -1:
-                assert roi_inds[0].item() == -1
-                all_inds.append(ext_pts_inds)  # keep -1 and do not plus the base
-                all_pts_info.append(ext_pts_info)
-                all_roi_inds.append(roi_inds)
-            else:
-                all_inds.append(ext_pts_inds + pts_inds_base)
-                all_pts_info.append(ext_pts_info)
-                all_roi_inds.append(roi_inds + roi_inds_base)
-            pts_inds_base += num_pts_this_batch
-            roi_inds_base += num_roi_this_batch
-        all_inds = torch.cat(all_inds, dim=0)
-        all_pts_info = torch.cat(all_pts_info, dim=0)
-        all_roi_inds = torch.cat(all_roi_inds, dim=0)
-        all_out_xyz = all_pts_info[:, :3]
-        all_local_xyz = all_pts_info[:, 3:6]
-        all_offset = all_pts_info[:, 6:-1]
-        is_in_margin = all_pts_info[:, -1]
+        assert len(pts_xyz) > 0 and len(batch_inds) > 0 and len(rois) > 0
+        cap_in_box = self.max_inbox_point if max_inbox_point is None else max_inbox_point
+        roi_sample = rois[:, 0].to(torch.int32)
+        pts_sample = batch_inds.to(torch.int32)
         if self.debug:
-            self.check_invariants(pts_xyz, rois[..., 1:], all_inds, all_roi_inds, all_out_xyz, all_local_xyz,
-                                  all_offset)
-        ext_pts_info = dict(local_xyz=all_local_xyz, boundary_offset=all_offset, is_in_margin=is_in_margin)
-        return all_inds, all_roi_inds, ext_pts_info
+            assert bool((pts_sample[1:] >= pts_sample[:-1]).all()), 'points must be sorted by sample'
+            assert bool((roi_sample[1:] >= roi_sample[:-1]).all()), 'RoIs must be sorted by sample'
+        n_samples = int(batch_size) if batch_size is not None else int(batch_inds[-1].item()) + 1
+        rows = n_samples * self.max_all_pts
+        pts_idx, roi_idx, feats, num_out = _pool(rois[:, 1:], roi_sample, pts_xyz, pts_sample, self.extra_wlh,
+                                                 cap_in_box, rows)
+        # pairs come out sorted by (RoI, point), RoIs are sorted by sample: the pairs of a sample are one run
+        row_sample = roi_sample.long()[roi_idx.clamp(min=0)]
+        row_sample = torch.where(torch.arange(rows, device=row_sample.device) < num_out, row_sample,
+                                 torch.full_like(row_sample, n_samples))
+        per_sample = torch.bincount(row_sample, minlength=n_samples + 1)[:n_samples].tolist()   # the one read-back
+        pieces, start = [], 0
+        for count in per_sample:
+            if count == 0:
+                fake = slice(rows - 1, rows)   # an untouched row of the buffers: (-1, -1, zeros)
+                pieces.append((pts_idx[fake], roi_idx[fake], feats[fake]))
+            else:
+                keep = slice(start, start + min(count, self.max_all_pts))
+                pieces.append((pts_idx[keep], roi_idx[keep], feats[keep]))
+            start += count
+        if len(pieces) == 1:
+            all_inds, all_roi_inds, info = pieces[0]
+        else:
+            all_inds, all_roi_inds, info = (torch.cat(col, dim=0) for col in zip(*pieces))
+        if self.debug:
+            self.check_invariants(pts_xyz, rois[..., 1:], all_inds, all_roi_inds, info[:, :3], info[:, 3:6], info[:, 6:-1])
+        return all_inds, all_roi_inds, dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1],
+                                            is_in_margin=info[:, -1])
 
     def check_invariants(self, pts_xyz, rois7, inds, roi_inds, out_xyz, local_xyz, offset):
         """the reference's debug block (:96-105); pairs of the fake row (-1) are skipped"""
@@ -167,13 +165,8 @@ class DynamicPointROIExtractor(nn.Module):
         assert (local_xyz[:, 2].abs() < roi_per_pts[:, 5] + self.extra_wlh[2] + 1e-5).all()
 
     def fast_single_sample_forward(self, pts_xyz, rois, max_inbox_point=None):
-        """:107-133 (the reference passes no max_all_pts here: the op's default of 50000 applies)"""
-        if max_inbox_point is None:
-            max_inbox_point = self.max_inbox_point
-        ext_pts_inds, roi_inds, ext_pts_info = dynamic_point_pool(
-            rois[..., 1:].contiguous(), pts_xyz.contiguous(), self.extra_wlh, max_inbox_point)
-        all_local_xyz = ext_pts_info[:, 3:6]
-        all_offset = ext_pts_info[:, 6:-1]
-        is_in_margin = ext_pts_info[:, -1]
-        ext_pts_info = dict(local_xyz=all_local_xyz, boundary_offset=all_offset, is_in_margin=is_in_margin)
-        return ext_pts_inds, roi_inds, ext_pts_info
+        """one sample (:107-133; the reference passes no max_all_pts here: the op's default of 50000 applies)"""
+        cap_in_box = self.max_inbox_point if max_inbox_point is None else max_inbox_point
+        pts_idx, roi_idx, info = dynamic_point_pool(rois[..., 1:].contiguous(), pts_xyz.contiguous(), self.extra_wlh,
+                                                    cap_in_box)
+        return pts_idx, roi_idx, dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])

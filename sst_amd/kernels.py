@@ -511,3 +511,54 @@ def vfe_decorate(features, inverse, voxel_mean, cluster_div, coors, voxel_size, 
                                   int(bool(with_center)), _lib.ptr(out), out.stride(0), _lib.stream_ptr())
     _lib.check(rc, 'sst_vfe_decorate_f32')
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# (a15 / f1) gather by the inverse map + concatenation between the layers of the point-group encoders
+# ----------------------------------------------------------------------------------------------
+class ConcatGather(Function):
+    """cat([x, g[idx]], dim=1) in one pass (csrc/scatter.hip).  Backward: d(x) is the left column block of the incoming
+    gradient; d(g) is a segmented sum over the members of every group, taken through ``group_sum`` (a callable
+    [N, C] -> [G, C], the deterministic CSR reduce of the grouping the index came from) when the caller supplies one,
+    else an index_add."""
+
+    @staticmethod
+    def forward(ctx, x, g, idx32, group_sum):
+        n, c1 = x.shape
+        c2 = g.size(1)
+        x = x if x.stride(1) == 1 else x.contiguous()
+        g = g if g.stride(1) == 1 else g.contiguous()
+        out = torch.empty((n, c1 + c2), dtype=torch.float32, device=x.device)
+        rc = _lib.load().sst_concat_gather_f32(_lib.ptr(x), x.stride(0), c1, _lib.ptr(g), g.stride(0), c2, _lib.ptr(idx32),
+                                               n, _lib.ptr(out), _lib.stream_ptr())
+        _lib.check(rc, 'sst_concat_gather_f32')
+        ctx.save_for_backward(idx32)
+        ctx.c1, ctx.rows, ctx.group_sum = c1, g.size(0), group_sum
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx32,) = ctx.saved_tensors
+        c1 = ctx.c1
+        dx = dy[:, :c1] if ctx.needs_input_grad[0] else None
+        dg = None
+        if ctx.needs_input_grad[1]:
+            part = dy[:, c1:].contiguous()
+            if ctx.group_sum is not None:
+                dg = ctx.group_sum(part)
+            else:
+                dg = torch.zeros((ctx.rows, part.size(1)), dtype=part.dtype, device=part.device)
+                dg.index_add_(0, idx32.long().clamp(min=0), part)
+        return dx, dg, None, None
+
+
+def concat_gather(x, g, idx, group_sum=None):
+    """[x | g[idx]] for [N, C1] point features, [G, C2] group features and the point -> group map ``idx`` (int32 or
+    int64, negative entries read row 0).  Shapes the kernel is not built for go through torch."""
+    ok = (x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.dim() == 2 and g.dim() == 2
+          and x.size(1) % 4 == 0 and g.size(1) % 4 == 0 and x.size(1) >= 4 and g.size(1) >= 4 and g.size(0) > 0
+          and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and g.stride(0) % 4 == 0)
+    if not ok:
+        return torch.cat([x, g[idx.long().clamp(min=0)]], dim=1)
+    idx32 = idx if idx.dtype == torch.int32 else idx.to(torch.int32)
+    return ConcatGather.apply(x, g, idx32.contiguous(), group_sum)

@@ -73,235 +73,193 @@ class SparseBasicBlock(SparseModule):
         return out
 
 
+_INVERSE_CONVS = tuple(f'SparseInverseConv{d}d' for d in (1, 2, 3, 4))
+
+
 def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, stride=1, padding=0,
                            conv_type='SubMConv3d', act_type='relu', norm_cfg=None, order=('conv', 'norm', 'act')):
-    """sparse_block.py:218-289 -> SparseSequential(conv [, norm] [, act]) in the given order"""
-    assert isinstance(order, tuple) and len(order) <= 3
-    assert set(order) | {'conv', 'norm', 'act'} == {'conv', 'norm', 'act'}
-    conv_cfg = dict(type=conv_type, indice_key=indice_key)
-    layers = []
-    for layer in order:
-        if layer == 'conv':
-            if conv_type not in ('SparseInverseConv4d', 'SparseInverseConv3d', 'SparseInverseConv2d',
-                                 'SparseInverseConv1d'):
-                layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
-                                               padding=padding, bias=False))
-            else:
-                layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, bias=False))
-        elif layer == 'norm':
-            layers.append(build_norm_layer(norm_cfg, out_channels)[1])
-        elif layer == 'act':
-            layers.append(_activation(act_type))
-    return SparseSequential(*layers)
+    """SparseSequential of convolution / norm / activation in ``order`` (sparse_block.py:218-289); an inverse
+    convolution takes its geometry from the rulebook of its ``indice_key`` instead of stride / padding."""
+    assert isinstance(order, tuple) and 0 < len(order) <= 3 and set(order) <= {'conv', 'norm', 'act'}
+    geometry = {} if conv_type in _INVERSE_CONVS else dict(stride=stride, padding=padding)
+    make = {'conv': lambda: build_conv_layer(dict(type=conv_type, indice_key=indice_key), in_channels, out_channels,
+                                             kernel_size, bias=False, **geometry),
+            'norm': lambda: build_norm_layer(norm_cfg, out_channels)[1],
+            'act': lambda: _activation(act_type)}
+    return SparseSequential(*[make[kind]() for kind in order])
 
 
-@MIDDLE_ENCODERS.register_module()
-class SparseUNet(nn.Module):
-    """encoder / decoder construction and the decoder step shared by the U-Nets (sparse_unet.py:16-321)."""
+class _UNetStages(nn.Module):
+    """What SparseUNet, SimpleSparseUNet and VirtualVoxelMixer share (sparse_unet.py:16-321): the input convolution, an
+    encoder of submanifold stages (every stage after the first opened by a stride-2 convolution), and a decoder that
+    walks back up - lateral residual block, concatenation with the coarser feature, merge convolution, channel-folded
+    residual, inverse convolution onto the finer level's voxels.  Sub-module names are the reference's (they are the
+    ``state_dict`` keys): conv_input, encoder_layers.encoder_layer{i}, lateral_layer{i}, merge_layer{i},
+    upsample_layer{i}."""
 
-    def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
-                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
-                 encoder_channels=((16, ), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
-                 encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
-                 decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
-                 decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)), ndim=3, act_type='relu', init_cfg=None):
-        super().__init__()
+    def _build_stages(self, in_channels, sparse_shape, order, norm_cfg, base_channels, output_channels, encoder_channels,
+                      encoder_paddings, decoder_channels, decoder_paddings, ndim, act_type, init_cfg):
         if ndim != 3:
-            raise NotImplementedError('sst_amd.SparseUNet: ndim=3 only')
-        self.init_cfg = init_cfg
-        self.sparse_shape = sparse_shape
-        self.in_channels = in_channels
-        self.order = order
-        self.base_channels = base_channels
-        self.output_channels = output_channels
-        self.encoder_channels = encoder_channels
-        self.encoder_paddings = encoder_paddings
-        self.decoder_channels = decoder_channels
-        self.decoder_paddings = decoder_paddings
-        self.stage_num = len(self.encoder_channels)
-        self.ndim = ndim
-        self.is_3d = ndim == 3
-        self.fp16_enabled = False
-        self.act_type = act_type
-        assert isinstance(order, tuple) and len(order) == 3
-        assert set(order) == {'conv', 'norm', 'act'}
-        if self.order[0] != 'conv':  # pre activate
-            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
-                                                     indice_key='subm1', conv_type=f'SubMConv{self.ndim}d',
-                                                     order=('conv', ), act_type=act_type)
-        else:
-            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
-                                                     indice_key='subm1', conv_type=f'SubMConv{self.ndim}d',
-                                                     act_type=act_type)
-        encoder_out_channels = self.make_encoder_layers(make_sparse_convmodule, norm_cfg, self.base_channels)
-        self.make_decoder_layers(make_sparse_convmodule, norm_cfg, encoder_out_channels)
-        self.conv_out = make_sparse_convmodule(encoder_out_channels, self.output_channels, kernel_size=(3, 1, 1),
-                                               stride=(2, 1, 1), norm_cfg=norm_cfg, padding=0,
-                                               indice_key='spconv_down2', conv_type=f'SparseConv{self.ndim}d',
-                                               act_type=act_type)
+            raise NotImplementedError('sst_amd sparse U-Nets: ndim=3 only')
+        assert isinstance(order, tuple) and set(order) == {'conv', 'norm', 'act'} and len(order) == 3
+        self.init_cfg, self.sparse_shape, self.in_channels, self.order = init_cfg, sparse_shape, in_channels, order
+        self.base_channels, self.output_channels = base_channels, output_channels
+        self.encoder_channels, self.encoder_paddings = encoder_channels, encoder_paddings
+        self.decoder_channels, self.decoder_paddings = decoder_channels, decoder_paddings
+        self.stage_num = len(encoder_channels)
+        self.ndim, self.is_3d, self.fp16_enabled, self.act_type = ndim, True, False, act_type
+        subm, strided, inverse = f'SubMConv{ndim}d', f'SparseConv{ndim}d', f'SparseInverseConv{ndim}d'
+        common = dict(norm_cfg=norm_cfg, act_type=act_type)
+        # a pre-activation order leaves the input convolution bare
+        self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, padding=1, indice_key='subm1',
+                                                 conv_type=subm, order=order if order[0] == 'conv' else ('conv', ),
+                                                 **common)
+        # encoder
+        self.encoder_layers = SparseSequential()
+        width = base_channels
+        for level, (channels, paddings) in enumerate(zip(encoder_channels, encoder_paddings), start=1):
+            stage = []
+            for j, (out, pad) in enumerate(zip(tuple(channels), tuple(paddings))):
+                down = level > 1 and j == 0
+                stage.append(make_sparse_convmodule(width, out, 3, padding=pad, stride=2 if down else 1,
+                                                    indice_key=f'spconv{level}' if down else f'subm{level}',
+                                                    conv_type=strided if down else subm, **common))
+                width = out
+            self.encoder_layers.add_module(f'encoder_layer{level}', SparseSequential(*stage))
+        self.encoder_out_channels = width
+        # decoder, coarsest level first
+        for level, ((c_lat, c_merge, c_up), pads) in zip(range(len(decoder_channels), 0, -1),
+                                                         zip(decoder_channels, decoder_paddings)):
+            setattr(self, f'lateral_layer{level}',
+                    SparseBasicBlock(width, c_lat, conv_cfg=dict(type=subm, indice_key=f'subm{level}'),
+                                     norm_cfg=norm_cfg, act_type=act_type))
+            setattr(self, f'merge_layer{level}',
+                    make_sparse_convmodule(2 * width, c_merge, 3, padding=pads[0], indice_key=f'subm{level}',
+                                           conv_type=subm, **common))
+            up = (dict(indice_key=f'spconv{level}', conv_type=inverse) if level > 1
+                  else dict(indice_key='subm1', conv_type=subm, padding=pads[1]))
+            setattr(self, f'upsample_layer{level}', make_sparse_convmodule(width, c_up, 3, **up, **common))
+            width = c_up
 
-    def forward(self, voxel_features, coors, batch_size):
-        """sparse_unet.py:114-159 -> dict(spatial_features [N, C*D, H, W], seg_features)"""
-        assert self.is_3d, 'This forward function only supports 3D spconv'
-        coors = coors.int()
-        x = self.conv_input(SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
-        encode_features = []
-        for encoder_layer in self.encoder_layers:
-            x = encoder_layer(x)
-            encode_features.append(x)
-        out = self.conv_out(encode_features[-1])
-        spatial_features = out.dense()
-        N, C, D, H, W = spatial_features.shape
-        spatial_features = spatial_features.view(N, C * D, H, W)
-        decode_features = []
-        x = encode_features[-1]
-        for i in range(self.stage_num, 0, -1):
-            x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f'lateral_layer{i}'),
-                                           getattr(self, f'merge_layer{i}'), getattr(self, f'upsample_layer{i}'))
-            decode_features.append(x)
-        return dict(spatial_features=spatial_features, seg_features=decode_features[-1].features)
+    def encode(self, voxel_features, coors, batch_size):
+        """-> the feature of every encoder level, finest first"""
+        x = self.conv_input(SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size))
+        levels = []
+        for stage in self.encoder_layers:
+            x = stage(x)
+            levels.append(x)
+        return levels
+
+    def decode(self, levels, keep_all=False):
+        """walk back up from the coarsest level: -> the finest decoder feature (and every level's, if asked)"""
+        x, outs = levels[-1], []
+        for level in range(self.stage_num, 0, -1):
+            x = self.decoder_layer_forward(levels[level - 1], x, getattr(self, f'lateral_layer{level}'),
+                                           getattr(self, f'merge_layer{level}'), getattr(self, f'upsample_layer{level}'))
+            if keep_all:
+                outs.append(x)
+        return x, outs
 
     def decoder_layer_forward(self, x_lateral, x_bottom, lateral_layer, merge_layer, upsample_layer):
-        """lateral block, concatenate with the feature from below, merge, channel-reduced residual, upsample"""
+        """one decoder step (sparse_unet.py:161-185)"""
         x = lateral_layer(x_lateral)
         x = x.replace_feature(torch.cat((x_bottom.features, x.features), dim=1))
-        x_merge = merge_layer(x)
-        x = self.reduce_channel(x, x_merge.features.shape[1])
-        x = x.replace_feature(x_merge.features + x.features)
-        x = upsample_layer(x)
-        return x
+        merged = merge_layer(x)
+        x = self.reduce_channel(x, merged.features.shape[1])
+        return upsample_layer(x.replace_feature(merged.features + x.features))
 
     @staticmethod
     def reduce_channel(x, out_channels):
-        features = x.features
-        n, in_channels = features.shape
-        assert (in_channels % out_channels == 0) and (in_channels >= out_channels)
-        return x.replace_feature(features.view(n, out_channels, -1).sum(dim=2))
+        """fold the channels down by summing groups of in / out neighbours (sparse_unet.py:187-202)"""
+        n, width = x.features.shape
+        assert width % out_channels == 0 and width >= out_channels
+        return x.replace_feature(x.features.view(n, out_channels, -1).sum(dim=2))
 
-    def make_encoder_layers(self, make_block, norm_cfg, in_channels):
-        self.encoder_layers = SparseSequential()
-        for i, blocks in enumerate(self.encoder_channels):
-            blocks_list = []
-            for j, out_channels in enumerate(tuple(blocks)):
-                padding = tuple(self.encoder_paddings[i])[j]
-                if i != 0 and j == 0:   # each stage but the first starts with a stride-2 convolution
-                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
-                                                  padding=padding, indice_key=f'spconv{i + 1}',
-                                                  conv_type=f'SparseConv{self.ndim}d', act_type=self.act_type))
-                else:
-                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, padding=padding,
-                                                  indice_key=f'subm{i + 1}', conv_type=f'SubMConv{self.ndim}d',
-                                                  act_type=self.act_type))
-                in_channels = out_channels
-            self.encoder_layers.add_module(f'encoder_layer{i + 1}', SparseSequential(*blocks_list))
-        return out_channels
 
-    def make_decoder_layers(self, make_block, norm_cfg, in_channels):
-        block_num = len(self.decoder_channels)
-        for i, block_channels in enumerate(self.decoder_channels):
-            paddings = self.decoder_paddings[i]
-            setattr(self, f'lateral_layer{block_num - i}',
-                    SparseBasicBlock(in_channels, block_channels[0],
-                                     conv_cfg=dict(type=f'SubMConv{self.ndim}d', indice_key=f'subm{block_num - i}'),
-                                     norm_cfg=norm_cfg, act_type=self.act_type))
-            setattr(self, f'merge_layer{block_num - i}',
-                    make_block(in_channels * 2, block_channels[1], 3, norm_cfg=norm_cfg, padding=paddings[0],
-                               indice_key=f'subm{block_num - i}', conv_type=f'SubMConv{self.ndim}d',
-                               act_type=self.act_type))
-            if block_num - i != 1:
-                setattr(self, f'upsample_layer{block_num - i}',
-                        make_block(in_channels, block_channels[2], 3, norm_cfg=norm_cfg,
-                                   indice_key=f'spconv{block_num - i}', conv_type=f'SparseInverseConv{self.ndim}d',
-                                   act_type=self.act_type))
-            else:
-                setattr(self, f'upsample_layer{block_num - i}',
-                        make_block(in_channels, block_channels[2], 3, norm_cfg=norm_cfg, padding=paddings[1],
-                                   indice_key='subm1', conv_type=f'SubMConv{self.ndim}d', act_type=self.act_type))
-            in_channels = block_channels[2]
+_UNET_DEFAULTS = dict(
+    encoder_channels=((16, ), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+    encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+    decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
+    decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)))
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseUNet(_UNetStages):
+    """SECOND-style U-Net with the dense output branch (sparse_unet.py:16-159)."""
+
+    def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=_UNET_DEFAULTS['encoder_channels'], encoder_paddings=_UNET_DEFAULTS['encoder_paddings'],
+                 decoder_channels=_UNET_DEFAULTS['decoder_channels'], decoder_paddings=_UNET_DEFAULTS['decoder_paddings'],
+                 ndim=3, act_type='relu', init_cfg=None):
+        super().__init__()
+        self._build_stages(in_channels, sparse_shape, order, norm_cfg, base_channels, output_channels, encoder_channels,
+                           encoder_paddings, decoder_channels, decoder_paddings, ndim, act_type, init_cfg)
+        self.conv_out = make_sparse_convmodule(self.encoder_out_channels, output_channels, kernel_size=(3, 1, 1),
+                                               stride=(2, 1, 1), norm_cfg=norm_cfg, padding=0, indice_key='spconv_down2',
+                                               conv_type=f'SparseConv{ndim}d', act_type=act_type)
+
+    def forward(self, voxel_features, coors, batch_size):
+        """-> dict(spatial_features [N, C*D, H, W] from the coarsest level, seg_features of the finest decoder level)"""
+        levels = self.encode(voxel_features, coors, batch_size)
+        dense = self.conv_out(levels[-1]).dense()
+        n, c, d, h, w = dense.shape
+        finest, _ = self.decode(levels)
+        return dict(spatial_features=dense.view(n, c * d, h, w), seg_features=finest.features)
 
 
 @BACKBONES.register_module()
-class SimpleSparseUNet(SparseUNet):
+class SimpleSparseUNet(_UNetStages):
     """the U-Net without the dense output branch: FSD's segmentor backbone (sparse_unet.py:324-414)."""
 
     def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
                  norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128, ndim=3,
-                 encoder_channels=((16, ), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
-                 encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
-                 decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
-                 decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)), keep_coors_dims=None, act_type='relu',
-                 return_multiscale_features=False, init_cfg=None):
-        super().__init__(in_channels=in_channels, sparse_shape=sparse_shape, order=order, norm_cfg=norm_cfg,
-                         base_channels=base_channels, output_channels=output_channels,
-                         encoder_channels=encoder_channels, encoder_paddings=encoder_paddings,
-                         decoder_channels=decoder_channels, decoder_paddings=decoder_paddings, ndim=ndim,
-                         act_type=act_type, init_cfg=init_cfg)
-        self.conv_out = None  # override
-        self.ndim = ndim
+                 encoder_channels=_UNET_DEFAULTS['encoder_channels'], encoder_paddings=_UNET_DEFAULTS['encoder_paddings'],
+                 decoder_channels=_UNET_DEFAULTS['decoder_channels'], decoder_paddings=_UNET_DEFAULTS['decoder_paddings'],
+                 keep_coors_dims=None, act_type='relu', return_multiscale_features=False, init_cfg=None):
+        super().__init__()
+        self._build_stages(in_channels, sparse_shape, order, norm_cfg, base_channels, output_channels, encoder_channels,
+                           encoder_paddings, decoder_channels, decoder_paddings, ndim, act_type, init_cfg)
+        self.conv_out = None
         self.keep_coors_dims = keep_coors_dims
         self.return_multiscale_features = return_multiscale_features
 
     def forward(self, voxel_info):
-        """voxel_info: dict(voxel_feats [N, C], voxel_coors [N, 4] (b, z, y, x)) -> [dict(voxel_feats, voxel_coors,
-        sparse_shape, batch_size, decoder_features)] (a list, like SSTv2)."""
+        """voxel_info: dict(voxel_feats [N, C], voxel_coors [N, 4] (b, z, y, x)[, batch_size]) -> [dict(voxel_feats,
+        voxel_coors, sparse_shape, batch_size, decoder_features)] (a list, like SSTv2)."""
         coors = voxel_info['voxel_coors']
         if self.keep_coors_dims is not None:
             coors = coors[:, self.keep_coors_dims]
-        voxel_features = voxel_info['voxel_feats']
-        coors = coors.int()
-        batch_size = coors[:, 0].max().item() + 1
-        x = self.conv_input(SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
-        encode_features = []
-        decode_features = []
-        for encoder_layer in self.encoder_layers:
-            x = encoder_layer(x)
-            encode_features.append(x)
-        x = encode_features[-1]
-        for i in range(self.stage_num, 0, -1):
-            x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f'lateral_layer{i}'),
-                                           getattr(self, f'merge_layer{i}'), getattr(self, f'upsample_layer{i}'))
-            if self.return_multiscale_features:
-                decode_features.append(x)
-        ret = {'voxel_feats': x.features, 'voxel_coors': x.indices, 'sparse_shape': x.spatial_shape,
-               'batch_size': x.batch_size, 'decoder_features': decode_features}
-        return [ret, ]
+        batch_size = voxel_info.get('batch_size')
+        if batch_size is None:   # the reference reads it off the coordinates (one read-back, sparse_unet.py:382)
+            batch_size = int(coors[:, 0].max().item()) + 1
+        finest, every = self.decode(self.encode(voxel_info['voxel_feats'], coors, batch_size),
+                                    keep_all=self.return_multiscale_features)
+        return [{'voxel_feats': finest.features, 'voxel_coors': finest.indices, 'sparse_shape': finest.spatial_shape,
+                 'batch_size': finest.batch_size, 'decoder_features': every}]
 
 
 @BACKBONES.register_module()
-class VirtualVoxelMixer(SparseUNet):
+class VirtualVoxelMixer(_UNetStages):
     """FSDv2's backbone over real + virtual voxels (sparse_unet.py:417-504): the U-Net followed by a submanifold
     output convolution; forward(voxel_features, coors, batch_size) -> (features, indices, spatial_shape)."""
 
     def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
                  norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128, ndim=3,
-                 encoder_channels=((16, ), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
-                 encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
-                 decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
-                 decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)), keep_coors_dims=None, act_type='relu',
-                 init_cfg=None):
-        super().__init__(in_channels=in_channels, sparse_shape=sparse_shape, order=order, norm_cfg=norm_cfg,
-                         base_channels=base_channels, output_channels=output_channels,
-                         encoder_channels=encoder_channels, encoder_paddings=encoder_paddings,
-                         decoder_channels=decoder_channels, decoder_paddings=decoder_paddings, ndim=ndim,
-                         act_type=act_type, init_cfg=init_cfg)
-        self.ndim = ndim
+                 encoder_channels=_UNET_DEFAULTS['encoder_channels'], encoder_paddings=_UNET_DEFAULTS['encoder_paddings'],
+                 decoder_channels=_UNET_DEFAULTS['decoder_channels'], decoder_paddings=_UNET_DEFAULTS['decoder_paddings'],
+                 keep_coors_dims=None, act_type='relu', init_cfg=None):
+        super().__init__()
+        self._build_stages(in_channels, sparse_shape, order, norm_cfg, base_channels, output_channels, encoder_channels,
+                           encoder_paddings, decoder_channels, decoder_paddings, ndim, act_type, init_cfg)
         self.keep_coors_dims = keep_coors_dims
-        self.conv_out = make_sparse_convmodule(decoder_channels[-1][-1], self.output_channels, kernel_size=3, stride=1,
+        self.conv_out = make_sparse_convmodule(decoder_channels[-1][-1], output_channels, kernel_size=3, stride=1,
                                                norm_cfg=norm_cfg, padding=0, indice_key='out_conv',
-                                               conv_type=f'SubMConv{self.ndim}d', act_type=act_type)
+                                               conv_type=f'SubMConv{ndim}d', act_type=act_type)
 
     def forward(self, voxel_features, coors, batch_size):
         if self.keep_coors_dims is not None:
             coors = coors[:, self.keep_coors_dims]
-        coors = coors.int()
-        x = self.conv_input(SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size))
-        encode_features = []
-        for encoder_layer in self.encoder_layers:
-            x = encoder_layer(x)
-            encode_features.append(x)
-        x = encode_features[-1]
-        for i in range(self.stage_num, 0, -1):
-            x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f'lateral_layer{i}'),
-                                           getattr(self, f'merge_layer{i}'), getattr(self, f'upsample_layer{i}'))
-        x = self.conv_out(x)
-        return x.features, x.indices, x.spatial_shape
+        finest, _ = self.decode(self.encode(voxel_features, coors, batch_size))
+        out = self.conv_out(finest)
+        return out.features, out.indices, out.spatial_shape

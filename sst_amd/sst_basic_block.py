@@ -18,7 +18,8 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
-from .dense import tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, tall_linear, weight_bias_grad
+from .dense import (tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
+                    weight_bias_grad)
 from .norm import build_norm_layer
 
 
@@ -135,6 +136,11 @@ class WindowAttention(nn.Module):
 # (62 us vs 54 us); SST_AMD_TALL_GEMM=0 switches the kernel off, =2 also routes the K = 256 shapes through it.
 import os as _os
 _TALL_GEMM = int(_os.environ.get('SST_AMD_TALL_GEMM', '1'))
+# GELU of the FFN in the epilogues of linear1 / of linear2's data gradient (csrc/tall_gemm.hip, EPI 2 / 3).  Measured and
+# rejected as the default (profiles/r02/f_*): the erf / exp arithmetic of 64 elements per lane sits in the store phase of a
+# hand-pipelined MFMA kernel where nothing overlaps it - 57 us (forward) and 104 us (backward) per 128-column half against
+# 38 us for the plain product, i.e. 16.2 ms per step instead of 14.6 with the library GEMM + torch's HBM-bound GELU kernels.
+_FUSED_GELU = int(_os.environ.get('SST_AMD_FUSED_GELU', '0'))
 
 
 def _linear_fwd(x, w, b):
@@ -177,8 +183,12 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         a = _linear_fwd(o, w_out, b_out)
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
         y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
-        pre = torch.addmm(b1, y1, w1.t())
-        h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
+        fused_act = linear_gelu(y1, w1, b1) if (act == 'gelu' and _FUSED_GELU) else None
+        if fused_act is not None:      # bias + GELU in the epilogue of linear1 (csrc/tall_gemm.hip)
+            pre, h = fused_act
+        else:
+            pre = torch.addmm(b1, y1, w1.t())
+            h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
         f = _linear_fwd(h, w2, b2)
         y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd)
         if not need_bwd:
@@ -193,11 +203,13 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         c = x.size(1)
         ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w)               # = d(y1 residual) = d(f)
         dw2, db2 = weight_bias_grad(ds2, h, True)
-        dh = ds2 @ w2
-        if ctx.act == 'gelu':
-            dpre = torch.ops.aten.gelu_backward(dh, pre)
-        else:
-            dpre = dh * (pre > 0).to(dh.dtype)
+        dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
+        if dpre is None:
+            dh = ds2 @ w2
+            if ctx.act == 'gelu':
+                dpre = torch.ops.aten.gelu_backward(dh, pre)
+            else:
+                dpre = dh * (pre > 0).to(dh.dtype)
         dw1, db1 = weight_bias_grad(dpre, y1, True)
         dy1 = _linear_dgrad(dpre, w1, out=ds2)                        # residual + FFN branch: GEMM with beta = 1
         ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)

@@ -51,83 +51,93 @@ def make_continuous_inds(inds):
     return plan.inverse.to(inds.dtype)
 
 
+def _levels_present(voxel_drop_lvl, drop_info):
+    """[(level key, int64 positions of its voxels)] for the drop levels that occur, in the order of ``drop_info``"""
+    out = []
+    for key in drop_info:
+        where = torch.nonzero(voxel_drop_lvl == key).squeeze(1)
+        if where.numel() > 0:
+            out.append((key, where))
+    return out
+
+
 @torch.no_grad()
 def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
-    flat2window_inds_dict = {}
-    for dl in drop_info:
-        dl_mask = voxel_drop_lvl == dl
-        if not dl_mask.any():
-            continue
-        conti_win_inds = make_continuous_inds(batch_win_inds[dl_mask])
-        max_tokens = drop_info[dl]['max_tokens']
-        inner_win_inds = get_inner_win_inds(conti_win_inds)
-        flat2window_inds = conti_win_inds * max_tokens + inner_win_inds
-        flat2window_inds_dict[dl] = (flat2window_inds, torch.where(dl_mask))
+    """{level: (slot of every voxel of the level in its padded [W * T] window tensor, (positions of those voxels,))}
+    (sst_ops.py:26-64): windows of a level numbered 0..W-1 in ascending window-id order, slot = window * T + rank of
+    the voxel inside its window (ascending voxel index)."""
+    table = {}
+    for key, where in _levels_present(voxel_drop_lvl, drop_info):
+        cap = drop_info[key]['max_tokens']
+        win = make_continuous_inds(batch_win_inds[where])
+        rank = get_inner_win_inds(win)
+        slots = win * cap + rank
+        table[key] = (slots, (where,))
         if debug:
-            num_windows = len(torch.unique(conti_win_inds))
-            assert inner_win_inds.max() < max_tokens, \
-                f'Max inner inds({inner_win_inds.max()}) larger(equal) than {max_tokens}'
-            assert (flat2window_inds >= 0).all()
-            max_ind = flat2window_inds.max().item()
-            assert max_ind < num_windows * max_tokens, \
-                f'max_ind({max_ind}) larger than upper bound({num_windows * max_tokens})'
-            assert max_ind >= (num_windows - 1) * max_tokens, \
-                f'max_ind({max_ind}) less than lower bound({(num_windows - 1) * max_tokens})'
-    return flat2window_inds_dict
+            n_win = int(win.max().item()) + 1
+            assert int(rank.max().item()) < cap, f'Max inner inds({int(rank.max())}) larger(equal) than {cap}'
+            top = int(slots.max().item())
+            assert int(slots.min().item()) >= 0 and (n_win - 1) * cap <= top < n_win * cap, \
+                f'slot range of level {key} inconsistent: max {top}, {n_win} windows of {cap} tokens'
+    return table
+
+
+def _rows_to_slots(rows, slots, n_slots, padding):
+    """out[slots[i]] = rows[i] on a [n_slots, C] tensor filled with ``padding``: the row-scatter kernel for fp32 CUDA
+    features, index assignment otherwise (integer / bool payloads of the reference-format dictionaries)"""
+    out = torch.full((n_slots, rows.shape[-1]), padding, dtype=rows.dtype, device=rows.device)
+    if rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and not rows.requires_grad:
+        K.scatter_rows(rows.contiguous(), slots.to(torch.int32).contiguous(), out)
+    else:
+        out[slots] = rows
+    return out
 
 
 def flat2window(feat, voxel_drop_lvl, flat2win_inds_dict, drop_info, padding=0):
-    """[N,C] -> {level: [num_windows, max_tokens, C]} (sst_ops.py:67-104)."""
-    dtype = feat.dtype
-    device = feat.device
-    feat_dim = feat.shape[-1]
-    feat_3d_dict = {}
-    for dl in drop_info:
-        dl_mask = voxel_drop_lvl == dl
-        if not dl_mask.any():
-            continue
-        feat_this_dl = feat[dl_mask]
-        this_inds = flat2win_inds_dict[dl][0]
-        max_tokens = drop_info[dl]['max_tokens']
-        num_windows = (this_inds // max_tokens).max().item() + 1
-        feat_3d = torch.full((num_windows * max_tokens, feat_dim), padding, dtype=dtype, device=device)
-        feat_3d[this_inds] = feat_this_dl
-        feat_3d_dict[dl] = feat_3d.reshape((num_windows, max_tokens, feat_dim))
-    return feat_3d_dict
+    """[N, C] -> {level: [W, T, C]} padded window tensors (sst_ops.py:67-104)."""
+    windows = {}
+    for key, where in _levels_present(voxel_drop_lvl, drop_info):
+        slots = flat2win_inds_dict[key][0]
+        cap = drop_info[key]['max_tokens']
+        n_win = int(torch.div(slots, cap, rounding_mode='floor').max().item()) + 1
+        windows[key] = _rows_to_slots(feat[where], slots, n_win * cap, padding).reshape(n_win, cap, feat.shape[-1])
+    return windows
 
 
 def window2flat(feat_3d_dict, inds_dict):
-    num_all_voxel = 0
-    for dl in inds_dict:
-        num_all_voxel += inds_dict[dl][0].shape[0]
-    first = feat_3d_dict[list(feat_3d_dict.keys())[0]]
-    all_flat_feat = torch.zeros((num_all_voxel, first.shape[-1]), device=first.device, dtype=first.dtype)
-    for dl in feat_3d_dict:
-        feat = feat_3d_dict[dl]
-        feat_dim = feat.shape[-1]
-        inds, flat_pos = inds_dict[dl]
-        feat = feat.reshape(-1, feat_dim)
-        all_flat_feat[flat_pos] = feat[inds]
-    return all_flat_feat
+    """{level: [W, T, C]} -> [N, C]: every voxel reads its slot back (sst_ops.py:106-132)."""
+    total = sum(inds_dict[key][0].shape[0] for key in inds_dict)
+    any_level = next(iter(feat_3d_dict.values()))
+    flat = torch.zeros((total, any_level.shape[-1]), device=any_level.device, dtype=any_level.dtype)
+    for key, padded in feat_3d_dict.items():
+        slots, where = inds_dict[key]
+        rows2d = padded.reshape(-1, padded.shape[-1])
+        if rows2d.is_cuda and rows2d.dtype == torch.float32 and not rows2d.requires_grad:
+            flat[where] = K.gather_rows(rows2d.contiguous(), slots.to(torch.int32).contiguous())
+        else:
+            flat[where] = rows2d[slots]
+    return flat
+
+
+def _numeric_levels(inds_dict):
+    return {key: val for key, val in inds_dict.items() if not isinstance(key, str)}
 
 
 def get_flat2win_inds_v2(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
-    transform_dict = get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug)
-    transform_dict['voxel_drop_level'] = voxel_drop_lvl
-    transform_dict['batching_info'] = drop_info
-    return transform_dict
+    """v2 dictionaries additionally carry the level of every voxel and the batching table (sst_ops.py:134-139)."""
+    table = get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug)
+    table.update(voxel_drop_level=voxel_drop_lvl, batching_info=drop_info)
+    return table
 
 
 def window2flat_v2(feat_3d_dict, inds_dict):
-    inds_v1 = {k: inds_dict[k] for k in inds_dict if not isinstance(k, str)}
-    return window2flat(feat_3d_dict, inds_v1)
+    return window2flat(feat_3d_dict, _numeric_levels(inds_dict))
 
 
 def flat2window_v2(feat, inds_dict, padding=0):
     assert 'voxel_drop_level' in inds_dict, 'voxel_drop_level should be in inds_dict in v2 function'
-    inds_v1 = {k: inds_dict[k] for k in inds_dict if not isinstance(k, str)}
-    batching_info = inds_dict['batching_info']
-    return flat2window(feat, inds_dict['voxel_drop_level'], inds_v1, batching_info, padding=padding)
+    return flat2window(feat, inds_dict['voxel_drop_level'], _numeric_levels(inds_dict), inds_dict['batching_info'],
+                       padding=padding)
 
 
 # --------------------------------------------------------------------------------------------
@@ -150,7 +160,8 @@ def unique_with_plan(coors, return_counts=False):
     return new_coors, unq_inv
 
 
-def _plan_from_inverse(unq_inv, num_groups):
+def plan_of_inverse(unq_inv, num_groups):
+    """the CSR (kernels.UniquePlan) behind an inverse map: the one it was produced with, or rebuilt from the ids"""
     plan = getattr(unq_inv, '_sst_plan', None)
     if plan is not None and plan.m == num_groups:
         return plan
@@ -190,7 +201,7 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
     else:
         assert new_coors is not None, \
             'please pass new_coors for interface consistency, caller: {}'.format(traceback.extract_stack()[-2][2])
-        plan = _plan_from_inverse(unq_inv, new_coors.size(0))
+        plan = plan_of_inverse(unq_inv, new_coors.size(0))
         unq_cnt = plan.counts().long() if min_points > 0 else None
 
     if min_points > 0:
@@ -212,51 +223,49 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
 
 
 # --------------------------------------------------------------------------------------------
-# MLP helpers (pure nn glue, sst_ops.py:334-391)
+# MLP helpers (sst_ops.py:334-391): pure nn glue; the Sequential layout fixes the state_dict keys (``{i}.0.weight`` ...)
 # --------------------------------------------------------------------------------------------
-def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias=False, dropout=0):
-    layer_list = []
-    last_channel = in_channel
-    if isinstance(hidden_dims, int):
-        hidden_dims = [hidden_dims, ]
-    for i, c in enumerate(hidden_dims):
-        act_layer = get_activation_layer(act, c)
-        norm_layer = build_norm_layer(norm_cfg, c)[1]
-        if i == len(hidden_dims) - 1 and is_head:
-            layer_list.append(nn.Linear(last_channel, c, bias=True), )
-        else:
-            sq = [nn.Linear(last_channel, c, bias=bias), norm_layer, act_layer]
-            if dropout > 0:
-                sq.append(nn.Dropout(dropout))
-            layer_list.append(nn.Sequential(*sq))
-        last_channel = c
-    return nn.Sequential(*layer_list)
-
-
-def get_activation(activation):
-    if activation == "relu":
-        return torch.nn.functional.relu
-    if activation == "gelu":
-        return torch.nn.functional.gelu
-    if activation == "glu":
-        return torch.nn.functional.glu
-    raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
+_ACTIVATION_LAYERS = {
+    'relu': lambda dim: nn.ReLU(inplace=True),
+    'gelu': lambda dim: nn.GELU(),
+    'leakyrelu': lambda dim: nn.LeakyReLU(inplace=True),
+    'prelu': lambda dim: nn.PReLU(num_parameters=dim),
+    'swish': lambda dim: nn.SiLU(inplace=True),
+    'silu': lambda dim: nn.SiLU(inplace=True),
+    'glu': lambda dim: nn.GLU(),
+    'elu': lambda dim: nn.ELU(inplace=True),
+}
 
 
 def get_activation_layer(act, dim=None):
-    act = act.lower()
-    if act == 'relu':
-        return nn.ReLU(inplace=True)
-    if act == 'gelu':
-        return nn.GELU()
-    if act == 'leakyrelu':
-        return nn.LeakyReLU(inplace=True)
-    if act == 'prelu':
-        return nn.PReLU(num_parameters=dim)
-    if act in ('swish', 'silu'):
-        return nn.SiLU(inplace=True)
-    if act == 'glu':
-        return nn.GLU()
-    if act == 'elu':
-        return nn.ELU(inplace=True)
-    raise NotImplementedError
+    try:
+        return _ACTIVATION_LAYERS[act.lower()](dim)
+    except KeyError:
+        raise NotImplementedError(act)
+
+
+def get_activation(activation):
+    fns = {'relu': torch.nn.functional.relu, 'gelu': torch.nn.functional.gelu, 'glu': torch.nn.functional.glu}
+    if activation not in fns:
+        raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
+    return fns[activation]
+
+
+def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias=False, dropout=0):
+    """Sequential of [Linear -> norm -> act (-> dropout)] stages; with ``is_head`` the last stage is a bare Linear
+    with bias (sst_ops.py:334-361)."""
+    dims = [hidden_dims] if isinstance(hidden_dims, int) else list(hidden_dims)
+    stages, width = [], in_channel
+    for i, out in enumerate(dims):
+        if is_head and i == len(dims) - 1:
+            stages.append(nn.Linear(width, out, bias=True))
+        else:
+            # activation, then norm: the construction order of the reference, which decides the RNG draws of the init
+            act_layer = get_activation_layer(act, out)
+            norm_layer = build_norm_layer(norm_cfg, out)[1]
+            parts = [nn.Linear(width, out, bias=bias), norm_layer, act_layer]
+            if dropout > 0:
+                parts.append(nn.Dropout(dropout))
+            stages.append(nn.Sequential(*parts))
+        width = out
+    return nn.Sequential(*stages)

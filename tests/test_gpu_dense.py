@@ -128,6 +128,30 @@ def test_tall_gemm_matches_float64(m, k, trans, acc):
             assert torch.equal(first, out)  # deterministic, bit for bit
 
 
+@pytest.mark.parametrize('m', [1, 33, 5000, 90107])
+def test_gelu_fused_gemms_match_float64(m):
+    """linear1 + bias + GELU in one pass and (dy w2) * gelu'(pre) in one pass (csrc/tall_gemm.hip epilogues) against
+    the float64 composition of torch's erf GELU (sst_basic_block_v2.py:116)."""
+    from sst_amd.dense import dgrad_gelu, linear_gelu
+    dev = torch.device('cuda:0')
+    torch.manual_seed(m)
+    x = torch.randn(m, 128, device=dev)
+    w1 = torch.randn(256, 128, device=dev) * 0.1
+    b1 = torch.randn(256, device=dev)
+    w2 = torch.randn(128, 256, device=dev) * 0.1
+    dy = torch.randn(m, 128, device=dev)
+    for rep in range(3):
+        pre, h = linear_gelu(x, w1, b1)
+        pre_ref = x.double() @ w1.double().t() + b1.double()
+        assert (pre.double() - pre_ref).abs().max().item() < 1e-4
+        assert (h.double() - torch.nn.functional.gelu(pre_ref)).abs().max().item() < 1e-4
+        dpre = dgrad_gelu(dy, w2, pre)
+        p = pre.double().requires_grad_(True)
+        (torch.nn.functional.gelu(p) * (dy.double() @ w2.double())).sum().backward()
+        assert (dpre.double() - p.grad).abs().max().item() < 1e-4
+    assert linear_gelu(torch.randn(8, 64, device=dev), torch.randn(256, 64, device=dev), b1) is None
+
+
 def test_tall_gemm_strided_operands_and_unsupported_shapes():
     from sst_amd.dense import tall_gemm
     dev = torch.device('cuda:0')
