@@ -90,6 +90,7 @@ class Pipeline(torch.nn.Module):
             info = self.middle_encoder.apply_plan(wplan, voxel_feats)
         else:                               # fused index plan: the voxel encoder is queued before the sizes are read
             voxel_feats, _ = self.voxel_encoder(prepared.points, prepared.coors, scatter_plan=prepared)
+            prepared.want_pos_rows = self.backbone.precision != 'bf16'   # bf16 layers add the embedding in the LN kernel
             info = prepared.finalize(voxel_feats, self.middle_encoder)
         self.last_voxel_coors = info['voxel_coors']
         return self.backbone(info)[0]['voxel_feats']
@@ -227,6 +228,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-time-sra-bwd', action='store_true', help='do not attach events to the SRA backward launches')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
+    ap.add_argument('--no-bf16-leg', action='store_true', help='skip the reduced-precision (bf16) measurement')
     ap.add_argument('--piecewise-index', action='store_true',
                     help='index plan through the module interfaces (three read-backs) instead of csrc/frame_plan.hip')
     ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
@@ -345,6 +347,59 @@ def main():
                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
                     'note': 'same pipeline under torch.no_grad(), training-mode drop/shuffle; not part of `value`'}
 
+    # Beside the fp32 headline: the same step with the encoder layers in the reduced-precision mode (bf16 storage, fp32
+    # accumulation / softmax / LayerNorm statistics, fp32 master weights: sst_amd/bf16.py) - what the reference's own
+    # fp16 training of these layers (configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82) corresponds to here.
+    bf16_leg = None
+    if not args.fwd_only and not args.no_bf16_leg:
+        with torch.no_grad():
+            ref_out, ref_key = gpu_forward_sorted(model, frames)
+        model.backbone.set_precision('bf16')
+        try:
+            with torch.no_grad():
+                low_out, low_key = gpu_forward_sorted(model, frames)
+            diff = (low_out - ref_out).abs() if torch.equal(ref_key, low_key) else None
+            for _ in range(3):
+                step()
+            bsink = []
+            K.EVENT_SINK = bsink
+            K.EVENT_KINDS = ('sra_fwd_bf16', 'sra_bwd_bf16')
+            sync()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            el = time.perf_counter() - t2
+            K.EVENT_SINK = None
+        finally:
+            model.backbone.set_precision('fp32')
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+
+        def bstats(kind, bytes_per_token):
+            ev = [(e0.elapsed_time(e1), n) for k_, e0, e1, n in bsink if k_ == kind]
+            ev = [(t_, n) for t_, n in ev if t_ > 0]
+            if not ev:
+                return None
+            ms_ = sum(t_ for t_, _ in ev) / len(ev)
+            tok_ = sum(n for _, n in ev) / len(ev)
+            ach = bytes_per_token * tok_ / (ms_ * 1e-3) / 1e9
+            return {'achieved': round(ach, 1), 'frac': round(ach / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(ms_, 4),
+                    'algorithmic_bytes_per_launch': int(bytes_per_token * tok_), 'launches_timed': len(ev)}
+
+        bf16_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                    'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': 'bf16',
+                    'what': 'same step, encoder layers in bf16 storage (fp32 accumulate / softmax / LayerNorm statistics, '
+                            'fp32 master weights); voxelize, VFE and the index plan unchanged (fp32, as the reference '
+                            'forces them: voxel_encoder.py:229)',
+                    'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'sra_fwd': bstats('sra_fwd_bf16', 4 * 128 * 2 + 8),
+                                 'sra_bwd': bstats('sra_bwd_bf16', 8 * 128 * 2 + 8)},
+                    'vs_fp32_forward': None if diff is None else {'max_abs': float(diff.max()), 'mean_abs': float(diff.mean()),
+                                                                  'voxels_equal': True}}
+
     # roofline of the dominant kernel group (SRA attention core, forward)
     def group_stats(kind):
         ev = [(e0.elapsed_time(e1), n) for k_, e0, e1, n in sink if k_ == kind]
@@ -412,6 +467,8 @@ def main():
         }
         if fwd_only is not None:
             res['forward_only'] = fwd_only
+        if bf16_leg is not None:
+            res['reduced_precision'] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], res['parity'] = cpu_reference_leg(model, frames[0].cpu(), args.blocks)
         else:

@@ -290,6 +290,43 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
                          int64_t lddv, void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (a12, reduced precision) The same attention core with bf16 storage: Q, K, V, O, dO, dQ, dK, dV are bf16 ([M, n_heads*16],
+ * row strides in elements, multiples of 4; 8-byte aligned), the softmax, the log-sum-exp (fp32 [M, n_heads]) and every
+ * accumulation are fp32; v_mfma_f32_16x16x16_bf16.  The reference's own training precision for these layers is fp16
+ * (configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82).  Windows up to 144 tokens (max_tokens must say so, else
+ * SST_ERR_UNSUPPORTED).  The backward is one pass per (window, head) wave (dQ, dK, dV from one read of Q, K, V, O, dO).
+ * sst_sra_attn_bf16_profile_next(backward, start, stop): one-shot kernel-bound events, as for the fp32 kernels.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_sra_attn_fwd_bf16(const void* d_q, const void* d_k, const void* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                          const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int n_heads, float scale,
+                          int max_tokens, void* d_o, int64_t ldo, float* d_lse, void* stream);
+int sst_sra_attn_bwd_bf16(const void* d_q, const void* d_k, const void* d_v, const void* d_o, const void* d_do,
+                          const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                          const int32_t* d_tok, const int32_t* d_winoff, int64_t n_windows, int n_heads, float scale,
+                          int max_tokens, void* d_dq, void* d_dk, void* d_dv, int64_t lddq, int64_t lddk, int64_t lddv,
+                          void* stream);
+int sst_sra_attn_bf16_profile_next(int backward, void* start, void* stop);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row kernels of the reduced-precision encoder layer: bf16 storage, fp32 parameters / statistics / arithmetic.
+ *   sst_add_layernorm_fwd_bf16: y = LN(x + res) * w + b  (res may be NULL); d_sum (optional) = x + res for the backward
+ *     pass; d_stats [m, 2] fp32 (mean, rstd); optional second output d_y_plus_pos = y + pos_table[pos_idx[row]] - the
+ *     next layer's q / k input "x + positional embedding" (sst_basic_block_v2.py:58-60; pos_table: fp32 [P, c], the
+ *     distinct rows of SSTInputLayerV2.get_pos_embed).
+ *   sst_add_layernorm_bwd_bf16: d(x + res) from dy (+ dy2, optional second gradient arriving at y) and dweight / dbias
+ *     (fp32).  Workspace: sst_add_layernorm_bwd_workspace_bytes(m, c).
+ *   sst_cast_add_pos_bf16: out(bf16) = x (fp32 or bf16) [+ pos_table[pos_idx]]: entry of the bf16 stack.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_add_layernorm_fwd_bf16(const void* d_x, const void* d_res, const float* d_weight, const float* d_bias, int64_t m,
+                               int c, float eps, void* d_y, void* d_sum, float* d_stats, const float* d_pos_table,
+                               const int32_t* d_pos_idx, void* d_y_plus_pos, void* stream);
+int sst_add_layernorm_bwd_bf16(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
+                               const float* d_weight, int64_t m, int c, void* d_dx, float* d_dweight, float* d_dbias,
+                               void* d_workspace, void* stream);
+int sst_cast_add_pos_bf16(const void* d_x, int x_is_bf16, int64_t m, int c, const float* d_pos_table,
+                          const int32_t* d_pos_idx, void* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (a10/a14) row gather / scatter used by flat2window / window2flat / recover_bev.
  *   gather:  d_out[i, :] = idx[i] >= 0 ? d_src[idx[i], :] : fill
  *   scatter: d_out[idx[i], :] = d_src[i, :]      (idx unique; rows with idx < 0 skipped)

@@ -54,6 +54,16 @@ _SIGNATURES = {
                                                                  c_i32, c_i32, c_ptr, c_ptr, c_ptr,
                                                                  c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sst_sra_attn_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
+    'sst_sra_attn_fwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_i32,
+                                      c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_sra_attn_bwd_bf16': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_i64, c_i32, c_f32, c_i32, c_ptr, c_ptr,
+                                                                  c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    'sst_sra_attn_bf16_profile_next': (c_i32, [c_i32, c_ptr, c_ptr]),
+    'sst_add_layernorm_fwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                           c_ptr, c_ptr, c_ptr]),
+    'sst_add_layernorm_bwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                           c_ptr]),
+    'sst_cast_add_pos_bf16': (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_gather_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_i64, c_ptr]),
     'sst_scatter_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_add_layernorm_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr,

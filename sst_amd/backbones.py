@@ -112,8 +112,24 @@ class _WindowTransformer(nn.Module):
             width = conv_out_channel
         self.conv_layer = nn.ModuleList(stages)
 
-    def run_blocks(self, feats, pos, plans, masks=None):
+    precision = 'fp32'
+
+    def set_precision(self, precision):
+        """'fp32' (default; the parity mode) or 'bf16': reduced-precision encoder layers (sst_amd/bf16.py) - what the
+        reference's fp16 training (Fp16OptimizerHook) corresponds to on this hardware.  Layers the bf16 kernels do not
+        cover (cosine attention, batch-norm layers, pre-norm) keep running in fp32."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError(precision)
+        self.precision = precision
+        return self
+
+    def run_blocks(self, feats, pos, plans, masks=None, pos_lookup=None):
         x = self.linear0(feats) if hasattr(self, 'linear0') else feats
+        if self.precision == 'bf16' and pos_lookup is not None and x.is_cuda and x.dtype == torch.float32:
+            from . import bf16
+            layers = [enc for block in self.block_list for enc in block.encoder_list]
+            if all(bf16.layer_supported(enc, plans[i % 2], x.size(0)) for i, enc in enumerate(layers)):
+                return bf16.run_encoder_stack(self.block_list, x, plans, pos_lookup)
         for i, block in enumerate(self.block_list):
             x = block(x, pos, plans, masks, using_checkpoint=i in self.checkpoint_blocks)
         return x
@@ -173,7 +189,10 @@ class SSTv2(_WindowTransformer):
         coors = voxel_info['voxel_coors']
         assert coors.dtype == torch.int64, 'data type of coors should be torch.int64!'
         plans, pos, masks = self._window_inputs(voxel_info)
-        feats = self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks)
+        lookup = None
+        if 'pos_table' in voxel_info and 'pos_index_shift0' in voxel_info:   # (table, row index) per partition
+            lookup = [(voxel_info['pos_table'], voxel_info[f'pos_index_shift{i}']) for i in range(2)]
+        feats = self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks, pos_lookup=lookup)
         if not self.to_bev:
             assert self.num_attached_conv <= 0, 'the attached convolutions need the BEV canvas'
             return [{'voxel_feats': feats, 'voxel_coors': coors}]

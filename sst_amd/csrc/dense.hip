@@ -308,6 +308,183 @@ __global__ __launch_bounds__(256) void colsum_partials2d_k(const float* __restri
   }
 }
 
+
+// ---- bf16 storage variants (the reduced-precision mode of the encoder layers; statistics and arithmetic in fp32) ------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 bf4_load(const unsigned short* __restrict__ p) {
+  const u32x2_t v = *(const u32x2_t*)p;
+  return make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                     __uint_as_float(v[1] & 0xffff0000u));
+}
+__device__ __forceinline__ void bf4_store(unsigned short* __restrict__ p, float4 v) {
+  unsigned lo, hi;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v.x), "v"(v.y));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v.z), "v"(v.w));
+  const u32x2_t o = {lo, hi};
+  *(u32x2_t*)p = o;
+}
+
+// y = LN(x + r) * w + b (bf16 in / out, fp32 parameters and statistics); sum_out (bf16, optional) = x + r for the
+// backward pass; yp (bf16, optional) = y + pos_table[pos_idx[row]]: the next layer's q / k input (x + positional
+// embedding, sst_basic_block_v2.py:58-60), so that no separate add pass and no [M, C] positional tensor exist.
+__global__ __launch_bounds__(kLnThreads) void add_ln_fwd_bf16_k(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ r, const float* __restrict__ w,
+    const float* __restrict__ b, int64_t m, int c, float eps, unsigned short* __restrict__ y,
+    unsigned short* __restrict__ sum_out, float2* __restrict__ stats, const float* __restrict__ pos_table,
+    const int32_t* __restrict__ pos_idx, unsigned short* __restrict__ yp) {
+  const int lane = threadIdx.x & 31;
+  const int sub = threadIdx.x >> 5;
+  const int nvec = (c + 127) / 128;
+  for (int64_t row = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row < m; row += (int64_t)gridDim.x * kLnRowsPerBlock) {
+    float4 v[kLnMaxVec];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < nvec && col < c) {
+        v[k] = bf4_load(x + row * c + col);
+        if (r != nullptr) {
+          const float4 rv = bf4_load(r + row * c + col);
+          v[k].x += rv.x, v[k].y += rv.y, v[k].z += rv.z, v[k].w += rv.w;
+        }
+        if (sum_out != nullptr) bf4_store(sum_out + row * c + col, v[k]);
+        s += v[k].x + v[k].y + v[k].z + v[k].w;
+      }
+    }
+    const float mean = group32_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      if (k < nvec && col < c) {
+        const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+        q += dx * dx + dy * dy + dz * dz + dw * dw;
+      }
+    }
+    const float rstd = rsqrtf(group32_sum(q) / (float)c + eps);
+    const float* prow = (pos_table != nullptr) ? pos_table + (int64_t)pos_idx[row] * c : nullptr;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      if (k < nvec && col < c) {
+        const float4 wv = *(const float4*)(w + col);
+        const float4 bv = *(const float4*)(b + col);
+        float4 o;
+        o.x = (v[k].x - mean) * rstd * wv.x + bv.x;
+        o.y = (v[k].y - mean) * rstd * wv.y + bv.y;
+        o.z = (v[k].z - mean) * rstd * wv.z + bv.z;
+        o.w = (v[k].w - mean) * rstd * wv.w + bv.w;
+        bf4_store(y + row * c + col, o);
+        if (prow != nullptr) {
+          const float4 pv = *(const float4*)(prow + col);
+          bf4_store(yp + row * c + col, make_float4(o.x + pv.x, o.y + pv.y, o.z + pv.z, o.w + pv.w));
+        }
+      }
+    }
+    if (lane == 0) stats[row] = make_float2(mean, rstd);
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = (dy [+ dy2]) * w; block partials of dw / db as in the fp32 kernel
+__global__ __launch_bounds__(kLnThreads) void add_ln_bwd_bf16_k(const unsigned short* __restrict__ dy,
+                                                                const unsigned short* __restrict__ dy2,
+                                                                const unsigned short* __restrict__ s,
+                                                                const float2* __restrict__ stats,
+                                                                const float* __restrict__ w, int64_t m, int c,
+                                                                unsigned short* __restrict__ dx,
+                                                                float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [2][c]
+  for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) part[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 31;
+  const int sub = threadIdx.x >> 5;
+  const int nvec = (c + 127) / 128;
+  float4 aw[kLnMaxVec], ab[kLnMaxVec];
+#pragma unroll
+  for (int k = 0; k < kLnMaxVec; ++k) aw[k] = ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t row = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row < m; row += (int64_t)gridDim.x * kLnRowsPerBlock) {
+    const float2 st = stats[row];
+    float4 g[kLnMaxVec], xh[kLnMaxVec];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      g[k] = xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < nvec && col < c) {
+        float4 d = bf4_load(dy + row * c + col);
+        if (dy2 != nullptr) {
+          const float4 d2 = bf4_load(dy2 + row * c + col);
+          d.x += d2.x, d.y += d2.y, d.z += d2.z, d.w += d2.w;
+        }
+        const float4 sv = bf4_load(s + row * c + col);
+        const float4 wv = *(const float4*)(w + col);
+        xh[k] = make_float4((sv.x - st.x) * st.y, (sv.y - st.x) * st.y, (sv.z - st.x) * st.y, (sv.w - st.x) * st.y);
+        g[k] = make_float4(d.x * wv.x, d.y * wv.y, d.z * wv.z, d.w * wv.w);
+        sg += g[k].x + g[k].y + g[k].z + g[k].w;
+        sgx += g[k].x * xh[k].x + g[k].y * xh[k].y + g[k].z * xh[k].z + g[k].w * xh[k].w;
+        aw[k].x += d.x * xh[k].x, aw[k].y += d.y * xh[k].y, aw[k].z += d.z * xh[k].z, aw[k].w += d.w * xh[k].w;
+        ab[k].x += d.x, ab[k].y += d.y, ab[k].z += d.z, ab[k].w += d.w;
+      }
+    }
+    const float mg = group32_sum(sg) / (float)c;
+    const float mgx = group32_sum(sgx) / (float)c;
+#pragma unroll
+    for (int k = 0; k < kLnMaxVec; ++k) {
+      const int col = k * 128 + lane * 4;
+      if (k < nvec && col < c) {
+        float4 o;
+        o.x = st.y * (g[k].x - mg - xh[k].x * mgx);
+        o.y = st.y * (g[k].y - mg - xh[k].y * mgx);
+        o.z = st.y * (g[k].z - mg - xh[k].z * mgx);
+        o.w = st.y * (g[k].w - mg - xh[k].w * mgx);
+        bf4_store(dx + row * c + col, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kLnMaxVec; ++k) {
+    const int col = k * 128 + lane * 4;
+    if (k < nvec && col < c) {
+      atomicAdd(&part[col + 0], aw[k].x);
+      atomicAdd(&part[col + 1], aw[k].y);
+      atomicAdd(&part[col + 2], aw[k].z);
+      atomicAdd(&part[col + 3], aw[k].w);
+      atomicAdd(&part[c + col + 0], ab[k].x);
+      atomicAdd(&part[c + col + 1], ab[k].y);
+      atomicAdd(&part[c + col + 2], ab[k].z);
+      atomicAdd(&part[c + col + 3], ab[k].w);
+    }
+  }
+  __syncthreads();
+  float* dst = partials + (int64_t)blockIdx.x * 2 * c;
+  for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
+}
+
+// out (bf16) = x (fp32 or bf16) [+ pos_table[pos_idx[row]]]: the entry of the bf16 encoder stack
+template <typename T>
+__global__ __launch_bounds__(256) void cast_add_pos_bf16_k(const T* __restrict__ x, int64_t m, int c,
+                                                           const float* __restrict__ pos_table,
+                                                           const int32_t* __restrict__ pos_idx,
+                                                           unsigned short* __restrict__ out) {
+  const int c4 = c >> 2;
+  const int64_t total = m * c4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / c4;
+    const int col = (int)(e - row * c4) * 4;
+    float4 v;
+    if (sizeof(T) == 4)
+      v = *(const float4*)((const float*)x + row * c + col);
+    else
+      v = bf4_load((const unsigned short*)x + row * c + col);
+    if (pos_table != nullptr) {
+      const float4 pv = *(const float4*)(pos_table + (int64_t)pos_idx[row] * c + col);
+      v.x += pv.x, v.y += pv.y, v.z += pv.z, v.w += pv.w;
+    }
+    bf4_store(out + row * c + col, v);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -352,6 +529,62 @@ int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float
                        (const float2*)d_stats, d_weight, m, c, d_dx, partials);
   hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
                      d_dbias, c);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_add_layernorm_fwd_bf16(const void* d_x, const void* d_res, const float* d_weight, const float* d_bias, int64_t m,
+                               int c, float eps, void* d_y, void* d_sum, float* d_stats, const float* d_pos_table,
+                               const int32_t* d_pos_idx, void* d_y_plus_pos, void* stream) {
+  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_weight || !d_bias || !d_y || !d_stats) return SST_ERR_ARG;
+  if ((d_pos_table != nullptr) != (d_pos_idx != nullptr) || (d_pos_table != nullptr) != (d_y_plus_pos != nullptr))
+    return SST_ERR_ARG;
+  hipLaunchKernelGGL(add_ln_fwd_bf16_k, dim3(sst_grid_1d(m, kLnRowsPerBlock)), dim3(kLnThreads), 0, (hipStream_t)stream,
+                     (const unsigned short*)d_x, (const unsigned short*)d_res, d_weight, d_bias, m, c, eps,
+                     (unsigned short*)d_y, (unsigned short*)d_sum, (float2*)d_stats, d_pos_table, d_pos_idx,
+                     (unsigned short*)d_y_plus_pos);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_add_layernorm_bwd_bf16(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
+                               const float* d_weight, int64_t m, int c, void* d_dx, float* d_dweight, float* d_dbias,
+                               void* d_workspace, void* stream) {
+  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (!d_dweight || !d_dbias) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (m == 0) {
+    SST_HIP(hipMemsetAsync(d_dweight, 0, sizeof(float) * c, st));
+    SST_HIP(hipMemsetAsync(d_dbias, 0, sizeof(float) * c, st));
+    return SST_OK;
+  }
+  if (!d_dy || !d_sum || !d_stats || !d_weight || !d_dx || !d_workspace) return SST_ERR_ARG;
+  int grid = (int)sst_div_up(m, kLnRowsPerBlock * 4);
+  if (grid > 1024) grid = 1024;
+  float* partials = (float*)d_workspace;
+  hipLaunchKernelGGL(add_ln_bwd_bf16_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st,
+                     (const unsigned short*)d_dy, (const unsigned short*)d_dy2, (const unsigned short*)d_sum,
+                     (const float2*)d_stats, d_weight, m, c, (unsigned short*)d_dx, partials);
+  hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
+                     d_dbias, c);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_cast_add_pos_bf16(const void* d_x, int x_is_bf16, int64_t m, int c, const float* d_pos_table,
+                          const int32_t* d_pos_idx, void* d_out, void* stream) {
+  if (m < 0 || c < 4 || (c & 3)) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_out || ((d_pos_table != nullptr) != (d_pos_idx != nullptr))) return SST_ERR_ARG;
+  const int grid = sst_grid_1d(m * (c >> 2), 256);
+  if (x_is_bf16)
+    hipLaunchKernelGGL(cast_add_pos_bf16_k<unsigned short>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)d_x, m, c, d_pos_table, d_pos_idx, (unsigned short*)d_out);
+  else
+    hipLaunchKernelGGL(cast_add_pos_bf16_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)d_x, m, c,
+                       d_pos_table, d_pos_idx, (unsigned short*)d_out);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

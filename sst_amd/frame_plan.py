@@ -23,6 +23,7 @@ class FramePlan(object):
 
     def __init__(self):
         self.info = None
+        self.want_pos_rows = True   # materialise the [M, C] positional tensors (the fp32 encoder layers add them to x)
 
     # -- the interface DynamicVFE.forward uses of a scatter plan ------------------------------------------------
     def reduce(self, feats, mode):
@@ -56,7 +57,10 @@ class FramePlan(object):
         for i in range(2):
             info[f'sra_plan_shift{i}'] = K.WindowPlan(toks[i], winoffs[i], n_win[i], m_keep,
                                                       min(cap, max(1, t_max[i])))
-            info[f'pos_embed_shift{i}'] = K.gather_rows(table, (self.posidx0, self.posidx1)[i][:m_keep])
+            info[f'pos_index_shift{i}'] = (self.posidx0, self.posidx1)[i][:m_keep]
+            info[f'pos_embed_shift{i}'] = K.gather_rows(table, info[f'pos_index_shift{i}']) if self.want_pos_rows else None
+        info['pos_table'] = table
+        info['batch_size'] = self.batch_size
         self.info = info
         return info
 
@@ -106,6 +110,7 @@ class FramePlanner(object):
         gz, gy, gx = self.grid_zyx
         plan = FramePlan()
         plan.points, plan.coors, plan.n_points = points, coors, n
+        plan.batch_size = bsz
         # 1. sorted-unique voxel keys of the points (count stays on the device)
         groups = K.unique_rows(coors, [0, -1, -1, -1], [bsz, gz + 1, gy + 1, gx + 1], invalid_if_negative=2,
                                defer_count=True)

@@ -212,6 +212,9 @@ class SSTInputLayerV2(nn.Module):
                 voxel_info[f'voxel_drop_level_shift{i}'] = lv
             voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep, win_max[i])
             voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], feat_dim, dtype)
+            voxel_info[f'pos_index_shift{i}'] = self.pos_table_index(ciws[i])
+        voxel_info['pos_table'] = self.pos_table_cached(feat_dim, dtype, voxel_coors.device)
+        voxel_info['batch_size'] = int(batch_size)
 
         if self.debug:
             for i in range(2):
@@ -306,9 +309,13 @@ class SSTInputLayerV2(nn.Module):
         """[M, feat_dim] positional embedding of every voxel (flat layout)."""
         wx, wy, _ = self._window_shape3()
         table = self.pos_table_cached(feat_dim, dtype, coors_in_win.device)
-        c = coors_in_win.long()
-        idx = (c[:, 0] * wy + c[:, 1]) * wx + c[:, 2]
-        return table.index_select(0, idx)
+        return table.index_select(0, self.pos_table_index(coors_in_win).long())
+
+    def pos_table_index(self, coors_in_win):
+        """row of pos_table for in-window coordinates (z, y, x): (z * wy + y) * wx + x, int32"""
+        wx, wy, _ = self._window_shape3()
+        c = coors_in_win
+        return ((c[:, 0] * wy + c[:, 1]) * wx + c[:, 2]).to(torch.int32)
 
     @torch.no_grad()
     def get_pos_embed(self, inds_dict, coors_in_win, feat_dim, dtype):

@@ -172,6 +172,46 @@ def gen_sst_block(ref, only=None):
         save(f'sst_block_{tag}.npz', **arrays)
 
 
+def gen_sst_block_bf16(ref):
+    """The 'std' block (d = 128, 8 heads, FFN 256; one BasicShiftBlockV2 = 2 encoder layers) through the reference
+    SSTv2 under torch.autocast(bfloat16) on CPU: linear layers and matrix products in bf16, softmax / LayerNorm /
+    residual stream in fp32 (torch's autocast policy) - the pin of the reduced-precision mode (sst_amd/bf16.py)."""
+    layer = ref.input_layer_v2.SSTInputLayerV2(drop_info=(DROP_TRAIN, DROP_TEST), window_shape=(12, 12, 1),
+                                               sparse_shape=(468, 468, 1), shuffle_voxels=False, debug=True,
+                                               mute=True)
+    layer.eval()
+    g = torch.Generator().manual_seed(2)
+    coors = make_voxel_coors(g, 170, 2, crowded=True)
+    m = coors.size(0)
+    torch.manual_seed(3)
+    net = ref.sst_v2.SSTv2(d_model=[128], nhead=[8], num_blocks=1, dim_feedforward=[256], output_shape=[468, 468],
+                           num_attached_conv=0, to_bev=False, debug=True)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn(p_.shape, generator=g) * 0.1)
+    net.train()
+    feats = torch.randn(m, 128, generator=g).requires_grad_(True)
+    info = layer(feats, coors.int(), 2)
+    with torch.autocast(device_type='cpu', dtype=torch.bfloat16):
+        out_feats = net(info)[0]['voxel_feats']
+    out_feats = out_feats.float()
+    gout = torch.randn(out_feats.shape, generator=g)
+    (out_feats * gout).sum().backward()
+    # the same network in fp32, for the size of the precision effect itself
+    feats32 = feats.detach().clone().requires_grad_(True)
+    out32 = net(layer(feats32, coors.int(), 2))[0]['voxel_feats']
+    arrays = {'in::voxel_coors': t2n(coors).astype(np.int32), 'in::voxel_feats': t2n(feats), 'in::grad_out': t2n(gout),
+              'out::voxel_feats': t2n(out_feats), 'out::grad_in': t2n(feats.grad), 'out::voxel_feats_fp32': t2n(out32)}
+    arrays.update(state_to_np(net.state_dict()))
+    for n_, p_ in net.named_parameters():
+        if 'encoder_list.0.win_attn.self_attn.in_proj' in n_ or 'encoder_list.1.linear1.weight' in n_ \
+                or 'encoder_list.1.norm2' in n_:
+            arrays['grad::' + n_] = t2n(p_.grad)
+    print('bf16 block: voxels', m, 'autocast vs fp32 max abs', float((out_feats - out32).abs().max()))
+    save('sst_block_bf16.npz', **arrays)
+
+
 def gen_sst_bev(ref):
     """The output side of SSTv2 (a14): recover_bev + attached dilated convolutions + BN2d + ReLU (sst_v2.py:86-92,
     139-197), with a 48 x 48 canvas so that the dense output stays a small fixture; also with conv_shortcut."""
@@ -551,10 +591,14 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == 'sst_block':     # regenerate single block variants only
         gen_sst_block(ref, only=sys.argv[2:])
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'sst_block_bf16':
+        gen_sst_block_bf16(ref)
+        return
     gen_voxelize()
     gen_hard_voxelize()
     gen_input_layer(ref)
     gen_sst_block(ref)
+    gen_sst_block_bf16(ref)
     gen_sst_bev(ref)
     gen_sst_v1(ref)
     gen_dynamic_vfe(ref)

@@ -1,0 +1,153 @@
+"""GPU: the reduced-precision (bf16) mode - attention core, LayerNorm kernels, encoder layers.
+
+Pins: the float64 oracle on bf16-rounded inputs for the kernels; for the block, tensors produced by the reference's own
+SSTv2 under torch.autocast(bfloat16) on CPU (tests/golden/sst_block_bf16.npz, made by tests/golden/make_golden.py).
+Tolerances are stated at bf16 resolution: a bf16 value carries 8 significant bits, so a stored activation of magnitude
+~4 is itself only known to +-0.016; the reference's autocast run differs from its own fp32 run by 2.0e-2 (max abs) on
+this block."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import DROP_TEST, DROP_TRAIN, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+BF = torch.bfloat16
+
+
+def _plan_from_sizes(sizes, seed):
+    from sst_amd import kernels as K
+    rng = np.random.default_rng(seed)
+    m = int(sum(sizes))
+    tok = rng.permutation(m).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    plan = K.WindowPlan(torch.from_numpy(tok).to(DEV), torch.from_numpy(off).to(DEV), len(sizes), m, max(sizes))
+    return plan, tok, off, m
+
+
+@pytest.mark.parametrize('heads', [8, 12])
+@pytest.mark.parametrize('sizes', [[1, 2, 3, 15, 16, 17], [30, 31, 33, 47, 48, 49, 60, 63, 64, 65, 79, 80, 81],
+                                   [96, 100, 111, 112, 113, 128, 143, 144], [1, 144, 7, 100, 64, 30, 16, 59, 81, 12, 5]])
+def test_sra_core_bf16_vs_oracle(sizes, heads):
+    from sst_amd import bf16
+    from oracle import sst_oracle
+    plan, tok, off, m = _plan_from_sizes(sizes, len(sizes) + heads)
+    c = heads * 16
+    g = torch.Generator().manual_seed(m + heads)
+    q, k, v, do = ((torch.randn(m, c, generator=g) * s).to(BF) for s in (1.5, 1.5, 1.0, 1.0))
+    qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    o = bf16.sra_attention(qg, kg, vg, plan, heads)
+    assert o.dtype == BF
+    f = lambda t: t.float().numpy()
+    ref = sst_oracle.sra_core(f(q), f(k), f(v), tok, off, heads)
+    err = np.abs(o.detach().float().cpu().numpy() - ref).max()
+    assert err < 2e-2, f'forward max abs err {err}'          # |o| <= max |v| ~ 4: bf16 output rounding alone is 1.6e-2
+    (o.float() * do.to(DEV).float()).sum().backward()
+    rdq, rdk, rdv = sst_oracle.sra_core_backward(f(q), f(k), f(v), f(do), tok, off, heads)
+    for name, got, want in (('dq', qg.grad, rdq), ('dk', kg.grad, rdk), ('dv', vg.grad, rdv)):
+        e = np.abs(got.float().cpu().numpy() - want).max()
+        assert e < 3e-2 * max(1.0, np.abs(want).max()), f'{name} max abs err {e} (scale {np.abs(want).max()})'
+
+
+def test_sra_core_bf16_full_size_against_fp32_kernels():
+    """M ~ 90k tokens: bf16 kernels against the fp32 kernels on the same (bf16-representable) inputs."""
+    from sst_amd import bf16, kernels as K
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(20, 101, size=1500).tolist()
+    plan, tok, off, m = _plan_from_sizes(sizes, 5)
+    g = torch.Generator().manual_seed(6)
+    q, k, v, do = (torch.randn(m, 128, generator=g).to(BF) for _ in range(4))
+    qa, ka, va = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    oa = bf16.sra_attention(qa, ka, va, plan, 8)
+    (oa.float() * do.to(DEV).float()).sum().backward()
+    qb, kb, vb = (t.float().to(DEV).requires_grad_(True) for t in (q, k, v))
+    ob = K.sra_attention(qb, kb, vb, plan, 8)
+    (ob * do.to(DEV).float()).sum().backward()
+    assert float((oa.float() - ob).abs().max()) < 2e-2
+    for a, b in ((qa, qb), (ka, kb), (va, vb)):
+        scale = max(1.0, float(b.grad.abs().max()))
+        assert float((a.grad.float() - b.grad).abs().max()) < 3e-2 * scale
+        assert float((a.grad.float() - b.grad).abs().mean()) < 3e-3 * scale
+
+
+@pytest.mark.parametrize('m,c', [(1, 128), (77, 128), (5000, 192), (90107, 128)])
+def test_layernorm_bf16_kernels(m, c):
+    from sst_amd import bf16
+    g = torch.Generator().manual_seed(m + c)
+    x, r, dy, dy2 = (torch.randn(m, c, generator=g).to(BF).to(DEV) for _ in range(4))
+    w = (1 + 0.1 * torch.randn(c, generator=g)).to(DEV)
+    b = (0.1 * torch.randn(c, generator=g)).to(DEV)
+    table = torch.randn(144, c, generator=g).to(DEV)
+    idx = torch.randint(0, 144, (m,), generator=g).to(torch.int32).to(DEV)
+    y, s, stats, yp = bf16.add_ln_fwd(x, r, w, b, 1e-5, pos=(table, idx))
+    xs = (x.float() + r.float()).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xs, (c,), w, b, 1e-5)
+    assert float((y.float() - ref).abs().max()) < 3e-2 and float((y.float() - ref).abs().mean()) < 3e-3
+    assert float((yp.float() - (ref + table[idx.long()])).abs().max()) < 5e-2
+    assert float((s.float() - xs).abs().max()) < 3e-2
+    dx, dw, db = bf16.add_ln_bwd(dy, dy2, s, stats, w)
+    gsum = dy.float() + dy2.float()
+    # reference gradient on the SAME rounded sum the kernel saw
+    xs2 = s.float().requires_grad_(True)
+    w2 = w.clone().requires_grad_(True)
+    b2 = b.clone().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xs2, (c,), w2, b2, 1e-5) * gsum).sum().backward()
+    assert float((dx.float() - xs2.grad).abs().max()) < 3e-2 * max(1.0, float(xs2.grad.abs().max()))
+    assert float((dw - w2.grad).abs().max()) < 2e-3 * max(1.0, float(w2.grad.abs().max()))
+    assert float((db - b2.grad).abs().max()) < 2e-3 * max(1.0, float(b2.grad.abs().max()))
+    out = bf16.cast_add_pos(x.float(), (table, idx))
+    assert float((out.float() - (x.float() + table[idx.long()])).abs().max()) < 3e-2
+
+
+def test_sst_block_bf16_matches_reference_autocast_golden():
+    import sst_amd
+    g = load_golden('sst_block_bf16.npz')
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128], nhead=[8], num_blocks=1, dim_feedforward=[256],
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=True))
+    net.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}, strict=True)
+    net = net.to(DEV).train().set_precision('bf16')
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
+                                    debug=True, mute=True, reference_outputs=False)
+    layer.eval()
+    feats = torch.from_numpy(g['in::voxel_feats']).to(DEV).requires_grad_(True)
+    info = layer(feats, torch.from_numpy(g['in::voxel_coors']).to(DEV), 2)
+    out = net(info)[0]['voxel_feats']
+    assert out.dtype == torch.float32
+    d = np.abs(out.detach().cpu().numpy() - g['out::voxel_feats'])
+    ref_gap = np.abs(g['out::voxel_feats'] - g['out::voxel_feats_fp32']).max()   # autocast vs fp32 in the reference
+    assert d.max() < 6e-2 and d.mean() < 8e-3, (d.max(), d.mean(), ref_gap)
+    d32 = np.abs(out.detach().cpu().numpy() - g['out::voxel_feats_fp32'])
+    assert d32.max() < 6e-2 and d32.mean() < 8e-3
+    (out * torch.from_numpy(g['in::grad_out']).to(DEV)).sum().backward()
+    scale = max(1.0, float(np.abs(g['out::grad_in']).max()))
+    e = np.abs(feats.grad.cpu().numpy() - g['out::grad_in'])
+    assert e.max() < 8e-2 * scale and e.mean() < 8e-3 * scale, (e.max(), e.mean())
+    params = dict(net.named_parameters())
+    for key in [k for k in g if k.startswith('grad::')]:
+        got = params[key[6:]].grad
+        assert got.dtype == torch.float32
+        sc = max(1.0, float(np.abs(g[key]).max()))
+        assert np.abs(got.cpu().numpy() - g[key]).max() < 5e-2 * sc, key
+
+
+def test_bf16_mode_leaves_unsupported_layers_in_fp32():
+    """cosine attention / batch-norm layers are not covered by the bf16 kernels: set_precision('bf16') must then give
+    the fp32 result bit for bit"""
+    import sst_amd
+    g = load_golden('sst_block_cosine.npz')
+    d, h, ffn = int(g['cfg::d_model']), int(g['cfg::nhead']), int(g['cfg::ffn'])
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[d], nhead=[h], num_blocks=1, dim_feedforward=[ffn],
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=True,
+                                      layer_cfg=dict(cosine=True, tau_min=0.01)))
+    net.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}, strict=True)
+    net = net.to(DEV).train()
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
+                                    debug=True, mute=True, reference_outputs=False)
+    layer.eval()
+    feats = torch.from_numpy(g['in::voxel_feats']).to(DEV)
+    coors = torch.from_numpy(g['in::voxel_coors']).to(DEV)
+    with torch.no_grad():
+        a = net(layer(feats, coors, 2))[0]['voxel_feats']
+        b = net.set_precision('bf16')(layer(feats, coors, 2))[0]['voxel_feats']
+    assert torch.equal(a, b)
