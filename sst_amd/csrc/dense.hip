@@ -317,11 +317,10 @@ __device__ __forceinline__ float4 bf4_load(const unsigned short* __restrict__ p)
                      __uint_as_float(v[1] & 0xffff0000u));
 }
 __device__ __forceinline__ void bf4_store(unsigned short* __restrict__ p, float4 v) {
-  unsigned lo, hi;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v.x), "v"(v.y));
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v.z), "v"(v.w));
-  const u32x2_t o = {lo, hi};
-  *(u32x2_t*)p = o;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t f = {v.x, v.y, v.z, v.w};
+  *(u32x2_t*)p = __builtin_bit_cast(u32x2_t, __builtin_convertvector(f, bf16x4_t));  // two v_cvt_pk_bf16_f32 (RNE)
 }
 
 // y = LN(x + r) * w + b (bf16 in / out, fp32 parameters and statistics); sum_out (bf16, optional) = x + r for the

@@ -37,10 +37,14 @@ constexpr float kLn2 = 0.6931471805599453f;
 #define SST_SRA_BLOCK(b, n) ((int)(n) - 1 - (int)(b))  // largest windows first (region batching lists them last)
 
 __device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {  // round-to-nearest-even pair
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// round-to-nearest-even pair: the conversion compiles to ONE v_cvt_pk_bf16_f32.  It must be the compiler's own
+// instruction, not inline asm: an MFMA that reads a register written by the VALU two instructions earlier needs wait
+// states on gfx950, and the hazard pass cannot see inside an asm statement (measured: stale operands, NaN).
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 __device__ __forceinline__ s16x4 pack4(float a, float b, float c, float d) {
   u32x2 p = {pack2(a, b), pack2(c, d)};
