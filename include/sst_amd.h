@@ -327,6 +327,33 @@ int sst_cast_add_pos_bf16(const void* d_x, int x_is_bf16, int64_t m, int c, cons
                           const int32_t* d_pos_idx, void* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense products of the reduced-precision encoder layer (csrc/dense_bf16.hip): bf16 operands, fp32 accumulation.
+ * Replace F.linear / nn.MultiheadAttention's in_proj / out_proj and linear1 - activation - linear2 of
+ * mmdet3d/models/sst/sst_basic_block_v2.py:41-75, 104-126 (forward and autograd's data / weight gradients).
+ *   sst_tall_linear_bf16: y[m, n] (bf16) = epilogue(x[m, k] w[n, k]^T + bias);  (k, n) in {(128,128), (128,256), (256,128)};
+ *     w bf16 row-major [n][k] contiguous, bias fp32 or NULL.  epilogue: 0 = bias; 1 / 2 = GELU(erf) / ReLU, the bf16
+ *     pre-activation also written to d_aux_out (may be NULL); 3 / 4 = multiply by GELU' / ReLU' of d_aux_in (the stored
+ *     pre-activation): the data gradient through the activation; 5 = add the bf16 [m, n] tensor d_aux_in (a residual
+ *     branch's gradient).  ldaux = row stride of d_aux_in / d_aux_out (elements).
+ *   sst_wgrad_group_bf16: for every problem, out_w[p][128] (fp32) = a[m, p]^T b[m, 128] with p = 128 or 256
+ *     (transpose_out: out_w[128][p] instead - the operands of a [128][256] weight swapped), and out_b = column sums of a
+ *     (bias_side 1, p values) or of b (bias_side 2, 128 values).  All problems (<= 8) run in ONE launch + one reduction.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_tall_linear_bf16(const void* d_x, int64_t ldx, const void* d_w, const float* d_bias, int64_t m, int k, int n,
+                         int epilogue, const void* d_aux_in, void* d_aux_out, int64_t ldaux, void* d_y, int64_t ldy,
+                         void* stream);
+typedef struct sst_wgrad_problem_bf16 {
+  const void* a;   /* bf16 [m, p], row stride lda */
+  const void* b;   /* bf16 [m, 128], row stride ldb */
+  int64_t lda, ldb, m;
+  float* out_w;    /* device, fp32 [p][128] (or [128][p]) contiguous */
+  float* out_b;    /* device, fp32, or NULL */
+  int32_t p, bias_side, transpose_out, reserved;
+} sst_wgrad_problem_bf16;
+int64_t sst_wgrad_group_workspace_bytes(const sst_wgrad_problem_bf16* problems, int n);
+int sst_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (a10/a14) row gather / scatter used by flat2window / window2flat / recover_bev.
  *   gather:  d_out[i, :] = idx[i] >= 0 ? d_src[idx[i], :] : fill
  *   scatter: d_out[idx[i], :] = d_src[i, :]      (idx unique; rows with idx < 0 skipped)

@@ -21,6 +21,15 @@ c_i32 = ctypes.c_int
 c_f32 = ctypes.c_float
 c_ptr = ctypes.c_void_p
 
+
+
+class WgradProblemBF16(ctypes.Structure):
+    """sst_wgrad_problem_bf16 of include/sst_amd.h"""
+    _fields_ = [('a', c_ptr), ('b', c_ptr), ('lda', c_i64), ('ldb', c_i64), ('m', c_i64), ('out_w', c_ptr),
+                ('out_b', c_ptr), ('p', ctypes.c_int32), ('bias_side', ctypes.c_int32),
+                ('transpose_out', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/sst_amd.h one to one
 _SIGNATURES = {
     'sst_version': (ctypes.c_char_p, []),
@@ -64,6 +73,10 @@ _SIGNATURES = {
     'sst_add_layernorm_bwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_ptr]),
     'sst_cast_add_pos_bf16': (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_tall_linear_bf16': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr,
+                                     c_i64, c_ptr]),
+    'sst_wgrad_group_workspace_bytes': (c_i64, [c_ptr, c_i32]),
+    'sst_wgrad_group_bf16': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
     'sst_gather_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_i64, c_ptr]),
     'sst_scatter_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_add_layernorm_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr,

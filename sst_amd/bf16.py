@@ -150,19 +150,61 @@ def cast_add_pos(x, pos=None):
     return out
 
 
+EPI_BIAS, EPI_GELU, EPI_RELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_ADD = range(6)
+_LINEAR_SHAPES = ((128, 128), (128, 256), (256, 128))
+
+
+def tall_linear(x, w, bias=None, epilogue=EPI_BIAS, aux_in=None, want_pre=False):
+    """y (bf16 [M, N]) = epilogue(x (bf16 [M, K]) @ w (bf16 [N, K])^T + bias (fp32)); csrc/dense_bf16.hip.
+    epilogue GELU / RELU with want_pre: -> (y, pre-activation bf16); MUL_*_GRAD / ADD read ``aux_in`` (bf16 [M, N])."""
+    m, k = x.shape
+    n = w.size(0)
+    if (k, n) not in _LINEAR_SHAPES or w.size(1) != k or x.dtype != BF16 or w.dtype != BF16 or not w.is_contiguous():
+        raise RuntimeError(f'sst_amd.bf16.tall_linear: unsupported operands {tuple(x.shape)} x {tuple(w.shape)}')
+    y = torch.empty((m, n), dtype=BF16, device=x.device)
+    pre = torch.empty((m, n), dtype=BF16, device=x.device) if want_pre else None
+    aux = aux_in if aux_in is not None else pre
+    rc = _lib.load().sst_tall_linear_bf16(_lib.ptr(x), _ld(x), _lib.ptr(w), _lib.ptr(bias), m, k, n, int(epilogue),
+                                          _lib.ptr(aux_in), _lib.ptr(pre), _ld(aux) if aux is not None else 0,
+                                          _lib.ptr(y), n, _lib.stream_ptr())
+    _lib.check(rc, 'sst_tall_linear_bf16')
+    return (y, pre) if want_pre else y
+
+
+def wgrad_group(problems):
+    """Weight / bias gradients of several tall products in ONE launch (csrc/dense_bf16.hip).
+    problems: list of (a bf16 [M, P], b bf16 [M, 128], out_w fp32, out_b fp32 | None, bias_side, transpose_out);
+    out_w[P][128] = a^T b (or its transpose [128][P]); out_b = column sums of a (bias_side 1) or b (bias_side 2)."""
+    lib = _lib.load()
+    arr = (_lib.WgradProblemBF16 * len(problems))()
+    for q, (a, b, out_w, out_b, side, tr) in zip(arr, problems):
+        if a.dtype != BF16 or b.dtype != BF16 or b.size(1) != 128 or a.size(1) not in (128, 256) or a.size(0) != b.size(0):
+            raise RuntimeError('sst_amd.bf16.wgrad_group: operands must be bf16 [M, 128|256] and [M, 128]')
+        if out_w.dtype != torch.float32 or not out_w.is_contiguous() or out_w.numel() != a.size(1) * 128:
+            raise RuntimeError('sst_amd.bf16.wgrad_group: out_w must be a contiguous fp32 tensor of P x 128 values')
+        q.a, q.b, q.lda, q.ldb, q.m = a.data_ptr(), b.data_ptr(), _ld(a), _ld(b), a.size(0)
+        q.out_w, q.out_b = out_w.data_ptr(), (out_b.data_ptr() if out_b is not None else None)
+        q.p, q.bias_side, q.transpose_out = a.size(1), int(side if out_b is not None else 0), int(tr)
+    dev = problems[0][0].device
+    ws = _lib.workspace(lib.sst_wgrad_group_workspace_bytes(arr, len(problems)), dev)
+    _lib.check(lib.sst_wgrad_group_bf16(arr, len(problems), _lib.ptr(ws), _lib.stream_ptr()), 'sst_wgrad_group_bf16')
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # host pieces
 # ------------------------------------------------------------------------------------------------------------------
 _shadows = {}
 
 
-def shadow(p):
-    """bf16 copy of an fp32 parameter (or of a slice of one), re-made when the parameter changes"""
-    key = (p.data_ptr(), tuple(p.shape))
+def shadow(p, rows=None, transposed=False):
+    """bf16 copy of an fp32 parameter - of the row range ``rows`` = (lo, hi) of it, transposed if asked (the operand of
+    a data gradient) - re-made when the parameter's version counter moves"""
+    key = (p.data_ptr(), tuple(p.shape), rows, transposed)
     hit = _shadows.get(key)
     if hit is not None and hit[0] == p._version and hit[1].device == p.device:
         return hit[1]
-    s = p.detach().to(BF16).contiguous()
+    src = p.detach() if rows is None else p.detach()[rows[0]:rows[1]]
+    s = (src.t() if transposed else src).to(BF16).contiguous()
     _shadows[key] = (p._version, s)
     return s
 
@@ -201,22 +243,23 @@ class _CastIn(Function):
 class EncoderLayerBF16Fn(Function):
     """One post-norm SRA encoder layer (sst_basic_block_v2.py:104-119) in the reduced-precision mode, as one autograd node.
     Inputs x and xp = x + positional embedding (bf16); outputs the layer result and (when ``pos_next`` is given) the
-    result + the next layer's positional embedding."""
+    result + the next layer's positional embedding.  Kernel sequence, forward: 2 projections, attention core,
+    out-projection, add+LayerNorm, linear1+activation, linear2, add+LayerNorm (8 launches); backward: 2 LayerNorm, 5 data
+    gradients, attention core, ONE grouped weight-gradient launch + its reduction (10 launches)."""
 
     @staticmethod
     def forward(ctx, x, xp, plan, nhead, act, eps, pos_next, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b):
         c = x.size(1)
-        ws_in, bs_in = shadow(w_in), shadow(b_in)
-        qk = torch.addmm(bs_in[:2 * c], xp, ws_in[:2 * c].t())
-        v = torch.addmm(bs_in[2 * c:], x, ws_in[2 * c:].t())
+        # q | k from x + pos, v from x (sst_basic_block_v2.py:58-63); written side by side for the core
+        qk = tall_linear(xp, shadow(w_in, (0, 2 * c)), b_in[:2 * c])
+        v = tall_linear(x, shadow(w_in, (2 * c, 3 * c)), b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
         o, lse = sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale)
-        a = torch.addmm(shadow(b_out), o, shadow(w_out).t())
+        a = tall_linear(o, shadow(w_out), b_out)
         need_bwd = any(ctx.needs_input_grad)
         y1, s1, st1, _ = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
-        pre = torch.addmm(shadow(b1), y1, shadow(w1).t())
-        h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
-        f = torch.addmm(shadow(b2), h, shadow(w2).t())
+        h, pre = tall_linear(y1, shadow(w1), b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
+        f = tall_linear(h, shadow(w2), b2)
         y2, s2, st2, y2p = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd, pos=pos_next)
         if need_bwd:
             ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
@@ -229,23 +272,29 @@ class EncoderLayerBF16Fn(Function):
     def backward(ctx, dy2, dy2p=None):
         x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
         c = x.size(1)
+        dev = x.device
         ds2, dn2w, dn2b = add_ln_bwd(dy2, dy2p if ctx.two else None, s2, st2, n2w)   # = d(y1 residual) = d(f)
-        dw2, db2 = weight_grad(ds2, h), bias_grad(ds2)
-        dh = ds2 @ shadow(w2)
-        dpre = torch.ops.aten.gelu_backward(dh, pre) if ctx.act == 'gelu' else dh * (pre > 0).to(dh.dtype)
-        dw1, db1 = weight_grad(dpre, y1), bias_grad(dpre)
-        dy1 = torch.addmm(ds2, dpre, shadow(w1))                                      # residual + FFN branch
-        ds1, dn1w, dn1b = add_ln_bwd(dy1, None, s1, st1, n1w)                         # = d(x residual) = d(a)
-        dwo, dbo = weight_grad(ds1, o), bias_grad(ds1)
-        do = ds1 @ shadow(w_out)
-        dqkv = torch.empty((x.size(0), 3 * c), dtype=BF16, device=x.device)
+        dpre = tall_linear(ds2, shadow(w2, transposed=True), None,
+                           EPI_MUL_GELU_GRAD if ctx.act == 'gelu' else EPI_MUL_RELU_GRAD, aux_in=pre)
+        dy1 = tall_linear(dpre, shadow(w1, transposed=True), None, EPI_ADD, aux_in=ds2)   # residual + FFN branch
+        ds1, dn1w, dn1b = add_ln_bwd(dy1, None, s1, st1, n1w)                             # = d(x residual) = d(a)
+        do = tall_linear(ds1, shadow(w_out, transposed=True))
+        dqkv = torch.empty((x.size(0), 3 * c), dtype=BF16, device=dev)
         sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, dqkv[:, :c], dqkv[:, c:2 * c],
                 dqkv[:, 2 * c:])
-        dw_in = torch.cat([weight_grad(dqkv[:, :2 * c], xp), weight_grad(dqkv[:, 2 * c:], x)], dim=0)
-        db_in = bias_grad(dqkv)
-        ws_in = shadow(w_in)
-        dxp = dqkv[:, :2 * c] @ ws_in[:2 * c]
-        dx = torch.addmm(ds1, dqkv[:, 2 * c:], ws_in[2 * c:])
+        dxp = tall_linear(dqkv[:, :2 * c], shadow(w_in, (0, 2 * c), transposed=True))
+        dx = tall_linear(dqkv[:, 2 * c:], shadow(w_in, (2 * c, 3 * c), transposed=True), None, EPI_ADD, aux_in=ds1)
+        # every parameter gradient of the layer in one launch
+        f32 = dict(dtype=torch.float32, device=dev)
+        dw_in, db_in = torch.empty((3 * c, c), **f32), torch.empty(3 * c, **f32)
+        dwo, dbo = torch.empty((c, c), **f32), torch.empty(c, **f32)
+        dw1, db1 = torch.empty_like(w1, dtype=torch.float32), torch.empty(w1.size(0), **f32)
+        dw2, db2 = torch.empty_like(w2, dtype=torch.float32), torch.empty(w2.size(0), **f32)
+        wgrad_group([(dqkv[:, :2 * c], xp, dw_in[:2 * c], db_in[:2 * c], 1, 0),
+                     (dqkv[:, 2 * c:], x, dw_in[2 * c:], db_in[2 * c:], 1, 0),
+                     (ds1, o, dwo, dbo, 1, 0),
+                     (dpre, y1, dw1, db1, 1, 0),
+                     (h, ds2, dw2, db2, 2, 1)])     # dW2 [128][256] = ds2^T h: operands swapped, stored transposed
         return (dx, dxp, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b)
 
 
@@ -254,7 +303,8 @@ def layer_supported(enc, plan, m):
     return (enc.post_norm and not wa.cosine and isinstance(enc.norm1, torch.nn.LayerNorm)
             and isinstance(enc.norm2, torch.nn.LayerNorm) and enc.act_name in ('gelu', 'relu')
             and isinstance(plan, K.WindowPlan) and plan.n_tokens == m and plan.max_tokens <= 144
-            and wa.d_model % 32 == 0 and not (enc.training and (wa.attn_dropout > 0 or enc.dropout.p > 0)))
+            and wa.d_model == 128 and enc.linear1.out_features == 256      # the shapes csrc/dense_bf16.hip is built for
+            and not (enc.training and (wa.attn_dropout > 0 or enc.dropout.p > 0)))
 
 
 def run_encoder_stack(blocks, feats, plans, pos_specs):

@@ -100,6 +100,62 @@ def test_layernorm_bf16_kernels(m, c):
     assert float((out.float() - (x.float() + table[idx.long()])).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize('m', [1, 77, 5000, 90107])
+@pytest.mark.parametrize('k,n', [(128, 128), (128, 256), (256, 128)])
+def test_tall_linear_bf16(m, k, n):
+    """y = epilogue(x w^T + b) against fp32 torch on the same bf16-rounded operands; every epilogue"""
+    from sst_amd import bf16
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g).to(BF).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(BF).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    aux = torch.randn(m, n, generator=g).to(BF).to(DEV)
+    ref = x.float() @ w.float().t() + b
+    tol = lambda r: 1.6e-2 * max(1.0, float(r.abs().max()))          # one bf16 rounding of the output
+    y = bf16.tall_linear(x, w, b)
+    assert y.dtype == BF and float((y.float() - ref).abs().max()) < tol(ref)
+    y0 = bf16.tall_linear(x, w)                                       # no bias
+    assert float((y0.float() - (ref - b)).abs().max()) < tol(ref)
+    for epi, fn in ((bf16.EPI_GELU, torch.nn.functional.gelu), (bf16.EPI_RELU, torch.relu)):
+        y, pre = bf16.tall_linear(x, w, b, epi, want_pre=True)
+        assert float((pre.float() - ref).abs().max()) < tol(ref)
+        assert float((y.float() - fn(pre.float())).abs().max()) < 1.6e-2 * max(1.0, float(ref.abs().max()))
+    xg = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(xg).sum().backward()
+    y = bf16.tall_linear(x, w, None, bf16.EPI_MUL_GELU_GRAD, aux_in=aux)
+    want = (ref - b) * xg.grad
+    assert float((y.float() - want).abs().max()) < tol(want)
+    y = bf16.tall_linear(x, w, None, bf16.EPI_MUL_RELU_GRAD, aux_in=aux)
+    want = (ref - b) * (aux.float() > 0)
+    assert float((y.float() - want).abs().max()) < tol(want)
+    y = bf16.tall_linear(x, w, None, bf16.EPI_ADD, aux_in=aux)
+    want = (ref - b) + aux.float()
+    assert float((y.float() - want).abs().max()) < tol(want)
+
+
+@pytest.mark.parametrize('m', [1, 31, 4097, 90107])
+def test_wgrad_group_bf16(m):
+    """the five parameter-gradient products of one encoder layer in one launch, against fp64 on the same operands"""
+    from sst_amd import bf16
+    g = torch.Generator().manual_seed(m)
+    mk = lambda c: torch.randn(m, c, generator=g).to(BF).to(DEV)
+    dqkv, xp, x, ds1, o, dpre, y1, h, ds2 = mk(384), mk(128), mk(128), mk(128), mk(128), mk(256), mk(128), mk(256), mk(128)
+    f32 = dict(dtype=torch.float32, device=DEV)
+    dw_in, db_in = torch.full((384, 128), 7.0, **f32), torch.full((384,), 7.0, **f32)
+    dwo, dbo = torch.empty((128, 128), **f32), torch.empty(128, **f32)
+    dw1, db1 = torch.empty((256, 128), **f32), torch.empty(256, **f32)
+    dw2, db2 = torch.empty((128, 256), **f32), torch.empty(128, **f32)
+    bf16.wgrad_group([(dqkv[:, :256], xp, dw_in[:256], db_in[:256], 1, 0), (dqkv[:, 256:], x, dw_in[256:], db_in[256:], 1, 0),
+                      (ds1, o, dwo, dbo, 1, 0), (dpre, y1, dw1, db1, 1, 0), (h, ds2, dw2, db2, 2, 1)])
+    d = lambda t: t.double()
+    want = [(d(dqkv[:, :256]).t() @ d(xp), dw_in[:256]), (d(dqkv[:, 256:]).t() @ d(x), dw_in[256:]), (d(ds1).t() @ d(o), dwo),
+            (d(dpre).t() @ d(y1), dw1), (d(ds2).t() @ d(h), dw2), (d(dqkv).sum(0), db_in), (d(ds1).sum(0), dbo),
+            (d(dpre).sum(0), db1), (d(ds2).sum(0), db2)]
+    for ref, got in want:
+        # fp32 accumulation of m exact bf16 x bf16 products: error ~ sqrt(m) * 2^-24 * |term|
+        assert float((got.double() - ref).abs().max()) < 2e-5 * max(1.0, m ** 0.5) * 4
+
+
 def test_sst_block_bf16_matches_reference_autocast_golden():
     import sst_amd
     g = load_golden('sst_block_bf16.npz')

@@ -16,17 +16,20 @@ from sst_amd import kernels as K  # noqa: E402
 DEV = torch.device('cuda:0')
 
 
-def timeit(fn, iters=30, warmup=5):
+def timeit(fn, iters=30, warmup=5, reps=1):
+    """median / min ms per call; reps > 1 queues that many calls between the two events (kernels shorter than the
+    host's launch time are otherwise timed as launch gaps)"""
     for _ in range(warmup):
         fn()
     ts = []
     for _ in range(iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn()
+        for _ in range(reps):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / reps)
     return float(np.median(ts)), float(np.min(ts))
 
 
@@ -355,8 +358,47 @@ def bench_pointpool():
               f'({2 * n_rois * n_pts / med / 1e6:.1f} G pair tests/s over the two passes)')
 
 
+def bench_dense_bf16(m=90107):
+    """bf16 tall linears and the grouped weight gradient (csrc/dense_bf16.hip) against their algorithmic bytes, with
+    the library product (torch addmm / matmul on the same bf16 tensors) beside each"""
+    from sst_amd import bf16
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(0)
+    mk = lambda c: torch.randn(m, c, generator=g).to(BF).to(DEV)
+    for k, n in ((128, 128), (128, 256), (256, 128)):
+        x, aux = mk(k), mk(n)
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(BF).to(DEV)
+        b = torch.randn(n, generator=g).to(DEV)
+        bb = b.to(BF)
+        nbytes = m * (k + n) * 2
+        for name, fn, extra in (('bias', lambda: bf16.tall_linear(x, w, b), 0),
+                                ('gelu+pre', lambda: bf16.tall_linear(x, w, b, bf16.EPI_GELU, want_pre=True), m * n * 2),
+                                ('*gelu_grad', lambda: bf16.tall_linear(x, w, None, bf16.EPI_MUL_GELU_GRAD, aux_in=aux), m * n * 2),
+                                ('+add', lambda: bf16.tall_linear(x, w, None, bf16.EPI_ADD, aux_in=aux), m * n * 2),
+                                ('library addmm', lambda: torch.addmm(bb, x, w.t()), 0)):
+            med, mn = timeit(fn, iters=10, reps=20)
+            print(f'tall_linear_bf16 K={k} N={n} {name:14s}: {med * 1e3:7.1f} us (min {mn * 1e3:6.1f})  '
+                  f'{(nbytes + extra) / med / 1e6:7.1f} GB/s of {(nbytes + extra) / 1e6:.1f} MB')
+    dqkv, xp, x, ds1, o, dpre, y1, h, ds2 = mk(384), mk(128), mk(128), mk(128), mk(128), mk(256), mk(128), mk(256), mk(128)
+    f32 = dict(dtype=torch.float32, device=DEV)
+    dw_in, db_in = torch.empty((384, 128), **f32), torch.empty(384, **f32)
+    dwo, dbo = torch.empty((128, 128), **f32), torch.empty(128, **f32)
+    dw1, db1 = torch.empty((256, 128), **f32), torch.empty(256, **f32)
+    dw2, db2 = torch.empty((128, 256), **f32), torch.empty(128, **f32)
+    probs = [(dqkv[:, :256], xp, dw_in[:256], db_in[:256], 1, 0), (dqkv[:, 256:], x, dw_in[256:], db_in[256:], 1, 0),
+             (ds1, o, dwo, dbo, 1, 0), (dpre, y1, dw1, db1, 1, 0), (h, ds2, dw2, db2, 2, 1)]
+    nbytes = m * (384 + 128 + 128 + 128 + 128 + 256 + 128 + 256 + 128) * 2
+    med, mn = timeit(lambda: bf16.wgrad_group(probs))
+    print(f'wgrad_group_bf16 (5 products of one layer + bias sums): {med * 1e3:7.1f} us (min {mn * 1e3:6.1f})  '
+          f'{nbytes / med / 1e6:7.1f} GB/s of {nbytes / 1e6:.1f} MB operand bytes')
+    med, mn = timeit(lambda: [bf16.weight_grad(a if not tr else b, b if not tr else a) for a, b, _, _, _, tr in probs])
+    print(f'  library form (batched split-K bmm + fp32 sum), same 5 products: {med * 1e3:7.1f} us')
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if what in ('dense_bf16',):
+        bench_dense_bf16()
     if what in ('sra', 'all'):
         bench_sra()
     if what in ('ln', 'all'):
