@@ -222,7 +222,10 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--frames-per-gpu', type=int, default=1)
-    ap.add_argument('--points', type=int, default=116000)
+    ap.add_argument('--points', type=int, default=None, help='points per frame (default: 116000 for the SST workloads)')
+    ap.add_argument('--workload', default='sst', choices=('sst', 'sst_bs2', 'fsd', 'fsdv2'),
+                    help="sst = the headline (BASELINE.json configs[1]/[2] geometry, 1 frame/GPU); sst_bs2 = configs[2]'s "
+                         "2 frames per GPU; fsd / fsdv2 = configs[3] / configs[4] hot paths (bench_workloads.py)")
     ap.add_argument('--blocks', type=int, default=6)
     ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -240,6 +243,11 @@ def main():
     ap.add_argument('--no-gemm-tuning', action='store_true',
                     help='do not let PyTorch TunableOp pick the hipBLASLt/rocBLAS solution of each dense GEMM shape')
     args = ap.parse_args()
+    args.points_given = args.points is not None
+    if args.points is None:
+        args.points = 116000
+    if args.workload == 'sst_bs2':
+        args.frames_per_gpu = 2
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # launched as plain `python bench.py --gpus N`: start one rank per GPU ourselves, the way the reference's
@@ -258,6 +266,13 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    if args.workload in ('fsd', 'fsdv2'):
+        import bench_workloads
+        bench_workloads.run(args, rank, world, dev, allreduce_grads)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from sst_amd import kernels as K
     if not args.no_gemm_tuning:
@@ -464,7 +479,9 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'gemm_tuning': 'off' if args.no_gemm_tuning else 'torch TunableOp (hipBLASLt/rocBLAS solution per shape)',
-            'config': {'workload': 'SST-base Waymo single-frame, 0.32 m voxel: uniform synthetic cloud '
+            'config': {'workload': ('SST-base Waymo training, bs=2/GPU, 0.32 m voxel: uniform synthetic cloud '
+                                    if args.workload == 'sst_bs2' else
+                                    'SST-base Waymo single-frame, 0.32 m voxel: uniform synthetic cloud ') +
                                    f'{args.points} points/frame -> {n_voxels // args.frames_per_gpu} non-empty '
                                    'voxels/frame; dynamic voxelize + DynamicVFE + SSTInputLayerV2 + '
                                    f'{args.blocks} SRA blocks, ' + ('fwd only' if args.fwd_only else 'fwd+bwd'),

@@ -350,3 +350,23 @@ def load_reference_function(relpath, name, extra_globals=None):
             return glb[name]
     raise KeyError(name)
 
+
+
+def load_reference_method(relpath, cls_name, name, extra_globals=None):
+    """One method of a class of a reference file, as a plain function taking ``self`` - executed from the file's own
+    source text (the detector modules import mmdet / mmseg and cannot be imported here).  Nothing is copied."""
+    import ast
+    import textwrap
+    path = os.path.join(REF_ROOT, relpath)
+    src = open(path).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == cls_name:
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == name:
+                    lines = src.splitlines()[item.lineno - 1:item.end_lineno]     # without the decorators
+                    code = textwrap.dedent('\n'.join(lines))
+                    glb = {'torch': torch}
+                    glb.update(extra_globals or {})
+                    exec(compile(code, path + ':' + cls_name + '.' + name, 'exec'), glb)
+                    return glb[name]
+    raise KeyError(cls_name + '.' + name)

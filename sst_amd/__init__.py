@@ -28,9 +28,12 @@ from .spconv import (SparseConv3d, SparseConvTensor, SparseConvTranspose3d, Spar
 from .sparse_unet import (SimpleSparseUNet, SparseBasicBlock, SparseUNet, VirtualVoxelMixer,  # noqa: F401
                           make_sparse_convmodule)
 
+from .virtual_voxel import VirtualVoxelExtractor  # noqa: F401
+
 __version__ = '0.1.0'
 
 __all__ = [
+    'VirtualVoxelExtractor',
     'Voxelization', 'voxelization', 'DynamicScatter', 'dynamic_scatter', 'dynamic_voxelize',
     'dynamic_point_to_voxel_forward', 'build_scatter_plan', 'flat2window', 'window2flat', 'get_flat2win_inds',
     'get_inner_win_inds', 'make_continuous_inds', 'flat2window_v2', 'window2flat_v2', 'get_flat2win_inds_v2',

@@ -559,6 +559,78 @@ def gen_sparse_unet():
     save('voxel_mixer.npz', **arrays2)
 
 
+VIRTUAL_VOXEL_CFG = dict(
+    virtual_point_projector=dict(in_channels=16 + 3 + 4 + 2, hidden_dims=[16, 16], norm_cfg=dict(type='naiveSyncBN1d'),
+                                 ori_in_channels=16, ori_hidden_dims=[16, 16]),
+    voxel_encoder=dict(type='DynamicScatterVFE', in_channels=3 + 16, feat_channels=[16, 8], voxel_size=(0.4, 0.4, 0.4),
+                       with_cluster_center=True, with_voxel_center=True, point_cloud_range=[-8, -8, -3.2, 8, 8, 3.2],
+                       norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01), unique_once=True),
+    backbone=dict(type='VirtualVoxelMixer', **VOXEL_MIXER_CFG))
+
+
+def gen_virtual_voxel():
+    """FSDv2's virtual-voxel chain: SingleStageFSDV2.extract_feat (single_stage_fsd_v2.py:159-271, non-baseline mode,
+    training), the method's own source executed on a stand-in ``self`` that carries the reference's own submodules
+    (build_mlp projectors, DynamicScatterVFE, VirtualVoxelMixer over the vendored spconv package) on CPU."""
+    import types
+    R = ref_loader.load_reference_spconv()
+    ref = ref_loader.load_reference()
+    rel = 'mmdet3d/models/detectors/single_stage_fsd_v2.py'
+    glb = {'scatter_v2': ref.sst_ops.scatter_v2}
+    cfg = VIRTUAL_VOXEL_CFG
+    vpp = cfg['virtual_point_projector']
+    torch.manual_seed(21)
+    me = types.SimpleNamespace()
+    me.baseline_mode, me.zero_virtual_feature, me.only_virtual, me.training, me.as_rpn = False, False, False, True, False
+    me.train_cfg, me.print_info = {}, {}
+    me.virtual_voxel_size, me.point_cloud_range = cfg['voxel_encoder']['voxel_size'], cfg['voxel_encoder']['point_cloud_range']
+    me.virtual_proj = ref.sst_ops.build_mlp(vpp['in_channels'], vpp['hidden_dims'], vpp['norm_cfg'])
+    me.ori_proj = ref.sst_ops.build_mlp(vpp['ori_in_channels'], vpp['ori_hidden_dims'], vpp['norm_cfg'])
+    vfe_cfg = dict(cfg['voxel_encoder'])
+    vfe_cfg.pop('type')
+    me.voxel_encoder = ref.voxel_encoder.DynamicScatterVFE(**vfe_cfg)
+    me.backbone = R.sparse_unet.VirtualVoxelMixer(**VOXEL_MIXER_CFG)
+    for m in (me.virtual_proj, me.ori_proj, me.voxel_encoder, me.backbone):
+        m.train()
+    for fn in ('voxelize_with_batch_idx', 'clip_points'):
+        f = ref_loader.load_reference_method(rel, 'SingleStageFSDV2', fn, glb)
+        setattr(me, fn, types.MethodType(f, me))
+    extract = ref_loader.load_reference_method(rel, 'SingleStageFSDV2', 'extract_feat', glb)
+    g = torch.Generator().manual_seed(22)
+    n_ori, n_fg, batch = 900, 260, 2
+    rng_lo, rng_hi = torch.tensor([-8.0, -8.0, -3.2]), torch.tensor([8.0, 8.0, 3.2])
+    ori_xyz = torch.rand(n_ori, 3, generator=g) * (rng_hi - rng_lo) * 0.6 + rng_lo * 0.6
+    ori = dict(seg_points=torch.cat([ori_xyz, torch.rand(n_ori, 2, generator=g)], 1),
+               seg_feats=torch.randn(n_ori, 16, generator=g), batch_idx=torch.randint(0, batch, (n_ori,), generator=g))
+    sel = torch.randperm(n_ori, generator=g)[:n_fg]
+    centers = ori_xyz[sel] + torch.randn(n_fg, 3, generator=g) * 0.8
+    centers[:6] += 20.0                                   # some predicted centres outside the range: clip_points
+    smp = dict(seg_points=ori['seg_points'][sel].clone(), center_preds=centers, seg_logits=torch.randn(n_fg, 4, generator=g),
+               seg_feats=ori['seg_feats'][sel].clone(), batch_idx=ori['batch_idx'][sel].clone())
+    leaves = {k: v.clone().requires_grad_(True) for k, v in (('ori_feats', ori['seg_feats']), ('smp_feats', smp['seg_feats']),
+                                                             ('smp_logits', smp['seg_logits']))}
+    ori_in = dict(ori, seg_feats=leaves['ori_feats'])
+    smp_in = dict(smp, seg_feats=leaves['smp_feats'], seg_logits=leaves['smp_logits'], center_preds=centers.clone())
+    out = extract(me, smp_in, ori_in)
+    gy = torch.randn(out['virtual_feats'].shape, generator=g)
+    (out['virtual_feats'] * gy).sum().backward()
+    arrays = {'in::ori_points': t2n(ori['seg_points']), 'in::ori_feats': t2n(ori['seg_feats']),
+              'in::ori_batch_idx': t2n(ori['batch_idx']), 'in::smp_points': t2n(smp['seg_points']),
+              'in::smp_centers': t2n(centers), 'in::smp_logits': t2n(smp['seg_logits']), 'in::smp_feats': t2n(smp['seg_feats']),
+              'in::smp_batch_idx': t2n(smp['batch_idx']), 'in::grad_out': t2n(gy),
+              'out::virtual_feats': t2n(out['virtual_feats']), 'out::virtual_coors': t2n(out['virtual_coors']),
+              'out::virtual_centers': t2n(out['virtual_centers']), 'out::virtual_centroid': t2n(out['virtual_centroid']),
+              'out::sparse_shape': np.asarray(out['sparse_shape']),
+              'out::grad_ori_feats': t2n(leaves['ori_feats'].grad), 'out::grad_smp_feats': t2n(leaves['smp_feats'].grad),
+              'out::grad_smp_logits': t2n(leaves['smp_logits'].grad)}
+    for prefix, mod in (('virtual_proj', me.virtual_proj), ('ori_proj', me.ori_proj), ('voxel_encoder', me.voxel_encoder),
+                        ('backbone', me.backbone)):
+        arrays.update({f'w::{prefix}.{k}': t2n(v.float()) for k, v in mod.state_dict().items()})
+    arrays['out::grad::virtual_proj.0.0.weight'] = t2n(me.virtual_proj[0][0].weight.grad)
+    arrays['out::grad::ori_proj.1.0.weight'] = t2n(me.ori_proj[1][0].weight.grad)
+    save('virtual_voxel.npz', **arrays)
+
+
 def gen_hard_voxelize():
     """Hard voxelization (max_num_points / max_voxels set) from the reference's own compiled C++
     (voxelization_cpu.cpp:43-142 through oracle/_ref/voxel_layer_ref.so): more voxels than max_voxels (later ones
@@ -594,6 +666,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'sst_block_bf16':
         gen_sst_block_bf16(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'virtual_voxel':
+        gen_virtual_voxel()
+        return
     gen_voxelize()
     gen_hard_voxelize()
     gen_input_layer(ref)
@@ -610,6 +685,7 @@ def main():
     build_ref.build_spconv_rulebook()
     gen_spconv()
     gen_sparse_unet()
+    gen_virtual_voxel()
 
 
 if __name__ == '__main__':
