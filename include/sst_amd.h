@@ -447,6 +447,15 @@ int sst_tall_linear_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t
  *   mode 1: y = (x W [+ b]) * gelu'(aux)      (data gradient through linear2 times the activation's derivative at
  *                                              the pre-activation aux)
  * d_aux has the row stride ldy.  A 256-wide FFN is two calls on column halves of W / y / aux. */
+/* sst_tall_linear_epi_f32 (csrc/dense_f32.hip): y[m, n] = epilogue(x[m, k] W^T + bias), exact fp32 (v_mfma_f32_16x16x4_f32),
+ * the whole weight matrix resident in LDS; (k, n) in {(128,128), (128,256), (256,128)}.  trans_w = 0: d_w holds W as [n][k]
+ * rows (F.linear's weight); trans_w = 1: d_w holds [k][n] rows - the data gradient dy[m, out] w[out, in] of a layer with
+ * parameter w (sst_basic_block_v2.py:41-75, 104-126 and their autograd).  epilogue: 0 = bias; 1 / 2 = GELU(erf) / ReLU with
+ * the pre-activation also written to d_aux_out (may be NULL); 3 / 4 = multiply by GELU' / ReLU' of d_aux_in; 5 = add
+ * d_aux_in (may alias d_y: in-place accumulation of a residual branch's gradient). */
+int sst_tall_linear_epi_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int trans_w, const float* d_bias,
+                            int64_t m, int k, int n, int epilogue, const float* d_aux_in, float* d_aux_out, int64_t ldaux,
+                            float* d_y, int64_t ldy, void* stream);
 int sst_tall_linear_gelu_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias,
                              int64_t m, int n, int k, int trans_w, int mode, float* d_aux, float* d_y, int64_t ldy,
                              void* stream);

@@ -97,9 +97,22 @@ __global__ __launch_bounds__(256, (K * N <= 128 * 128 ? 3 : 2)) void tall_linear
     }
   };
   load_x(r0 < M ? r0 : M - 1, xb);  // the first row tile is in flight while the weights are copied to LDS
-  for (int idx = threadIdx.x; idx < N * (K / 8); idx += 256) {
-    const int n = idx / (K / 8), ch = idx - n * (K / 8);
-    *(u32x4*)(wimg + w_lds_row(n) * RS + ch * 16) = *(const u32x4*)(W + (size_t)n * K + ch * 8);
+  // weight fill: batches of 8 independent 16-byte loads per thread, then the LDS writes (a load -> write loop would be
+  // paced by one L2 round trip per iteration)
+  constexpr int CHUNKS = N * K / 8, BATCH = 8;
+  static_assert(CHUNKS % (256 * BATCH) == 0, "fill loop assumes a whole number of batches");
+  for (int base = threadIdx.x; base < CHUNKS; base += 256 * BATCH) {
+    u32x4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = base + u * 256, n = idx / (K / 8), ch = idx - n * (K / 8);
+      v[u] = *(const u32x4*)(W + (size_t)n * K + ch * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = base + u * 256, n = idx / (K / 8), ch = idx - n * (K / 8);
+      *(u32x4*)(wimg + w_lds_row(n) * RS + ch * 16) = v[u];
+    }
   }
   for (int n = threadIdx.x; n < N; n += 256) bimg[n] = bias != nullptr ? bias[n] : 0.f;
   __syncthreads();
@@ -108,6 +121,9 @@ __global__ __launch_bounds__(256, (K * N <= 128 * 128 ? 3 : 2)) void tall_linear
   for (; r0 < r1; r0 += 32) {
     asm volatile("" ::: "memory");  // W fragments are re-read from LDS per row tile (never hoisted into registers)
     const bool more = r0 + 32 < r1;
+    // this step's X tile (requested a whole step ago) has landed BEFORE the next one is requested: the compiler sizes the
+    // wait in front of the first MFMA for the path without a prefetch, which would otherwise stall on the new loads
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (more) load_x(r0 + 32, xn);
 #pragma unroll
     for (int nh = 0; nh < N / 128; ++nh) {  // 128 output columns at a time: 64 accumulator registers

@@ -1,0 +1,287 @@
+// Tall fp32 linear layers with the weight matrix resident in LDS (gfx950):
+//   Y[M, N] = epilogue(X[M, K] W^T + b),  W given as [N][K] rows (trans_w = 0) or as [K][N] rows (trans_w = 1, the data
+//   gradient dY[M, out] w[out, in] of a layer whose parameter is w), (K, N) in {(128,128), (128,256), (256,128)}.
+// The projections and the FFN of an SRA encoder layer, forward and data gradient: sst_basic_block_v2.py:41-75, 104-126.
+// Exact fp32: v_mfma_f32_16x16x4_f32 (the same arithmetic as an fmaf chain), fp32 operands in HBM.
+//
+// Bound: the fp32 matrix pipe AND HBM at once - 32 flop per byte at K = N = 128 is exactly 157 TFLOP/s over 4.9 TB/s - so
+// the kernel has to keep the pipe issuing while a whole row tile is in flight:
+//   * W lives in LDS for the whole kernel (<= 136 KB, rows permuted as in csrc/dense_bf16.hip so that the TRANSPOSED
+//     product Y^T = W X^T leaves a lane with 8 consecutive output columns of one row: two 16-byte stores);
+//   * one wave per SIMD, each with a contiguous range of rows; the X fragments are the MFMA B operand straight from
+//     global memory - a 16-byte load gives a lane 4 consecutive k of its row, which are then 4 consecutive MFMA k-steps
+//     (the k order inside a product is free as long as both operands agree) - and the next 32-row tile is prefetched
+//     during the ~14 us of MFMAs of the current one; no LDS round trip for X, no barrier after the weight fill;
+//   * bias, GELU (+ stored pre-activation), multiplication by the activation's derivative, and the residual sum of a
+//     data gradient ride on the epilogue, where they overlap the other waves' MFMAs - this is what removes the
+//     separate GELU / GELU-backward / add passes over [M, 256] (the hand-pipelined tall_gemm.hip could not hide them).
+#include <math.h>
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float erf_as(float z, float& e) {  // Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+  e = __expf(-az * az);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  return copysignf(fmaf(-poly, e, 1.f), z);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float e;
+  return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f, e));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  float e;
+  const float phi = 0.5f * (1.f + erf_as(x * 0.70710678118654752f, e));
+  return fmaf(x * 0.3989422804014327f, e, phi);
+}
+
+enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5 };
+
+__device__ __forceinline__ int w_lds_row(int n) {  // see csrc/dense_bf16.hip
+  const int tp = n >> 5, within = n & 31;
+  return 16 * (2 * tp + ((within >> 2) & 1)) + ((within >> 3) << 2) + (within & 3);
+}
+
+// 128 output columns x one 32-row (TWO) / 16-row step: W fragments are read one group ahead of the MFMAs that consume
+// them; the scheduling barriers keep the compiler from sinking the LDS read next to its first use, where its latency
+// would be exposed every 8 MFMAs (measured: 42 us -> see profiles for K = N = 128).
+template <int K, bool TWO, typename EMIT>
+__device__ __forceinline__ void mfma_phase(const float* __restrict__ wbase, const f32x4 (&xb)[2][K / 16], f32x4 (&acc)[2][8],
+                                           EMIT&& emit) {
+  constexpr int RS = K + 4, KJ = K / 16, HT = 8, G = KJ * HT;
+  f32x4 wf = *(const f32x4*)(wbase);
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const int j = q / HT, T = q - j * HT;
+    const int qn = q + 1 < G ? q + 1 : q;
+    const f32x4 wn = *(const f32x4*)(wbase + (qn % HT) * 16 * RS + (qn / HT) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      acc[0][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x], xb[0][j][x], acc[0][T], 0, 0, 0);
+      if (TWO) acc[1][T] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[x], xb[1][j][x], acc[1][T], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // one eighth of the PREVIOUS phase's epilogue (bias / activation / stores of one 16-row x 32-column unit) behind
+    // every G / 8 groups: its arithmetic and its store issue overlap this phase's MFMAs instead of stalling the wave
+    // (one wave per SIMD: nobody else would use the pipe meanwhile)
+    if ((q + 1) % (G / 8) == 0) emit((q + 1) / (G / 8) - 1);
+    wf = wn;
+  }
+}
+
+template <int K, int N, int EPI>
+__global__ __launch_bounds__(256, 1) void tall_linear_lds_f32_k(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw, int trans_w,
+    const float* __restrict__ bias, int64_t M, int rows_per_wave, float* __restrict__ Y, int64_t ldy,
+    const float* __restrict__ aux_in, float* __restrict__ aux_out, int64_t ldaux) {
+  constexpr int RS = K + 4;  // LDS row stride in floats: the 16 lanes of a ds_read_b128 phase on distinct banks
+  constexpr int KJ = K / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  float* wimg = smem_f;
+  float* bimg = smem_f + N * RS;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int64_t r0 = wave * rows_per_wave;
+  const int64_t r1 = r0 + rows_per_wave < M ? r0 + rows_per_wave : M;
+  f32x4 xb[2][KJ], xn[2][KJ];
+  auto load_x = [&](int64_t r, f32x4 (&dst)[2][KJ]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int64_t row = r + 16 * t + c;
+      row = row < M ? row : M - 1;
+      const float* p = X + row * ldx + 4 * g;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) dst[t][j] = *(const f32x4*)(p + 16 * j);
+    }
+  };
+  load_x(r0 < M ? r0 : M - 1, xb);  // in flight while the weights are copied to LDS
+  // weight fill: batches of 8 independent 16-byte loads per thread before the LDS writes (a load -> write loop is paced
+  // by one L2 round trip per iteration: 32 iterations for 128 KB, ~17 us measured as idle matrix pipe)
+  constexpr int CHUNKS = N * K / 4, BATCH = 8;
+  static_assert(CHUNKS % (256 * BATCH) == 0, "fill loop assumes a whole number of batches");
+  for (int base = threadIdx.x; base < CHUNKS; base += 256 * BATCH) {
+    f32x4 v[BATCH];
+    if (!trans_w) {
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * 256, n = idx / (K / 4), ch = idx - n * (K / 4);
+        v[u] = *(const f32x4*)(W + (size_t)n * ldw + ch * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * 256, n = idx / (K / 4), ch = idx - n * (K / 4);
+        *(f32x4*)(wimg + w_lds_row(n) * RS + ch * 4) = v[u];
+      }
+    } else {  // W[n][k] = w[k][n]: 16-byte reads along n, scattered to four LDS rows
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * 256, k = idx / (N / 4), n4 = (idx - k * (N / 4)) * 4;
+        v[u] = *(const f32x4*)(W + (size_t)k * ldw + n4);
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * 256, k = idx / (N / 4), n4 = (idx - k * (N / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wimg[w_lds_row(n4 + e) * RS + k] = v[u][e];
+      }
+    }
+  }
+  for (int n = threadIdx.x; n < N; n += 256) bimg[n] = bias != nullptr ? bias[n] : 0.f;
+  __syncthreads();
+  if (r0 >= r1) return;
+  const float* wlane = wimg + c * RS + 4 * g;
+
+  // the finished accumulators of one phase wait in `pend` and are written out during the next phase
+  f32x4 pend[2][8];
+  int64_t pend_r0 = 0;
+  int pend_nh = 0;
+  bool pend_valid = false;
+  auto emit = [&](int slot) {
+    if (!pend_valid) return;
+    const int t = slot >> 2, tp = slot & 3;
+    const int64_t row = pend_r0 + 16 * t + c;
+    if (row >= r1) return;
+    const int n0 = 128 * pend_nh + 32 * tp + 8 * g;
+    const f32x4 b0 = *(const f32x4*)(bimg + n0), b1 = *(const f32x4*)(bimg + n0 + 4);
+    f32x4 v0 = pend[t][2 * tp] + b0, v1 = pend[t][2 * tp + 1] + b1;
+    if (EPI == kEpiGelu || EPI == kEpiRelu) {
+      if (aux_out != nullptr) {
+        *(f32x4*)(aux_out + row * ldaux + n0) = v0;
+        *(f32x4*)(aux_out + row * ldaux + n0 + 4) = v1;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v0[r] = EPI == kEpiGelu ? gelu_f(v0[r]) : fmaxf(v0[r], 0.f);
+        v1[r] = EPI == kEpiGelu ? gelu_f(v1[r]) : fmaxf(v1[r], 0.f);
+      }
+    }
+    if (EPI == kEpiMulGeluGrad || EPI == kEpiMulReluGrad) {
+      const f32x4 p0 = *(const f32x4*)(aux_in + row * ldaux + n0), p1 = *(const f32x4*)(aux_in + row * ldaux + n0 + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v0[r] *= EPI == kEpiMulGeluGrad ? gelu_grad_f(p0[r]) : (p0[r] > 0.f ? 1.f : 0.f);
+        v1[r] *= EPI == kEpiMulGeluGrad ? gelu_grad_f(p1[r]) : (p1[r] > 0.f ? 1.f : 0.f);
+      }
+    }
+    if (EPI == kEpiAdd) {  // + a second [M, N] term; aux_in may be Y itself (in-place accumulation)
+      v0 += *(const f32x4*)(aux_in + row * ldaux + n0);
+      v1 += *(const f32x4*)(aux_in + row * ldaux + n0 + 4);
+    }
+    *(f32x4*)(Y + row * ldy + n0) = v0;
+    *(f32x4*)(Y + row * ldy + n0 + 4) = v1;
+  };
+
+  for (; r0 < r1; r0 += 32) {
+    asm volatile("" ::: "memory");  // W fragments are re-read from LDS per row tile (never hoisted into registers)
+    const bool more = r0 + 32 < r1;
+    const bool two = r0 + 16 < r1;  // the second 16-row tile of this step exists
+    // everything issued so far has landed (this step's X tile was requested a whole step ago) BEFORE the next tile is
+    // requested: otherwise the wait the compiler places in front of the first MFMA - vmcnt(15), sized for the path on
+    // which no prefetch was issued - makes the phase wait for the loads just issued, and nothing overlaps (measured:
+    // kernel time = load time + MFMA time + store time)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    if (more) load_x(r0 + 32, xn);
+#pragma unroll
+    for (int nh = 0; nh < N / 128; ++nh) {  // 128 output columns at a time
+      f32x4 acc[2][8];
+#pragma unroll
+      for (int T = 0; T < 8; ++T) {
+        acc[0][T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1][T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      if (two)
+        mfma_phase<K, true>(wlane + nh * 8 * 16 * (K + 4), xb, acc, emit);
+      else
+        mfma_phase<K, false>(wlane + nh * 8 * 16 * (K + 4), xb, acc, emit);
+#pragma unroll
+      for (int T = 0; T < 8; ++T) {
+        pend[0][T] = acc[0][T];
+        pend[1][T] = acc[1][T];
+      }
+      pend_r0 = r0;
+      pend_nh = nh;
+      pend_valid = true;
+    }
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) xb[t][j] = xn[t][j];
+    }
+  }
+#pragma unroll
+  for (int slot = 0; slot < 8; ++slot) emit(slot);
+}
+
+template <int K, int N, int EPI>
+int launch_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, int trans_w, const float* bias, int64_t m,
+                  float* y, int64_t ldy, const float* aux_in, float* aux_out, int64_t ldaux, hipStream_t st) {
+  constexpr int lds = (N * (K + 4) + N) * 4;
+  static bool configured = false;
+  if (!configured) {
+    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_lds_f32_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    configured = true;
+  }
+  // one workgroup per CU (up to 136 KB of LDS); every wave a contiguous row range, a multiple of 8
+  int64_t blocks = 256;  // one wave per SIMD: the epilogue of a phase is software-pipelined under the next phase's MFMAs
+  int64_t rpw = sst_align_up(sst_div_up(m, blocks * 4), 8);
+  blocks = sst_div_up(m, rpw * 4);
+  hipLaunchKernelGGL((tall_linear_lds_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, x, ldx, w, ldw, trans_w,
+                     bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux);
+  return SST_OK;
+}
+
+template <int K, int N>
+int dispatch_epi(int epi, const float* x, int64_t ldx, const float* w, int64_t ldw, int trans_w, const float* bias, int64_t m,
+                 float* y, int64_t ldy, const float* aux_in, float* aux_out, int64_t ldaux, hipStream_t st) {
+#define SST_CASE(E) \
+  case E: return launch_linear<K, N, E>(x, ldx, w, ldw, trans_w, bias, m, y, ldy, aux_in, aux_out, ldaux, st)
+  switch (epi) {
+    SST_CASE(kEpiBias);
+    SST_CASE(kEpiGelu);
+    SST_CASE(kEpiRelu);
+    SST_CASE(kEpiMulGeluGrad);
+    SST_CASE(kEpiMulReluGrad);
+    SST_CASE(kEpiAdd);
+  }
+#undef SST_CASE
+  return SST_ERR_ARG;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int sst_tall_linear_epi_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int trans_w, const float* d_bias,
+                            int64_t m, int k, int n, int epilogue, const float* d_aux_in, float* d_aux_out, int64_t ldaux,
+                            float* d_y, int64_t ldy, void* stream) {
+  if (m < 0 || !d_w || epilogue < 0 || epilogue > kEpiAdd) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_y || (ldx & 3) || (ldy & 3) || (ldw & 3) || !aligned16(d_x) || !aligned16(d_y) || !aligned16(d_w))
+    return SST_ERR_ARG;
+  if (epilogue >= kEpiMulGeluGrad && (!d_aux_in || (ldaux & 3) || !aligned16(d_aux_in))) return SST_ERR_ARG;
+  if (d_aux_out && ((ldaux & 3) || !aligned16(d_aux_out))) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (k == 128 && n == 128)
+    rc = dispatch_epi<128, 128>(epilogue, d_x, ldx, d_w, ldw, trans_w, d_bias, m, d_y, ldy, d_aux_in, d_aux_out, ldaux, st);
+  else if (k == 128 && n == 256)
+    rc = dispatch_epi<128, 256>(epilogue, d_x, ldx, d_w, ldw, trans_w, d_bias, m, d_y, ldy, d_aux_in, d_aux_out, ldaux, st);
+  else if (k == 256 && n == 128)
+    rc = dispatch_epi<256, 128>(epilogue, d_x, ldx, d_w, ldw, trans_w, d_bias, m, d_y, ldy, d_aux_in, d_aux_out, ldaux, st);
+  else
+    return SST_ERR_UNSUPPORTED;
+  if (rc) return rc;
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+}  // extern "C"

@@ -91,6 +91,37 @@ def tall_gemm(x, w, bias=None, trans_w=False, out=None, accumulate=False):
     return out
 
 
+EPI_BIAS, EPI_GELU, EPI_RELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_ADD = range(6)
+_LDS_LINEAR_SHAPES = ((128, 128), (128, 256), (256, 128))
+
+
+def lds_linear_ok(x, w, trans_w=False):
+    """shapes / layouts csrc/dense_f32.hip is built for"""
+    k, n = (w.size(0), w.size(1)) if trans_w else (w.size(1), w.size(0))
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and x.size(1) == k
+            and (k, n) in _LDS_LINEAR_SHAPES and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0
+            and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def lds_linear(x, w, bias=None, epilogue=EPI_BIAS, trans_w=False, aux_in=None, want_pre=False, out=None):
+    """y = epilogue(x @ (w if trans_w else w.t()) + bias) in exact fp32 with the weight matrix resident in LDS
+    (csrc/dense_f32.hip).  GELU / RELU with want_pre -> (y, pre-activation); MUL_*_GRAD / ADD read ``aux_in`` ([M, N]);
+    ``out``: written in place (with EPI_ADD and aux_in = out: out += product)."""
+    m = x.size(0)
+    k, n = (w.size(0), w.size(1)) if trans_w else (w.size(1), w.size(0))
+    y = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=x.device)
+    pre = torch.empty((m, n), dtype=torch.float32, device=x.device) if want_pre else None
+    aux = aux_in if aux_in is not None else pre
+    if aux is not None and (aux.stride(1) != 1 or aux.data_ptr() % 16 or aux.stride(0) % 4):
+        raise RuntimeError('sst_amd.dense.lds_linear: aux tensor must be row-major and 16-byte aligned')
+    rc = _lib.load().sst_tall_linear_epi_f32(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), int(trans_w), _lib.ptr(bias),
+                                             m, k, n, int(epilogue), _lib.ptr(aux_in), _lib.ptr(pre),
+                                             aux.stride(0) if aux is not None else 0, _lib.ptr(y), y.stride(0),
+                                             _lib.stream_ptr())
+    _lib.check(rc, 'sst_tall_linear_epi_f32')
+    return (y, pre) if want_pre else y
+
+
 def _gelu_gemm_ok(x, w, n, k):
     return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and k == 128 and n % 128 == 0
             and x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0

@@ -18,7 +18,8 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
-from .dense import (tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
+from .dense import (EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
+                    tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
                     weight_bias_grad)
 from .norm import build_norm_layer
 
@@ -141,10 +142,19 @@ _TALL_GEMM = int(_os.environ.get('SST_AMD_TALL_GEMM', '1'))
 # hand-pipelined MFMA kernel where nothing overlaps it - 57 us (forward) and 104 us (backward) per 128-column half against
 # 38 us for the plain product, i.e. 16.2 ms per step instead of 14.6 with the library GEMM + torch's HBM-bound GELU kernels.
 _FUSED_GELU = int(_os.environ.get('SST_AMD_FUSED_GELU', '0'))
+# Exact-fp32 linears with the weight matrix resident in LDS and the activation / residual arithmetic in their epilogues
+# (csrc/dense_f32.hip; the bf16 mode's kernels are built the same way and are 2-3x faster than the library there).
+# Measured and NOT the default in fp32 (profiles/r02, tools/lds_linear_only.py): with one wave per SIMD the fp32 matrix
+# pipe runs at 80 % inside a phase and fill / first-tile latency / store tail stay exposed - 38 / 67 / 70 us for
+# (K, N) = (128,128) / (128,256) / (256,128) against 37 us (csrc/tall_gemm.hip) and 60-63 us (hipBLASLt, TunableOp), so even
+# with the GELU passes folded in the step is 15.8 ms instead of 14.2.  SST_AMD_LDS_LINEAR=1 switches it on.
+_LDS_LINEAR = int(_os.environ.get('SST_AMD_LDS_LINEAR', '0'))
 
 
 def _linear_fwd(x, w, b):
     """x @ w.t() + b"""
+    if _LDS_LINEAR and lds_linear_ok(x, w):
+        return lds_linear(x, w, b)
     if _TALL_GEMM and w.size(0) == 128 and (w.size(1) == 128 or _TALL_GEMM > 1):
         y = tall_gemm(x, w, b)
         if y is not None:
@@ -154,6 +164,10 @@ def _linear_fwd(x, w, b):
 
 def _linear_dgrad(dy, w, out=None):
     """dy @ w (w: [out_features, in_features]); ``out`` given: out += dy @ w in place."""
+    if _LDS_LINEAR and lds_linear_ok(dy, w, trans_w=True):
+        if out is not None:
+            return lds_linear(dy, w, None, EPI_ADD, trans_w=True, aux_in=out, out=out)
+        return lds_linear(dy, w, None, trans_w=True)
     if _TALL_GEMM and w.size(1) == 128 and (w.size(0) == 128 or _TALL_GEMM > 1):
         y = tall_gemm(dy, w, None, trans_w=True, out=out, accumulate=out is not None)
         if y is not None:
@@ -176,7 +190,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         c = x.size(1)
         x = x.contiguous()
         xp = x + pos if pos is not None else x
-        qk = torch.addmm(b_in[:2 * c], xp, w_in[:2 * c].t())
+        qk = _linear_fwd(xp, w_in[:2 * c], b_in[:2 * c])
         v = _linear_fwd(x, w_in[2 * c:], b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
         o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
@@ -184,7 +198,9 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
         y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
         fused_act = linear_gelu(y1, w1, b1) if (act == 'gelu' and _FUSED_GELU) else None
-        if fused_act is not None:      # bias + GELU in the epilogue of linear1 (csrc/tall_gemm.hip)
+        if _LDS_LINEAR and lds_linear_ok(y1, w1):   # bias + activation in the epilogue of linear1 (csrc/dense_f32.hip)
+            h, pre = lds_linear(y1, w1, b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
+        elif fused_act is not None:    # csrc/tall_gemm.hip
             pre, h = fused_act
         else:
             pre = torch.addmm(b1, y1, w1.t())
@@ -204,6 +220,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w)               # = d(y1 residual) = d(f)
         dw2, db2 = weight_bias_grad(ds2, h, True)
         dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
+        if _LDS_LINEAR and lds_linear_ok(ds2, w2, trans_w=True) and pre.is_contiguous():
+            # the activation's derivative in the epilogue of linear2's data gradient
+            dpre = lds_linear(ds2, w2, None, EPI_MUL_GELU_GRAD if ctx.act == 'gelu' else EPI_MUL_RELU_GRAD, trans_w=True,
+                              aux_in=pre)
         if dpre is None:
             dh = ds2 @ w2
             if ctx.act == 'gelu':
@@ -224,7 +244,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         db_in = torch.empty(3 * c, dtype=torch.float32, device=x.device)
         weight_bias_grad(dqk, xp, True, out_w=dw_in[:2 * c], out_b=db_in[:2 * c])
         weight_bias_grad(dv, x, True, out_w=dw_in[2 * c:], out_b=db_in[2 * c:])
-        dx = ds1.addmm_(dqkv, w_in)                                   # residual + q,k,v branches (in place)
+        if _LDS_LINEAR and lds_linear_ok(dqk, w_in[:2 * c], trans_w=True) and lds_linear_ok(dv, w_in[2 * c:], trans_w=True):
+            dx = _linear_dgrad(dv, w_in[2 * c:], out=_linear_dgrad(dqk, w_in[:2 * c], out=ds1))
+        else:
+            dx = ds1.addmm_(dqkv, w_in)                               # residual + q,k,v branches (in place)
         return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
                 None)
 

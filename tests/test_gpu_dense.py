@@ -163,3 +163,43 @@ def test_tall_gemm_strided_operands_and_unsupported_shapes():
     assert (y.double() - x.double() @ w_in[256:].double().t()).abs().max().item() < 1e-3
     assert tall_gemm(torch.randn(100, 64, device=dev), torch.randn(128, 64, device=dev)) is None   # K = 64
     assert tall_gemm(torch.randn(100, 128, device=dev), torch.randn(256, 128, device=dev)) is None  # N = 256
+
+
+@pytest.mark.parametrize('m', [1, 77, 5000, 90107])
+@pytest.mark.parametrize('k,n', [(128, 128), (128, 256), (256, 128)])
+@pytest.mark.parametrize('trans_w', [False, True])
+def test_lds_linear_f32(m, k, n, trans_w):
+    """csrc/dense_f32.hip against float64 on the same operands: exact-fp32 products, every epilogue, both weight layouts"""
+    from sst_amd import dense as D
+    g = torch.Generator().manual_seed(m + k + 3 * n + int(trans_w))
+    x = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(DEV)
+    wa = w.t().contiguous() if trans_w else w
+    b = torch.randn(n, generator=g).to(DEV)
+    aux = torch.randn(m, n, generator=g).to(DEV)
+    ref = (x.double() @ w.double().t())
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert D.lds_linear_ok(x, wa, trans_w)
+    y = D.lds_linear(x, wa, b, trans_w=trans_w)
+    assert float((y.double() - (ref + b.double())).abs().max()) < tol
+    y = D.lds_linear(x, wa, None, trans_w=trans_w)
+    assert float((y.double() - ref).abs().max()) < tol
+    for epi, fn in ((D.EPI_GELU, torch.nn.functional.gelu), (D.EPI_RELU, torch.relu)):
+        y, pre = D.lds_linear(x, wa, b, epi, trans_w=trans_w, want_pre=True)
+        assert float((pre.double() - (ref + b.double())).abs().max()) < tol
+        assert float((y.double() - fn(ref + b.double())).abs().max()) < tol
+    xg = aux.double().requires_grad_(True)
+    torch.nn.functional.gelu(xg).sum().backward()
+    y = D.lds_linear(x, wa, None, D.EPI_MUL_GELU_GRAD, trans_w=trans_w, aux_in=aux)
+    assert float((y.double() - ref * xg.grad).abs().max()) < tol
+    y = D.lds_linear(x, wa, None, D.EPI_MUL_RELU_GRAD, trans_w=trans_w, aux_in=aux)
+    assert float((y.double() - ref * (aux.double() > 0)).abs().max()) < tol
+    y = D.lds_linear(x, wa, None, D.EPI_ADD, trans_w=trans_w, aux_in=aux)
+    assert float((y.double() - (ref + aux.double())).abs().max()) < tol
+    acc = aux.clone()
+    D.lds_linear(x, wa, None, D.EPI_ADD, trans_w=trans_w, aux_in=acc, out=acc)      # in place: acc += x w^T
+    assert float((acc.double() - (ref + aux.double())).abs().max()) < tol
+    # column slices of a wider tensor as operands (dq | dk of the [M, 3C] gradient buffer, rows of in_proj_weight)
+    wide = torch.randn(m, k + 64, generator=g).to(DEV)
+    y = D.lds_linear(wide[:, 64:], wa, None, trans_w=trans_w)
+    assert float((y.double() - wide[:, 64:].double() @ w.double().t()).abs().max()) < tol

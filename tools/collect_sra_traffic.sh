@@ -22,14 +22,14 @@ def avg(path, counter, pat):
             if r['Counter_Name'] == counter and re.search(pat, r['Kernel_Name'])]
     return sum(vals) / len(vals), len(vals)
 res = {}
-for kern in ('sra_fwd_wave_k', 'sra_bwd_fused_k'):
+for kern in ('sra_fwd_wave_k', 'sra_bwd_fused_k', 'sra_fwd_bf16_k', 'sra_bwd_bf16_k'):
     f, nf = avg(out + '/fetch_counter_collection.csv', 'FETCH_SIZE', kern)
     w, nw = avg(out + '/write_counter_collection.csv', 'WRITE_SIZE', kern)
     res[kern] = {'FETCH_SIZE_KB_raw': f, 'WRITE_SIZE_KB_raw': w, 'launches_averaged': nf,
                  'hbm_read_bytes': 2 * f * 1024, 'hbm_write_bytes': w * 1024,
                  'hbm_bytes_per_launch': 2 * f * 1024 + w * 1024,
                  'correction': 'FETCH_SIZE x2 (gfx950 wide-stream under-count, MI355X_MICROARCH.md HBM section)'}
-res['workload'] = 'tools/sra_only.py: bench frame (116000 points -> 90107 tokens, 1521 windows), d=128, 8 heads, fp32'
+res['workload'] = 'tools/sra_only.py: bench frame (116000 points -> 90107 tokens, 1521 windows), d=128, 8 heads; fp32 kernels and the bf16-storage kernels'
 json.dump(res, open(out + '/sra_traffic.json', 'w'), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -26,5 +26,12 @@ q, k, v = qkv[:, :128], qkv[:, 128:256], qkv[:, 256:]
 for _ in range(iters):
     o, lse = K._sra_fwd(q, k, v, plan, 8, 0.25, 0)
     K._sra_bwd(q, k, v, o, lse, do, plan, 8, 0.25, 0, dqkv[:, :128], dqkv[:, 128:256], dqkv[:, 256:])
+# the reduced-precision kernels on the same plan (bf16 storage)
+from sst_amd import bf16  # noqa: E402
+qb, kb, vb, dob = (t.to(torch.bfloat16).contiguous() for t in (q, k, v, do))
+dqb, dkb, dvb = (torch.empty_like(qb) for _ in range(3))
+for _ in range(iters):
+    ob, lseb = bf16.sra_fwd(qb, kb, vb, plan, 8, 0.25)
+    bf16.sra_bwd(qb, kb, vb, ob, lseb, dob, plan, 8, 0.25, dqb, dkb, dvb)
 torch.cuda.synchronize()
 print('tokens', m, 'windows', plan.n_windows)
