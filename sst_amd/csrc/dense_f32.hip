@@ -75,6 +75,32 @@ __device__ __forceinline__ void mfma_phase(const float* __restrict__ wbase, cons
   }
 }
 
+// The same for ONE 16-row tile (the 8-wave variant below): two column tiles per group, their MFMAs interleaved, so that
+// consecutive MFMAs never depend on each other; 4 emission slots (one per 32-column unit of the previous phase).
+template <int K, typename EMIT>
+__device__ __forceinline__ void mfma_phase_single(const float* __restrict__ wbase, const f32x4 (&xb)[K / 16], f32x4 (&acc)[8],
+                                                  EMIT&& emit) {
+  constexpr int RS = K + 4, KJ = K / 16, HP = 4, G = KJ * HP;
+  f32x4 wa = *(const f32x4*)(wbase), wb = *(const f32x4*)(wbase + 16 * RS);
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const int j = q / HP, P = q - j * HP;
+    const int qn = q + 1 < G ? q + 1 : q;
+    const float* pn = wbase + (2 * (qn % HP)) * 16 * RS + (qn / HP) * 16;
+    const f32x4 na = *(const f32x4*)(pn), nb = *(const f32x4*)(pn + 16 * RS);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      acc[2 * P] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[x], xb[j][x], acc[2 * P], 0, 0, 0);
+      acc[2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[x], xb[j][x], acc[2 * P + 1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((q + 1) % (G / 4) == 0) emit((q + 1) / (G / 4) - 1);
+    wa = na;
+    wb = nb;
+  }
+}
+
 template <int K, int N, int EPI>
 __global__ __launch_bounds__(256, 1) void tall_linear_lds_f32_k(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw, int trans_w,
@@ -219,21 +245,150 @@ __global__ __launch_bounds__(256, 1) void tall_linear_lds_f32_k(
   for (int slot = 0; slot < 8; ++slot) emit(slot);
 }
 
+// 8-wave variant: two waves per SIMD over the same LDS image, 16-row steps.  While one wave of a SIMD is between phases
+// (waiting for its X tile, issuing stores, copying registers) the other one owns the matrix pipe: the load / MFMA /
+// store phases that are strictly additive with one wave per SIMD overlap across the pair.
+template <int K, int N, int EPI>
+__global__ __launch_bounds__(512, 2) void tall_linear_lds8_f32_k(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw, int trans_w,
+    const float* __restrict__ bias, int64_t M, int rows_per_wave, float* __restrict__ Y, int64_t ldy,
+    const float* __restrict__ aux_in, float* __restrict__ aux_out, int64_t ldaux) {
+  constexpr int RS = K + 4, KJ = K / 16, NTH = 512;
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  float* wimg = smem_f;
+  float* bimg = smem_f + N * RS;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t wave = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+  int64_t r0 = wave * rows_per_wave;
+  const int64_t r1 = r0 + rows_per_wave < M ? r0 + rows_per_wave : M;
+  f32x4 xb[KJ], xn[KJ];
+  auto load_x = [&](int64_t r, f32x4 (&dst)[KJ]) {
+    int64_t row = r + c;
+    row = row < M ? row : M - 1;
+    const float* p = X + row * ldx + 4 * g;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) dst[j] = *(const f32x4*)(p + 16 * j);
+  };
+  load_x(r0 < M ? r0 : M - 1, xb);
+  constexpr int CHUNKS = N * K / 4, BATCH = 8;
+  static_assert(CHUNKS % (NTH * BATCH) == 0, "fill loop assumes a whole number of batches");
+  for (int base = threadIdx.x; base < CHUNKS; base += NTH * BATCH) {
+    f32x4 v[BATCH];
+    if (!trans_w) {
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * NTH, n = idx / (K / 4), ch = idx - n * (K / 4);
+        v[u] = *(const f32x4*)(W + (size_t)n * ldw + ch * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * NTH, n = idx / (K / 4), ch = idx - n * (K / 4);
+        *(f32x4*)(wimg + w_lds_row(n) * RS + ch * 4) = v[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * NTH, k = idx / (N / 4), n4 = (idx - k * (N / 4)) * 4;
+        v[u] = *(const f32x4*)(W + (size_t)k * ldw + n4);
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = base + u * NTH, k = idx / (N / 4), n4 = (idx - k * (N / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wimg[w_lds_row(n4 + e) * RS + k] = v[u][e];
+      }
+    }
+  }
+  for (int n = threadIdx.x; n < N; n += NTH) bimg[n] = bias != nullptr ? bias[n] : 0.f;
+  __syncthreads();
+  if (r0 >= r1) return;
+  const float* wlane = wimg + c * RS + 4 * g;
+
+  f32x4 pend[8];
+  int64_t pend_r0 = 0;
+  int pend_nh = 0;
+  bool pend_valid = false;
+  auto emit = [&](int tp) {
+    if (!pend_valid) return;
+    const int64_t row = pend_r0 + c;
+    if (row >= r1) return;
+    const int n0 = 128 * pend_nh + 32 * tp + 8 * g;
+    const f32x4 b0 = *(const f32x4*)(bimg + n0), b1 = *(const f32x4*)(bimg + n0 + 4);
+    f32x4 v0 = pend[2 * tp] + b0, v1 = pend[2 * tp + 1] + b1;
+    if (EPI == kEpiGelu || EPI == kEpiRelu) {
+      if (aux_out != nullptr) {
+        *(f32x4*)(aux_out + row * ldaux + n0) = v0;
+        *(f32x4*)(aux_out + row * ldaux + n0 + 4) = v1;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v0[r] = EPI == kEpiGelu ? gelu_f(v0[r]) : fmaxf(v0[r], 0.f);
+        v1[r] = EPI == kEpiGelu ? gelu_f(v1[r]) : fmaxf(v1[r], 0.f);
+      }
+    }
+    if (EPI == kEpiMulGeluGrad || EPI == kEpiMulReluGrad) {
+      const f32x4 p0 = *(const f32x4*)(aux_in + row * ldaux + n0), p1 = *(const f32x4*)(aux_in + row * ldaux + n0 + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v0[r] *= EPI == kEpiMulGeluGrad ? gelu_grad_f(p0[r]) : (p0[r] > 0.f ? 1.f : 0.f);
+        v1[r] *= EPI == kEpiMulGeluGrad ? gelu_grad_f(p1[r]) : (p1[r] > 0.f ? 1.f : 0.f);
+      }
+    }
+    if (EPI == kEpiAdd) {
+      v0 += *(const f32x4*)(aux_in + row * ldaux + n0);
+      v1 += *(const f32x4*)(aux_in + row * ldaux + n0 + 4);
+    }
+    *(f32x4*)(Y + row * ldy + n0) = v0;
+    *(f32x4*)(Y + row * ldy + n0 + 4) = v1;
+  };
+
+  for (; r0 < r1; r0 += 16) {
+    asm volatile("" ::: "memory");
+    const bool more = r0 + 16 < r1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see tall_linear_lds_f32_k
+    if (more) load_x(r0 + 16, xn);
+#pragma unroll
+    for (int nh = 0; nh < N / 128; ++nh) {
+      f32x4 acc[8];
+#pragma unroll
+      for (int T = 0; T < 8; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mfma_phase_single<K>(wlane + nh * 8 * 16 * RS, xb, acc, emit);
+#pragma unroll
+      for (int T = 0; T < 8; ++T) pend[T] = acc[T];
+      pend_r0 = r0;
+      pend_nh = nh;
+      pend_valid = true;
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) xb[j] = xn[j];
+    }
+  }
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp) emit(tp);
+}
+
 template <int K, int N, int EPI>
 int launch_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, int trans_w, const float* bias, int64_t m,
                   float* y, int64_t ldy, const float* aux_in, float* aux_out, int64_t ldaux, hipStream_t st) {
   constexpr int lds = (N * (K + 4) + N) * 4;
-  static bool configured = false;
-  if (!configured) {
+  static int variant = -1;  // SST_AMD_LDS_LINEAR_WAVES = 4: one wave per SIMD, 32-row steps; 8 (default): two, 16-row steps
+  if (variant < 0) {
+    const char* e = getenv("SST_AMD_LDS_LINEAR_WAVES");
+    variant = (e != nullptr && atoi(e) == 4) ? 4 : 8;
     SST_HIP(hipFuncSetAttribute((const void*)tall_linear_lds_f32_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
+    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_lds8_f32_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   // one workgroup per CU (up to 136 KB of LDS); every wave a contiguous row range, a multiple of 8
-  int64_t blocks = 256;  // one wave per SIMD: the epilogue of a phase is software-pipelined under the next phase's MFMAs
-  int64_t rpw = sst_align_up(sst_div_up(m, blocks * 4), 8);
-  blocks = sst_div_up(m, rpw * 4);
-  hipLaunchKernelGGL((tall_linear_lds_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, x, ldx, w, ldw, trans_w,
-                     bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux);
+  int64_t blocks = 256;
+  int64_t rpw = sst_align_up(sst_div_up(m, blocks * variant), 8);
+  blocks = sst_div_up(m, rpw * variant);
+  if (variant == 4)
+    hipLaunchKernelGGL((tall_linear_lds_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, x, ldx, w, ldw, trans_w,
+                       bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux);
+  else
+    hipLaunchKernelGGL((tall_linear_lds8_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(512), lds, st, x, ldx, w, ldw,
+                       trans_w, bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux);
   return SST_OK;
 }
 

@@ -143,12 +143,12 @@ _TALL_GEMM = int(_os.environ.get('SST_AMD_TALL_GEMM', '1'))
 # 38 us for the plain product, i.e. 16.2 ms per step instead of 14.6 with the library GEMM + torch's HBM-bound GELU kernels.
 _FUSED_GELU = int(_os.environ.get('SST_AMD_FUSED_GELU', '0'))
 # Exact-fp32 linears with the weight matrix resident in LDS and the activation / residual arithmetic in their epilogues
-# (csrc/dense_f32.hip; the bf16 mode's kernels are built the same way and are 2-3x faster than the library there).
-# Measured and NOT the default in fp32 (profiles/r02, tools/lds_linear_only.py): with one wave per SIMD the fp32 matrix
-# pipe runs at 80 % inside a phase and fill / first-tile latency / store tail stay exposed - 38 / 67 / 70 us for
-# (K, N) = (128,128) / (128,256) / (256,128) against 37 us (csrc/tall_gemm.hip) and 60-63 us (hipBLASLt, TunableOp), so even
-# with the GELU passes folded in the step is 15.8 ms instead of 14.2.  SST_AMD_LDS_LINEAR=1 switches it on.
-_LDS_LINEAR = int(_os.environ.get('SST_AMD_LDS_LINEAR', '0'))
+# (csrc/dense_f32.hip; the bf16 mode's kernels are built the same way).  Default since the 8-wave variant: 35 / 62 / 65 us
+# for (K, N) = (128,128) / (128,256) / (256,128) against 37 us (csrc/tall_gemm.hip) and 60-63 us (hipBLASLt, TunableOp) -
+# the products themselves are at the sustained fp32 MFMA rate either way (47 us floor at 2.07 GHz for the 256-wide ones) -
+# and torch's GELU / GELU-backward passes over [M, 256] (0.85 ms per step) are gone: 14.1 ms per step against 14.2-14.4.
+# SST_AMD_LDS_LINEAR=0 restores the library GEMMs + csrc/tall_gemm.hip + torch's GELU kernels.
+_LDS_LINEAR = int(_os.environ.get('SST_AMD_LDS_LINEAR', '1'))
 
 
 def _linear_fwd(x, w, b):
