@@ -303,7 +303,7 @@ def layer_supported(enc, plan, m):
     return (enc.post_norm and not wa.cosine and isinstance(enc.norm1, torch.nn.LayerNorm)
             and isinstance(enc.norm2, torch.nn.LayerNorm) and enc.act_name in ('gelu', 'relu')
             and isinstance(plan, K.WindowPlan) and plan.n_tokens == m and plan.max_tokens <= 144
-            and wa.d_model == 128 and enc.linear1.out_features == 256      # the shapes csrc/dense_bf16.hip is built for
+            and wa.d_model == 128 and wa.head_dim == 16 and enc.linear1.out_features == 256      # the shapes csrc/dense_bf16.hip is built for
             and not (enc.training and (wa.attn_dropout > 0 or enc.dropout.p > 0)))
 
 

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
+from .sra_composed import sra_attention_composed
 from .dense import (EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
                     tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
                     weight_bias_grad)
@@ -79,8 +80,11 @@ class WindowAttention(nn.Module):
         super().__init__()
         self.nhead = nhead
         self.d_model = d_model
-        if d_model % nhead != 0 or d_model // nhead != 16:
-            raise NotImplementedError('the SRA kernels are built for head_dim 16 (every SST config: 128/8, 192/12)')
+        if d_model % nhead != 0:
+            raise ValueError('embed_dim must be divisible by num_heads')     # nn.MultiheadAttention's own check
+        # head_dim 16 (every SST config: 128/8, 192/12) runs on the SRA kernels; any other one, and attention-weight
+        # dropout in training, on the composed path of sst_amd/sra_composed.py
+        self.head_dim = d_model // nhead
         self.cosine = layer_cfg.get('cosine', False)
         if self.cosine:
             tau_min = layer_cfg.get('tau_min', 0.01)
@@ -104,9 +108,7 @@ class WindowAttention(nn.Module):
             ind_dict: kernels.WindowPlan (or the reference's flat2win dict).
             key_padding_dict: unused (there is no padding); accepted for signature parity.
         '''
-        if self.attn_dropout > 0 and self.training:
-            raise NotImplementedError('attention-weight dropout is not implemented in the SRA kernels '
-                                      '(every SST/FSD config uses dropout=0)')
+        composed = self.head_dim != 16 or (self.attn_dropout > 0 and self.training)
         if isinstance(ind_dict, K.WindowPlan):
             plan, pos = ind_dict, pos_dict
         else:
@@ -122,11 +124,17 @@ class WindowAttention(nn.Module):
         v = tall_linear(x, w[2 * c:], b[2 * c:])
         if self.cosine:
             h = self.nhead
-            q = F.normalize(qk[:, :c].reshape(-1, h, 16), dim=2)
-            k = F.normalize(qk[:, c:].reshape(-1, h, 16), dim=2)
+            q = F.normalize(qk[:, :c].reshape(-1, h, self.head_dim), dim=2)
+            k = F.normalize(qk[:, c:].reshape(-1, h, self.head_dim), dim=2)
             tau = attn.tau.clamp(min=attn.tau_min).reshape(1, -1, 1)  # [1,1,1] or [1,h,1]
             q = (q / tau).reshape(-1, c)
-            o = K.sra_attention(q, k.reshape(-1, c), v, plan, h, scale=1.0, impl=self.impl)
+            if composed:
+                o = sra_attention_composed(q, k.reshape(-1, c), v, plan, h, 1.0, self.attn_dropout, self.training)
+            else:
+                o = K.sra_attention(q, k.reshape(-1, c), v, plan, h, scale=1.0, impl=self.impl)
+        elif composed:
+            o = sra_attention_composed(qk[:, :c], qk[:, c:], v, plan, self.nhead, 1.0 / math.sqrt(self.head_dim),
+                                       self.attn_dropout, self.training)
         else:
             o = K.sra_attention_qk_v(qk, v, plan, self.nhead, scale=1.0 / math.sqrt(16.0), impl=self.impl)
         return tall_linear(o, attn.out_proj.weight, attn.out_proj.bias)
@@ -286,7 +294,7 @@ class EncoderLayer(nn.Module):
         wa = self.win_attn
         return (self.fused and self.post_norm and isinstance(ind_dict, K.WindowPlan)
                 and ind_dict.n_tokens == src.size(0)
-                and (pos_dict is None or torch.is_tensor(pos_dict)) and not wa.cosine
+                and (pos_dict is None or torch.is_tensor(pos_dict)) and not wa.cosine and wa.head_dim == 16
                 and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
                 and self.act_name in ('gelu', 'relu') and src.dtype == torch.float32 and src.is_cuda
                 and src.size(1) % 32 == 0 and self.linear1.out_features % 32 == 0

@@ -273,3 +273,61 @@ def test_sstv2_bev_and_attached_convs_match_reference_golden(tag, shortcut):
     for key in [k for k in g if k.startswith('grad::')]:
         got = params[key[6:]].grad.cpu().numpy()
         assert np.abs(got - g[key]).max() < TOL * 5 * max(1.0, float(np.abs(g[key]).max())), key
+
+
+@pytest.mark.parametrize('heads', [4, 2])
+def test_composed_attention_other_head_dims_vs_oracle(heads):
+    """head_dim 32 / 64 (nn.MultiheadAttention accepts any divisor; no SST config uses them): composed path, fwd + bwd"""
+    from sst_amd.sra_composed import sra_attention_composed
+    from sst_amd import kernels as K
+    from oracle import sst_oracle
+    rng = np.random.default_rng(heads)
+    sizes = [1, 5, 16, 30, 47, 60, 3, 100]
+    m = sum(sizes)
+    tok = rng.permutation(m).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    plan = K.WindowPlan(torch.from_numpy(tok).to(DEV), torch.from_numpy(off).to(DEV), len(sizes), m, max(sizes))
+    g = torch.Generator().manual_seed(heads)
+    q, k, v, do = (torch.randn(m, 128, generator=g) for _ in range(4))
+    qg, kg, vg = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    scale = 1.0 / (128 // heads) ** 0.5
+    o = sra_attention_composed(qg, kg, vg, plan, heads, scale)
+    ref = sst_oracle.sra_core(q.numpy(), k.numpy(), v.numpy(), tok, off, heads)
+    assert np.abs(o.detach().cpu().numpy() - ref).max() < 1e-4
+    (o * do.to(DEV)).sum().backward()
+    for got, want in zip((qg.grad, kg.grad, vg.grad), sst_oracle.sra_core_backward(q.numpy(), k.numpy(), v.numpy(),
+                                                                                  do.numpy(), tok, off, heads)):
+        assert np.abs(got.cpu().numpy() - want).max() < 1e-3
+
+
+def test_encoder_layer_attention_dropout_and_head_dim_32():
+    """attention-weight dropout > 0: identity in eval mode, active in training; a head_dim-32 layer runs end to end"""
+    import sst_amd
+    from sst_amd import kernels as K
+    rng = np.random.default_rng(3)
+    sizes = [20, 33, 60, 7]
+    m = sum(sizes)
+    plan = K.WindowPlan(torch.from_numpy(rng.permutation(m).astype(np.int32)).to(DEV),
+                        torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(DEV), len(sizes), m,
+                        max(sizes))
+    torch.manual_seed(0)
+    plain = sst_amd.EncoderLayer(128, 8, 256, dropout=0.0).to(DEV)
+    drop = sst_amd.EncoderLayer(128, 8, 256, dropout=0.2).to(DEV)
+    drop.load_state_dict(plain.state_dict())
+    x = torch.randn(m, 128, device=DEV)
+    pos = torch.randn(m, 128, device=DEV)
+    plain.eval(), drop.eval()
+    with torch.no_grad():
+        assert torch.allclose(plain(x, pos, plan), drop(x, pos, plan), atol=1e-5)
+    drop.train()
+    xa = x.clone().requires_grad_(True)
+    out = drop(xa, pos, plan)
+    out.square().sum().backward()
+    assert torch.isfinite(out).all() and torch.isfinite(xa.grad).all()
+    with torch.no_grad():
+        assert float((out - plain(x, pos, plan)).abs().max()) > 1e-3          # the dropout did something
+    wide = sst_amd.EncoderLayer(128, 4, 256, dropout=0.0).to(DEV).train()     # head_dim 32
+    xb = x.clone().requires_grad_(True)
+    y = wide(xb, pos, plan)
+    y.square().sum().backward()
+    assert y.shape == x.shape and torch.isfinite(xb.grad).all()
