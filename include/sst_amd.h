@@ -342,6 +342,14 @@ int sst_cast_add_pos_bf16(const void* d_x, int x_is_bf16, int64_t m, int c, cons
 int sst_tall_linear_bf16(const void* d_x, int64_t ldx, const void* d_w, const float* d_bias, int64_t m, int k, int n,
                          int epilogue, const void* d_aux_in, void* d_aux_out, int64_t ldaux, void* d_y, int64_t ldy,
                          void* stream);
+/* sst_tall_linear_ln_bf16: y = LayerNorm(x w^T + bias + res) - `norm(src + src2)` (sst_basic_block_v2.py:113-118) in the
+ * epilogue of the projection that produces src2 (out_proj, linear2): n = 128, k = 128 or 256.  Also written: d_sum (bf16
+ * [m, 128], row stride ldres like d_res; the backward pass's input; may be NULL), d_stats [m, 2] fp32 (mean, rstd), and, when
+ * the positional arguments are given, d_y_plus_pos = y + pos_table[pos_idx[row]] (the next layer's q / k input). */
+int sst_tall_linear_ln_bf16(const void* d_x, int64_t ldx, const void* d_w, const float* d_bias, int64_t m, int k,
+                            const void* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
+                            void* d_y, void* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
+                            void* d_y_plus_pos, void* stream);
 typedef struct sst_wgrad_problem_bf16 {
   const void* a;   /* bf16 [m, p], row stride lda */
   const void* b;   /* bf16 [m, 128], row stride ldb */

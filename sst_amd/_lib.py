@@ -77,6 +77,8 @@ _SIGNATURES = {
                                         c_i64, c_ptr, c_i64, c_ptr]),
     'sst_tall_linear_bf16': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr,
                                      c_i64, c_ptr]),
+    'sst_tall_linear_ln_bf16': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr, c_ptr,
+                                        c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_wgrad_group_workspace_bytes': (c_i64, [c_ptr, c_i32]),
     'sst_wgrad_group_bf16': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
     'sst_gather_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_i64, c_ptr]),

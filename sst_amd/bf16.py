@@ -28,6 +28,8 @@ from . import _lib
 from . import kernels as K
 
 BF16 = torch.bfloat16
+# residual + LayerNorm in the epilogue of the projection in front of it (SST_AMD_BF16_FUSED_LN=0: separate LayerNorm kernel)
+_FUSED_LN = int(__import__('os').environ.get('SST_AMD_BF16_FUSED_LN', '1'))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -171,6 +173,24 @@ def tall_linear(x, w, bias=None, epilogue=EPI_BIAS, aux_in=None, want_pre=False)
     return (y, pre) if want_pre else y
 
 
+def linear_add_ln(x, w, bias, res, ln_weight, ln_bias, eps, save_sum=True, pos=None):
+    """(y, s, stats, y_plus_pos) with y = LayerNorm(x @ w^T + bias + res): the projection and `norm(src + src2)` in one
+    kernel (csrc/dense_bf16.hip, kEpiAddLN); w bf16 [128, K], K = 128 | 256."""
+    m, k = x.shape
+    if w.shape != (128, k) or k not in (128, 256) or x.dtype != BF16 or res.shape != (m, 128) or not res.is_contiguous():
+        raise RuntimeError('sst_amd.bf16.linear_add_ln: unsupported operands')
+    y = torch.empty((m, 128), dtype=BF16, device=x.device)
+    s = torch.empty((m, 128), dtype=BF16, device=x.device) if save_sum else None
+    stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
+    yp = torch.empty((m, 128), dtype=BF16, device=x.device) if pos is not None else None
+    rc = _lib.load().sst_tall_linear_ln_bf16(
+        _lib.ptr(x), _ld(x), _lib.ptr(w), _lib.ptr(bias), m, k, _lib.ptr(res), 128, _lib.ptr(ln_weight), _lib.ptr(ln_bias),
+        float(eps), _lib.ptr(y), _lib.ptr(s), _lib.ptr(stats), _lib.ptr(pos[0]) if pos is not None else None,
+        _lib.ptr(pos[1]) if pos is not None else None, _lib.ptr(yp), _lib.stream_ptr())
+    _lib.check(rc, 'sst_tall_linear_ln_bf16')
+    return y, s, stats, yp
+
+
 def wgrad_group(problems):
     """Weight / bias gradients of several tall products in ONE launch (csrc/dense_bf16.hip).
     problems: list of (a bf16 [M, P], b bf16 [M, 128], out_w fp32, out_b fp32 | None, bias_side, transpose_out);
@@ -244,7 +264,7 @@ class EncoderLayerBF16Fn(Function):
     """One post-norm SRA encoder layer (sst_basic_block_v2.py:104-119) in the reduced-precision mode, as one autograd node.
     Inputs x and xp = x + positional embedding (bf16); outputs the layer result and (when ``pos_next`` is given) the
     result + the next layer's positional embedding.  Kernel sequence, forward: 2 projections, attention core,
-    out-projection, add+LayerNorm, linear1+activation, linear2, add+LayerNorm (8 launches); backward: 2 LayerNorm, 5 data
+    out-projection+add+LayerNorm, linear1+activation, linear2+add+LayerNorm (6 launches); backward: 2 LayerNorm, 5 data
     gradients, attention core, ONE grouped weight-gradient launch + its reduction (10 launches)."""
 
     @staticmethod
@@ -255,12 +275,18 @@ class EncoderLayerBF16Fn(Function):
         v = tall_linear(x, shadow(w_in, (2 * c, 3 * c)), b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
         o, lse = sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale)
-        a = tall_linear(o, shadow(w_out), b_out)
         need_bwd = any(ctx.needs_input_grad)
-        y1, s1, st1, _ = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
-        h, pre = tall_linear(y1, shadow(w1), b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
-        f = tall_linear(h, shadow(w2), b2)
-        y2, s2, st2, y2p = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd, pos=pos_next)
+        if _FUSED_LN:
+            # out-projection + residual + LayerNorm, linear1 + activation, linear2 + residual + LayerNorm: three launches
+            y1, s1, st1, _ = linear_add_ln(o, shadow(w_out), b_out, x, n1w, n1b, eps, save_sum=need_bwd)
+            h, pre = tall_linear(y1, shadow(w1), b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
+            y2, s2, st2, y2p = linear_add_ln(h, shadow(w2), b2, y1, n2w, n2b, eps, save_sum=need_bwd, pos=pos_next)
+        else:
+            a = tall_linear(o, shadow(w_out), b_out)
+            y1, s1, st1, _ = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
+            h, pre = tall_linear(y1, shadow(w1), b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
+            f = tall_linear(h, shadow(w2), b2)
+            y2, s2, st2, y2p = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd, pos=pos_next)
         if need_bwd:
             ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
             ctx.plan, ctx.nhead, ctx.act, ctx.scale, ctx.two = plan, nhead, act, scale, y2p is not None

@@ -61,7 +61,21 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // ------------------------------------------------------------------------------------------------------------------
 // Y = epi(X W^T + b)
 // ------------------------------------------------------------------------------------------------------------------
-enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5 };
+enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5, kEpiAddLN = 6 };
+
+// kEpiAddLN (N = 128): y = LayerNorm(x W^T + bias + residual) - `norm(src + src2)` of sst_basic_block_v2.py:113-118 in the
+// epilogue of the projection that produces src2 (out_proj / linear2).  A row's 128 columns sit in the four lanes (g = 0..3)
+// of its MFMA column, 32 values each: two shuffle reductions give the statistics.  Also written: the sum (bf16, for the
+// backward pass), (mean, rstd), and optionally y + pos_table[pos_idx[row]] (the next layer's q / k input).
+struct ln_epi {
+  const float* w;
+  const float* b;
+  float eps;
+  float2* stats;
+  const float* pos_table;
+  const int32_t* pos_idx;
+  bf16_t* yp;
+};
 
 // LDS image of W: row rho = 16 T + i holds W[n(T, i)][0..K), n(T, i) = 32 (T >> 1) + 8 (i >> 2) + 4 (T & 1) + (i & 3):
 // tile pair (2 tp, 2 tp + 1) then leaves lane (g, c) with columns 32 tp + 8 g .. + 7 of row c.
@@ -70,19 +84,20 @@ __device__ __forceinline__ int w_lds_row(int n) {
   return 16 * (2 * tp + ((within >> 2) & 1)) + ((within >> 3) << 2) + (within & 3);
 }
 
-template <int K, int N, int EPI>
-__global__ __launch_bounds__(256, (K * N <= 128 * 128 ? 3 : 2)) void tall_linear_bf16_k(const bf16_t* __restrict__ X, int64_t ldx,
+template <int K, int N, int EPI, int NTH>
+__global__ __launch_bounds__(NTH, (NTH == 512 ? 2 : (K * N <= 128 * 128 ? 3 : 2))) void tall_linear_bf16_k(const bf16_t* __restrict__ X, int64_t ldx,
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                              int64_t M, int rows_per_wave, bf16_t* __restrict__ Y,
                                                              int64_t ldy, const bf16_t* __restrict__ aux_in,
-                                                             bf16_t* __restrict__ aux_out, int64_t ldaux) {
+                                                             bf16_t* __restrict__ aux_out, int64_t ldaux, const ln_epi ln) {
+  static_assert(EPI != kEpiAddLN || N == 128, "the LayerNorm epilogue needs a whole row in one accumulator set");
   constexpr int RS = K * 2 + 16;  // LDS row stride in bytes: 16-byte lanes of one ds_read_b128 phase on distinct banks
   constexpr int KS = K / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wimg = smem;
-  float* bimg = (float*)(smem + N * RS);
+  float* bimg = (float*)(smem + N * RS);  // [N] bias, then (kEpiAddLN) [N] LayerNorm weight, [N] LayerNorm bias
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * (NTH / 64) + (threadIdx.x >> 6);
   int64_t r0 = wave * rows_per_wave;
   const int64_t r1 = r0 + rows_per_wave < M ? r0 + rows_per_wave : M;
   u32x4 xb[2][KS], xn[2][KS];
@@ -99,22 +114,28 @@ __global__ __launch_bounds__(256, (K * N <= 128 * 128 ? 3 : 2)) void tall_linear
   load_x(r0 < M ? r0 : M - 1, xb);  // the first row tile is in flight while the weights are copied to LDS
   // weight fill: batches of 8 independent 16-byte loads per thread, then the LDS writes (a load -> write loop would be
   // paced by one L2 round trip per iteration)
-  constexpr int CHUNKS = N * K / 8, BATCH = 8;
-  static_assert(CHUNKS % (256 * BATCH) == 0, "fill loop assumes a whole number of batches");
-  for (int base = threadIdx.x; base < CHUNKS; base += 256 * BATCH) {
+  constexpr int CHUNKS = N * K / 8, BATCH = (CHUNKS / NTH >= 8 ? 8 : CHUNKS / NTH);
+  static_assert(CHUNKS % (NTH * BATCH) == 0, "fill loop assumes a whole number of batches");
+  for (int base = threadIdx.x; base < CHUNKS; base += NTH * BATCH) {
     u32x4 v[BATCH];
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
-      const int idx = base + u * 256, n = idx / (K / 8), ch = idx - n * (K / 8);
+      const int idx = base + u * NTH, n = idx / (K / 8), ch = idx - n * (K / 8);
       v[u] = *(const u32x4*)(W + (size_t)n * K + ch * 8);
     }
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
-      const int idx = base + u * 256, n = idx / (K / 8), ch = idx - n * (K / 8);
+      const int idx = base + u * NTH, n = idx / (K / 8), ch = idx - n * (K / 8);
       *(u32x4*)(wimg + w_lds_row(n) * RS + ch * 16) = v[u];
     }
   }
-  for (int n = threadIdx.x; n < N; n += 256) bimg[n] = bias != nullptr ? bias[n] : 0.f;
+  for (int n = threadIdx.x; n < N; n += NTH) {
+    bimg[n] = bias != nullptr ? bias[n] : 0.f;
+    if (EPI == kEpiAddLN) {
+      bimg[N + n] = ln.w[n];
+      bimg[2 * N + n] = ln.b[n];
+    }
+  }
   __syncthreads();
   if (r0 >= r1) return;
   const unsigned char* wlane = wimg + c * RS + g * 16;
@@ -143,6 +164,70 @@ __global__ __launch_bounds__(256, (K * N <= 128 * 128 ? 3 : 2)) void tall_linear
         acc[1][T] = mma32(wf, xb[1][s], acc[1][T]);
       }
     }
+    if (EPI == kEpiAddLN) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int64_t row = r0 + 16 * t + c;
+        if (row < r1) {  // uniform over the four lanes (g) that share the row
+          float v[4][8];
+          float sum = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < 4; ++tp) {
+            const int n0 = 32 * tp + 8 * g;
+            const f32x4 b0 = *(const f32x4*)(bimg + n0), b1 = *(const f32x4*)(bimg + n0 + 4);
+            const u32x4 res = *(const u32x4*)(aux_in + row * ldaux + n0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[tp][r] = acc[t][2 * tp][r] + b0[r];
+              v[tp][4 + r] = acc[t][2 * tp + 1][r] + b1[r];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[tp][2 * q] += lo_f(res[q]);
+              v[tp][2 * q + 1] += hi_f(res[q]);
+            }
+            if (aux_out != nullptr)
+              *(u32x4*)(aux_out + row * ldaux + n0) =
+                  (u32x4){pack2(v[tp][0], v[tp][1]), pack2(v[tp][2], v[tp][3]), pack2(v[tp][4], v[tp][5]), pack2(v[tp][6], v[tp][7])};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[tp][e];
+          }
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          const float mean = sum * (1.f / 128.f);
+          float sq = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[tp][e] -= mean;
+              sq = fmaf(v[tp][e], v[tp][e], sq);
+            }
+          sq += __shfl_xor(sq, 16, 64);
+          sq += __shfl_xor(sq, 32, 64);
+          const float rstd = rsqrtf(sq * (1.f / 128.f) + ln.eps);
+          if (g == 0) ln.stats[row] = make_float2(mean, rstd);
+          const float* prow = ln.yp != nullptr ? ln.pos_table + (size_t)ln.pos_idx[row] * 128 : nullptr;
+#pragma unroll
+          for (int tp = 0; tp < 4; ++tp) {
+            const int n0 = 32 * tp + 8 * g;
+            float y[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 gw = *(const f32x4*)(bimg + N + n0 + 4 * h), gb = *(const f32x4*)(bimg + 2 * N + n0 + 4 * h);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) y[4 * h + r] = fmaf(v[tp][4 * h + r] * rstd, gw[r], gb[r]);
+            }
+            *(u32x4*)(Y + row * ldy + n0) = (u32x4){pack2(y[0], y[1]), pack2(y[2], y[3]), pack2(y[4], y[5]), pack2(y[6], y[7])};
+            if (ln.yp != nullptr) {
+              const f32x4 p0 = *(const f32x4*)(prow + n0), p1 = *(const f32x4*)(prow + n0 + 4);
+              *(u32x4*)(ln.yp + row * 128 + n0) = (u32x4){pack2(y[0] + p0[0], y[1] + p0[1]), pack2(y[2] + p0[2], y[3] + p0[3]),
+                                                          pack2(y[4] + p1[0], y[5] + p1[1]), pack2(y[6] + p1[2], y[7] + p1[3])};
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t row = r0 + 16 * t + c;
@@ -192,6 +277,7 @@ __global__ __launch_bounds__(256, (K * N <= 128 * 128 ? 3 : 2)) void tall_linear
       }
     }
     }
+    }
     if (more) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -203,19 +289,27 @@ __global__ __launch_bounds__(256, (K * N <= 128 * 128 ? 3 : 2)) void tall_linear
 
 template <int K, int N, int EPI>
 int launch_linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const float* bias, int64_t m, bf16_t* y, int64_t ldy,
-                  const bf16_t* aux_in, bf16_t* aux_out, int64_t ldaux, hipStream_t st) {
-  constexpr int lds = N * (K * 2 + 16) + N * 4;
-  static bool configured = false;
-  if (!configured) {
-    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_bf16_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
+                  const bf16_t* aux_in, bf16_t* aux_out, int64_t ldaux, hipStream_t st, const ln_epi ln = ln_epi()) {
+  constexpr int lds = N * (K * 2 + 16) + N * 4 * (EPI == kEpiAddLN ? 3 : 1);
+  // SST_AMD_BF16_LINEAR_WAVES = 8: one 8-wave workgroup per CU (the weights are copied to LDS once per CU, not 2-3 times)
+  static int nth = 0;
+  if (nth == 0) {
+    const char* e = getenv("SST_AMD_BF16_LINEAR_WAVES");
+    nth = (e != nullptr && atoi(e) == 8) ? 512 : 256;
+    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_bf16_k<K, N, EPI, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_bf16_k<K, N, EPI, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  // persistent shape: 2 workgroups per CU, every wave a contiguous row range (multiple of 16 rows)
-  int64_t blocks = 256 * (lds <= 40 * 1024 ? 3 : 2);
-  int64_t rpw = sst_align_up(sst_div_up(m, blocks * 4), 16);
-  blocks = sst_div_up(m, rpw * 4);
-  hipLaunchKernelGGL((tall_linear_bf16_k<K, N, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, x, ldx, w, bias, m, (int)rpw,
-                     y, ldy, aux_in, aux_out, ldaux);
+  // persistent shape: every wave a contiguous row range (multiple of 16 rows)
+  const int wpb = nth / 64;
+  int64_t blocks = nth == 512 ? 256 : 256 * (lds <= 40 * 1024 ? 3 : 2);
+  int64_t rpw = sst_align_up(sst_div_up(m, blocks * wpb), 16);
+  blocks = sst_div_up(m, rpw * wpb);
+  if (nth == 512)
+    hipLaunchKernelGGL((tall_linear_bf16_k<K, N, EPI, 512>), dim3((unsigned)blocks), dim3(512), lds, st, x, ldx, w, bias, m,
+                       (int)rpw, y, ldy, aux_in, aux_out, ldaux, ln);
+  else
+    hipLaunchKernelGGL((tall_linear_bf16_k<K, N, EPI, 256>), dim3((unsigned)blocks), dim3(256), lds, st, x, ldx, w, bias, m,
+                       (int)rpw, y, ldy, aux_in, aux_out, ldaux, ln);
   return SST_OK;
 }
 
@@ -482,6 +576,41 @@ int sst_tall_linear_bf16(const void* d_x, int64_t ldx, const void* d_w, const fl
   return SST_OK;
 }
 
+
+int sst_tall_linear_ln_bf16(const void* d_x, int64_t ldx, const void* d_w, const float* d_bias, int64_t m, int k,
+                            const void* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
+                            void* d_y, void* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
+                            void* d_y_plus_pos, void* stream) {
+  if (m < 0 || !d_w || !d_ln_weight || !d_ln_bias || !d_stats) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_y || !d_res || (ldx & 7) || (ldres & 7) || !aligned16(d_x) || !aligned16(d_y) || !aligned16(d_w) ||
+      !aligned16(d_res) || (d_sum && !aligned16(d_sum)))
+    return SST_ERR_ARG;
+  if ((d_pos_table != nullptr) != (d_pos_idx != nullptr) || (d_pos_table != nullptr) != (d_y_plus_pos != nullptr))
+    return SST_ERR_ARG;
+  ln_epi ln;
+  ln.w = d_ln_weight;
+  ln.b = d_ln_bias;
+  ln.eps = eps;
+  ln.stats = (float2*)d_stats;
+  ln.pos_table = d_pos_table;
+  ln.pos_idx = d_pos_idx;
+  ln.yp = (bf16_t*)d_y_plus_pos;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  // the residual and the stored sum share the row stride ldres (both are [m, 128] activations of the layer)
+  if (k == 128)
+    rc = launch_linear<128, 128, kEpiAddLN>((const bf16_t*)d_x, ldx, (const bf16_t*)d_w, d_bias, m, (bf16_t*)d_y, 128,
+                                            (const bf16_t*)d_res, (bf16_t*)d_sum, ldres, st, ln);
+  else if (k == 256)
+    rc = launch_linear<256, 128, kEpiAddLN>((const bf16_t*)d_x, ldx, (const bf16_t*)d_w, d_bias, m, (bf16_t*)d_y, 128,
+                                            (const bf16_t*)d_res, (bf16_t*)d_sum, ldres, st, ln);
+  else
+    return SST_ERR_UNSUPPORTED;
+  if (rc) return rc;
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
 
 // problems: n x sst_wgrad_problem_bf16 (host array, include/sst_amd.h).  workspace: sst_wgrad_group_workspace_bytes.
 int64_t sst_wgrad_group_workspace_bytes(const sst_wgrad_problem_bf16* problems, int n) {

@@ -133,6 +133,33 @@ def test_tall_linear_bf16(m, k, n):
     assert float((y.float() - want).abs().max()) < tol(want)
 
 
+@pytest.mark.parametrize('m', [1, 77, 5000, 90107])
+@pytest.mark.parametrize('k', [128, 256])
+def test_linear_add_layernorm_bf16(m, k):
+    """projection + residual + LayerNorm (+ positional second output) in one kernel against fp32 torch"""
+    from sst_amd import bf16
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g).to(BF).to(DEV)
+    res = torch.randn(m, 128, generator=g).to(BF).to(DEV)
+    w = (torch.randn(128, k, generator=g) / k ** 0.5).to(BF).to(DEV)
+    b = torch.randn(128, generator=g).to(DEV)
+    lw = (1 + 0.1 * torch.randn(128, generator=g)).to(DEV)
+    lb = (0.1 * torch.randn(128, generator=g)).to(DEV)
+    table = torch.randn(144, 128, generator=g).to(DEV)
+    idx = torch.randint(0, 144, (m,), generator=g).to(torch.int32).to(DEV)
+    y, s, stats, yp = bf16.linear_add_ln(x, w, b, res, lw, lb, 1e-5, pos=(table, idx))
+    ssum = x.float() @ w.float().t() + b + res.float()
+    ref = torch.nn.functional.layer_norm(ssum, (128,), lw, lb, 1e-5)
+    assert float((s.float() - ssum).abs().max()) < 1.6e-2 * max(1.0, float(ssum.abs().max()))
+    assert float((y.float() - ref).abs().max()) < 3e-2 and float((y.float() - ref).abs().mean()) < 3e-3
+    assert float((yp.float() - (ref + table[idx.long()])).abs().max()) < 5e-2
+    mean, var = ssum.mean(1), ssum.var(1, unbiased=False)
+    assert float((stats[:, 0] - mean).abs().max()) < 1e-3
+    assert float((stats[:, 1] - torch.rsqrt(var + 1e-5)).abs().max()) < 1e-3 * float(torch.rsqrt(var + 1e-5).max())
+    y2, s2, _, none = bf16.linear_add_ln(x, w, b, res, lw, lb, 1e-5, save_sum=False)
+    assert s2 is None and none is None and torch.equal(y2, y)
+
+
 @pytest.mark.parametrize('m', [1, 31, 4097, 90107])
 def test_wgrad_group_bf16(m):
     """the five parameter-gradient products of one encoder layer in one launch, against fp64 on the same operands"""
