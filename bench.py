@@ -90,7 +90,7 @@ class Pipeline(torch.nn.Module):
             info = self.middle_encoder.apply_plan(wplan, voxel_feats)
         else:                               # fused index plan: the voxel encoder is queued before the sizes are read
             voxel_feats, _ = self.voxel_encoder(prepared.points, prepared.coors, scatter_plan=prepared)
-            prepared.want_pos_rows = self.backbone.precision != 'bf16'   # bf16 layers add the embedding in the LN kernel
+            prepared.want_pos_rows = False   # the encoder stacks (fp32 chain and bf16) take (table, row index) instead
             info = prepared.finalize(voxel_feats, self.middle_encoder)
         self.last_voxel_coors = info['voxel_coors']
         return self.backbone(info)[0]['voxel_feats']

@@ -455,6 +455,18 @@ int sst_tall_linear_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t
  *   mode 1: y = (x W [+ b]) * gelu'(aux)      (data gradient through linear2 times the activation's derivative at
  *                                              the pre-activation aux)
  * d_aux has the row stride ldy.  A 256-wide FFN is two calls on column halves of W / y / aux. */
+/* sst_tall_linear_ln_f32: y = LayerNorm(x w^T + bias + res) in exact fp32 - `norm(src + src2)` (sst_basic_block_v2.py:113-118)
+ * in the epilogue of the projection that produces src2 (out_proj, linear2; n = 128, k = 128 | 256; d_w [128][k] rows).  Also
+ * written: d_sum ([m, 128], row stride ldres like d_res; may be NULL), d_stats [m, 2] (mean, rstd), and with the positional
+ * arguments d_y_plus_pos = y + pos_table[pos_idx[row]].  sst_add_layernorm_bwd2_f32: the LayerNorm backward with an
+ * optional SECOND upstream gradient d_dy2 (the one that arrives through y + pos), c = 128. */
+int sst_tall_linear_ln_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias, int64_t m, int k,
+                           const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
+                           float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
+                           float* d_y_plus_pos, void* stream);
+int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
+                               const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
+                               void* d_workspace, void* stream);
 /* sst_tall_linear_epi_f32 (csrc/dense_f32.hip): y[m, n] = epilogue(x[m, k] W^T + bias), exact fp32 (v_mfma_f32_16x16x4_f32),
  * the whole weight matrix resident in LDS; (k, n) in {(128,128), (128,256), (256,128)}.  trans_w = 0: d_w holds W as [n][k]
  * rows (F.linear's weight); trans_w = 1: d_w holds [k][n] rows - the data gradient dy[m, out] w[out, in] of a layer with

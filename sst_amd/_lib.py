@@ -73,6 +73,9 @@ _SIGNATURES = {
     'sst_add_layernorm_bwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_ptr]),
     'sst_cast_add_pos_bf16': (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_tall_linear_ln_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr,
+                                       c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_add_layernorm_bwd2_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_tall_linear_epi_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr,
                                         c_i64, c_ptr, c_i64, c_ptr]),
     'sst_tall_linear_bf16': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr,

@@ -130,6 +130,16 @@ class _WindowTransformer(nn.Module):
             layers = [enc for block in self.block_list for enc in block.encoder_list]
             if all(bf16.layer_supported(enc, plans[i % 2], x.size(0)) for i, enc in enumerate(layers)):
                 return bf16.run_encoder_stack(self.block_list, x, plans, pos_lookup)
+        if (self.precision == 'fp32' and pos_lookup is not None and x.is_cuda and x.dtype == torch.float32
+                and not self.checkpoint_blocks and x.size(1) == 128):
+            # fp32 chain: every layer hands (x, x + positional embedding) to the next one (sst_basic_block.py)
+            from .sst_basic_block import run_encoder_stack_fp32
+            layers = [enc for block in self.block_list for enc in block.encoder_list]
+            if all(enc._can_fuse(x, None, plans[i % 2]) for i, enc in enumerate(layers)):
+                return run_encoder_stack_fp32(self.block_list, x, plans, pos_lookup)
+        if pos_lookup is not None and any(p is None for p in pos):
+            # the caller skipped the [M, C] positional tensors (frame plan with want_pos_rows = False): form them here
+            pos = [t.index_select(0, idx.long()) for t, idx in pos_lookup]
         for i, block in enumerate(self.block_list):
             x = block(x, pos, plans, masks, using_checkpoint=i in self.checkpoint_blocks)
         return x

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restri
 // kernel above issues the two loads of a single row, then two dependent 5-step shuffle reductions: latency-bound
 // at two waves per SIMD, 4.2 TB/s).
 __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_c128_k(const float* __restrict__ dy,
+                                                                const float* __restrict__ dy2,
                                                                 const float* __restrict__ s,
                                                                 const float2* __restrict__ stats,
                                                                 const float* __restrict__ w, int64_t m,
@@ -181,6 +182,10 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_c128_k(const float* __r
       ok[u] = row < m;
       const int64_t rr = ok[u] ? row : row0;  // clamped: loads are unconditional
       d[u] = *(const float4*)(dy + rr * C + col);
+      if (dy2 != nullptr) {  // second gradient arriving at the LayerNorm output (its "+ positional embedding" copy)
+        const float4 e = *(const float4*)(dy2 + rr * C + col);
+        d[u].x += e.x, d[u].y += e.y, d[u].z += e.z, d[u].w += e.w;
+      }
       sv[u] = *(const float4*)(s + rr * C + col);
       st[u] = stats[rr];
     }
@@ -594,9 +599,9 @@ int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c) {
   return (int64_t)1024 * 2 * c * sizeof(float) + 256;
 }
 
-int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats, const float* d_weight,
-                              int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias, void* d_workspace,
-                              void* stream) {
+int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
+                               const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
+                               void* d_workspace, void* stream) {
   if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
   if (!d_dweight || !d_dbias) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -609,8 +614,9 @@ int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float
   int grid = (int)sst_div_up(m, kLnRowsPerBlock * 4);
   if (grid > 512) grid = 512;
   float* partials = (float*)d_workspace;
+  if (d_dy2 != nullptr && c != 128) return SST_ERR_UNSUPPORTED;
   if (c == 128)
-    hipLaunchKernelGGL(add_ln_bwd_c128_k, dim3(grid), dim3(kLnThreads), 0, st, d_dy, d_sum, (const float2*)d_stats,
+    hipLaunchKernelGGL(add_ln_bwd_c128_k, dim3(grid), dim3(kLnThreads), 0, st, d_dy, d_dy2, d_sum, (const float2*)d_stats,
                        d_weight, m, d_dx, partials);
   else
     hipLaunchKernelGGL(add_ln_bwd_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
@@ -619,6 +625,12 @@ int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float
                      d_dbias, c);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats, const float* d_weight,
+                              int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias, void* d_workspace,
+                              void* stream) {
+  return sst_add_layernorm_bwd2_f32(d_dy, nullptr, d_sum, d_stats, d_weight, m, c, d_dx, d_dweight, d_dbias, d_workspace, stream);
 }
 
 int sst_add_layernorm_fwd_bf16(const void* d_x, const void* d_res, const float* d_weight, const float* d_bias, int64_t m,

@@ -40,7 +40,21 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.3989422804014327f, e, phi);
 }
 
-enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5 };
+enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5, kEpiAddLN = 6 };
+
+// kEpiAddLN (N = 128, 8-wave kernel): y = LayerNorm(x W^T + bias + residual) - `norm(src + src2)` of
+// sst_basic_block_v2.py:113-118 in the epilogue of the projection that produces src2.  A row's 128 columns sit in the four
+// lanes (g = 0..3) of its MFMA column: two shuffle reductions give the statistics.  Also written: the sum (for the
+// backward pass), (mean, rstd), and optionally y + pos_table[pos_idx[row]] (the next layer's q / k input).
+struct ln_epi {
+  const float* w;
+  const float* b;
+  float eps;
+  float2* stats;
+  const float* pos_table;
+  const int32_t* pos_idx;
+  float* yp;
+};
 
 __device__ __forceinline__ int w_lds_row(int n) {  // see csrc/dense_bf16.hip
   const int tp = n >> 5, within = n & 31;
@@ -55,7 +69,7 @@ __device__ __forceinline__ void mfma_phase(const float* __restrict__ wbase, cons
                                            EMIT&& emit) {
   constexpr int RS = K + 4, KJ = K / 16, HT = 8, G = KJ * HT;
   f32x4 wf = *(const f32x4*)(wbase);
-#pragma unroll
+#pragma clang loop unroll(full)
   for (int q = 0; q < G; ++q) {
     const int j = q / HT, T = q - j * HT;
     const int qn = q + 1 < G ? q + 1 : q;
@@ -82,7 +96,7 @@ __device__ __forceinline__ void mfma_phase_single(const float* __restrict__ wbas
                                                   EMIT&& emit) {
   constexpr int RS = K + 4, KJ = K / 16, HP = 4, G = KJ * HP;
   f32x4 wa = *(const f32x4*)(wbase), wb = *(const f32x4*)(wbase + 16 * RS);
-#pragma unroll
+#pragma clang loop unroll(full)  // the X fragments are indexed by the group: anything less than a full unroll sends them to scratch
   for (int q = 0; q < G; ++q) {
     const int j = q / HP, P = q - j * HP;
     const int qn = q + 1 < G ? q + 1 : q;
@@ -252,7 +266,8 @@ template <int K, int N, int EPI>
 __global__ __launch_bounds__(512, 2) void tall_linear_lds8_f32_k(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw, int trans_w,
     const float* __restrict__ bias, int64_t M, int rows_per_wave, float* __restrict__ Y, int64_t ldy,
-    const float* __restrict__ aux_in, float* __restrict__ aux_out, int64_t ldaux) {
+    const float* __restrict__ aux_in, float* __restrict__ aux_out, int64_t ldaux, const ln_epi ln) {
+  static_assert(EPI != kEpiAddLN || N == 128, "the LayerNorm epilogue needs a whole row in one accumulator set");
   constexpr int RS = K + 4, KJ = K / 16, NTH = 512;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   float* wimg = smem_f;
@@ -299,7 +314,13 @@ __global__ __launch_bounds__(512, 2) void tall_linear_lds8_f32_k(
       }
     }
   }
-  for (int n = threadIdx.x; n < N; n += NTH) bimg[n] = bias != nullptr ? bias[n] : 0.f;
+  for (int n = threadIdx.x; n < N; n += NTH) {
+    bimg[n] = bias != nullptr ? bias[n] : 0.f;
+    if (EPI == kEpiAddLN) {
+      bimg[N + n] = ln.w[n];
+      bimg[2 * N + n] = ln.b[n];
+    }
+  }
   __syncthreads();
   if (r0 >= r1) return;
   const float* wlane = wimg + c * RS + 4 * g;
@@ -308,10 +329,54 @@ __global__ __launch_bounds__(512, 2) void tall_linear_lds8_f32_k(
   int64_t pend_r0 = 0;
   int pend_nh = 0;
   bool pend_valid = false;
+  float ln_rstd = 0.f;
   auto emit = [&](int tp) {
     if (!pend_valid) return;
     const int64_t row = pend_r0 + c;
-    if (row >= r1) return;
+    if (row >= r1) return;  // uniform over the four lanes (g) that share the row
+    if (EPI == kEpiAddLN) {
+      if (tp == 0) {  // the whole row: sum = product + bias + residual, statistics; pend <- sum - mean
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int n0 = 32 * u + 8 * g;
+          pend[2 * u] += *(const f32x4*)(bimg + n0) + *(const f32x4*)(aux_in + row * ldaux + n0);
+          pend[2 * u + 1] += *(const f32x4*)(bimg + n0 + 4) + *(const f32x4*)(aux_in + row * ldaux + n0 + 4);
+          if (aux_out != nullptr) {
+            *(f32x4*)(aux_out + row * ldaux + n0) = pend[2 * u];
+            *(f32x4*)(aux_out + row * ldaux + n0 + 4) = pend[2 * u + 1];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum += pend[2 * u][r] + pend[2 * u + 1][r];
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.f / 128.f);
+        float sq = 0.f;
+#pragma unroll
+        for (int T = 0; T < 8; ++T)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pend[T][r] -= mean;
+            sq = fmaf(pend[T][r], pend[T][r], sq);
+          }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        ln_rstd = rsqrtf(sq * (1.f / 128.f) + ln.eps);
+        if (g == 0) ln.stats[row] = make_float2(mean, ln_rstd);
+      }
+      const int n0 = 32 * tp + 8 * g;
+      const f32x4 y0 = pend[2 * tp] * ln_rstd * *(const f32x4*)(bimg + N + n0) + *(const f32x4*)(bimg + 2 * N + n0);
+      const f32x4 y1 = pend[2 * tp + 1] * ln_rstd * *(const f32x4*)(bimg + N + n0 + 4) + *(const f32x4*)(bimg + 2 * N + n0 + 4);
+      *(f32x4*)(Y + row * ldy + n0) = y0;
+      *(f32x4*)(Y + row * ldy + n0 + 4) = y1;
+      if (ln.yp != nullptr) {
+        const float* prow = ln.pos_table + (size_t)ln.pos_idx[row] * 128 + n0;
+        *(f32x4*)(ln.yp + row * 128 + n0) = y0 + *(const f32x4*)(prow);
+        *(f32x4*)(ln.yp + row * 128 + n0 + 4) = y1 + *(const f32x4*)(prow + 4);
+      }
+      return;
+    }
     const int n0 = 128 * pend_nh + 32 * tp + 8 * g;
     const f32x4 b0 = *(const f32x4*)(bimg + n0), b1 = *(const f32x4*)(bimg + n0 + 4);
     f32x4 v0 = pend[2 * tp] + b0, v1 = pend[2 * tp + 1] + b1;
@@ -342,11 +407,14 @@ __global__ __launch_bounds__(512, 2) void tall_linear_lds8_f32_k(
     *(f32x4*)(Y + row * ldy + n0 + 4) = v1;
   };
 
+  // K = 256 with the LayerNorm epilogue does not fit a second X tile in 256 registers (it went to scratch: 239 us): the
+  // next tile is then loaded into the same registers after the phase, the partner wave of the SIMD covers the latency
+  constexpr bool PREFETCH = !(EPI == kEpiAddLN && K == 256);
   for (; r0 < r1; r0 += 16) {
     asm volatile("" ::: "memory");
     const bool more = r0 + 16 < r1;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see tall_linear_lds_f32_k
-    if (more) load_x(r0 + 16, xn);
+    if (PREFETCH && more) load_x(r0 + 16, xn);
 #pragma unroll
     for (int nh = 0; nh < N / 128; ++nh) {
       f32x4 acc[8];
@@ -360,8 +428,12 @@ __global__ __launch_bounds__(512, 2) void tall_linear_lds8_f32_k(
       pend_valid = true;
     }
     if (more) {
+      if (PREFETCH) {
 #pragma unroll
-      for (int j = 0; j < KJ; ++j) xb[j] = xn[j];
+        for (int j = 0; j < KJ; ++j) xb[j] = xn[j];
+      } else {
+        load_x(r0 + 16, xb);
+      }
     }
   }
 #pragma unroll
@@ -370,25 +442,30 @@ __global__ __launch_bounds__(512, 2) void tall_linear_lds8_f32_k(
 
 template <int K, int N, int EPI>
 int launch_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, int trans_w, const float* bias, int64_t m,
-                  float* y, int64_t ldy, const float* aux_in, float* aux_out, int64_t ldaux, hipStream_t st) {
-  constexpr int lds = (N * (K + 4) + N) * 4;
+                  float* y, int64_t ldy, const float* aux_in, float* aux_out, int64_t ldaux, hipStream_t st,
+                  const ln_epi ln = ln_epi()) {
+  constexpr int lds = (N * (K + 4) + N * (EPI == kEpiAddLN ? 3 : 1)) * 4;
   static int variant = -1;  // SST_AMD_LDS_LINEAR_WAVES = 4: one wave per SIMD, 32-row steps; 8 (default): two, 16-row steps
   if (variant < 0) {
     const char* e = getenv("SST_AMD_LDS_LINEAR_WAVES");
-    variant = (e != nullptr && atoi(e) == 4) ? 4 : 8;
-    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_lds_f32_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    variant = (e != nullptr && atoi(e) == 4 && EPI != kEpiAddLN) ? 4 : 8;
+    if constexpr (EPI != kEpiAddLN)
+      SST_HIP(hipFuncSetAttribute((const void*)tall_linear_lds_f32_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     SST_HIP(hipFuncSetAttribute((const void*)tall_linear_lds8_f32_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   // one workgroup per CU (up to 136 KB of LDS); every wave a contiguous row range, a multiple of 8
   int64_t blocks = 256;
   int64_t rpw = sst_align_up(sst_div_up(m, blocks * variant), 8);
   blocks = sst_div_up(m, rpw * variant);
-  if (variant == 4)
-    hipLaunchKernelGGL((tall_linear_lds_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, x, ldx, w, ldw, trans_w,
-                       bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux);
-  else
-    hipLaunchKernelGGL((tall_linear_lds8_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(512), lds, st, x, ldx, w, ldw,
-                       trans_w, bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux);
+  if constexpr (EPI != kEpiAddLN) {
+    if (variant == 4) {
+      hipLaunchKernelGGL((tall_linear_lds_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(256), lds, st, x, ldx, w, ldw,
+                         trans_w, bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux);
+      return SST_OK;
+    }
+  }
+  hipLaunchKernelGGL((tall_linear_lds8_f32_k<K, N, EPI>), dim3((unsigned)blocks), dim3(512), lds, st, x, ldx, w, ldw, trans_w,
+                     bias, m, (int)rpw, y, ldy, aux_in, aux_out, ldaux, ln);
   return SST_OK;
 }
 
@@ -432,6 +509,38 @@ int sst_tall_linear_epi_f32(const float* d_x, int64_t ldx, const float* d_w, int
     rc = dispatch_epi<128, 256>(epilogue, d_x, ldx, d_w, ldw, trans_w, d_bias, m, d_y, ldy, d_aux_in, d_aux_out, ldaux, st);
   else if (k == 256 && n == 128)
     rc = dispatch_epi<256, 128>(epilogue, d_x, ldx, d_w, ldw, trans_w, d_bias, m, d_y, ldy, d_aux_in, d_aux_out, ldaux, st);
+  else
+    return SST_ERR_UNSUPPORTED;
+  if (rc) return rc;
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_tall_linear_ln_f32(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias, int64_t m, int k,
+                           const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
+                           float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
+                           float* d_y_plus_pos, void* stream) {
+  if (m < 0 || !d_w || !d_ln_weight || !d_ln_bias || !d_stats) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_y || !d_res || (ldx & 3) || (ldw & 3) || (ldres & 3) || !aligned16(d_x) || !aligned16(d_y) ||
+      !aligned16(d_w) || !aligned16(d_res) || (d_sum && !aligned16(d_sum)))
+    return SST_ERR_ARG;
+  if ((d_pos_table != nullptr) != (d_pos_idx != nullptr) || (d_pos_table != nullptr) != (d_y_plus_pos != nullptr))
+    return SST_ERR_ARG;
+  ln_epi ln;
+  ln.w = d_ln_weight;
+  ln.b = d_ln_bias;
+  ln.eps = eps;
+  ln.stats = (float2*)d_stats;
+  ln.pos_table = d_pos_table;
+  ln.pos_idx = d_pos_idx;
+  ln.yp = d_y_plus_pos;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (k == 128)
+    rc = launch_linear<128, 128, kEpiAddLN>(d_x, ldx, d_w, ldw, 0, d_bias, m, d_y, 128, d_res, d_sum, ldres, st, ln);
+  else if (k == 256)
+    rc = launch_linear<256, 128, kEpiAddLN>(d_x, ldx, d_w, ldw, 0, d_bias, m, d_y, 128, d_res, d_sum, ldres, st, ln);
   else
     return SST_ERR_UNSUPPORTED;
   if (rc) return rc;

@@ -211,8 +211,8 @@ def add_ln_fwd(x, res, weight, bias, eps, save_sum=True):
     return y, s, stats
 
 
-def add_ln_bwd(dy, s, stats, weight):
-    """-> (d(x + res), dweight, dbias)."""
+def add_ln_bwd(dy, s, stats, weight, dy2=None):
+    """-> (d(x + res), dweight, dbias); dy2: optional second gradient arriving at the LayerNorm output (c = 128)."""
     dy = dy.contiguous()
     m, c = s.shape
     dx = torch.empty_like(s)
@@ -220,10 +220,36 @@ def add_ln_bwd(dy, s, stats, weight):
     db = torch.empty(c, dtype=torch.float32, device=s.device)
     lib = _lib.load()
     ws = _lib.workspace(lib.sst_add_layernorm_bwd_workspace_bytes(m, c), s.device)
-    rc = lib.sst_add_layernorm_bwd_f32(_lib.ptr(dy), _lib.ptr(s), _lib.ptr(stats), _lib.ptr(weight), m, c,
-                                       _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream_ptr())
-    _lib.check(rc, 'sst_add_layernorm_bwd_f32')
+    if dy2 is not None and c != 128:
+        dy, dy2 = dy + dy2, None
+    rc = lib.sst_add_layernorm_bwd2_f32(_lib.ptr(dy), _lib.ptr(dy2.contiguous() if dy2 is not None else None), _lib.ptr(s),
+                                        _lib.ptr(stats), _lib.ptr(weight), m, c, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                        _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, 'sst_add_layernorm_bwd2_f32')
     return dx, dw, db
+
+
+def lds_linear_add_ln_ok(x, w, res, c):
+    return (c == 128 and lds_linear_ok(x, w) and w.size(0) == 128 and res.is_cuda and res.dtype == torch.float32
+            and res.shape == (x.size(0), 128) and res.is_contiguous() and res.data_ptr() % 16 == 0)
+
+
+def lds_linear_add_ln(x, w, bias, res, ln_weight, ln_bias, eps, save_sum=True, pos=None):
+    """(y, s, stats, y_plus_pos) with y = LayerNorm(x @ w^T + bias + res) in exact fp32: the projection and
+    `norm(src + src2)` in one kernel (csrc/dense_f32.hip, kEpiAddLN); w [128, K], K = 128 | 256; pos = (table fp32 [P, 128],
+    row index int32 [M]) adds the second output y + table[index]."""
+    m, k = x.shape
+    y = torch.empty((m, 128), dtype=torch.float32, device=x.device)
+    s = torch.empty((m, 128), dtype=torch.float32, device=x.device) if save_sum else None
+    stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
+    yp = torch.empty((m, 128), dtype=torch.float32, device=x.device) if pos is not None else None
+    rc = _lib.load().sst_tall_linear_ln_f32(
+        _lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), m, k, _lib.ptr(res), 128, _lib.ptr(ln_weight),
+        _lib.ptr(ln_bias), float(eps), _lib.ptr(y), _lib.ptr(s), _lib.ptr(stats),
+        _lib.ptr(pos[0]) if pos is not None else None, _lib.ptr(pos[1]) if pos is not None else None, _lib.ptr(yp),
+        _lib.stream_ptr())
+    _lib.check(rc, 'sst_tall_linear_ln_f32')
+    return y, s, stats, yp
 
 
 class AddLayerNorm(Function):

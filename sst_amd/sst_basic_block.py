@@ -20,6 +20,7 @@ from torch.utils.checkpoint import checkpoint
 from . import kernels as K
 from .sra_composed import sra_attention_composed
 from .dense import (EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
+                    lds_linear_add_ln, lds_linear_add_ln_ok,
                     tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
                     weight_bias_grad)
 from .norm import build_norm_layer
@@ -194,17 +195,26 @@ class FusedEncoderLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, pos, plan, nhead, impl, act, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps):
+    def forward(ctx, x, pos, plan, nhead, impl, act, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps,
+                xp=None, pos_next=None):
+        """xp (optional): x + positional embedding, already formed (the previous layer's second output) - ``pos`` is then
+        ignored; pos_next = (table, row index): also return y + table[index], the next layer's xp."""
         c = x.size(1)
         x = x.contiguous()
-        xp = x + pos if pos is not None else x
+        ctx.split_input = xp is not None
+        if xp is None:
+            xp = x + pos if pos is not None else x
         qk = _linear_fwd(xp, w_in[:2 * c], b_in[:2 * c])
         v = _linear_fwd(x, w_in[2 * c:], b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
         o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
-        a = _linear_fwd(o, w_out, b_out)
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
-        y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
+        fuse_ln = _LDS_LINEAR and lds_linear_add_ln_ok(o, w_out, x, c)
+        if fuse_ln:    # out-projection + residual + LayerNorm in one kernel (csrc/dense_f32.hip)
+            y1, s1, st1, _ = lds_linear_add_ln(o, w_out, b_out, x, n1w, n1b, eps, save_sum=need_bwd)
+        else:
+            a = _linear_fwd(o, w_out, b_out)
+            y1, s1, st1 = add_ln_fwd(x, a, n1w, n1b, eps, save_sum=need_bwd)
         fused_act = linear_gelu(y1, w1, b1) if (act == 'gelu' and _FUSED_GELU) else None
         if _LDS_LINEAR and lds_linear_ok(y1, w1):   # bias + activation in the epilogue of linear1 (csrc/dense_f32.hip)
             h, pre = lds_linear(y1, w1, b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
@@ -213,19 +223,25 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         else:
             pre = torch.addmm(b1, y1, w1.t())
             h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
-        f = _linear_fwd(h, w2, b2)
-        y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd)
-        if not need_bwd:
-            return y2
-        ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
-        ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
-        return y2
+        y2p = None
+        if fuse_ln and lds_linear_add_ln_ok(h, w2, y1, c):
+            y2, s2, st2, y2p = lds_linear_add_ln(h, w2, b2, y1, n2w, n2b, eps, save_sum=need_bwd, pos=pos_next)
+        else:
+            f = _linear_fwd(h, w2, b2)
+            y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd)
+        if pos_next is not None and y2p is None:
+            y2p = y2 + pos_next[0].index_select(0, pos_next[1].long())
+        if need_bwd:
+            ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
+            ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
+        ctx.two = pos_next is not None
+        return (y2, y2p) if ctx.two else y2
 
     @staticmethod
-    def backward(ctx, dy2):
+    def backward(ctx, dy2, dy2p=None):
         x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
         c = x.size(1)
-        ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w)               # = d(y1 residual) = d(f)
+        ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
         dw2, db2 = weight_bias_grad(ds2, h, True)
         dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
         if _LDS_LINEAR and lds_linear_ok(ds2, w2, trans_w=True) and pre.is_contiguous():
@@ -252,12 +268,35 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         db_in = torch.empty(3 * c, dtype=torch.float32, device=x.device)
         weight_bias_grad(dqk, xp, True, out_w=dw_in[:2 * c], out_b=db_in[:2 * c])
         weight_bias_grad(dv, x, True, out_w=dw_in[2 * c:], out_b=db_in[2 * c:])
-        if _LDS_LINEAR and lds_linear_ok(dqk, w_in[:2 * c], trans_w=True) and lds_linear_ok(dv, w_in[2 * c:], trans_w=True):
+        dxp = None
+        if ctx.split_input:      # x and xp are separate inputs: their gradients leave separately
+            dxp = _linear_dgrad(dqk, w_in[:2 * c])
+            dx = _linear_dgrad(dv, w_in[2 * c:], out=ds1)
+        elif _LDS_LINEAR and lds_linear_ok(dqk, w_in[:2 * c], trans_w=True) and lds_linear_ok(dv, w_in[2 * c:], trans_w=True):
             dx = _linear_dgrad(dv, w_in[2 * c:], out=_linear_dgrad(dqk, w_in[:2 * c], out=ds1))
         else:
             dx = ds1.addmm_(dqkv, w_in)                               # residual + q,k,v branches (in place)
         return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
-                None)
+                None, dxp, None)
+
+
+def run_encoder_stack_fp32(blocks, feats, plans, pos_specs):
+    """All encoder layers of the shift blocks as a chain of FusedEncoderLayerFn nodes that hand (x, x + positional embedding)
+    to each other: "+ positional embedding" of layer i + 1 is the second output of layer i's last kernel, so no add pass and
+    no [M, C] positional tensor exist after the first layer.  pos_specs: per partition (table fp32 [P, C], row index int32)."""
+    layers = [enc for block in blocks for enc in block.encoder_list]
+    x = feats.contiguous()
+    xp = x + pos_specs[0][0].index_select(0, pos_specs[0][1].long())
+    for li, enc in enumerate(layers):
+        attn = enc.win_attn.self_attn
+        pos_next = pos_specs[(li + 1) % 2] if li + 1 < len(layers) else None
+        out = FusedEncoderLayerFn.apply(
+            x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
+            attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
+            enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
+            enc.norm1.eps, xp, pos_next)
+        x, xp = out if pos_next is not None else (out, None)
+    return x
 
 
 class EncoderLayer(nn.Module):
@@ -307,7 +346,7 @@ class EncoderLayer(nn.Module):
                 src, pos_dict, ind_dict, self.win_attn.nhead, self.win_attn.impl, self.act_name, attn.in_proj_weight,
                 attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, self.linear1.weight, self.linear1.bias,
                 self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias, self.norm2.weight,
-                self.norm2.bias, self.norm1.eps)
+                self.norm2.bias, self.norm1.eps, None, None)
         if self.post_norm:
             src2 = self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)  # [N, d_model]
             src = add_layer_norm(src, self.dropout1(src2), self.norm1)     # norm1(src + src2), one kernel
