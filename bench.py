@@ -467,6 +467,10 @@ def main():
                 roofline['traffic_source'] = 'profiles/latest_sra_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
                 if 'sra_bwd' in roofline and 'sra_bwd_fused_k' in tj:
                     roofline['sra_bwd']['traffic'] = int(tj['sra_bwd_fused_k']['hbm_bytes_per_launch'])
+                if bf16_leg is not None:
+                    for key, kern in (('sra_fwd', 'sra_fwd_bf16_k'), ('sra_bwd', 'sra_bwd_bf16_k')):
+                        if bf16_leg['roofline'].get(key) and kern in tj:
+                            bf16_leg['roofline'][key]['traffic'] = int(tj[kern]['hbm_bytes_per_launch'])
             except Exception:
                 pass
 
