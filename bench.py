@@ -110,10 +110,16 @@ def allreduce_grads(params, world):
     return flat
 
 
+def voxel_sort_key(coors):
+    """(b, z, y, x) -> one int64 key whose order is the sorted-unique voxel order (bench-side helper: the reduced-precision
+    leg compares two GPU runs and must not touch oracle/)"""
+    c = coors.long()
+    return ((c[:, 0] * 64 + c[:, 1]) * 4096 + c[:, 2]) * 4096 + c[:, 3]
+
+
 def gpu_forward_sorted(model, frames):
     """Forward of the GPU pipeline without the voxel shuffle, rows re-ordered to the reference's sorted-unique voxel
     order: (features [M, C] on the host, int64 voxel keys [M] ascending)."""
-    from oracle.cpu_pipeline import voxel_sort_key
     me = model.middle_encoder
     orig_shuffle = me.shuffle_voxels
     me.shuffle_voxels = False
@@ -142,7 +148,7 @@ def cpu_reference_leg(model, frame_cpu, num_blocks, budget_s=75.0):
         threads and with one thread;
       * `parity`: the GPU forward of the SAME network (weights copied) on the SAME frame against the first timed
         CPU forward: kept-voxel sets equal, max abs feature error (north-star bar: 1e-3)."""
-    from oracle.cpu_pipeline import CpuSSTBackbone, load_pipeline_weights, voxel_sort_key
+    from oracle.cpu_pipeline import CpuSSTBackbone, load_pipeline_weights   # the ONLY place bench.py touches oracle/
     threads = torch.get_num_threads()
     net = load_pipeline_weights(CpuSSTBackbone(VOXEL_SIZE, PC_RANGE, DROP_TRAIN, num_blocks=num_blocks).train(), model)
     small = make_cloud(20000, 7, 'cpu')

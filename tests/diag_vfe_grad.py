@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import bench  # noqa: E402
 from oracle.cpu_pipeline import CpuSSTBackbone, load_pipeline_weights  # noqa: E402
 

@@ -88,7 +88,7 @@ def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks, fused
         assert errs[name] < 1e-3, f'relative parameter gradient errors {errs}'
     # The VFE's parameters sit behind max pooling over the points of a voxel: where two points of a voxel are within
     # rounding of each other in a channel, the two devices may route the gradient to different points (measured with
-    # tools/diag_vfe_grad.py: forward values equal to 2e-6, 2 of 55 000 point rows receive another gradient).  Count
+    # tests/diag_vfe_grad.py: forward values equal to 2e-6, 2 of 55 000 point rows receive another gradient).  Count
     # those rows (a channel whose largest pre-activation in a voxel is within rounding of zero is enough: ReLU gives 0
     # on one device and 1e-9 on the other, the arg max moves to another point): without a flipped decision the
     # north-star bar applies, with flips (a handful of rows in 1e4) the bound is the one such rows can move the sum by.
