@@ -15,9 +15,9 @@
 // At bf16 the matrix pipe is 8x faster than at fp32 and no longer the limiter: the kernels are bound by the softmax
 // arithmetic (VALU) and HBM, which is why the simple one-accumulator chains below are enough.
 // Backward: ONE pass per (window, head) wave, as sra_bwd_fused_k: S and dP in the orientation row = query, col = key;
-// dV^T += dO^T P and dK^T += Q^T dS consume the D layout directly, dQ^T += K^T dS^T takes the tile through a
-// wave-private fp32 LDS tile (transposed hand-over), and the operands contracted over tokens come from fp32 LDS images
-// of the row fragments.  5 MFMAs per tile pair.
+// dV^T += dO^T P and dK^T += Q^T dS consume the D layout directly; the operands contracted over tokens and the dS^T tile
+// of dQ^T += K^T dS^T are transposed by a product with the identity on the matrix core (no LDS at all).  6 MFMAs per
+// tile pair.
 #include <math.h>
 #include <stdlib.h>
 #include <hip/hip_ext.h>
@@ -194,8 +194,11 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_bf16_k(const unsigned short*
 // ------------------------------------------------------------------------------------------------------------------
 // backward, one pass
 // ------------------------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int bwd_lds_floats_per_wave(int nt) { return (nt * 16 + 3 * 16) * kTS; }
-
+// Operands contracted over tokens (K / Q / dO as [token][d] column fragments, dS^T) are produced from the row fragments BY
+// THE MATRIX CORE: X I with the fragment as A operand (lane = token, registers = 4 consecutive d) lands in the D layout
+// (lane = d, registers = 4 consecutive tokens), which packed to bf16 is the operand wanted - exact (a selection of bf16
+// values accumulated in fp32).  The same product turns the dS tile (D layout: lane = key, registers = queries, read as
+// the A operand of dS^T) into the B operand of dQ^T += K^T dS^T.  No LDS, no barrier, no wave-private tiles.
 template <int NT, bool EXACT>
 __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                          const unsigned short* __restrict__ V, const unsigned short* __restrict__ O,
@@ -203,15 +206,10 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
                                          uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t ldo, uint32_t lddo,
                                          const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H,
                                          float scale, unsigned short* __restrict__ dQ, unsigned short* __restrict__ dK,
-                                         unsigned short* __restrict__ dV, uint32_t lddq, uint32_t lddk, uint32_t lddv,
-                                         float* __restrict__ lds) {
+                                         unsigned short* __restrict__ dV, uint32_t lddq, uint32_t lddk, uint32_t lddv) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
-  float* Kimg = lds;                    // [NT * 16][kTS]  K rows (fp32)
-  float* Qimg = Kimg + NT * 16 * kTS;   // [16][kTS]       Q rows of the current query tile
-  float* Gimg = Qimg + 16 * kTS;        // [16][kTS]       dO rows of the current query tile
-  float* Dimg = Gimg + 16 * kTS;        // [16][kTS]       dS tile, [key][query]
   constexpr int NTK = (NT * 16 + 63) / 64;
   int tk[NTK];
 #pragma unroll
@@ -226,7 +224,14 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
     return (uint32_t)__shfl(sel, (i & 3) * 16 + within, 64);
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  s16x4 kf[NT], vf[NT];
+  // identity as B operand: B[k = 4 g + x][j = c] = 1 iff 4 g + x == c
+  s16x4 ident = {0, 0, 0, 0};
+  if (g == (c >> 2)) ident[c & 3] = (short)0x3f80;
+  auto transposed = [&](s16x4 frag) -> s16x4 {
+    const f32x4 d = mma(frag, ident, zero4);
+    return pack4(d[0], d[1], d[2], d[3]);
+  };
+  s16x4 kf[NT], vf[NT], kcf[NT];
   f32x4 dk[NT], dv[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -257,38 +262,26 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
   };
   qtile cur = load_tile(0);
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
-    if (EXACT || j < nt) *(f32x4*)(Kimg + (j * 16 + c) * kTS + 4 * g) = unpack4(kf[j]);
+  for (int j = 0; j < NT; ++j) kcf[j] = (EXACT || j < nt) ? transposed(kf[j]) : (s16x4){0, 0, 0, 0};  // K [key 4g + r][d = c]
   const float s2 = scale * kLog2e;
-  const float* kcol = Kimg + (4 * g) * kTS + c;
-  const float* qcol = Qimg + (4 * g) * kTS + c;
-  const float* gcol = Gimg + (4 * g) * kTS + c;
-  float* drow = Dimg + c * kTS + 4 * g;
-  const float* dcol = Dimg + (4 * g) * kTS + c;
 
   for (int i = 0; i < nt; ++i) {
-    asm volatile("" ::: "memory");  // the K column fragments are re-read per pair (registers for a third wave)
     const s16x4 qf = cur.qf, gf = cur.gf;
     const f32x4 gq = unpack4(gf), oq = unpack4(cur.of);
     float dd = gq[0] * oq[0] + gq[1] * oq[1] + gq[2] * oq[2] + gq[3] * oq[3];
     dd = rows4_sum(dd);
     const float lse_c = cur.lse * kLog2e;
     const uint32_t qrow = cur.row;
-    *(f32x4*)(Qimg + c * kTS + 4 * g) = unpack4(qf);
-    *(f32x4*)(Gimg + c * kTS + 4 * g) = gq;
     cur = load_tile(i + 1 < nt ? i + 1 : i);
+    const s16x4 qcp = transposed(qf);  // Q [query 4g + r][d = c]: A operand of dK^T += Q^T dS
+    const s16x4 gcp = transposed(gf);  // dO[query 4g + r][d = c]: A operand of dV^T += dO^T P
     float lse2[4], dd4[4], rmask[4];
-    float qc[4], gc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      qc[r] = qcol[r * kTS];
-      gc[r] = gcol[r * kTS];
       lse2[r] = __shfl(lse_c, 4 * g + r, 64);
       dd4[r] = __shfl(dd, 4 * g + r, 64);
       rmask[r] = (i * 16 + 4 * g + r) < t ? 1.f : 0.f;
     }
-    const s16x4 qcp = pack4(qc[0], qc[1], qc[2], qc[3]);  // Q [query 4g + r][d = c]: A operand of dK^T += Q^T dS
-    const s16x4 gcp = pack4(gc[0], gc[1], gc[2], gc[3]);  // dO[query 4g + r][d = c]: A operand of dV^T += dO^T P
     f32x4 dq = zero4;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -305,16 +298,10 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
           pe[r] = p;
           ds[r] = p * (dp[r] - dd4[r]) * scale;
         }
-        *(f32x4*)drow = ds;  // transposed hand-over of the dS tile
+        const s16x4 dsp = pack4(ds[0], ds[1], ds[2], ds[3]);          // dS [query 4g + r][key c]: B operand over queries
         dv[j] = mma(gcp, pack4(pe[0], pe[1], pe[2], pe[3]), dv[j]);  // dV^T[d][key] += dO^T P
-        dk[j] = mma(qcp, pack4(ds[0], ds[1], ds[2], ds[3]), dk[j]);  // dK^T[d][key] += Q^T dS
-        float dst[4], kc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dst[r] = dcol[r * kTS];            // dS[query c][key 4g + r]
-          kc[r] = kcol[(j * 16 + r) * kTS];  // K [key 4g + r][d = c]
-        }
-        dq = mma(pack4(kc[0], kc[1], kc[2], kc[3]), pack4(dst[0], dst[1], dst[2], dst[3]), dq);  // dQ^T += K^T dS^T
+        dk[j] = mma(qcp, dsp, dk[j]);                                 // dK^T[d][key] += Q^T dS
+        dq = mma(kcf[j], transposed(dsp), dq);                        // dQ^T[d][query] += K^T dS^T
       }
     }
     if (i * 16 + c < t) {
@@ -343,7 +330,6 @@ __global__ __launch_bounds__(64 * kWH, (NTMAX > 7 ? 2 : 3)) void sra_bwd_bf16_k(
     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* __restrict__ tok,
     const int32_t* __restrict__ winoff, int n_groups, int H, float scale, unsigned short* __restrict__ dQ,
     unsigned short* __restrict__ dK, unsigned short* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
   const int w = bid / n_groups;
   const int hg = bid - w * n_groups;
@@ -351,8 +337,7 @@ __global__ __launch_bounds__(64 * kWH, (NTMAX > 7 ? 2 : 3)) void sra_bwd_bf16_k(
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;
-  float* lds = smem + (threadIdx.x >> 6) * bwd_lds_floats_per_wave(NTMAX);
-#define SST_B_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, lds
+#define SST_B_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv
   switch (nt) {
     case 1: bwd_body<1, true>(SST_B_ARGS); break;
     case 2: bwd_body<2, true>(SST_B_ARGS); break;
@@ -395,12 +380,7 @@ int launch_bwd(const unsigned short* q, const unsigned short* k, const unsigned 
                const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, unsigned short* dq,
                unsigned short* dk, unsigned short* dv, int64_t lddq, int64_t lddk, int64_t lddv, hipStream_t st) {
   const int n_groups = H / kWH;
-  const size_t lds = (size_t)kWH * bwd_lds_floats_per_wave(NTMAX) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    SST_HIP(hipFuncSetAttribute((const void*)sra_bwd_bf16_k<NTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  const size_t lds = 0;
   const dim3 grid((unsigned)(n_windows * n_groups));
   hipEvent_t e0 = g_ev[1][0], e1 = g_ev[1][1];
   g_ev[1][0] = g_ev[1][1] = nullptr;
