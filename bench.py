@@ -48,9 +48,10 @@ class Pipeline(torch.nn.Module):
     """The SST-base hot path behind the reference's registry names (configs/sst_refactor/
     sst_waymoD5_1x_3class_8heads_v2.py:26-79), without the dense BEV neck/head."""
 
-    def __init__(self, num_blocks=6):
+    def __init__(self, num_blocks=6, with_bev=False):
         super().__init__()
         import sst_amd
+        self.with_bev = with_bev
         self.voxel_layer = sst_amd.Voxelization(VOXEL_SIZE, PC_RANGE, -1, (-1, -1))
         self.voxel_encoder = sst_amd.build_voxel_encoder(dict(
             type='DynamicVFE', in_channels=3, feat_channels=[64, 128], with_distance=False, voxel_size=VOXEL_SIZE,
@@ -63,8 +64,14 @@ class Pipeline(torch.nn.Module):
             reference_outputs=False))
         self.backbone = sst_amd.build_backbone(dict(
             type='SSTv2', d_model=[128] * num_blocks, nhead=[8] * num_blocks, num_blocks=num_blocks,
-            dim_feedforward=[256] * num_blocks, output_shape=[468, 468], num_attached_conv=0, to_bev=False,
-            debug=False))
+            dim_feedforward=[256] * num_blocks, output_shape=[468, 468], debug=False,
+            # --workload sst_bev: the backbone as the config builds it (sst_waymoD5_1x_3class_8heads_v2.py:64-79): BEV canvas +
+            # three dilated 3 x 3 convolutions (MIOpen); the headline leaves them out
+            **(dict(num_attached_conv=3, to_bev=True, conv_in_channel=128, conv_out_channel=128,
+                    conv_kwargs=[dict(kernel_size=3, dilation=1, padding=1, stride=1),
+                                 dict(kernel_size=3, dilation=1, padding=1, stride=1),
+                                 dict(kernel_size=3, dilation=2, padding=2, stride=1)])
+               if with_bev else dict(num_attached_conv=0, to_bev=False))))
         self.fused_index = True     # csrc/frame_plan.hip; False: the piecewise path through the module interfaces
         self._planner = None
 
@@ -93,7 +100,8 @@ class Pipeline(torch.nn.Module):
             prepared.want_pos_rows = False   # the encoder stacks (fp32 chain and bf16) take (table, row index) instead
             info = prepared.finalize(voxel_feats, self.middle_encoder)
         self.last_voxel_coors = info['voxel_coors']
-        return self.backbone(info)[0]['voxel_feats']
+        out = self.backbone(info)[0]
+        return out if self.with_bev else out['voxel_feats']
 
 
 def allreduce_grads(params, world):
@@ -229,9 +237,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--frames-per-gpu', type=int, default=1)
     ap.add_argument('--points', type=int, default=None, help='points per frame (default: 116000 for the SST workloads)')
-    ap.add_argument('--workload', default='sst', choices=('sst', 'sst_bs2', 'fsd', 'fsdv2'),
+    ap.add_argument('--workload', default='sst', choices=('sst', 'sst_bs2', 'sst_bev', 'fsd', 'fsdv2'),
                     help="sst = the headline (BASELINE.json configs[1]/[2] geometry, 1 frame/GPU); sst_bs2 = configs[2]'s "
-                         "2 frames per GPU; fsd / fsdv2 = configs[3] / configs[4] hot paths (bench_workloads.py)")
+                         "2 frames per GPU; sst_bev = sst + recover_bev + the three attached convolutions of the config; "
+                         "fsd / fsdv2 = configs[3] / configs[4] hot paths (bench_workloads.py)")
     ap.add_argument('--blocks', type=int, default=6)
     ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -294,7 +303,9 @@ def main():
         tunable.tuning_enable(True)
         tunable.set_filename(work_file)
     torch.manual_seed(0)                      # identical initial weights on every rank
-    model = Pipeline(args.blocks).to(dev)
+    model = Pipeline(args.blocks, with_bev=args.workload == 'sst_bev').to(dev)
+    if args.workload == 'sst_bev':
+        args.no_bf16_leg = args.no_cpu_baseline = True     # the CPU port and the bf16 comparison cover the voxel features only
     model.train()
     model.backbone.set_impl(args.impl)
     model.fused_index = not args.piecewise_index
@@ -327,7 +338,7 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    n_voxels = int(out.size(0))
+    n_voxels = int(model.last_voxel_coors.size(0))
 
     def sync():
         torch.cuda.synchronize()
@@ -494,7 +505,8 @@ def main():
                                     'SST-base Waymo single-frame, 0.32 m voxel: uniform synthetic cloud ') +
                                    f'{args.points} points/frame -> {n_voxels // args.frames_per_gpu} non-empty '
                                    'voxels/frame; dynamic voxelize + DynamicVFE + SSTInputLayerV2 + '
-                                   f'{args.blocks} SRA blocks, ' + ('fwd only' if args.fwd_only else 'fwd+bwd'),
+                                   f'{args.blocks} SRA blocks' + (' + BEV canvas + 3 attached convolutions' if args.workload == 'sst_bev' else '') + ', '
+                                   + ('fwd only' if args.fwd_only else 'fwd+bwd'),
                        'frames_per_gpu': args.frames_per_gpu, 'points_per_frame': args.points,
                        'voxels_per_gpu': n_voxels, 'parallelism': f'dp{world}',
                        'grad_sync': ('one flat all-reduce over ' + ('RCCL' if args.backend == 'nccl' else args.backend)) if world > 1 else 'none'},
