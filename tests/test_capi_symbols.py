@@ -54,3 +54,23 @@ def test_grid_helper_matches_reference_ceil():
     from sst_amd import kernels as K
     assert K.voxel_grid([0.32, 0.32, 6], [-74.88, -74.88, -2, 74.88, 74.88, 4]) == [468, 468, 1]
     assert K.voxel_grid([0.25, 0.25, 0.2], [-80, -80, -2, 80, 80, 4]) == [640, 640, 30]
+
+
+def test_bench_cli_contract_and_workloads_registry():
+    """bench.py's command line (the driver's contract: --gpus / --steps / --warmup, defaults N = 1) and the workload
+    registry, without a GPU"""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--help'], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ('--gpus', '--steps', '--warmup', '--workload', '--precision', '--no-cpu-baseline'):
+        assert flag in out.stdout
+    for w in ('sst_bs2', 'sst_bev', 'fsd', 'fsdv2'):
+        assert w in out.stdout
+    sys.path.insert(0, root)
+    import bench_workloads
+    assert set(bench_workloads.WORKLOADS) == {'fsd', 'fsdv2'}
+    for spec in bench_workloads.WORKLOADS.values():
+        assert {'cls', 'points', 'metric', 'name'} <= set(spec)
