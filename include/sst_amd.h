@@ -401,6 +401,18 @@ int sst_colsum_f32(const float* d_x, int64_t m, int c, int64_t ld, float* d_out,
 int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in);
 int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out, int in, int64_t ld_dy,
                         int64_t ld_x, float* d_dw, float* d_db, void* d_workspace, void* stream);
+/* The same for several problems (e.g. the five parameter gradients of an encoder layer): the split-K kernels one after
+ * the other, ONE reduction launch for all.  dw [out, in] contiguous, db [out] or NULL. */
+typedef struct sst_wgrad_problem_f32 {
+  const float* dy;  /* [m, out], row stride ld_dy */
+  const float* x;   /* [m, in], row stride ld_x */
+  int64_t m, ld_dy, ld_x;
+  float* dw;
+  float* db;
+  int32_t out, in;
+} sst_wgrad_problem_f32;
+int64_t sst_weight_grad_group_workspace_bytes(const sst_wgrad_problem_f32* problems, int n);
+int sst_weight_grad_group_f32(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a11/a12, §8 f1) BatchNorm1d (+ ReLU) of the point-wise "Linear -> norm -> ReLU" layers of DynamicVFE / SIR

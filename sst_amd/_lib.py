@@ -30,6 +30,12 @@ class WgradProblemBF16(ctypes.Structure):
                 ('transpose_out', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class WgradProblemF32(ctypes.Structure):
+    """sst_wgrad_problem_f32 of include/sst_amd.h"""
+    _fields_ = [('dy', c_ptr), ('x', c_ptr), ('m', c_i64), ('ld_dy', c_i64), ('ld_x', c_i64), ('dw', c_ptr), ('db', c_ptr),
+                ('out', ctypes.c_int32), ('inn', ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/sst_amd.h one to one
 _SIGNATURES = {
     'sst_version': (ctypes.c_char_p, []),
@@ -73,6 +79,8 @@ _SIGNATURES = {
     'sst_add_layernorm_bwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_ptr]),
     'sst_cast_add_pos_bf16': (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_weight_grad_group_workspace_bytes': (c_i64, [c_ptr, c_i32]),
+    'sst_weight_grad_group_f32': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
     'sst_tall_linear_ln_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr,
                                        c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_add_layernorm_bwd2_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),

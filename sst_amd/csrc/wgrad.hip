@@ -503,6 +503,49 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const float* __restrict__ 
   }
 }
 
+constexpr int kGroupMax = 8;
+struct wg_reduce_problem {
+  const float* part;
+  int nsplit;
+  int64_t n_w, n_b;
+  float* dw;
+  float* db;
+};
+struct wg_reduce_group {
+  wg_reduce_problem pr[kGroupMax];
+  int n;
+};
+
+// wgrad_reduce_k for several problems in one launch (blockIdx.y = problem)
+__global__ __launch_bounds__(256) void wgrad_reduce_group_k(const wg_reduce_group args) {
+  __shared__ float red[8][33];
+  const wg_reduce_problem& pr = args.pr[blockIdx.y];
+  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+  const int64_t n = pr.n_w + pr.n_b;
+  if ((int64_t)blockIdx.x * 32 >= n) return;
+  const int64_t e = (int64_t)blockIdx.x * 32 + cx;
+  float a0 = 0.f, a1 = 0.f;
+  if (e < n) {
+    int s = gy;
+    for (; s + 8 < pr.nsplit; s += 16) {
+      a0 += pr.part[(int64_t)s * n + e];
+      a1 += pr.part[(int64_t)(s + 8) * n + e];
+    }
+    if (s < pr.nsplit) a0 += pr.part[(int64_t)s * n + e];
+  }
+  red[gy][cx] = a0 + a1;
+  __syncthreads();
+  if (gy == 0 && e < n) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += red[k][cx];
+    if (e < pr.n_w)
+      pr.dw[e] = r;
+    else
+      pr.db[e - pr.n_w] = r;
+  }
+}
+
 int pick_splits(int64_t m, int out, int in, int64_t* rows_per_split) {
   const int tiles = ((out + kWgTileO - 1) / kWgTileO) * ((in + kWgTileI - 1) / kWgTileI);
   static int target = 0;
@@ -555,20 +598,12 @@ int64_t sst_weight_grad_workspace_bytes(int64_t m, int out, int in) {
   return sst_align_up((int64_t)s * ((int64_t)out * in + out) * sizeof(float), 256) + 256;
 }
 
-int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out, int in, int64_t ld_dy, int64_t ld_x,
-                        float* d_dw, float* d_db, void* d_workspace, void* stream) {
-  if (m < 0 || out < 1 || in < 1 || out > 4096 || in > 4096) return SST_ERR_UNSUPPORTED;
-  if (!d_dw || !d_workspace || ld_dy < out || ld_x < in) return SST_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  if (m == 0) {
-    SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * out * in, st));
-    if (d_db) SST_HIP(hipMemsetAsync(d_db, 0, sizeof(float) * out, st));
-    return SST_OK;
-  }
-  if (!d_dy || !d_x) return SST_ERR_ARG;
+// split-K partial records of one problem into d_workspace (the kernel choice of sst_weight_grad_f32); *splits = records written
+static int launch_partials(const float* d_dy, const float* d_x, int64_t m, int out, int in, int64_t ld_dy, int64_t ld_x,
+                           bool want_bias, void* d_workspace, hipStream_t st, int* splits) {
   const int64_t nw = (int64_t)out * in;
   float* part_w = (float*)d_workspace;
-  float* part_b = d_db ? part_w + nw : nullptr;  // bias sums sit behind the dW block of each split record
+  float* part_b = want_bias ? part_w + nw : nullptr;  // bias sums sit behind the dW block of each split record
   int64_t rps;
   int s;
   // Tiled mode (default): any out % 128 == 0, in % 64 == 0 with up to 64 tiles; SST_WGRAD_TILED=0 selects the older
@@ -632,9 +667,64 @@ int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out,
     hipLaunchKernelGGL((wgrad_k<8, KW>), dim3((unsigned)(s * tiles)), dim3(256 * KW), lds, st, d_dy, d_x, m, out, in,
                        ld_dy, ld_x, rps, part_w, part_b);
   }
-  const int64_t nb = d_db ? out : 0;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)sst_div_up(nw + nb, 32)), dim3(256), 0, st, part_w, s, nw, nb, d_dw,
-                     d_db);
+  *splits = s;
+  return SST_OK;
+}
+
+int sst_weight_grad_f32(const float* d_dy, const float* d_x, int64_t m, int out, int in, int64_t ld_dy, int64_t ld_x,
+                        float* d_dw, float* d_db, void* d_workspace, void* stream) {
+  if (m < 0 || out < 1 || in < 1 || out > 4096 || in > 4096) return SST_ERR_UNSUPPORTED;
+  if (!d_dw || !d_workspace || ld_dy < out || ld_x < in) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (m == 0) {
+    SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * out * in, st));
+    if (d_db) SST_HIP(hipMemsetAsync(d_db, 0, sizeof(float) * out, st));
+    return SST_OK;
+  }
+  if (!d_dy || !d_x) return SST_ERR_ARG;
+  int s = 0;
+  const int rc = launch_partials(d_dy, d_x, m, out, in, ld_dy, ld_x, d_db != nullptr, d_workspace, st, &s);
+  if (rc) return rc;
+  const int64_t nw = (int64_t)out * in, nb = d_db ? out : 0;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)sst_div_up(nw + nb, 32)), dim3(256), 0, st, (const float*)d_workspace, s,
+                     nw, nb, d_dw, d_db);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+// Several problems (the five parameter gradients of an encoder layer): the same split-K kernels, launched one after the
+// other into their own slices of the workspace, and ONE reduction launch for all of them (5 us saved per problem).
+int64_t sst_weight_grad_group_workspace_bytes(const sst_wgrad_problem_f32* problems, int n) {
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) total += sst_weight_grad_workspace_bytes(problems[i].m, problems[i].out, problems[i].in);
+  return total;
+}
+
+int sst_weight_grad_group_f32(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream) {
+  if (n < 1 || n > kGroupMax || !problems || !d_workspace) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  wg_reduce_group args;
+  args.n = n;
+  char* ws = (char*)d_workspace;
+  unsigned max_blocks = 1;
+  for (int i = 0; i < n; ++i) {
+    const sst_wgrad_problem_f32& q = problems[i];
+    if (q.m < 1 || q.out < 1 || q.in < 1 || q.out > 4096 || q.in > 4096) return SST_ERR_UNSUPPORTED;
+    if (!q.dy || !q.x || !q.dw || q.ld_dy < q.out || q.ld_x < q.in) return SST_ERR_ARG;
+    int s = 0;
+    const int rc = launch_partials(q.dy, q.x, q.m, q.out, q.in, q.ld_dy, q.ld_x, q.db != nullptr, ws, st, &s);
+    if (rc) return rc;
+    args.pr[i].part = (const float*)ws;
+    args.pr[i].nsplit = s;
+    args.pr[i].n_w = (int64_t)q.out * q.in;
+    args.pr[i].n_b = q.db ? q.out : 0;
+    args.pr[i].dw = q.dw;
+    args.pr[i].db = q.db;
+    const unsigned blocks = (unsigned)sst_div_up(args.pr[i].n_w + args.pr[i].n_b, 32);
+    if (blocks > max_blocks) max_blocks = blocks;
+    ws += sst_weight_grad_workspace_bytes(q.m, q.out, q.in);
+  }
+  hipLaunchKernelGGL(wgrad_reduce_group_k, dim3(max_blocks, (unsigned)n), dim3(256), 0, st, args);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -71,6 +71,26 @@ def weight_bias_grad(dy, x, want_bias, out_w=None, out_b=None):
     return dw, db
 
 
+def weight_bias_grad_group(problems):
+    """Weight / bias gradients of several linears at once: problems = [(dy, x, out_w, out_b | None), ...] with contiguous
+    fp32 destinations; the split-K kernels of csrc/wgrad.hip one after the other and ONE reduction launch for all of them
+    (sst_weight_grad_group_f32).  Problems the kernel is not built for go through weight_bias_grad one by one."""
+    ok = all(dy.stride(1) == 1 and x.stride(1) == 1 and dy.size(0) >= 4096 and dy.size(1) <= 4096 and x.size(1) <= 4096
+             and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.is_cuda and ow.is_contiguous()
+             and (ob is None or ob.is_contiguous()) for dy, x, ow, ob in problems)
+    if not ok or len(problems) > 8:
+        for dy, x, ow, ob in problems:
+            weight_bias_grad(dy, x, ob is not None, out_w=ow, out_b=ob)
+        return
+    lib = _lib.load()
+    arr = (_lib.WgradProblemF32 * len(problems))()
+    for q, (dy, x, ow, ob) in zip(arr, problems):
+        q.dy, q.x, q.m, q.ld_dy, q.ld_x = dy.data_ptr(), x.data_ptr(), dy.size(0), dy.stride(0), x.stride(0)
+        q.dw, q.db, q.out, q.inn = ow.data_ptr(), (ob.data_ptr() if ob is not None else None), dy.size(1), x.size(1)
+    ws = _lib.workspace(lib.sst_weight_grad_group_workspace_bytes(arr, len(problems)), problems[0][0].device)
+    _lib.check(lib.sst_weight_grad_group_f32(arr, len(problems), _lib.ptr(ws), _lib.stream_ptr()), 'sst_weight_grad_group_f32')
+
+
 def tall_gemm(x, w, bias=None, trans_w=False, out=None, accumulate=False):
     """out (+)= x @ (w if trans_w else w.t()) + bias through csrc/tall_gemm.hip (W resident in LDS, fp32 MFMA);
     returns None when the shape is not one the kernel is built for (the caller then uses the library GEMM)."""

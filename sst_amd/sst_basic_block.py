@@ -20,7 +20,7 @@ from torch.utils.checkpoint import checkpoint
 from . import kernels as K
 from .sra_composed import sra_attention_composed
 from .dense import (EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
-                    lds_linear_add_ln, lds_linear_add_ln_ok,
+                    lds_linear_add_ln, lds_linear_add_ln_ok, weight_bias_grad_group,
                     tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
                     weight_bias_grad)
 from .norm import build_norm_layer
@@ -242,7 +242,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
         c = x.size(1)
         ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
-        dw2, db2 = weight_bias_grad(ds2, h, True)
+        ds2_for_w2 = ds2
         dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
         if _LDS_LINEAR and lds_linear_ok(ds2, w2, trans_w=True) and pre.is_contiguous():
             # the activation's derivative in the epilogue of linear2's data gradient
@@ -254,10 +254,13 @@ class FusedEncoderLayerFn(torch.autograd.Function):
                 dpre = torch.ops.aten.gelu_backward(dh, pre)
             else:
                 dpre = dh * (pre > 0).to(dh.dtype)
-        dw1, db1 = weight_bias_grad(dpre, y1, True)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        dw2, db2 = torch.empty_like(w2), torch.empty(w2.size(0), **f32)
+        dw1, db1 = torch.empty_like(w1), torch.empty(w1.size(0), **f32)
+        # dW2 must be taken BEFORE the next GEMM accumulates into ds2 in place: first group (2 problems) here
+        weight_bias_grad_group([(ds2_for_w2, h, dw2, db2), (dpre, y1, dw1, db1)])
         dy1 = _linear_dgrad(dpre, w1, out=ds2)                        # residual + FFN branch: GEMM with beta = 1
         ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
-        dwo, dbo = weight_bias_grad(ds1, o, True)
         do = _linear_dgrad(ds1, w_out)
         # dq | dk | dv in ONE [M, 3C] buffer: d(x) of the whole in-projection is then a single GEMM
         dqkv = torch.empty((x.size(0), 3 * c), dtype=torch.float32, device=x.device)
@@ -265,9 +268,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         K._sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, ctx.impl, dqkv[:, :c],
                    dqkv[:, c:2 * c], dv)
         dw_in = torch.empty_like(w_in)
-        db_in = torch.empty(3 * c, dtype=torch.float32, device=x.device)
-        weight_bias_grad(dqk, xp, True, out_w=dw_in[:2 * c], out_b=db_in[:2 * c])
-        weight_bias_grad(dv, x, True, out_w=dw_in[2 * c:], out_b=db_in[2 * c:])
+        db_in = torch.empty(3 * c, **f32)
+        dwo, dbo = torch.empty_like(w_out), torch.empty(w_out.size(0), **f32)
+        # second group (3 problems), before ds1 is accumulated into in place
+        weight_bias_grad_group([(ds1, o, dwo, dbo), (dqk, xp, dw_in[:2 * c], db_in[:2 * c]), (dv, x, dw_in[2 * c:], db_in[2 * c:])])
         dxp = None
         if ctx.split_input:      # x and xp are separate inputs: their gradients leave separately
             dxp = _linear_dgrad(dqk, w_in[:2 * c])
