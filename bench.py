@@ -305,6 +305,7 @@ def main():
     torch.manual_seed(0)                      # identical initial weights on every rank
     model = Pipeline(args.blocks, with_bev=args.workload == 'sst_bev').to(dev)
     if args.workload == 'sst_bev':
+        torch.backends.cudnn.benchmark = True    # MIOpen: search for the convolution solvers during warm-up
         args.no_bf16_leg = args.no_cpu_baseline = True     # the CPU port and the bf16 comparison cover the voxel features only
     model.train()
     model.backbone.set_impl(args.impl)
