@@ -205,6 +205,7 @@ def _conv_roofline(model, clouds):
     (2 x pairs x C_in x C_out).  The other instrumented kernel family: the segmented reductions (SIR / VFE pooling)."""
     from sst_amd import spconv as SP
     from sst_amd import kernels as K
+    from sst_amd import _lib
     records, handles = [], []
 
     def pre(mod, inp):
@@ -230,12 +231,14 @@ def _conv_roofline(model, clouds):
     seg_records = []
     orig_reduce = K.segment_reduce
 
+    lib = _lib.load()
+
     def timed_reduce(feat, plan, mode, *a, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        ke = K._KernelEvents(lib)                      # HIP events bound to the kernel launch itself (start / stop)
+        lib.sst_segment_reduce_profile_next(ke.start, ke.stop)
         out = orig_reduce(feat, plan, mode, *a, **kw)
-        e1.record()
-        seg_records.append((e0, e1, feat.numel() * 4 + out.numel() * 4 + feat.size(0) * 4))
+        lib.sst_segment_reduce_profile_next(None, None)
+        seg_records.append((ke, feat.numel() * 4 + out.numel() * 4 + feat.size(0) * 4))
         return out
 
     K.segment_reduce = timed_reduce
@@ -258,10 +261,12 @@ def _conv_roofline(model, clouds):
                 'frac': round(fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                 'algorithmic_flops': fl, 'ms': round(ms, 3)}
     seg = None
-    if seg_records:
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in seg_records)
-        by = sum(b for _, _, b in seg_records)
-        seg = {'bound': 'hbm', 'kernel': f'seg_reduce_fwd_* ({len(seg_records)} segmented reductions of one forward pass)',
+    timed = [(t, b) for t, b in ((ke.elapsed_time(ke), b) for ke, b in seg_records) if t > 0]
+    if timed:
+        ms = sum(t for t, _ in timed)
+        by = sum(b for _, b in timed)
+        seg = {'bound': 'hbm', 'kernel': f'seg_reduce_fwd_* ({len(timed)} segmented reductions of one forward pass; HIP events bound '
+                                       'to each launch)',
                'achieved': round(by / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'algorithmic_bytes': by, 'ms': round(ms, 3)}
     return conv, seg

@@ -115,6 +115,9 @@ int sst_unpack_keys(const uint64_t* d_ukeys, int64_t m, int ncols, const int64_t
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream);
+/* sst_segment_reduce_profile_next(start, stop): one-shot hipEvent_t pair bound to the NEXT forward launch of this thread
+ * (kernel start / stop; measurement hook of bench.py's FSD workloads, as sst_sra_attn_profile_next_fwd). */
+int sst_segment_reduce_profile_next(void* start, void* stop);
 /* Backward (scatter_points_cuda.cu:236-303).  d_grad_feats [n, c] is fully written (zero where no
  * gradient flows).  SUM/MEAN: g[i] = G[inv[i]] (/count); rows with d_inverse[i] < 0 get 0.
  * MAX: gradient goes to d_argmax[g, ch] only.  d_inverse may be shifted by the caller

@@ -11,6 +11,7 @@
 // exactly one thread walking its group's CSR range: no atomics, deterministic, and a wave reads 64
 // consecutive channels of one row (coalesced 256 B) — HBM-bound: (4C+4) B/point + 4C B/group.
 #include <math.h>
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace {
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
                                                            const int32_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
-                                                           int32_t n_rows, const int32_t* __restrict__ d_mlim) {
+                                                           int32_t n_rows, const int32_t* __restrict__ d_mlim, int skip_len) {
   if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int c4 = c >> 2;
   const int64_t total = m * c4;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
     const int ch = (int)(e - g * c4) * 4;
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
     const int beg = offsets[gs], end = offsets[gs + 1];
+    if (skip_len > 0 && end - beg > skip_len) continue;  // long group: seg_reduce_fwd_block_k takes it
     float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
     int32_t a0 = n_rows, a1 = n_rows, a2 = n_rows, a3 = n_rows;
@@ -102,6 +104,90 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
     if (end <= beg) acc = make_float4(0.f, 0.f, 0.f, 0.f);  // empty group: 0 (torch_scatter.scatter_max's fill)
     *(float4*)(out + g * c + ch) = acc;
     if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + ch) = make_int4(a0, a1, a2, a3);
+  }
+}
+
+// Long groups (FSD clusters: hundreds to thousands of points each): ONE WORKGROUP per group.  The eight 32-lane halves of
+// the block stride over the group's points (each half reads whole 16-byte-per-lane row segments, two points in flight),
+// the eight partial results meet in LDS in a fixed order.  The thread-per-(group, 4 channels) kernel above walks such a
+// group serially behind one load latency per 4 points (measured on FSD's clusters: 0.34 TB/s).  Launched beside it when
+// the average group has at least 8 points: groups of more than kLongGroup (16) points are skipped there and taken here.  Ties of the maximum: smallest row index, as above (every half sees its rows
+// in ascending order, the halves are combined with value first, then the smaller index).
+__global__ __launch_bounds__(256) void seg_reduce_fwd_block_k(const float* __restrict__ feats, int c,
+                                                              const uint32_t* __restrict__ perm,
+                                                              const int32_t* __restrict__ offsets,
+                                                              const int32_t* __restrict__ gidx, int64_t m, int mode,
+                                                              float* __restrict__ out, int32_t* __restrict__ argmax,
+                                                              int32_t n_rows, const int32_t* __restrict__ d_mlim, int min_len) {
+  __shared__ float4 lds_v[8][32];
+  __shared__ int4 lds_a[8][32];
+  if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;
+  const int half = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int c4 = c >> 2;
+  for (int64_t g = blockIdx.x; g < m; g += gridDim.x) {
+    const int64_t gs = gidx != nullptr ? gidx[g] : g;
+    const int beg = offsets[gs], end = offsets[gs + 1];
+    if (end - beg <= min_len) continue;     // short group: the thread-per-(group, 4 channels) kernel took it (uniform)
+    for (int q0 = 0; q0 < c4; q0 += 32) {  // 32 channel quads per pass (c = 128: one pass)
+      const int q = q0 + l;
+      const bool live = q < c4;
+      float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      int4 arg = make_int4(n_rows, n_rows, n_rows, n_rows);
+      for (int p = beg + half; p < end; p += 16) {
+        const bool two = p + 8 < end;
+        const uint32_t r0 = perm[p], r1 = perm[two ? p + 8 : p];
+        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+        if (live) {
+          x0 = *(const float4*)(feats + (int64_t)r0 * c + 4 * q);
+          x1 = *(const float4*)(feats + (int64_t)r1 * c + 4 * q);
+        }
+        if (mode == SST_REDUCE_MAX) {
+          if (x0.x > acc.x) acc.x = x0.x, arg.x = (int)r0;
+          if (x0.y > acc.y) acc.y = x0.y, arg.y = (int)r0;
+          if (x0.z > acc.z) acc.z = x0.z, arg.z = (int)r0;
+          if (x0.w > acc.w) acc.w = x0.w, arg.w = (int)r0;
+          if (two) {
+            if (x1.x > acc.x) acc.x = x1.x, arg.x = (int)r1;
+            if (x1.y > acc.y) acc.y = x1.y, arg.y = (int)r1;
+            if (x1.z > acc.z) acc.z = x1.z, arg.z = (int)r1;
+            if (x1.w > acc.w) acc.w = x1.w, arg.w = (int)r1;
+          }
+        } else {
+          acc.x += x0.x, acc.y += x0.y, acc.z += x0.z, acc.w += x0.w;
+          if (two) acc.x += x1.x, acc.y += x1.y, acc.z += x1.z, acc.w += x1.w;
+        }
+      }
+      lds_v[half][l] = acc;
+      lds_a[half][l] = arg;
+      __syncthreads();
+      if (half == 0 && live) {
+        float4 r = lds_v[0][l];
+        int4 a = lds_a[0][l];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) {
+          const float4 v = lds_v[h][l];
+          const int4 b = lds_a[h][l];
+          if (mode == SST_REDUCE_MAX) {
+            // a half that saw no point holds (-inf, n_rows): never wins; -inf values of real rows keep the smaller index
+            if (v.x > r.x || (v.x == r.x && b.x < a.x)) r.x = v.x, a.x = b.x;
+            if (v.y > r.y || (v.y == r.y && b.y < a.y)) r.y = v.y, a.y = b.y;
+            if (v.z > r.z || (v.z == r.z && b.z < a.z)) r.z = v.z, a.z = b.z;
+            if (v.w > r.w || (v.w == r.w && b.w < a.w)) r.w = v.w, a.w = b.w;
+          } else {
+            r.x += v.x, r.y += v.y, r.z += v.z, r.w += v.w;
+          }
+        }
+        if (mode == SST_REDUCE_MEAN && end > beg) {
+          const float cnt = (float)(end - beg);
+          r.x = r.x / cnt, r.y = r.y / cnt, r.z = r.z / cnt, r.w = r.w / cnt;
+        }
+        if (end <= beg) r = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(out + g * c + 4 * q) = r;
+        if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + 4 * q) = a;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -378,22 +464,56 @@ int sst_vfe_decorate_f32(const float* d_points, int64_t ldp, int64_t n, int c, c
   return SST_OK;
 }
 
+// one-shot kernel-bound events for the next forward launch on this thread (bench.py's roofline block of the FSD workloads;
+// same scheme as sst_sra_attn_profile_next_fwd: hipExtLaunchKernelGGL start / stop events)
+static thread_local hipEvent_t g_seg_ev[2] = {nullptr, nullptr};
+int sst_segment_reduce_profile_next(void* start, void* stop) {
+  g_seg_ev[0] = (hipEvent_t)start;
+  g_seg_ev[1] = (hipEvent_t)stop;
+  return SST_OK;
+}
+
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream) {
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_offsets || !d_out || (n > 0 && (!d_feats || !d_perm))) return SST_ERR_ARG;
+  hipEvent_t e0 = g_seg_ev[0], e1 = g_seg_ev[1];
+  g_seg_ev[0] = g_seg_ev[1] = nullptr;
+  const bool timed = e0 != nullptr && e1 != nullptr;
   if ((c & 3) == 0 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15) == 0 && n > 0) {
+    // groups of many points can only exist when the average is not tiny: the second kernel (one workgroup per LONG group,
+    // every other block leaves at once) is launched when n >= 8 m - never for voxel grouping at 1-6 points per voxel
+    constexpr int kLongGroup = 16;
+    const bool split = n >= 8 * m;
     const int grid = sst_grid_1d(m * (c >> 2), 256);
-    hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                       d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
+    if (timed)
+      hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, split ? nullptr : e1, 0,
+                            d_feats, c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit,
+                            split ? kLongGroup : 0);
+    else
+      hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
+                         d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, split ? kLongGroup : 0);
+    if (split) {
+      const int grid_b = (int)(m < 65536 ? m : 65536);
+      if (timed)
+        hipExtLaunchKernelGGL(seg_reduce_fwd_block_k, dim3(grid_b), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0, d_feats,
+                              c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kLongGroup);
+      else
+        hipLaunchKernelGGL(seg_reduce_fwd_block_k, dim3(grid_b), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
+                           d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kLongGroup);
+    }
     SST_LAUNCH_CHECK();
     return SST_OK;
   }
   const int grid = sst_grid_1d(m * c, 256);
-  hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                     d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
+  if (timed)
+    hipExtLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, d_feats, c, d_perm,
+                          d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
+  else
+    hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
+                       d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

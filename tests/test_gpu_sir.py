@@ -113,3 +113,44 @@ def test_dynamic_scatter_vfe_matches_reference_golden():
     np.testing.assert_allclose(vf.detach().cpu().numpy(), g['out::voxel_feats'], rtol=1e-3, atol=1e-3)
     (vf * torch.from_numpy(g['in::grad_out']).to(DEV)).sum().backward()
     np.testing.assert_allclose(pts.grad.cpu().numpy(), g['out::grad_points'], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize('c', [128, 132, 64])
+def test_segment_reduce_long_groups_one_workgroup_per_group(c):
+    """FSD-like clusters: a few groups with thousands of points, many with a handful (average >= 4 points: the
+    one-workgroup-per-group kernel of csrc/scatter.hip); max with its arg-max (ties -> smallest row), sum, mean and the
+    gradients, against float64 torch"""
+    from sst_amd import kernels as K
+    from sst_amd.sst_ops import plan_of_inverse
+    rng = np.random.default_rng(c)
+    sizes = np.concatenate([[3000, 1700, 512, 65, 64, 63], rng.integers(1, 40, size=700)])
+    m = len(sizes)
+    inv = np.repeat(np.arange(m), sizes)
+    rng.shuffle(inv)
+    n = inv.size
+    assert n >= 8 * m
+    feat = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32))
+    feat[:, :8] = torch.round(feat[:, :8])            # ties of the maximum in the first channels
+    inv_t = torch.from_numpy(inv).to(DEV)
+    plan = plan_of_inverse(inv_t, m)
+    fg = feat.to(DEV).requires_grad_(True)
+    idx = torch.from_numpy(inv).view(-1, 1).expand(-1, c)
+    f64 = feat.double()
+    for mode, red in (('max', 'amax'), ('sum', 'sum'), ('mean', 'mean')):
+        got = K.segment_reduce(fg, plan, mode)
+        ref = torch.zeros(m, c, dtype=torch.float64).scatter_reduce(0, idx, f64, reduce=red, include_self=False)
+        assert float((got.detach().cpu().double() - ref).abs().max()) < 1e-4, mode
+    mx, arg = K.segment_argmax(feat.to(DEV), plan)
+    ref = torch.full((m, c), float('-inf'), dtype=torch.float64).scatter_reduce(0, idx, f64, reduce='amax')
+    assert torch.equal(mx.cpu().double(), ref)
+    # smallest row index among the rows attaining the maximum
+    hit = (f64 == ref[inv])
+    cand = torch.where(hit, torch.arange(n).view(-1, 1).expand(-1, c), torch.full((n, c), n))
+    first = torch.full((m, c), n, dtype=torch.long).scatter_reduce(0, idx, cand, reduce='amin')
+    assert torch.equal(arg.cpu().long(), first)
+    out = K.segment_reduce(fg, plan, 'max')
+    gout = torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32))
+    (out * gout.to(DEV)).sum().backward()
+    want = torch.zeros(n, c, dtype=torch.float64)
+    want.scatter_(0, first, gout.double())
+    assert float((fg.grad.cpu().double() - want).abs().max()) < 1e-6
