@@ -213,19 +213,27 @@ def wgrad_group(problems):
 # ------------------------------------------------------------------------------------------------------------------
 # host pieces
 # ------------------------------------------------------------------------------------------------------------------
-_shadows = {}
+_shadows = {}   # id(parameter) -> (weak reference to it, {(rows, transposed): (version, bf16 copy)})
 
 
 def shadow(p, rows=None, transposed=False):
     """bf16 copy of an fp32 parameter - of the row range ``rows`` = (lo, hi) of it, transposed if asked (the operand of
-    a data gradient) - re-made when the parameter's version counter moves"""
-    key = (p.data_ptr(), tuple(p.shape), rows, transposed)
-    hit = _shadows.get(key)
+    a data gradient) - re-made when the parameter's version counter moves.  The cache belongs to the parameter OBJECT
+    (checked through a weak reference, dropped when it dies): a new parameter that happens to reuse the id, address, shape
+    and version of a dead one never sees its copy."""
+    import weakref
+    entry = _shadows.get(id(p))
+    if entry is None or entry[0]() is not p:
+        pid = id(p)
+        entry = _shadows[pid] = (weakref.ref(p, lambda _r, pid=pid: _shadows.pop(pid, None)), {})
+    per_param = entry[1]
+    key = (rows, transposed)
+    hit = per_param.get(key)
     if hit is not None and hit[0] == p._version and hit[1].device == p.device:
         return hit[1]
     src = p.detach() if rows is None else p.detach()[rows[0]:rows[1]]
     s = (src.t() if transposed else src).to(BF16).contiguous()
-    _shadows[key] = (p._version, s)
+    per_param[key] = (p._version, s)
     return s
 
 
