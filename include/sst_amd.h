@@ -599,6 +599,16 @@ int sst_spconv_maxpool_fwd_f32(const float* d_x, int64_t ldx, const int32_t* d_o
 int sst_spconv_maxpool_bwd_f32(const float* d_x, int64_t ldx, const float* d_y, int64_t ldy, const float* d_dy,
                                int64_t lddy, const int32_t* d_in2out, int64_t n, int kvol, int c, float* d_dx,
                                int64_t lddx, void* stream);
+/*   sst_spconv_conv_os_f32: the same contraction as sst_spconv_gather_gemm_f32 (indiceConv and the data gradient of
+ *     indiceConvBackward, spconv_ops.h:256-446) as an output-stationary implicit GEMM: W[k] packed into MFMA-fragment
+ *     order (d_workspace, sst_spconv_conv_os_workspace_bytes) and staged through LDS, partner rows gathered straight into
+ *     MFMA operands, XCD-aware tile numbering (csrc/spconv_os.hip).  K <= 32, cin % 4 == 0, ldx % 4 == 0, d_x 16-byte
+ *     aligned; SST_ERR_UNSUPPORTED otherwise (use sst_spconv_gather_gemm_f32).  trans_w as above.  tile_cfg: 0 = tile
+ *     shape chosen from m and cout, else 10 * (column tiles of 16: 4 | 8) + (16-row blocks per wave: 1 | 2). */
+int64_t sst_spconv_conv_os_workspace_bytes(int kvol, int cin, int cout);
+int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
+                           int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy,
+                           int tile_cfg, void* d_workspace, void* stream);
 int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout);
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                          int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,

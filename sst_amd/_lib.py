@@ -121,6 +121,9 @@ _SIGNATURES = {
     'sst_spconv_pair_lists_i32': (c_i32, [c_ptr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_spconv_gather_gemm_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr,
                                            c_i64, c_i32, c_ptr]),
+    'sst_spconv_conv_os_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),
+    'sst_spconv_conv_os_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i64,
+                                       c_i32, c_ptr, c_ptr]),
     'sst_spconv_maxpool_fwd_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_spconv_maxpool_bwd_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr,
                                            c_i64, c_ptr]),

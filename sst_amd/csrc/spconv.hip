@@ -553,6 +553,11 @@ __device__ __forceinline__ bool sp_find_chunk(const int32_t* __restrict__ num, i
   return false;
 }
 
+// NQ = column tiles of 32 per strip (2: layers with up to 64 output columns, where a 128-column strip would multiply
+// zeros half of the time; 4 otherwise).  Software pipeline: the pair indices of step i + 2 and the rows of step i + 1
+// are in flight while step i is multiplied; every load is unconditional (clamped pair / channel index, zeroed by a
+// select on the A side), so the s_waitcnt counters the compiler derives stay exact.
+template <int NQ>
 __global__ __launch_bounds__(256) void sp_wgrad_k(const float* __restrict__ x, int64_t ldx,
                                                   const float* __restrict__ dy, int64_t lddy,
                                                   const int32_t* __restrict__ pairs, int64_t pair_ld, int x_side,
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256) void sp_wgrad_k(const float* __restrict__ x, i
   if (!sp_find_chunk(num, kvol, blockIdx.x, k, first)) return;  // uniform
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, kk = lane >> 5;
-  const int n_cog = (cout + 127) / 128;  // column groups of 128
+  const int n_cog = (cout + 32 * NQ - 1) / (32 * NQ);  // column groups of 32 NQ
   const int strip = blockIdx.y * 4 + wave;
   const int n_ci = (cin + 31) / 32;
   const int ci = strip / n_cog, cog = strip - ci * n_cog;
@@ -570,47 +575,65 @@ __global__ __launch_bounds__(256) void sp_wgrad_k(const float* __restrict__ x, i
   const int np = num[k];
   const int p0 = (blockIdx.x - first) * kSpChunk;
   const int p1 = p0 + kSpChunk < np ? p0 + kSpChunk : np;
+  if (p0 >= p1) return;
   const int32_t* pa = pairs + ((int64_t)k * 2 + x_side) * pair_ld;
   const int32_t* pb = pairs + ((int64_t)k * 2 + (1 - x_side)) * pair_ld;
-  f32x16 acc[4];
+  f32x16 acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   const int ca = ci * 32 + l31;
   const bool a_ok = ca < cin;
-  bool b_ok[4];
-  int cb[4];
+  const int ca_ld = a_ok ? ca : cin - 1;
+  bool b_ok[NQ];
+  int cb[NQ], cb_ld[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    cb[q] = cog * 128 + q * 32 + l31;
+  for (int q = 0; q < NQ; ++q) {
+    cb[q] = cog * 32 * NQ + q * 32 + l31;
     b_ok[q] = cb[q] < cout;
+    cb_ld[q] = b_ok[q] ? cb[q] : cout - 1;
   }
+  int ia[4], ib[4];
+  float a[4], b[4][NQ];
+  auto load_idx = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int pp = p + 2 * u + kk;
+      pp = pp < p1 ? pp : p1 - 1;
+      ia[u] = pa[pp];
+      ib[u] = pb[pp];
+    }
+  };
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = x[(int64_t)ia[u] * ldx + ca_ld];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) b[u][q] = dy[(int64_t)ib[u] * lddy + cb_ld[q]];
+    }
+  };
+  load_idx(p0);
+  load_rows();
+  load_idx(p0 + 8);
   for (int p = p0; p < p1; p += 8) {
-    int ia[4], ib[4];
-    bool ok[4];
+    float ac[4], bc[4][NQ];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int pp = p + 2 * u + kk;
-      ok[u] = pp < p1;
-      ia[u] = ok[u] ? pa[pp] : 0;
-      ib[u] = ok[u] ? pb[pp] : 0;
-    }
-    float a[4], b[4][4];
+      ac[u] = (a_ok && p + 2 * u + kk < p1) ? a[u] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = (ok[u] && a_ok) ? x[(int64_t)ia[u] * ldx + ca] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b[u][q] = (ok[u] && b_ok[q]) ? dy[(int64_t)ib[u] * lddy + cb[q]] : 0.f;
+      for (int q = 0; q < NQ; ++q) bc[u][q] = b[u][q];
     }
+    load_rows();       // rows of step p + 8 (their indices were requested a step ago)
+    load_idx(p + 16);  // indices of step p + 16
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][q], acc[q], 0, 0, 0);
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u][q], acc[q], 0, 0, 0);
   }
   float* dst = part + (int64_t)blockIdx.x * cin * cout;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     if (!b_ok[q]) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -855,11 +878,20 @@ int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64
     return SST_OK;
   }
   const int64_t chunks = sp_wgrad_chunks(kvol, pair_ld, total_pairs);
-  const int strips = (int)(sst_div_up(cin, 32) * sst_div_up(cout, 128));
+  // strips of 32 input channels x 64 or 128 output columns: the narrow strip whenever the columns beyond the last
+  // multiple of 128 fit into 64 (64-channel layers: a 128-column strip would multiply zeros half of the time)
+  const int rem = cout % 128;
+  const int nq = (rem > 0 && rem <= 64) ? 2 : 4;
+  const int strips = (int)(sst_div_up(cin, 32) * sst_div_up(cout, 32 * nq));
   if (kvol > 65535 || chunks > 0x7fffffff || sst_div_up(strips, 4) > 65535) return SST_ERR_UNSUPPORTED;
   float* part = (float*)d_workspace;
-  hipLaunchKernelGGL(sp_wgrad_k, dim3((unsigned)chunks, (unsigned)sst_div_up(strips, 4)), dim3(256), 0, st, d_x, ldx,
-                     d_dy, lddy, d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, part);
+  const dim3 wg_grid((unsigned)chunks, (unsigned)sst_div_up(strips, 4));
+  if (nq == 2)
+    hipLaunchKernelGGL(sp_wgrad_k<2>, wg_grid, dim3(256), 0, st, d_x, ldx, d_dy, lddy, d_pairs, pair_ld, x_side, d_num,
+                       kvol, cin, cout, part);
+  else
+    hipLaunchKernelGGL(sp_wgrad_k<4>, wg_grid, dim3(256), 0, st, d_x, ldx, d_dy, lddy, d_pairs, pair_ld, x_side, d_num,
+                       kvol, cin, cout, part);
   hipLaunchKernelGGL(sp_wgrad_reduce_k, dim3((unsigned)sst_div_up(per_k, 256), (unsigned)kvol), dim3(256), 0, st, part,
                      d_num, kvol, per_k, d_dw);
   SST_LAUNCH_CHECK();

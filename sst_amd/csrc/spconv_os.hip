@@ -1,0 +1,310 @@
+// (§8 f4) sparse 3-D convolution, second generation of the contraction kernel: output-stationary implicit GEMM with the
+// weights of one kernel offset staged through LDS and the partner rows gathered straight into MFMA operands.
+//
+// Replaces the same reference code as csrc/spconv.hip's sp_gather_gemm_k / sp_conv_seg_k: indiceConv and the data
+// gradient of indiceConvBackward (mmdet3d/ops/spconv/include/spconv/spconv_ops.h:256-446; per kernel offset gather ->
+// mm -> scatter-add there), on the dense maps out2in / in2out of the rulebook:
+//     Y[r, :] = sum_k X[map[k][r], :] W[k]        (map[k][r] = -1: no partner)
+//
+// Why a second kernel.  On LiDAR-like voxel sets every level below the first has 17-18 of 27 partners per voxel and,
+// with voxels numbered by ascending (b, z, y, x), 85-97 % of the (16..128-row block, offset) slots that have ANY partner
+// are fully populated (tools/rulebook_stats.py).  Compacting rows per offset (sp_conv_seg_k: LDS row lists, LDS atomics,
+// 32-row stages behind a barrier) buys nothing there; what the contraction needs is what a dense tall GEMM needs:
+//   * a workgroup owns 64 or 128 output rows x 64 or 128 output columns; every wave owns 16 or 32 of the rows and ALL
+//     the columns of the group, so the accumulators never leave registers (no LDS adds, no atomics, deterministic);
+//   * the TRANSPOSED product Y^T = W[k]^T X_g^T on v_mfma_f32_16x16x4_f32: a lane ends up with 4 consecutive output
+//     columns of one row (16-byte stores), and the gathered X fragment is the MFMA B operand as it comes from memory - a
+//     16-byte load gives a lane 4 consecutive channels of its partner row = 4 consecutive k-steps (idiom of
+//     csrc/dense_f32.hip); no LDS round trip for X;
+//   * W[k] (one 64-channel chunk: 16 / 32 KB) is staged through LDS in MFMA-fragment order (packed once per call by
+//     sp_os_pack_w_k, which also absorbs the transposition the data gradient needs), double-buffered, ONE barrier per
+//     stage; the partner rows and the W slab of stage s + 1 are requested before the MFMAs of stage s are issued
+//     (128-256 MFMAs = 1.7-3.4 us per wave and stage: more than an L2 / MALL round trip);
+//   * loads are unconditional (absent partners read row 0 and are zeroed by a select, channel tails read a clamped
+//     address against zero weights), so the compiler's s_waitcnt bookkeeping stays static (DESIGN.md, round-2 finding);
+//   * offsets without a partner in the workgroup's rows are never staged; a wave whose own rows have none skips the MFMAs;
+//   * XCD-aware numbering: workgroup b runs on XCD b % 8, so XCD i is handed the i-th CONTIGUOUS eighth of the row
+//     tiles: its 4 MB L2 then sees one eighth of X plus halo instead of all of it.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kOsMaxK = 32;   // kernel offsets the index image holds (3 x 3 x 3 = 27)
+constexpr int kOsChunk = 64;  // input channels per stage
+
+// Packed weights: slab (k, column group cg, channel chunk cc) = [4 j][NCT ct][64 lanes][4 t] floats with
+//   value = W[k][c = 64 cc + 16 j + 4 (lane >> 4) + t][n = 16 NCT cg + 16 ct + (lane & 15)]   (0 outside cin x cout),
+// i.e. the A fragments of the four k-steps a 16-byte X load feeds, one ds_read_b128 per lane.
+// trans_w: W[k] is stored [n][c] (the data gradient reads the forward weights with the roles swapped).
+__global__ __launch_bounds__(256) void sp_os_pack_w_k(const float* __restrict__ w, int kvol, int cin, int cout,
+                                                      int trans_w, int nct, int n_cg, int n_cc,
+                                                      float* __restrict__ wp) {
+  const int64_t total = (int64_t)kvol * n_cg * n_cc * 64 * 16 * nct;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    int64_t rest = e >> 8;
+    const int ct = (int)(rest % nct);
+    rest /= nct;
+    const int j = (int)(rest & 3);
+    int64_t slab = rest >> 2;
+    const int cc = (int)(slab % n_cc);
+    slab /= n_cc;
+    const int cg = (int)(slab % n_cg);
+    const int k = (int)(slab / n_cg);
+    const int c = cc * kOsChunk + 16 * j + 4 * (lane >> 4) + t;
+    const int n = cg * 16 * nct + 16 * ct + (lane & 15);
+    float v = 0.f;
+    if (c < cin && n < cout)
+      v = trans_w ? w[((int64_t)k * cout + n) * cin + c] : w[((int64_t)k * cin + c) * cout + n];
+    wp[e] = v;
+  }
+}
+
+template <int NCT, int RB>
+__global__ __launch_bounds__(256) void sp_conv_os_k(const float* __restrict__ x, int64_t ldx,
+                                                    const int32_t* __restrict__ map, int64_t m, int kvol,
+                                                    const float* __restrict__ wp, int cin, int cout,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
+                                                    int n_units, int n_cg, int n_cc, int units_per_xcd, int vec_store) {
+  constexpr int ROWS = 64 * RB;          // rows of the workgroup: 4 waves x RB blocks of 16
+  constexpr int SLAB = 64 * 16 * NCT;    // floats of one packed W slab
+  constexpr int WREG = SLAB / 4 / 256;   // 16-byte pieces of a slab per thread
+  extern __shared__ __attribute__((aligned(16))) float os_smem[];
+  float (*wbuf)[SLAB] = (float (*)[SLAB])os_smem;                      // [2][SLAB]
+  int (*idx)[ROWS] = (int (*)[ROWS])(os_smem + 2 * SLAB);              // [kOsMaxK][ROWS]
+  unsigned* live_w = (unsigned*)(os_smem + 2 * SLAB + kOsMaxK * ROWS);  // [4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  // ---- which (row tile, column group) ----
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int unit = xcd * units_per_xcd + slot;
+  if (unit >= n_units) return;  // uniform
+  const int tile = unit / n_cg, cg = unit - tile * n_cg;
+  const int64_t r0 = (int64_t)tile * ROWS;
+  // ---- partner rows of the tile for every offset -> LDS; which offsets are populated ----
+  for (int e = tid; e < kvol * ROWS; e += 256) {
+    const int k = e / ROWS, row = e - k * ROWS;
+    idx[k][row] = (r0 + row < m) ? map[(int64_t)k * m + r0 + row] : -1;
+  }
+  __syncthreads();
+  {
+    unsigned mine = 0;
+    for (int k = 0; k < kvol; ++k) {
+      const int v = lane < 16 * RB ? idx[k][wave * 16 * RB + lane] : -1;
+      mine |= (__ballot(v >= 0) != 0ull ? 1u : 0u) << k;
+    }
+    if (lane == 0) live_w[wave] = mine;
+  }
+  __syncthreads();
+  const unsigned wave_live = live_w[wave];
+  const unsigned live = live_w[0] | live_w[1] | live_w[2] | live_w[3];
+  const int wave_row = wave * 16 * RB;
+
+  f32x4 acc[RB][NCT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[rb][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (live != 0u) {
+    const int c_last = cin - 4;  // cin % 4 == 0 (checked by the host): the last whole 16-byte piece of a row
+    f32x4 xc[RB][4], xn[RB][4], wr[WREG];
+    int sn[RB];
+    auto fetch_w = [&](int k, int cc) {
+      const f32x4* src = (const f32x4*)(wp + ((int64_t)(k * n_cg + cg) * n_cc + cc) * SLAB);
+#pragma unroll
+      for (int u = 0; u < WREG; ++u) wr[u] = src[tid + 256 * u];
+    };
+    auto gather_x = [&](int k, int cc, f32x4 (&dst)[RB][4], int (&s)[RB]) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        s[rb] = idx[k][wave_row + 16 * rb + l15];
+        const float* p = x + (int64_t)(s[rb] >= 0 ? s[rb] : 0) * ldx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int c = cc * kOsChunk + 16 * j + 4 * kq;
+          c = c < c_last ? c : c_last;  // beyond cin the packed weights are zero: any finite value will do
+          dst[rb][j] = *(const f32x4*)(p + c);
+        }
+      }
+    };
+    auto next_live = [&](int k) {  // first populated offset >= k (32 if none)
+      const unsigned rest = k < 32 ? (live >> k) : 0u;
+      return rest ? k + __builtin_ctz(rest) : 32;
+    };
+    int k = next_live(0), cc = 0, buf = 0;
+    fetch_w(k, 0);
+    gather_x(k, 0, xn, sn);
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) *(f32x4*)(&wbuf[0][4 * (tid + 256 * u)]) = wr[u];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xc[rb][j] = sn[rb] >= 0 ? xn[rb][j] : zero4;  // rows without a partner contribute 0
+    __syncthreads();
+    while (true) {
+      int nk = k, ncc = cc + 1;
+      if (ncc == n_cc) {
+        ncc = 0;
+        nk = next_live(k + 1);
+      }
+      const bool has_next = nk < 32;
+      if (!has_next) {  // keep the loads unconditional: the last stage requests itself once more
+        nk = k;
+        ncc = cc;
+      }
+      fetch_w(nk, ncc);
+      gather_x(nk, ncc, xn, sn);
+      if ((wave_live >> k) & 1u) {  // uniform per wave
+        const float* wb = &wbuf[buf][4 * lane];
+        // column tiles in groups of 4; the fragments of group q + 1 are read while the MFMAs of group q issue
+        constexpr int CG4 = NCT / 4, G = 4 * CG4;
+        f32x4 wf[4], wnx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wf[u] = *(const f32x4*)(wb + u * 256);
+#pragma clang loop unroll(full)
+        for (int q = 0; q < G; ++q) {
+          const int j = q / CG4, g4 = q - j * CG4;
+          const int qn = q + 1 < G ? q + 1 : q;
+          const int jn = qn / CG4, gn = qn - jn * CG4;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) wnx[u] = *(const f32x4*)(wb + ((jn * NCT + 4 * gn + u) * 256));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int rb = 0; rb < RB; ++rb)
+                acc[rb][4 * g4 + u] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][t], xc[rb][j][t], acc[rb][4 * g4 + u], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) wf[u] = wnx[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WREG; ++u) *(f32x4*)(&wbuf[buf ^ 1][4 * (tid + 256 * u)]) = wr[u];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xc[rb][j] = sn[rb] >= 0 ? xn[rb][j] : zero4;
+      __syncthreads();
+      if (!has_next) break;
+      k = nk;
+      cc = ncc;
+      buf ^= 1;
+    }
+  }
+  // ---- epilogue: lane = (row l15 of its block, 4 consecutive columns at 4 kq of every column tile) ----
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int64_t row = r0 + wave_row + 16 * rb + l15;
+    if (row >= m) continue;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int n = cg * 16 * NCT + 16 * ct + 4 * kq;
+      if (n >= cout) continue;
+      f32x4 v = acc[rb][ct];
+      if (vec_store && n + 3 < cout) {
+        if (bias) v += *(const f32x4*)(bias + n);
+        *(f32x4*)(y + row * ldy + n) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < cout) y[row * ldy + n + e] = v[e] + (bias ? bias[n + e] : 0.f);
+      }
+    }
+  }
+}
+
+struct os_cfg {
+  int nct, rb, n_cg, n_cc;
+  int64_t n_tiles;
+};
+
+// tile shape of a call: 128 rows x 128 columns when that still gives the 256 CUs a few workgroups each, smaller tiles
+// for the deep levels of a U-Net (3 k - 12 k voxels x 128 - 256 channels), where the large ones would leave CUs idle
+os_cfg os_pick(int64_t m, int cout, int tile_cfg) {
+  static int env_cfg = -1;  // SST_SPCONV_OS_TILE = 10 * NCT + RB overrides the automatic choice (A/B measurements)
+  if (env_cfg < 0) {
+    const char* e = getenv("SST_SPCONV_OS_TILE");
+    env_cfg = e ? atoi(e) : 0;
+  }
+  if (tile_cfg == 0) tile_cfg = env_cfg;
+  const int env_nct = tile_cfg / 10, env_rb = tile_cfg % 10;
+  os_cfg c;
+  c.nct = cout <= 64 ? 4 : 8;
+  c.rb = 2;
+  auto units = [&](int nct, int rb) { return sst_div_up(m, 64 * rb) * sst_div_up(cout, 16 * nct); };
+  if (units(c.nct, 2) < 1024) c.rb = 1;
+  if (c.nct == 8 && units(8, c.rb) < 512) c.nct = 4;
+  if (env_nct == 4 || env_nct == 8) c.nct = env_nct;
+  if (env_rb == 1 || env_rb == 2) c.rb = env_rb;
+  c.n_cg = (int)sst_div_up(cout, 16 * c.nct);
+  c.n_tiles = sst_div_up(m, 64 * c.rb);
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sst_spconv_conv_os_workspace_bytes(int kvol, int cin, int cout) {
+  if (kvol < 1 || cin < 1 || cout < 1) return 256;
+  // the packed size does not depend on the tile shape: column groups x 16 NCT columns = cout rounded up to 64 or 128
+  const int64_t cols = sst_div_up(cout, 128) * 128;
+  return (int64_t)kvol * sst_div_up(cin, kOsChunk) * kOsChunk * cols * (int64_t)sizeof(float) + 256;
+}
+
+int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
+                           int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy,
+                           int tile_cfg, void* d_workspace, void* stream) {
+  if (m < 0 || kvol < 1 || cin < 1 || cout < 1 || ldx < cin || ldy < cout) return SST_ERR_ARG;
+  if (tile_cfg != 0 && tile_cfg != 41 && tile_cfg != 42 && tile_cfg != 81 && tile_cfg != 82) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_map || !d_w || !d_y || !d_workspace) return SST_ERR_ARG;
+  if (kvol > kOsMaxK || (cin & 3) || (ldx & 3) || (((uintptr_t)d_x) & 15) || (((uintptr_t)d_workspace) & 15))
+    return SST_ERR_UNSUPPORTED;
+  const os_cfg c = os_pick(m, cout, tile_cfg);
+  const int n_cc = (int)sst_div_up(cin, kOsChunk);
+  const int64_t n_units = c.n_tiles * c.n_cg;
+  if (n_units > 0x3fffffff) return SST_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  float* wp = (float*)d_workspace;
+  const int64_t packed = (int64_t)kvol * c.n_cg * n_cc * 64 * 16 * c.nct;
+  hipLaunchKernelGGL(sp_os_pack_w_k, dim3(sst_grid_1d(packed, 256)), dim3(256), 0, st, d_w, kvol, cin, cout, trans_w,
+                     c.nct, c.n_cg, n_cc, wp);
+  const int units_per_xcd = (int)sst_div_up(n_units, 8);
+  const dim3 grid((unsigned)(8 * units_per_xcd));
+  const int vec_store = ((ldy & 3) == 0 && (((uintptr_t)d_y) & 15) == 0 && (!d_bias || (((uintptr_t)d_bias) & 15) == 0)) ? 1 : 0;
+#define SST_OS_LAUNCH(NCT, RB)                                                                                         \
+  do {                                                                                                                 \
+    constexpr int lds = (2 * 64 * 16 * NCT + kOsMaxK * 64 * RB + 4) * (int)sizeof(float);                              \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      SST_HIP(hipFuncSetAttribute((const void*)sp_conv_os_k<NCT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((sp_conv_os_k<NCT, RB>), grid, dim3(256), lds, st, d_x, ldx, d_map, m, kvol, wp, cin, cout,     \
+                       d_bias, d_y, ldy, (int)n_units, c.n_cg, n_cc, units_per_xcd, vec_store);                        \
+  } while (0)
+  if (c.nct == 4 && c.rb == 2)
+    SST_OS_LAUNCH(4, 2);
+  else if (c.nct == 4)
+    SST_OS_LAUNCH(4, 1);
+  else if (c.rb == 2)
+    SST_OS_LAUNCH(8, 2);
+  else
+    SST_OS_LAUNCH(8, 1);
+#undef SST_OS_LAUNCH
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+}  // extern "C"

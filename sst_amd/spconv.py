@@ -16,6 +16,7 @@ reference's GPU path (``torch::_unique`` of the linear indices, spconv_ops.h:128
 input row (the reference's CPU order; its GPU order is left to atomics).  3-D int32 indices and fp32 features only.
 """
 import math
+import os
 import weakref
 
 import numpy as np
@@ -217,20 +218,39 @@ def rulebook_of(indice_pairs, indice_pair_num, num_out):
     return rb
 
 
-def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None):
+def _conv_kernel_choice():
+    """SST_SPCONV_KERNEL=os (default: output-stationary implicit GEMM, csrc/spconv_os.hip) | legacy (the first-generation
+    kernels of csrc/spconv.hip, kept for A/B measurements and for shapes the new kernel does not take)"""
+    return os.environ.get('SST_SPCONV_KERNEL', 'os')
+
+
+def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cfg=0):
+    """Y[r] = sum_k X[mapping[k][r]] W[k]; weight3 is [K, cin, cout], or [K, cout, cin] with trans_w."""
     lib = _lib.load()
-    # compacted rows pay off when few offsets are populated or one 64-column group covers the layer (measured on FSD's
-    # U-Net: 64-channel levels 0.29-0.82 ms against 0.39-1.08 ms, 128 / 256-channel levels 1.46 / 0.90 against 0.85 / 0.64)
-    form = 2 if (cout <= 64 or (density is not None and density < 0.2)) else 1
     x = x if x.stride(1) == 1 else x.contiguous()
     if x.size(0) == 0:   # nothing to gather from (e.g. the data gradient of a layer whose output side is empty)
         return torch.zeros((rows, cout), dtype=torch.float32, device=x.device)
     y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
-    if rows > 0:
-        rc = lib.sst_spconv_gather_gemm_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, weight3.size(0),
-                                            _lib.ptr(weight3), x.size(1), cout, int(trans_w), None, _lib.ptr(y),
-                                            y.stride(0), form, _lib.stream_ptr())
-        _lib.check(rc, 'sst_spconv_gather_gemm_f32')
+    if rows == 0:
+        return y
+    kvol, cin = weight3.size(0), x.size(1)
+    weight3 = weight3 if weight3.is_contiguous() else weight3.contiguous()
+    if (_conv_kernel_choice() == 'os' and kvol <= 32 and cin % 4 == 0 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0):
+        ws = _lib.workspace(lib.sst_spconv_conv_os_workspace_bytes(kvol, cin, cout), x.device)
+        rc = lib.sst_spconv_conv_os_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin,
+                                        cout, int(trans_w), None, _lib.ptr(y), y.stride(0), int(tile_cfg), _lib.ptr(ws),
+                                        _lib.stream_ptr())
+        _lib.check(rc, 'sst_spconv_conv_os_f32')
+        return y
+    # first-generation kernels: compacted rows pay off when few offsets are populated or one 64-column group covers the
+    # layer; they read W as [cin, cout] only
+    if trans_w:
+        weight3 = weight3.transpose(1, 2).contiguous()
+    form = 2 if (cout <= 64 or (density is not None and density < 0.2)) else 1
+    rc = lib.sst_spconv_gather_gemm_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin,
+                                        cout, 0, None, _lib.ptr(y), y.stride(0), form, _lib.stream_ptr())
+    _lib.check(rc, 'sst_spconv_gather_gemm_f32')
     return y
 
 
@@ -271,14 +291,12 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     rb = rulebook_of(indice_pairs, indice_pair_num, features.size(0) if inverse else out_bp.size(0))
     w3 = filters.reshape(-1, filters.shape[-2], filters.shape[-1])
     out_bp = out_bp.contiguous()
-    # the data gradient is the same contraction with W[k]^T: transposed once (K x Cin x Cout floats) so that it runs
-    # through the compacted-row kernel, which reads W as [cin_of_the_op, cout_of_the_op]
-    w3t = w3.transpose(1, 2).contiguous()
+    # the data gradient is the same contraction with W[k]^T: the forward weights are read with the roles swapped
     if inverse:
-        input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3t, False, w3.size(1), rb.density)
+        input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3, True, w3.size(1), rb.density)
         filters_bp = _wgrad(features, out_bp, rb, indice_pairs, 1, filters.shape)
     else:
-        input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3t, False, w3.size(1), rb.density)
+        input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3, True, w3.size(1), rb.density)
         filters_bp = _wgrad(features, out_bp, rb, indice_pairs, 0, filters.shape)
     return input_bp, filters_bp
 

@@ -69,6 +69,33 @@ def test_conv_forward_backward_match_oracle(tag, cin, cout):
         assert err < 1e-4 * max(1.0, np.abs(want).max()), err
 
 
+@pytest.mark.parametrize('tile_cfg', [41, 42, 81, 82])
+@pytest.mark.parametrize('cin,cout', [(64, 64), (16, 32), (128, 160), (192, 256)])
+def test_output_stationary_kernel_every_tile_shape(tile_cfg, cin, cout):
+    """csrc/spconv_os.hip: each of the four tile shapes (64 / 128 rows x 64 / 128 columns), forward orientation and the
+    transposed-weight orientation of the data gradient, several row tiles with a ragged last one, against the float64
+    restatement of indiceConv (spconv_ops.h:256-357)."""
+    from oracle import spconv_oracle as O
+    from sst_amd import spconv
+    rng = np.random.default_rng(cin + cout + tile_cfg)
+    batch, shape, n = 2, [6, 24, 26], 1500
+    ind = _cloud(rng, n, batch, shape)
+    for subm, st in ((True, 1), (False, 2)):
+        outids, pairs, num, rb = _rulebook(ind, batch, shape, [3] * 3, [st] * 3, [1] * 3, [1] * 3, subm, False)
+        m = len(outids)
+        gen = torch.Generator().manual_seed(7)
+        x = torch.randn(n, cin, generator=gen)
+        w = torch.randn(27, cin, cout, generator=gen) * 0.2
+        gy = torch.randn(m, cout, generator=gen)
+        p_np, n_np = pairs.cpu().numpy(), num.cpu().numpy()
+        y = spconv._gather_gemm(x.to(DEV), rb.out2in, m, w.to(DEV), False, cout, rb.density, tile_cfg)
+        y_ref = O.indice_conv(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), p_np, n_np, m)
+        assert np.abs(y.cpu().numpy() - y_ref).max() < 1e-4 * max(1.0, np.abs(y_ref).max())
+        dx = spconv._gather_gemm(gy.to(DEV), rb.in2out, n, w.to(DEV), True, cin, rb.density, tile_cfg)
+        dx_ref, _ = O.indice_conv_backward(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), gy.numpy(), p_np, n_np)
+        assert np.abs(dx.cpu().numpy() - dx_ref).max() < 1e-4 * max(1.0, np.abs(dx_ref).max())
+
+
 def test_inverse_conv_matches_oracle_and_modules_chain():
     """SubMConv3d -> SparseConv3d (stride 2, indice_key) -> SubMConv3d -> SparseInverseConv3d back to the input voxels
     (the down / up pattern of middle_encoders/sparse_unet.py), forward and all gradients against the oracle."""
