@@ -363,6 +363,18 @@ typedef struct sst_wgrad_problem_bf16 {
 } sst_wgrad_problem_bf16;
 int64_t sst_wgrad_group_workspace_bytes(const sst_wgrad_problem_bf16* problems, int n);
 int sst_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_workspace, void* stream);
+/* sst_cast_group_bf16: the bf16 copies of the fp32 master weights the reduced-precision mode computes with, any number of
+ * them in one launch (what mmcv's Fp16OptimizerHook.copy_params_to_fp16 does after every optimizer step for
+ * configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82).  Problem = rows x cols block of an fp32 matrix with row stride
+ * ld_src -> bf16 [rows][cols] contiguous, or, with transpose, [cols][rows] (the operand of a data gradient).  problems is a
+ * HOST array. */
+typedef struct sst_cast_problem_bf16 {
+  const float* src; /* device */
+  void* dst;        /* device, bf16, rows * cols elements */
+  int64_t ld_src;
+  int32_t rows, cols, transpose, reserved;
+} sst_cast_problem_bf16;
+int sst_cast_group_bf16(const sst_cast_problem_bf16* problems, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a10/a14) row gather / scatter used by flat2window / window2flat / recover_bev.

@@ -30,6 +30,12 @@ class WgradProblemBF16(ctypes.Structure):
                 ('transpose_out', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class CastProblemBF16(ctypes.Structure):
+    """sst_cast_problem_bf16 of include/sst_amd.h"""
+    _fields_ = [('src', c_ptr), ('dst', c_ptr), ('ld_src', c_i64), ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
+                ('transpose', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 class WgradProblemF32(ctypes.Structure):
     """sst_wgrad_problem_f32 of include/sst_amd.h"""
     _fields_ = [('dy', c_ptr), ('x', c_ptr), ('m', c_i64), ('ld_dy', c_i64), ('ld_x', c_i64), ('dw', c_ptr), ('db', c_ptr),
@@ -93,6 +99,7 @@ _SIGNATURES = {
                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_wgrad_group_workspace_bytes': (c_i64, [c_ptr, c_i32]),
     'sst_wgrad_group_bf16': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
+    'sst_cast_group_bf16': (c_i32, [c_ptr, c_i32, c_ptr]),
     'sst_gather_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_i64, c_ptr]),
     'sst_scatter_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_add_layernorm_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr,

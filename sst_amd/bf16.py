@@ -213,28 +213,71 @@ def wgrad_group(problems):
 # ------------------------------------------------------------------------------------------------------------------
 # host pieces
 # ------------------------------------------------------------------------------------------------------------------
-_shadows = {}   # id(parameter) -> (weak reference to it, {(rows, transposed): (version, bf16 copy)})
+_shadows = {}   # id(parameter) -> (weak reference to it, {(rows, transposed): bf16 copy})
 
 
-def shadow(p, rows=None, transposed=False):
-    """bf16 copy of an fp32 parameter - of the row range ``rows`` = (lo, hi) of it, transposed if asked (the operand of
-    a data gradient) - re-made when the parameter's version counter moves.  The cache belongs to the parameter OBJECT
-    (checked through a weak reference, dropped when it dies): a new parameter that happens to reuse the id, address, shape
-    and version of a dead one never sees its copy."""
+def _shadow_slot(p):
     import weakref
     entry = _shadows.get(id(p))
     if entry is None or entry[0]() is not p:
         pid = id(p)
         entry = _shadows[pid] = (weakref.ref(p, lambda _r, pid=pid: _shadows.pop(pid, None)), {})
-    per_param = entry[1]
-    key = (rows, transposed)
-    hit = per_param.get(key)
-    if hit is not None and hit[0] == p._version and hit[1].device == p.device:
-        return hit[1]
-    src = p.detach() if rows is None else p.detach()[rows[0]:rows[1]]
-    s = (src.t() if transposed else src).to(BF16).contiguous()
-    per_param[key] = (p._version, s)
-    return s
+    return entry[1]
+
+
+def refresh_shadows(specs):
+    """(Re)make the bf16 copies of fp32 parameters: specs = iterable of (parameter, rows | None, transposed).  ONE launch
+    for all of them (sst_cast_group_bf16); the destination buffers are kept per parameter object and overwritten in place.
+    Called by run_encoder_stack at EVERY forward: the copies follow the parameters whatever wrote them - optimizer steps,
+    but also `.data` writes (mmcv's EMAHook swap, a master-to-model copy the Fp16OptimizerHook way), which do not move
+    the version counter a cache could watch."""
+    specs = list(specs)
+    if not specs:
+        return
+    arr = (_lib.CastProblemBF16 * len(specs))()
+    for q, (p, rows, transposed) in zip(arr, specs):
+        if p.dtype != torch.float32 or p.dim() != 2 or not p.is_cuda or p.stride(1) != 1:
+            raise RuntimeError('sst_amd.bf16.refresh_shadows: fp32 CUDA matrices with unit column stride only')
+        lo, hi = (0, p.size(0)) if rows is None else rows
+        r, c = hi - lo, p.size(1)
+        per_param = _shadow_slot(p)
+        dst = per_param.get((rows, transposed))
+        shape = (c, r) if transposed else (r, c)
+        if dst is None or dst.shape != shape or dst.device != p.device:
+            dst = per_param[(rows, transposed)] = torch.empty(shape, dtype=BF16, device=p.device)
+        q.src, q.dst, q.ld_src = p.data_ptr() + 4 * lo * p.stride(0), dst.data_ptr(), p.stride(0)
+        q.rows, q.cols, q.transpose = r, c, int(bool(transposed))
+    _lib.check(_lib.load().sst_cast_group_bf16(arr, len(specs), _lib.stream_ptr()), 'sst_cast_group_bf16')
+
+
+def invalidate_shadows():
+    """Drop every bf16 copy (they are re-made by the next forward anyway; frees their memory)."""
+    _shadows.clear()
+
+
+def shadow(p, rows=None, transposed=False):
+    """bf16 copy of an fp32 parameter - of the row range ``rows`` = (lo, hi) of it, transposed if asked (the operand of
+    a data gradient).  Inside an encoder stack the copies were refreshed by this forward's refresh_shadows call; a copy
+    that does not exist yet is made on the spot.  The cache belongs to the parameter OBJECT (weak reference, dropped
+    when it dies): a new parameter that reuses the id of a dead one never sees its copy."""
+    hit = _shadow_slot(p).get((rows, transposed))
+    if hit is None or hit.device != p.device:
+        refresh_shadows([(p, rows, transposed)])
+        hit = _shadow_slot(p)[(rows, transposed)]
+    return hit
+
+
+def layer_shadow_specs(enc, with_grad):
+    """the copies one encoder layer's kernels read: q|k rows and v rows of in_proj, out_proj, linear1, linear2, and, for
+    the backward pass, the transposes of all five"""
+    attn = enc.win_attn.self_attn
+    c = attn.out_proj.weight.size(0)
+    mats = [(attn.in_proj_weight, (0, 2 * c)), (attn.in_proj_weight, (2 * c, 3 * c)), (attn.out_proj.weight, None),
+            (enc.linear1.weight, None), (enc.linear2.weight, None)]
+    specs = [(p, rows, False) for p, rows in mats]
+    if with_grad:
+        specs += [(p, rows, True) for p, rows in mats]
+    return specs
 
 
 def weight_grad(dy, x, chunk=2048):
@@ -345,6 +388,8 @@ def run_encoder_stack(blocks, feats, plans, pos_specs):
     """The shift blocks in the reduced-precision mode: feats fp32 [M, C] -> fp32 [M, C].  plans: the two WindowPlans;
     pos_specs: per partition (positional table fp32 [P, C], row index int32 [M])."""
     layers = [enc for block in blocks for enc in block.encoder_list]
+    with_grad = torch.is_grad_enabled()
+    refresh_shadows(spec for enc in layers for spec in layer_shadow_specs(enc, with_grad))   # one launch, every forward
     x, xp = _CastIn.apply(feats, pos_specs[0][0], pos_specs[0][1])
     for li, enc in enumerate(layers):
         attn = enc.win_attn.self_attn

@@ -33,6 +33,7 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {  // one v_cvt_pk
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)(pack2(v, 0.f) & 0xffffu); }
 __device__ __forceinline__ float lo_f(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float hi_f(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
 __device__ __forceinline__ f32x4 mma32(u32x4 a, u32x4 b, f32x4 c) {
@@ -546,6 +547,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_bf16_k(const wg_args args) {
   }
 }
 
+// bf16 copies ("shadows") of fp32 parameters for the reduced-precision mode, ALL of an encoder stack in one launch:
+// problem i = a rows x cols block of an fp32 matrix (row stride ld_src) -> bf16 [rows][cols], or its transpose
+// [cols][rows].  The reference keeps fp16 copies of the fp32 master weights and re-makes them after every optimizer step
+// (mmcv Fp16OptimizerHook.copy_params_to_fp16; configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82); here they are
+// re-made at every forward call, so no cache can go stale whatever wrote the parameters (`.data` writes of an EMA hook do not
+// move the version counter a cache could watch).  32 x 32 tiles through LDS: coalesced on both sides in both orientations.
+constexpr int kCastMaxProblems = 96;
+struct cast_args {
+  const float* src[kCastMaxProblems];
+  bf16_t* dst[kCastMaxProblems];
+  int ld_src[kCastMaxProblems];
+  short rows[kCastMaxProblems], cols[kCastMaxProblems];
+  unsigned short first_tile[kCastMaxProblems + 1];
+  unsigned char transpose[kCastMaxProblems];
+  int n;
+};
+__global__ __launch_bounds__(256) void cast_group_bf16_k(const cast_args a) {
+  __shared__ float tile[32][33];
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.first_tile[i + 1]) ++i;  // uniform
+  const int t = blockIdx.x - a.first_tile[i];
+  const int rows = a.rows[i], cols = a.cols[i], tc = (cols + 31) / 32;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* src = a.src[i];
+  for (int y = ty; y < 32; y += 8)
+    if (r0 + y < rows && c0 + tx < cols) tile[y][tx] = src[(int64_t)(r0 + y) * a.ld_src[i] + c0 + tx];
+  __syncthreads();
+  bf16_t* dst = a.dst[i];
+  if (!a.transpose[i]) {
+    for (int y = ty; y < 32; y += 8)
+      if (r0 + y < rows && c0 + tx < cols) dst[(int64_t)(r0 + y) * cols + c0 + tx] = f2bf(tile[y][tx]);
+  } else {
+    for (int y = ty; y < 32; y += 8)
+      if (c0 + y < cols && r0 + tx < rows) dst[(int64_t)(c0 + y) * rows + r0 + tx] = f2bf(tile[tx][y]);
+  }
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -608,6 +648,36 @@ int sst_tall_linear_ln_bf16(const void* d_x, int64_t ldx, const void* d_w, const
   else
     return SST_ERR_UNSUPPORTED;
   if (rc) return rc;
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_cast_group_bf16(const sst_cast_problem_bf16* problems, int n, void* stream) {
+  if (n < 0 || (n > 0 && !problems)) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < n; base += kCastMaxProblems) {
+    cast_args a;
+    const int cnt = n - base < kCastMaxProblems ? n - base : kCastMaxProblems;
+    int tiles = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const sst_cast_problem_bf16& q = problems[base + i];
+      if (!q.src || !q.dst || q.rows < 1 || q.cols < 1 || q.rows > 32767 || q.cols > 32767 || q.ld_src < q.cols ||
+          q.ld_src > 0x7fffffff)
+        return SST_ERR_ARG;
+      a.src[i] = q.src;
+      a.dst[i] = (bf16_t*)q.dst;
+      a.ld_src[i] = (int)q.ld_src;
+      a.rows[i] = (short)q.rows;
+      a.cols[i] = (short)q.cols;
+      a.transpose[i] = q.transpose ? 1 : 0;
+      a.first_tile[i] = (unsigned short)tiles;
+      tiles += (int)(sst_div_up(q.rows, 32) * sst_div_up(q.cols, 32));
+      if (tiles > 65535) return SST_ERR_UNSUPPORTED;
+    }
+    a.first_tile[cnt] = (unsigned short)tiles;
+    a.n = cnt;
+    hipLaunchKernelGGL(cast_group_bf16_k, dim3((unsigned)tiles), dim3(256), 0, st, a);
+  }
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -119,10 +119,9 @@ class DynamicPointROIExtractor(nn.Module):
         cap_in_box = self.max_inbox_point if max_inbox_point is None else max_inbox_point
         roi_sample = rois[:, 0].to(torch.int32)
         pts_sample = batch_inds.to(torch.int32)
-        if self.debug:
-            assert bool((pts_sample[1:] >= pts_sample[:-1]).all()), 'points must be sorted by sample'
-            assert bool((roi_sample[1:] >= roi_sample[:-1]).all()), 'RoIs must be sorted by sample'
-        n_samples = int(batch_size) if batch_size is not None else int(batch_inds[-1].item()) + 1
+        # the reference asserts sorted batch indices unconditionally (:44-46): the two flags ride on the one read-back
+        order_ok = torch.stack([(pts_sample[1:] >= pts_sample[:-1]).all(), (roi_sample[1:] >= roi_sample[:-1]).all()])
+        n_samples = int(batch_size) if batch_size is not None else int(batch_inds.max().item()) + 1
         rows = n_samples * self.max_all_pts
         pts_idx, roi_idx, feats, num_out = _pool(rois[:, 1:], roi_sample, pts_xyz, pts_sample, self.extra_wlh,
                                                  cap_in_box, rows)
@@ -130,12 +129,19 @@ class DynamicPointROIExtractor(nn.Module):
         row_sample = roi_sample.long()[roi_idx.clamp(min=0)]
         row_sample = torch.where(torch.arange(rows, device=row_sample.device) < num_out, row_sample,
                                  torch.full_like(row_sample, n_samples))
-        per_sample = torch.bincount(row_sample, minlength=n_samples + 1)[:n_samples].tolist()   # the one read-back
+        host = torch.cat([torch.bincount(row_sample, minlength=n_samples + 1)[:n_samples], order_ok.long(),
+                          num_out.reshape(1).long()]).tolist()                                  # the one read-back
+        per_sample, (pts_sorted, rois_sorted), total = host[:n_samples], host[n_samples:n_samples + 2], host[-1]
+        assert pts_sorted, 'points must be sorted by sample'
+        assert rois_sorted, 'RoIs must be sorted by sample'
+        if total >= rows:
+            # the shared buffer filled up: a sample above its own cap may have pushed later samples' pairs out.  The
+            # reference caps every sample on its own (:51-80) - do what it does, sample by sample
+            return self._per_sample_forward(pts_xyz, pts_sample, rois, roi_sample, n_samples, cap_in_box)
         pieces, start = [], 0
         for count in per_sample:
             if count == 0:
-                fake = slice(rows - 1, rows)   # an untouched row of the buffers: (-1, -1, zeros)
-                pieces.append((pts_idx[fake], roi_idx[fake], feats[fake]))
+                pieces.append(self._fake_row(pts_idx.device))
             else:
                 keep = slice(start, start + min(count, self.max_all_pts))
                 pieces.append((pts_idx[keep], roi_idx[keep], feats[keep]))
@@ -146,6 +152,31 @@ class DynamicPointROIExtractor(nn.Module):
             all_inds, all_roi_inds, info = (torch.cat(col, dim=0) for col in zip(*pieces))
         if self.debug:
             self.check_invariants(pts_xyz, rois[..., 1:], all_inds, all_roi_inds, info[:, :3], info[:, 3:6], info[:, 6:-1])
+        return all_inds, all_roi_inds, dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1],
+                                            is_in_margin=info[:, -1])
+
+    @staticmethod
+    def _fake_row(dev):
+        """what the reference emits for a sample without any pair (:70-75): indices -1, zero features"""
+        return (torch.full((1,), -1, dtype=torch.long, device=dev), torch.full((1,), -1, dtype=torch.long, device=dev),
+                torch.zeros((1, 13), dtype=torch.float, device=dev))
+
+    def _per_sample_forward(self, pts_xyz, pts_sample, rois, roi_sample, n_samples, cap_in_box):
+        """one pool call per sample, each capped at max_all_pts on its own (the reference's loop, :51-80)"""
+        pieces = []
+        for b in range(n_samples):
+            p_sel = torch.nonzero(pts_sample == b).squeeze(1)
+            r_sel = torch.nonzero(roi_sample == b).squeeze(1)
+            if p_sel.numel() == 0 or r_sel.numel() == 0:
+                pieces.append(self._fake_row(pts_xyz.device))
+                continue
+            pi, ri, ft = _valid_rows(*_pool(rois[r_sel, 1:].contiguous(), None, pts_xyz[p_sel].contiguous(), None,
+                                            self.extra_wlh, cap_in_box, self.max_all_pts))
+            if int(pi[0]) < 0:   # the op's own fake row: no pair in this sample
+                pieces.append(self._fake_row(pts_xyz.device))
+            else:
+                pieces.append((p_sel[pi], r_sel[ri], ft))
+        all_inds, all_roi_inds, info = (torch.cat(col, dim=0) for col in zip(*pieces))
         return all_inds, all_roi_inds, dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1],
                                             is_in_margin=info[:, -1])
 

@@ -82,14 +82,54 @@ def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
     return table
 
 
+class _ScatterRowsFn(torch.autograd.Function):
+    """out[slots[i]] = rows[i] on a [n_slots, C] tensor filled with ``padding`` (slots unique): sst_scatter_rows_f32;
+    backward = the row gather of the upstream gradient (sst_gather_rows_f32).  `feat_3d[this_inds] = feat` of
+    ops/sst/sst_ops.py:98 with its autograd."""
+
+    @staticmethod
+    def forward(ctx, rows, slots, n_slots, padding):
+        out = torch.full((n_slots, rows.shape[-1]), padding, dtype=rows.dtype, device=rows.device)
+        K.scatter_rows(rows.contiguous(), slots, out)
+        ctx.save_for_backward(slots)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        slots, = ctx.saved_tensors
+        return K.gather_rows(grad_out.contiguous(), slots), None, None, None
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """rows2d[slots] (slots unique): sst_gather_rows_f32; backward = row scatter of the upstream gradient into zeros.
+    `feat[inds]` of ops/sst/sst_ops.py:124-125 with its autograd."""
+
+    @staticmethod
+    def forward(ctx, rows2d, slots):
+        ctx.save_for_backward(slots)
+        ctx.n_src = rows2d.size(0)
+        return K.gather_rows(rows2d.contiguous(), slots)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        slots, = ctx.saved_tensors
+        grad_src = torch.zeros((ctx.n_src, grad_out.size(1)), dtype=grad_out.dtype, device=grad_out.device)
+        K.scatter_rows(grad_out.contiguous(), slots, grad_src)
+        return grad_src, None
+
+
+def _kernel_rows(t):
+    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 2
+
+
 def _rows_to_slots(rows, slots, n_slots, padding):
     """out[slots[i]] = rows[i] on a [n_slots, C] tensor filled with ``padding``: the row-scatter kernel for fp32 CUDA
-    features, index assignment otherwise (integer / bool payloads of the reference-format dictionaries)"""
+    features - with autograd, so training keeps the kernel -, index assignment otherwise (integer / bool payloads of the
+    reference-format dictionaries)"""
+    if _kernel_rows(rows):
+        return _ScatterRowsFn.apply(rows, slots.to(torch.int32).contiguous(), int(n_slots), float(padding))
     out = torch.full((n_slots, rows.shape[-1]), padding, dtype=rows.dtype, device=rows.device)
-    if rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and not rows.requires_grad:
-        K.scatter_rows(rows.contiguous(), slots.to(torch.int32).contiguous(), out)
-    else:
-        out[slots] = rows
+    out[slots] = rows
     return out
 
 
@@ -112,8 +152,8 @@ def window2flat(feat_3d_dict, inds_dict):
     for key, padded in feat_3d_dict.items():
         slots, where = inds_dict[key]
         rows2d = padded.reshape(-1, padded.shape[-1])
-        if rows2d.is_cuda and rows2d.dtype == torch.float32 and not rows2d.requires_grad:
-            flat[where] = K.gather_rows(rows2d.contiguous(), slots.to(torch.int32).contiguous())
+        if _kernel_rows(rows2d):
+            flat[where] = _GatherRowsFn.apply(rows2d, slots.to(torch.int32).contiguous())
         else:
             flat[where] = rows2d[slots]
     return flat

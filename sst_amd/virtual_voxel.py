@@ -38,6 +38,10 @@ class VirtualVoxelExtractor(nn.Module):
         self.only_virtual = vpp.get('only_virtual', False)
         self.train_cfg = train_cfg or {}
         self.test_cfg = test_cfg or {}
+        if (self.train_cfg or {}).get('as_rpn', False) or (self.test_cfg or {}).get('as_rpn', False):
+            # the detector takes as_rpn from its bbox_head config (single_stage_fsd_v2.py:83) and then returns pts_feats /
+            # pts_xyz / ... for a second stage (:263-270): not produced by this stage
+            raise NotImplementedError('as_rpn outputs (single_stage_fsd_v2.py:263-270) are not part of this stage')
         if (self.train_cfg or self.test_cfg).get('baseline_mode', False):
             raise NotImplementedError('baseline_mode (extract_feat_baseline) is not part of this stage')
         self.print_info = {}
@@ -53,10 +57,12 @@ class VirtualVoxelExtractor(nn.Module):
         return torch.cat([batch_idx[:, None], cells[:, [2, 1, 0]]], dim=1)
 
     def clip_points(self, points, pc_range):
+        """IN PLACE, as the reference does (single_stage_fsd_v2.py:124-129 assigns into the columns of
+        sampled_dict['center_preds']): callers that read the dictionary after extract_feat see the clipped centres."""
         eps = 1e-5
         lo = points.new_tensor(pc_range[:3]) + eps
         hi = points.new_tensor(pc_range[3:]) - eps
-        return torch.max(torch.min(points, hi), lo)
+        return points.clamp_(min=lo, max=hi)
 
     def extract_feat(self, sampled_dict, origin_dict):
         fg_pts, fg_batch = sampled_dict['seg_points'], sampled_dict['batch_idx']

@@ -76,27 +76,30 @@ def test_bench_cli_contract_and_workloads_registry():
         assert {'cls', 'points', 'metric', 'name'} <= set(spec)
 
 
-def test_bf16_shadow_cache_follows_the_parameter_object():
-    """the bf16 copies of the fp32 master weights: re-made when the parameter changes in place, never handed to another
-    parameter that reuses a dead one's address, dropped with the parameter (host logic, no GPU)"""
+def test_bf16_shadow_slots_follow_the_parameter_object():
+    """the bf16 copies of the fp32 master weights (host logic, no GPU): a slot belongs to one parameter OBJECT, is never
+    handed to another parameter that reuses a dead one's id, is dropped with the parameter, and making a copy of a CPU
+    parameter fails loudly (the copies are made by a kernel: tests/test_gpu_bf16.py)"""
     import gc
+    import pytest
     import torch
     from sst_amd import bf16
     p = torch.nn.Parameter(torch.randn(6, 4))
-    a = bf16.shadow(p)
-    assert bf16.shadow(p) is a and a.dtype == torch.bfloat16
-    with torch.no_grad():
-        p.mul_(2.0)
-    b = bf16.shadow(p)
-    assert b is not a and torch.equal(b, p.detach().to(torch.bfloat16))
-    t = bf16.shadow(p, (2, 6), transposed=True)
-    assert t.shape == (4, 4) and torch.equal(t, p.detach()[2:6].t().to(torch.bfloat16))
+    slot = bf16._shadow_slot(p)
+    assert bf16._shadow_slot(p) is slot and slot == {}
+    slot[(None, False)] = 'marker'
     before = len(bf16._shadows)
     del p
     gc.collect()
     assert len(bf16._shadows) == before - 1
-    # a new parameter is never served another one's copy, whatever id / address it lands on
-    for _ in range(20):
+    for _ in range(20):   # a new parameter never sees another one's slot, whatever id / address it lands on
         q = torch.nn.Parameter(torch.randn(6, 4))
-        assert torch.equal(bf16.shadow(q), q.detach().to(torch.bfloat16))
+        assert bf16._shadow_slot(q) == {}
+        bf16._shadow_slot(q)[(None, False)] = 'marker'
         del q
+    q = torch.nn.Parameter(torch.randn(6, 4))
+    with pytest.raises(RuntimeError):
+        bf16.shadow(q)
+    bf16.invalidate_shadows()
+    assert len(bf16._shadows) == 0
+

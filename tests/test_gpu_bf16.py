@@ -234,3 +234,58 @@ def test_bf16_mode_leaves_unsupported_layers_in_fp32():
         a = net(layer(feats, coors, 2))[0]['voxel_feats']
         b = net.set_precision('bf16')(layer(feats, coors, 2))[0]['voxel_feats']
     assert torch.equal(a, b)
+
+
+def test_bf16_shadow_weights_follow_every_kind_of_parameter_update():
+    """`.data` writes (mmcv's EMAHook swap, a master-to-model copy) do not move the version counter of a
+    parameter.  The bf16 copies are re-made by one grouped launch at every forward, so the bf16 forward must follow the
+    fp32 forward after optimizer.step(), after p.data.copy_() and after p.data.mul_()."""
+    import sst_amd
+    from sst_amd import bf16
+    g = load_golden('sst_block_bf16.npz')
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128], nhead=[8], num_blocks=1, dim_feedforward=[256],
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=True))
+    net.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}, strict=True)
+    net = net.to(DEV).train()
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
+                                    debug=True, mute=True, reference_outputs=False)
+    layer.eval()
+    feats = torch.from_numpy(g['in::voxel_feats']).to(DEV)
+    coors = torch.from_numpy(g['in::voxel_coors']).to(DEV)
+
+    def both():
+        with torch.no_grad():
+            a = net.set_precision('fp32')(layer(feats, coors, 2))[0]['voxel_feats']
+            b = net.set_precision('bf16')(layer(feats, coors, 2))[0]['voxel_feats']
+        return a, b
+
+    a0, b0 = both()
+    assert float((a0 - b0).abs().max()) < 6e-2
+    enc = net.block_list[0].encoder_list[0]
+    # 1. an optimizer step (moves the version counter)
+    opt = torch.optim.SGD(net.parameters(), lr=0.5)
+    out = net.set_precision('bf16')(layer(feats.clone().requires_grad_(True), coors, 2))[0]['voxel_feats']
+    out.square().sum().backward()
+    opt.step()
+    a1, b1 = both()
+    assert float((a1 - a0).abs().max()) > 0.2, 'the step must change the network visibly'
+    assert float((a1 - b1).abs().max()) < 6e-2
+    # 2. p.data.copy_() and p.data.mul_(): no version bump
+    gen = torch.Generator().manual_seed(1)
+    v0 = enc.linear1.weight._version
+    enc.linear1.weight.data.copy_(torch.randn(enc.linear1.weight.shape, generator=gen).to(DEV) * 0.3)
+    enc.win_attn.self_attn.in_proj_weight.data.mul_(-1.5)
+    enc.win_attn.self_attn.out_proj.weight.data.mul_(2.0)
+    assert enc.linear1.weight._version == v0
+    a2, b2 = both()
+    assert float((a2 - a1).abs().max()) > 0.2
+    assert float((a2 - b2).abs().max()) < 8e-2 and float((a2 - b2).abs().mean()) < 1e-2
+    # the copies themselves: bit-equal to torch's round-to-nearest-even cast, both orientations, row ranges
+    w = enc.win_attn.self_attn.in_proj_weight
+    bf16.refresh_shadows([(w, (0, 256), False), (w, (256, 384), True), (enc.linear2.weight, None, True)])
+    assert torch.equal(bf16.shadow(w, (0, 256)), w.detach()[:256].to(BF))
+    assert torch.equal(bf16.shadow(w, (256, 384), transposed=True), w.detach()[256:].t().to(BF).contiguous())
+    assert torch.equal(bf16.shadow(enc.linear2.weight, transposed=True), enc.linear2.weight.detach().t().to(BF).contiguous())
+    odd = torch.nn.Parameter(torch.randn(45, 70, device=DEV))
+    assert torch.equal(bf16.shadow(odd, (3, 40), transposed=True), odd.detach()[3:40].t().to(BF).contiguous())
+    assert torch.equal(bf16.shadow(odd), odd.detach().to(BF))

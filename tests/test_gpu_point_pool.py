@@ -142,6 +142,37 @@ def test_roi_extractor_mirrors_reference_flow():
     np.testing.assert_array_equal(one[1].cpu().numpy(), ref1[1])
 
 
+def test_roi_extractor_caps_every_sample_on_its_own():
+    """sample 0 far above max_all_pts must not take pairs away from sample 1 (the reference caps each
+    sample in its own call, dynamic_point_roi_extractor.py:51-80); a sample without pairs gets the (-1, -1, zeros) row;
+    unsorted batch indices are refused whatever `debug` says (the reference asserts them unconditionally, :44-46)."""
+    import sst_amd
+    rng = np.random.default_rng(5)
+    rois = np.array([[0, 0, 0, 0, 4, 4, 2, 0.3], [0, 10, 0, 0, 4, 4, 2, 0.0], [1, 0, 0, 0, 4, 4, 2, -0.2],
+                     [2, 50, 50, 0, 1, 1, 1, 0.0]], np.float32)
+    p0 = np.concatenate([rng.uniform(-1.5, 1.5, (3000, 3)), rng.uniform(-1.5, 1.5, (3000, 3)) + [10, 0, 0]]) * [1, 1, 0.5]
+    p1 = rng.uniform(-1.5, 1.5, (300, 3)) * [1, 1, 0.5]
+    p2 = rng.uniform(-1.5, 1.5, (50, 3))                      # nowhere near the RoI of sample 2
+    pts = np.concatenate([p0, p1, p2]).astype(np.float32)
+    pb = np.concatenate([np.zeros(len(p0)), np.ones(len(p1)), np.full(len(p2), 2)]).astype(np.int64)
+    ext = sst_amd.DynamicPointROIExtractor(extra_wlh=[0.2, 0.2, 0.2], max_inbox_point=4096, max_all_pts=500, debug=False)
+    inds, roi_inds, info = ext(torch.from_numpy(pts).to(DEV), torch.from_numpy(pb).to(DEV), torch.from_numpy(rois).to(DEV))
+    inds, roi_inds = inds.cpu().numpy(), roi_inds.cpu().numpy()
+    s0 = np.isin(roi_inds, [0, 1])
+    assert s0.sum() == 500                                     # sample 0: thousands of candidates, capped at 500
+    s1 = roi_inds == 2
+    single = sst_amd.dynamic_point_pool(torch.from_numpy(rois[2:3, 1:]).to(DEV), torch.from_numpy(p1.astype(np.float32)).to(DEV),
+                                        [0.2, 0.2, 0.2], 4096, 500)
+    assert s1.sum() == len(single[0]) > 100                    # sample 1: every one of its own pairs, none lost
+    np.testing.assert_array_equal(inds[s1] - len(p0), single[0].cpu().numpy())
+    assert (pb[inds[s0]] == 0).all() and (pb[inds[s1]] == 1).all()
+    fake = ~(s0 | s1)
+    assert fake.sum() == 1 and inds[fake][0] == -1 and roi_inds[fake][0] == -1     # sample 2: the fake row
+    assert float(info['local_xyz'][torch.from_numpy(fake).to(DEV)].abs().max()) == 0.0
+    with pytest.raises(AssertionError):
+        ext(torch.from_numpy(pts).to(DEV), torch.from_numpy(pb[::-1].copy()).to(DEV), torch.from_numpy(rois).to(DEV))
+
+
 def test_point_pool_full_size_properties():
     """FSD second-stage scale (2e5 points, 2000 RoIs): invariants, caps, sortedness, determinism, and the pair count
     against a float64 membership count away from faces."""

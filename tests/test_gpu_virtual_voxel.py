@@ -46,7 +46,13 @@ def test_virtual_voxel_stage_matches_reference_golden():
     origin = dict(seg_points=t('in::ori_points'), seg_feats=leaves['in::ori_feats'], batch_idx=t('in::ori_batch_idx'))
     sampled = dict(seg_points=t('in::smp_points'), center_preds=t('in::smp_centers'), seg_logits=leaves['in::smp_logits'],
                    seg_feats=leaves['in::smp_feats'], batch_idx=t('in::smp_batch_idx'))
+    raw_centers = sampled['center_preds'].clone()
     out = net(sampled, origin)
+    # the reference clips the predicted centres IN PLACE (single_stage_fsd_v2.py:124-129): the caller's dictionary holds the
+    # clipped values afterwards
+    rng_lo = torch.tensor(CFG['voxel_encoder']['point_cloud_range'][:3], device=DEV)
+    rng_hi = torch.tensor(CFG['voxel_encoder']['point_cloud_range'][3:], device=DEV)
+    assert torch.equal(sampled['center_preds'], torch.max(torch.min(raw_centers, rng_hi - 1e-5), rng_lo + 1e-5))
     # the index part is exact: the same voxels, in the same (sorted-unique) order, flagged virtual
     assert torch.equal(out['virtual_coors'].cpu(), torch.from_numpy(g['out::virtual_coors']).to(out['virtual_coors'].dtype))
     assert list(out['sparse_shape']) == list(g['out::sparse_shape'])

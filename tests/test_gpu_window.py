@@ -123,6 +123,47 @@ def test_input_layer_matches_reference_golden(tag):
         assert (np.diff(starts) > 0).all(), 'windows must be in ascending id order'
 
 
+def test_flat2window_window2flat_keep_the_kernels_under_autograd():
+    """integration path B in TRAINING: flat2window_v2 / window2flat_v2 on features that require grad run through the row
+    scatter / gather kernels (sst_scatter_rows_f32 / sst_gather_rows_f32) as autograd Functions; values and gradients equal
+    the index-assignment formulation of the reference (ops/sst/sst_ops.py:67-132)."""
+    import sst_amd
+    from sst_amd import sst_ops
+    g = load_golden('input_layer_train.npz')
+    layer = sst_amd.build_middle_encoder(dict(
+        type='SSTInputLayerV2', window_shape=(12, 12, 1), sparse_shape=(468, 468, 1), shuffle_voxels=False,
+        debug=True, drop_info=(DROP_TRAIN, DROP_TEST), pos_temperature=10000, normalize_pos=False, mute=True))
+    layer.train()
+    coors = torch.from_numpy(g['in::voxel_coors']).to(DEV)
+    info = layer(torch.randn(coors.size(0), 32, device=DEV), coors, 2)
+    inds = info['flat2win_inds_shift1']
+    m = info['voxel_coors'].size(0)
+    gen = torch.Generator().manual_seed(0)
+    feat = torch.randn(m, 32, generator=gen).to(DEV)
+    a = feat.clone().requires_grad_(True)
+    win = sst_amd.flat2window_v2(a, inds, padding=-3.0)
+    assert all(isinstance(v.grad_fn, sst_ops._ScatterRowsFn._backward_cls) for v in win.values())
+    back = sst_amd.window2flat_v2({k: v * (k + 2.0) for k, v in win.items()}, inds)
+    up = torch.randn(back.shape, generator=gen).to(DEV)
+    (back * up).sum().backward()
+    # reference formulation with plain indexing
+    b = feat.clone().requires_grad_(True)
+    lvl = inds['voxel_drop_level']
+    ref_back = torch.zeros_like(b)
+    for k in [k for k in inds if not isinstance(k, str)]:
+        slots, (where,) = inds[k]
+        cap = inds['batching_info'][k]['max_tokens']
+        n_win = int(slots.max()) // cap + 1
+        padded = torch.full((n_win * cap, 32), -3.0, device=DEV)
+        padded[slots] = b[where]
+        assert torch.equal(win[k].detach().reshape(-1, 32), padded.detach())
+        ref_back = ref_back.index_put((where,), (padded * (k + 2.0))[slots])
+        assert bool((lvl[where] == k).all())
+    (ref_back * up).sum().backward()
+    assert torch.equal(back.detach(), ref_back.detach())
+    assert torch.equal(a.grad, b.grad)
+
+
 def test_input_layer_shuffle_and_full_size_properties():
     """M ~ 90k voxels (bench size), training mode with shuffle: drop respects the caps, plans partition."""
     import sst_amd

@@ -4,7 +4,7 @@ its DynamicVFE -> SSTInputLayerV2 -> SSTv2, tests/test_ref_assembly.ReferenceAss
 (oracle/cpu_pipeline.CpuSSTBackbone = bench.py's cpu_baseline, kind "port") on the SAME host cores, same clouds, same
 weights: the measured ratio port / reference that stands behind `cpu_baseline.kind: "port"`.
 Protocol of SURVEY.md §8(d): warm-up passes, then timed passes, median; thread counts 1 and all.
-Usage: python tools/cpu_ref_vs_port.py [--full] > profiles/rNN/cpu_ref_vs_port.json"""
+Usage: python tools/cpu_ref_vs_port.py [--full] profiles/rNN/cpu_ref_vs_port.json   (the reference prints to stdout)"""
 import json
 import os
 import sys
@@ -76,7 +76,12 @@ def main():
     if full:
         out['cases'].append(case('headline frame: 116k points, 6 SRA blocks', [A.uniform_cloud(116000, 0)], 6, True, 1, 2,
                                  [all_threads]))
-    print(json.dumps(out, indent=1))
+    dst = [a for a in sys.argv[1:] if not a.startswith('--')]
+    text = json.dumps(out, indent=1)
+    if dst:
+        open(dst[0], 'w').write(text + '\n')
+    else:
+        print(text)
 
 
 if __name__ == '__main__':

@@ -54,3 +54,33 @@ k=keys; s=shape
 for lvl in range(1,5):
     k,s = down(k,s)
     m = subm_map(k,s); stats(m,f'L{lvl} subm shape {s}')
+
+
+def sorted_tile_stats(m, name, tile=128, bs=16):
+    """rows permuted INSIDE each tile by their offset bitmask: live (16-row block, offset) slots afterwards"""
+    K, n = m.shape
+    live = (m >= 0)
+    nt = (n + tile - 1) // tile
+    pad = nt * tile - n
+    l = np.pad(live, ((0, 0), (0, pad))).T.reshape(nt, tile, K)          # [tile][row][k]
+    weights = (1 << np.arange(K, dtype=np.int64))
+    mask = (l * weights).sum(-1)                                          # [nt][tile] int64 bitmask
+    for how in ('none', 'mask', 'gray'):
+        if how == 'none':
+            order = np.tile(np.arange(tile), (nt, 1))
+        elif how == 'mask':
+            order = np.argsort(mask, axis=1, kind='stable')
+        else:   # sort by popcount-major then mask
+            pc = l.sum(-1)
+            order = np.lexsort((mask, pc), axis=1)
+        ls = np.take_along_axis(l, order[:, :, None], axis=1)
+        lb = ls.reshape(nt, tile // bs, bs, K).any(2)                     # [nt][blocks][k]
+        pairs = live.sum()
+        print(f'   {name} tile {tile} sort={how:5s}: live 16-row slots per row {lb.sum() * bs / n:.2f} (pairs per row {pairs / n:.2f}), '
+              f'useful fraction {pairs / (lb.sum() * bs):.3f}')
+
+
+if __name__ == '__main__':
+    sorted_tile_stats(m0, 'L0', 128)
+    sorted_tile_stats(m0, 'L0', 256)
+    sorted_tile_stats(m0, 'L0', 512)
