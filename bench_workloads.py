@@ -38,75 +38,156 @@ def lidar_like_cloud(n, seed, dev, half_extent=75.0, z_ground=-1.8, extra_channe
     return torch.cat([xyz, torch.rand(n, extra_channels, generator=g)], 1).to(dev), centres
 
 
-class FSDPath(nn.Module):
-    """configs/fsd/fsd_waymoD1_1x.py at hot-path level.  Stand-ins: `seg_head` (VoteSegHead), `box_head` (the FSD head's
-    regression branch); foreground = points above the ground plane, class by a position hash (no labels here)."""
-    SEG_VOXEL = (0.25, 0.25, 0.2)
-    PC_RANGE = [-80, -80, -2, 80, 80, 4]
-    CLASSES = ['Car', 'Pedestrian', 'Cyclist']
+def chain_cloud(n, seed, half_extent=18.0, n_objects=14, z_ground=-1.8):
+    """fixture-size cloud for the chain goldens: a ground plane and a few DENSE objects (so that clusters survive the
+    min_points filter of the cluster voxels, down to 5 cm for pedestrians), two extra channels"""
+    g = torch.Generator().manual_seed(seed)
+    n_obj = n // 2
+    ext = 2 * half_extent
+    ground = torch.rand(n - n_obj, 3, generator=g) * torch.tensor([ext, ext, 0.15]) + torch.tensor([-half_extent, -half_extent, z_ground])
+    centres = torch.rand(n_objects, 3, generator=g) * torch.tensor([ext * 0.8, ext * 0.8, 0.0]) \
+        + torch.tensor([-half_extent * 0.8, -half_extent * 0.8, z_ground + 0.9])
+    size = torch.rand(n_objects, 3, generator=g) * torch.tensor([1.2, 0.6, 0.6]) + torch.tensor([0.3, 0.3, 0.8])
+    which = torch.randint(0, n_objects, (n_obj,), generator=g)
+    obj = centres[which] + (torch.rand(n_obj, 3, generator=g) - 0.5) * size[which]
+    return torch.cat([torch.cat([ground, obj]), torch.rand(n, 2, generator=g)], 1)
 
-    def __init__(self):
+
+class GpuOps(object):
+    """the module provider of the product: sst_amd (the reference's registry names, csrc kernels underneath)"""
+    name = 'sst_amd'
+    DynamicScatterVFE = sst_amd.DynamicScatterVFE
+    PseudoMiddleEncoderForSpconvFSD = sst_amd.PseudoMiddleEncoderForSpconvFSD
+    SimpleSparseUNet = sst_amd.SimpleSparseUNet
+    ClusterAssigner = sst_amd.ClusterAssigner
+    SIR = sst_amd.SIR
+    DynamicPointROIExtractor = sst_amd.DynamicPointROIExtractor
+    VirtualVoxelExtractor = sst_amd.VirtualVoxelExtractor
+    scatter_v2 = staticmethod(scatter_v2)
+
+    @staticmethod
+    def voxelize(points_list, voxel_size, point_cloud_range):
+        layer = sst_amd.Voxelization(voxel_size, point_cloud_range, -1, (-1, -1))
+        points, coors = layer.voxelize_batch(points_list)
+        return points, coors.long()
+
+
+SIR_NORM = dict(type='LN', eps=1e-3)
+# configs/fsd/fsd_waymoD1_1x.py at hot-path level
+FSD_CFG = dict(
+    seg_voxel=(0.25, 0.25, 0.2), pc_range=[-80, -80, -2, 80, 80, 4], classes=['Car', 'Pedestrian', 'Cyclist'],
+    vfe=dict(in_channels=5, feat_channels=[64, 64]),
+    unet=dict(in_channels=64, sparse_shape=[32, 640, 640], base_channels=64, output_channels=128,
+              encoder_channels=((64, ), (64, 64, 64), (64, 64, 64), (128, 128, 128), (256, 256, 256)),
+              encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1), (1, 1, 1)),
+              decoder_channels=((256, 256, 128), (128, 128, 64), (64, 64, 64), (64, 64, 64), (64, 64, 64)),
+              decoder_paddings=((1, 1), (1, 0), (1, 0), (0, 0), (0, 1))),
+    cluster=dict(cluster_voxel_size=dict(Car=(0.3, 0.3, 6), Cyclist=(0.2, 0.2, 6), Pedestrian=(0.05, 0.05, 6)), min_points=2,
+                 connected_dist=dict(Car=0.6, Cyclist=0.4, Pedestrian=0.1)),
+    sir=dict(num_blocks=3, feat=128, rel_hidden=[16, 32]), roi_sir=dict(num_blocks=2, feat=128, rel_hidden=[16, 32]),
+    roi=dict(extra_wlh=[0.5, 0.5, 0.5], max_inbox_point=256))
+# the same chain at fixture size (tests/golden/fsd_chain.npz: narrow U-Net on a [16, 160, 160] grid, 32-wide SIR)
+FSD_SMALL_CFG = dict(
+    seg_voxel=(0.25, 0.25, 0.2), pc_range=[-20, -20, -2, 20, 20, 1.2], classes=['Car', 'Pedestrian', 'Cyclist'],
+    vfe=dict(in_channels=5, feat_channels=[16, 16]),
+    unet=dict(in_channels=16, sparse_shape=[16, 160, 160], base_channels=16, output_channels=16,
+              encoder_channels=((16, ), (16, 16), (32, 32)), encoder_paddings=((1, ), (1, 1), (1, 1)),
+              decoder_channels=((32, 32, 16), (16, 16, 16), (16, 16, 16)), decoder_paddings=((1, 1), (1, 0), (0, 1))),
+    cluster=dict(cluster_voxel_size=dict(Car=(0.3, 0.3, 6), Cyclist=(0.2, 0.2, 6), Pedestrian=(0.05, 0.05, 6)), min_points=2,
+                 connected_dist=dict(Car=0.6, Cyclist=0.4, Pedestrian=0.1)),
+    sir=dict(num_blocks=3, feat=32, rel_hidden=[8, 16]), roi_sir=dict(num_blocks=2, feat=32, rel_hidden=[8, 16]),
+    roi=dict(extra_wlh=[0.5, 0.5, 0.5], max_inbox_point=256))
+
+
+def fsd_foreground_stand_in(batch_points, votes, z_cut=-1.4):
+    """STAND-IN for the segmentation decision and the vote decoding of VoteSegHead (out of scope): foreground = points
+    above the ground plane, class by a position hash, voted centre = point + 0.05 tanh(vote of its class).  Shared by the
+    GPU path, the CPU port and the reference chain that produces the golden (tests/golden/make_golden.py)."""
+    fg = batch_points[:, 2] > z_cut
+    cls = (batch_points[:, 0].abs() * 7).long() % 3
+    sel_l, pts_l = [], []
+    for c in range(3):
+        sel = torch.nonzero(fg & (cls == c)).squeeze(1)
+        sel_l.append(sel)
+        pts_l.append((batch_points[sel, :3] + 0.05 * torch.tanh(votes[sel, c])).detach())
+    return sel_l, pts_l
+
+
+class FSDPath(nn.Module):
+    """configs/fsd/fsd_waymoD1_1x.py at hot-path level, over a module provider `ops` (GpuOps = sst_amd; oracle.fsd_cpu = the
+    CPU port; oracle.ref_fsd = the reference's own Python in the build container): the SAME wiring for all three.
+    Stand-ins: `seg_head` (VoteSegHead), `box_head` (the FSD head's regression branch); foreground / class / vote decoding =
+    fsd_foreground_stand_in.  `roi_stage=False` stops after SingleStageFSD.extract_feat (the chain the goldens pin: the
+    point-pool features behind it are TorchEx's and unpinned)."""
+
+    def __init__(self, ops=GpuOps, cfg=None, roi_stage=True):
         super().__init__()
-        self.voxel_layer = sst_amd.Voxelization(self.SEG_VOXEL, self.PC_RANGE, -1, (-1, -1))
-        self.voxel_encoder = sst_amd.DynamicScatterVFE(in_channels=5, feat_channels=[64, 64], voxel_size=self.SEG_VOXEL,
-                                                       with_cluster_center=True, with_voxel_center=True,
-                                                       point_cloud_range=self.PC_RANGE, norm_cfg=BN, unique_once=True)
-        self.middle_encoder = sst_amd.PseudoMiddleEncoderForSpconvFSD()
-        self.seg_backbone = sst_amd.SimpleSparseUNet(
-            in_channels=64, sparse_shape=[32, 640, 640], order=('conv', 'norm', 'act'), norm_cfg=BN, base_channels=64,
-            output_channels=128, encoder_channels=((64, ), (64, 64, 64), (64, 64, 64), (128, 128, 128), (256, 256, 256)),
-            encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1), (1, 1, 1)),
-            decoder_channels=((256, 256, 128), (128, 128, 64), (64, 64, 64), (64, 64, 64), (64, 64, 64)),
-            decoder_paddings=((1, 1), (1, 0), (1, 0), (0, 0), (0, 1)))
-        self.seg_head = nn.Linear(67, 3 + 9)       # stand-in: 3 class logits + 3 x 3 centre votes
-        self.cluster_assigner = sst_amd.ClusterAssigner(
-            cluster_voxel_size=dict(Car=(0.3, 0.3, 6), Cyclist=(0.2, 0.2, 6), Pedestrian=(0.05, 0.05, 6)), min_points=2,
-            point_cloud_range=self.PC_RANGE, connected_dist=dict(Car=0.6, Cyclist=0.4, Pedestrian=0.1),
-            class_names=self.CLASSES)
-        self.backbone = sst_amd.SIR(num_blocks=3, in_channels=[84, 133, 133], feat_channels=[[128, 128]] * 3,
-                                    rel_mlp_hidden_dims=[[16, 32]] * 3, norm_cfg=dict(type='LN', eps=1e-3), mode='max',
-                                    xyz_normalizer=[20, 20, 4], act='gelu', unique_once=True)
-        self.box_head = nn.Linear(128 * 3 * 2, 7)  # stand-in: centre offset, log sizes, yaw
-        self.roi_extractor = sst_amd.DynamicPointROIExtractor(extra_wlh=[0.5, 0.5, 0.5], max_inbox_point=256, debug=False)
-        self.roi_backbone = sst_amd.SIR(num_blocks=2, in_channels=[13 + 128 + 13, 13 + 128], feat_channels=[[128, 128]] * 2,
-                                        rel_mlp_hidden_dims=[[16, 32]] * 2, norm_cfg=dict(type='LN', eps=1e-3),
-                                        mode='max', xyz_normalizer=[20, 20, 4], act='gelu', unique_once=True)
+        cfg = self.cfg = FSD_CFG if cfg is None else cfg
+        self.ops, self.roi_stage = ops, roi_stage
+        self.SEG_VOXEL, self.PC_RANGE, self.CLASSES = cfg['seg_voxel'], cfg['pc_range'], cfg['classes']
+        c_vox = cfg['vfe']['feat_channels'][-1]
+        c_seg = cfg['unet']['decoder_channels'][-1][-1]
+        self.voxel_encoder = ops.DynamicScatterVFE(voxel_size=self.SEG_VOXEL, with_cluster_center=True, with_voxel_center=True,
+                                                   point_cloud_range=self.PC_RANGE, norm_cfg=BN, unique_once=True, **cfg['vfe'])
+        assert cfg['unet']['in_channels'] == c_vox
+        self.middle_encoder = ops.PseudoMiddleEncoderForSpconvFSD()
+        self.seg_backbone = ops.SimpleSparseUNet(order=('conv', 'norm', 'act'), norm_cfg=BN, **cfg['unet'])
+        self.seg_head = nn.Linear(c_seg + 3, 3 + 9)       # stand-in: 3 class logits + 3 x 3 centre votes
+        self.cluster_assigner = ops.ClusterAssigner(point_cloud_range=self.PC_RANGE, class_names=self.CLASSES, **cfg['cluster'])
+        self.cluster_assigner.num_classes = len(self.CLASSES)      # the detector sets it (single_stage_fsd.py:418)
+        f, nb = cfg['sir']['feat'], cfg['sir']['num_blocks']
+        c_pts = c_seg + 3 + 3 + 9                          # point features handed to SIR: seg feats + logits + votes
+        self.backbone = ops.SIR(num_blocks=nb, in_channels=[5 + c_pts] + [5 + f] * (nb - 1), feat_channels=[[f, f]] * nb,
+                                rel_mlp_hidden_dims=[list(cfg['sir']['rel_hidden']) for _ in range(nb)], norm_cfg=SIR_NORM,
+                                mode='max', xyz_normalizer=[20, 20, 4], act='gelu', unique_once=True)
+        self.box_head = nn.Linear(f * nb * 2, 7)           # stand-in: centre offset, log sizes, yaw
+        if roi_stage:
+            f2, nb2 = cfg['roi_sir']['feat'], cfg['roi_sir']['num_blocks']
+            self.roi_extractor = ops.DynamicPointROIExtractor(debug=False, **cfg['roi'])
+            self.roi_backbone = ops.SIR(num_blocks=nb2, in_channels=[13 + f + 13] + [13 + f2] * (nb2 - 1),
+                                        feat_channels=[[f2, f2]] * nb2,
+                                        rel_mlp_hidden_dims=[list(cfg['roi_sir']['rel_hidden']) for _ in range(nb2)],
+                                        norm_cfg=SIR_NORM, mode='max', xyz_normalizer=[20, 20, 4], act='gelu', unique_once=True)
 
     def make_cloud(self, n, seed, dev):
         return lidar_like_cloud(n, seed, dev)[0]
 
-    def forward(self, points_list):
+    def forward(self, points_list, return_tensors=False):
+        ops = self.ops
         dev = points_list[0].device
-        batch_points, coors = self.voxel_layer.voxelize_batch(points_list)
-        coors = coors.long()
+        batch_points, coors = ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
         voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
         x = self.seg_backbone(self.middle_encoder(voxel_feats, voxel_coors))[0]
-        # Voxel2PointScatterNeck
+        # Voxel2PointScatterNeck (necks/voxel2point_neck.py:28-63)
         pts_feats = x['voxel_feats'][v2p]
         vs = torch.tensor(self.SEG_VOXEL, device=dev).reshape(1, 3)
         centre = (coors[:, [3, 2, 1]].float() + 0.5) * vs + torch.tensor(self.PC_RANGE[:3], device=dev).reshape(1, 3)
-        seg_feats = torch.cat([pts_feats, batch_points[:, :3] - centre], 1)            # [N, 67]
+        seg_feats = torch.cat([pts_feats, batch_points[:, :3] - centre], 1)            # [N, C + 3]
         head = self.seg_head(seg_feats)
         logits, votes = head[:, :3], head[:, 3:].reshape(-1, 3, 3)
-        fg = batch_points[:, 2] > -1.4
-        cls = (batch_points[:, 0].abs() * 7).long() % 3
         batch_idx = coors[:, 0]
-        pts_l, bidx_l, sel_l = [], [], []
-        for c in range(3):
-            sel = torch.nonzero(fg & (cls == c)).squeeze(1)
-            sel_l.append(sel)
-            pts_l.append((batch_points[sel, :3] + 0.05 * torch.tanh(votes[sel, c])).detach())
-            bidx_l.append(batch_idx[sel])
-        cluster_inds_l, valid_l = self.cluster_assigner(pts_l, bidx_l)
+        sel_l, pts_l = fsd_foreground_stand_in(batch_points, votes)
+        # called as SingleStageFSD.forward_train does (single_stage_fsd.py:521): per-class lists, origin_points = the points
+        cluster_inds_l, valid_l = self.cluster_assigner(pts_l, [batch_idx[s] for s in sel_l], None, None,
+                                                        origin_points=[batch_points[s] for s in sel_l])
         sel = torch.cat([s[v] for s, v in zip(sel_l, valid_l)])
-        cluster_inds = torch.cat(cluster_inds_l)                                      # [P, 3] (class, sample, cluster)
+        cluster_inds = torch.cat(cluster_inds_l).long()                               # [P, 3] (class, sample, cluster)
         centres = torch.cat([p[v] for p, v in zip(pts_l, valid_l)])
         points = batch_points[sel]
-        feats = torch.cat([seg_feats[sel], logits[sel], votes[sel].reshape(-1, 9)], 1)  # [P, 79]
-        # SingleStageFSD.extract_feat
-        cluster_xyz, _, inv = scatter_v2(centres, cluster_inds, mode='avg', return_inv=True)
+        feats = torch.cat([seg_feats[sel], logits[sel], votes[sel].reshape(-1, 9)], 1)
+        # SingleStageFSD.extract_feat (single_stage_fsd.py:467-483)
+        cluster_xyz, _, inv = ops.scatter_v2(centres, cluster_inds, mode='avg', return_inv=True)
         f_cluster = points[:, :3] - cluster_xyz[inv]
         pts_out, cluster_feats, cluster_coors = self.backbone(points, feats, cluster_inds, f_cluster)
+        stats = dict(points=batch_points.size(0), voxels=voxel_feats.size(0), fg_points=points.size(0),
+                     clusters=cluster_feats.size(0))
+        loss = cluster_feats.sum() * 1e-3 + logits.sum() * 1e-3
+        tensors = dict(voxel_coors=voxel_coors, voxel_feats=voxel_feats, unet_feats=x['voxel_feats'], seg_feats=seg_feats,
+                       head=head, sel=sel, cluster_inds=cluster_inds, pts_out=pts_out, cluster_feats=cluster_feats,
+                       cluster_coors=cluster_coors, cluster_xyz=cluster_xyz)
+        if not self.roi_stage:
+            loss = loss + cluster_feats.square().mean() + pts_out.square().mean()
+            return (loss, stats, tensors) if return_tensors else (loss, stats)
         box = self.box_head(cluster_feats)
         rois = torch.cat([cluster_coors[:, 1:2].float(),
                           cluster_xyz + 0.1 * torch.tanh(box[:, :3]) - torch.tensor([0, 0, 0.9], device=dev),
@@ -120,65 +201,84 @@ class FSDPath(nn.Module):
         pooled_xyz = points[p_order][ext_inds.clamp(min=0), :3]
         geo = torch.cat([info['local_xyz'], info['boundary_offset'], info['is_in_margin'][:, None], pooled_xyz], 1)[keep]
         ext_inds, roi_inds = ext_inds[keep], roi_inds[keep]
-        roi_feats = torch.cat([pts_out[p_order][ext_inds], geo], 1)                     # [Q, 128 + 13]
+        roi_feats = torch.cat([pts_out[p_order][ext_inds], geo], 1)                     # [Q, F + 13]
         roi_coors = torch.stack([torch.zeros_like(roi_inds), rois[roi_inds, 0].long(), roi_inds], 1)
         _, roi_cluster_feats, _ = self.roi_backbone(geo, roi_feats, roi_coors, geo[:, :3].contiguous())
-        stats = dict(points=batch_points.size(0), voxels=voxel_feats.size(0), fg_points=points.size(0),
-                     clusters=cluster_feats.size(0), pooled_pairs=roi_feats.size(0))
-        return roi_cluster_feats.sum() + cluster_feats.sum() * 1e-3 + logits.sum() * 1e-3, stats
+        stats['pooled_pairs'] = roi_feats.size(0)
+        tensors['roi_cluster_feats'] = roi_cluster_feats
+        loss = loss + roi_cluster_feats.sum()
+        return (loss, stats, tensors) if return_tensors else (loss, stats)
+
+
+# configs/fsdv2/fsdv2_nusc_1x.py at hot-path level
+FSDV2_CFG = dict(
+    seg_voxel=(0.2, 0.2, 0.2), virtual_voxel=(0.4, 0.4, 0.4), pc_range=[-51.2, -51.2, -5, 51.2, 51.2, 3], n_logits=11,
+    vfe=dict(in_channels=5, feat_channels=[64, 64]),
+    unet=dict(in_channels=64, sparse_shape=[40, 512, 512], base_channels=64, output_channels=128,
+              encoder_channels=((128, ), (128, 128), (128, 128), (128, 128, 128), (256, 256, 256), (256, 256, 256)),
+              encoder_paddings=((1, ), (1, 1), (1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+              decoder_channels=((256, 256, 256), (256, 256, 128), (128, 128, 128), (128, 128, 128), (128, 128, 128),
+                                (128, 128, 128)),
+              decoder_paddings=((1, 1), (1, 0), (1, 0), (0, 0), (0, 1), (1, 1))),
+    mixer=dict(in_channels=128, sparse_shape=[20, 256, 256], base_channels=64, output_channels=128,
+               encoder_channels=((64, ), (64, 64), (64, 64)), encoder_paddings=((1, ), (1, 1), (1, 1)),
+               decoder_channels=((64, 64, 64), (64, 64, 64), (64, 64, 64)), decoder_paddings=((1, 1), (1, 1), (1, 1))),
+    virtual_vfe=dict(feat_channels=[64, 128]), proj_hidden=[64, 64])
+FSDV2_SMALL_CFG = dict(
+    seg_voxel=(0.2, 0.2, 0.2), virtual_voxel=(0.4, 0.4, 0.4), pc_range=[-12.8, -12.8, -2, 12.8, 12.8, 1.2], n_logits=5,
+    vfe=dict(in_channels=5, feat_channels=[16, 16]),
+    unet=dict(in_channels=16, sparse_shape=[16, 128, 128], base_channels=16, output_channels=16,
+              encoder_channels=((16, ), (16, 16), (32, 32)), encoder_paddings=((1, ), (1, 1), (1, 1)),
+              decoder_channels=((32, 32, 16), (16, 16, 16), (16, 16, 16)), decoder_paddings=((1, 1), (1, 0), (0, 1))),
+    mixer=dict(in_channels=16, sparse_shape=[8, 64, 64], base_channels=16, output_channels=16,
+               encoder_channels=((16, ), (16, 16)), encoder_paddings=((1, ), (1, 1)),
+               decoder_channels=((16, 16, 16), (16, 16, 16)), decoder_paddings=((1, 1), (1, 1))),
+    virtual_vfe=dict(feat_channels=[16, 16]), proj_hidden=[16, 16])
 
 
 class FSDv2Path(nn.Module):
-    """configs/fsdv2/fsdv2_nusc_1x.py at hot-path level: segmentor (DynamicScatterVFE + SimpleSparseUNet, 0.2 m,
-    [40, 512, 512]) -> point features -> virtual-voxel stage (0.4 m, [20, 256, 256]).  Stand-ins: `seg_head` (VoteSegHead:
-    11 logits + one 3-vector vote), foreground = points above the ground plane; the multi-scale fusion of the config
-    (multiscale_cfg) is not part of the stage (sst_amd/virtual_voxel.py)."""
-    SEG_VOXEL = (0.2, 0.2, 0.2)
-    VIRTUAL_VOXEL = (0.4, 0.4, 0.4)
-    PC_RANGE = [-51.2, -51.2, -5, 51.2, 51.2, 3]
+    """configs/fsdv2/fsdv2_nusc_1x.py at hot-path level over a module provider: segmentor (DynamicScatterVFE +
+    SimpleSparseUNet) -> point features -> virtual-voxel stage (SingleStageFSDV2.extract_feat).  Stand-ins: `seg_head`
+    (VoteSegHead: class logits + one 3-vector vote), foreground = points above the ground plane; the multi-scale fusion of
+    the config (multiscale_cfg) is not part of the stage (sst_amd/virtual_voxel.py)."""
 
-    def __init__(self):
+    def __init__(self, ops=GpuOps, cfg=None):
         super().__init__()
-        self.voxel_layer = sst_amd.Voxelization(self.SEG_VOXEL, self.PC_RANGE, -1, (-1, -1))
-        self.voxel_encoder = sst_amd.DynamicScatterVFE(in_channels=5, feat_channels=[64, 64], voxel_size=self.SEG_VOXEL,
-                                                       with_cluster_center=True, with_voxel_center=True,
-                                                       point_cloud_range=self.PC_RANGE, norm_cfg=BN, unique_once=True)
-        self.middle_encoder = sst_amd.PseudoMiddleEncoderForSpconvFSD()
-        self.seg_backbone = sst_amd.SimpleSparseUNet(
-            in_channels=64, sparse_shape=[40, 512, 512], order=('conv', 'norm', 'act'), norm_cfg=BN, base_channels=64,
-            output_channels=128,
-            encoder_channels=((128, ), (128, 128), (128, 128), (128, 128, 128), (256, 256, 256), (256, 256, 256)),
-            encoder_paddings=((1, ), (1, 1), (1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
-            decoder_channels=((256, 256, 256), (256, 256, 128), (128, 128, 128), (128, 128, 128), (128, 128, 128), (128, 128, 128)),
-            decoder_paddings=((1, 1), (1, 0), (1, 0), (0, 0), (0, 1), (1, 1)))
-        self.seg_head = nn.Linear(131, 11 + 3)      # stand-in: 10 classes + background, one centre vote
-        self.virtual_stage = sst_amd.VirtualVoxelExtractor(
-            backbone=dict(type='VirtualVoxelMixer', in_channels=128, sparse_shape=[20, 256, 256],
-                          order=('conv', 'norm', 'act'), norm_cfg=BN, base_channels=64, output_channels=128,
-                          encoder_channels=((64, ), (64, 64), (64, 64)), encoder_paddings=((1, ), (1, 1), (1, 1)),
-                          decoder_channels=((64, 64, 64), (64, 64, 64), (64, 64, 64)),
-                          decoder_paddings=((1, 1), (1, 1), (1, 1))),
-            voxel_encoder=dict(type='DynamicScatterVFE', in_channels=67, feat_channels=[64, 128],
-                               voxel_size=self.VIRTUAL_VOXEL, with_cluster_center=True, with_voxel_center=True,
-                               point_cloud_range=self.PC_RANGE, norm_cfg=BN, unique_once=True),
-            virtual_point_projector=dict(in_channels=83 + 64, hidden_dims=[64, 64], norm_cfg=dict(type='naiveSyncBN1d'),
-                                         ori_in_channels=67 + 64, ori_hidden_dims=[64, 64]))
+        cfg = self.cfg = FSDV2_CFG if cfg is None else cfg
+        self.ops = ops
+        self.SEG_VOXEL, self.VIRTUAL_VOXEL, self.PC_RANGE = cfg['seg_voxel'], cfg['virtual_voxel'], cfg['pc_range']
+        self.n_logits = cfg['n_logits']
+        c_seg = cfg['unet']['decoder_channels'][-1][-1]
+        self.voxel_encoder = ops.DynamicScatterVFE(voxel_size=self.SEG_VOXEL, with_cluster_center=True, with_voxel_center=True,
+                                                   point_cloud_range=self.PC_RANGE, norm_cfg=BN, unique_once=True, **cfg['vfe'])
+        self.middle_encoder = ops.PseudoMiddleEncoderForSpconvFSD()
+        self.seg_backbone = ops.SimpleSparseUNet(order=('conv', 'norm', 'act'), norm_cfg=BN, **cfg['unet'])
+        self.seg_head = nn.Linear(c_seg + 3, self.n_logits + 3)      # stand-in: classes + background, one centre vote
+        hid = cfg['proj_hidden']
+        self.virtual_stage = ops.VirtualVoxelExtractor(
+            backbone=dict(type='VirtualVoxelMixer', order=('conv', 'norm', 'act'), norm_cfg=BN, **cfg['mixer']),
+            voxel_encoder=dict(type='DynamicScatterVFE', in_channels=3 + hid[-1], voxel_size=self.VIRTUAL_VOXEL,
+                               with_cluster_center=True, with_voxel_center=True, point_cloud_range=self.PC_RANGE, norm_cfg=BN,
+                               unique_once=True, **cfg['virtual_vfe']),
+            virtual_point_projector=dict(in_channels=(c_seg + 3) + 3 + self.n_logits + 2, hidden_dims=hid,
+                                         norm_cfg=dict(type='naiveSyncBN1d'), ori_in_channels=c_seg + 3,
+                                         ori_hidden_dims=hid))
+        assert cfg['mixer']['in_channels'] == cfg['virtual_vfe']['feat_channels'][-1]
 
     def make_cloud(self, n, seed, dev):
         return lidar_like_cloud(n, seed, dev, half_extent=50.0, z_ground=-1.8)[0]
 
-    def forward(self, points_list):
+    def forward(self, points_list, return_tensors=False):
         dev = points_list[0].device
-        batch_points, coors = self.voxel_layer.voxelize_batch(points_list)
-        coors = coors.long()
+        batch_points, coors = self.ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
         voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
         x = self.seg_backbone(self.middle_encoder(voxel_feats, voxel_coors))[0]
         pts_feats = x['voxel_feats'][v2p]                                               # Voxel2PointScatterNeck
         vs = torch.tensor(self.SEG_VOXEL, device=dev).reshape(1, 3)
         centre = (coors[:, [3, 2, 1]].float() + 0.5) * vs + torch.tensor(self.PC_RANGE[:3], device=dev).reshape(1, 3)
-        seg_feats = torch.cat([pts_feats, batch_points[:, :3] - centre], 1)            # [N, 131]
+        seg_feats = torch.cat([pts_feats, batch_points[:, :3] - centre], 1)            # [N, C + 3]
         head = self.seg_head(seg_feats)
-        logits, vote = head[:, :11], head[:, 11:]
+        logits, vote = head[:, :self.n_logits], head[:, self.n_logits:]
         sel = torch.nonzero(batch_points[:, 2] > -1.4).squeeze(1)                        # foreground stand-in
         sampled = dict(seg_points=batch_points[sel], center_preds=(batch_points[sel, :3] + torch.tanh(vote[sel])).detach(),
                        seg_logits=logits[sel], seg_feats=seg_feats[sel], batch_idx=coors[sel, 0])
@@ -186,7 +286,13 @@ class FSDv2Path(nn.Module):
         out = self.virtual_stage(sampled, origin)
         stats = dict(points=batch_points.size(0), voxels=voxel_feats.size(0), fg_points=int(sel.numel()),
                      virtual_voxels=out['virtual_feats'].size(0))
-        return out['virtual_feats'].sum() + logits.sum() * 1e-3, stats
+        loss = out['virtual_feats'].sum() + logits.sum() * 1e-3
+        if return_tensors:
+            return loss, stats, dict(voxel_coors=voxel_coors, voxel_feats=voxel_feats, unet_feats=x['voxel_feats'],
+                                     seg_feats=seg_feats, head=head, virtual_feats=out['virtual_feats'],
+                                     virtual_coors=out['virtual_coors'], virtual_centers=out['virtual_centers'],
+                                     virtual_centroid=out.get('virtual_centroid'))
+        return loss, stats
 
 
 WORKLOADS = {

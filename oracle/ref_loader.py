@@ -370,3 +370,20 @@ def load_reference_method(relpath, cls_name, name, extra_globals=None):
                     exec(compile(code, path + ':' + cls_name + '.' + name, 'exec'), glb)
                     return glb[name]
     raise KeyError(cls_name + '.' + name)
+
+
+def load_reference_class(relpath, cls_name, extra_globals=None):
+    """One class of a reference file, executed from the file's own source text (for files that cannot be imported here,
+    e.g. detectors/single_stage_fsd.py needs mmdet / mmseg).  Decorators are dropped (registry registration); nothing is
+    copied into the repository."""
+    import ast
+    path = os.path.join(REF_ROOT, relpath)
+    src = open(path).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == cls_name:
+            lines = src.splitlines()[node.lineno - 1:node.end_lineno]      # from the `class` line on: no decorators
+            glb = {'torch': torch, 'nn': nn}
+            glb.update(extra_globals or {})
+            exec(compile('\n'.join(lines), path + ':' + cls_name, 'exec'), glb)
+            return glb[cls_name]
+    raise KeyError(cls_name)

@@ -631,6 +631,56 @@ def gen_virtual_voxel():
     save('virtual_voxel.npz', **arrays)
 
 
+CHAIN_GRAD_KEYS = {
+    'fsd': ['voxel_encoder.vfe_layers.0.linear.weight', 'seg_backbone.conv_input.0.weight',
+            'seg_backbone.encoder_layers.encoder_layer2.0.0.weight', 'seg_backbone.upsample_layer2.0.weight',
+            'seg_backbone.lateral_layer1.conv2.weight', 'seg_head.weight', 'backbone.block_list.0.rel_mlp.0.0.weight',
+            'backbone.block_list.1.vfe_layers.1.linear.weight', 'backbone.block_list.2.vfe_layers.0.norm.weight'],
+    'fsdv2': ['voxel_encoder.vfe_layers.1.linear.weight', 'seg_backbone.encoder_layers.encoder_layer3.0.0.weight',
+              'seg_backbone.merge_layer1.0.weight', 'seg_head.weight', 'virtual_stage.virtual_proj.0.0.weight',
+              'virtual_stage.ori_proj.1.0.weight', 'virtual_stage.voxel_encoder.vfe_layers.0.linear.weight',
+              'virtual_stage.backbone.conv_out.0.weight', 'virtual_stage.backbone.encoder_layers.encoder_layer2.0.0.weight'],
+}
+
+
+def gen_fsd_chains():
+    """BASELINE.json configs[3] / configs[4] as CHAINS, produced by the reference's own modules wired the way its detectors
+    wire them (oracle/ref_fsd.reference_ops: DynamicScatterVFE -> SimpleSparseUNet -> Voxel2PointScatterNeck -> ClusterAssigner
+    -> SingleStageFSD.extract_feat / SIR, and -> SingleStageFSDV2.extract_feat / VirtualVoxelMixer), at fixture size
+    (bench_workloads.FSD_SMALL_CFG / FSDV2_SMALL_CFG), training mode, forward + backward.  The wiring code itself is
+    bench_workloads.FSDPath / FSDv2Path - the same code the GPU path and the CPU port run."""
+    import bench_workloads as BW
+    from oracle import ref_fsd
+    ops = ref_fsd.reference_ops()
+    for tag, cls, cfg, kw, half in (('fsd', BW.FSDPath, BW.FSD_SMALL_CFG, dict(roi_stage=False), 18.0),
+                                    ('fsdv2', BW.FSDv2Path, BW.FSDV2_SMALL_CFG, dict(), 12.0)):
+        torch.manual_seed(40)
+        net = cls(ops, cfg, **kw).train()
+        g = torch.Generator().manual_seed(41)
+        with torch.no_grad():
+            for p in net.parameters():      # biases and norm parameters away from their 0 / 1 defaults
+                if p.dim() == 1:
+                    p.add_(torch.randn(p.shape, generator=g) * 0.1)
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        clouds = [BW.chain_cloud(4000, 1, half_extent=half), BW.chain_cloud(3000, 2, half_extent=half)]
+        loss, stats, out = net(clouds, return_tensors=True)
+        loss.backward()
+        arrays = {f'in::points{i}': t2n(c) for i, c in enumerate(clouds)}
+        arrays['out::loss'] = t2n(loss)
+        for k, v in out.items():
+            if v is None or k in ('seg_feats', 'voxel_feats'):      # implied by unet_feats / head; keeps the fixture small
+                continue
+            v = v[::4] if k == 'head' else v                        # every 4th point
+            arrays['out::' + k] = t2n(v) if v.is_floating_point() else t2n(v).astype(np.int32)
+        arrays.update({'stats::' + k: np.asarray(v) for k, v in stats.items()})
+        params = dict(net.named_parameters())
+        for k in CHAIN_GRAD_KEYS[tag]:
+            arrays['grad::' + k] = t2n(params[k].grad)
+        arrays.update(state_to_np(state))
+        print(tag, stats)
+        save(f'{tag}_chain.npz', **arrays)
+
+
 def gen_hard_voxelize():
     """Hard voxelization (max_num_points / max_voxels set) from the reference's own compiled C++
     (voxelization_cpu.cpp:43-142 through oracle/_ref/voxel_layer_ref.so): more voxels than max_voxels (later ones
@@ -658,6 +708,10 @@ def gen_hard_voxelize():
 
 def main():
     assert ref_loader.available(), 'the reference tree is required'
+    if len(sys.argv) > 1 and sys.argv[1] == 'chains':      # only the chain goldens
+        build_ref.build()
+        gen_fsd_chains()
+        return
     build_ref.build()
     ref = ref_loader.load_reference()
     if len(sys.argv) > 2 and sys.argv[1] == 'sst_block':     # regenerate single block variants only
@@ -686,6 +740,7 @@ def main():
     gen_spconv()
     gen_sparse_unet()
     gen_virtual_voxel()
+    gen_fsd_chains()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,117 @@
+"""BASELINE.json configs[3] (FSD) and configs[4] (FSDv2) as CHAINS ("a chain-level FSD / FSDv2 golden").
+
+The wiring is bench_workloads.FSDPath / FSDv2Path - one piece of code over a module provider:
+  * the reference's own modules (oracle/ref_fsd.py, build container) produced tests/golden/fsd_chain.npz and
+    fsdv2_chain.npz: VoteSegmentor.extract_feat -> Voxel2PointScatterNeck -> ClusterAssigner -> SingleStageFSD.extract_feat
+    (detectors/single_stage_fsd.py:228-250, 467-483, 922-999) and SingleStageFSDV2.extract_feat
+    (single_stage_fsd_v2.py:159-271), forward + backward, training mode, fixture size;
+  * the CPU port (oracle/fsd_cpu.py = bench.py's cpu_baseline for these workloads) is checked against the goldens on any box
+    and against the live reference in the build container (other seed, eval mode);
+  * the GPU path (sst_amd) is checked against the goldens (`-m gpu`): integer outputs - voxels, foreground selection,
+    cluster assignment, virtual voxels - exactly, features 1e-3 (measured ~1e-5), gradients 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+import bench_workloads as BW
+from oracle import ref_loader
+
+CASES = {'fsd': (BW.FSDPath, BW.FSD_SMALL_CFG, dict(roi_stage=False), 18.0),
+         'fsdv2': (BW.FSDv2Path, BW.FSDV2_SMALL_CFG, dict(), 12.0)}
+INT_KEYS = ('voxel_coors', 'sel', 'cluster_inds', 'cluster_coors', 'virtual_coors')
+
+
+def _build(tag, ops, golden, dev='cpu'):
+    cls, cfg, kw, _ = CASES[tag]
+    net = cls(ops, cfg, **kw)
+    net.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in golden.items() if k.startswith('w::')}, strict=True)
+    return net.to(dev).train()
+
+
+def _check_against_golden(tag, net, g, dev, feat_tol, grad_tol):
+    clouds = [torch.from_numpy(g['in::points0']).to(dev), torch.from_numpy(g['in::points1']).to(dev)]
+    loss, stats, out = net(clouds, return_tensors=True)
+    loss.backward()
+    for k, v in stats.items():
+        assert int(v) == int(g['stats::' + k]), (k, int(v), int(g['stats::' + k]))
+    for key in [k[5:] for k in g if k.startswith('out::') and k != 'out::loss']:
+        got = out[key][::4] if key == 'head' else out[key]
+        want = g['out::' + key]
+        if key in INT_KEYS:
+            np.testing.assert_array_equal(got.cpu().numpy().astype(np.int64), want.astype(np.int64), err_msg=key)
+        else:
+            err = float(np.abs(got.detach().cpu().numpy() - want).max())
+            assert err <= feat_tol * max(1.0, float(np.abs(want).max())), (key, err)
+    assert abs(float(loss.detach()) - float(g['out::loss'])) <= feat_tol * max(1.0, abs(float(g['out::loss'])))
+    params = dict(net.named_parameters())
+    grad_keys = [k[6:] for k in g if k.startswith('grad::')]
+    assert len(grad_keys) >= 8
+    for key in grad_keys:
+        want = g['grad::' + key]
+        err = float(np.abs(params[key].grad.cpu().numpy() - want).max())
+        assert err <= grad_tol * max(1.0, float(np.abs(want).max())), (key, err)
+
+
+@pytest.mark.parametrize('tag', ['fsd', 'fsdv2'])
+def test_cpu_port_chain_matches_reference_golden(tag):
+    from oracle import fsd_cpu
+    g = load_golden(f'{tag}_chain.npz')
+    _check_against_golden(tag, _build(tag, fsd_cpu, g), g, 'cpu', 1e-4, 1e-4)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason='needs the reference tree (build container)')
+@pytest.mark.parametrize('tag', ['fsd', 'fsdv2'])
+@pytest.mark.parametrize('train', [True, False])
+def test_cpu_port_chain_matches_live_reference(tag, train):
+    """other weights, other clouds, training and eval mode (running batch-norm statistics, single-batch clustering),
+    every gradient of the chain"""
+    from oracle import fsd_cpu, ref_fsd
+    cls, cfg, kw, half = CASES[tag]
+    torch.manual_seed(7 + int(train))
+    ref = cls(ref_fsd.reference_ops(), cfg, **kw)
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2, generator=gen)
+                m.running_var.uniform_(0.5, 1.5, generator=gen)
+    port = cls(fsd_cpu, cfg, **kw)
+    port.load_state_dict(ref.state_dict(), strict=True)
+    ref.train(train)
+    port.train(train)
+    clouds = [BW.chain_cloud(3500, 11, half_extent=half)] if not train else \
+        [BW.chain_cloud(3000, 12, half_extent=half), BW.chain_cloud(2500, 13, half_extent=half)]
+    lr, sr, tr = ref(clouds, return_tensors=True)
+    lp, sp, tp = port(clouds, return_tensors=True)
+    assert sr == sp
+    for key, a in tr.items():
+        if a is None:
+            continue
+        if a.is_floating_point():
+            assert float((a - tp[key]).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max())), key
+        else:
+            assert torch.equal(a.long(), tp[key].long()), key
+    if train:
+        lr.backward()
+        lp.backward()
+        theirs, ours = dict(ref.named_parameters()), dict(port.named_parameters())
+        checked = 0
+        for name, p in theirs.items():
+            if p.grad is None:
+                assert ours[name].grad is None, name
+                continue
+            assert float((p.grad - ours[name].grad).abs().max()) <= 1e-4 * max(1.0, float(p.grad.abs().max())), name
+            checked += 1
+        assert checked > 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['fsd', 'fsdv2'])
+def test_gpu_chain_matches_reference_golden(tag):
+    g = load_golden(f'{tag}_chain.npz')
+    _check_against_golden(tag, _build(tag, BW.GpuOps, g, 'cuda:0'), g, 'cuda:0', 1e-3, 1e-3)

@@ -141,11 +141,28 @@ def test_flat2window_window2flat_keep_the_kernels_under_autograd():
     gen = torch.Generator().manual_seed(0)
     feat = torch.randn(m, 32, generator=gen).to(DEV)
     a = feat.clone().requires_grad_(True)
-    win = sst_amd.flat2window_v2(a, inds, padding=-3.0)
-    assert all(isinstance(v.grad_fn, sst_ops._ScatterRowsFn._backward_cls) for v in win.values())
-    back = sst_amd.window2flat_v2({k: v * (k + 2.0) for k, v in win.items()}, inds)
-    up = torch.randn(back.shape, generator=gen).to(DEV)
-    (back * up).sum().backward()
+    calls = {'scatter': 0, 'gather': 0}
+    real_scatter, real_gather = sst_ops.K.scatter_rows, sst_ops.K.gather_rows
+
+    def counted_scatter(*args, **kw):
+        calls['scatter'] += 1
+        return real_scatter(*args, **kw)
+
+    def counted_gather(*args, **kw):
+        calls['gather'] += 1
+        return real_gather(*args, **kw)
+
+    sst_ops.K.scatter_rows, sst_ops.K.gather_rows = counted_scatter, counted_gather
+    try:
+        win = sst_amd.flat2window_v2(a, inds, padding=-3.0)
+        back = sst_amd.window2flat_v2({k: v * (k + 2.0) for k, v in win.items()}, inds)
+        up = torch.randn(back.shape, generator=gen).to(DEV)
+        (back * up).sum().backward()
+    finally:
+        sst_ops.K.scatter_rows, sst_ops.K.gather_rows = real_scatter, real_gather
+    n_levels = len(win)
+    # forward: one scatter + one gather per level; backward: the same again with the roles swapped
+    assert calls == {'scatter': 2 * n_levels, 'gather': 2 * n_levels}, calls
     # reference formulation with plain indexing
     b = feat.clone().requires_grad_(True)
     lvl = inds['voxel_drop_level']
