@@ -378,6 +378,58 @@ def _conv_roofline(model, clouds):
     return conv, seg
 
 
+def cpu_chain_leg(spec, model, clouds):
+    """The CPU port of the same chain (oracle/fsd_cpu.py: the reference's algorithm module by module, pinned to the
+    reference by tests/test_fsd_chain.py) on the host cores, rank 0 at N = 1 - the ONLY place this file touches oracle/:
+      * `cpu_baseline`: frames/s of forward + backward of the first bench frame: one untimed warm-up pass on a 20 000-point
+        cloud (thread pools, allocator), then ONE timed pass at full size (tens of seconds);
+      * `parity`: the GPU chain with the SAME weights on the SAME frame against that CPU pass - integer side (voxel set,
+        foreground selection, cluster assignment / virtual voxels) and the features along the chain; gradients of three
+        parameters at the ends and the middle of the chain."""
+    from oracle import fsd_cpu
+    threads = torch.get_num_threads()
+    port = spec['cls'](fsd_cpu).train()
+    port.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
+    port(([model.make_cloud(20000, 7, 'cpu')]))[0].backward()                  # warm-up, untimed
+    port.zero_grad(set_to_none=True)
+    frame = [clouds[0].cpu()]
+    t0 = time.perf_counter()
+    loss_c, _, tc = port(frame, return_tensors=True)
+    loss_c.backward()
+    cpu_s = time.perf_counter() - t0
+    model.zero_grad(set_to_none=True)
+    loss_g, stats, tg = model([clouds[0]], return_tensors=True)
+    loss_g.backward()
+    ints, feats = {}, {}
+    for key, a in tc.items():
+        b = tg.get(key)
+        if a is None or b is None:
+            continue
+        b = b.detach().cpu()
+        same_shape = tuple(a.shape) == tuple(b.shape)
+        if a.is_floating_point():
+            feats[key] = float((a.detach() - b).abs().max()) if same_shape else None
+        else:
+            ints[key] = bool(same_shape and torch.equal(a.long(), b.long()))
+    pg, pc = dict(model.named_parameters()), dict(port.named_parameters())
+    grad_names = [n for n in ('seg_backbone.conv_input.0.weight', 'seg_head.weight', 'backbone.block_list.0.vfe_layers.0.linear.weight',
+                              'virtual_stage.backbone.conv_out.0.weight') if n in pc and pc[n].grad is not None]
+    grads = {n: float((pg[n].grad.cpu() - pc[n].grad).abs().max() / pc[n].grad.abs().max().clamp(min=1e-12))
+             for n in grad_names}
+    finite = [v for v in feats.values() if v is not None]
+    parity = {'integer_outputs_equal': ints, 'max_abs_err': {k: (round(v, 9) if v is not None else None) for k, v in feats.items()},
+              'max_abs_err_overall': max(finite) if finite else None, 'max_rel_grad_err': grads, 'tolerance': 1e-3,
+              'what': 'GPU chain (fp32) vs the CPU port of the reference chain, same weights, first bench frame, training '
+                      'mode; a feature entry is null when an integer stage upstream of it differs (its rows are then not '
+                      'comparable); the RoI stage rides on the point pool, whose features are unpinned (TorchEx absent)'}
+    base = {'value': round(1.0 / cpu_s, 5), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': f'1 timed pass of 1 frame ({frame[0].size(0)} points), forward + backward, {cpu_s:.1f} s, after one '
+                      'untimed warm-up pass on a 20 000-point cloud; CPU port of the reference chain (oracle/fsd_cpu.py: '
+                      'torch.unique + scatter_reduce, per-offset gather / mm / index_add sparse convolutions, dense-adjacency '
+                      'scipy connected components, numpy point pool)'}
+    return base, parity
+
+
 def run(args, rank, world, dev, allreduce_grads):
     """bench.py's contract for --workload fsd | fsdv2: W warm-up steps, K timed steps between barriers, max over ranks,
     one JSON line from rank 0."""
@@ -417,6 +469,9 @@ def run(args, rank, world, dev, allreduce_grads):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     conv, seg = _conv_roofline(model, clouds)
+    cpu_base = parity = None
+    if rank == 0 and world == 1 and not getattr(args, 'no_cpu_baseline', False):
+        cpu_base, parity = cpu_chain_leg(spec, model, clouds)
     if rank == 0:
         frames = world * args.frames_per_gpu * args.steps
         res = {'metric': spec['metric'], 'value': round(frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world,
@@ -427,5 +482,6 @@ def run(args, rank, world, dev, allreduce_grads):
                           'sizes': {k: int(v) for k, v in stats.items()},
                           'stand_ins': 'segmentation / box heads = linear layers, foreground = geometric rule '
                                        '(detector glue is out of scope)'},
-               'roofline': conv if conv is not None else seg, 'roofline_seg_reduce': seg, 'cpu_baseline': None}
+               'roofline': conv if conv is not None else seg, 'roofline_seg_reduce': seg, 'cpu_baseline': cpu_base,
+               'parity': parity}
         print(json.dumps(res))
