@@ -118,6 +118,50 @@ def allreduce_grads(params, world):
     return flat
 
 
+def make_reducer(params, world, args):
+    """N > 1: persistent flat gradient buffer, buckets sent from autograd hooks while the backward pass still runs
+    (sst_amd/parallel.py); --grad-sync flat = the round-2 behaviour (one blocking all-reduce after the backward pass)"""
+    if world <= 1:
+        return None
+    from sst_amd.parallel import GradBucketReducer
+    overlap = getattr(args, 'grad_sync', 'overlap') == 'overlap'
+    return GradBucketReducer(params, n_buckets=getattr(args, 'grad_buckets', 2) if overlap else 1, overlap=overlap)
+
+
+def collective_costs(reducer, dev, reps=20):
+    """what the exchanges of one step cost when nothing overlaps them (HIP events around blocking calls, outside the timed
+    region): `allreduce_ms` = the gradient buckets, `bn_sync_ms` = naiveSyncBN's statistics messages of one step
+    (2 layers x (forward [mean || meansqr] of 2 C floats + backward 2 C floats), ops/norm.py:9-24, latency-bound)"""
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    scratch = torch.zeros_like(reducer.flat)
+
+    def grads():
+        for start, end, _ in reducer.buckets:
+            dist.all_reduce(scratch[start:end])
+
+    small = [torch.zeros(2 * c, device=dev) for c in (64, 128)]
+
+    def bn():
+        for t in small:
+            dist.all_reduce(t)     # forward statistics
+        for t in small:
+            dist.all_reduce(t)     # backward sums
+
+    return {'allreduce_ms': round(timed(grads), 4), 'bn_sync_ms': round(timed(bn), 4),
+            'gradient_bytes': int(reducer.flat.numel() * 4), 'buckets': [int((e - s_) * 4) for s_, e, _ in reducer.buckets]}
+
+
 def voxel_sort_key(coors):
     """(b, z, y, x) -> one int64 key whose order is the sorted-unique voxel order (bench-side helper: the reduced-precision
     leg compares two GPU runs and must not touch oracle/)"""
@@ -286,6 +330,13 @@ def main():
     ap.add_argument('--blocks', type=int, default=6)
     ap.add_argument('--fwd-only', action='store_true', help='also report nothing else; time the forward only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-plan-prefetch', action='store_true',
+                    help='build the index plan of a batch at the head of its own step (round-2 behaviour) instead of behind '
+                         'the previous step\'s backward pass')
+    ap.add_argument('--grad-sync', default='overlap', choices=('overlap', 'flat'),
+                    help='N > 1: overlap = buckets sent from autograd hooks during the backward pass (default); flat = one '
+                         'blocking all-reduce of the whole buffer after it')
+    ap.add_argument('--grad-buckets', type=int, default=2)
     ap.add_argument('--no-time-sra-bwd', action='store_true', help='do not attach events to the SRA backward launches')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the reduced-precision (bf16) measurement')
@@ -326,7 +377,7 @@ def main():
 
     if args.workload in ('fsd', 'fsdv2'):
         import bench_workloads
-        bench_workloads.run(args, rank, world, dev, allreduce_grads)
+        bench_workloads.run(args, rank, world, dev, make_reducer)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -358,25 +409,41 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
     torch.manual_seed(1234 + rank)            # per-rank voxel shuffles
+    reducer = make_reducer(params, world, args)
 
     seed_grad = {}
+    ahead = []      # the index plan of the NEXT batch (depends on the point clouds only: no parameters, no features)
+
+    def next_plan():
+        """Software pipelining across steps, as a data loader's prefetch would do it: the index plan of the next batch
+        (voxelize, sorted-unique, window bucketing: ~50 short launches) is queued on the SAME stream right behind this
+        step's backward pass, while the host is still ahead of the device - its launches then run back to back instead of
+        at the host's launch rate at the head of the next step.  Every timed step still builds exactly one plan."""
+        if args.no_plan_prefetch:
+            return None
+        return ahead.pop() if ahead else model.prepare(frames)
 
     def step():
         if args.fwd_only:
             with torch.no_grad():
-                return model(frames)
+                out = model(frames, next_plan())
+                if not args.no_plan_prefetch:
+                    ahead.append(model.prepare(frames))
+                return out
         for p in params:
             p.grad = None
-        out = model(frames)
+        out = model(frames, next_plan())
         # backward from a fixed random upstream gradient (what a detection head would hand back).  NOT out.sum(): the
         # sum over the channels of a LayerNorm output is a constant, so its gradient is exactly zero upstream of the
         # last LayerNorm and every backward kernel would be timed on all-zero operands (lower power, higher clocks)
         g = seed_grad.get(out.shape)
         if g is None:
             g = seed_grad[out.shape] = torch.randn(out.shape, device=out.device, dtype=out.dtype)
-        out.backward(g)
-        if world > 1:
-            allreduce_grads(params, world)
+        out.backward(g)                       # the reducer's hooks send a bucket as soon as its gradients exist
+        if not args.no_plan_prefetch:
+            ahead.append(model.prepare(frames))
+        if reducer is not None:
+            reducer.finish()
         return out
 
     for _ in range(args.warmup):
@@ -408,6 +475,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    comm = collective_costs(reducer, dev) if reducer is not None else None   # every rank takes part
 
     # Outside the timed region: the forward-only rate of the same workload (BASELINE.json configs[1] is quoted
     # forward-only, the metric forward + backward; `value` is the harder one, this is reported beside it).
@@ -552,9 +621,18 @@ def main():
                                    + ('fwd only' if args.fwd_only else 'fwd+bwd'),
                        'frames_per_gpu': args.frames_per_gpu, 'points_per_frame': args.points,
                        'voxels_per_gpu': n_voxels, 'parallelism': f'dp{world}',
-                       'grad_sync': ('one flat all-reduce over ' + ('RCCL' if args.backend == 'nccl' else args.backend)) if world > 1 else 'none'},
+                       'index_plan': 'built at the head of its step' if args.no_plan_prefetch else
+                                     'one plan per step, queued behind the previous step\'s backward pass (same stream)',
+                       'grad_sync': ('one flat persistent fp32 buffer, ' + (f'{len(reducer.buckets)} bucket(s) sent from autograd '
+                                     'hooks during the backward pass' if args.grad_sync == 'overlap' else
+                                     'one blocking all-reduce after the backward pass') + ', over '
+                                     + ('RCCL' if args.backend == 'nccl' else args.backend)) if world > 1 else 'none'},
             'roofline': roofline,
         }
+        if comm is not None:
+            # the exchanges of one step when nothing overlaps them; in the timed step all but the last bucket ride under the
+            # backward pass of the voxel encoder / index stages
+            res.update(allreduce_ms=comm['allreduce_ms'], bn_sync_ms=comm['bn_sync_ms'], communication=comm)
         if fwd_only is not None:
             res['forward_only'] = fwd_only
         if bf16_leg is not None:

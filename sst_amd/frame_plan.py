@@ -41,7 +41,11 @@ class FramePlan(object):
         """Read the sizes (the only host synchronisation of the plan) and return the ``voxel_info`` dictionary the
         SST backbone consumes: surviving voxel features in window-major order, their coordinates, the window CSR and
         the positional embedding of both partitions."""
-        counts = self.d_counts.tolist()
+        # the sizes were copied to pinned host memory right behind the plan's kernels (build()): waiting for THAT copy does
+        # not wait for anything queued after it (the voxel encoder of this step, or - when the plan was built ahead, behind
+        # the previous step's backward pass - nothing at all)
+        self.counts_ready.synchronize()
+        counts = self.h_counts.tolist()
         m, m_keep, n_win, t_max = counts[0], counts[1], (counts[2], counts[3]), (counts[4], counts[5])
         self.num_voxels, self.num_kept = m, m_keep
         dev = voxel_feats.device
@@ -153,4 +157,8 @@ class FramePlanner(object):
                                      _lib.ptr(plan.winoff0), _lib.ptr(plan.winoff1), _lib.ptr(plan.posidx0),
                                      _lib.ptr(plan.posidx1), _lib.ptr(plan.d_counts), _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, 'sst_window_plan_i32')
+        plan.h_counts = torch.empty(8, dtype=torch.int32, pin_memory=True)
+        plan.h_counts.copy_(plan.d_counts, non_blocking=True)
+        plan.counts_ready = torch.cuda.Event()
+        plan.counts_ready.record()
         return plan

@@ -46,6 +46,34 @@ def _worker(rank, world, port, ret):
         assert torch.allclose(flat, sum(gathered) / world, atol=1e-6)
         ret[rank] = dict(y=y.detach(), gx=x.grad.detach(), flat=flat.clone(), mean=bn.running_mean.clone(),
                          gw=bn.weight.grad.clone())
+        # the bucketed reducer (sst_amd/parallel.py): same averaged gradients, persistent buffer, buckets sent from hooks
+        from sst_amd.parallel import GradBucketReducer
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                  torch.nn.Linear(16, 4))
+        unused = torch.nn.Linear(3, 3)                   # never part of the graph: must arrive as zeros
+        ps = list(net.parameters()) + list(unused.parameters())
+        results = {}
+        for mode, kw in (('overlap3', dict(n_buckets=3, overlap=True)), ('flat', dict(n_buckets=1, overlap=False))):
+            red = GradBucketReducer(ps, **kw)
+            ptr = red.flat.data_ptr()
+            for it in range(2):                          # two steps: the buffer and the views persist
+                for p in ps:
+                    p.grad = None
+                xin = full[start:start + sizes[rank]] * (it + 1)
+                (net(xin) ** 2).sum().backward()
+                local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in ps]
+                out = red.finish()
+                assert out.data_ptr() == ptr and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ps, red.views))
+                for p, g_local in zip(ps, local):
+                    both = [torch.zeros_like(g_local) for _ in range(world)]
+                    dist.all_gather(both, g_local)
+                    assert torch.allclose(p.grad, sum(both) / world, atol=1e-6)
+            assert sum(e - s_ for s_, e, _ in red.buckets) == red.flat.numel() == sum(p.numel() for p in ps)
+            results[mode] = red.flat.clone()
+            red.remove()
+        assert torch.equal(results['overlap3'], results['flat'])
+        assert float(results['flat'][:12].abs().sum()) == 0.0      # the unused layer (registered last) sits first
     finally:
         dist.destroy_process_group()
 

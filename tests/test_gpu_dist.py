@@ -47,19 +47,23 @@ def _bn_stats(model):
             for t in (layer.norm.running_mean, layer.norm.running_var)]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend='gloo', one_device=True):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     sys.path.insert(0, ROOT)
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = 'cuda:0' if one_device else f'cuda:{rank}'
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        bench, model = _build('cuda:0')
+        from sst_amd.parallel import GradBucketReducer
+        bench, model = _build(dev)
         params = [p for p in model.parameters() if p.requires_grad]
-        frame = bench.make_cloud(N_POINTS, 100 + rank, 'cuda:0')
+        reducer = GradBucketReducer(params, n_buckets=2)      # what bench.py --gpus N uses: buckets sent from hooks
+        frame = bench.make_cloud(N_POINTS, 100 + rank, dev)
         out = model([frame])
         _loss(out).backward()
-        bench.allreduce_grads(params, world)
+        reducer.finish()
         ret[rank] = dict(out_sum=float(out.detach().abs().double().sum()), n=int(out.size(0)),
                          grads=[p.grad.detach().cpu().clone() for p in params], bn=_bn_stats(model))
     finally:
@@ -98,6 +102,29 @@ def test_two_ranks_on_one_gpu_equal_the_concatenated_batch():
     assert errs[worst] < GRAD_TOL, f'{worst}: relative gradient error {errs[worst]}'
     for a, b in zip(_bn_stats(model), ret[0]['bn']):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL over xGMI)')
+def test_two_ranks_over_rccl_equal_the_concatenated_batch():
+    """the same check with one rank per GPU over backend 'nccl' (= RCCL): runs wherever `pytest -m gpu` sees two devices
+    (the driver's 8-GPU node), so RCCL initialisation, the async bucket all-reduces (ReduceOp.AVG) and naiveSyncBN's
+    messages are exercised before bench.py --gpus N is"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, 'nccl', False), nprocs=world, join=True)
+    assert len(ret) == 2
+    for a, b in zip(ret[0]['grads'], ret[1]['grads']):
+        assert torch.equal(a, b)
+    bench, model = _build('cuda:0')
+    params = [p for p in model.parameters() if p.requires_grad]
+    frames = [bench.make_cloud(N_POINTS, 100 + r, 'cuda:0') for r in range(world)]
+    out = model(frames)
+    _loss(out).backward()
+    assert out.size(0) == ret[0]['n'] + ret[1]['n']
+    for n, p, g2 in zip([n for n, p in model.named_parameters() if p.requires_grad], params, ret[0]['grads']):
+        ref = p.grad.cpu()
+        assert float((world * g2 - ref).abs().max()) / max(1e-3, float(ref.abs().max())) < GRAD_TOL, n
 
 
 def test_bench_launches_its_own_ranks():
