@@ -157,7 +157,9 @@ class FSDPath(nn.Module):
         dev = points_list[0].device
         batch_points, coors = ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
         voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
-        x = self.seg_backbone(self.middle_encoder(voxel_feats, voxel_coors))[0]
+        info = self.middle_encoder(voxel_feats, voxel_coors)
+        info.setdefault('batch_size', len(points_list))       # known here: spares the U-Net its read-back of coors[:, 0].max()
+        x = self.seg_backbone(info)[0]
         # Voxel2PointScatterNeck (necks/voxel2point_neck.py:28-63)
         pts_feats = x['voxel_feats'][v2p]
         vs = torch.tensor(self.SEG_VOXEL, device=dev).reshape(1, 3)
@@ -272,7 +274,9 @@ class FSDv2Path(nn.Module):
         dev = points_list[0].device
         batch_points, coors = self.ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
         voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
-        x = self.seg_backbone(self.middle_encoder(voxel_feats, voxel_coors))[0]
+        info = self.middle_encoder(voxel_feats, voxel_coors)
+        info.setdefault('batch_size', len(points_list))
+        x = self.seg_backbone(info)[0]
         pts_feats = x['voxel_feats'][v2p]                                               # Voxel2PointScatterNeck
         vs = torch.tensor(self.SEG_VOXEL, device=dev).reshape(1, 3)
         centre = (coors[:, [3, 2, 1]].float() + 0.5) * vs + torch.tensor(self.PC_RANGE[:3], device=dev).reshape(1, 3)

@@ -621,6 +621,13 @@ int64_t sst_spconv_conv_os_workspace_bytes(int kvol, int cin, int cout);
 int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
                            int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy,
                            int tile_cfg, void* d_workspace, void* stream);
+/*   sst_spconv_wgrad_os_f32: the same filter gradient as sst_spconv_wgrad_f32 (indiceConvBackward, spconv_ops.h:359-446)
+ *     with the gathered rows staged through LDS transposed, 64 x 64 blocks of dW[k], 2048-pair chunks (csrc/spconv_os.hip).
+ *     cin % 4 == 0, cout % 4 == 0, row strides % 4 == 0, 16-byte aligned operands; SST_ERR_UNSUPPORTED otherwise. */
+int64_t sst_spconv_wgrad_os_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout);
+int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+                            int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
+                            int cout, float* d_dw, void* d_workspace, void* stream);
 int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout);
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                          int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,

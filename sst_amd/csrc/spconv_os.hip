@@ -223,6 +223,173 @@ __global__ __launch_bounds__(256) void sp_conv_os_k(const float* __restrict__ x,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Filter gradient of indiceConvBackward (spconv_ops.h:359-446): dW[k] (cin x cout) = sum over the pairs p of offset k of
+// X[pa[p], :]^T dY[pb[p], :], second generation.  The first-generation kernel (sp_wgrad_k) feeds the MFMAs with one 4-byte
+// load per lane and operand straight from global memory (two gather latencies per 8 pairs, 512-pair chunks so that enough
+// workgroups overlap them, hence 6 k partial tiles of 16 KB for a 3 M-pair level and a 37 us reduction per call).  Here:
+//   * a workgroup owns a 64 x 64 block of dW[k] and a chunk of 2048 pairs of that offset; wave w a 32 x 32 quadrant;
+//   * a stage = 64 pairs: the 64 gathered X rows and the 64 gathered dY rows (64 channels of each: 16-byte loads, whole
+//     256-byte row pieces per 16 lanes) go global -> registers -> LDS TRANSPOSED ([channel][pair], XOR-swizzled by 4-pair
+//     groups so that both the transposing writes and the 16-byte fragment reads are conflict-free); the contraction runs
+//     over the pairs, so a ds_read_b128 hands a lane 4 consecutive pairs of its channel = 4 MFMA k-steps
+//     (v_mfma_f32_16x16x4_f32) for both operands;
+//   * software pipeline: pair indices of stage s + 2 and rows of stage s + 1 are in flight while stage s is multiplied,
+//     double-buffered LDS, one barrier per stage, every load unconditional (clamped pair index / channel, zeroed on the X
+//     side by a select);
+//   * partial blocks per chunk are summed in chunk order by sp_wgrad_os_reduce_k (deterministic): 4 x fewer, larger chunks.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWgChunk = 2048;  // pairs per workgroup
+constexpr int kWgStage = 64;    // pairs per stage
+constexpr int kWgLd = 68;       // LDS row stride (floats) of a [64 channels][64 pairs] image
+
+__device__ __forceinline__ bool os_find_chunk(const int32_t* __restrict__ num, int kvol, int chunk, int& k, int& first) {
+  int c0 = 0;
+  for (int i = 0; i < kvol; ++i) {
+    const int nc = (num[i] + kWgChunk - 1) / kWgChunk;
+    if (chunk < c0 + nc) {
+      k = i;
+      first = c0;
+      return true;
+    }
+    c0 += nc;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void sp_wgrad_os_k(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ dy, int64_t lddy,
+                                                     const int32_t* __restrict__ pairs, int64_t pair_ld, int x_side,
+                                                     const int32_t* __restrict__ num, int kvol, int cin, int cout,
+                                                     int n_bj, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float At[2][64 * kWgLd];
+  __shared__ __attribute__((aligned(16))) float Bt[2][64 * kWgLd];
+  int k, first;
+  if (!os_find_chunk(num, kvol, blockIdx.x, k, first)) return;  // uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int bi = blockIdx.y / n_bj, bj = blockIdx.y - bi * n_bj;
+  const int ci0 = bi * 64, co0 = bj * 64;
+  const int np = num[k];
+  const int p0 = (blockIdx.x - first) * kWgChunk;
+  const int p1 = p0 + kWgChunk < np ? p0 + kWgChunk : np;
+  const int32_t* pa = pairs + ((int64_t)k * 2 + x_side) * pair_ld;
+  const int32_t* pb = pairs + ((int64_t)k * 2 + (1 - x_side)) * pair_ld;
+  // staging role of this thread: pairs prow + 16 u (u < 4) of the stage, channels 4 ch4 .. + 3 of the block
+  const int ch4 = tid & 15, prow = tid >> 4;
+  int ca = ci0 + 4 * ch4, cb = co0 + 4 * ch4;
+  ca = ca < cin - 4 ? ca : cin - 4;      // channel tails: a clamped (finite) piece whose products are never stored
+  cb = cb < cout - 4 ? cb : cout - 4;
+  int ia[4], ib[4];
+  f32x4 ra[4], rb[4];
+  bool live[4];
+  auto load_idx = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int pp = p + prow + 16 * u;
+      pp = pp < p1 ? pp : p1 - 1;
+      ia[u] = pa[pp];
+      ib[u] = pb[pp];
+    }
+  };
+  auto load_rows = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      live[u] = p + prow + 16 * u < p1;
+      ra[u] = *(const f32x4*)(x + (int64_t)ia[u] * ldx + ca);
+      rb[u] = *(const f32x4*)(dy + (int64_t)ib[u] * lddy + cb);
+    }
+  };
+  // [channel row][pair]: 4-pair group g of row r sits at group g ^ ((r >> 4) & 3) (conflict-free writes and reads)
+  auto store_rows = [&](int buf) {
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pair = prow + 16 * u;
+      const int col = (((pair >> 2) ^ (ch4 >> 2)) << 2) + (pair & 3);   // rows 4 ch4 + e: (row >> 4) == ch4 >> 2
+      const f32x4 va = live[u] ? ra[u] : zero4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        At[buf][(4 * ch4 + e) * kWgLd + col] = va[e];
+        Bt[buf][(4 * ch4 + e) * kWgLd + col] = rb[u][e];
+      }
+    }
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;   // this wave's quadrant of the 64 x 64 block
+  load_idx(p0);
+  load_rows(p0);
+  load_idx(p0 + kWgStage);
+  store_rows(0);
+  __syncthreads();
+  int buf = 0;
+  for (int p = p0; p < p1; p += kWgStage) {
+    load_rows(p + kWgStage);        // rows of the next stage (their indices were requested a stage ago)
+    load_idx(p + 2 * kWgStage);     // indices of the stage after it
+    __builtin_amdgcn_sched_barrier(0);   // the loads are issued HERE, in front of the MFMAs that hide their latency
+    const float* a_img = At[buf];
+    const float* b_img = Bt[buf];
+#pragma unroll
+    for (int s = 0; s < kWgStage / 16; ++s) {
+      f32x4 af[2], bf[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ra_ = wi + 16 * h + l15, rb_ = wj + 16 * h + l15;
+        af[h] = *(const f32x4*)(a_img + ra_ * kWgLd + (((4 * s + kq) ^ ((ra_ >> 4) & 3)) << 2));
+        bf[h] = *(const f32x4*)(b_img + rb_ * kWgLd + (((4 * s + kq) ^ ((rb_ >> 4) & 3)) << 2));
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_rows(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D[i][j]: lane = (j = l15, rows i = 4 kq + r): dW[k][ci0 + wi + 16 a + 4 kq + r][co0 + wj + 16 b + l15]
+  float* dst = part + (int64_t)blockIdx.x * cin * cout;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int n = co0 + wj + 16 * b + l15;
+      if (n >= cout) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = ci0 + wi + 16 * a + 4 * kq + r;
+        if (c < cin) dst[(int64_t)c * cout + n] = acc[a][b][r];
+      }
+    }
+}
+
+// dw[k][e] = sum over the chunks of offset k, in chunk order
+__global__ __launch_bounds__(256) void sp_wgrad_os_reduce_k(const float* __restrict__ part, const int32_t* __restrict__ num,
+                                                            int kvol, int64_t per_k, float* __restrict__ dw) {
+  const int k = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per_k) return;
+  int first = 0;
+  for (int i = 0; i < k; ++i) first += (num[i] + kWgChunk - 1) / kWgChunk;
+  const int nc = (num[k] + kWgChunk - 1) / kWgChunk;
+  float s = 0.f;
+  for (int c = 0; c < nc; ++c) s += part[(int64_t)(first + c) * per_k + e];
+  dw[(int64_t)k * per_k + e] = s;
+}
+
+int64_t os_wgrad_chunks(int kvol, int64_t pair_ld, int64_t total_pairs) {
+  const int64_t total = (total_pairs >= 0 && total_pairs <= (int64_t)kvol * pair_ld) ? total_pairs : (int64_t)kvol * pair_ld;
+  return total / kWgChunk + kvol;
+}
+
 struct os_cfg {
   int nct, rb, n_cg, n_cc;
   int64_t n_tiles;
@@ -303,6 +470,36 @@ int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, 
   else
     SST_OS_LAUNCH(8, 1);
 #undef SST_OS_LAUNCH
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int64_t sst_spconv_wgrad_os_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout) {
+  return os_wgrad_chunks(kvol > 0 ? kvol : 1, pair_ld > 0 ? pair_ld : 1, total_pairs) * cin * cout * (int64_t)sizeof(float) + 256;
+}
+
+int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+                            int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
+                            int cout, float* d_dw, void* d_workspace, void* stream) {
+  if (kvol < 1 || cin < 1 || cout < 1 || ldx < cin || lddy < cout || pair_ld < 0 || (x_side != 0 && x_side != 1))
+    return SST_ERR_ARG;
+  if (!d_pairs || !d_num || !d_dw || !d_workspace) return SST_ERR_ARG;
+  if ((cin & 3) || (cout & 3) || (ldx & 3) || (lddy & 3) || (((uintptr_t)d_x | (uintptr_t)d_dy) & 15))
+    return SST_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per_k = (int64_t)cin * cout;
+  if (pair_ld == 0 || !d_x || !d_dy) {
+    SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * kvol * per_k, st));
+    return SST_OK;
+  }
+  const int64_t chunks = os_wgrad_chunks(kvol, pair_ld, total_pairs);
+  const int n_bi = (int)sst_div_up(cin, 64), n_bj = (int)sst_div_up(cout, 64);
+  if (kvol > 65535 || chunks > 0x7fffffff || n_bi * n_bj > 65535) return SST_ERR_UNSUPPORTED;
+  float* part = (float*)d_workspace;
+  hipLaunchKernelGGL(sp_wgrad_os_k, dim3((unsigned)chunks, (unsigned)(n_bi * n_bj)), dim3(256), 0, st, d_x, ldx, d_dy, lddy,
+                     d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, n_bj, part);
+  hipLaunchKernelGGL(sp_wgrad_os_reduce_k, dim3((unsigned)sst_div_up(per_k, 256), (unsigned)kvol), dim3(256), 0, st, part,
+                     d_num, kvol, per_k, d_dw);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -115,7 +115,24 @@ class Rulebook(object):
     The pair-list tensor carries its Rulebook as an attribute (it rides along wherever the reference passes
     ``indice_pairs`` around); the Rulebook refers back to the tensor only weakly, so the pair lists and the two dense
     maps (~4 K n int32 each) are released by reference counting as soon as the tensor is, not by the cycle collector."""
-    __slots__ = ('in2out', 'out2in', '_pairs_ref', 'num', 'n', 'm', 'kvol', 'density', 'total_pairs')
+    __slots__ = ('in2out', 'out2in', '_pairs_ref', 'num', 'n', 'm', 'kvol', '_total')
+
+    def known_total_pairs(self):
+        """the pair count if somebody has read it back already, else -1 (callers then size by the upper bound K x n)"""
+        return -1 if self._total is None else self._total
+
+    @property
+    def total_pairs(self):
+        """sum of the pairs over the offsets: ONE host read-back, on first use only - the convolutions themselves never
+        need it (the rulebook of a submanifold level is then built without any host synchronisation)"""
+        if self._total is None:
+            self._total = int(self.num.sum().item()) if self.n > 0 else 0
+        return self._total
+
+    @property
+    def density(self):
+        """populated share of the (offset, row) slots (picks the form of the first-generation kernels)"""
+        return self.total_pairs / max(1, self.kvol * max(self.n, self.m))
 
     @property
     def pairs(self):
@@ -143,9 +160,7 @@ def _finish_rulebook(in2out, kvol, n, m, dev):
                                              _lib.ptr(ws), _lib.stream_ptr()), 'sst_spconv_pair_lists_i32')
     rb._pairs_ref = weakref.ref(pairs)
     pairs._sst_rulebook = rb
-    # populated share of the (offset, row) slots, read once per rulebook: picks the kernel form of every convolution on it
-    rb.total_pairs = int(rb.num.sum().item()) if n > 0 else 0
-    rb.density = rb.total_pairs / max(1, kvol * max(n, m))
+    rb._total = None if n > 0 else 0
     return rb, pairs
 
 
@@ -177,8 +192,12 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
         rb, pairs = _finish_rulebook(in2out, kvol, 0, 0, dev)
         return indices, pairs, rb.num
     if subm:
-        plan = K.unique_rows(indices, [0, 0, 0, 0], [int(batch_size)] + out_shape, invalid_if_negative=0)
-        if plan.m != n:
+        # no host synchronisation on this path: the group count stays on the device.  SST_AMD_DEBUG=1 reads it back and
+        # checks that no voxel is listed twice (a SparseConvTensor never does; the reference does not check either)
+        debug = os.environ.get('SST_AMD_DEBUG', '0') == '1'
+        plan = K.unique_rows(indices, [0, 0, 0, 0], [int(batch_size)] + out_shape, invalid_if_negative=0,
+                             defer_count=not debug)
+        if debug and plan.m != n:
             raise RuntimeError('sst_amd.spconv: a SparseConvTensor must not contain a voxel twice')
         rc = lib.sst_spconv_subm_map_i32(_lib.ptr(indices), n, _i32(out_shape), _i32(ksize), _i32(dilation),
                                          _lib.ptr(plan.ukeys), _lib.ptr(plan.perm), _lib.ptr(in2out),
@@ -225,6 +244,7 @@ def _conv_kernel_choice():
 
 
 def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cfg=0):
+    # density: a number, None, or the Rulebook (its `density` costs a host read-back: only the legacy path asks for it)
     """Y[r] = sum_k X[mapping[k][r]] W[k]; weight3 is [K, cin, cout], or [K, cout, cin] with trans_w."""
     lib = _lib.load()
     x = x if x.stride(1) == 1 else x.contiguous()
@@ -247,6 +267,8 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cf
     # layer; they read W as [cin, cout] only
     if trans_w:
         weight3 = weight3.transpose(1, 2).contiguous()
+    if isinstance(density, Rulebook):
+        density = density.density
     form = 2 if (cout <= 64 or (density is not None and density < 0.2)) else 1
     rc = lib.sst_spconv_gather_gemm_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin,
                                         cout, 0, None, _lib.ptr(y), y.stride(0), form, _lib.stream_ptr())
@@ -258,11 +280,19 @@ def _wgrad(x, dy, rb, pairs, x_side, shape):
     lib = _lib.load()
     kvol, cin, cout = rb.kvol, x.size(1), dy.size(1)
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
-    ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, rb.n, rb.total_pairs, cin, cout), x.device)
     x = x if x.stride(1) == 1 else x.contiguous()
     dy = dy if dy.stride(1) == 1 else dy.contiguous()
-    rc = lib.sst_spconv_wgrad_f32(_lib.ptr(x), x.stride(0) if x.size(0) else cin, _lib.ptr(dy),
-                                  dy.stride(0) if dy.size(0) else cout, _lib.ptr(pairs), rb.n, rb.total_pairs, x_side,
+    ldx, lddy = (x.stride(0) if x.size(0) else cin), (dy.stride(0) if dy.size(0) else cout)
+    total = rb.known_total_pairs()     # -1 while nobody has read the count back: launch and workspace use the upper bound
+    if (_conv_kernel_choice() == 'os' and cin % 4 == 0 and cout % 4 == 0 and ldx % 4 == 0 and lddy % 4 == 0
+            and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0):
+        ws = _lib.workspace(lib.sst_spconv_wgrad_os_workspace_bytes(kvol, rb.n, total, cin, cout), x.device)
+        rc = lib.sst_spconv_wgrad_os_f32(_lib.ptr(x), ldx, _lib.ptr(dy), lddy, _lib.ptr(pairs), rb.n, total, x_side,
+                                         _lib.ptr(rb.num), kvol, cin, cout, _lib.ptr(dw), _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, 'sst_spconv_wgrad_os_f32')
+        return dw.view(shape)
+    ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, rb.n, total, cin, cout), x.device)
+    rc = lib.sst_spconv_wgrad_f32(_lib.ptr(x), ldx, _lib.ptr(dy), lddy, _lib.ptr(pairs), rb.n, total, x_side,
                                   _lib.ptr(rb.num), kvol, cin, cout, _lib.ptr(dw), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, 'sst_spconv_wgrad_f32')
     return dw.view(shape)
@@ -281,8 +311,8 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     rb = rulebook_of(indice_pairs, indice_pair_num, features.size(0) if inverse else num_activate_out)
     w3 = filters.reshape(-1, filters.shape[-2], filters.shape[-1])
     if inverse:
-        return _gather_gemm(features, rb.in2out, rb.n, w3, False, w3.size(2), rb.density)
-    return _gather_gemm(features, rb.out2in, rb.m, w3, False, w3.size(2), rb.density)
+        return _gather_gemm(features, rb.in2out, rb.n, w3, False, w3.size(2), rb)
+    return _gather_gemm(features, rb.out2in, rb.m, w3, False, w3.size(2), rb)
 
 
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
@@ -293,10 +323,10 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     out_bp = out_bp.contiguous()
     # the data gradient is the same contraction with W[k]^T: the forward weights are read with the roles swapped
     if inverse:
-        input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3, True, w3.size(1), rb.density)
+        input_bp = _gather_gemm(out_bp, rb.out2in, rb.m, w3, True, w3.size(1), rb)
         filters_bp = _wgrad(features, out_bp, rb, indice_pairs, 1, filters.shape)
     else:
-        input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3, True, w3.size(1), rb.density)
+        input_bp = _gather_gemm(out_bp, rb.in2out, rb.n, w3, True, w3.size(1), rb)
         filters_bp = _wgrad(features, out_bp, rb, indice_pairs, 0, filters.shape)
     return input_bp, filters_bp
 

@@ -145,8 +145,9 @@ def test_inverse_conv_matches_oracle_and_modules_chain():
     assert set(t.indice_dict) == {'subm1', 'down1', 'subm2'}
 
 
-def test_spconv_edge_cases():
+def test_spconv_edge_cases(monkeypatch):
     from sst_amd import spconv
+    monkeypatch.setenv('SST_AMD_DEBUG', '1')     # the duplicate-voxel check costs a host read-back: debug mode only
     shape, batch = [5, 8, 8], 1
     conv = spconv.SubMConv3d(4, 8, 3, padding=1, indice_key='k').to(DEV)
     empty = spconv.SparseConvTensor(torch.zeros(0, 4, device=DEV), torch.zeros(0, 4, dtype=torch.int32, device=DEV),

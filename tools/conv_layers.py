@@ -62,12 +62,12 @@ def main():
         model(clouds)
     torch.cuda.synchronize()
     tot = dict(fl=0.0)
-    cols = ('f_os', 'f_old', 'd_os', 'd_old', 'wg')
+    cols = ('f_os', 'f_old', 'd_os', 'd_old', 'wg', 'wg_old')
     for c in cols:
         tot[c] = 0.0
     print(f'{what}: {len(layers)} sparse convolutions, {n_pts} points')
     print(f'{"layer":44s} {"kind":4s} {"n_in":>7s} {"n_out":>7s} {"cin":>4s} {"cout":>4s} {"pairs":>8s} {"dens":>5s} | '
-          f'{"fwd os":>8s} {"TF":>5s} {"fwd old":>8s} | {"dgrad os":>8s} {"dgrad old":>9s} | {"wgrad":>7s} {"TF":>5s}')
+          f'{"fwd os":>8s} {"TF":>5s} {"fwd old":>8s} | {"dgrad os":>8s} {"dgrad old":>9s} | {"wgrad":>7s} {"TF":>5s} {"wg old":>7s}')
     for L in layers:
         mod, x, rb = L['mod'], L['x'], L['rb']
         w3 = mod.weight.detach().reshape(-1, mod.in_channels, mod.out_channels)
@@ -82,18 +82,18 @@ def main():
             os.environ['SST_SPCONV_KERNEL'] = kern
             res['f_' + tag] = timeit(lambda: SP._gather_gemm(x, fmap, frows, w3, False, cout, rb.density))
             res['d_' + tag] = timeit(lambda: SP._gather_gemm(gy, dmap, drows, w3, True, cin, rb.density))
+            res['wg' + ('' if tag == 'os' else '_old')] = timeit(lambda: SP._wgrad(x, gy, rb, L['pairs'], x_side, mod.weight.shape))
         os.environ['SST_SPCONV_KERNEL'] = 'os'
-        res['wg'] = timeit(lambda: SP._wgrad(x, gy, rb, L['pairs'], x_side, mod.weight.shape))
         fl = 2.0 * rb.total_pairs * cin * cout
         tot['fl'] += fl
         for c in cols:
             tot[c] += res[c]
         print(f'{names[mod][-44:]:44s} {L["kind"]:4s} {x.size(0):7d} {frows:7d} {cin:4d} {cout:4d} {rb.total_pairs:8d} '
               f'{rb.density:5.2f} | {res["f_os"] * 1e3:8.0f} {fl / res["f_os"] / 1e9:5.1f} {res["f_old"] * 1e3:8.0f} | '
-              f'{res["d_os"] * 1e3:8.0f} {res["d_old"] * 1e3:9.0f} | {res["wg"] * 1e3:7.0f} {fl / res["wg"] / 1e9:5.1f}')
+              f'{res["d_os"] * 1e3:8.0f} {res["d_old"] * 1e3:9.0f} | {res["wg"] * 1e3:7.0f} {fl / res["wg"] / 1e9:5.1f} {res["wg_old"] * 1e3:7.0f}')
     print(f'total: {tot["fl"] / 1e9:.1f} GFLOP per pass; forward os {tot["f_os"]:.2f} ms = {tot["fl"] / tot["f_os"] / 1e9:.1f} TF/s '
           f'({100 * tot["fl"] / tot["f_os"] / 1e9 / PEAK:.1f} % of {PEAK}), old {tot["f_old"]:.2f} ms; dgrad os {tot["d_os"]:.2f} ms, '
-          f'old {tot["d_old"]:.2f} ms; wgrad {tot["wg"]:.2f} ms = {tot["fl"] / tot["wg"] / 1e9:.1f} TF/s')
+          f'old {tot["d_old"]:.2f} ms; wgrad {tot["wg"]:.2f} ms = {tot["fl"] / tot["wg"] / 1e9:.1f} TF/s, old {tot["wg_old"]:.2f} ms')
 
 
 if __name__ == '__main__':
