@@ -378,7 +378,8 @@ def _conv_roofline(model, clouds):
         seg = {'bound': 'hbm', 'kernel': f'seg_reduce_fwd_* ({len(timed)} segmented reductions of one forward pass; HIP events bound '
                                        'to each launch)',
                'achieved': round(by / (ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-               'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'algorithmic_bytes': by, 'ms': round(ms, 3)}
+               'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'algorithmic_bytes': by, 'ms': round(ms, 3),
+               'launches_mb_us': [[round(b / 1e6, 2), round(t * 1e3, 1)] for t, b in timed]}
     return conv, seg
 
 

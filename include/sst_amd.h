@@ -115,6 +115,18 @@ int sst_unpack_keys(const uint64_t* d_ukeys, int64_t m, int ncols, const int64_t
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream);
+/* sst_segment_reduce_long_f32: the same reduction (all three modes, the arg-max tie rule) for groupings whose groups are
+ * long and uneven (FSD's clusters, voxel_encoder.py:696-764 / backbones/sir.py:67-88: torch_scatter.scatter_max / scatter over
+ * cluster ids): work is cut into tiles of sorted positions whatever group they belong to, groups inside a tile are written
+ * directly, a group that crosses tiles is merged by the last of its tiles to arrive (one atomic ticket per crossing group and
+ * tile; deterministic merge order; csrc/scatter.hip).  d_inverse [n] int32 = group of every point (+ inverse_shift; negative =
+ * not reduced); every group with at least one point is written, groups without points are NOT.  d_scratch:
+ * sst_segment_long_scratch_bytes(n, m, c) bytes, 256-byte aligned, its first 4 m bytes ZEROED ONCE by the caller; the kernel
+ * leaves them zeroed (reusable by every later call on the same grouping without a fill).  c <= 256. */
+int64_t sst_segment_long_scratch_bytes(int64_t n, int64_t m, int c);
+int sst_segment_reduce_long_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm, const int32_t* d_inverse,
+                                int inverse_shift, const int32_t* d_offsets, int64_t m, int mode, void* d_scratch,
+                                float* d_out, int32_t* d_argmax, void* stream);
 /* sst_segment_reduce_profile_next(start, stop): one-shot hipEvent_t pair bound to the NEXT forward launch of this thread
  * (kernel start / stop; measurement hook of bench.py's FSD workloads, as sst_sra_attn_profile_next_fwd). */
 int sst_segment_reduce_profile_next(void* start, void* stop);

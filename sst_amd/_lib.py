@@ -57,6 +57,9 @@ _SIGNATURES = {
     'sst_unpack_keys': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr]),
     'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                            c_ptr, c_ptr]),
+    'sst_segment_long_scratch_bytes': (c_i64, [c_i64, c_i64, c_i32]),
+    'sst_segment_reduce_long_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr,
+                                            c_ptr]),
     'sst_segment_reduce_profile_next': (c_i32, [c_ptr, c_ptr]),
     'sst_segment_reduce_bwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                                            c_ptr, c_ptr, c_ptr]),

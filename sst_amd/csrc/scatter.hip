@@ -11,6 +11,7 @@
 // exactly one thread walking its group's CSR range: no atomics, deterministic, and a wave reads 64
 // consecutive channels of one row (coalesced 256 B) — HBM-bound: (4C+4) B/point + 4C B/group.
 #include <math.h>
+#include <stdlib.h>
 #include <hip/hip_ext.h>
 #include "common.h"
 
@@ -188,6 +189,262 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_block_k(const float* __res
       }
       __syncthreads();
     }
+  }
+}
+
+// Reduction over LONG, UNEVEN groups (FSD's clusters / RoI point sets: tens to thousands of points per group, Zipf-like;
+// torch_scatter.scatter_max / scatter(mean) over cluster ids, voxel_encoder.py:696-764, single_stage_fsd.py:469), balanced
+// and in ONE launch.  The per-group kernels above walk a 3 000-point cluster with one workgroup (16 us for 9 MB) or, for
+// the 3-channel centroid means, with three threads (25 us for 0.2 MB).  Here the unit of work is a TILE of sorted positions,
+// whatever groups they belong to:
+//   * a workgroup = `lanes` row lanes x `cv` channel vectors (float4, or scalars when c % 4 != 0); a row lane walks 8
+//     consecutive sorted rows (all loads in flight), reducing runs of equal group id;
+//   * a run that begins and ends strictly inside a lane's span is a whole group: written straight to the output;
+//   * the first and the last run of every lane meet in LDS, where lane 0's threads merge them in order: groups that are whole
+//     inside the tile are written out; a run that began before the tile (record 0) or continues behind it (record 1) goes
+//     to a global record;
+//   * a group that crosses tiles is finished by the LAST of its tiles to arrive (one atomic ticket per crossing group and
+//     tile, in a per-grouping counter array that is zeroed once and cleans itself): that workgroup merges the group's records
+//     with all its threads, in a fixed order.
+// Deterministic: every merge order is fixed, MAX carries (value, row) and prefers the smaller row on ties, like
+// max_reduce_traceback_scatter_idx_kernel (scatter_points_cuda.cu:135-160).  No float atomics, nothing spins.  (A first
+// version with one 64-bit atomic maximum per partial result was 2 x SLOWER than the unbalanced kernels: device-scope
+// atomics cross the XCDs.)
+constexpr int kSegSpan = 8;       // rows per row lane
+constexpr int kSegNone = -3;      // "no record" (group ids are >= -1: -1 = rows of a discarded group)
+
+struct seg_rec {                  // partial result of a run, one channel vector
+  float4 v;
+  int4 a;
+};
+
+// Records travel between workgroups (possibly on different XCDs, whose L2s are not coherent with each other) as
+// device-scope atomic READ-MODIFY-WRITE operations, word by word: an RMW is always performed at the coherence point of its
+// scope, whatever the caches hold (the relaxed atomic load / store builtins compiled to one device-scope access followed by
+// seven plain ones here, which is not enough).  A device-scope FENCE instead (__threadfence) writes back the whole L2 of
+// the XCD: with one per workgroup the launch serialised (measured: 50 us for 10 MB).
+__device__ __forceinline__ void seg_rec_store(seg_rec* p, const seg_rec& r) {
+  int* d = (int*)p;
+  const int w[8] = {__float_as_int(r.v.x), __float_as_int(r.v.y), __float_as_int(r.v.z), __float_as_int(r.v.w),
+                    r.a.x, r.a.y, r.a.z, r.a.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) atomicExch(d + i, w[i]);
+}
+__device__ __forceinline__ seg_rec seg_rec_load(const seg_rec* p) {
+  int* d = (int*)p;
+  int w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = atomicOr(d + i, 0);
+  seg_rec r;
+  r.v = make_float4(__int_as_float(w[0]), __int_as_float(w[1]), __int_as_float(w[2]), __int_as_float(w[3]));
+  r.a = make_int4(w[4], w[5], w[6], w[7]);
+  return r;
+}
+
+// (v, a) <- merge((v, a), (w, b)); MAX: larger value, on ties the smaller row index (order-independent)
+__device__ __forceinline__ void seg_merge(int mode, float4& v, int4& a, const float4& w, const int4& b) {
+  if (mode == SST_REDUCE_MAX) {
+    if (w.x > v.x || (w.x == v.x && b.x < a.x)) v.x = w.x, a.x = b.x;
+    if (w.y > v.y || (w.y == v.y && b.y < a.y)) v.y = w.y, a.y = b.y;
+    if (w.z > v.z || (w.z == v.z && b.z < a.z)) v.z = w.z, a.z = b.z;
+    if (w.w > v.w || (w.w == v.w && b.w < a.w)) v.w = w.w, a.w = b.w;
+  } else {
+    v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+    a.x += b.x;                   // SUM / MEAN: a.x counts the rows merged so far
+  }
+}
+
+template <int V>                  // channel vector width: 4 (16-byte accesses) or 1
+__device__ __forceinline__ void seg_write(int mode, float* __restrict__ out, int32_t* __restrict__ argmax, int c, int64_t g,
+                                          int ch, float4 v, int4 a) {
+  if (mode == SST_REDUCE_MEAN) {
+    const float cnt = (float)a.x;   // rows of the group (every row was merged exactly once)
+    v.x = v.x / cnt, v.y = v.y / cnt, v.z = v.z / cnt, v.w = v.w / cnt;
+  }
+  if (V == 4) {
+    *(float4*)(out + g * c + ch) = v;
+    if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + ch) = a;
+  } else {
+    out[g * c + ch] = v.x;
+    if (mode == SST_REDUCE_MAX && argmax != nullptr) argmax[g * c + ch] = a.x;
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void seg_tiles_k(const float* __restrict__ feats, int c, int cv, int lanes,
+                                                   const uint32_t* __restrict__ perm,
+                                                   const int32_t* __restrict__ inverse, int inverse_shift,
+                                                   const int32_t* __restrict__ offsets, int32_t n, int mode,
+                                                   float* __restrict__ out, int32_t* __restrict__ argmax,
+                                                   seg_rec* __restrict__ recs, int32_t* __restrict__ counters, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char seg_smem[];
+  seg_rec* lrec = (seg_rec*)seg_smem;                               // [lanes][2][cv]
+  int* lgrp = (int*)(seg_smem + sizeof(seg_rec) * lanes * 2 * cv);  // [lanes][2]
+  __shared__ int tile_grp[2];   // groups of the tile's two boundary records (kSegNone: none)
+  __shared__ int finish[3];     // this workgroup finishes the group: flag, first tile, last tile
+  const int tid = threadIdx.x;
+  const int q = tid % cv, lane = tid / cv;
+  const int ch = V * q;
+  const int tile_rows = lanes * kSegSpan;
+  const int64_t t0 = (int64_t)blockIdx.x * tile_rows;
+  const int64_t t1 = t0 + tile_rows < n ? t0 + tile_rows : n;
+  const float4 ident = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int4 noarg = mode == SST_REDUCE_MAX ? make_int4(n, n, n, n) : make_int4(0, 0, 0, 0);
+  __shared__ int edge_grp[2];   // groups of the sorted rows right before / right behind the tile (kSegNone: none)
+  if (tid < 2) {
+    tile_grp[tid] = kSegNone;
+    const int64_t pos = tid == 0 ? t0 - 1 : t1;
+    edge_grp[tid] = (pos >= 0 && pos < n) ? inverse[perm[pos]] + inverse_shift : kSegNone;
+  }
+  if (lane < lanes) {
+    const int64_t s0 = t0 + (int64_t)lane * kSegSpan;
+    const int cnt = s0 >= n ? 0 : (int)(n - s0 < kSegSpan ? n - s0 : kSegSpan);
+    uint32_t rows[kSegSpan];
+    int grp[kSegSpan];
+    float4 x[kSegSpan];
+#pragma unroll
+    for (int i = 0; i < kSegSpan; ++i) rows[i] = cnt > 0 ? perm[s0 + (i < cnt ? i : cnt - 1)] : 0u;
+#pragma unroll
+    for (int i = 0; i < kSegSpan; ++i) {
+      grp[i] = cnt > 0 ? inverse[rows[i]] + inverse_shift : kSegNone;
+      x[i] = ident;
+      if (cnt > 0) {
+        if (V == 4)
+          x[i] = *(const float4*)(feats + (int64_t)rows[i] * c + ch);
+        else
+          x[i].x = feats[(int64_t)rows[i] * c + ch];
+      }
+    }
+    // runs of equal group id inside the span: run 0 -> record 0, the last run (if there is a second one) -> record 1,
+    // the runs between them are whole groups
+    int cur = grp[0], n_closed = 0, first_grp = kSegNone;
+    float4 acc = ident;
+    int4 arg = noarg;
+    seg_rec first;
+    first.v = ident, first.a = noarg;
+#pragma unroll
+    for (int i = 0; i < kSegSpan; ++i) {
+      if (i < cnt) {
+        if (grp[i] != cur) {   // the run `cur` just ended
+          if (n_closed == 0) {
+            first.v = acc, first.a = arg, first_grp = cur;
+          } else if (cur >= 0) {
+            seg_write<V>(mode, out, argmax, c, cur, ch, acc, arg);
+          }
+          ++n_closed;
+          cur = grp[i];
+          acc = ident;
+          arg = noarg;
+        }
+        const int r = mode == SST_REDUCE_MAX ? (int)rows[i] : 1;
+        seg_merge(mode, acc, arg, x[i], make_int4(r, r, r, r));
+      }
+    }
+    seg_rec last;
+    last.v = acc, last.a = arg;
+    int last_grp = cur;
+    if (cnt == 0) {
+      first_grp = last_grp = kSegNone;
+    } else if (n_closed == 0) {   // the span is one run: its only record is record 0
+      first = last;
+      first_grp = cur;
+      last_grp = kSegNone;
+    }
+    lrec[(lane * 2 + 0) * cv + q] = first;
+    lrec[(lane * 2 + 1) * cv + q] = last;
+    if (q == 0) {
+      lgrp[lane * 2 + 0] = first_grp;
+      lgrp[lane * 2 + 1] = last_grp;
+    }
+  }
+  __syncthreads();
+  if (dbg == 1) return;
+  // ---- lane 0's threads merge the lane records of their channel vector in row order ----
+  if (lane == 0) {
+    int cur = kSegNone;
+    float4 acc = ident;
+    int4 arg = noarg;
+    bool first_run = true;
+    const int before = edge_grp[0], behind = edge_grp[1];
+    auto close_run = [&](bool last_run) {
+      const bool was_first = first_run;
+      first_run = false;
+      if (cur < 0) return;                 // nothing yet, or rows of a discarded group
+      // the groups are contiguous in sorted order: a run goes on outside the tile iff the neighbouring row has its id
+      const bool starts_here = !(was_first && cur == before), ends_here = !(last_run && cur == behind);
+      if (starts_here && ends_here) {
+        seg_write<V>(mode, out, argmax, c, cur, ch, acc, arg);
+      } else {
+        const int slot = starts_here ? 1 : 0;    // began before the tile: record 0; begins here and goes on: record 1
+        seg_rec r;
+        r.v = acc, r.a = arg;
+        seg_rec_store(recs + ((int64_t)blockIdx.x * 2 + slot) * cv + q, r);
+        if (q == 0) tile_grp[slot] = cur;
+      }
+    };
+    for (int l = 0; l < lanes; ++l) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = lgrp[l * 2 + h];
+        if (g == kSegNone) continue;
+        const seg_rec r = lrec[(l * 2 + h) * cv + q];
+        if (cur == kSegNone) {
+          cur = g;
+          acc = r.v;
+          arg = r.a;
+        } else if (g != cur) {
+          close_run(false);
+          cur = g;
+          acc = r.v;
+          arg = r.a;
+        } else {
+          seg_merge(mode, acc, arg, r.v, r.a);
+        }
+      }
+    }
+    if (cur != kSegNone) close_run(true);
+  }
+  // ---- groups that cross tiles: the last of their tiles to arrive merges their records ----
+  if (dbg == 2) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the record stores have completed (s_waitcnt) ...
+  __syncthreads();                                         // ... in every thread, before the tickets are taken
+#pragma unroll 1
+  for (int slot = 0; slot < 2; ++slot) {
+    const int g = tile_grp[slot];
+    if (g < 0) continue;   // uniform
+    if (tid == 0) {
+      const int ta = offsets[g] / tile_rows, tb = (offsets[g + 1] - 1) / tile_rows;
+      const int before = atomicAdd(counters + g, 1);
+      const int fin = before == tb - ta;       // tb - ta + 1 tiles hold a record of g
+      if (fin) atomicExch(counters + g, 0);    // every other tile of g has already taken its ticket
+      finish[0] = fin, finish[1] = ta, finish[2] = tb;
+    }
+    __syncthreads();
+    if (finish[0]) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int ta = finish[1], tb = finish[2];
+      float4 acc = ident;
+      int4 arg = noarg;
+      if (lane < lanes) {
+        for (int t = ta + lane; t <= tb; t += lanes) {
+          const seg_rec r = seg_rec_load(recs + ((int64_t)t * 2 + (t == ta ? 1 : 0)) * cv + q);
+          seg_merge(mode, acc, arg, r.v, r.a);
+        }
+        seg_rec r;
+        r.v = acc, r.a = arg;
+        lrec[lane * cv + q] = r;
+      }
+      __syncthreads();
+      if (lane == 0) {
+        for (int l = 1; l < lanes; ++l) {
+          const seg_rec r = lrec[l * cv + q];
+          seg_merge(mode, acc, arg, r.v, r.a);
+        }
+        seg_write<V>(mode, out, argmax, c, g, ch, acc, arg);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -514,6 +771,63 @@ int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uin
   else
     hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
                        d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+// geometry of seg_tiles_k for a width: channel vectors, row lanes per workgroup
+static void seg_tiles_shape(int c, int* v, int* cv, int* lanes) {
+  *v = (c % 4 == 0) ? 4 : 1;
+  *cv = c / *v;
+  *lanes = 256 / *cv;
+  if (*lanes > 32) *lanes = 32;      // <= 256 rows per tile: enough tiles for a small input to spread over the CUs
+}
+
+int64_t sst_segment_long_scratch_bytes(int64_t n, int64_t m, int c) {
+  if (n < 1 || m < 1 || c < 1 || c > 256) return 256;
+  int v, cv, lanes;
+  seg_tiles_shape(c, &v, &cv, &lanes);
+  const int64_t tiles = sst_div_up(n, (int64_t)lanes * kSegSpan);
+  return sst_align_up(m * 4, 256) + sst_align_up(tiles * 2 * cv * (int64_t)sizeof(seg_rec), 256);
+}
+
+int sst_segment_reduce_long_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm, const int32_t* d_inverse,
+                                int inverse_shift, const int32_t* d_offsets, int64_t m, int mode, void* d_scratch,
+                                float* d_out, int32_t* d_argmax, void* stream) {
+  if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
+  if (n == 0 || m == 0) return SST_OK;
+  if (!d_feats || !d_perm || !d_inverse || !d_offsets || !d_scratch || !d_out) return SST_ERR_ARG;
+  if (c > 256 || n > 0x7fffffff || (((uintptr_t)d_scratch) & 255)) return SST_ERR_UNSUPPORTED;
+  int v, cv, lanes;
+  seg_tiles_shape(c, &v, &cv, &lanes);
+  if (256 % cv != 0 && cv * lanes > 256) return SST_ERR_UNSUPPORTED;
+  if (v == 4 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15)) return SST_ERR_UNSUPPORTED;
+  const int64_t tiles = sst_div_up(n, (int64_t)lanes * kSegSpan);
+  if (tiles > 0x3fffffff) return SST_ERR_UNSUPPORTED;
+  int32_t* counters = (int32_t*)d_scratch;                   // [m], zeroed once by the caller, left zeroed
+  seg_rec* recs = (seg_rec*)((char*)d_scratch + sst_align_up(m * 4, 256));
+  const size_t lds = sizeof(seg_rec) * lanes * 2 * cv + sizeof(int) * lanes * 2;
+  hipEvent_t e0 = g_seg_ev[0], e1 = g_seg_ev[1];
+  g_seg_ev[0] = g_seg_ev[1] = nullptr;
+  const bool timed = e0 != nullptr && e1 != nullptr;
+  const char* dbg_env = getenv("SST_SEG_TILES_DEBUG_PHASE");     // developer switch: stop after phase 1 / 2 (timing only)
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+#define SST_SEG_LAUNCH(V)                                                                                                \
+  do {                                                                                                                   \
+    if (timed)                                                                                                           \
+      hipExtLaunchKernelGGL(seg_tiles_k<V>, dim3((unsigned)tiles), dim3(256), lds, (hipStream_t)stream, e0, e1, 0, d_feats, \
+                            c, cv, lanes, d_perm, d_inverse, inverse_shift, d_offsets, (int32_t)n, mode, d_out, d_argmax,  \
+                            recs, counters, dbg);                                                                        \
+    else                                                                                                                 \
+      hipLaunchKernelGGL(seg_tiles_k<V>, dim3((unsigned)tiles), dim3(256), lds, (hipStream_t)stream, d_feats, c, cv, lanes, \
+                         d_perm, d_inverse, inverse_shift, d_offsets, (int32_t)n, mode, d_out, d_argmax, recs, counters,  \
+                         dbg);                                                                                           \
+  } while (0)
+  if (v == 4)
+    SST_SEG_LAUNCH(4);
+  else
+    SST_SEG_LAUNCH(1);
+#undef SST_SEG_LAUNCH
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

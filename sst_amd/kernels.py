@@ -6,6 +6,8 @@ output tensors and (where the reference API itself needs a host-side size) one `
 """
 import math
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -79,7 +81,8 @@ def sort_pairs_u64(keys, key_bits):
 
 class UniquePlan(object):
     """Result of unique_rows: the grouping of N rows into M sorted-unique rows (all device int32)."""
-    __slots__ = ('n', 'm', 'num', 'perm', 'inverse', 'offsets', 'ukeys', 'mins', 'extents', 'ncols', 'has_invalid_group')
+    __slots__ = ('n', 'm', 'num', 'perm', 'inverse', 'offsets', 'ukeys', 'mins', 'extents', 'ncols', 'has_invalid_group',
+                 'scratch')
 
     def counts(self):
         return self.offsets[1:self.m + 1] - self.offsets[:self.m]
@@ -167,6 +170,25 @@ def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=
     return out, argmax
 
 
+def _long_group_scratch(plan, n, m, c, dev):
+    """counters zeroed once per (grouping, width); seg_tiles_k leaves them zeroed (csrc/scatter.hip)"""
+    cache = getattr(plan, 'scratch', None)
+    if cache is None:
+        cache = plan.scratch = {}
+    buf = cache.get((n, m, c))
+    if buf is None:
+        buf = cache[(n, m, c)] = torch.zeros(int(_lib.load().sst_segment_long_scratch_bytes(n, m, c)), dtype=torch.uint8,
+                                             device=dev)
+    return buf
+
+
+def _long_group_applies(n, m, c, inverse, group_index, m_limit):
+    """few, long, uneven groups (FSD's clusters, RoI point sets): n >= 8 m"""
+    cv = c // 4 if c % 4 == 0 else c
+    return (group_index is None and m_limit is None and inverse is not None and m > 0 and n >= 8 * m and c <= 256
+            and (256 % cv == 0 or cv * min(32, 256 // cv) <= 256) and os.environ.get('SST_SEG_LONG', '1') != '0')
+
+
 class SegmentReduce(Function):
     """out[g] = reduce(feats[perm[offsets[g]:offsets[g+1]]]) for groups first..first+m-1 of a plan.
 
@@ -175,12 +197,23 @@ class SegmentReduce(Function):
     """
 
     @staticmethod
-    def forward(ctx, feats, perm, offsets, inverse, m, mode, inverse_shift, group_index=None, m_limit=None):
+    def forward(ctx, feats, perm, offsets, inverse, m, mode, inverse_shift, group_index=None, m_limit=None, plan=None):
         if feats.dtype != torch.float32:
             raise RuntimeError('sst_amd: features must be float32')
         feats = feats.contiguous()
         _lib.require_cuda(feats, perm, offsets)
-        out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2, group_index, m_limit)
+        n, c = feats.shape
+        if plan is not None and _long_group_applies(n, m, c, inverse, group_index, m_limit) \
+                and (c % 4 != 0 or feats.data_ptr() % 16 == 0):
+            out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
+            argmax = torch.empty((m, c), dtype=torch.int32, device=feats.device) if mode == 2 else None
+            scratch = _long_group_scratch(plan, n, m, c, feats.device)
+            rc = _lib.load().sst_segment_reduce_long_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(inverse),
+                                                         int(inverse_shift), _lib.ptr(offsets), m, mode, _lib.ptr(scratch),
+                                                         _lib.ptr(out), _lib.ptr(argmax), _lib.stream_ptr())
+            _lib.check(rc, 'sst_segment_reduce_long_f32')
+        else:
+            out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2, group_index, m_limit)
         ctx.mode, ctx.m, ctx.shift = mode, m, inverse_shift
         ctx.shape = feats.shape
         ctx.has_gidx = group_index is not None
@@ -200,7 +233,7 @@ class SegmentReduce(Function):
             _lib.ptr(gidx) if ctx.has_gidx else None, _lib.ptr(argmax) if ctx.mode == 2 else None, n, ctx.mode,
             _lib.ptr(grad_feats), _lib.ptr(ctx.m_limit), _lib.stream_ptr())
         _lib.check(rc, 'sst_segment_reduce_bwd_f32')
-        return grad_feats, None, None, None, None, None, None, None, None
+        return grad_feats, None, None, None, None, None, None, None, None, None
 
 
 def segment_reduce(feats, plan, mode, first=0, group_index=None, inverse=None, m_limit=None):
@@ -214,7 +247,7 @@ def segment_reduce(feats, plan, mode, first=0, group_index=None, inverse=None, m
                                    group_index, m_limit)
     m = plan.m - first
     offsets = plan.offsets[first:]
-    return SegmentReduce.apply(feats, plan.perm, offsets, plan.inverse, m, REDUCE[mode], -first)
+    return SegmentReduce.apply(feats, plan.perm, offsets, plan.inverse, m, REDUCE[mode], -first, None, None, plan)
 
 
 def segment_argmax(feats, plan, first=0):

@@ -82,3 +82,45 @@ def test_make_continuous_inds():
     ids = torch.tensor([70, 3, 3, 1000, 70, 5], dtype=torch.long)
     out = sst_amd.make_continuous_inds(ids.to(_dev()))
     assert out.cpu().tolist() == [2, 0, 0, 3, 2, 1]
+
+
+@pytest.mark.parametrize('c', [128, 32, 64, 16, 3, 5, 256])
+@pytest.mark.parametrize('n,k,first', [(18443, 1554, 0), (50000, 1554, 0), (4097, 60, 0), (5000, 333, 1), (100, 3, 0), (9, 1, 0)])
+def test_long_group_reduce_equals_the_csr_walk(n, k, first, c, monkeypatch):
+    """FSD-like groupings (Zipf cluster sizes, thousands of points in the largest): the tile kernel (seg_tiles_k: groups
+    that cross tiles are merged by the last of their tiles to arrive) against the per-group CSR kernels.  MAX: values AND
+    arg-max rows bit-identical (ties -> smallest row index), gradients through the recorded arg-max; repeated calls reuse the
+    self-cleaning counters; SUM / MEAN against float64."""
+    from sst_amd import kernels as K
+    rng = np.random.default_rng(n + c)
+    w = 1.0 / np.arange(1, k + 1) ** 1.1
+    ids = rng.choice(k, size=n, p=w / w.sum())
+    ids[:k] = np.arange(k)                                  # every group has a point
+    coors = torch.from_numpy(np.stack([np.zeros(n, np.int64), ids // 7, ids % 7], 1)).to(_dev())
+    plan = K.unique_rows(coors)
+    assert plan.m == k and n >= 8 * (k - first)
+    feats = torch.from_numpy(rng.integers(-3, 4, size=(n, c)).astype(np.float32)).to(_dev())   # many exact ties
+    feats[rng.integers(0, n, 50)] = 0.0
+    feats[rng.integers(0, n, 50)] = -0.0
+    outs = []
+    for flag in ('1', '0', '1'):
+        monkeypatch.setenv('SST_SEG_LONG', flag)
+        x = feats.clone().requires_grad_(True)
+        y = K.segment_reduce(x, plan, 'max', first=first)
+        y.backward(torch.ones_like(y) * torch.arange(1, c + 1, device=_dev()))
+        outs.append((y.detach(), x.grad.clone()))
+    (y_new, g_new), (y_old, g_old), (y_again, g_again) = outs
+    assert torch.equal(y_new, y_old) and torch.equal(g_new, g_old)          # same values, same arg-max rows
+    assert torch.equal(y_new, y_again) and torch.equal(g_new, g_again)      # the counters cleaned themselves
+    inv = plan.inverse.long()[:, None].expand(n, c)
+    ref = torch.full((k, c), float('-inf'), device=_dev()).scatter_reduce(0, inv, feats, reduce='amax')
+    assert torch.equal(y_new, ref[first:])
+    monkeypatch.setenv('SST_SEG_LONG', '1')
+    real = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(_dev())
+    want = torch.zeros((k, c), dtype=torch.float64, device=_dev()).index_add_(0, plan.inverse.long(), real.double())
+    got_sum = K.segment_reduce(real, plan, 'sum', first=first)
+    got_mean = K.segment_reduce(real, plan, 'mean', first=first)
+    cnt = torch.bincount(plan.inverse.long(), minlength=k).double()[:, None]
+    assert float((got_sum.double() - want[first:]).abs().max()) < 1e-3
+    assert float((got_mean.double() - (want / cnt)[first:]).abs().max()) < 1e-5
+    assert torch.equal(got_sum, K.segment_reduce(real, plan, 'sum', first=first))     # deterministic
