@@ -604,6 +604,25 @@ int sst_spconv_candidates_i32(const int32_t* d_coors, int64_t n, const int32_t* 
                               const int32_t* ksize, const int32_t* stride, const int32_t* padding,
                               const int32_t* dilation, int transpose, int32_t* d_rows, void* stream);
 int sst_spconv_inverse_to_map_i32(const int32_t* d_inverse, int64_t total, int32_t* d_in2out, void* stream);
+/*   Dense-grid builders of the SAME rulebooks (getIndicePair<3>, spconv_ops.h:26-150; identical numbering): a cell -> row
+ *     grid over batch x shape replaces the sort / binary search when the grid fits (cells <= 2^31).
+ *     sst_spconv_grid_subm_i32: d_grid [batch * prod(shape)] int32 scratch -> in2out AND out2in [K, n].
+ *     sst_spconv_grid_conv_count_i32: regular / transposed convolution, pass 1: flags the output cells, scans them,
+ *     *d_num_out = number of output voxels (device int32: the caller reads it back to size pass 2's outputs);
+ *     workspace sst_spconv_grid_conv_workspace_bytes(batch * prod(out_shape)), handed on to
+ *     sst_spconv_grid_conv_maps_i32: d_outids [m, 4] (b, z, y, x) ascending, in2out [K, n], out2in [K, m]. */
+int sst_spconv_grid_subm_i32(const int32_t* d_coors, int64_t n, int batch, const int32_t* shape, const int32_t* ksize,
+                             const int32_t* dilation, int32_t* d_grid, int32_t* d_in2out, int32_t* d_out2in,
+                             void* stream);
+int64_t sst_spconv_grid_conv_workspace_bytes(int64_t cells);
+int sst_spconv_grid_conv_count_i32(const int32_t* d_coors, int64_t n, int batch, const int32_t* in_shape,
+                                   const int32_t* out_shape, const int32_t* ksize, const int32_t* stride,
+                                   const int32_t* padding, const int32_t* dilation, int transpose, void* d_workspace,
+                                   int32_t* d_num_out, void* stream);
+int sst_spconv_grid_conv_maps_i32(const int32_t* d_coors, int64_t n, int batch, const int32_t* in_shape,
+                                  const int32_t* out_shape, const int32_t* ksize, const int32_t* stride,
+                                  const int32_t* padding, const int32_t* dilation, int transpose, void* d_workspace,
+                                  int64_t m, int32_t* d_outids, int32_t* d_in2out, int32_t* d_out2in, void* stream);
 int sst_spconv_subm_map_i32(const int32_t* d_coors, int64_t n, const int32_t* shape, const int32_t* ksize,
                             const int32_t* dilation, const uint64_t* d_sorted_keys, const uint32_t* d_perm,
                             int32_t* d_in2out, void* stream);

@@ -125,6 +125,12 @@ _SIGNATURES = {
                                            c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_spconv_candidates_i32': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr]),
     'sst_spconv_inverse_to_map_i32': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_spconv_grid_subm_i32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_spconv_grid_conv_workspace_bytes': (c_i64, [c_i64]),
+    'sst_spconv_grid_conv_count_i32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr,
+                                               c_ptr, c_ptr]),
+    'sst_spconv_grid_conv_maps_i32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr,
+                                              c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_spconv_subm_map_i32': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_spconv_invert_map_i32': (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_ptr, c_ptr]),
     'sst_spconv_pair_lists_workspace_bytes': (c_i64, [c_i32, c_i64]),

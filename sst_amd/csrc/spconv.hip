@@ -119,6 +119,108 @@ __global__ __launch_bounds__(256) void sp_subm_map_k(const int32_t* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Rulebook through a DENSE CELL GRID (second builder; the sort-based one above stays for grids too large to hold).
+// The spatial shape of a SparseConvTensor is known and small next to 288 GB of HBM (FSD: 2 x 32 x 640 x 640 cells = 105 MB
+// of int32), so "which row sits at position p" is one load from a cell -> row grid instead of a binary search in sorted
+// keys, and the output voxels of a strided / transposed convolution are the marked cells of the OUTPUT grid compacted by a
+// scan over the cells - which numbers them by ascending (b, z, y, x), exactly like the sorted-unique of the candidate rows
+// (the reference's torch::_unique of the linear indices, spconv_ops.h:128).  A submanifold rulebook is memset + 2 launches
+// instead of ~20 (pack, 3 radix passes of 5 launches, head flags, scan, finish, map, invert), a strided one memset +
+// mark + scan + 2 launches instead of ~35.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t sp_cell(int b, const int (&p)[3], const int* shape) {
+  return (((int64_t)b * shape[0] + p[0]) * shape[1] + p[1]) * shape[2] + p[2];
+}
+
+// grid[cell of row j] = j
+__global__ __launch_bounds__(256) void sp_grid_rows_k(const int32_t* __restrict__ coors, int64_t n, SpGeom g,
+                                                      int32_t* __restrict__ grid) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = ((const int4*)coors)[j];
+    const int p[3] = {c.y, c.z, c.w};
+    grid[sp_cell(c.x, p, g.in_shape)] = (int32_t)j;
+  }
+}
+
+// Submanifold: in2out[k][j] = row at pos(j) + pd - ko * dl (the output position offset k sends input j to), and
+// out2in[k][i] = row at pos(i) - pd + ko * dl (the input position output i reads through offset k); -1 outside / empty.
+__global__ __launch_bounds__(256) void sp_grid_subm_k(const int32_t* __restrict__ coors, int64_t n, SpGeom g,
+                                                      const int32_t* __restrict__ grid, int32_t* __restrict__ in2out,
+                                                      int32_t* __restrict__ out2in) {
+  const int64_t total = (int64_t)g.kvol * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e / n);
+    const int64_t j = e - (int64_t)k * n;
+    const int4 c = ((const int4*)coors)[j];
+    const int pos[3] = {c.y, c.z, c.w};
+    int ko[3];
+    sp_koff(g, k, ko);
+    int fwd[3], bwd[3];
+    bool okf = true, okb = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      fwd[d] = pos[d] + g.pd[d] - ko[d] * g.dl[d];
+      bwd[d] = pos[d] - g.pd[d] + ko[d] * g.dl[d];
+      okf = okf && fwd[d] >= 0 && fwd[d] < g.out_shape[d];
+      okb = okb && bwd[d] >= 0 && bwd[d] < g.in_shape[d];
+    }
+    in2out[e] = okf ? grid[sp_cell(c.x, fwd, g.in_shape)] : -1;
+    out2in[e] = okb ? grid[sp_cell(c.x, bwd, g.in_shape)] : -1;
+  }
+}
+
+// Regular / transposed convolution, pass 1: flag the output cells touched by any (offset, input row)
+__global__ __launch_bounds__(256) void sp_grid_mark_k(const int32_t* __restrict__ coors, int64_t n, SpGeom g,
+                                                      int transpose, int32_t* __restrict__ flags) {
+  const int64_t total = (int64_t)g.kvol * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e / n);
+    const int64_t j = e - (int64_t)k * n;
+    const int4 c = ((const int4*)coors)[j];
+    const int in[3] = {c.y, c.z, c.w};
+    int ko[3], out[3];
+    sp_koff(g, k, ko);
+    if (sp_out_pos(g, in, ko, transpose != 0, out)) flags[sp_cell(c.x, out, g.out_shape)] = 1;
+  }
+}
+
+// pass 2 (after the exclusive scan of the flags -> pos): coordinates of the output voxels, in ascending cell order
+__global__ __launch_bounds__(256) void sp_grid_outids_k(const int32_t* __restrict__ flags, const int32_t* __restrict__ pos,
+                                                        int64_t cells, SpGeom g, int32_t* __restrict__ outids) {
+  const int64_t per_b = (int64_t)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cells; e += (int64_t)gridDim.x * blockDim.x) {
+    if (!flags[e]) continue;
+    const int64_t b = e / per_b;
+    int64_t r = e - b * per_b;
+    const int z = (int)(r / ((int64_t)g.out_shape[1] * g.out_shape[2]));
+    r -= (int64_t)z * g.out_shape[1] * g.out_shape[2];
+    const int y = (int)(r / g.out_shape[2]);
+    ((int4*)outids)[pos[e]] = make_int4((int)b, z, y, (int)(r - (int64_t)y * g.out_shape[2]));
+  }
+}
+
+// pass 3: both maps (out2in pre-filled with -1; (k, i) has at most one input row: no conflicts)
+__global__ __launch_bounds__(256) void sp_grid_conv_maps_k(const int32_t* __restrict__ coors, int64_t n, SpGeom g,
+                                                           int transpose, const int32_t* __restrict__ pos, int64_t m,
+                                                           int32_t* __restrict__ in2out, int32_t* __restrict__ out2in) {
+  const int64_t total = (int64_t)g.kvol * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e / n);
+    const int64_t j = e - (int64_t)k * n;
+    const int4 c = ((const int4*)coors)[j];
+    const int in[3] = {c.y, c.z, c.w};
+    int ko[3], out[3];
+    sp_koff(g, k, ko);
+    int res = -1;
+    if (sp_out_pos(g, in, ko, transpose != 0, out)) {
+      res = pos[sp_cell(c.x, out, g.out_shape)];
+      out2in[(int64_t)k * m + res] = (int32_t)j;
+    }
+    in2out[e] = res;
+  }
+}
+
 __global__ __launch_bounds__(256) void sp_fill_i32_k(int32_t* __restrict__ p, int64_t n, int32_t v) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
 }
@@ -739,6 +841,80 @@ int sst_spconv_candidates_i32(const int32_t* d_coors, int64_t n, const int32_t* 
   const int64_t total = (int64_t)g.kvol * n + 1;
   hipLaunchKernelGGL(sp_candidates_k, dim3(sst_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, d_coors, n, g,
                      transpose, (int4*)d_rows);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+/* Dense-grid rulebooks (see the kernels).  Cells = batch x shape[0] x shape[1] x shape[2] of the INPUT shape (submanifold)
+ * or of the OUTPUT shape (regular / transposed); the caller provides the cell arrays. */
+int sst_spconv_grid_subm_i32(const int32_t* d_coors, int64_t n, int batch, const int32_t* shape, const int32_t* ksize,
+                             const int32_t* dilation, int32_t* d_grid, int32_t* d_in2out, int32_t* d_out2in,
+                             void* stream) {
+  int32_t st[3] = {1, 1, 1}, pd[3];
+  if (!ksize || batch < 1) return SST_ERR_ARG;
+  for (int d = 0; d < 3; ++d) pd[d] = ksize[d] / 2;   // spconv_ops.h:74-77
+  SpGeom g;
+  if (n < 0 || !sp_geom(shape, shape, ksize, st, pd, dilation, &g)) return SST_ERR_ARG;
+  if ((int64_t)g.kvol * n > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
+  if (n == 0) return SST_OK;
+  if (!d_coors || !d_grid || !d_in2out || !d_out2in || (((uintptr_t)d_coors) & 15)) return SST_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t cells = (int64_t)batch * shape[0] * shape[1] * shape[2];
+  SST_HIP(hipMemsetAsync(d_grid, 0xFF, sizeof(int32_t) * cells, s));
+  hipLaunchKernelGGL(sp_grid_rows_k, dim3(sst_grid_1d(n, 256)), dim3(256), 0, s, d_coors, n, g, d_grid);
+  hipLaunchKernelGGL(sp_grid_subm_k, dim3(sst_grid_1d((int64_t)g.kvol * n, 256)), dim3(256), 0, s, d_coors, n, g, d_grid,
+                     d_in2out, d_out2in);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int64_t sst_spconv_grid_conv_workspace_bytes(int64_t cells) {
+  return 2 * sst_align_up((cells > 0 ? cells : 1) * (int64_t)sizeof(int32_t), 256) +
+         sst_align_up(sst_scan_workspace_bytes(cells > 0 ? cells : 1), 256) + 256;
+}
+
+/* pass 1: marks + scan; d_num_out [1] = number of output voxels (device; the caller reads it to size outids / out2in) */
+int sst_spconv_grid_conv_count_i32(const int32_t* d_coors, int64_t n, int batch, const int32_t* in_shape,
+                                   const int32_t* out_shape, const int32_t* ksize, const int32_t* stride,
+                                   const int32_t* padding, const int32_t* dilation, int transpose, void* d_workspace,
+                                   int32_t* d_num_out, void* stream) {
+  SpGeom g;
+  if (n < 0 || batch < 1 || !sp_geom(in_shape, out_shape, ksize, stride, padding, dilation, &g)) return SST_ERR_ARG;
+  if ((int64_t)g.kvol * n > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
+  if (!d_workspace || !d_num_out || (n > 0 && (!d_coors || (((uintptr_t)d_coors) & 15)))) return SST_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t cells = (int64_t)batch * out_shape[0] * out_shape[1] * out_shape[2];
+  if (cells > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
+  const int64_t seg = sst_align_up(cells * (int64_t)sizeof(int32_t), 256);
+  int32_t* flags = (int32_t*)d_workspace;
+  int32_t* pos = (int32_t*)((char*)d_workspace + seg);
+  void* scan_ws = (char*)d_workspace + 2 * seg;
+  SST_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * cells, s));
+  if (n > 0)
+    hipLaunchKernelGGL(sp_grid_mark_k, dim3(sst_grid_1d((int64_t)g.kvol * n, 256)), dim3(256), 0, s, d_coors, n, g, transpose,
+                       flags);
+  SST_LAUNCH_CHECK();
+  return sst_exclusive_scan_i32(flags, pos, cells, d_num_out, scan_ws, stream);
+}
+
+/* pass 2: output coordinates [m, 4] and both maps; d_workspace as left by pass 1 */
+int sst_spconv_grid_conv_maps_i32(const int32_t* d_coors, int64_t n, int batch, const int32_t* in_shape,
+                                  const int32_t* out_shape, const int32_t* ksize, const int32_t* stride,
+                                  const int32_t* padding, const int32_t* dilation, int transpose, void* d_workspace,
+                                  int64_t m, int32_t* d_outids, int32_t* d_in2out, int32_t* d_out2in, void* stream) {
+  SpGeom g;
+  if (n < 0 || m < 0 || batch < 1 || !sp_geom(in_shape, out_shape, ksize, stride, padding, dilation, &g)) return SST_ERR_ARG;
+  if (n == 0 || m == 0) return SST_OK;
+  if (!d_workspace || !d_coors || !d_outids || !d_in2out || !d_out2in || (((uintptr_t)d_outids) & 15)) return SST_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t cells = (int64_t)batch * out_shape[0] * out_shape[1] * out_shape[2];
+  const int64_t seg = sst_align_up(cells * (int64_t)sizeof(int32_t), 256);
+  const int32_t* flags = (const int32_t*)d_workspace;
+  const int32_t* pos = (const int32_t*)((const char*)d_workspace + seg);
+  SST_HIP(hipMemsetAsync(d_out2in, 0xFF, sizeof(int32_t) * g.kvol * m, s));
+  hipLaunchKernelGGL(sp_grid_outids_k, dim3(sst_grid_1d(cells, 256)), dim3(256), 0, s, flags, pos, cells, g, d_outids);
+  hipLaunchKernelGGL(sp_grid_conv_maps_k, dim3(sst_grid_1d((int64_t)g.kvol * n, 256)), dim3(256), 0, s, d_coors, n, g,
+                     transpose, pos, m, d_in2out, d_out2in);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -146,13 +146,16 @@ def _i32(vals):
     return _lib.i32array([int(v) for v in vals])
 
 
-def _finish_rulebook(in2out, kvol, n, m, dev):
+def _finish_rulebook(in2out, kvol, n, m, dev, out2in=None):
     lib = _lib.load()
     rb = Rulebook()
     rb.in2out, rb.kvol, rb.n, rb.m = in2out, kvol, n, m
-    rb.out2in = torch.empty((kvol, m), dtype=torch.int32, device=dev)
-    _lib.check(lib.sst_spconv_invert_map_i32(_lib.ptr(in2out), kvol, n, m, _lib.ptr(rb.out2in), _lib.stream_ptr()),
-               'sst_spconv_invert_map_i32')
+    if out2in is not None:
+        rb.out2in = out2in
+    else:
+        rb.out2in = torch.empty((kvol, m), dtype=torch.int32, device=dev)
+        _lib.check(lib.sst_spconv_invert_map_i32(_lib.ptr(in2out), kvol, n, m, _lib.ptr(rb.out2in), _lib.stream_ptr()),
+                   'sst_spconv_invert_map_i32')
     pairs = torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
     rb.num = torch.zeros(kvol, dtype=torch.int32, device=dev)
     ws = _lib.workspace(lib.sst_spconv_pair_lists_workspace_bytes(kvol, n), dev)
@@ -191,10 +194,40 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     if n == 0:
         rb, pairs = _finish_rulebook(in2out, kvol, 0, 0, dev)
         return indices, pairs, rb.num
+    # dense cell grids (csrc/spconv.hip, second builder) whenever batch x shape fits 2^28 cells (1 GB of int32);
+    # SST_SPCONV_RULEBOOK=sort forces the sort-based builder
+    n_cells = int(batch_size) * int(np.prod(spatial_shape if subm else out_shape))
+    debug = os.environ.get('SST_AMD_DEBUG', '0') == '1'     # debug: the sort-based builder, which can tell a voxel listed twice
+    use_grid = (os.environ.get('SST_SPCONV_RULEBOOK', 'grid') == 'grid' and 0 < n_cells <= (1 << 28) and min(out_shape) > 0
+                and not debug)
+    if use_grid and subm:
+        grid = torch.empty(n_cells, dtype=torch.int32, device=dev)
+        out2in = torch.empty((kvol, n), dtype=torch.int32, device=dev)
+        rc = lib.sst_spconv_grid_subm_i32(_lib.ptr(indices), n, int(batch_size), _i32(spatial_shape), _i32(ksize),
+                                          _i32(dilation), _lib.ptr(grid), _lib.ptr(in2out), _lib.ptr(out2in),
+                                          _lib.stream_ptr())
+        _lib.check(rc, 'sst_spconv_grid_subm_i32')
+        rb, pairs = _finish_rulebook(in2out, kvol, n, n, dev, out2in=out2in)
+        return indices, pairs, rb.num
+    if use_grid:
+        geom = (_i32(spatial_shape), _i32(out_shape), _i32(ksize), _i32(stride), _i32(padding), _i32(dilation))
+        ws = _lib.workspace(lib.sst_spconv_grid_conv_workspace_bytes(n_cells), dev)
+        num_out = torch.empty(1, dtype=torch.int32, device=dev)
+        rc = lib.sst_spconv_grid_conv_count_i32(_lib.ptr(indices), n, int(batch_size), *geom, int(bool(transpose)),
+                                                _lib.ptr(ws), _lib.ptr(num_out), _lib.stream_ptr())
+        _lib.check(rc, 'sst_spconv_grid_conv_count_i32')
+        m = int(num_out.item())      # the one read-back an output tensor of data-dependent length needs
+        outids = torch.empty((m, 4), dtype=torch.int32, device=dev)
+        out2in = torch.empty((kvol, m), dtype=torch.int32, device=dev)
+        rc = lib.sst_spconv_grid_conv_maps_i32(_lib.ptr(indices), n, int(batch_size), *geom, int(bool(transpose)),
+                                               _lib.ptr(ws), m, _lib.ptr(outids), _lib.ptr(in2out), _lib.ptr(out2in),
+                                               _lib.stream_ptr())
+        _lib.check(rc, 'sst_spconv_grid_conv_maps_i32')
+        rb, pairs = _finish_rulebook(in2out, kvol, n, m, dev, out2in=out2in)
+        return outids, pairs, rb.num
     if subm:
         # no host synchronisation on this path: the group count stays on the device.  SST_AMD_DEBUG=1 reads it back and
         # checks that no voxel is listed twice (a SparseConvTensor never does; the reference does not check either)
-        debug = os.environ.get('SST_AMD_DEBUG', '0') == '1'
         plan = K.unique_rows(indices, [0, 0, 0, 0], [int(batch_size)] + out_shape, invalid_if_negative=0,
                              defer_count=not debug)
         if debug and plan.m != n:

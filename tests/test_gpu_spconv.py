@@ -27,9 +27,12 @@ def _rulebook(ind, batch, shape, ks, st, pd, dl, subm, tr):
     return outids, pairs, num, pairs._sst_rulebook
 
 
+@pytest.mark.parametrize('builder', ['grid', 'sort'])
 @pytest.mark.parametrize('tag', TAGS)
-def test_rulebook_matches_oracle_and_reference_golden(tag):
+def test_rulebook_matches_oracle_and_reference_golden(tag, builder, monkeypatch):
+    """both rulebook builders (dense cell grid; sort + binary search) against the oracle and the reference's own output"""
     from oracle import spconv_oracle as O
+    monkeypatch.setenv('SST_SPCONV_RULEBOOK', builder)
     g = load_golden('spconv.npz')
     ind, batch, shape, ks, st, pd, dl, subm, tr = spconv_case(g, tag)
     outids, pairs, num, rb = _rulebook(ind, batch, shape, ks, st, pd, dl, subm, tr)
