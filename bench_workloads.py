@@ -172,9 +172,10 @@ class FSDPath(nn.Module):
         # called as SingleStageFSD.forward_train does (single_stage_fsd.py:521): per-class lists, origin_points = the points
         cluster_inds_l, valid_l = self.cluster_assigner(pts_l, [batch_idx[s] for s in sel_l], None, None,
                                                         origin_points=[batch_points[s] for s in sel_l])
-        sel = torch.cat([s[v] for s, v in zip(sel_l, valid_l)])
+        keep_l = [torch.nonzero(v).squeeze(1) for v in valid_l]                        # one read-back per class, used twice
+        sel = torch.cat([s[k] for s, k in zip(sel_l, keep_l)])
         cluster_inds = torch.cat(cluster_inds_l).long()                               # [P, 3] (class, sample, cluster)
-        centres = torch.cat([p[v] for p, v in zip(pts_l, valid_l)])
+        centres = torch.cat([p[k] for p, k in zip(pts_l, keep_l)])
         points = batch_points[sel]
         feats = torch.cat([seg_feats[sel], logits[sel], votes[sel].reshape(-1, 9)], 1)
         # SingleStageFSD.extract_feat (single_stage_fsd.py:467-483)
@@ -441,6 +442,13 @@ def run(args, rank, world, dev, make_reducer):
     """bench.py's contract for --workload fsd | fsdv2: W warm-up steps, K timed steps between barriers, max over ranks,
     one JSON line from rank 0."""
     spec = WORKLOADS[args.workload]
+    if not getattr(args, 'no_gemm_tuning', False):
+        # the point-wise linears (VFE / SIR layers, the stand-in heads: tall and very narrow products) are library GEMMs:
+        # TunableOp picks the fastest hipBLASLt / rocBLAS solution per shape during warm-up, as bench.py does for the headline
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_filename(f'/tmp/sst_amd_tunableop_{args.workload}_rank{rank}.csv')
     torch.manual_seed(0)
     model = spec['cls']().to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]

@@ -134,7 +134,7 @@ class DynamicPointROIExtractor(nn.Module):
         per_sample, (pts_sorted, rois_sorted), total = host[:n_samples], host[n_samples:n_samples + 2], host[-1]
         assert pts_sorted, 'points must be sorted by sample'
         assert rois_sorted, 'RoIs must be sorted by sample'
-        if total >= rows:
+        if total >= rows and n_samples > 1:      # one sample: the shared cap IS its own cap
             # the shared buffer filled up: a sample above its own cap may have pushed later samples' pairs out.  The
             # reference caps every sample on its own (:51-80) - do what it does, sample by sample
             return self._per_sample_forward(pts_xyz, pts_sample, rois, roi_sample, n_samples, cap_in_box)
