@@ -44,6 +44,35 @@ def make_cloud(n, seed, device):
     return xyz.to(device)
 
 
+def make_lidar_cloud(seed, device, beams=64, azimuth_steps=2650, sensor_height=2.0, outside_fraction=0.05,
+                     duplicate_fraction=0.02):
+    """SURVEY.md section 8(d) "L-cloud" + its pathological input in one frame: a spinning 64-beam sensor 2 m above a ground
+    plane (range = ray / ground intersection, 2 cm noise; rays above the horizon hit a far wall at 75 m), 5 % of the rays
+    replaced by box surfaces, then 5 % of the points pushed OUTSIDE the point-cloud range (the voxelizer's clamp) and 2 %
+    duplicated exactly.  ~170 k points that pile up near the sensor: few, crowded windows - the opposite of the uniform cloud."""
+    g = torch.Generator().manual_seed(seed)
+    az = torch.arange(azimuth_steps, dtype=torch.float32) * (2 * 3.14159265 / azimuth_steps)
+    el = torch.linspace(-25.0, 3.0, beams) * (3.14159265 / 180)
+    el, az = torch.meshgrid(el, az, indexing='ij')
+    el, az = el.reshape(-1), az.reshape(-1)
+    rng = torch.where(el < -0.01, sensor_height / torch.tan(-el).clamp(min=1e-3), torch.full_like(el, 75.0))
+    rng = (rng + 0.02 * torch.randn(rng.shape, generator=g)).clamp(1.0, 75.0)
+    xyz = torch.stack([rng * torch.cos(el) * torch.cos(az), rng * torch.cos(el) * torch.sin(az),
+                       sensor_height - 2.0 + rng * torch.sin(el) - 0.0], 1)
+    xyz[:, 2] -= 1.8                                              # ground near z = -1.8 (the range is z in [-2, 4])
+    n = xyz.size(0)
+    box = torch.rand(n, generator=g) < 0.05                       # rays that hit an object instead
+    centres = (torch.rand(40, 3, generator=g) - 0.5) * torch.tensor([100.0, 100.0, 0.0]) + torch.tensor([0.0, 0.0, -0.9])
+    which = torch.randint(0, 40, (n,), generator=g)
+    on_box = centres[which] + (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([4.2, 1.9, 1.7])
+    xyz = torch.where(box[:, None], on_box, xyz)
+    out = torch.rand(n, generator=g) < outside_fraction            # outside the range: clamped by the voxelizer
+    xyz = torch.where(out[:, None], xyz * torch.tensor([1.0, 1.0, 1.0]) + torch.sign(xyz) * torch.tensor([80.0, 80.0, 0.0]), xyz)
+    dup = torch.randint(0, n, (int(n * duplicate_fraction),), generator=g)
+    xyz = torch.cat([xyz, xyz[dup]])
+    return xyz[torch.randperm(xyz.size(0), generator=g)].contiguous().to(device)
+
+
 class Pipeline(torch.nn.Module):
     """The SST-base hot path behind the reference's registry names (configs/sst_refactor/
     sst_waymoD5_1x_3class_8heads_v2.py:26-79), without the dense BEV neck/head."""
@@ -100,6 +129,7 @@ class Pipeline(torch.nn.Module):
             prepared.want_pos_rows = False   # the encoder stacks (fp32 chain and bf16) take (table, row index) instead
             info = prepared.finalize(voxel_feats, self.middle_encoder)
         self.last_voxel_coors = info['voxel_coors']
+        self.last_plans = [info.get('sra_plan_shift0'), info.get('sra_plan_shift1')]
         out = self.backbone(info)[0]
         return out if self.with_bev else out['voxel_feats']
 
@@ -160,6 +190,23 @@ def collective_costs(reducer, dev, reps=20):
 
     return {'allreduce_ms': round(timed(grads), 4), 'bn_sync_ms': round(timed(bn), 4),
             'gradient_bytes': int(reducer.flat.numel() * 4), 'buckets': [int((e - s_) * 4) for s_, e, _ in reducer.buckets]}
+
+
+def remeasure_sra_traffic(args, timeout_s=240):
+    """HBM traffic of the attention kernels measured NOW when rocprofv3 is on PATH (two PMC passes over tools/sra_only.py in a
+    child process, after the timed region): -> path of the JSON, or None (no profiler, --no-traffic-remeasure, failure)."""
+    import shutil
+    import subprocess
+    if args.no_traffic_remeasure or shutil.which('rocprofv3') is None or args.points != 116000 or args.frames_per_gpu != 1:
+        return None
+    out = os.path.join('gpurun_out', 'traffic_live')
+    try:
+        r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'collect_sra_traffic.sh'), out], cwd=ROOT, timeout=timeout_s,
+                           capture_output=True, text=True, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+        path = os.path.join(ROOT, out, 'sra_traffic.json')
+        return path if r.returncode == 0 and os.path.exists(path) else None
+    except Exception:
+        return None
 
 
 def voxel_sort_key(coors):
@@ -339,6 +386,9 @@ def main():
     ap.add_argument('--grad-buckets', type=int, default=2)
     ap.add_argument('--no-time-sra-bwd', action='store_true', help='do not attach events to the SRA backward launches')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
+    ap.add_argument('--no-traffic-remeasure', action='store_true',
+                    help='take roofline.traffic from profiles/latest_sra_traffic.json instead of two rocprofv3 --pmc passes now')
+    ap.add_argument('--no-lidar-leg', action='store_true', help='skip the LiDAR-like / pathological frame beside the headline')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the reduced-precision (bf16) measurement')
     ap.add_argument('--precision', default='f32', choices=('f32', 'bf16'),
                     help="precision of the encoder layers in the TIMED region; the contract's headline is f32 (default), "
@@ -399,7 +449,7 @@ def main():
     model = Pipeline(args.blocks, with_bev=args.workload == 'sst_bev').to(dev)
     if args.workload == 'sst_bev':
         torch.backends.cudnn.benchmark = True    # MIOpen: search for the convolution solvers during warm-up
-        args.no_bf16_leg = args.no_cpu_baseline = True     # the CPU port and the bf16 comparison cover the voxel features only
+        args.no_bf16_leg = args.no_cpu_baseline = args.no_lidar_leg = True   # those legs cover the voxel features only
     model.train()
     model.backbone.set_impl(args.impl)
     model.fused_index = not args.piecewise_index
@@ -499,6 +549,51 @@ def main():
                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
                     'note': 'same pipeline under torch.no_grad(), training-mode drop/shuffle; not part of `value`'}
 
+    # Beside the headline (uniform cloud): the same step on a LiDAR-like frame with out-of-range points and duplicates
+    lidar_leg = None
+    if not args.fwd_only and not args.no_lidar_leg:
+        lframes = [make_lidar_cloud(2000 * rank + i, dev) for i in range(args.frames_per_gpu)]
+
+        def lstep():
+            for p in params:
+                p.grad = None
+            o = model(lframes)
+            gg = seed_grad.get(o.shape)
+            if gg is None:
+                gg = seed_grad[o.shape] = torch.randn(o.shape, device=o.device, dtype=o.dtype)
+            o.backward(gg)
+            if reducer is not None:
+                reducer.finish()
+            return o
+
+        for _ in range(3):
+            lo = lstep()
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            lstep()
+        sync()
+        el = time.perf_counter() - t3
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        sizes = []
+        for sft in range(2):
+            pl = model.last_plans[sft]
+            if pl is not None:
+                off = pl.winoff[:pl.n_windows + 1].cpu()
+                d = (off[1:] - off[:-1]).float()
+                sizes.append({'windows': int(pl.n_windows), 'tokens_min': int(d.min()), 'tokens_mean': round(float(d.mean()), 1),
+                              'tokens_max': int(d.max())})
+        lidar_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
+                     'points_per_frame': int(lframes[0].size(0)), 'voxels_kept_per_gpu': int(lo.size(0)),
+                     'window_sizes': sizes,
+                     'what': 'same step (fwd + bwd) on a LiDAR-like frame: 64 beams x 2650 azimuth steps over a ground plane, '
+                             '5 % box hits, 5 % of the points outside the range (clamped), 2 % exact duplicates '
+                             '(SURVEY.md section 8(d) L-cloud + pathological input); not part of `value`'}
+
     # Beside the fp32 headline: the same step with the encoder layers in the reduced-precision mode (bf16 storage, fp32
     # accumulation / softmax / LayerNorm statistics, fp32 master weights: sst_amd/bf16.py) - what the reference's own
     # fp16 training of these layers (configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82) corresponds to here.
@@ -589,11 +684,16 @@ def main():
         # HBM traffic of this kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately by
         # tools/collect_sra_traffic.sh on the same workload and committed under profiles/): per launch, like `achieved`
         tpath = os.path.join(ROOT, 'profiles', 'latest_sra_traffic.json')
+        source = 'profiles/latest_sra_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed)'
+        live = remeasure_sra_traffic(args) if (rank == 0 and world == 1) else None
+        if live is not None:
+            tpath, source = live, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/sra_only.py '
+                                   '(tools/collect_sra_traffic.sh, gfx950 x2 FETCH correction)')
         if os.path.exists(tpath) and args.points == 116000 and args.frames_per_gpu == 1:
             try:
                 tj = json.load(open(tpath))
                 roofline['traffic'] = int(tj['sra_fwd_wave_k']['hbm_bytes_per_launch'])
-                roofline['traffic_source'] = 'profiles/latest_sra_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'
+                roofline['traffic_source'] = source
                 if 'sra_bwd' in roofline and 'sra_bwd_fused_k' in tj:
                     roofline['sra_bwd']['traffic'] = int(tj['sra_bwd_fused_k']['hbm_bytes_per_launch'])
                 if bf16_leg is not None:
@@ -635,6 +735,8 @@ def main():
             res.update(allreduce_ms=comm['allreduce_ms'], bn_sync_ms=comm['bn_sync_ms'], communication=comm)
         if fwd_only is not None:
             res['forward_only'] = fwd_only
+        if lidar_leg is not None:
+            res['lidar_like_cloud'] = lidar_leg
         if bf16_leg is not None:
             res['reduced_precision'] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
