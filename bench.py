@@ -386,6 +386,7 @@ def main():
     ap.add_argument('--grad-buckets', type=int, default=2)
     ap.add_argument('--no-time-sra-bwd', action='store_true', help='do not attach events to the SRA backward launches')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
+    ap.add_argument('--no-f32x3-leg', action='store_true', help='skip the split-precision (bf16 x 3) leg beside the headline')
     ap.add_argument('--no-traffic-remeasure', action='store_true',
                     help='take roofline.traffic from profiles/latest_sra_traffic.json instead of two rocprofv3 --pmc passes now')
     ap.add_argument('--no-lidar-leg', action='store_true', help='skip the LiDAR-like / pathological frame beside the headline')
@@ -449,7 +450,7 @@ def main():
     model = Pipeline(args.blocks, with_bev=args.workload == 'sst_bev').to(dev)
     if args.workload == 'sst_bev':
         torch.backends.cudnn.benchmark = True    # MIOpen: search for the convolution solvers during warm-up
-        args.no_bf16_leg = args.no_cpu_baseline = args.no_lidar_leg = True   # those legs cover the voxel features only
+        args.no_bf16_leg = args.no_cpu_baseline = args.no_lidar_leg = args.no_f32x3_leg = True   # those legs cover the voxel features only
     model.train()
     model.backbone.set_impl(args.impl)
     model.fused_index = not args.piecewise_index
@@ -548,6 +549,41 @@ def main():
         fwd_only = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
                     'note': 'same pipeline under torch.no_grad(), training-mode drop/shuffle; not part of `value`'}
+
+    # Beside the exact-fp32 headline: the same step with the projections / FFN products of the encoder layers evaluated as three
+    # bf16 products of split fp32 operands with fp32 accumulation (csrc/dense_f32x3.hip; everything stays fp32 in HBM, the
+    # attention core, LayerNorm and the weight gradients stay exact fp32).  ~1e-5 relative per product - tighter than the TF32
+    # tensor-core products torch 1.8 (the reference's pinned version) uses for these layers by default on Ampere.
+    x3_leg = None
+    if not args.fwd_only and not args.no_f32x3_leg and args.precision == 'f32':
+        with torch.no_grad():
+            ref_out, ref_key = gpu_forward_sorted(model, frames)
+        model.backbone.set_precision('f32x3')
+        try:
+            with torch.no_grad():
+                x3_out, x3_key = gpu_forward_sorted(model, frames)
+            same = torch.equal(ref_key, x3_key)
+            for _ in range(3):
+                step()
+            sync()
+            t4 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            el = time.perf_counter() - t4
+        finally:
+            model.backbone.set_precision('fp32')
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        x3_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                  'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': 'f32 storage, bf16 x 3 products',
+                  'max_abs_err_vs_exact_fp32_forward': float((x3_out - ref_out).abs().max()) if same else None,
+                  'voxels_equal': bool(same),
+                  'what': 'same step; q|k, v, out-proj, FFN products and their data gradients as x_hi w_hi + x_lo w_hi + x_hi w_lo '
+                          'on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (12 layers: error of the whole forward vs the '
+                          'exact-fp32 forward in max_abs_err_vs_exact_fp32_forward); not part of `value`'}
 
     # Beside the headline (uniform cloud): the same step on a LiDAR-like frame with out-of-range points and duplicates
     lidar_leg = None
@@ -737,6 +773,8 @@ def main():
             res['forward_only'] = fwd_only
         if lidar_leg is not None:
             res['lidar_like_cloud'] = lidar_leg
+        if x3_leg is not None:
+            res['precision_f32x3'] = x3_leg
         if bf16_leg is not None:
             res['reduced_precision'] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:

@@ -503,6 +503,18 @@ int sst_tall_linear_ln_f32(const float* d_x, int64_t ldx, const float* d_w, int6
                            const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
                            float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
                            float* d_y_plus_pos, void* stream);
+/* sst_tall_linear_epi_f32x3 / sst_tall_linear_ln_f32x3: the same two entry points (same arguments, fp32 tensors) with the
+ * product evaluated on the bf16 matrix pipe from SPLIT operands, x w ~= x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulation
+ * (csrc/dense_f32x3.hip): ~1e-5 relative error per product - tighter than the TF32 the reference's nn.Linear ran on under
+ * torch 1.8's default allow_tf32 = True on Ampere - at 3 / 16 of the fp32 pipe time.  Selected by SSTv2.set_precision('f32x3');
+ * reported beside the exact-fp32 headline. */
+int sst_tall_linear_epi_f32x3(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int trans_w, const float* d_bias,
+                              int64_t m, int k, int n, int epilogue, const float* d_aux_in, float* d_aux_out, int64_t ldaux,
+                              float* d_y, int64_t ldy, void* stream);
+int sst_tall_linear_ln_f32x3(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias, int64_t m, int k,
+                             const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
+                             float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
+                             float* d_y_plus_pos, void* stream);
 int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
                                const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
                                void* d_workspace, void* stream);

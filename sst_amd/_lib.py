@@ -93,6 +93,10 @@ _SIGNATURES = {
     'sst_weight_grad_group_f32': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
     'sst_tall_linear_ln_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr,
                                        c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_tall_linear_ln_f32x3': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr,
+                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_tall_linear_epi_f32x3': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr,
+                                          c_i64, c_ptr, c_i64, c_ptr]),
     'sst_add_layernorm_bwd2_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_tall_linear_epi_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr,
                                         c_i64, c_ptr, c_i64, c_ptr]),

@@ -118,9 +118,15 @@ class _WindowTransformer(nn.Module):
         """'fp32' (default; the parity mode) or 'bf16': reduced-precision encoder layers (sst_amd/bf16.py) - what the
         reference's fp16 training (Fp16OptimizerHook) corresponds to on this hardware.  Layers the bf16 kernels do not
         cover (cosine attention, batch-norm layers, pre-norm) keep running in fp32."""
-        if precision not in ('fp32', 'bf16'):
+        if precision not in ('fp32', 'bf16', 'f32x3'):
             raise ValueError(precision)
-        self.precision = precision
+        # 'f32x3': fp32 storage everywhere, the projections / FFN products as three bf16 products of split operands with fp32
+        # accumulation (csrc/dense_f32x3.hip): ~1e-5 relative - tighter than the TF32 the reference's torch 1.8 used for
+        # these products on Ampere.  The attention core, LayerNorm and the weight gradients stay exact fp32.
+        from . import dense
+        dense.set_matmul_mode('f32x3' if precision == 'f32x3' else 'f32')
+        self.precision = 'fp32' if precision == 'f32x3' else precision
+        self.matmul = 'f32x3' if precision == 'f32x3' else 'f32'
         return self
 
     def run_blocks(self, feats, pos, plans, masks=None, pos_lookup=None):

@@ -113,6 +113,21 @@ def tall_gemm(x, w, bias=None, trans_w=False, out=None, accumulate=False):
 
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_ADD = range(6)
 _LDS_LINEAR_SHAPES = ((128, 128), (128, 256), (256, 128))
+# How the LDS-resident linears multiply: 'f32' = exact fp32 (v_mfma_f32_16x16x4_f32, csrc/dense_f32.hip; the parity mode and
+# the headline) or 'f32x3' = three bf16 products of split operands with fp32 accumulation (csrc/dense_f32x3.hip; ~1e-5
+# relative, tighter than the TF32 products of the reference's own torch 1.8 on Ampere).  SSTv2.set_precision switches it.
+_MATMUL_MODE = 'f32'
+
+
+def set_matmul_mode(mode):
+    global _MATMUL_MODE
+    if mode not in ('f32', 'f32x3'):
+        raise ValueError(mode)
+    _MATMUL_MODE = mode
+
+
+def matmul_mode():
+    return _MATMUL_MODE
 
 
 def lds_linear_ok(x, w, trans_w=False):
@@ -134,11 +149,12 @@ def lds_linear(x, w, bias=None, epilogue=EPI_BIAS, trans_w=False, aux_in=None, w
     aux = aux_in if aux_in is not None else pre
     if aux is not None and (aux.stride(1) != 1 or aux.data_ptr() % 16 or aux.stride(0) % 4):
         raise RuntimeError('sst_amd.dense.lds_linear: aux tensor must be row-major and 16-byte aligned')
-    rc = _lib.load().sst_tall_linear_epi_f32(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), int(trans_w), _lib.ptr(bias),
-                                             m, k, n, int(epilogue), _lib.ptr(aux_in), _lib.ptr(pre),
-                                             aux.stride(0) if aux is not None else 0, _lib.ptr(y), y.stride(0),
-                                             _lib.stream_ptr())
-    _lib.check(rc, 'sst_tall_linear_epi_f32')
+    lib = _lib.load()
+    entry = lib.sst_tall_linear_epi_f32x3 if _MATMUL_MODE == 'f32x3' else lib.sst_tall_linear_epi_f32
+    rc = entry(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), int(trans_w), _lib.ptr(bias), m, k, n, int(epilogue),
+               _lib.ptr(aux_in), _lib.ptr(pre), aux.stride(0) if aux is not None else 0, _lib.ptr(y), y.stride(0),
+               _lib.stream_ptr())
+    _lib.check(rc, 'sst_tall_linear_epi_' + _MATMUL_MODE)
     return (y, pre) if want_pre else y
 
 
@@ -263,12 +279,14 @@ def lds_linear_add_ln(x, w, bias, res, ln_weight, ln_bias, eps, save_sum=True, p
     s = torch.empty((m, 128), dtype=torch.float32, device=x.device) if save_sum else None
     stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
     yp = torch.empty((m, 128), dtype=torch.float32, device=x.device) if pos is not None else None
-    rc = _lib.load().sst_tall_linear_ln_f32(
+    lib = _lib.load()
+    entry = lib.sst_tall_linear_ln_f32x3 if _MATMUL_MODE == 'f32x3' else lib.sst_tall_linear_ln_f32
+    rc = entry(
         _lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), m, k, _lib.ptr(res), 128, _lib.ptr(ln_weight),
         _lib.ptr(ln_bias), float(eps), _lib.ptr(y), _lib.ptr(s), _lib.ptr(stats),
         _lib.ptr(pos[0]) if pos is not None else None, _lib.ptr(pos[1]) if pos is not None else None, _lib.ptr(yp),
         _lib.stream_ptr())
-    _lib.check(rc, 'sst_tall_linear_ln_f32')
+    _lib.check(rc, 'sst_tall_linear_ln_' + _MATMUL_MODE)
     return y, s, stats, yp
 
 

@@ -1,0 +1,119 @@
+"""GPU: the split-precision linears (csrc/dense_f32x3.hip: x w ~= x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix pipe,
+fp32 accumulation) against float64 and against the exact-fp32 kernels of csrc/dense_f32.hip - every shape, both weight
+orientations, every epilogue; error bound 3e-5 of the output scale (measured ~5e-6), i.e. two orders inside the 1e-3 parity
+bar and tighter than the TF32 products (10-bit mantissas, ~5e-4) the reference's torch 1.8 used for the same layers on Ampere.
+Then one SST block in the mode against the exact-fp32 block and the reference golden."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import DROP_TEST, DROP_TRAIN, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SHAPES = [(128, 128), (128, 256), (256, 128)]
+
+
+@pytest.fixture
+def x3():
+    from sst_amd import dense
+    dense.set_matmul_mode('f32x3')
+    yield dense
+    dense.set_matmul_mode('f32')
+
+
+@pytest.mark.parametrize('m', [1, 77, 5000, 90107])
+@pytest.mark.parametrize('k,n', SHAPES)
+@pytest.mark.parametrize('trans_w', [False, True])
+def test_linear_all_epilogues_vs_float64(x3, m, k, n, trans_w):
+    D = x3
+    g = torch.Generator().manual_seed(m + k + 2 * n + int(trans_w))
+    x = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn((k, n) if trans_w else (n, k), generator=g) * 0.2).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    aux = torch.randn(m, n, generator=g).to(DEV)
+    ref = x.double() @ (w.double() if trans_w else w.double().t()) + b.double()
+    scale = max(1.0, float(ref.abs().max()))
+
+    def close(got, want, tol=3e-5):
+        err = float((got.double() - want).abs().max())
+        assert err <= tol * scale, (err, scale)
+
+    close(D.lds_linear(x, w, b, D.EPI_BIAS, trans_w), ref)
+    y, pre = D.lds_linear(x, w, b, D.EPI_GELU, trans_w, want_pre=True)
+    close(pre, ref)
+    close(y, torch.nn.functional.gelu(ref), 5e-5)
+    y, pre = D.lds_linear(x, w, b, D.EPI_RELU, trans_w, want_pre=True)
+    close(y, torch.relu(ref))
+    gp = torch.nn.functional.gelu
+    ad = aux.double().requires_grad_(True)
+    gp(ad).sum().backward()
+    close(D.lds_linear(x, w, b, D.EPI_MUL_GELU_GRAD, trans_w, aux_in=aux), ref * ad.grad, 5e-5)
+    close(D.lds_linear(x, w, b, D.EPI_MUL_RELU_GRAD, trans_w, aux_in=aux), ref * (aux.double() > 0))
+    close(D.lds_linear(x, w, b, D.EPI_ADD, trans_w, aux_in=aux), ref + aux.double())
+    # beside the exact-fp32 kernel: the two agree far inside the bar, and f32x3 is not bit-identical to it (it really ran)
+    D.set_matmul_mode('f32')
+    exact = D.lds_linear(x, w, b, D.EPI_BIAS, trans_w)
+    D.set_matmul_mode('f32x3')
+    split = D.lds_linear(x, w, b, D.EPI_BIAS, trans_w)
+    assert float((exact - split).abs().max()) <= 3e-5 * scale
+    if m >= 77:
+        assert not torch.equal(exact, split)
+
+
+@pytest.mark.parametrize('m', [1, 77, 5000, 90107])
+@pytest.mark.parametrize('k', [128, 256])
+def test_linear_add_layernorm_vs_float64(x3, m, k):
+    D = x3
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn(128, k, generator=g) * 0.2).to(DEV)
+    b, lw, lb = (torch.randn(128, generator=g).to(DEV) for _ in range(3))
+    res = torch.randn(m, 128, generator=g).to(DEV)
+    table = torch.randn(144, 128, generator=g).to(DEV)
+    idx = torch.randint(0, 144, (m,), generator=g, dtype=torch.int32).to(DEV)
+    y, s, stats, yp = D.lds_linear_add_ln(x, w, b, res, lw, lb, 1e-5, pos=(table, idx))
+    ssum = x.double() @ w.double().t() + b.double() + res.double()
+    ref = torch.nn.functional.layer_norm(ssum, (128,), lw.double(), lb.double(), 1e-5)
+    assert float((s.double() - ssum).abs().max()) <= 3e-5 * max(1.0, float(ssum.abs().max()))
+    assert float((y.double() - ref).abs().max()) <= 1e-4
+    assert float((yp.double() - (ref + table.double()[idx.long()])).abs().max()) <= 1e-4
+    mean, var = ssum.mean(1), ssum.var(1, unbiased=False)
+    assert float((stats[:, 0].double() - mean).abs().max()) <= 1e-4
+    assert float((stats[:, 1].double() * torch.sqrt(var + 1e-5) - 1).abs().max()) <= 1e-4
+
+
+def test_sst_block_f32x3_vs_exact_and_reference_golden():
+    """one BasicShiftBlockV2 (two encoder layers), forward + backward: 'f32x3' against the exact-fp32 mode of this library and
+    against the golden produced by the reference's own SSTv2 - inside the 1e-3 bar of the north star on both"""
+    import sst_amd
+    g = load_golden('sst_block_std.npz')
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128], nhead=[8], num_blocks=1, dim_feedforward=[256],
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=True))
+    net.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}, strict=True)
+    net = net.to(DEV).train()
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
+                                    debug=True, mute=True, reference_outputs=False)
+    layer.eval()
+    coors = torch.from_numpy(g['in::voxel_coors']).to(DEV)
+    up = torch.from_numpy(g['in::grad_out']).to(DEV)
+    outs = {}
+    try:
+        for mode in ('fp32', 'f32x3'):
+            net.set_precision(mode)
+            net.zero_grad(set_to_none=True)
+            feats = torch.from_numpy(g['in::voxel_feats']).to(DEV).requires_grad_(True)
+            out = net(layer(feats, coors, 2))[0]['voxel_feats']
+            (out * up).sum().backward()
+            outs[mode] = (out.detach().clone(), feats.grad.clone(),
+                          {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        net.set_precision('fp32')
+    (o32, g32, p32), (ox3, gx3, px3) = outs['fp32'], outs['f32x3']
+    assert float((o32 - ox3).abs().max()) <= 1e-4 and not torch.equal(o32, ox3)
+    assert np.abs(ox3.cpu().numpy() - g['out::voxel_feats']).max() <= 1e-4
+    sc = max(1.0, float(np.abs(g['out::grad_in']).max()))
+    assert np.abs(gx3.cpu().numpy() - g['out::grad_in']).max() <= 2e-4 * sc
+    for name, grad in px3.items():
+        s_ = max(1.0, float(p32[name].abs().max()))
+        assert float((grad - p32[name]).abs().max()) <= 3e-4 * s_, name
