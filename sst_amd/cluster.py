@@ -112,27 +112,50 @@ class ClusterAssigner(torch.nn.Module):
         return cluster_inds_list, [o[1] for o in outs]
 
     def forward_single_class(self, points, batch_idx, class_name, origin_points):
+        """One class: cluster-voxel grouping of the voted centres -> centroids of the voxels with at least ``min_points``
+        votes -> connected components of the centroids -> every surviving point inherits its voxel's component
+        (single_stage_fsd.py:953-999).  ONE sorted-unique grouping serves the occupancy filter, the centroid reduction and
+        the point -> centroid map (the reference groups the same keys three times: filter_almost_empty, scatter_v2 and its
+        inverse), and the two data-dependent lengths (surviving points, surviving voxels) are read back together."""
+        dev = points.device
         batch_idx = batch_idx.int()
-        voxel_size = torch.tensor(self._per_class(self.cluster_voxel_size, class_name), device=points.device)
-        pc_range = torch.tensor(self.point_cloud_range, device=points.device)
-        coors = torch.div(points - pc_range[None, :3], voxel_size[None, :], rounding_mode='floor').int()
-        coors = torch.cat([batch_idx[:, None], coors], dim=1)
-
-        valid_mask = filter_almost_empty(coors, min_points=self.min_points)
-        if not valid_mask.any():
-            valid_mask = ~valid_mask
-        points = points[valid_mask]
-        batch_idx = batch_idx[valid_mask]
-        coors = coors[valid_mask]
-
-        sampled_centers, voxel_coors, inv_inds = scatter_v2(points, coors, mode='avg', return_inv=True)
+        cell = points.new_tensor(self._per_class(self.cluster_voxel_size, class_name))
+        origin = points.new_tensor(self.point_cloud_range[:3])
+        cells = torch.cat([batch_idx[:, None], torch.div(points - origin, cell, rounding_mode='floor').int()], dim=1)
+        n = points.size(0)
+        if n == 0:
+            empty = torch.zeros((0, 2), dtype=torch.int32, device=dev)
+            return empty, torch.zeros(0, dtype=torch.bool, device=dev)
+        groups = K.unique_rows(cells.contiguous())
+        occupancy = groups.counts()                                         # votes per cluster voxel, sorted-voxel order
+        crowded = occupancy >= self.min_points
+        point_group = groups.inverse.long()
+        valid_mask = crowded[point_group]
+        sizes = torch.stack([valid_mask.sum(), crowded.sum()]).tolist()     # the one read-back of this class
+        if sizes[0] == 0:
+            # nothing survives the filter: the reference then keeps EVERY point (valid_mask = ~valid_mask, :968-970)
+            valid_mask = torch.ones_like(valid_mask)
+            crowded = torch.ones_like(crowded)
+            sizes = [n, groups.m]
+        keep_points = _nonzero_known(valid_mask, sizes[0])
+        keep_groups = _nonzero_known(crowded, sizes[1])
+        # centroids of the surviving voxels: the mean over ALL votes of a voxel (a voxel survives or falls as a whole)
+        centroids = K.segment_reduce(points.float().contiguous(), groups, 'mean').index_select(0, keep_groups)
+        centroid_sample = K.unpack_unique_rows(groups, torch.int32).index_select(0, keep_groups)[:, 0]
         dist = self._per_class(self.connected_dist, class_name)
         if self.training:
-            cluster_inds = find_connected_componets(sampled_centers, voxel_coors[:, 0], dist)
+            component = connected_components_xy(centroids, centroid_sample, dist)   # sorted-unique order = sample after sample
         else:
             # the reference's test path clusters all samples as one graph (both of its variants, :36-43 / :70-84)
-            cluster_inds = find_connected_componets_single_batch(sampled_centers, voxel_coors[:, 0], dist)
-        assert len(cluster_inds) == len(sampled_centers)
-        cluster_inds_per_point = cluster_inds[inv_inds]
-        cluster_inds_per_point = torch.stack([batch_idx, cluster_inds_per_point], 1)
-        return cluster_inds_per_point, valid_mask
+            component = find_connected_componets_single_batch(centroids, centroid_sample, dist)
+        assert component.numel() == sizes[1]
+        rank_of_group = torch.cumsum(crowded.int(), 0) - 1                   # surviving voxel -> row of `centroids`
+        point_component = component[rank_of_group[point_group[keep_points]].long()]
+        return torch.stack([batch_idx[keep_points], point_component.int()], 1), valid_mask
+
+
+def _nonzero_known(mask, count):
+    """indices of the set entries of a 1-D mask whose number is already on the host: no further read-back"""
+    if hasattr(torch, 'nonzero_static'):
+        return torch.nonzero_static(mask, size=int(count)).squeeze(1)
+    return torch.nonzero(mask).squeeze(1)

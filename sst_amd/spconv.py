@@ -492,42 +492,40 @@ def is_sparse_conv(module):
 
 
 class SparseSequential(SparseModule):
-    """modules.py:42-140: sparse modules get the tensor, everything else its features."""
+    """Ordered container (modules.py:42-140): sparse modules receive the SparseConvTensor, everything else its features.
+    Accepts positional modules, one dict of modules, and keyword modules; children are named '0', '1', ... or by their keys
+    (these names are the ``state_dict`` prefixes of the reference's checkpoints)."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *modules, **named):
         super().__init__()
-        if len(args) == 1 and isinstance(args[0], dict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
+        if len(modules) == 1 and isinstance(modules[0], dict):
+            entries = list(modules[0].items())
         else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if name in self._modules:
+            entries = [(str(position), module) for position, module in enumerate(modules)]
+        for key, module in entries + list(named.items()):
+            if key in self._modules:
                 raise ValueError('name exists.')
-            self.add_module(name, module)
+            self.add_module(key, module)
         self._sparity_dict = {}
-
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError('index {} is out of range'.format(idx))
-        if idx < 0:
-            idx += len(self)
-        return list(self._modules.values())[idx]
 
     def __len__(self):
         return len(self._modules)
+
+    def __getitem__(self, idx):
+        children = list(self._modules.values())
+        if not -len(children) <= idx < len(children):
+            raise IndexError('index {} is out of range'.format(idx))
+        return children[idx]
 
     @property
     def sparity_dict(self):
         return self._sparity_dict
 
     def add(self, module, name=None):
-        if name is None:
-            name = str(len(self._modules))
-            if name in self._modules:
-                raise KeyError('name exists')
-        self.add_module(name, module)
+        key = str(len(self._modules)) if name is None else name
+        if name is None and key in self._modules:
+            raise KeyError('name exists')
+        self.add_module(key, module)
 
     def forward(self, input):
         from .norm import batch_norm_act
