@@ -659,11 +659,17 @@ int sst_spconv_maxpool_bwd_f32(const float* d_x, int64_t ldx, const float* d_y, 
  *     order (d_workspace, sst_spconv_conv_os_workspace_bytes) and staged through LDS, partner rows gathered straight into
  *     MFMA operands, XCD-aware tile numbering (csrc/spconv_os.hip).  K <= 32, cin % 4 == 0, ldx % 4 == 0, d_x 16-byte
  *     aligned; SST_ERR_UNSUPPORTED otherwise (use sst_spconv_gather_gemm_f32).  trans_w as above.  tile_cfg: 0 = tile
- *     shape chosen from m and cout, else 10 * (column tiles of 16: 4 | 8) + (16-row blocks per wave: 1 | 2). */
+ *     shape chosen from m and cout, else 10 * (column tiles of 16: 4 | 8) + (16-row blocks per wave: 1 | 2).
+ *     d_tile_order (may be NULL): a permutation of the ceil(m / tile_rows) row tiles, the order in which they are launched -
+ *     heaviest first evens out the end of the launch; tile_rows = sst_spconv_conv_os_tile_rows(m, cout, tile_cfg) (64 or
+ *     128), and sst_spconv_os_tile_work_i32 writes work[tile] = populated (16-row block, offset) slots of the tile, the key
+ *     to sort by (descending).  The result does not depend on the order. */
 int64_t sst_spconv_conv_os_workspace_bytes(int kvol, int cin, int cout);
+int sst_spconv_conv_os_tile_rows(int64_t m, int cout, int tile_cfg);
+int sst_spconv_os_tile_work_i32(const int32_t* d_map, int64_t m, int kvol, int tile_rows, int32_t* d_work, void* stream);
 int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
                            int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy,
-                           int tile_cfg, void* d_workspace, void* stream);
+                           int tile_cfg, const int32_t* d_tile_order, void* d_workspace, void* stream);
 /*   sst_spconv_wgrad_os_f32: the same filter gradient as sst_spconv_wgrad_f32 (indiceConvBackward, spconv_ops.h:359-446)
  *     with the gathered rows staged through LDS transposed, 64 x 64 blocks of dW[k], 2048-pair chunks (csrc/spconv_os.hip).
  *     cin % 4 == 0, cout % 4 == 0, row strides % 4 == 0, 16-byte aligned operands; SST_ERR_UNSUPPORTED otherwise. */

@@ -23,8 +23,16 @@
 //   * loads are unconditional (absent partners read row 0 and are zeroed by a select, channel tails read a clamped
 //     address against zero weights), so the compiler's s_waitcnt bookkeeping stays static (DESIGN.md, round-2 finding);
 //   * offsets without a partner in the workgroup's rows are never staged; a wave whose own rows have none skips the MFMAs;
-//   * XCD-aware numbering: workgroup b runs on XCD b % 8, so XCD i is handed the i-th CONTIGUOUS eighth of the row
-//     tiles: its 4 MB L2 then sees one eighth of X plus halo instead of all of it.
+//   * XCD-aware numbering: workgroup b runs on XCD b % 8.  Runs of kOsXcdChunk consecutive units go to one XCD (their
+//     halos overlap in its L2), the runs round-robin over the XCDs.  NOT one contiguous eighth of the rows per XCD: with
+//     voxels numbered by (b, z, y, x) the work per tile follows z - on the top level of FSD's U-Net the ground slab is
+//     3/4 of the rows with 4-5 partners each, the objects above it have 15+, and the last two XCDs were handed 2.3 x the
+//     MFMA work of the others (the launch took as long as they did);
+//   * tiles are LAUNCHED in the order of decreasing work when the caller passes the permutation computed from
+//     sp_os_tile_work_k (once per rulebook and map): workgroups are dispatched in blockIdx order, the work of a tile
+//     varies 6 .. 27 staged offsets on that level, and in row order the heavy tiles - the objects, at the highest z -
+//     came last, so the launch ended with a few long workgroups on an otherwise empty chip (CUs busy 55 % of the launch:
+//     SQ_BUSY_CU_CYCLES; 292 -> 182 us together with the point above).
 #include <stdlib.h>
 
 #include "common.h"
@@ -35,6 +43,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kOsMaxK = 32;   // kernel offsets the index image holds (3 x 3 x 3 = 27)
 constexpr int kOsChunk = 64;  // input channels per stage
+constexpr int kOsXcdChunk = 4;  // consecutive units handed to one XCD
 
 // Packed weights: slab (k, column group cg, channel chunk cc) = [4 j][NCT ct][64 lanes][4 t] floats with
 //   value = W[k][c = 64 cc + 16 j + 4 (lane >> 4) + t][n = 16 NCT cg + 16 ct + (lane & 15)]   (0 outside cin x cout),
@@ -65,25 +74,27 @@ __global__ __launch_bounds__(256) void sp_os_pack_w_k(const float* __restrict__ 
 }
 
 template <int NCT, int RB>
-__global__ __launch_bounds__(256) void sp_conv_os_k(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os_k(const float* __restrict__ x, int64_t ldx,
                                                     const int32_t* __restrict__ map, int64_t m, int kvol,
                                                     const float* __restrict__ wp, int cin, int cout,
                                                     const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
-                                                    int n_units, int n_cg, int n_cc, int units_per_xcd, int vec_store) {
+                                                    int n_units, int n_cg, int n_cc, int xcd_chunk, int vec_store,
+                                                    const int32_t* __restrict__ tile_order) {
   constexpr int ROWS = 64 * RB;          // rows of the workgroup: 4 waves x RB blocks of 16
   constexpr int SLAB = 64 * 16 * NCT;    // floats of one packed W slab
   constexpr int WREG = SLAB / 4 / 256;   // 16-byte pieces of a slab per thread
   extern __shared__ __attribute__((aligned(16))) float os_smem[];
   float (*wbuf)[SLAB] = (float (*)[SLAB])os_smem;                      // [2][SLAB]
-  int (*idx)[ROWS] = (int (*)[ROWS])(os_smem + 2 * SLAB);              // [kOsMaxK][ROWS]
-  unsigned* live_w = (unsigned*)(os_smem + 2 * SLAB + kOsMaxK * ROWS);  // [4]
+  int (*idx)[ROWS] = (int (*)[ROWS])(os_smem + 2 * SLAB);              // [kvol][ROWS]
+  unsigned* live_w = (unsigned*)(os_smem + 2 * SLAB + kvol * ROWS);     // [4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
   // ---- which (row tile, column group) ----
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int unit = xcd * units_per_xcd + slot;
+  const int unit = ((slot / xcd_chunk) * 8 + xcd) * xcd_chunk + slot % xcd_chunk;
   if (unit >= n_units) return;  // uniform
-  const int tile = unit / n_cg, cg = unit - tile * n_cg;
+  const int pos = unit / n_cg, cg = unit - pos * n_cg;
+  const int tile = tile_order ? tile_order[pos] : pos;   // heaviest tiles first (sst_spconv_os_tile_work_i32)
   const int64_t r0 = (int64_t)tile * ROWS;
   // ---- partner rows of the tile for every offset -> LDS; which offsets are populated ----
   for (int e = tid; e < kvol * ROWS; e += 256) {
@@ -221,6 +232,26 @@ __global__ __launch_bounds__(256) void sp_conv_os_k(const float* __restrict__ x,
       }
     }
   }
+}
+
+// work[tile] = number of (16-row block, offset) slots of the tile with at least one partner: the MFMA work of the tile in
+// units of 16 rows x one offset.  One wave per tile.
+__global__ __launch_bounds__(256) void sp_os_tile_work_k(const int32_t* __restrict__ map, int64_t m, int kvol,
+                                                         int tile_rows, int64_t n_tiles, int32_t* __restrict__ work) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;  // uniform per wave
+  const int64_t r0 = tile * tile_rows;
+  int slots = 0;
+  for (int k = 0; k < kvol; ++k)
+    for (int r = 0; r < tile_rows; r += 64) {
+      const int64_t row = r0 + r + lane;
+      const bool has = row < m && map[(int64_t)k * m + row] >= 0;
+      const unsigned long long b = __ballot(has);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) slots += ((b >> (16 * q)) & 0xffffull) != 0ull ? 1 : 0;
+    }
+  if (lane == 0) work[tile] = slots;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -395,8 +426,10 @@ struct os_cfg {
   int64_t n_tiles;
 };
 
-// tile shape of a call: 128 rows x 128 columns when that still gives the 256 CUs a few workgroups each, smaller tiles
-// for the deep levels of a U-Net (3 k - 12 k voxels x 128 - 256 channels), where the large ones would leave CUs idle
+// tile shape of a call.  64-row workgroups (one 16-row block per wave) everywhere: they run 4 per CU (109 VGPRs, 40 KB of
+// LDS) where the 128-row form runs 3, have twice as many workgroups to balance, and measured 10-30 % faster on every level
+// of FSD's U-Net although they stage W twice as often; 128 columns per workgroup only while that still leaves a few
+// workgroups per CU
 os_cfg os_pick(int64_t m, int cout, int tile_cfg) {
   static int env_cfg = -1;  // SST_SPCONV_OS_TILE = 10 * NCT + RB overrides the automatic choice (A/B measurements)
   if (env_cfg < 0) {
@@ -407,10 +440,9 @@ os_cfg os_pick(int64_t m, int cout, int tile_cfg) {
   const int env_nct = tile_cfg / 10, env_rb = tile_cfg % 10;
   os_cfg c;
   c.nct = cout <= 64 ? 4 : 8;
-  c.rb = 2;
+  c.rb = 1;
   auto units = [&](int nct, int rb) { return sst_div_up(m, 64 * rb) * sst_div_up(cout, 16 * nct); };
-  if (units(c.nct, 2) < 1024) c.rb = 1;
-  if (c.nct == 8 && units(8, c.rb) < 512) c.nct = 4;
+  if (c.nct == 8 && units(8, c.rb) < 2048) c.nct = 4;
   if (env_nct == 4 || env_nct == 8) c.nct = env_nct;
   if (env_rb == 1 || env_rb == 2) c.rb = env_rb;
   c.n_cg = (int)sst_div_up(cout, 16 * c.nct);
@@ -431,7 +463,7 @@ int64_t sst_spconv_conv_os_workspace_bytes(int kvol, int cin, int cout) {
 
 int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
                            int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy,
-                           int tile_cfg, void* d_workspace, void* stream) {
+                           int tile_cfg, const int32_t* d_tile_order, void* d_workspace, void* stream) {
   if (m < 0 || kvol < 1 || cin < 1 || cout < 1 || ldx < cin || ldy < cout) return SST_ERR_ARG;
   if (tile_cfg != 0 && tile_cfg != 41 && tile_cfg != 42 && tile_cfg != 81 && tile_cfg != 82) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
@@ -447,19 +479,26 @@ int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, 
   const int64_t packed = (int64_t)kvol * c.n_cg * n_cc * 64 * 16 * c.nct;
   hipLaunchKernelGGL(sp_os_pack_w_k, dim3(sst_grid_1d(packed, 256)), dim3(256), 0, st, d_w, kvol, cin, cout, trans_w,
                      c.nct, c.n_cg, n_cc, wp);
-  const int units_per_xcd = (int)sst_div_up(n_units, 8);
-  const dim3 grid((unsigned)(8 * units_per_xcd));
+  static int xcd_chunk = -1;  // SST_SPCONV_OS_XCD_CHUNK: units per run (A/B measurements)
+  if (xcd_chunk < 0) {
+    const char* e = getenv("SST_SPCONV_OS_XCD_CHUNK");
+    xcd_chunk = e && atoi(e) > 0 ? atoi(e) : kOsXcdChunk;
+  }
+  const int chunk = n_units >= 64 * (int64_t)xcd_chunk ? xcd_chunk : 1;
+  const dim3 grid((unsigned)(sst_div_up(n_units, 8 * chunk) * 8 * chunk));
   const int vec_store = ((ldy & 3) == 0 && (((uintptr_t)d_y) & 15) == 0 && (!d_bias || (((uintptr_t)d_bias) & 15) == 0)) ? 1 : 0;
 #define SST_OS_LAUNCH(NCT, RB)                                                                                         \
   do {                                                                                                                 \
-    constexpr int lds = (2 * 64 * 16 * NCT + kOsMaxK * 64 * RB + 4) * (int)sizeof(float);                              \
+    constexpr int lds_max = (2 * 64 * 16 * NCT + kOsMaxK * 64 * RB + 4) * (int)sizeof(float);                          \
+    const int lds = (2 * 64 * 16 * NCT + kvol * 64 * RB + 4) * (int)sizeof(float);                                     \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
-      SST_HIP(hipFuncSetAttribute((const void*)sp_conv_os_k<NCT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+      SST_HIP(hipFuncSetAttribute((const void*)sp_conv_os_k<NCT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                  lds_max));                                                                           \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((sp_conv_os_k<NCT, RB>), grid, dim3(256), lds, st, d_x, ldx, d_map, m, kvol, wp, cin, cout,     \
-                       d_bias, d_y, ldy, (int)n_units, c.n_cg, n_cc, units_per_xcd, vec_store);                        \
+                       d_bias, d_y, ldy, (int)n_units, c.n_cg, n_cc, chunk, vec_store, d_tile_order);                        \
   } while (0)
   if (c.nct == 4 && c.rb == 2)
     SST_OS_LAUNCH(4, 2);
@@ -470,6 +509,22 @@ int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, 
   else
     SST_OS_LAUNCH(8, 1);
 #undef SST_OS_LAUNCH
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_spconv_conv_os_tile_rows(int64_t m, int cout, int tile_cfg) {
+  if (m < 0 || cout < 1) return SST_ERR_ARG;
+  return 64 * os_pick(m, cout, tile_cfg).rb;
+}
+
+int sst_spconv_os_tile_work_i32(const int32_t* d_map, int64_t m, int kvol, int tile_rows, int32_t* d_work, void* stream) {
+  if (m < 0 || kvol < 1 || (tile_rows != 64 && tile_rows != 128)) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_map || !d_work) return SST_ERR_ARG;
+  const int64_t n_tiles = sst_div_up(m, tile_rows);
+  hipLaunchKernelGGL(sp_os_tile_work_k, dim3((unsigned)sst_div_up(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, d_map, m,
+                     kvol, tile_rows, n_tiles, d_work);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -115,7 +115,25 @@ class Rulebook(object):
     The pair-list tensor carries its Rulebook as an attribute (it rides along wherever the reference passes
     ``indice_pairs`` around); the Rulebook refers back to the tensor only weakly, so the pair lists and the two dense
     maps (~4 K n int32 each) are released by reference counting as soon as the tensor is, not by the cycle collector."""
-    __slots__ = ('in2out', 'out2in', '_pairs_ref', 'num', 'n', 'm', 'kvol', '_total')
+    __slots__ = ('in2out', 'out2in', '_pairs_ref', 'num', 'n', 'm', 'kvol', '_total', '_orders')
+
+    def tile_order(self, mapping, rows, tile_rows):
+        """launch order of the row tiles of the output-stationary kernel for one of the two maps: heaviest tile first
+        (csrc/spconv_os.hip; two small launches + a sort ONCE per rulebook, map and tile height - a submanifold rulebook
+        serves every convolution of its level, forward and backward)"""
+        if getattr(self, '_orders', None) is None:
+            self._orders = {}
+        key = (mapping.data_ptr(), tile_rows)
+        order = self._orders.get(key)
+        if order is None:
+            lib = _lib.load()
+            work = torch.empty(-(-rows // tile_rows), dtype=torch.int32, device=mapping.device)
+            rc = lib.sst_spconv_os_tile_work_i32(_lib.ptr(mapping), rows, mapping.size(0), tile_rows, _lib.ptr(work),
+                                                 _lib.stream_ptr())
+            _lib.check(rc, 'sst_spconv_os_tile_work_i32')
+            order = torch.sort(work, descending=True, stable=True)[1].to(torch.int32)
+            self._orders[key] = order
+        return order
 
     def known_total_pairs(self):
         """the pair count if somebody has read it back already, else -1 (callers then size by the upper bound K x n)"""
@@ -276,6 +294,13 @@ def _conv_kernel_choice():
     return os.environ.get('SST_SPCONV_KERNEL', 'os')
 
 
+_OS_ORDER_MIN_ROWS = 16384   # below: fewer tiles than workgroup slots on the chip, the order cannot matter
+
+
+def _os_tile_order_enabled():
+    return os.environ.get('SST_SPCONV_OS_ORDER', '1') != '0'
+
+
 def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cfg=0):
     # density: a number, None, or the Rulebook (its `density` costs a host read-back: only the legacy path asks for it)
     """Y[r] = sum_k X[mapping[k][r]] W[k]; weight3 is [K, cin, cout], or [K, cout, cin] with trans_w."""
@@ -291,9 +316,12 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cf
     if (_conv_kernel_choice() == 'os' and kvol <= 32 and cin % 4 == 0 and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0):
         ws = _lib.workspace(lib.sst_spconv_conv_os_workspace_bytes(kvol, cin, cout), x.device)
+        order = None
+        if isinstance(density, Rulebook) and rows >= _OS_ORDER_MIN_ROWS and _os_tile_order_enabled():
+            order = density.tile_order(mapping, rows, lib.sst_spconv_conv_os_tile_rows(rows, cout, int(tile_cfg)))
         rc = lib.sst_spconv_conv_os_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin,
-                                        cout, int(trans_w), None, _lib.ptr(y), y.stride(0), int(tile_cfg), _lib.ptr(ws),
-                                        _lib.stream_ptr())
+                                        cout, int(trans_w), None, _lib.ptr(y), y.stride(0), int(tile_cfg),
+                                        _lib.ptr(order) if order is not None else None, _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, 'sst_spconv_conv_os_f32')
         return y
     # first-generation kernels: compacted rows pay off when few offsets are populated or one 64-column group covers the

@@ -99,6 +99,36 @@ def test_output_stationary_kernel_every_tile_shape(tile_cfg, cin, cout):
         assert np.abs(dx.cpu().numpy() - dx_ref).max() < 1e-4 * max(1.0, np.abs(dx_ref).max())
 
 
+@pytest.mark.parametrize('tile_cfg', [41, 82])
+def test_output_stationary_kernel_launch_order(tile_cfg, monkeypatch):
+    """the heaviest-first launch order of the row tiles (csrc/spconv_os.hip, sp_os_tile_work_k + a sort, cached on the
+    rulebook): the work figures equal a numpy count of the populated (16-row block, offset) slots, the order is a
+    permutation by decreasing work, and the contraction gives bit for bit what it gives in row order."""
+    from sst_amd import spconv, _lib
+    rng = np.random.default_rng(tile_cfg)
+    batch, shape, n, cin, cout = 2, [6, 40, 44], 5000, 32, 64 if tile_cfg == 41 else 128
+    ind = _cloud(rng, n, batch, shape)
+    _, _, _, rb = _rulebook(ind, batch, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True, False)
+    lib = _lib.load()
+    rows = lib.sst_spconv_conv_os_tile_rows(n, cout, tile_cfg)
+    assert rows == 64 * (tile_cfg % 10)
+    order = rb.tile_order(rb.out2in, n, rows)
+    n_tiles = -(-n // rows)
+    live = rb.out2in.cpu().numpy() >= 0
+    live = np.pad(live, ((0, 0), (0, n_tiles * rows - n))).reshape(27, n_tiles, rows // 16, 16).any(-1)
+    work = live.sum((0, 2))
+    o = order.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(n_tiles))
+    assert (np.diff(work[o]) <= 0).all() and work.max() > work.min()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, generator=gen).to(DEV)
+    w = (torch.randn(27, cin, cout, generator=gen) * 0.2).to(DEV)
+    y_rows = spconv._gather_gemm(x, rb.out2in, n, w, False, cout, rb.density, tile_cfg)
+    monkeypatch.setattr(spconv, '_OS_ORDER_MIN_ROWS', 0)
+    y_ordered = spconv._gather_gemm(x, rb.out2in, n, w, False, cout, rb, tile_cfg)
+    assert torch.equal(y_rows, y_ordered)
+
+
 def test_inverse_conv_matches_oracle_and_modules_chain():
     """SubMConv3d -> SparseConv3d (stride 2, indice_key) -> SubMConv3d -> SparseInverseConv3d back to the input voxels
     (the down / up pattern of middle_encoders/sparse_unet.py), forward and all gradients against the oracle."""

@@ -80,8 +80,8 @@ def main():
         res = {}
         for tag, kern in (('os', 'os'), ('old', 'legacy')):
             os.environ['SST_SPCONV_KERNEL'] = kern
-            res['f_' + tag] = timeit(lambda: SP._gather_gemm(x, fmap, frows, w3, False, cout, rb.density))
-            res['d_' + tag] = timeit(lambda: SP._gather_gemm(gy, dmap, drows, w3, True, cin, rb.density))
+            res['f_' + tag] = timeit(lambda: SP._gather_gemm(x, fmap, frows, w3, False, cout, rb))
+            res['d_' + tag] = timeit(lambda: SP._gather_gemm(gy, dmap, drows, w3, True, cin, rb))
             res['wg' + ('' if tag == 'os' else '_old')] = timeit(lambda: SP._wgrad(x, gy, rb, L['pairs'], x_side, mod.weight.shape))
         os.environ['SST_SPCONV_KERNEL'] = 'os'
         fl = 2.0 * rb.total_pairs * cin * cout
