@@ -41,6 +41,43 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Debug instrumentation (build with -DSST_OS_TIMING, see tools/conv_os_phases.py): per-wave phase times of sp_conv_os_k
+// in ticks of the constant 100 MHz clock.  Compiled out of the product library.
+#ifdef SST_OS_TIMING
+constexpr int kOsTsUnits = 4096, kOsTsSlots = 16;
+__device__ unsigned long long g_os_ts[kOsTsUnits * 4 * kOsTsSlots];
+#define OS_TS_DECL unsigned long long ts_prev_ = 0, ts_acc_[4] = {0, 0, 0, 0}; unsigned ts_n_[2] = {0, 0}
+#define OS_NOW() wall_clock64()
+#define OS_MARK(i)                                                                                                   \
+  do {                                                                                                               \
+    if (lane == 0 && unit < kOsTsUnits) g_os_ts[(unit * 4 + wave) * kOsTsSlots + (i)] = OS_NOW();                    \
+  } while (0)
+#define OS_LAP_START() ts_prev_ = OS_NOW()
+#define OS_LAP(j)                                                                                                    \
+  do {                                                                                                               \
+    const unsigned long long now_ = OS_NOW();                                                                        \
+    ts_acc_[j] += now_ - ts_prev_;                                                                                   \
+    ts_prev_ = now_;                                                                                                 \
+  } while (0)
+#define OS_COUNT(j) ++ts_n_[j]
+#define OS_FLUSH()                                                                                                   \
+  do {                                                                                                               \
+    if (lane == 0 && unit < kOsTsUnits) {                                                                            \
+      unsigned long long* t_ = g_os_ts + (unit * 4 + wave) * kOsTsSlots;                                             \
+      for (int j_ = 0; j_ < 4; ++j_) t_[8 + j_] = ts_acc_[j_];                                                       \
+      t_[12] = ts_n_[0];                                                                                             \
+      t_[13] = ts_n_[1];                                                                                             \
+    }                                                                                                                \
+  } while (0)
+#else
+#define OS_TS_DECL
+#define OS_MARK(i)
+#define OS_LAP_START()
+#define OS_LAP(j)
+#define OS_COUNT(j)
+#define OS_FLUSH()
+#endif
+
 constexpr int kOsMaxK = 32;   // kernel offsets the index image holds (3 x 3 x 3 = 27)
 constexpr int kOsChunk = 64;  // input channels per stage
 constexpr int kOsXcdChunk = 4;  // consecutive units handed to one XCD
@@ -96,21 +133,45 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
   const int pos = unit / n_cg, cg = unit - pos * n_cg;
   const int tile = tile_order ? tile_order[pos] : pos;   // heaviest tiles first (sst_spconv_os_tile_work_i32)
   const int64_t r0 = (int64_t)tile * ROWS;
-  // ---- partner rows of the tile for every offset -> LDS; which offsets are populated ----
-  for (int e = tid; e < kvol * ROWS; e += 256) {
-    const int k = e / ROWS, row = e - k * ROWS;
-    idx[k][row] = (r0 + row < m) ? map[(int64_t)k * m + r0 + row] : -1;
-  }
+  OS_TS_DECL;
+  OS_MARK(0);
+  // ---- partner rows of the tile for every offset -> LDS; which offsets are populated, per wave (ONE pass: a wave loads
+  // 64 consecutive rows of one offset per step, so a ballot tells for every 16-row block whether that offset has a partner)
+  if (tid < 4) live_w[tid] = 0u;
   __syncthreads();
   {
-    unsigned mine = 0;
-    for (int k = 0; k < kvol; ++k) {
-      const int v = lane < 16 * RB ? idx[k][wave * 16 * RB + lane] : -1;
-      mine |= (__ballot(v >= 0) != 0ull ? 1u : 0u) << k;
+    unsigned mine[4] = {0u, 0u, 0u, 0u};   // bit k of mine[v]: wave v multiplies offset k (as far as THIS wave has seen)
+    for (int e0 = 0; e0 < kvol * ROWS; e0 += 256) {
+      const int e = e0 + tid;
+      const int k = e / ROWS, row = e - k * ROWS;   // uniform k per wave (ROWS is a multiple of 64)
+      int v = -1;
+      if (k < kvol) {
+        v = (r0 + row < m) ? map[(int64_t)k * m + r0 + row] : -1;
+        idx[k][row] = v;
+      }
+      const unsigned long long b = __ballot(v >= 0);
+      const int kk = k < kvol ? k : 0;
+      const int first_blk = (row & ~63) / 16;        // the 4 sixteen-row blocks this wave's 64 rows cover
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int owner = (first_blk + q) / RB;      // wave that owns the block
+        if ((b >> (16 * q)) & 0xffffull) {
+#pragma unroll
+          for (int v4 = 0; v4 < 4; ++v4)
+            if (owner == v4) mine[v4] |= 1u << kk;
+        }
+      }
     }
-    if (lane == 0) live_w[wave] = mine;
+    if (lane < 4 && mine[lane & 3] != 0u) {
+      unsigned val = mine[0];
+      if (lane == 1) val = mine[1];
+      if (lane == 2) val = mine[2];
+      if (lane == 3) val = mine[3];
+      atomicOr(&live_w[lane], val);
+    }
   }
   __syncthreads();
+  OS_MARK(1);
   const unsigned wave_live = live_w[wave];
   const unsigned live = live_w[0] | live_w[1] | live_w[2] | live_w[3];
   const int wave_row = wave * 16 * RB;
@@ -158,7 +219,10 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
 #pragma unroll
       for (int j = 0; j < 4; ++j) xc[rb][j] = sn[rb] >= 0 ? xn[rb][j] : zero4;  // rows without a partner contribute 0
     __syncthreads();
+    OS_MARK(2);
     while (true) {
+      OS_LAP_START();
+      OS_COUNT(0);
       int nk = k, ncc = cc + 1;
       if (ncc == n_cc) {
         ncc = 0;
@@ -171,7 +235,9 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
       }
       fetch_w(nk, ncc);
       gather_x(nk, ncc, xn, sn);
+      OS_LAP(0);   // loads of the next stage issued
       if ((wave_live >> k) & 1u) {  // uniform per wave
+        OS_COUNT(1);
         const float* wb = &wbuf[buf][4 * lane];
         // column tiles in groups of 4; the fragments of group q + 1 are read while the MFMAs of group q issue
         constexpr int CG4 = NCT / 4, G = 4 * CG4;
@@ -199,19 +265,26 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
           for (int u = 0; u < 4; ++u) wf[u] = wnx[u];
         }
       }
+      OS_LAP(1);   // MFMAs issued (the clock read waits for the LDS fragments, not for the matrix pipe)
 #pragma unroll
       for (int u = 0; u < WREG; ++u) *(f32x4*)(&wbuf[buf ^ 1][4 * (tid + 256 * u)]) = wr[u];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) xc[rb][j] = sn[rb] >= 0 ? xn[rb][j] : zero4;
+#ifdef SST_OS_TIMING
+      __builtin_amdgcn_s_waitcnt(0);
+#endif
+      OS_LAP(2);   // loads arrived, W in LDS
       __syncthreads();
+      OS_LAP(3);   // barrier
       if (!has_next) break;
       k = nk;
       cc = ncc;
       buf ^= 1;
     }
   }
+  OS_MARK(3);
   // ---- epilogue: lane = (row l15 of its block, 4 consecutive columns at 4 kq of every column tile) ----
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -232,6 +305,8 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
       }
     }
   }
+  OS_MARK(4);
+  OS_FLUSH();
 }
 
 // work[tile] = number of (16-row block, offset) slots of the tile with at least one partner: the MFMA work of the tile in
@@ -528,6 +603,14 @@ int sst_spconv_os_tile_work_i32(const int32_t* d_map, int64_t m, int kvol, int t
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
+
+#ifdef SST_OS_TIMING
+int sst_debug_conv_os_timestamps(void* host_dst, int64_t bytes) {
+  if (bytes > (int64_t)sizeof(g_os_ts)) bytes = sizeof(g_os_ts);
+  SST_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_os_ts), (size_t)bytes, 0, hipMemcpyDeviceToHost));
+  return SST_OK;
+}
+#endif
 
 int64_t sst_spconv_wgrad_os_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout) {
   return os_wgrad_chunks(kvol > 0 ? kvol : 1, pair_ld > 0 ? pair_ld : 1, total_pairs) * cin * cout * (int64_t)sizeof(float) + 256;
