@@ -345,14 +345,15 @@ __global__ __launch_bounds__(256) void sp_os_tile_work_k(const int32_t* __restri
 //     side by a select);
 //   * partial blocks per chunk are summed in chunk order by sp_wgrad_os_reduce_k (deterministic): 4 x fewer, larger chunks.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kWgChunk = 2048;  // pairs per workgroup
+constexpr int kWgChunk = 2048;  // pairs per workgroup (upper bound; os_wgrad_chunk_size picks 512 .. 2048)
 constexpr int kWgStage = 64;    // pairs per stage
 constexpr int kWgLd = 68;       // LDS row stride (floats) of a [64 channels][64 pairs] image
 
-__device__ __forceinline__ bool os_find_chunk(const int32_t* __restrict__ num, int kvol, int chunk, int& k, int& first) {
+__device__ __forceinline__ bool os_find_chunk(const int32_t* __restrict__ num, int kvol, int chunk, int csize, int& k,
+                                              int& first) {
   int c0 = 0;
   for (int i = 0; i < kvol; ++i) {
-    const int nc = (num[i] + kWgChunk - 1) / kWgChunk;
+    const int nc = (num[i] + csize - 1) / csize;
     if (chunk < c0 + nc) {
       k = i;
       first = c0;
@@ -367,18 +368,18 @@ __global__ __launch_bounds__(256) void sp_wgrad_os_k(const float* __restrict__ x
                                                      const float* __restrict__ dy, int64_t lddy,
                                                      const int32_t* __restrict__ pairs, int64_t pair_ld, int x_side,
                                                      const int32_t* __restrict__ num, int kvol, int cin, int cout,
-                                                     int n_bj, float* __restrict__ part) {
+                                                     int n_bj, int csize, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float At[2][64 * kWgLd];
   __shared__ __attribute__((aligned(16))) float Bt[2][64 * kWgLd];
   int k, first;
-  if (!os_find_chunk(num, kvol, blockIdx.x, k, first)) return;  // uniform
+  if (!os_find_chunk(num, kvol, blockIdx.x, csize, k, first)) return;  // uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
   const int bi = blockIdx.y / n_bj, bj = blockIdx.y - bi * n_bj;
   const int ci0 = bi * 64, co0 = bj * 64;
   const int np = num[k];
-  const int p0 = (blockIdx.x - first) * kWgChunk;
-  const int p1 = p0 + kWgChunk < np ? p0 + kWgChunk : np;
+  const int p0 = (blockIdx.x - first) * csize;
+  const int p1 = p0 + csize < np ? p0 + csize : np;
   const int32_t* pa = pairs + ((int64_t)k * 2 + x_side) * pair_ld;
   const int32_t* pb = pairs + ((int64_t)k * 2 + (1 - x_side)) * pair_ld;
   // staging role of this thread: pairs prow + 16 u (u < 4) of the stage, channels 4 ch4 .. + 3 of the block
@@ -479,21 +480,39 @@ __global__ __launch_bounds__(256) void sp_wgrad_os_k(const float* __restrict__ x
 
 // dw[k][e] = sum over the chunks of offset k, in chunk order
 __global__ __launch_bounds__(256) void sp_wgrad_os_reduce_k(const float* __restrict__ part, const int32_t* __restrict__ num,
-                                                            int kvol, int64_t per_k, float* __restrict__ dw) {
+                                                            int kvol, int64_t per_k, int csize, float* __restrict__ dw) {
   const int k = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= per_k) return;
   int first = 0;
-  for (int i = 0; i < k; ++i) first += (num[i] + kWgChunk - 1) / kWgChunk;
-  const int nc = (num[k] + kWgChunk - 1) / kWgChunk;
+  for (int i = 0; i < k; ++i) first += (num[i] + csize - 1) / csize;
+  const int nc = (num[k] + csize - 1) / csize;
   float s = 0.f;
   for (int c = 0; c < nc; ++c) s += part[(int64_t)(first + c) * per_k + e];
   dw[(int64_t)k * per_k + e] = s;
 }
 
-int64_t os_wgrad_chunks(int kvol, int64_t pair_ld, int64_t total_pairs) {
+// pairs per workgroup: 2048 when that still gives every CU a few workgroups, down to 512 for the thin levels (a level with
+// 5 partners per voxel has 330 chunks of 2048 pairs for 256 CUs)
+int os_wgrad_chunk_size(int kvol, int64_t pair_ld, int64_t total_pairs, int n_blocks) {
+  static int env = -1;   // SST_SPCONV_WGRAD_CHUNK overrides (A/B measurements)
+  if (env < 0) {
+    const char* e = getenv("SST_SPCONV_WGRAD_CHUNK");
+    env = e ? atoi(e) : 0;
+  }
+  if (env >= 64 && env <= kWgChunk && env % 64 == 0) return env;
   const int64_t total = (total_pairs >= 0 && total_pairs <= (int64_t)kvol * pair_ld) ? total_pairs : (int64_t)kvol * pair_ld;
-  return total / kWgChunk + kvol;
+  // 2 workgroups fit a CU (70 KB of LDS each): below one full round of 512, size the chunks so that the launch IS about
+  // one round (a level with 5 partners per voxel: 330 chunks of 2048 pairs would leave a third of the CUs with twice the work)
+  if ((total / kWgChunk + kvol / 2) * n_blocks >= 480) return kWgChunk;
+  int64_t c = total * n_blocks / 480;
+  c = (c + kWgStage - 1) / kWgStage * kWgStage;
+  return (int)(c < 512 ? 512 : (c > kWgChunk ? kWgChunk : c));
+}
+
+int64_t os_wgrad_chunks(int kvol, int64_t pair_ld, int64_t total_pairs, int csize) {
+  const int64_t total = (total_pairs >= 0 && total_pairs <= (int64_t)kvol * pair_ld) ? total_pairs : (int64_t)kvol * pair_ld;
+  return total / csize + kvol;
 }
 
 struct os_cfg {
@@ -613,7 +632,11 @@ int sst_debug_conv_os_timestamps(void* host_dst, int64_t bytes) {
 #endif
 
 int64_t sst_spconv_wgrad_os_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout) {
-  return os_wgrad_chunks(kvol > 0 ? kvol : 1, pair_ld > 0 ? pair_ld : 1, total_pairs) * cin * cout * (int64_t)sizeof(float) + 256;
+  kvol = kvol > 0 ? kvol : 1;
+  pair_ld = pair_ld > 0 ? pair_ld : 1;
+  const int n_blocks = (int)(sst_div_up(cin > 0 ? cin : 1, 64) * sst_div_up(cout > 0 ? cout : 1, 64));
+  const int csize = os_wgrad_chunk_size(kvol, pair_ld, total_pairs, n_blocks);
+  return os_wgrad_chunks(kvol, pair_ld, total_pairs, csize) * cin * cout * (int64_t)sizeof(float) + 256;
 }
 
 int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
@@ -630,14 +653,15 @@ int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, in
     SST_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * kvol * per_k, st));
     return SST_OK;
   }
-  const int64_t chunks = os_wgrad_chunks(kvol, pair_ld, total_pairs);
   const int n_bi = (int)sst_div_up(cin, 64), n_bj = (int)sst_div_up(cout, 64);
+  const int csize = os_wgrad_chunk_size(kvol, pair_ld, total_pairs, n_bi * n_bj);
+  const int64_t chunks = os_wgrad_chunks(kvol, pair_ld, total_pairs, csize);
   if (kvol > 65535 || chunks > 0x7fffffff || n_bi * n_bj > 65535) return SST_ERR_UNSUPPORTED;
   float* part = (float*)d_workspace;
   hipLaunchKernelGGL(sp_wgrad_os_k, dim3((unsigned)chunks, (unsigned)(n_bi * n_bj)), dim3(256), 0, st, d_x, ldx, d_dy, lddy,
-                     d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, n_bj, part);
+                     d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, n_bj, csize, part);
   hipLaunchKernelGGL(sp_wgrad_os_reduce_k, dim3((unsigned)sst_div_up(per_k, 256), (unsigned)kvol), dim3(256), 0, st, part,
-                     d_num, kvol, per_k, d_dw);
+                     d_num, kvol, per_k, csize, d_dw);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
