@@ -100,15 +100,28 @@ FSD_SMALL_CFG = dict(
     roi=dict(extra_wlh=[0.5, 0.5, 0.5], max_inbox_point=256))
 
 
+_CONSTS = {}
+
+
+def _const(values, dev):
+    """small fp32 constant on `dev`, uploaded once (torch.tensor(list, device=cuda) synchronises the host every call)"""
+    key = (tuple(float(v) for v in values), str(dev))
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor([float(v) for v in values], dtype=torch.float32).to(dev)
+    return _CONSTS[key]
+
+
 def fsd_foreground_stand_in(batch_points, votes, z_cut=-1.4):
     """STAND-IN for the segmentation decision and the vote decoding of VoteSegHead (out of scope): foreground = points
     above the ground plane, class by a position hash, voted centre = point + 0.05 tanh(vote of its class).  Shared by the
     GPU path, the CPU port and the reference chain that produces the golden (tests/golden/make_golden.py)."""
     fg = batch_points[:, 2] > z_cut
     cls = (batch_points[:, 0].abs() * 7).long() % 3
+    masks = [fg & (cls == c) for c in range(3)]
+    counts = torch.stack([m.sum() for m in masks]).tolist()          # ONE read-back for the three classes
     sel_l, pts_l = [], []
     for c in range(3):
-        sel = torch.nonzero(fg & (cls == c)).squeeze(1)
+        sel = torch.nonzero_static(masks[c], size=int(counts[c])).squeeze(1)
         sel_l.append(sel)
         pts_l.append((batch_points[sel, :3] + 0.05 * torch.tanh(votes[sel, c])).detach())
     return sel_l, pts_l
@@ -163,8 +176,8 @@ class FSDPath(nn.Module):
         x = self.seg_backbone(info)[0]
         # Voxel2PointScatterNeck (necks/voxel2point_neck.py:28-63)
         pts_feats = x['voxel_feats'][v2p]
-        vs = torch.tensor(self.SEG_VOXEL, device=dev).reshape(1, 3)
-        centre = (coors[:, [3, 2, 1]].float() + 0.5) * vs + torch.tensor(self.PC_RANGE[:3], device=dev).reshape(1, 3)
+        vs = _const(self.SEG_VOXEL, dev).reshape(1, 3)
+        centre = (coors[:, [3, 2, 1]].float() + 0.5) * vs + _const(self.PC_RANGE[:3], dev).reshape(1, 3)
         seg_feats = torch.cat([pts_feats, batch_points[:, :3] - centre], 1)            # [N, C + 3]
         head = self.seg_head(seg_feats)
         logits, votes = head[:, :3], head[:, 3:].reshape(-1, 3, 3)
@@ -173,7 +186,9 @@ class FSDPath(nn.Module):
         # called as SingleStageFSD.forward_train does (single_stage_fsd.py:521): per-class lists, origin_points = the points
         cluster_inds_l, valid_l = self.cluster_assigner(pts_l, [batch_idx[s] for s in sel_l], None, None,
                                                         origin_points=[batch_points[s] for s in sel_l])
-        keep_l = [torch.nonzero(v).squeeze(1) for v in valid_l]                        # one read-back per class, used twice
+        # the GPU assigner hands the indices of the surviving points over with the mask (no second search / read-back)
+        keep_l = [getattr(v, '_sst_keep', None) for v in valid_l]
+        keep_l = [torch.nonzero(v).squeeze(1) if k is None else k for v, k in zip(valid_l, keep_l)]
         sel = torch.cat([s[k] for s, k in zip(sel_l, keep_l)])
         cluster_inds = torch.cat(cluster_inds_l).long()                               # [P, 3] (class, sample, cluster)
         centres = torch.cat([p[k] for p, k in zip(pts_l, keep_l)])
@@ -194,8 +209,8 @@ class FSDPath(nn.Module):
             return (loss, stats, tensors) if return_tensors else (loss, stats)
         box = self.box_head(cluster_feats)
         rois = torch.cat([cluster_coors[:, 1:2].float(),
-                          cluster_xyz + 0.1 * torch.tanh(box[:, :3]) - torch.tensor([0, 0, 0.9], device=dev),
-                          torch.tensor([2.0, 4.4, 1.8], device=dev) * torch.exp(0.1 * torch.tanh(box[:, 3:6])),
+                          cluster_xyz + 0.1 * torch.tanh(box[:, :3]) - _const([0, 0, 0.9], dev),
+                          _const([2.0, 4.4, 1.8], dev) * torch.exp(0.1 * torch.tanh(box[:, 3:6])),
                           box[:, 6:7]], 1).detach()
         order = torch.argsort(rois[:, 0], stable=True)                                 # RoIs sample after sample
         rois = rois[order]
@@ -280,8 +295,8 @@ class FSDv2Path(nn.Module):
         info.setdefault('batch_size', len(points_list))
         x = self.seg_backbone(info)[0]
         pts_feats = x['voxel_feats'][v2p]                                               # Voxel2PointScatterNeck
-        vs = torch.tensor(self.SEG_VOXEL, device=dev).reshape(1, 3)
-        centre = (coors[:, [3, 2, 1]].float() + 0.5) * vs + torch.tensor(self.PC_RANGE[:3], device=dev).reshape(1, 3)
+        vs = _const(self.SEG_VOXEL, dev).reshape(1, 3)
+        centre = (coors[:, [3, 2, 1]].float() + 0.5) * vs + _const(self.PC_RANGE[:3], dev).reshape(1, 3)
         seg_feats = torch.cat([pts_feats, batch_points[:, :3] - centre], 1)            # [N, C + 3]
         head = self.seg_head(seg_feats)
         logits, vote = head[:, :self.n_logits], head[:, self.n_logits:]

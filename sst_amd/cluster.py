@@ -119,8 +119,8 @@ class ClusterAssigner(torch.nn.Module):
         inverse), and the two data-dependent lengths (surviving points, surviving voxels) are read back together."""
         dev = points.device
         batch_idx = batch_idx.int()
-        cell = points.new_tensor(self._per_class(self.cluster_voxel_size, class_name))
-        origin = points.new_tensor(self.point_cloud_range[:3])
+        cell = K.const_tensor(self._per_class(self.cluster_voxel_size, class_name), dev, points.dtype)
+        origin = K.const_tensor(self.point_cloud_range[:3], dev, points.dtype)
         cells = torch.cat([batch_idx[:, None], torch.div(points - origin, cell, rounding_mode='floor').int()], dim=1)
         n = points.size(0)
         if n == 0:
@@ -151,6 +151,7 @@ class ClusterAssigner(torch.nn.Module):
         assert component.numel() == sizes[1]
         rank_of_group = torch.cumsum(crowded.int(), 0) - 1                   # surviving voxel -> row of `centroids`
         point_component = component[rank_of_group[point_group[keep_points]].long()]
+        valid_mask._sst_keep = keep_points     # the indices of the set entries ride along: callers need not search again
         return torch.stack([batch_idx[keep_points], point_component.int()], 1), valid_mask
 
 

@@ -19,6 +19,21 @@ REDUCE = {'sum': 0, 'mean': 1, 'avg': 1, 'max': 2}
 # ----------------------------------------------------------------------------------------------
 # (a1) dynamic voxelization
 # ----------------------------------------------------------------------------------------------
+_CONSTANTS = {}
+
+
+def const_tensor(values, device, dtype=torch.float32):
+    """a small constant (voxel size, range, normaliser ...) as a device tensor, uploaded ONCE per (values, device, dtype):
+    ``torch.tensor(list, device=cuda)`` is a pageable host-to-device copy, i.e. a host synchronisation per call.
+    The tensor is shared: never write to it in place."""
+    key = (tuple(float(v) for v in values), str(device), dtype)
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = torch.tensor([float(v) for v in values], dtype=dtype).to(device)
+        _CONSTANTS[key] = t
+    return t
+
+
 def voxel_grid(voxel_size, coors_range):
     """grid (x, y, z) the kernel clamps to: fp32 ceil((max-min)/v), voxelization_cuda.cu:355-357."""
     import ctypes

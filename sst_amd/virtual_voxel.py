@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from .registry import MODELS, build_backbone, build_voxel_encoder
+from . import kernels as K
 from .sst_ops import build_mlp, scatter_v2
 
 
@@ -51,8 +52,8 @@ class VirtualVoxelExtractor(nn.Module):
         """floor((xyz - range_min) / voxel) in zyx order behind the sample index; no clamping (the centres were clipped,
         the original points lie inside the range by construction of the segmentor's voxelisation)"""
         xyz = points[:, :3]
-        vs = xyz.new_tensor(self.virtual_voxel_size)
-        lo = xyz.new_tensor(self.point_cloud_range[:3])
+        vs = K.const_tensor(self.virtual_voxel_size, xyz.device, xyz.dtype)
+        lo = K.const_tensor(self.point_cloud_range[:3], xyz.device, xyz.dtype)
         cells = torch.div(xyz - lo[None], vs[None], rounding_mode='floor').long()
         return torch.cat([batch_idx[:, None], cells[:, [2, 1, 0]]], dim=1)
 
@@ -60,8 +61,8 @@ class VirtualVoxelExtractor(nn.Module):
         """IN PLACE, as the reference does (single_stage_fsd_v2.py:124-129 assigns into the columns of
         sampled_dict['center_preds']): callers that read the dictionary after extract_feat see the clipped centres."""
         eps = 1e-5
-        lo = points.new_tensor(pc_range[:3]) + eps
-        hi = points.new_tensor(pc_range[3:]) - eps
+        lo = K.const_tensor(pc_range[:3], points.device, points.dtype) + eps
+        hi = K.const_tensor(pc_range[3:], points.device, points.dtype) - eps
         return points.clamp_(min=lo, max=hi)
 
     def extract_feat(self, sampled_dict, origin_dict):
@@ -93,8 +94,8 @@ class VirtualVoxelExtractor(nn.Module):
             voxel_feats, voxel_coors = voxel_feats[virtual_mask], voxel_coors[virtual_mask]
         out_feats, out_coors, sparse_shape = self.backbone(voxel_feats, voxel_coors, batch_size)
 
-        vs = out_feats.new_tensor(self.virtual_voxel_size)
-        lo = out_feats.new_tensor(self.point_cloud_range[:3])
+        vs = K.const_tensor(self.virtual_voxel_size, out_feats.device, out_feats.dtype)
+        lo = K.const_tensor(self.point_cloud_range[:3], out_feats.device, out_feats.dtype)
         voxel_centers = (out_coors[:, [3, 2, 1]].to(out_feats.dtype) + 0.5) * vs[None] + lo[None]
         if self.only_virtual:
             out = dict(virtual_feats=out_feats, virtual_coors=out_coors, virtual_centers=voxel_centers)

@@ -302,7 +302,7 @@ class SIRLayer(_PointGroupEncoder):
         features = features.float()
         grouping = _UniqueGrouping(coors, new_coors_once, unq_inv_once)
         xyz, rest = features[:, :3], features[:, 3:]
-        scale = torch.tensor(self.xyz_normalizer, device=features.device, dtype=features.dtype)
+        scale = K.const_tensor(self.xyz_normalizer, features.device, features.dtype)
         base = torch.cat([xyz / scale[None, :], rest], dim=1)
         if f_cluster is None:   # offsets from the instance centre
             centre = grouping.reduce(xyz, 'mean')
