@@ -475,6 +475,27 @@ int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int
 int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const float* d_weight, const float* d_bias,
                        float eps, float* d_running_mean, float* d_running_var, float factor, float* d_out4,
                        void* d_workspace, void* stream);
+/*   sst_bn_prepare_tracked_f32: the same, and *d_num_batches_tracked += 1 (nn.BatchNorm1d's int64 counter; may be NULL)
+ *     in the same launch. */
+int sst_bn_prepare_tracked_f32(const float* d_x, int64_t n, int c, int64_t ld, const float* d_weight,
+                               const float* d_bias, float eps, float* d_running_mean, float* d_running_var,
+                               float factor, int64_t* d_num_batches_tracked, float* d_out4, void* d_workspace,
+                               void* stream);
+/* The residual tail of a sparse basic block (mmdet3d/ops/spconv/... sparse_block.py:127-139: bn2 -> += identity -> ReLU)
+ * in the batch-norm passes: y = act(x * scale + shift + res).  The *_res_* entries are the calls above with the identity
+ * branch d_res [n, c] (row stride ldr; NULL = none) inside the activation; the backward apply also writes the gradient of
+ * the identity branch, d_dres = dy masked by the activation (NULL = not wanted). */
+int sst_bn_act_res_fwd_f32(const float* d_x, int64_t n, int c, int64_t ldx, const float* d_res, int64_t ldr,
+                           const float* d_scale, const float* d_shift, int act, float* d_y, int64_t ldy, void* stream);
+int sst_bn_act_res_bwd_reduce_f32(const float* d_dy, const float* d_x, const float* d_res, int64_t n, int c,
+                                  int64_t lddy, int64_t ldx, int64_t ldr, const float* d_mean, const float* d_invstd,
+                                  const float* d_scale, const float* d_shift, int act, float* d_sum_g,
+                                  float* d_sum_gxhat, void* d_workspace, void* stream);
+int sst_bn_act_res_bwd_apply_f32(const float* d_dy, const float* d_x, const float* d_res, int64_t n, int c,
+                                 int64_t lddy, int64_t ldx, int64_t ldr, const float* d_mean, const float* d_invstd,
+                                 const float* d_scale, const float* d_shift, const float* d_coef_a,
+                                 const float* d_coef_b, float coef_scale, int act, float* d_dres, int64_t lddres,
+                                 float* d_dx, int64_t lddx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tall fp32 linear layer  y[m, n] (+)= x[m, k] W^T + bias  on the fp32 MFMA pipe with W resident in LDS

@@ -175,6 +175,15 @@ _SIGNATURES = {
                                          c_ptr, c_ptr, ctypes.c_float, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_bn_prepare_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, ctypes.c_float, c_ptr, c_ptr,
                                    ctypes.c_float, c_ptr, c_ptr, c_ptr]),
+    'sst_bn_prepare_tracked_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, ctypes.c_float, c_ptr, c_ptr,
+                                           ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_bn_act_res_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_ptr, c_i64,
+                                       c_ptr]),
+    'sst_bn_act_res_bwd_reduce_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64, c_i64, c_ptr, c_ptr,
+                                              c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_bn_act_res_bwd_apply_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64, c_i64, c_ptr, c_ptr,
+                                             c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float, c_i32, c_ptr, c_i64, c_ptr,
+                                             c_i64, c_ptr]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -14,7 +14,7 @@ namespace {
 constexpr int kBnThreads = 256;
 
 // Block partials of two column moments.  MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g * xhat) with
-// g = dy * [act(x*scale+shift) > 0 or no act], xhat = (x - mean) * invstd.
+// g = dy * [act(x*scale+shift (+ res)) > 0 or no act], xhat = (x - mean) * invstd.
 // Thread (ry, cx) owns float4 column group cx and rows ry, ry + rpi, ...; partial[block][2c] doubles.
 template <int MODE>
 __global__ __launch_bounds__(kBnThreads) void bn_moments_k(const float* __restrict__ x, const float* __restrict__ dy,
@@ -23,6 +23,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_moments_k(const float* __restri
                                                           const float* __restrict__ invstd,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int act,
+                                                          const float* __restrict__ res, int64_t ldr,
                                                           int64_t rows_per_block, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double red[];  // [rpi][2c]
   const int c4 = c >> 2;
@@ -49,10 +50,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_moments_k(const float* __restri
         } else {
           float4 g = *(const float4*)(dy + row * lddy + cc * 4);
           if (act) {
-            g.x = (v.x * sc.x + sh.x) > 0.f ? g.x : 0.f;
-            g.y = (v.y * sc.y + sh.y) > 0.f ? g.y : 0.f;
-            g.z = (v.z * sc.z + sh.z) > 0.f ? g.z : 0.f;
-            g.w = (v.w * sc.w + sh.w) > 0.f ? g.w : 0.f;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res != nullptr) r = *(const float4*)(res + row * ldr + cc * 4);
+            g.x = (v.x * sc.x + sh.x + r.x) > 0.f ? g.x : 0.f;
+            g.y = (v.y * sc.y + sh.y + r.y) > 0.f ? g.y : 0.f;
+            g.z = (v.z * sc.z + sh.z + r.z) > 0.f ? g.z : 0.f;
+            g.w = (v.w * sc.w + sh.w + r.w) > 0.f ? g.w : 0.f;
           }
           s1[0] += g.x, s1[1] += g.y, s1[2] += g.z, s1[3] += g.w;
           s2[0] += (double)(g.x * ((v.x - mu.x) * is.x)), s2[1] += (double)(g.y * ((v.y - mu.y) * is.y));
@@ -118,7 +121,8 @@ __global__ __launch_bounds__(1024) void bn_prepare_finish_k(const double* __rest
                                                             const float* __restrict__ bias, float eps,
                                                             float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, float factor,
-                                                            float unbiased, float* __restrict__ out) {  // out [4][c]
+                                                            float unbiased, int64_t* __restrict__ tracked,
+                                                            float* __restrict__ out) {  // out [4][c]
   __shared__ double r1[32][33], r2[32][33];
   const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
   const int ch = blockIdx.x * 32 + cx;
@@ -148,13 +152,16 @@ __global__ __launch_bounds__(1024) void bn_prepare_finish_k(const double* __rest
     out[3 * c + ch] = sh;
     if (running_mean != nullptr) running_mean[ch] = (1.f - factor) * running_mean[ch] + factor * mean;
     if (running_var != nullptr) running_var[ch] = (1.f - factor) * running_var[ch] + factor * (var * unbiased);
+    if (tracked != nullptr && ch == 0) tracked[0] += 1;   // nn.BatchNorm1d.num_batches_tracked
   }
 }
 
-// y = act(x * scale + shift); one float4 per thread, grid-stride.
+// y = act(x * scale + shift (+ res)); one float4 per thread, grid-stride.  res: the identity branch of a residual block
+// (sparse_block.py:127-139: bn2 -> += identity -> ReLU), folded into the same pass.
 __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_k(const float* __restrict__ x, int64_t n, int c, int64_t ldx,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int act,
+                                                          const float* __restrict__ res, int64_t ldr,
                                                           float* __restrict__ y, int64_t ldy) {
   const int c4 = c >> 2;
   const int64_t total = n * c4;
@@ -165,6 +172,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_k(const float* __restri
     const float4 sc = *(const float4*)(scale + cc * 4);
     const float4 sh = *(const float4*)(shift + cc * 4);
     float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (res != nullptr) {
+      const float4 r = *(const float4*)(res + row * ldr + cc * 4);
+      o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
+    }
     if (act) {
       o.x = o.x > 0.f ? o.x : 0.f;
       o.y = o.y > 0.f ? o.y : 0.f;
@@ -183,8 +194,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_k(const float* __restri
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ ca, const float* __restrict__ cb,
-                                                          float coef_scale, int act, float* __restrict__ dx,
-                                                          int64_t lddx) {
+                                                          float coef_scale, int act, const float* __restrict__ res,
+                                                          int64_t ldr, float* __restrict__ dres, int64_t lddres,
+                                                          float* __restrict__ dx, int64_t lddx) {
   const int c4 = c >> 2;
   const int64_t total = n * c4;
   for (int64_t i = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBnThreads) {
@@ -201,11 +213,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_k(const float* __restri
     a.x *= coef_scale, a.y *= coef_scale, a.z *= coef_scale, a.w *= coef_scale;
     b.x *= coef_scale, b.y *= coef_scale, b.z *= coef_scale, b.w *= coef_scale;
     if (act) {
-      g.x = (v.x * sc.x + sh.x) > 0.f ? g.x : 0.f;
-      g.y = (v.y * sc.y + sh.y) > 0.f ? g.y : 0.f;
-      g.z = (v.z * sc.z + sh.z) > 0.f ? g.z : 0.f;
-      g.w = (v.w * sc.w + sh.w) > 0.f ? g.w : 0.f;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res != nullptr) r = *(const float4*)(res + row * ldr + cc * 4);
+      g.x = (v.x * sc.x + sh.x + r.x) > 0.f ? g.x : 0.f;
+      g.y = (v.y * sc.y + sh.y + r.y) > 0.f ? g.y : 0.f;
+      g.z = (v.z * sc.z + sh.z + r.z) > 0.f ? g.z : 0.f;
+      g.w = (v.w * sc.w + sh.w + r.w) > 0.f ? g.w : 0.f;
     }
+    if (dres != nullptr) *(float4*)(dres + row * lddres + cc * 4) = g;   // gradient of the identity branch
     float4 o;
     o.x = sc.x * (g.x - a.x - (v.x - mu.x) * is.x * b.x);
     o.y = sc.y * (g.y - a.y - (v.y - mu.y) * is.y * b.y);
@@ -248,33 +263,41 @@ int sst_bn_stats_f32(const float* d_x, int64_t n, int c, int64_t ld, float* d_me
   double* partial = (double*)d_workspace;
   const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
   hipLaunchKernelGGL(bn_moments_k<0>, dim3(grid), dim3(kBnThreads), lds, st, d_x, nullptr, n, c, ld, 0, nullptr,
-                     nullptr, nullptr, nullptr, 0, rpb, partial);
+                     nullptr, nullptr, nullptr, 0, nullptr, 0, rpb, partial);
   hipLaunchKernelGGL(bn_finish_k<0>, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 1.0 / (double)n,
                      d_mean, d_var);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
 
-int sst_bn_act_fwd_f32(const float* d_x, int64_t n, int c, int64_t ldx, const float* d_scale, const float* d_shift,
-                       int act, float* d_y, int64_t ldy, void* stream) {
+int sst_bn_act_res_fwd_f32(const float* d_x, int64_t n, int c, int64_t ldx, const float* d_res, int64_t ldr,
+                           const float* d_scale, const float* d_shift, int act, float* d_y, int64_t ldy, void* stream) {
   if (!bn_shape_ok(n, c) || ldx < c || ldy < c || (ldx & 3) || (ldy & 3) || act < 0 || act > 1)
     return SST_ERR_UNSUPPORTED;
+  if (d_res && (ldr < c || (ldr & 3) || ((uintptr_t)d_res & 15))) return SST_ERR_UNSUPPORTED;
   if (n == 0) return SST_OK;
   if (!d_x || !d_scale || !d_shift || !d_y || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return SST_ERR_ARG;
   const int64_t total = n * (c >> 2);
   int64_t grid = sst_div_up(total, kBnThreads);
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(bn_act_fwd_k, dim3((unsigned)grid), dim3(kBnThreads), 0, (hipStream_t)stream, d_x, n, c, ldx,
-                     d_scale, d_shift, act, d_y, ldy);
+                     d_scale, d_shift, act, d_res, ldr, d_y, ldy);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
 
-int sst_bn_act_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
-                              const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
-                              int act, float* d_sum_g, float* d_sum_gxhat, void* d_workspace, void* stream) {
+int sst_bn_act_fwd_f32(const float* d_x, int64_t n, int c, int64_t ldx, const float* d_scale, const float* d_shift,
+                       int act, float* d_y, int64_t ldy, void* stream) {
+  return sst_bn_act_res_fwd_f32(d_x, n, c, ldx, nullptr, 0, d_scale, d_shift, act, d_y, ldy, stream);
+}
+
+int sst_bn_act_res_bwd_reduce_f32(const float* d_dy, const float* d_x, const float* d_res, int64_t n, int c,
+                                  int64_t lddy, int64_t ldx, int64_t ldr, const float* d_mean, const float* d_invstd,
+                                  const float* d_scale, const float* d_shift, int act, float* d_sum_g,
+                                  float* d_sum_gxhat, void* d_workspace, void* stream) {
   if (!bn_shape_ok(n, c) || ldx < c || lddy < c || (ldx & 3) || (lddy & 3) || act < 0 || act > 1)
     return SST_ERR_UNSUPPORTED;
+  if (d_res && (ldr < c || (ldr & 3) || ((uintptr_t)d_res & 15))) return SST_ERR_UNSUPPORTED;
   if (!d_sum_g || !d_sum_gxhat) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) {
@@ -290,20 +313,30 @@ int sst_bn_act_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, in
   double* partial = (double*)d_workspace;
   const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
   hipLaunchKernelGGL(bn_moments_k<1>, dim3(grid), dim3(kBnThreads), lds, st, d_x, d_dy, n, c, ldx, lddy, d_mean,
-                     d_invstd, d_scale, d_shift, act, rpb, partial);
+                     d_invstd, d_scale, d_shift, act, d_res, ldr, rpb, partial);
   hipLaunchKernelGGL(bn_finish_k<1>, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 0.0, d_sum_g,
                      d_sum_gxhat);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
 
-int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
-                             const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
-                             const float* d_coef_a, const float* d_coef_b, float coef_scale, int act, float* d_dx,
-                             int64_t lddx, void* stream) {
+int sst_bn_act_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                              const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
+                              int act, float* d_sum_g, float* d_sum_gxhat, void* d_workspace, void* stream) {
+  return sst_bn_act_res_bwd_reduce_f32(d_dy, d_x, nullptr, n, c, lddy, ldx, 0, d_mean, d_invstd, d_scale, d_shift, act,
+                                       d_sum_g, d_sum_gxhat, d_workspace, stream);
+}
+
+int sst_bn_act_res_bwd_apply_f32(const float* d_dy, const float* d_x, const float* d_res, int64_t n, int c,
+                                 int64_t lddy, int64_t ldx, int64_t ldr, const float* d_mean, const float* d_invstd,
+                                 const float* d_scale, const float* d_shift, const float* d_coef_a,
+                                 const float* d_coef_b, float coef_scale, int act, float* d_dres, int64_t lddres,
+                                 float* d_dx, int64_t lddx, void* stream) {
   if (!bn_shape_ok(n, c) || ldx < c || lddy < c || lddx < c || (ldx & 3) || (lddy & 3) || (lddx & 3) || act < 0 ||
       act > 1)
     return SST_ERR_UNSUPPORTED;
+  if (d_res && (ldr < c || (ldr & 3) || ((uintptr_t)d_res & 15))) return SST_ERR_UNSUPPORTED;
+  if (d_dres && (lddres < c || (lddres & 3) || ((uintptr_t)d_dres & 15))) return SST_ERR_UNSUPPORTED;
   if (n == 0) return SST_OK;
   if (!d_dy || !d_x || !d_mean || !d_invstd || !d_scale || !d_shift || !d_coef_a || !d_coef_b || !d_dx ||
       ((uintptr_t)d_x & 15) || ((uintptr_t)d_dy & 15) || ((uintptr_t)d_dx & 15))
@@ -312,14 +345,24 @@ int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int
   int64_t grid = sst_div_up(total, kBnThreads);
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(bn_act_bwd_k, dim3((unsigned)grid), dim3(kBnThreads), 0, (hipStream_t)stream, d_dy, d_x, n, c,
-                     lddy, ldx, d_mean, d_invstd, d_scale, d_shift, d_coef_a, d_coef_b, coef_scale, act, d_dx, lddx);
+                     lddy, ldx, d_mean, d_invstd, d_scale, d_shift, d_coef_a, d_coef_b, coef_scale, act, d_res, ldr,
+                     d_dres, lddres, d_dx, lddx);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
 
-int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const float* d_weight, const float* d_bias,
-                       float eps, float* d_running_mean, float* d_running_var, float factor, float* d_out4,
-                       void* d_workspace, void* stream) {
+int sst_bn_act_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                             const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
+                             const float* d_coef_a, const float* d_coef_b, float coef_scale, int act, float* d_dx,
+                             int64_t lddx, void* stream) {
+  return sst_bn_act_res_bwd_apply_f32(d_dy, d_x, nullptr, n, c, lddy, ldx, 0, d_mean, d_invstd, d_scale, d_shift,
+                                      d_coef_a, d_coef_b, coef_scale, act, nullptr, 0, d_dx, lddx, stream);
+}
+
+int sst_bn_prepare_tracked_f32(const float* d_x, int64_t n, int c, int64_t ld, const float* d_weight,
+                               const float* d_bias, float eps, float* d_running_mean, float* d_running_var,
+                               float factor, int64_t* d_num_batches_tracked, float* d_out4, void* d_workspace,
+                               void* stream) {
   if (!bn_shape_ok(n, c) || ld < c || (ld & 3)) return SST_ERR_UNSUPPORTED;
   if (n == 0) return SST_ERR_ARG;
   if (!d_x || !d_out4 || !d_workspace || ((uintptr_t)d_x & 15)) return SST_ERR_ARG;
@@ -329,12 +372,20 @@ int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const flo
   double* partial = (double*)d_workspace;
   const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
   hipLaunchKernelGGL(bn_moments_k<0>, dim3(grid), dim3(kBnThreads), lds, st, d_x, nullptr, n, c, ld, 0, nullptr,
-                     nullptr, nullptr, nullptr, 0, rpb, partial);
+                     nullptr, nullptr, nullptr, 0, nullptr, 0, rpb, partial);
   const float unbiased = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
   hipLaunchKernelGGL(bn_prepare_finish_k, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 1.0 / (double)n,
-                     d_weight, d_bias, eps, d_running_mean, d_running_var, factor, unbiased, d_out4);
+                     d_weight, d_bias, eps, d_running_mean, d_running_var, factor, unbiased, d_num_batches_tracked,
+                     d_out4);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const float* d_weight, const float* d_bias,
+                       float eps, float* d_running_mean, float* d_running_var, float factor, float* d_out4,
+                       void* d_workspace, void* stream) {
+  return sst_bn_prepare_tracked_f32(d_x, n, c, ld, d_weight, d_bias, eps, d_running_mean, d_running_var, factor, nullptr,
+                                    d_out4, d_workspace, stream);
 }
 
 }  // extern "C"

@@ -51,52 +51,71 @@ def _dist_world():
 
 
 class _BatchNormActFn(Function):
-    """y = act(x * scale + shift) through csrc/bn.hip; ``prep`` [4, C] = mean, invstd, scale, shift.
+    """y = act(x * scale + shift (+ res)) through csrc/bn.hip; ``prep`` [4, C] = mean, invstd, scale, shift.
     ``batch_stats``: mean / invstd were computed from this batch (training), so the gradient flows through them:
     dx = scale * (g - (G1 + xhat * G2) / count), G1 = sum g, G2 = sum g * xhat taken over every rank when ``sync``
     (naiveSyncBN averages the per-rank means, ops/norm.py:53-58, hence count = world_size * N_local; its AllReduce
-    backward sums the statistic gradients, :20-24)."""
+    backward sums the statistic gradients, :20-24).  ``res``: the identity branch of a residual block, added before
+    the activation in the same pass; its gradient (dy masked by the activation) leaves the backward apply kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, prep, act, batch_stats, count, sync):
+    def forward(ctx, x, weight, bias, prep, act, batch_stats, count, sync, res=None):
         from . import _lib
         n, c = x.shape
         y = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        rc = _lib.load().sst_bn_act_fwd_f32(_lib.ptr(x), n, c, x.stride(0), _lib.ptr(prep[2]), _lib.ptr(prep[3]),
-                                            int(act), _lib.ptr(y), y.stride(0), _lib.stream_ptr())
-        _lib.check(rc, 'sst_bn_act_fwd_f32')
-        ctx.save_for_backward(x, prep)
+        rc = _lib.load().sst_bn_act_res_fwd_f32(_lib.ptr(x), n, c, x.stride(0),
+                                                _lib.ptr(res) if res is not None else None,
+                                                res.stride(0) if res is not None else 0, _lib.ptr(prep[2]),
+                                                _lib.ptr(prep[3]), int(act), _lib.ptr(y), y.stride(0), _lib.stream_ptr())
+        _lib.check(rc, 'sst_bn_act_res_fwd_f32')
+        ctx.has_res = res is not None
+        if ctx.has_res:
+            ctx.save_for_backward(x, prep, res)
+        else:
+            ctx.save_for_backward(x, prep)
         ctx.cfg = (int(act), bool(batch_stats), float(count), bool(sync), weight is not None, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import _lib
-        x, prep = ctx.saved_tensors
+        if ctx.has_res:
+            x, prep, res = ctx.saved_tensors
+        else:
+            (x, prep), res = ctx.saved_tensors, None
         act, batch_stats, count, sync, has_w, has_b = ctx.cfg
         n, c = x.shape
         dy = dy.contiguous()
         lib = _lib.load()
+        res_p, ldr = (_lib.ptr(res), res.stride(0)) if res is not None else (None, 0)
         sums = torch.empty((2, c), dtype=torch.float32, device=x.device)
         ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
-        rc = lib.sst_bn_act_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(x), n, c, dy.stride(0), x.stride(0), _lib.ptr(prep[0]),
-                                           _lib.ptr(prep[1]), _lib.ptr(prep[2]), _lib.ptr(prep[3]), act,
-                                           _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(ws), _lib.stream_ptr())
-        _lib.check(rc, 'sst_bn_act_bwd_reduce_f32')
+        rc = lib.sst_bn_act_res_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(x), res_p, n, c, dy.stride(0), x.stride(0), ldr,
+                                               _lib.ptr(prep[0]), _lib.ptr(prep[1]), _lib.ptr(prep[2]),
+                                               _lib.ptr(prep[3]), act, _lib.ptr(sums[0]), _lib.ptr(sums[1]),
+                                               _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, 'sst_bn_act_res_bwd_reduce_f32')
         total = sums
         if sync and batch_stats:
             total = sums.clone()  # the parameter gradients stay the local sums (DDP averages them afterwards)
             dist.all_reduce(total, async_op=False)
-        dx = None
-        if ctx.needs_input_grad[0]:
+        dx = dres = None
+        want_dres = res is not None and ctx.needs_input_grad[8]
+        if ctx.needs_input_grad[0] or want_dres:
             dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
-            rc = lib.sst_bn_act_bwd_apply_f32(_lib.ptr(dy), _lib.ptr(x), n, c, dy.stride(0), x.stride(0),
-                                              _lib.ptr(prep[0]), _lib.ptr(prep[1]), _lib.ptr(prep[2]), _lib.ptr(prep[3]),
-                                              _lib.ptr(total[0]), _lib.ptr(total[1]),
-                                              (1.0 / count) if batch_stats else 0.0, act, _lib.ptr(dx), dx.stride(0),
-                                              _lib.stream_ptr())
-            _lib.check(rc, 'sst_bn_act_bwd_apply_f32')
-        return dx, (sums[1] if has_w else None), (sums[0] if has_b else None), None, None, None, None, None
+            if want_dres:
+                dres = torch.empty((n, c), dtype=torch.float32, device=x.device)
+            rc = lib.sst_bn_act_res_bwd_apply_f32(_lib.ptr(dy), _lib.ptr(x), res_p, n, c, dy.stride(0), x.stride(0),
+                                                  ldr, _lib.ptr(prep[0]), _lib.ptr(prep[1]), _lib.ptr(prep[2]),
+                                                  _lib.ptr(prep[3]), _lib.ptr(total[0]), _lib.ptr(total[1]),
+                                                  (1.0 / count) if batch_stats else 0.0, act,
+                                                  _lib.ptr(dres) if dres is not None else None,
+                                                  dres.stride(0) if dres is not None else 0, _lib.ptr(dx),
+                                                  dx.stride(0), _lib.stream_ptr())
+            _lib.check(rc, 'sst_bn_act_res_bwd_apply_f32')
+            if not ctx.needs_input_grad[0]:
+                dx = None
+        return (dx, (sums[1] if has_w else None), (sums[0] if has_b else None), None, None, None, None, None, dres)
 
 
 def _bn_kernel_ok(bn, x):
@@ -105,16 +124,23 @@ def _bn_kernel_ok(bn, x):
             and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
-def batch_norm_act(bn, x, relu=False):
-    """``relu(bn(x))`` / ``bn(x)`` for a BatchNorm1d-family module on [N, C] point features.
+def batch_norm_act(bn, x, relu=False, residual=None):
+    """``relu(bn(x))`` / ``bn(x)`` / ``relu(bn(x) + residual)`` for a BatchNorm1d-family module on [N, C] point features.
 
     CUDA float32 inputs go through the fused kernels (csrc/bn.hip) with the module's exact bookkeeping:
     nn.BatchNorm1d (torch/nn/modules/batchnorm.py: biased batch variance for the output, unbiased for
     running_var, num_batches_tracked) or, for NaiveSyncBatchNorm1d in distributed training, the reference's
     averaging of per-rank [mean || meansqr] and its ``running += momentum * (stat - running)`` update
     (mmdet3d/ops/norm.py:50-66).  Anything else (CPU tensors, 3-D inputs) takes the module's own forward."""
+    if residual is not None and not (residual.shape == x.shape and residual.dtype == torch.float32 and residual.is_cuda
+                                     and residual.stride(1) == 1 and residual.stride(0) % 4 == 0
+                                     and residual.data_ptr() % 16 == 0):
+        y = batch_norm_act(bn, x, relu=False) + residual
+        return torch.relu(y) if relu else y
     if not _bn_kernel_ok(bn, x):
         y = bn(x)
+        if residual is not None:
+            y = y + residual
         return torch.relu(y) if relu else y
     from . import _lib
     n, c = x.shape
@@ -129,22 +155,29 @@ def batch_norm_act(bn, x, relu=False):
         count = float(n)
         factor = 0.0
         update = bn.training and bn.track_running_stats and bn.running_mean is not None
+        tracked = None
         if update:
             factor = 0.0 if bn.momentum is None else bn.momentum
             if bn.num_batches_tracked is not None:
-                with torch.no_grad():
-                    bn.num_batches_tracked.add_(1)
-                if bn.momentum is None:
+                if bn.momentum is None:   # cumulative average: the factor needs the counter on the host
+                    with torch.no_grad():
+                        bn.num_batches_tracked.add_(1)
                     factor = 1.0 / float(bn.num_batches_tracked)
+                elif bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64:
+                    tracked = bn.num_batches_tracked      # incremented by the prepare kernel: no launch of its own
+                else:
+                    with torch.no_grad():
+                        bn.num_batches_tracked.add_(1)
         xd = x.detach()
         ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
-        rc = lib.sst_bn_prepare_f32(_lib.ptr(xd), n, c, xd.stride(0),
-                                    _lib.ptr(bn.weight.detach()) if bn.weight is not None else None,
-                                    _lib.ptr(bn.bias.detach()) if bn.bias is not None else None, float(bn.eps),
-                                    _lib.ptr(bn.running_mean) if update else None,
-                                    _lib.ptr(bn.running_var) if update else None, float(factor), _lib.ptr(prep),
-                                    _lib.ptr(ws), _lib.stream_ptr())
-        _lib.check(rc, 'sst_bn_prepare_f32')
+        rc = lib.sst_bn_prepare_tracked_f32(_lib.ptr(xd), n, c, xd.stride(0),
+                                            _lib.ptr(bn.weight.detach()) if bn.weight is not None else None,
+                                            _lib.ptr(bn.bias.detach()) if bn.bias is not None else None, float(bn.eps),
+                                            _lib.ptr(bn.running_mean) if update else None,
+                                            _lib.ptr(bn.running_var) if update else None, float(factor),
+                                            _lib.ptr(tracked) if tracked is not None else None, _lib.ptr(prep),
+                                            _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, 'sst_bn_prepare_tracked_f32')
     else:
         if batch_stats:  # naiveSyncBN across ranks
             xd = x.detach()
@@ -170,7 +203,7 @@ def batch_norm_act(bn, x, relu=False):
             scale = invstd if bn.weight is None else bn.weight * invstd
             shift = -mean * scale if bn.bias is None else bn.bias - mean * scale
             prep[0], prep[1], prep[2], prep[3] = mean, invstd, scale, shift
-    return _BatchNormActFn.apply(x, bn.weight, bn.bias, prep, bool(relu), batch_stats, count, sync)
+    return _BatchNormActFn.apply(x, bn.weight, bn.bias, prep, bool(relu), batch_stats, count, sync, residual)
 
 
 class BatchNorm1d(nn.BatchNorm1d):

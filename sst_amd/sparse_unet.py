@@ -10,7 +10,7 @@ Only 3-D (``ndim=3``) is built.
 import torch
 from torch import nn
 
-from .norm import build_conv_layer, build_norm_layer
+from .norm import batch_norm_act, build_conv_layer, build_norm_layer
 from .registry import BACKBONES, MIDDLE_ENCODERS
 from .spconv import SparseConvTensor, SparseModule, SparseSequential
 
@@ -61,13 +61,22 @@ class SparseBasicBlock(SparseModule):
     def forward(self, x):
         identity = x.features
         assert x.features.dim() == 2, f'x.features.dim()={x.features.dim()}'
+        # BatchNorm1d + ReLU, and BatchNorm1d + identity + ReLU, are one pass each (csrc/bn.hip) when the block is built
+        # from them - the reference's order of operations otherwise
+        fused = (type(self.relu) is nn.ReLU and isinstance(self.norm1, nn.BatchNorm1d)
+                 and isinstance(self.norm2, nn.BatchNorm1d) and identity.is_cuda)
         out = self.conv1(x)
-        out = replace_feature(out, self.norm1(out.features))
-        out = replace_feature(out, self.relu(out.features))
+        if fused:
+            out = replace_feature(out, batch_norm_act(self.norm1, out.features, relu=True))
+        else:
+            out = replace_feature(out, self.norm1(out.features))
+            out = replace_feature(out, self.relu(out.features))
         out = self.conv2(out)
-        out = replace_feature(out, self.norm2(out.features))
         if self.downsample is not None:
             identity = self.downsample(x)
+        if fused:
+            return replace_feature(out, batch_norm_act(self.norm2, out.features, relu=True, residual=identity))
+        out = replace_feature(out, self.norm2(out.features))
         out = replace_feature(out, out.features + identity)
         out = replace_feature(out, self.relu(out.features))
         return out

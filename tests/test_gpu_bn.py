@@ -59,6 +59,70 @@ def test_batch_norm_act_matches_torch(n, c, relu, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize('n,c', [(7, 36), (5001, 64), (60000, 128)])
+@pytest.mark.parametrize('training', [True, False])
+def test_batch_norm_residual_relu_matches_torch(n, c, training):
+    """relu(bn(x) + identity) in the batch-norm passes (the tail of a sparse basic block, sparse_block.py:127-139): output,
+    the gradients of x, of the identity branch and of the affine parameters, and the bookkeeping, against torch in
+    float64; then the block itself (SparseBasicBlock) with the fused passes against its reference order of operations."""
+    from sst_amd.norm import BatchNorm1d, batch_norm_act
+    torch.manual_seed(n + c)
+    dev = _dev()
+    x = (torch.randn(n, c, device=dev) * 2 + torch.linspace(-5, 5, c, device=dev)).requires_grad_(True)
+    res = torch.randn(n, c, device=dev).requires_grad_(True)
+    bn = BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).double()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(-1.0, 2.0, c))
+        bn.bias.copy_(torch.linspace(-0.5, 0.5, c))
+        ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    bn.train(training)
+    ref.train(training)
+    y = batch_norm_act(bn, x, relu=True, residual=res)
+    xr, rr = x.detach().double().requires_grad_(True), res.detach().double().requires_grad_(True)
+    pre = ref(xr) + rr
+    yr = F.relu(pre)
+    gy = torch.randn(n, c, device=dev)
+    y.backward(gy)
+    yr.backward(gy.double())
+    assert (y.double() - yr).abs().max().item() < TOL * 0.1
+    safe = pre.detach().abs() > 1e-4
+    assert (~safe).float().mean().item() < 1e-2
+    scale = max(1.0, xr.grad.abs().max().item())
+    assert ((x.grad.double() - xr.grad).abs() * safe).max().item() < TOL * 0.1 * scale
+    assert ((res.grad.double() - rr.grad).abs() * safe).max().item() < 1e-6
+    flip = ((gy.double().abs() * (~safe)).sum(0) * 6.0).max().item()
+    for p, q in ((bn.weight, ref.weight), (bn.bias, ref.bias)):
+        assert (p.grad.double() - q.grad).abs().max().item() < 1e-4 * max(1.0, q.grad.abs().max().item()) + flip
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == (1 if training else 0)
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, atol=1e-5, rtol=1e-5)
+
+
+def test_sparse_basic_block_fused_tail_equals_the_composed_one():
+    from sst_amd import spconv
+    from sst_amd.sparse_unet import SparseBasicBlock
+    torch.manual_seed(5)
+    dev = _dev()
+    n, c = 3000, 32
+    coords = torch.unique(torch.cat([torch.zeros(n, 1, dtype=torch.int32), torch.randint(0, 24, (n, 3), dtype=torch.int32)], 1), dim=0)
+    feats = torch.randn(coords.size(0), c)
+    blk = SparseBasicBlock(c, c, norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01),
+                           conv_cfg=dict(type='SubMConv3d', indice_key='k')).to(dev).train()
+    outs = []
+    for fused in (True, False):
+        blk.zero_grad()
+        f = feats.to(dev).requires_grad_(True)
+        t = spconv.SparseConvTensor(f, coords.to(dev), [24, 24, 24], 1)
+        if not fused:
+            blk.relu = torch.nn.ReLU(inplace=False)
+            blk.relu.__class__ = type('ReLUComposed', (torch.nn.ReLU,), {})   # not `nn.ReLU` itself: the composed order runs
+        y = blk(t).features
+        y.backward(torch.ones_like(y) * 0.01)
+        outs.append((y.detach(), f.grad.clone(), blk.conv1.weight.grad.clone(), blk.norm2.weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+
+
 def test_batch_norm_strided_rows_and_module_forward():
     from sst_amd.norm import BatchNorm1d, build_norm_layer
     dev = _dev()
