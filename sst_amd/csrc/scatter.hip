@@ -218,26 +218,43 @@ struct seg_rec {                  // partial result of a run, one channel vector
   int4 a;
 };
 
-// Records travel between workgroups (possibly on different XCDs, whose L2s are not coherent with each other) as
-// device-scope atomic READ-MODIFY-WRITE operations, word by word: an RMW is always performed at the coherence point of its
-// scope, whatever the caches hold (the relaxed atomic load / store builtins compiled to one device-scope access followed by
-// seven plain ones here, which is not enough).  A device-scope FENCE instead (__threadfence) writes back the whole L2 of
-// the XCD: with one per workgroup the launch serialised (measured: 50 us for 10 MB).
+// Records travel between workgroups that may run on different XCDs, whose L2s are not coherent with each other: they are
+// written and read with AGENT-scope accesses (`sc1`: the store writes through to, the load reads from, the point that is
+// coherent for the whole device), 16 bytes at a time, and the writer waits for its stores (s_waitcnt vmcnt(0)) BEFORE the
+// workgroup takes the group's ticket.  History: the relaxed atomic load / store builtins compiled to one scoped access
+// followed by seven plain ones; word-wise atomic exchanges worked only once their results were consumed (a fire-and-forget
+// exchange is not ordered before the ticket by a workgroup-scope fence, which is `s_waitcnt lgkmcnt(0)` on this target:
+// 1-8 % of the launches at 50 000 x 256 gave one wrong group) and cost 8 atomics per lane and record (a 160 000-row
+// reduction spent most of its 93 us in them); a device-scope FENCE (__threadfence) writes back the whole L2 of the XCD and
+// serialised the launch (50 us for 10 MB).
 __device__ __forceinline__ void seg_rec_store(seg_rec* p, const seg_rec& r) {
-  int* d = (int*)p;
-  const int w[8] = {__float_as_int(r.v.x), __float_as_int(r.v.y), __float_as_int(r.v.z), __float_as_int(r.v.w),
-                    r.a.x, r.a.y, r.a.z, r.a.w};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) atomicExch(d + i, w[i]);
+  typedef float seg_f4 __attribute__((ext_vector_type(4)));
+  typedef int seg_i4 __attribute__((ext_vector_type(4)));
+  const seg_f4 v = {r.v.x, r.v.y, r.v.z, r.v.w};
+  const seg_i4 a = {r.a.x, r.a.y, r.a.z, r.a.w};
+  asm volatile(
+      "global_store_dwordx4 %0, %1, off sc1\n\t"
+      "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      :
+      : "v"(p), "v"(v), "v"(a)
+      : "memory");
 }
 __device__ __forceinline__ seg_rec seg_rec_load(const seg_rec* p) {
-  int* d = (int*)p;
-  int w[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = atomicOr(d + i, 0);
+  typedef float seg_f4 __attribute__((ext_vector_type(4)));
+  typedef int seg_i4 __attribute__((ext_vector_type(4)));
+  seg_f4 v;
+  seg_i4 a;
+  asm volatile(
+      "global_load_dwordx4 %0, %2, off sc1\n\t"
+      "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v), "=&v"(a)
+      : "v"(p)
+      : "memory");
   seg_rec r;
-  r.v = make_float4(__int_as_float(w[0]), __int_as_float(w[1]), __int_as_float(w[2]), __int_as_float(w[3]));
-  r.a = make_int4(w[4], w[5], w[6], w[7]);
+  r.v = make_float4(v.x, v.y, v.z, v.w);
+  r.a = make_int4(a.x, a.y, a.z, a.w);
   return r;
 }
 
@@ -407,8 +424,9 @@ __global__ __launch_bounds__(256) void seg_tiles_k(const float* __restrict__ fea
   }
   // ---- groups that cross tiles: the last of their tiles to arrive merges their records ----
   if (dbg == 2) return;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the record stores have completed (s_waitcnt) ...
-  __syncthreads();                                         // ... in every thread, before the tickets are taken
+  // every record store above waited for its own completion (seg_rec_store); the barrier then orders all of them, in every
+  // thread, before the tickets are taken
+  __syncthreads();
 #pragma unroll 1
   for (int slot = 0; slot < 2; ++slot) {
     const int g = tile_grp[slot];
@@ -422,7 +440,6 @@ __global__ __launch_bounds__(256) void seg_tiles_k(const float* __restrict__ fea
     }
     __syncthreads();
     if (finish[0]) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const int ta = finish[1], tb = finish[2];
       float4 acc = ident;
       int4 arg = noarg;
@@ -776,17 +793,20 @@ int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uin
 }
 
 // geometry of seg_tiles_k for a width: channel vectors, row lanes per workgroup
-static void seg_tiles_shape(int c, int* v, int* cv, int* lanes) {
+static void seg_tiles_shape(int c, int64_t n, int* v, int* cv, int* lanes) {
   *v = (c % 4 == 0) ? 4 : 1;
   *cv = c / *v;
   *lanes = 256 / *cv;
-  if (*lanes > 32) *lanes = 32;      // <= 256 rows per tile: enough tiles for a small input to spread over the CUs
+  if (*lanes > 32) *lanes = 32;      // <= 256 rows per tile
+  // narrow inputs (the 3-channel centroid means): fewer row lanes per tile while that is what it takes to give every CU a
+  // tile - the merge of the lane records is serial in the lanes
+  while (*lanes > 8 && n / ((int64_t)*lanes * kSegSpan) < 256) *lanes >>= 1;
 }
 
 int64_t sst_segment_long_scratch_bytes(int64_t n, int64_t m, int c) {
   if (n < 1 || m < 1 || c < 1 || c > 256) return 256;
   int v, cv, lanes;
-  seg_tiles_shape(c, &v, &cv, &lanes);
+  seg_tiles_shape(c, n, &v, &cv, &lanes);
   const int64_t tiles = sst_div_up(n, (int64_t)lanes * kSegSpan);
   return sst_align_up(m * 4, 256) + sst_align_up(tiles * 2 * cv * (int64_t)sizeof(seg_rec), 256);
 }
@@ -799,7 +819,7 @@ int sst_segment_reduce_long_f32(const float* d_feats, int64_t n, int c, const ui
   if (!d_feats || !d_perm || !d_inverse || !d_offsets || !d_scratch || !d_out) return SST_ERR_ARG;
   if (c > 256 || n > 0x7fffffff || (((uintptr_t)d_scratch) & 255)) return SST_ERR_UNSUPPORTED;
   int v, cv, lanes;
-  seg_tiles_shape(c, &v, &cv, &lanes);
+  seg_tiles_shape(c, n, &v, &cv, &lanes);
   if (256 % cv != 0 && cv * lanes > 256) return SST_ERR_UNSUPPORTED;
   if (v == 4 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15)) return SST_ERR_UNSUPPORTED;
   const int64_t tiles = sst_div_up(n, (int64_t)lanes * kSegSpan);
