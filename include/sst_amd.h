@@ -403,7 +403,8 @@ int sst_scatter_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_id
  * (a13, §8 f1) row-wise pieces of an encoder layer around the attention core.
  *   sst_add_layernorm_fwd_f32: y = LayerNorm(x + res) * weight + bias per row (res may be NULL);
  *     replaces `src = self.norm1(src + src2)` (models/sst/sst_basic_block_v2.py:113-118).  d_sum (optional)
- *     receives x + res (saved for backward), d_stats [m,2] receives (mean, rstd).  c % 4 == 0, c <= 512.
+ *     receives x + res (saved for backward), d_stats [m,2] receives (mean, rstd).  1 <= c <= 512 (16-byte accesses
+ *     when c % 4 == 0 and the operands are 16-byte aligned, 4-byte accesses otherwise: FSD's SIR layers have C = 133 ...).
  *   sst_add_layernorm_bwd_f32: d_dx = gradient w.r.t. (x + res) (same tensor for both addends);
  *     d_dweight / d_dbias [c] are overwritten with the column reductions.
  *   sst_colsum_f32: out[c] = sum over rows of x[m, c] (row stride ld) — bias gradients of the

@@ -152,6 +152,93 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restri
   for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
 }
 
+// Any width 1 <= C <= 512 (FSD's first SIR layer of a stack and its relative-position gate have C = 5 + point features: 133,
+// 148 ...; rows are then not 16-byte aligned): the same two kernels with 4-byte accesses, lane l of the row's 32-lane group
+// owning columns l, l + 32, ...  The row (<= 2 KB) is read from cache in the later passes instead of being kept in registers.
+constexpr int kLnMaxScalar = 16;   // 512 / 32 columns per lane
+
+__global__ __launch_bounds__(kLnThreads) void add_ln_fwd_any_k(const float* __restrict__ x, const float* __restrict__ r,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               int64_t m, int c, float eps, float* __restrict__ y,
+                                                               float* __restrict__ sum_out, float2* __restrict__ stats) {
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  for (int64_t row = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row < m; row += (int64_t)gridDim.x * kLnRowsPerBlock) {
+    float v[kLnMaxScalar];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxScalar; ++k) {
+      const int col = k * 32 + lane;
+      v[k] = 0.f;
+      if (col < c) {
+        v[k] = x[row * c + col] + (r != nullptr ? r[row * c + col] : 0.f);
+        if (sum_out != nullptr) sum_out[row * c + col] = v[k];
+        s += v[k];
+      }
+    }
+    const float mean = group32_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxScalar; ++k)
+      if (k * 32 + lane < c) q += (v[k] - mean) * (v[k] - mean);
+    const float rstd = rsqrtf(group32_sum(q) / (float)c + eps);
+#pragma unroll
+    for (int k = 0; k < kLnMaxScalar; ++k) {
+      const int col = k * 32 + lane;
+      if (col < c) y[row * c + col] = (v[k] - mean) * rstd * w[col] + b[col];
+    }
+    if (lane == 0) stats[row] = make_float2(mean, rstd);
+  }
+}
+
+__global__ __launch_bounds__(kLnThreads) void add_ln_bwd_any_k(const float* __restrict__ dy, const float* __restrict__ s,
+                                                               const float2* __restrict__ stats,
+                                                               const float* __restrict__ w, int64_t m, int c,
+                                                               float* __restrict__ dx, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [2][c]
+  for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) part[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  float aw[kLnMaxScalar], ab[kLnMaxScalar];
+#pragma unroll
+  for (int k = 0; k < kLnMaxScalar; ++k) aw[k] = ab[k] = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row < m; row += (int64_t)gridDim.x * kLnRowsPerBlock) {
+    const float2 st = stats[row];
+    float g[kLnMaxScalar], xh[kLnMaxScalar];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxScalar; ++k) {
+      const int col = k * 32 + lane;
+      g[k] = xh[k] = 0.f;
+      if (col < c) {
+        const float d = dy[row * c + col];
+        xh[k] = (s[row * c + col] - st.x) * st.y;
+        g[k] = d * w[col];
+        sg += g[k];
+        sgx += g[k] * xh[k];
+        aw[k] += d * xh[k];
+        ab[k] += d;
+      }
+    }
+    const float mg = group32_sum(sg) / (float)c, mgx = group32_sum(sgx) / (float)c;
+#pragma unroll
+    for (int k = 0; k < kLnMaxScalar; ++k) {
+      const int col = k * 32 + lane;
+      if (col < c) dx[row * c + col] = st.y * (g[k] - mg - xh[k] * mgx);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kLnMaxScalar; ++k) {
+    const int col = k * 32 + lane;
+    if (col < c) {
+      atomicAdd(&part[col], aw[k]);       // LDS: the 8 row groups of the block (order-dependent only in the last bit)
+      atomicAdd(&part[c + col], ab[k]);
+    }
+  }
+  __syncthreads();
+  float* dst = partials + (int64_t)blockIdx.x * 2 * c;
+  for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
+}
+
 // C = 128 (every SST config): one float4 per lane, FOUR rows per 32-lane group in flight per iteration (the generic
 // kernel above issues the two loads of a single row, then two dependent 5-step shuffle reductions: latency-bound
 // at two waves per SIMD, 4.2 TB/s).
@@ -584,12 +671,18 @@ extern "C" {
 
 int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
                               int64_t m, int c, float eps, float* d_y, float* d_sum, float* d_stats, void* stream) {
-  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (m < 0 || c < 1 || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
   if (m == 0) return SST_OK;
   if (!d_x || !d_weight || !d_bias || !d_y || !d_stats) return SST_ERR_ARG;
   const int grid = sst_grid_1d(m, kLnRowsPerBlock);
-  hipLaunchKernelGGL(add_ln_fwd_k, dim3(grid), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res, d_weight, d_bias,
-                     m, c, eps, d_y, d_sum, (float2*)d_stats);
+  const bool vec = (c & 3) == 0 && (((uintptr_t)d_x | (uintptr_t)d_res | (uintptr_t)d_y | (uintptr_t)d_sum |
+                                      (uintptr_t)d_weight | (uintptr_t)d_bias) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(add_ln_fwd_k, dim3(grid), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res, d_weight, d_bias,
+                       m, c, eps, d_y, d_sum, (float2*)d_stats);
+  else
+    hipLaunchKernelGGL(add_ln_fwd_any_k, dim3(grid), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res, d_weight,
+                       d_bias, m, c, eps, d_y, d_sum, (float2*)d_stats);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
@@ -602,7 +695,7 @@ int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c) {
 int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
                                const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
                                void* d_workspace, void* stream) {
-  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (m < 0 || c < 1 || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
   if (!d_dweight || !d_dbias) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (m == 0) {
@@ -615,7 +708,13 @@ int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const floa
   if (grid > 512) grid = 512;
   float* partials = (float*)d_workspace;
   if (d_dy2 != nullptr && c != 128) return SST_ERR_UNSUPPORTED;
-  if (c == 128)
+  const bool vec = (c & 3) == 0 && (((uintptr_t)d_dy | (uintptr_t)d_dy2 | (uintptr_t)d_sum | (uintptr_t)d_dx |
+                                      (uintptr_t)d_weight) & 15) == 0;
+  if (!vec && d_dy2 != nullptr) return SST_ERR_UNSUPPORTED;
+  if (!vec)
+    hipLaunchKernelGGL(add_ln_bwd_any_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
+                       (const float2*)d_stats, d_weight, m, c, d_dx, partials);
+  else if (c == 128)
     hipLaunchKernelGGL(add_ln_bwd_c128_k, dim3(grid), dim3(kLnThreads), 0, st, d_dy, d_dy2, d_sum, (const float2*)d_stats,
                        d_weight, m, d_dx, partials);
   else
@@ -652,7 +751,7 @@ int sst_add_layernorm_fwd_bf16(const void* d_x, const void* d_res, const float* 
 int sst_add_layernorm_bwd_bf16(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
                                const float* d_weight, int64_t m, int c, void* d_dx, float* d_dweight, float* d_dbias,
                                void* d_workspace, void* stream) {
-  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (m < 0 || c < 1 || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
   if (!d_dweight || !d_dbias) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (m == 0) {

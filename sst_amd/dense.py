@@ -309,15 +309,15 @@ class AddLayerNorm(Function):
 
 def add_layer_norm(x, res, norm):
     """norm(x + res) (res may be None): the fused add + LayerNorm kernel for an nn.LayerNorm, the module's own forward
-    for any other norm layer; torch for LayerNorm shapes the kernel is not built for (never for the SST configs:
-    C = 128 / 192)."""
+    for any other norm layer; torch for LayerNorm shapes the kernel is not built for (C > 512, norms over more than the
+    last dimension)."""
     c = x.size(-1)
     if not isinstance(norm, torch.nn.LayerNorm):
         # layer_cfg use_bn=True (sst_basic_block_v2.py:92-99, configs/fsd/fsd_waymoD1_1x_sst_encoder.py): norm1 / norm2
         # are naiveSyncBN1d modules, whose own forward runs the batch-norm kernels of csrc/bn.hip
         return norm(x + res if res is not None else x)
     ok = (x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda
-          and norm.elementwise_affine and norm.bias is not None and c % 4 == 0 and c <= 512)
+          and norm.elementwise_affine and norm.bias is not None and 1 <= c <= 512 and len(norm.normalized_shape) == 1)
     if not ok:
         y = x + res if res is not None else x
         return torch.nn.functional.layer_norm(y, norm.normalized_shape, norm.weight, norm.bias, norm.eps)

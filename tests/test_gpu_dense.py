@@ -7,7 +7,8 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.mark.parametrize('m,c', [(1, 128), (77, 128), (5000, 192), (90107, 128), (1000, 64), (300, 512)])
+@pytest.mark.parametrize('m,c', [(1, 128), (77, 128), (5000, 192), (90107, 128), (1000, 64), (300, 512), (18443, 133), (50000, 148), (7, 1),
+                                 (333, 16), (1000, 511)])
 @pytest.mark.parametrize('with_res', [True, False])
 def test_add_layer_norm_matches_torch(m, c, with_res):
     from sst_amd.dense import add_layer_norm
