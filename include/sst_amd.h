@@ -410,6 +410,16 @@ int sst_scatter_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_id
  *   sst_colsum_f32: out[c] = sum over rows of x[m, c] (row stride ld) — bias gradients of the
  *     projections / FFN.  c % 4 == 0, c <= 1024.
  * ---------------------------------------------------------------------------------------------- */
+/*   sst_add_layernorm_act_{fwd,bwd}_f32: the same with an activation behind the norm in the same pass, y = act(LayerNorm(
+ *     x + res)) - "Linear -> LN -> GELU" of FSD's SIR layers and MLPs (voxel_encoder.py:628-650, sst_ops.py:334-361).
+ *     act: 0 none, 1 GELU (erf form), 2 ReLU.  The backward takes dy at the activation's OUTPUT and recomputes the norm's
+ *     output from the saved sum and statistics (hence d_bias). */
+int sst_add_layernorm_act_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
+                                  int64_t m, int c, float eps, int act, float* d_y, float* d_sum, float* d_stats,
+                                  void* stream);
+int sst_add_layernorm_act_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats, const float* d_weight,
+                                  const float* d_bias, int act, int64_t m, int c, float* d_dx, float* d_dweight,
+                                  float* d_dbias, void* d_workspace, void* stream);
 int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
                               int64_t m, int c, float eps, float* d_y, float* d_sum, float* d_stats,
                               void* stream);

@@ -11,6 +11,31 @@ constexpr int kLnThreads = 256;
 constexpr int kLnRowsPerBlock = kLnThreads / 32;  // one row per 32-lane half-wave
 constexpr int kLnMaxVec = 4;                      // up to 4 float4 per lane -> C <= 512
 
+// activation folded into the LayerNorm passes ("Linear -> LN -> GELU" of FSD's SIR layers, voxel_encoder.py:628-650):
+// 0 none, 1 GELU (erf form; Abramowitz-Stegun 7.1.26, |error| < 1.5e-7, as in csrc/dense_f32.hip), 2 ReLU
+__device__ __forceinline__ float ln_erf(float z, float& e) {
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+  e = __expf(-az * az);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  return copysignf(fmaf(-poly, e, 1.f), z);
+}
+__device__ __forceinline__ float ln_act(float x, int act) {
+  if (act == 1) {
+    float e;
+    return 0.5f * x * (1.f + ln_erf(x * 0.70710678118654752f, e));
+  }
+  return act == 2 ? fmaxf(x, 0.f) : x;
+}
+__device__ __forceinline__ float ln_act_grad(float x, int act) {
+  if (act == 1) {
+    float e;
+    const float phi = 0.5f * (1.f + ln_erf(x * 0.70710678118654752f, e));
+    return fmaf(x * 0.3989422804014327f, e, phi);
+  }
+  return act == 2 ? (x > 0.f ? 1.f : 0.f) : 1.f;
+}
+
 __device__ __forceinline__ float group32_sum(float v) {
 #pragma unroll
   for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d, 64);
@@ -20,8 +45,9 @@ __device__ __forceinline__ float group32_sum(float v) {
 // y = LN(x + r) * w + b ; stats[row] = (mean, rstd).  r may be null.
 __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_k(const float* __restrict__ x, const float* __restrict__ r,
                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                           int64_t m, int c, float eps, float* __restrict__ y,
-                                                           float* __restrict__ sum_out, float2* __restrict__ stats) {
+                                                           int64_t m, int c, float eps, int act,
+                                                           float* __restrict__ y, float* __restrict__ sum_out,
+                                                           float2* __restrict__ stats) {
   const int lane = threadIdx.x & 31;
   const int sub = threadIdx.x >> 5;
   const int nvec = (c + 127) / 128;
@@ -68,6 +94,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_k(const float* __restri
         o.y = (v[k].y - mean) * rstd * wv.y + bv.y;
         o.z = (v[k].z - mean) * rstd * wv.z + bv.z;
         o.w = (v[k].w - mean) * rstd * wv.w + bv.w;
+        if (act) o.x = ln_act(o.x, act), o.y = ln_act(o.y, act), o.z = ln_act(o.z, act), o.w = ln_act(o.w, act);
         *(float4*)(y + row * c + col) = o;
       }
     }
@@ -79,7 +106,8 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_k(const float* __restri
 // dw += sum_rows dy * xhat ; db += sum_rows dy   (block partials in LDS, then one atomic per column per block)
 __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restrict__ dy, const float* __restrict__ s,
                                                            const float2* __restrict__ stats,
-                                                           const float* __restrict__ w, int64_t m, int c,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ b, int act, int64_t m, int c,
                                                            float* __restrict__ dx,
                                                            float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float part[];  // [2][c]
@@ -100,10 +128,17 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restri
       const int col = k * 128 + lane * 4;
       g[k] = xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k < nvec && col < c) {
-        const float4 d = *(const float4*)(dy + row * c + col);
+        float4 d = *(const float4*)(dy + row * c + col);
         const float4 sv = *(const float4*)(s + row * c + col);
         const float4 wv = *(const float4*)(w + col);
         xh[k] = make_float4((sv.x - st.x) * st.y, (sv.y - st.x) * st.y, (sv.z - st.x) * st.y, (sv.w - st.x) * st.y);
+        if (act) {   // the gradient arrives behind the activation: through it first, at the recomputed LayerNorm output
+          const float4 bv = *(const float4*)(b + col);
+          d.x *= ln_act_grad(fmaf(xh[k].x, wv.x, bv.x), act);
+          d.y *= ln_act_grad(fmaf(xh[k].y, wv.y, bv.y), act);
+          d.z *= ln_act_grad(fmaf(xh[k].z, wv.z, bv.z), act);
+          d.w *= ln_act_grad(fmaf(xh[k].w, wv.w, bv.w), act);
+        }
         g[k] = make_float4(d.x * wv.x, d.y * wv.y, d.z * wv.z, d.w * wv.w);
         sg += g[k].x + g[k].y + g[k].z + g[k].w;
         sgx += g[k].x * xh[k].x + g[k].y * xh[k].y + g[k].z * xh[k].z + g[k].w * xh[k].w;
@@ -159,8 +194,9 @@ constexpr int kLnMaxScalar = 16;   // 512 / 32 columns per lane
 
 __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_any_k(const float* __restrict__ x, const float* __restrict__ r,
                                                                const float* __restrict__ w, const float* __restrict__ b,
-                                                               int64_t m, int c, float eps, float* __restrict__ y,
-                                                               float* __restrict__ sum_out, float2* __restrict__ stats) {
+                                                               int64_t m, int c, float eps, int act,
+                                                               float* __restrict__ y, float* __restrict__ sum_out,
+                                                               float2* __restrict__ stats) {
   const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
   for (int64_t row = (int64_t)blockIdx.x * kLnRowsPerBlock + sub; row < m; row += (int64_t)gridDim.x * kLnRowsPerBlock) {
     float v[kLnMaxScalar];
@@ -184,7 +220,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_any_k(const float* __re
 #pragma unroll
     for (int k = 0; k < kLnMaxScalar; ++k) {
       const int col = k * 32 + lane;
-      if (col < c) y[row * c + col] = (v[k] - mean) * rstd * w[col] + b[col];
+      if (col < c) y[row * c + col] = ln_act((v[k] - mean) * rstd * w[col] + b[col], act);
     }
     if (lane == 0) stats[row] = make_float2(mean, rstd);
   }
@@ -192,7 +228,8 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_any_k(const float* __re
 
 __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_any_k(const float* __restrict__ dy, const float* __restrict__ s,
                                                                const float2* __restrict__ stats,
-                                                               const float* __restrict__ w, int64_t m, int c,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ b, int act, int64_t m, int c,
                                                                float* __restrict__ dx, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float part[];  // [2][c]
   for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) part[i] = 0.f;
@@ -210,8 +247,9 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_any_k(const float* __re
       const int col = k * 32 + lane;
       g[k] = xh[k] = 0.f;
       if (col < c) {
-        const float d = dy[row * c + col];
+        float d = dy[row * c + col];
         xh[k] = (s[row * c + col] - st.x) * st.y;
+        if (act) d *= ln_act_grad(fmaf(xh[k], w[col], b[col]), act);
         g[k] = d * w[col];
         sg += g[k];
         sgx += g[k] * xh[k];
@@ -669,9 +707,10 @@ __global__ __launch_bounds__(256) void cast_add_pos_bf16_k(const T* __restrict__
 
 extern "C" {
 
-int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
-                              int64_t m, int c, float eps, float* d_y, float* d_sum, float* d_stats, void* stream) {
-  if (m < 0 || c < 1 || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+int sst_add_layernorm_act_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
+                                  int64_t m, int c, float eps, int act, float* d_y, float* d_sum, float* d_stats,
+                                  void* stream) {
+  if (m < 0 || c < 1 || c > 128 * kLnMaxVec || act < 0 || act > 2) return SST_ERR_UNSUPPORTED;
   if (m == 0) return SST_OK;
   if (!d_x || !d_weight || !d_bias || !d_y || !d_stats) return SST_ERR_ARG;
   const int grid = sst_grid_1d(m, kLnRowsPerBlock);
@@ -679,12 +718,17 @@ int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float*
                                       (uintptr_t)d_weight | (uintptr_t)d_bias) & 15) == 0;
   if (vec)
     hipLaunchKernelGGL(add_ln_fwd_k, dim3(grid), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res, d_weight, d_bias,
-                       m, c, eps, d_y, d_sum, (float2*)d_stats);
+                       m, c, eps, act, d_y, d_sum, (float2*)d_stats);
   else
     hipLaunchKernelGGL(add_ln_fwd_any_k, dim3(grid), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res, d_weight,
-                       d_bias, m, c, eps, d_y, d_sum, (float2*)d_stats);
+                       d_bias, m, c, eps, act, d_y, d_sum, (float2*)d_stats);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
+                              int64_t m, int c, float eps, float* d_y, float* d_sum, float* d_stats, void* stream) {
+  return sst_add_layernorm_act_fwd_f32(d_x, d_res, d_weight, d_bias, m, c, eps, 0, d_y, d_sum, d_stats, stream);
 }
 
 int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c) {
@@ -692,10 +736,11 @@ int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c) {
   return (int64_t)1024 * 2 * c * sizeof(float) + 256;
 }
 
-int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
-                               const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
-                               void* d_workspace, void* stream) {
-  if (m < 0 || c < 1 || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+static int add_layernorm_bwd_any(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
+                                 const float* d_weight, const float* d_bias, int act, int64_t m, int c, float* d_dx,
+                                 float* d_dweight, float* d_dbias, void* d_workspace, void* stream) {
+  if (m < 0 || c < 1 || c > 128 * kLnMaxVec || act < 0 || act > 2) return SST_ERR_UNSUPPORTED;
+  if (act && (!d_bias || d_dy2)) return SST_ERR_ARG;
   if (!d_dweight || !d_dbias) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (m == 0) {
@@ -709,21 +754,35 @@ int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const floa
   float* partials = (float*)d_workspace;
   if (d_dy2 != nullptr && c != 128) return SST_ERR_UNSUPPORTED;
   const bool vec = (c & 3) == 0 && (((uintptr_t)d_dy | (uintptr_t)d_dy2 | (uintptr_t)d_sum | (uintptr_t)d_dx |
-                                      (uintptr_t)d_weight) & 15) == 0;
+                                      (uintptr_t)d_weight | (uintptr_t)d_bias) & 15) == 0;
   if (!vec && d_dy2 != nullptr) return SST_ERR_UNSUPPORTED;
   if (!vec)
     hipLaunchKernelGGL(add_ln_bwd_any_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
-                       (const float2*)d_stats, d_weight, m, c, d_dx, partials);
-  else if (c == 128)
+                       (const float2*)d_stats, d_weight, d_bias, act, m, c, d_dx, partials);
+  else if (c == 128 && act == 0)
     hipLaunchKernelGGL(add_ln_bwd_c128_k, dim3(grid), dim3(kLnThreads), 0, st, d_dy, d_dy2, d_sum, (const float2*)d_stats,
                        d_weight, m, d_dx, partials);
   else
     hipLaunchKernelGGL(add_ln_bwd_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
-                       (const float2*)d_stats, d_weight, m, c, d_dx, partials);
+                       (const float2*)d_stats, d_weight, d_bias, act, m, c, d_dx, partials);
   hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
                      d_dbias, c);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
+                               const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
+                               void* d_workspace, void* stream) {
+  return add_layernorm_bwd_any(d_dy, d_dy2, d_sum, d_stats, d_weight, nullptr, 0, m, c, d_dx, d_dweight, d_dbias,
+                               d_workspace, stream);
+}
+
+int sst_add_layernorm_act_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats, const float* d_weight,
+                                  const float* d_bias, int act, int64_t m, int c, float* d_dx, float* d_dweight,
+                                  float* d_dbias, void* d_workspace, void* stream) {
+  return add_layernorm_bwd_any(d_dy, nullptr, d_sum, d_stats, d_weight, d_bias, act, m, c, d_dx, d_dweight, d_dbias,
+                               d_workspace, stream);
 }
 
 int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats, const float* d_weight,

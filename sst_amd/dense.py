@@ -229,9 +229,13 @@ def tall_linear(x, weight, bias=None):
     return TallLinear.apply(x, weight, bias)
 
 
-def add_ln_fwd(x, res, weight, bias, eps, save_sum=True):
+_LN_ACTS = {None: 0, 'gelu': 1, 'relu': 2}
+
+
+def add_ln_fwd(x, res, weight, bias, eps, save_sum=True, act=None):
     """-> (y, s, stats) with s = x + res (== x when res is None), stats [M,2] = (mean, rstd).
-    save_sum=False (inference): the sum is not written (s is None), a quarter of the kernel's traffic."""
+    save_sum=False (inference): the sum is not written (s is None), a quarter of the kernel's traffic.
+    act: None | 'gelu' | 'relu' applied to the norm's output in the same pass."""
     x = x.contiguous()
     m, c = x.shape
     if res is not None:
@@ -239,12 +243,28 @@ def add_ln_fwd(x, res, weight, bias, eps, save_sum=True):
     y = torch.empty_like(x)
     s = (torch.empty_like(x) if save_sum else None) if res is not None else x
     stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
-    rc = _lib.load().sst_add_layernorm_fwd_f32(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), m, c,
-                                               float(eps), _lib.ptr(y),
-                                               _lib.ptr(s) if (res is not None and save_sum) else None,
-                                               _lib.ptr(stats), _lib.stream_ptr())
-    _lib.check(rc, 'sst_add_layernorm_fwd_f32')
+    rc = _lib.load().sst_add_layernorm_act_fwd_f32(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), m, c,
+                                                   float(eps), _LN_ACTS[act], _lib.ptr(y),
+                                                   _lib.ptr(s) if (res is not None and save_sum) else None,
+                                                   _lib.ptr(stats), _lib.stream_ptr())
+    _lib.check(rc, 'sst_add_layernorm_act_fwd_f32')
     return y, s, stats
+
+
+def add_ln_act_bwd(dy, s, stats, weight, bias, act):
+    """-> (d(x + res), dweight, dbias) of y = act(LayerNorm(x + res)); dy arrives at the activation's output"""
+    dy = dy.contiguous()
+    m, c = s.shape
+    dx = torch.empty_like(s)
+    dw = torch.empty(c, dtype=torch.float32, device=s.device)
+    db = torch.empty(c, dtype=torch.float32, device=s.device)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_add_layernorm_bwd_workspace_bytes(m, c), s.device)
+    rc = lib.sst_add_layernorm_act_bwd_f32(_lib.ptr(dy), _lib.ptr(s), _lib.ptr(stats), _lib.ptr(weight), _lib.ptr(bias),
+                                           _LN_ACTS[act], m, c, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
+                                           _lib.stream_ptr())
+    _lib.check(rc, 'sst_add_layernorm_act_bwd_f32')
+    return dx, dw, db
 
 
 def add_ln_bwd(dy, s, stats, weight, dy2=None):
@@ -291,34 +311,53 @@ def lds_linear_add_ln(x, w, bias, res, ln_weight, ln_bias, eps, save_sum=True, p
 
 
 class AddLayerNorm(Function):
-    """y = LayerNorm(x + res); the gradient w.r.t. x and res is the same tensor."""
+    """y = act(LayerNorm(x + res)) (act None | 'gelu' | 'relu'); the gradient w.r.t. x and res is the same tensor."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, eps):
-        y, s, stats = add_ln_fwd(x, res, weight, bias, eps)
-        ctx.save_for_backward(s, stats, weight)
-        ctx.has_res = res is not None
+    def forward(ctx, x, res, weight, bias, eps, act=None):
+        y, s, stats = add_ln_fwd(x, res, weight, bias, eps, act=act)
+        ctx.save_for_backward(s, stats, weight, bias)
+        ctx.has_res, ctx.act = res is not None, act
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        s, stats, weight = ctx.saved_tensors
-        dx, dw, db = add_ln_bwd(dy, s, stats, weight)
-        return dx, (dx if ctx.has_res else None), dw, db, None
+        s, stats, weight, bias = ctx.saved_tensors
+        if ctx.act is None:
+            dx, dw, db = add_ln_bwd(dy, s, stats, weight)
+        else:
+            dx, dw, db = add_ln_act_bwd(dy, s, stats, weight, bias, ctx.act)
+        return dx, (dx if ctx.has_res else None), dw, db, None, None
 
 
-def add_layer_norm(x, res, norm):
-    """norm(x + res) (res may be None): the fused add + LayerNorm kernel for an nn.LayerNorm, the module's own forward
+def _act_name(act):
+    """None / 'gelu' / 'relu' for the activations the LayerNorm kernels fold in, False for anything else"""
+    if act is None or isinstance(act, torch.nn.Identity):
+        return None
+    if isinstance(act, torch.nn.GELU) and getattr(act, 'approximate', 'none') == 'none':
+        return 'gelu'
+    if type(act) is torch.nn.ReLU:
+        return 'relu'
+    return False
+
+
+def add_layer_norm(x, res, norm, act=None):
+    """act(norm(x + res)) (res may be None; act: an nn.GELU / nn.ReLU module or None, folded into the same pass when the
+    kernel runs): the fused add + LayerNorm kernel for an nn.LayerNorm, the module's own forward
     for any other norm layer; torch for LayerNorm shapes the kernel is not built for (C > 512, norms over more than the
     last dimension)."""
     c = x.size(-1)
+    post = (lambda t: t) if act is None else act
     if not isinstance(norm, torch.nn.LayerNorm):
         # layer_cfg use_bn=True (sst_basic_block_v2.py:92-99, configs/fsd/fsd_waymoD1_1x_sst_encoder.py): norm1 / norm2
         # are naiveSyncBN1d modules, whose own forward runs the batch-norm kernels of csrc/bn.hip
-        return norm(x + res if res is not None else x)
+        return post(norm(x + res if res is not None else x))
     ok = (x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda
           and norm.elementwise_affine and norm.bias is not None and 1 <= c <= 512 and len(norm.normalized_shape) == 1)
     if not ok:
         y = x + res if res is not None else x
-        return torch.nn.functional.layer_norm(y, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
-    return AddLayerNorm.apply(x, res, norm.weight, norm.bias, norm.eps)
+        return post(torch.nn.functional.layer_norm(y, norm.normalized_shape, norm.weight, norm.bias, norm.eps))
+    name = _act_name(act)
+    if name is False:
+        return act(AddLayerNorm.apply(x, res, norm.weight, norm.bias, norm.eps))
+    return AddLayerNorm.apply(x, res, norm.weight, norm.bias, norm.eps, name)

@@ -291,6 +291,21 @@ def get_activation(activation):
     return fns[activation]
 
 
+class _MLPStage(nn.Sequential):
+    """[Linear, norm, act (, dropout)] with the children and parameter names of the nn.Sequential the reference builds;
+    LayerNorm + activation run as one pass (csrc/dense.hip) on CUDA float32 features."""
+
+    def forward(self, x):
+        norm = self[1]
+        if isinstance(norm, nn.LayerNorm) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            from .dense import add_layer_norm
+            y = add_layer_norm(self[0](x), None, norm, act=self[2])
+            for extra in list(self)[3:]:
+                y = extra(y)
+            return y
+        return super().forward(x)
+
+
 def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias=False, dropout=0):
     """Sequential of [Linear -> norm -> act (-> dropout)] stages; with ``is_head`` the last stage is a bare Linear
     with bias (sst_ops.py:334-361)."""
@@ -306,6 +321,6 @@ def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias
             parts = [nn.Linear(width, out, bias=bias), norm_layer, act_layer]
             if dropout > 0:
                 parts.append(nn.Dropout(dropout))
-            stages.append(nn.Sequential(*parts))
+            stages.append(_MLPStage(*parts))
         width = out
     return nn.Sequential(*stages)

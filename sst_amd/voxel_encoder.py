@@ -70,7 +70,7 @@ class DynamicVFELayerV2(nn.Module):
             y = batch_norm_act(self.norm, y, relu=relu)
             return y if relu else self.act(y)
         if isinstance(self.norm, nn.LayerNorm):  # FSD's SIR layers: norm_cfg = LN (row kernel of csrc/dense.hip)
-            return self.act(add_layer_norm(y, None, self.norm))
+            return add_layer_norm(y, None, self.norm, act=self.act)   # norm + activation in one pass
         return self.act(self.norm(y))
 
 

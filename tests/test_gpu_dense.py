@@ -38,6 +38,58 @@ def test_add_layer_norm_matches_torch(m, c, with_res):
     assert torch.allclose(gb, norm.bias.grad, atol=2e-4 * scale, rtol=1e-3)
 
 
+@pytest.mark.parametrize('m,c', [(18443, 128), (5000, 133), (1000, 16), (300, 512), (9, 3)])
+@pytest.mark.parametrize('act', ['gelu', 'relu'])
+def test_layer_norm_with_folded_activation_matches_torch(m, c, act):
+    """act(LayerNorm(x)) in one pass (Linear -> LN -> GELU of FSD's SIR layers, voxel_encoder.py:628-650): output and every
+    gradient against torch's composition in float64; then an MLP stage of build_mlp (sst_ops.py:334-361) end to end."""
+    from sst_amd.dense import add_layer_norm
+    g = torch.Generator().manual_seed(m + c)
+    x = (torch.randn(m, c, generator=g) * 2 + 0.5).to(DEV)
+    norm = torch.nn.LayerNorm(c).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(c, generator=g) * 0.1)
+    mod = torch.nn.GELU() if act == 'gelu' else torch.nn.ReLU()
+    gout = torch.randn(m, c, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.double().clone().requires_grad_(True)
+    y = add_layer_norm(xa, None, norm, act=mod)
+    (y * gout).sum().backward()
+    gw, gb = norm.weight.grad.clone(), norm.bias.grad.clone()
+    pre = F.layer_norm(xb, (c,), norm.weight.double(), norm.bias.double(), norm.eps)
+    wd, bd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    pre = F.layer_norm(xb, (c,), wd, bd, norm.eps)
+    y_ref = F.gelu(pre) if act == 'gelu' else F.relu(pre)
+    (y_ref * gout.double()).sum().backward()
+    assert float((y.double() - y_ref).abs().max()) < 2e-5
+    safe = (pre.detach().abs() > 1e-4) if act == 'relu' else torch.ones_like(pre, dtype=torch.bool)
+    assert float(((xa.grad.double() - xb.grad).abs() * safe.any(1, keepdim=True)).max()) < 5e-4 * max(1.0, float(xb.grad.abs().max()))
+    flip = float((gout.double().abs() * (~safe)).sum(0).max()) * 6.0
+    assert float((gw.double() - wd.grad).abs().max()) < 2e-4 * max(1.0, float(wd.grad.abs().max())) + flip
+    assert float((gb.double() - bd.grad).abs().max()) < 2e-4 * max(1.0, float(bd.grad.abs().max())) + flip
+
+
+def test_mlp_stage_runs_the_fused_norm_and_keeps_the_reference_layout():
+    from sst_amd.sst_ops import build_mlp
+    torch.manual_seed(3)
+    mlp = build_mlp(3, [16, 32, 133], dict(type='LN', eps=1e-3), act='gelu').to(DEV)
+    assert [k for k in mlp.state_dict()][:3] == ['0.0.weight', '0.1.weight', '0.1.bias']
+    x = torch.randn(4000, 3, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = mlp(xa)
+    y.square().sum().backward()
+    ga = [p.grad.clone() for p in mlp.parameters()]
+    mlp.zero_grad()
+    t = xb
+    for stage in mlp:      # the composition the reference runs: Linear, LayerNorm, GELU one after the other
+        t = F.gelu(F.layer_norm(F.linear(t, stage[0].weight), stage[1].normalized_shape, stage[1].weight, stage[1].bias, stage[1].eps))
+    t.square().sum().backward()
+    assert float((y - t).abs().max()) < 1e-4
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-3 * max(1.0, float(xb.grad.abs().max()))
+    for a, p in zip(ga, mlp.parameters()):
+        assert float((a - p.grad).abs().max()) < 1e-3 * max(1.0, float(p.grad.abs().max()))
+
+
 @pytest.mark.parametrize('m,cin,cout,bias', [(90107, 128, 384, True), (4097, 256, 128, True), (116000, 9, 64, False),
                                              (100, 128, 128, True), (50000, 128, 256, True), (90107, 128, 128, False),
                                              (33333, 96, 160, True), (116000, 128, 128, False), (5000, 64, 32, True),
