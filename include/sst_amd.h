@@ -304,6 +304,21 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
                          int impl, float* d_dq, float* d_dk, float* d_dv, int64_t lddq, int64_t lddk,
                          int64_t lddv, void* d_workspace, void* stream);
 
+/* The same two calls with a LAUNCH ORDER of the windows: d_win_order (may be NULL) is a permutation of 0 .. n_windows - 1;
+ * the workgroups are dispatched from its END (so: windows sorted by ascending token count = the largest windows first,
+ * which shortens the tail of the launch: -5 % on the bench frame).  Results do not depend on it.  Used by the
+ * register-resident kernels (impl 0 / 3 forward, impl 0 backward); the other kernels ignore it. */
+int sst_sra_attn_fwd_ord_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int n_heads, float scale, int max_tokens, int impl, float* d_o, int64_t ldo, float* d_lse,
+                             void* stream);
+int sst_sra_attn_bwd_ord_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o, const float* d_do,
+                             const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int64_t n_tokens, int n_heads, float scale, int max_tokens, int impl, float* d_dq,
+                             float* d_dk, float* d_dv, int64_t lddq, int64_t lddk, int64_t lddv, void* d_workspace,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (a12, reduced precision) The same attention core with bf16 storage: Q, K, V, O, dO, dQ, dK, dV are bf16 ([M, n_heads*16],
  * row strides in elements, multiples of 4; 8-byte aligned), the softmax, the log-sum-exp (fp32 [M, n_heads]) and every

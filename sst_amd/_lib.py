@@ -78,6 +78,11 @@ _SIGNATURES = {
     'sst_sra_attn_bwd_f32': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_i64, c_i64, c_i32, c_f32,
                                                                  c_i32, c_i32, c_ptr, c_ptr, c_ptr,
                                                                  c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'sst_sra_attn_fwd_ord_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i32,
+                                         c_f32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_sra_attn_bwd_ord_f32': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_f32,
+                                                                     c_i32, c_i32, c_ptr, c_ptr, c_ptr,
+                                                                     c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sst_sra_attn_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_sra_attn_fwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_i32,
                                       c_ptr, c_i64, c_ptr, c_ptr]),

@@ -141,14 +141,23 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
   __syncthreads();
   {
     unsigned mine[4] = {0u, 0u, 0u, 0u};   // bit k of mine[v]: wave v multiplies offset k (as far as THIS wave has seen)
-    for (int e0 = 0; e0 < kvol * ROWS; e0 += 256) {
-      const int e = e0 + tid;
+    // all the index loads of the thread are issued before the first one is used (one memory round trip for the image,
+    // not one per step: the set-up of a workgroup was 9 of its 95 us)
+    constexpr int NIT = (kOsMaxK * ROWS + 255) / 256;
+    int vals[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = it * 256 + tid;
+      const int k = e / ROWS, row = e - k * ROWS;
+      vals[it] = (k < kvol && r0 + row < m) ? map[(int64_t)k * m + r0 + row] : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = it * 256 + tid;
       const int k = e / ROWS, row = e - k * ROWS;   // uniform k per wave (ROWS is a multiple of 64)
-      int v = -1;
-      if (k < kvol) {
-        v = (r0 + row < m) ? map[(int64_t)k * m + r0 + row] : -1;
-        idx[k][row] = v;
-      }
+      if (it * 256 >= kvol * ROWS) break;           // uniform
+      const int v = vals[it];
+      if (k < kvol) idx[k][row] = v;
       const unsigned long long b = __ballot(v >= 0);
       const int kk = k < kvol ? k : 0;
       const int first_blk = (row & ~63) / 16;        // the 4 sixteen-row blocks this wave's 64 rows cover

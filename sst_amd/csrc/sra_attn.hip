@@ -56,6 +56,9 @@ constexpr int kGC = 64;     // channels per workgroup (kGH * kHD)
 // one-shot measurement hooks (sst_sra_attn_profile_next_fwd / _bwd): per calling thread, consumed by the next launch
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 thread_local hipEvent_t g_prof_bwd_start = nullptr, g_prof_bwd_stop = nullptr;
+// launch order of the windows of the CURRENT call (sst_sra_attn_{fwd,bwd}_ord_f32 set it around the plain entry points):
+// workgroup position p handles window order[p]; nullptr = window p
+thread_local const int32_t* g_win_order = nullptr;
 constexpr int kWH = SST_WAVE_HEADS;  // heads (= waves) per workgroup of the register-resident kernels
 constexpr int kRS = 68;     // LDS row stride (floats)
 constexpr int kMaxTilesMfma = 9;
@@ -442,10 +445,11 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_wave_k(const float* __restri
                                                       int64_t ldv, const int32_t* __restrict__ tok,
                                                       const int32_t* __restrict__ winoff, int n_groups, int H,
                                                       float scale, float* __restrict__ O, int64_t ldo,
-                                                      float* __restrict__ LSE) {
+                                                      float* __restrict__ LSE, const int32_t* __restrict__ order) {
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
-  const int w = bid / n_groups;
-  const int hg = bid - w * n_groups;
+  const int wpos = bid / n_groups;
+  const int hg = bid - wpos * n_groups;
+  const int w = order != nullptr ? order[wpos] : wpos;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
@@ -1057,12 +1061,14 @@ __global__ __launch_bounds__(64 * kWH, WPS) void sra_bwd_fused_k(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     int64_t lddo, const int32_t* __restrict__ tok, const int32_t* __restrict__ winoff, int n_groups, int H, float scale,
-    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv) {
+    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv,
+    const int32_t* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool NH = WPS >= 3;
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
-  const int w = bid / n_groups;
-  const int hg = bid - w * n_groups;
+  const int wpos = bid / n_groups;
+  const int hg = bid - wpos * n_groups;
+  const int w = order != nullptr ? order[wpos] : wpos;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
@@ -1106,10 +1112,10 @@ int launch_bwd_fused(const float* Q, const float* K, const float* V, const float
   }
   if (e0 != nullptr)  // kernel-exact start / stop timestamps on the launch stream
     hipExtLaunchKernelGGL((sra_bwd_fused_k<NTMAX, WPS>), grid, dim3(64 * kWH), lds, st, e0, e1, 0, Q, K, V, O, dO, LSE, ldq,
-                          ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
+                          ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order);
   else
     hipLaunchKernelGGL((sra_bwd_fused_k<NTMAX, WPS>), grid, dim3(64 * kWH), lds, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo,
-                       lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv);
+                       lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order);
   return SST_OK;
 }
 
@@ -1150,12 +1156,12 @@ int launch_fwd_wave(const float* Q, const float* K, const float* V, int64_t ldq,
     // between the marks and the kernel, unlike a pair of hipEventRecord calls around the launch)
     hipExtLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st,
                           g_prof_start, g_prof_stop, 0, Q, K, V, ldq, ldk, ldv, tok, winoff, n_groups, H, scale, O, ldo,
-                          LSE);
+                          LSE, g_win_order);
     g_prof_start = g_prof_stop = nullptr;
     return SST_OK;
   }
   hipLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st, Q, K, V, ldq, ldk,
-                     ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE);
+                     ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE, g_win_order);
   return SST_OK;
 }
 
@@ -1227,6 +1233,17 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
   }
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_sra_attn_fwd_ord_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int n_heads, float scale, int max_tokens, int impl, float* d_o, int64_t ldo, float* d_lse,
+                             void* stream) {
+  g_win_order = d_win_order;
+  const int rc = sst_sra_attn_fwd_f32(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale,
+                                      max_tokens, impl, d_o, ldo, d_lse, stream);
+  g_win_order = nullptr;
+  return rc;
 }
 
 int64_t sst_sra_attn_bwd_workspace_bytes(int64_t n_tokens, int n_heads) {
@@ -1324,6 +1341,20 @@ float sst_event_elapsed_ms(void* start, void* stop) {
   if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
   if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
   return ms;
+}
+
+int sst_sra_attn_bwd_ord_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o, const float* d_do,
+                             const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int64_t n_tokens, int n_heads, float scale, int max_tokens, int impl, float* d_dq,
+                             float* d_dk, float* d_dv, int64_t lddq, int64_t lddk, int64_t lddv, void* d_workspace,
+                             void* stream) {
+  g_win_order = d_win_order;
+  const int rc = sst_sra_attn_bwd_f32(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
+                                      n_windows, n_tokens, n_heads, scale, max_tokens, impl, d_dq, d_dk, d_dv, lddq,
+                                      lddk, lddv, d_workspace, stream);
+  g_win_order = nullptr;
+  return rc;
 }
 
 int sst_sra_attn_profile_next_fwd(void* start, void* stop) {

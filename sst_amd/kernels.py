@@ -350,11 +350,25 @@ def region_batching(win0, win1, win_bits, levels):
 # ----------------------------------------------------------------------------------------------
 class WindowPlan(object):
     """Window CSR consumed by the SRA kernels: tokens of window w are tok[winoff[w]:winoff[w+1]]."""
-    __slots__ = ('tok', 'winoff', 'n_windows', 'n_tokens', 'max_tokens')
+    __slots__ = ('tok', 'winoff', 'n_windows', 'n_tokens', 'max_tokens', '_order')
 
     def __init__(self, tok, winoff, n_windows, n_tokens, max_tokens):
         self.tok, self.winoff = tok, winoff
         self.n_windows, self.n_tokens, self.max_tokens = int(n_windows), int(n_tokens), int(max_tokens)
+        self._order = None
+
+    @property
+    def order(self):
+        """launch order of the windows for the register-resident kernels: ascending token count (they dispatch from the
+        end: largest windows first).  Two small launches, once per plan - a plan serves every encoder layer of its shift,
+        forward and backward.  None for small plans, where every workgroup is resident at once anyway."""
+        if self._order is None and self.n_windows >= WINDOW_ORDER_MIN:
+            off = self.winoff[:self.n_windows + 1]
+            self._order = torch.sort(off[1:] - off[:-1], stable=True)[1].to(torch.int32)
+        return self._order
+
+
+WINDOW_ORDER_MIN = 512    # windows below which the launch order is left alone (0 switches the ordering off: set to 1 << 30)
 
 
 def _row_stride(t):
@@ -423,11 +437,12 @@ def _sra_fwd(q, k, v, plan, n_heads, scale, impl):
     else:
         o = torch.empty((m, c), dtype=torch.float32, device=q.device)
     lse = torch.empty((m, n_heads), dtype=torch.float32, device=q.device)
-    rc = _bracket('sra_fwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_fwd_f32(
+    order = plan.order
+    rc = _bracket('sra_fwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_fwd_ord_f32(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _row_stride(q), _row_stride(k), _row_stride(v),
-        _lib.ptr(plan.tok), _lib.ptr(plan.winoff), plan.n_windows, n_heads, float(scale), plan.max_tokens,
-        impl, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr()))
-    _lib.check(rc, 'sst_sra_attn_fwd_f32')
+        _lib.ptr(plan.tok), _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None, plan.n_windows,
+        n_heads, float(scale), plan.max_tokens, impl, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_sra_attn_fwd_ord_f32')
     return o, lse
 
 
@@ -435,13 +450,14 @@ def _sra_bwd(q, k, v, o, lse, grad_o, plan, n_heads, scale, impl, dq, dk, dv):
     m = q.size(0)
     lib = _lib.load()
     ws = _lib.workspace(lib.sst_sra_attn_bwd_workspace_bytes(m, n_heads), q.device)
-    rc = _bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_sra_attn_bwd_f32(
+    order = plan.order
+    rc = _bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_sra_attn_bwd_ord_f32(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(grad_o), _lib.ptr(lse), _row_stride(q),
         _row_stride(k), _row_stride(v), o.stride(0), grad_o.stride(0), _lib.ptr(plan.tok),
-        _lib.ptr(plan.winoff), plan.n_windows, m, n_heads, scale, plan.max_tokens, impl,
-        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk), _row_stride(dv),
-        _lib.ptr(ws), _lib.stream_ptr()))
-    _lib.check(rc, 'sst_sra_attn_bwd_f32')
+        _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None, plan.n_windows, m, n_heads, scale,
+        plan.max_tokens, impl, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk),
+        _row_stride(dv), _lib.ptr(ws), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_sra_attn_bwd_ord_f32')
 
 
 def _grad_buf(shape, device, full):

@@ -132,6 +132,31 @@ def test_sra_core_properties_full_size():
     assert float((ol - o1).abs().max()) < 1e-4
 
 
+def test_sra_window_launch_order_changes_nothing_but_the_schedule(monkeypatch):
+    """the plan's launch order (windows by ascending token count, dispatched from the end) is a permutation, and the
+    forward output and the three gradients are bit for bit what the row order gives"""
+    from sst_amd import kernels as K
+    rng = np.random.default_rng(1)
+    sizes = rng.integers(1, 101, size=1500).tolist()
+    plan, tok, off, m = _plan_from_sizes(sizes, 4)
+    order = plan.order
+    assert order is not None and sorted(order.cpu().tolist()) == list(range(len(sizes)))
+    assert (np.diff(np.asarray(sizes)[order.cpu().numpy()]) >= 0).all()
+    g = torch.Generator().manual_seed(5)
+    q, k, v, do = (torch.randn(m, 128, generator=g).to(DEV) for _ in range(4))
+    outs = []
+    for ordered in (True, False):
+        monkeypatch.setattr(K, 'WINDOW_ORDER_MIN', 512 if ordered else 1 << 30)
+        p = K.WindowPlan(plan.tok, plan.winoff, plan.n_windows, plan.n_tokens, plan.max_tokens)
+        assert (p.order is not None) == ordered
+        qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+        o = K.sra_attention(qa, ka, va, p, 8)
+        o.backward(do)
+        outs.append((o.detach(), qa.grad, ka.grad, va.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _load_block(g, layer_cfg):
     import sst_amd
     d, h, ffn = int(g['cfg::d_model']), int(g['cfg::nhead']), int(g['cfg::ffn'])
