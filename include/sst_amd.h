@@ -336,6 +336,16 @@ int sst_sra_attn_bwd_bf16(const void* d_q, const void* d_k, const void* d_v, con
                           int max_tokens, void* d_dq, void* d_dk, void* d_dv, int64_t lddq, int64_t lddk, int64_t lddv,
                           void* stream);
 int sst_sra_attn_bf16_profile_next(int backward, void* start, void* stop);
+/* with a launch order of the windows (see sst_sra_attn_fwd_ord_f32) */
+int sst_sra_attn_fwd_ord_bf16(const void* d_q, const void* d_k, const void* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, float scale, int max_tokens, void* d_o, int64_t ldo, float* d_lse,
+                              void* stream);
+int sst_sra_attn_bwd_ord_bf16(const void* d_q, const void* d_k, const void* d_v, const void* d_o, const void* d_do,
+                              const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, float scale, int max_tokens, void* d_dq, void* d_dk, void* d_dv, int64_t lddq,
+                              int64_t lddk, int64_t lddv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels of the reduced-precision encoder layer: bf16 storage, fp32 parameters / statistics / arithmetic.

@@ -89,6 +89,10 @@ _SIGNATURES = {
     'sst_sra_attn_bwd_bf16': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_i64, c_i32, c_f32, c_i32, c_ptr, c_ptr,
                                                                   c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     'sst_sra_attn_bf16_profile_next': (c_i32, [c_i32, c_ptr, c_ptr]),
+    'sst_sra_attn_fwd_ord_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32,
+                                          c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_sra_attn_bwd_ord_bf16': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_i32, c_ptr,
+                                                                      c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
     'sst_add_layernorm_fwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_ptr, c_ptr, c_ptr]),
     'sst_add_layernorm_bwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,

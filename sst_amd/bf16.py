@@ -52,20 +52,24 @@ def sra_fwd(q, k, v, plan, n_heads, scale):
     o = alloc((m, c), dtype=BF16, device=q.device)
     lse = torch.empty((m, n_heads), dtype=torch.float32, device=q.device)
     lib = _lib.load()
-    rc = _timed('sra_fwd_bf16', plan.n_tokens, 0, lambda: lib.sst_sra_attn_fwd_bf16(
+    order = plan.order
+    rc = _timed('sra_fwd_bf16', plan.n_tokens, 0, lambda: lib.sst_sra_attn_fwd_ord_bf16(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _ld(q), _ld(k), _ld(v), _lib.ptr(plan.tok), _lib.ptr(plan.winoff),
-        plan.n_windows, n_heads, float(scale), plan.max_tokens, _lib.ptr(o), _ld(o), _lib.ptr(lse), _lib.stream_ptr()))
-    _lib.check(rc, 'sst_sra_attn_fwd_bf16')
+        _lib.ptr(order) if order is not None else None, plan.n_windows, n_heads, float(scale), plan.max_tokens,
+        _lib.ptr(o), _ld(o), _lib.ptr(lse), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_sra_attn_fwd_ord_bf16')
     return o, lse
 
 
 def sra_bwd(q, k, v, o, lse, do, plan, n_heads, scale, dq, dk, dv):
     lib = _lib.load()
-    rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_sra_attn_bwd_bf16(
+    order = plan.order
+    rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_sra_attn_bwd_ord_bf16(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(do), _lib.ptr(lse), _ld(q), _ld(k), _ld(v), _ld(o),
-        _ld(do), _lib.ptr(plan.tok), _lib.ptr(plan.winoff), plan.n_windows, n_heads, float(scale), plan.max_tokens,
-        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _ld(dq), _ld(dk), _ld(dv), _lib.stream_ptr()))
-    _lib.check(rc, 'sst_sra_attn_bwd_bf16')
+        _ld(do), _lib.ptr(plan.tok), _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None,
+        plan.n_windows, n_heads, float(scale), plan.max_tokens, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _ld(dq), _ld(dk),
+        _ld(dv), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_sra_attn_bwd_ord_bf16')
 
 
 def _timed(kind, n_tokens, backward, fn):

@@ -173,10 +173,11 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_bf16_k(const unsigned short*
                                                            int64_t ldv, const int32_t* __restrict__ tok,
                                                            const int32_t* __restrict__ winoff, int n_groups, int H,
                                                            float scale, unsigned short* __restrict__ O, int64_t ldo,
-                                                           float* __restrict__ LSE) {
+                                                           float* __restrict__ LSE, const int32_t* __restrict__ order) {
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
-  const int w = bid / n_groups;
-  const int hg = bid - w * n_groups;
+  const int wpos = bid / n_groups;
+  const int hg = bid - wpos * n_groups;
+  const int w = order != nullptr ? order[wpos] : wpos;   // launch order of the windows (sst_sra_attn_*_ord_bf16)
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
@@ -329,10 +330,12 @@ __global__ __launch_bounds__(64 * kWH, (NTMAX > 7 ? 2 : 3)) void sra_bwd_bf16_k(
     const unsigned short* __restrict__ O, const unsigned short* __restrict__ dO, const float* __restrict__ LSE,
     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* __restrict__ tok,
     const int32_t* __restrict__ winoff, int n_groups, int H, float scale, unsigned short* __restrict__ dQ,
-    unsigned short* __restrict__ dK, unsigned short* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv) {
+    unsigned short* __restrict__ dK, unsigned short* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv,
+    const int32_t* __restrict__ order) {
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
-  const int w = bid / n_groups;
-  const int hg = bid - w * n_groups;
+  const int wpos = bid / n_groups;
+  const int hg = bid - wpos * n_groups;
+  const int w = order != nullptr ? order[wpos] : wpos;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(64 * kWH, (NTMAX > 7 ? 2 : 3)) void sra_bwd_bf16_k(
 }
 
 thread_local hipEvent_t g_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // one-shot hooks: [fwd|bwd][start|stop]
+thread_local const int32_t* g_win_order = nullptr;   // launch order of the current call (the *_ord_* entries set it)
 
 bool aligned8(const void* p) { return ((uintptr_t)p & 7) == 0; }
 
@@ -367,10 +371,10 @@ int launch_fwd(const unsigned short* q, const unsigned short* k, const unsigned 
   g_ev[0][0] = g_ev[0][1] = nullptr;
   if (e0 != nullptr && e1 != nullptr)
     hipExtLaunchKernelGGL(sra_fwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), 0, st, e0, e1, 0, q, k, v, ldq, ldk, ldv, tok, winoff,
-                          n_groups, H, scale, o, ldo, lse);
+                          n_groups, H, scale, o, ldo, lse, g_win_order);
   else
     hipLaunchKernelGGL(sra_fwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), 0, st, q, k, v, ldq, ldk, ldv, tok, winoff, n_groups, H,
-                       scale, o, ldo, lse);
+                       scale, o, ldo, lse, g_win_order);
   return SST_OK;
 }
 
@@ -386,10 +390,10 @@ int launch_bwd(const unsigned short* q, const unsigned short* k, const unsigned 
   g_ev[1][0] = g_ev[1][1] = nullptr;
   if (e0 != nullptr && e1 != nullptr)
     hipExtLaunchKernelGGL(sra_bwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), lds, st, e0, e1, 0, q, k, v, o, g, lse, ldq, ldk, ldv,
-                          ldo, ldg, tok, winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv);
+                          ldo, ldg, tok, winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv, g_win_order);
   else
     hipLaunchKernelGGL(sra_bwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), lds, st, q, k, v, o, g, lse, ldq, ldk, ldv, ldo, ldg, tok,
-                       winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv);
+                       winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv, g_win_order);
   return SST_OK;
 }
 
@@ -450,6 +454,29 @@ int sst_sra_attn_bwd_bf16(const void* d_q, const void* d_k, const void* d_v, con
   if (rc) return rc;
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_sra_attn_fwd_ord_bf16(const void* d_q, const void* d_k, const void* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, float scale, int max_tokens, void* d_o, int64_t ldo, float* d_lse,
+                              void* stream) {
+  g_win_order = d_win_order;
+  const int rc = sst_sra_attn_fwd_bf16(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, scale, max_tokens,
+                                       d_o, ldo, d_lse, stream);
+  g_win_order = nullptr;
+  return rc;
+}
+
+int sst_sra_attn_bwd_ord_bf16(const void* d_q, const void* d_k, const void* d_v, const void* d_o, const void* d_do,
+                              const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, float scale, int max_tokens, void* d_dq, void* d_dk, void* d_dv, int64_t lddq,
+                              int64_t lddk, int64_t lddv, void* stream) {
+  g_win_order = d_win_order;
+  const int rc = sst_sra_attn_bwd_bf16(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
+                                       n_windows, n_heads, scale, max_tokens, d_dq, d_dk, d_dv, lddq, lddk, lddv, stream);
+  g_win_order = nullptr;
+  return rc;
 }
 
 int sst_sra_attn_bf16_profile_next(int backward, void* start, void* stop) {
