@@ -14,6 +14,8 @@ objects instead of the reference's per-level dictionaries:
   channels-last) and handed on as the channels-last view of the reference's [B, C, ny, nx] tensor;
 * SIR groups the points of a cluster ONCE (``UniquePlan``) and every layer's pooling reuses it.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -67,6 +69,38 @@ def recover_bev(voxel_feat, coors, batch_size, output_shape):
     flat = (coors[:, 0] * ny + coors[:, 2]) * nx + coors[:, 3]
     canvas = voxel_feat.new_zeros((batch_size * ny * nx, c)).index_put((flat.long(),), voxel_feat)
     return canvas.view(batch_size, ny, nx, c).permute(0, 3, 1, 2)
+
+
+def _sparse_first_conv_ok(conv, voxel_feat):
+    """the first attached convolution can run on the voxel rows themselves: a plain 2-D convolution that keeps the canvas
+    size, fp32 CUDA rows of a width the sparse-convolution kernels take"""
+    if os.environ.get('SST_BEV_SPARSE_FIRST_CONV', '1') == '0' or not isinstance(conv, nn.Conv2d):
+        return False
+    k, d, p = conv.kernel_size, conv.dilation, conv.padding
+    return (conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == 'zeros'
+            and not isinstance(p, str) and all(2 * p[i] == d[i] * (k[i] - 1) for i in range(2)) and k[0] * k[1] <= 32
+            and voxel_feat.is_cuda and voxel_feat.dtype == torch.float32 and voxel_feat.size(1) % 4 == 0
+            and voxel_feat.size(0) > 0)
+
+
+def sparse_first_conv(voxel_feat, coors, batch_size, output_shape, conv):
+    """``conv(recover_bev(voxel_feat))`` WITHOUT the dense input canvas (recover_bev + first dilated
+    convolution, sst_v2.py:139-197): the non-empty voxels are 41 % of the 468 x 468 cells on the bench frame, so the
+    convolution runs as a sparse one - the cells with at least one voxel under their stencil are the output rows of a
+    2-D rulebook (csrc/spconv.hip, dense-grid builder), the contraction and both gradients are the sparse-convolution
+    kernels (csrc/spconv_os.hip: 9 x M pairs instead of 9 x all cells) - and only its OUTPUT is scattered into the dense
+    canvas the batch norm behind it needs (every other cell is exactly 0, as in the dense convolution without bias)."""
+    from . import spconv
+    ny, nx = output_shape
+    (kh, kw), (dh, dw), (ph, pw) = conv.kernel_size, conv.dilation, conv.padding
+    zeros = torch.zeros_like(coors[:, 0])
+    cells = torch.stack([coors[:, 0], zeros, coors[:, 2], coors[:, 3]], 1).int()
+    outids, pairs, num = spconv.get_indice_pairs(cells, int(batch_size), [1, int(ny), int(nx)], [1, kh, kw], [1, 1, 1],
+                                                 [0, ph, pw], [1, dh, dw], subm=False)
+    # Conv2d weight [Cout, Cin, kh, kw] (cross-correlation) -> spconv filters [1, kh, kw, Cin, Cout]
+    filters = conv.weight.permute(2, 3, 1, 0).reshape(1, kh, kw, conv.in_channels, conv.out_channels)
+    rows = spconv.SparseConvFunction.apply(voxel_feat.contiguous(), filters, pairs, num, outids.size(0))
+    return recover_bev(rows, outids.long(), batch_size, output_shape)
 
 
 def _batch_size_of(info, coors_key):
@@ -150,11 +184,23 @@ class _WindowTransformer(nn.Module):
             x = block(x, pos, plans, masks, using_checkpoint=i in self.checkpoint_blocks)
         return x
 
-    def run_attached_convs(self, canvas, shortcut=False):
-        for stage in getattr(self, 'conv_layer', ()):
+    def run_attached_convs(self, canvas, shortcut=False, first=0):
+        for stage in list(getattr(self, 'conv_layer', ()))[first:]:
             y = stage(canvas)
             canvas = y + canvas if (shortcut and y.shape == canvas.shape) else y
         return canvas
+
+    def bev_and_attached_convs(self, feats, coors, batch_size, shortcut=False):
+        """recover_bev + the attached convolutions; the first convolution consumes the voxel rows directly when it can
+        (sparse_first_conv) - no dense input canvas - unless a shortcut needs that canvas"""
+        stages = getattr(self, 'conv_layer', ())
+        if len(stages) > 0 and not shortcut and _sparse_first_conv_ok(stages[0][0], feats):
+            y = sparse_first_conv(feats, coors, batch_size, self.output_shape, stages[0][0])
+            for layer in list(stages[0])[1:]:     # norm, ReLU of the first stage
+                y = layer(y)
+            return self.run_attached_convs(y, shortcut, first=1)
+        canvas = recover_bev(feats, coors, batch_size, self.output_shape)
+        return self.run_attached_convs(canvas, shortcut)
 
     def set_impl(self, impl):
         """0: MFMA SRA kernels (default); 1: generic VALU kernels (in-library cross-check)."""
@@ -212,8 +258,7 @@ class SSTv2(_WindowTransformer):
         if not self.to_bev:
             assert self.num_attached_conv <= 0, 'the attached convolutions need the BEV canvas'
             return [{'voxel_feats': feats, 'voxel_coors': coors}]
-        canvas = self.recover_bev(feats, coors, _batch_size_of(voxel_info, 'voxel_coors'))
-        return [self.run_attached_convs(canvas, self.conv_shortcut)]
+        return [self.bev_and_attached_convs(feats, coors, _batch_size_of(voxel_info, 'voxel_coors'), self.conv_shortcut)]
 
     def recover_bev(self, voxel_feat, coors, batch_size):
         return recover_bev(voxel_feat, coors, batch_size, self.output_shape)
@@ -277,8 +322,7 @@ class SSTv1(_WindowTransformer):
             plans.append(plan)
             pos.append(self.get_pos_embed_flat(voxel_info[f'coors_in_win_shift{i}'], voxel_feat.dtype))
         feats = self.run_blocks(voxel_feat, pos, plans)
-        canvas = recover_bev(feats, voxel_info['coors'], _batch_size_of(voxel_info, 'coors'), self.output_shape)
-        return [self.run_attached_convs(canvas)]
+        return [self.bev_and_attached_convs(feats, voxel_info['coors'], _batch_size_of(voxel_info, 'coors'))]
 
 
 @BACKBONES.register_module()
