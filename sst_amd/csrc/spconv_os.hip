@@ -140,9 +140,8 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
   if (tid < 4) live_w[tid] = 0u;
   __syncthreads();
   {
-    unsigned mine[4] = {0u, 0u, 0u, 0u};   // bit k of mine[v]: wave v multiplies offset k (as far as THIS wave has seen)
     // all the index loads of the thread are issued before the first one is used (one memory round trip for the image,
-    // not one per step: the set-up of a workgroup was 9 of its 95 us)
+    // not one per step)
     constexpr int NIT = (kOsMaxK * ROWS + 255) / 256;
     int vals[NIT];
 #pragma unroll
@@ -155,28 +154,13 @@ __global__ __launch_bounds__(256, (NCT == 4 && RB == 1) ? 4 : 1) void sp_conv_os
     for (int it = 0; it < NIT; ++it) {
       const int e = it * 256 + tid;
       const int k = e / ROWS, row = e - k * ROWS;   // uniform k per wave (ROWS is a multiple of 64)
-      if (it * 256 >= kvol * ROWS) break;           // uniform
-      const int v = vals[it];
+      const int v = vals[it];                        // (-1 behind the last offset: no bit set below)
       if (k < kvol) idx[k][row] = v;
+      // a wave holds 64 consecutive rows of ONE offset here: the ballot tells for each of their four 16-row blocks whether
+      // the offset has a partner; lane q < 4 reports block q to the wave that owns it
       const unsigned long long b = __ballot(v >= 0);
-      const int kk = k < kvol ? k : 0;
-      const int first_blk = (row & ~63) / 16;        // the 4 sixteen-row blocks this wave's 64 rows cover
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int owner = (first_blk + q) / RB;      // wave that owns the block
-        if ((b >> (16 * q)) & 0xffffull) {
-#pragma unroll
-          for (int v4 = 0; v4 < 4; ++v4)
-            if (owner == v4) mine[v4] |= 1u << kk;
-        }
-      }
-    }
-    if (lane < 4 && mine[lane & 3] != 0u) {
-      unsigned val = mine[0];
-      if (lane == 1) val = mine[1];
-      if (lane == 2) val = mine[2];
-      if (lane == 3) val = mine[3];
-      atomicOr(&live_w[lane], val);
+      const int blk = (row & ~63) / 16 + (lane & 3);
+      if (lane < 4 && k < kvol && ((b >> (16 * (lane & 3))) & 0xffffull)) atomicOr(&live_w[blk / RB], 1u << k);
     }
   }
   __syncthreads();
