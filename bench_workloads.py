@@ -454,6 +454,46 @@ def cpu_chain_leg(spec, model, clouds):
     return base, parity
 
 
+def _f32x3_leg(model, clouds, step, sync, args, world, dev):
+    """the same step with the sparse convolutions (forward contraction and data gradient) in split precision: three bf16
+    products of split fp32 operands, fp32 accumulation, fp32 in memory (csrc/spconv_os_x3.hip); reported BESIDE the exact-fp32
+    headline, with the forward deviation from it on the same frame"""
+    from sst_amd import spconv
+    with torch.no_grad():                               # training mode as in the step: batch statistics in both passes
+        _, _, ref = model(clouds, return_tensors=True)
+        spconv.set_conv_precision('f32x3')
+        try:
+            _, _, got = model(clouds, return_tensors=True)
+        finally:
+            spconv.set_conv_precision('f32')
+    errs = {}
+    for key in ('unet_feats', 'seg_feats', 'cluster_feats', 'virtual_feats'):
+        if key in ref and key in got and ref[key].shape == got[key].shape and ref[key].is_floating_point():
+            scale = max(1.0, float(ref[key].abs().max()))
+            errs[key] = round(float((ref[key] - got[key]).abs().max()) / scale, 8)
+    spconv.set_conv_precision('f32x3')
+    try:
+        for _ in range(2):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+    finally:
+        spconv.set_conv_precision('f32')
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {'value': round(world * args.frames_per_gpu * args.steps / elapsed, 3), 'unit': 'frames/s',
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'steps': args.steps,
+            'what': 'same step, sparse convolutions (forward + data gradient) as three bf16 MFMA products of split fp32 operands '
+                    'with fp32 accumulation; filter gradients, everything else and all tensors exact fp32',
+            'max_err_vs_exact_fp32_forward_rel_to_output_scale': errs}
+
+
 def run(args, rank, world, dev, make_reducer):
     """bench.py's contract for --workload fsd | fsdv2: W warm-up steps, K timed steps between barriers, max over ranks,
     one JSON line from rank 0."""
@@ -507,6 +547,9 @@ def run(args, rank, world, dev, make_reducer):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     conv, seg = _conv_roofline(model, clouds)
+    x3 = None
+    if not getattr(args, 'no_f32x3_leg', False):
+        x3 = _f32x3_leg(model, clouds, step, sync, args, world, dev)
     cpu_base = parity = None
     if rank == 0 and world == 1 and not getattr(args, 'no_cpu_baseline', False):
         cpu_base, parity = cpu_chain_leg(spec, model, clouds)
@@ -522,4 +565,6 @@ def run(args, rank, world, dev, make_reducer):
                                        '(detector glue is out of scope)'},
                'roofline': conv if conv is not None else seg, 'roofline_seg_reduce': seg, 'cpu_baseline': cpu_base,
                'parity': parity}
+        if x3 is not None:
+            res['precision_f32x3'] = x3
         print(json.dumps(res))

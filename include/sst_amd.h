@@ -727,6 +727,12 @@ int sst_spconv_os_tile_work_i32(const int32_t* d_map, int64_t m, int kvol, int t
 int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
                            int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy,
                            int tile_cfg, const int32_t* d_tile_order, void* d_workspace, void* stream);
+/*   sst_spconv_conv_os_f32x3: sst_spconv_conv_os_f32 in SPLIT precision - every fp32 product as three bf16 products of split
+ *     operands (x w ~= x_hi w_hi + x_lo w_hi + x_hi w_lo) on v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 in memory
+ *     (csrc/spconv_os_x3.hip; ~1e-5 of the output scale).  Same arguments, workspace size and launch order; tile_cfg = 0. */
+int sst_spconv_conv_os_f32x3(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
+                             int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
+                             const int32_t* d_tile_order, void* d_workspace, void* stream);
 /*   sst_spconv_wgrad_os_f32: the same filter gradient as sst_spconv_wgrad_f32 (indiceConvBackward, spconv_ops.h:359-446)
  *     with the gathered rows staged through LDS transposed, 64 x 64 blocks of dW[k], 2048-pair chunks (csrc/spconv_os.hip).
  *     cin % 4 == 0, cout % 4 == 0, row strides % 4 == 0, 16-byte aligned operands; SST_ERR_UNSUPPORTED otherwise. */

@@ -301,6 +301,23 @@ def _os_tile_order_enabled():
     return os.environ.get('SST_SPCONV_OS_ORDER', '1') != '0'
 
 
+_CONV_PRECISION = 'f32'
+
+
+def set_conv_precision(mode):
+    """'f32' (default: exact fp32 products, the parity mode) or 'f32x3': the forward contraction and the data gradient of
+    every sparse convolution as three bf16 products of split fp32 operands with fp32 accumulation
+    (csrc/spconv_os_x3.hip; ~1e-5 of the output scale per layer).  Filter gradients stay exact fp32."""
+    global _CONV_PRECISION
+    if mode not in ('f32', 'f32x3'):
+        raise ValueError(mode)
+    _CONV_PRECISION = mode
+
+
+def conv_precision():
+    return _CONV_PRECISION
+
+
 def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cfg=0):
     # density: a number, None, or the Rulebook (its `density` costs a host read-back: only the legacy path asks for it)
     """Y[r] = sum_k X[mapping[k][r]] W[k]; weight3 is [K, cin, cout], or [K, cout, cin] with trans_w."""
@@ -319,9 +336,10 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cf
         order = None
         if isinstance(density, Rulebook) and rows >= _OS_ORDER_MIN_ROWS and _os_tile_order_enabled():
             order = density.tile_order(mapping, rows, lib.sst_spconv_conv_os_tile_rows(rows, cout, int(tile_cfg)))
-        rc = lib.sst_spconv_conv_os_f32(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin,
-                                        cout, int(trans_w), None, _lib.ptr(y), y.stride(0), int(tile_cfg),
-                                        _lib.ptr(order) if order is not None else None, _lib.ptr(ws), _lib.stream_ptr())
+        entry = lib.sst_spconv_conv_os_f32x3 if (_CONV_PRECISION == 'f32x3' and int(tile_cfg) == 0) else lib.sst_spconv_conv_os_f32
+        rc = entry(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin, cout, int(trans_w), None,
+                   _lib.ptr(y), y.stride(0), int(tile_cfg), _lib.ptr(order) if order is not None else None, _lib.ptr(ws),
+                   _lib.stream_ptr())
         _lib.check(rc, 'sst_spconv_conv_os_f32')
         return y
     # first-generation kernels: compacted rows pay off when few offsets are populated or one 64-column group covers the

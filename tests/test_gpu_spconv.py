@@ -129,6 +129,40 @@ def test_output_stationary_kernel_launch_order(tile_cfg, monkeypatch):
     assert torch.equal(y_rows, y_ordered)
 
 
+@pytest.mark.parametrize('cin,cout', [(64, 64), (16, 32), (128, 160), (192, 256), (64, 128)])
+def test_split_precision_convolution_kernel(cin, cout):
+    """csrc/spconv_os_x3.hip: the contraction as three bf16 products of split fp32 operands (fp32 accumulation), forward
+    orientation and the transposed-weight orientation of the data gradient, against the float64 restatement of indiceConv
+    (spconv_ops.h:256-357): ~1e-5 of the output scale (the exact-fp32 kernel: ~1e-6), far inside the 1e-3 feature tolerance;
+    then a submanifold layer end to end in that mode (filter gradient exact fp32)."""
+    from oracle import spconv_oracle as O
+    from sst_amd import spconv
+    rng = np.random.default_rng(cin + cout)
+    batch, shape, n = 2, [6, 40, 44], 6000
+    ind = _cloud(rng, n, batch, shape)
+    try:
+        for subm, st in ((True, 1), (False, 2)):
+            outids, pairs, num, rb = _rulebook(ind, batch, shape, [3] * 3, [st] * 3, [1] * 3, [1] * 3, subm, False)
+            m = len(outids)
+            gen = torch.Generator().manual_seed(7)
+            x = torch.randn(n, cin, generator=gen) * 3
+            w = torch.randn(27, cin, cout, generator=gen) * 0.2
+            gy = torch.randn(m, cout, generator=gen)
+            p_np, n_np = pairs.cpu().numpy(), num.cpu().numpy()
+            y_ref = O.indice_conv(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), p_np, n_np, m)
+            dx_ref, _ = O.indice_conv_backward(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), gy.numpy(), p_np, n_np)
+            errs = {}
+            for mode in ('f32', 'f32x3'):
+                spconv.set_conv_precision(mode)
+                y = spconv._gather_gemm(x.to(DEV), rb.out2in, m, w.to(DEV), False, cout, rb)
+                dx = spconv._gather_gemm(gy.to(DEV), rb.in2out, n, w.to(DEV), True, cin, rb)
+                errs[mode] = (np.abs(y.cpu().numpy() - y_ref).max() / max(1.0, np.abs(y_ref).max()),
+                              np.abs(dx.cpu().numpy() - dx_ref).max() / max(1.0, np.abs(dx_ref).max()))
+            assert max(errs['f32']) < 5e-6 and max(errs['f32x3']) < 5e-5, errs
+    finally:
+        spconv.set_conv_precision('f32')
+
+
 def test_inverse_conv_matches_oracle_and_modules_chain():
     """SubMConv3d -> SparseConv3d (stride 2, indice_key) -> SubMConv3d -> SparseInverseConv3d back to the input voxels
     (the down / up pattern of middle_encoders/sparse_unet.py), forward and all gradients against the oracle."""
