@@ -1,0 +1,64 @@
+"""Host-side behaviour of the module mirrors added in round 3 that does not need a GPU: the torch compositions the fused
+passes stand for are what CPU tensors get (LayerNorm + activation, batch norm + identity + ReLU, the MLP stages of
+build_mlp), the parameter layout of the reference is kept, constants are uploaded once."""
+import torch
+import torch.nn.functional as F
+
+
+def test_mlp_stage_keeps_the_reference_layout_and_composition_on_cpu():
+    from sst_amd.sst_ops import build_mlp
+    torch.manual_seed(0)
+    mlp = build_mlp(3, [16, 32, 13], dict(type='LN', eps=1e-3), act='gelu')
+    keys = list(mlp.state_dict())
+    assert keys == ['0.0.weight', '0.1.weight', '0.1.bias', '1.0.weight', '1.1.weight', '1.1.bias', '2.0.weight', '2.1.weight',
+                    '2.1.bias']
+    x = torch.randn(50, 3)
+    t = x
+    for stage in mlp:
+        t = F.gelu(F.layer_norm(F.linear(t, stage[0].weight), stage[1].normalized_shape, stage[1].weight, stage[1].bias,
+                                stage[1].eps))
+    assert torch.allclose(mlp(x), t, atol=1e-6)
+    head = build_mlp(8, [16, 4], dict(type='LN', eps=1e-3), is_head=True, act='relu')
+    assert isinstance(head[1], torch.nn.Linear) and head[1].bias is not None
+
+
+def test_layer_norm_with_activation_on_cpu_is_the_torch_composition():
+    from sst_amd.dense import add_layer_norm
+    torch.manual_seed(1)
+    norm = torch.nn.LayerNorm(12)
+    x, r = torch.randn(9, 12), torch.randn(9, 12)
+    for act, fn in ((torch.nn.GELU(), F.gelu), (torch.nn.ReLU(), F.relu), (None, lambda t: t), (torch.nn.Tanh(), torch.tanh)):
+        want = fn(F.layer_norm(x + r, (12,), norm.weight, norm.bias, norm.eps))
+        assert torch.allclose(add_layer_norm(x, r, norm, act=act), want, atol=1e-6)
+
+
+def test_batch_norm_with_identity_branch_on_cpu_is_the_torch_composition():
+    from sst_amd.norm import BatchNorm1d, batch_norm_act
+    torch.manual_seed(2)
+    bn, ref = BatchNorm1d(8).train(), torch.nn.BatchNorm1d(8).train()
+    x, res = torch.randn(40, 8), torch.randn(40, 8)
+    got = batch_norm_act(bn, x, relu=True, residual=res)
+    want = F.relu(ref(x) + res)
+    assert torch.allclose(got, want, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-6)
+
+
+def test_constants_are_cached_per_value_device_and_dtype():
+    from sst_amd import kernels as K
+    a = K.const_tensor([0.25, 0.25, 0.2], torch.device('cpu'))
+    b = K.const_tensor((0.25, 0.25, 0.2), 'cpu')
+    c = K.const_tensor([0.25, 0.25, 0.2], torch.device('cpu'), torch.float64)
+    assert a is b and a is not c and c.dtype == torch.float64
+    assert a.tolist() == [0.25, 0.25, 0.20000000298023224]
+
+
+def test_conv_precision_switch_rejects_unknown_modes():
+    import pytest
+    from sst_amd import spconv
+    assert spconv.conv_precision() == 'f32'
+    spconv.set_conv_precision('f32x3')
+    assert spconv.conv_precision() == 'f32x3'
+    spconv.set_conv_precision('f32')
+    with pytest.raises(ValueError):
+        spconv.set_conv_precision('bf16')
