@@ -242,24 +242,35 @@ FSDV2_CFG = dict(
     mixer=dict(in_channels=128, sparse_shape=[20, 256, 256], base_channels=64, output_channels=128,
                encoder_channels=((64, ), (64, 64), (64, 64)), encoder_paddings=((1, ), (1, 1), (1, 1)),
                decoder_channels=((64, 64, 64), (64, 64, 64), (64, 64, 64)), decoder_paddings=((1, 1), (1, 1), (1, 1))),
-    virtual_vfe=dict(feat_channels=[64, 128]), proj_hidden=[64, 64])
+    virtual_vfe=dict(feat_channels=[64, 128]), proj_hidden=[64, 64],
+    # configs/fsdv2/fsdv2_nusc_1x.py:122-128 (norm_cfg is the projector's: naiveSyncBN1d with torch's defaults)
+    multiscale=dict(multiscale_levels=[0, 1, 2], projector_hiddens=[[256, 128], [128, 128], [128, 128]], fusion_mode='avg',
+                    target_sparse_shape=[20, 256, 256], norm_cfg=dict(type='naiveSyncBN1d')),
+    as_rpn=False)
+# the same chain at fixture size: a 4-level segmentor U-Net on [16, 128, 128] whose two coarsest decoder levels (strides 2 and 1
+# against the [8, 64, 64] virtual-voxel grid) are fused in; as_rpn on, as in configs/fsdv2/fsdv2_waymo_1x.py:103-104, 175
 FSDV2_SMALL_CFG = dict(
     seg_voxel=(0.2, 0.2, 0.2), virtual_voxel=(0.4, 0.4, 0.4), pc_range=[-12.8, -12.8, -2, 12.8, 12.8, 1.2], n_logits=5,
     vfe=dict(in_channels=5, feat_channels=[16, 16]),
     unet=dict(in_channels=16, sparse_shape=[16, 128, 128], base_channels=16, output_channels=16,
-              encoder_channels=((16, ), (16, 16), (32, 32)), encoder_paddings=((1, ), (1, 1), (1, 1)),
-              decoder_channels=((32, 32, 16), (16, 16, 16), (16, 16, 16)), decoder_paddings=((1, 1), (1, 0), (0, 1))),
+              encoder_channels=((16, ), (16, 16), (32, 32), (32, 32)), encoder_paddings=((1, ), (1, 1), (1, 1), (1, 1)),
+              decoder_channels=((32, 32, 32), (32, 32, 16), (16, 16, 16), (16, 16, 16)),
+              decoder_paddings=((1, 1), (1, 0), (0, 0), (0, 1))),
     mixer=dict(in_channels=16, sparse_shape=[8, 64, 64], base_channels=16, output_channels=16,
                encoder_channels=((16, ), (16, 16)), encoder_paddings=((1, ), (1, 1)),
                decoder_channels=((16, 16, 16), (16, 16, 16)), decoder_paddings=((1, 1), (1, 1))),
-    virtual_vfe=dict(feat_channels=[16, 16]), proj_hidden=[16, 16])
+    virtual_vfe=dict(feat_channels=[16, 16]), proj_hidden=[16, 16],
+    multiscale=dict(multiscale_levels=[0, 1], projector_hiddens=[[32, 16], [16, 16]], fusion_mode='avg',
+                    target_sparse_shape=[8, 64, 64], norm_cfg=dict(type='naiveSyncBN1d')),
+    as_rpn=True, recover_hidden=[16, 16])
 
 
 class FSDv2Path(nn.Module):
     """configs/fsdv2/fsdv2_nusc_1x.py at hot-path level over a module provider: segmentor (DynamicScatterVFE +
-    SimpleSparseUNet) -> point features -> virtual-voxel stage (SingleStageFSDV2.extract_feat).  Stand-ins: `seg_head`
-    (VoteSegHead: class logits + one 3-vector vote), foreground = points above the ground plane; the multi-scale fusion of
-    the config (multiscale_cfg) is not part of the stage (sst_amd/virtual_voxel.py)."""
+    SimpleSparseUNet with return_multiscale_features) -> point features -> virtual-voxel stage (SingleStageFSDV2.extract_feat
+    WITH the config's multiscale_cfg: the three coarsest decoder levels through their projectors into the virtual-voxel
+    grid, single_stage_fsd_v2.py:208-221, 375-433; with `as_rpn` also the per-point outputs of :263-270).  Stand-ins:
+    `seg_head` (VoteSegHead: class logits + one 3-vector vote), foreground = points above the ground plane."""
 
     def __init__(self, ops=GpuOps, cfg=None):
         super().__init__()
@@ -271,17 +282,24 @@ class FSDv2Path(nn.Module):
         self.voxel_encoder = ops.DynamicScatterVFE(voxel_size=self.SEG_VOXEL, with_cluster_center=True, with_voxel_center=True,
                                                    point_cloud_range=self.PC_RANGE, norm_cfg=BN, unique_once=True, **cfg['vfe'])
         self.middle_encoder = ops.PseudoMiddleEncoderForSpconvFSD()
-        self.seg_backbone = ops.SimpleSparseUNet(order=('conv', 'norm', 'act'), norm_cfg=BN, **cfg['unet'])
+        self.multiscale = cfg.get('multiscale')
+        self.as_rpn = bool(cfg.get('as_rpn', False))
+        self.seg_backbone = ops.SimpleSparseUNet(order=('conv', 'norm', 'act'), norm_cfg=BN,
+                                                 return_multiscale_features=self.multiscale is not None, **cfg['unet'])
         self.seg_head = nn.Linear(c_seg + 3, self.n_logits + 3)      # stand-in: classes + background, one centre vote
         hid = cfg['proj_hidden']
+        extra = {}
+        if self.as_rpn:
+            extra = dict(recover_in_channels=cfg['mixer']['output_channels'] + 3, recover_hidden_dims=cfg['recover_hidden'])
         self.virtual_stage = ops.VirtualVoxelExtractor(
+            multiscale_cfg=self.multiscale, as_rpn=self.as_rpn,
             backbone=dict(type='VirtualVoxelMixer', order=('conv', 'norm', 'act'), norm_cfg=BN, **cfg['mixer']),
             voxel_encoder=dict(type='DynamicScatterVFE', in_channels=3 + hid[-1], voxel_size=self.VIRTUAL_VOXEL,
                                with_cluster_center=True, with_voxel_center=True, point_cloud_range=self.PC_RANGE, norm_cfg=BN,
                                unique_once=True, **cfg['virtual_vfe']),
             virtual_point_projector=dict(in_channels=(c_seg + 3) + 3 + self.n_logits + 2, hidden_dims=hid,
                                          norm_cfg=dict(type='naiveSyncBN1d'), ori_in_channels=c_seg + 3,
-                                         ori_hidden_dims=hid))
+                                         ori_hidden_dims=hid, **extra))
         assert cfg['mixer']['in_channels'] == cfg['virtual_vfe']['feat_channels'][-1]
 
     def make_cloud(self, n, seed, dev):
@@ -304,15 +322,20 @@ class FSDv2Path(nn.Module):
         sampled = dict(seg_points=batch_points[sel], center_preds=(batch_points[sel, :3] + torch.tanh(vote[sel])).detach(),
                        seg_logits=logits[sel], seg_feats=seg_feats[sel], batch_idx=coors[sel, 0])
         origin = dict(seg_points=batch_points, seg_feats=seg_feats, batch_idx=coors[:, 0], batch_size=len(points_list))
-        out = self.virtual_stage(sampled, origin)
+        ms = x['decoder_features'] if self.multiscale is not None else None
+        out = self.virtual_stage(sampled, origin, multiscale_features=ms)
         stats = dict(points=batch_points.size(0), voxels=voxel_feats.size(0), fg_points=int(sel.numel()),
                      virtual_voxels=out['virtual_feats'].size(0))
+        if ms is not None:
+            stats['multiscale_voxels'] = sum(int(ms[lvl].features.size(0)) for lvl in self.multiscale['multiscale_levels'])
         loss = out['virtual_feats'].sum() + logits.sum() * 1e-3
+        if self.as_rpn:
+            loss = loss + out['pts_feats'].sum() * 1e-2
         if return_tensors:
             return loss, stats, dict(voxel_coors=voxel_coors, voxel_feats=voxel_feats, unet_feats=x['voxel_feats'],
                                      seg_feats=seg_feats, head=head, virtual_feats=out['virtual_feats'],
                                      virtual_coors=out['virtual_coors'], virtual_centers=out['virtual_centers'],
-                                     virtual_centroid=out.get('virtual_centroid'))
+                                     virtual_centroid=out.get('virtual_centroid'), pts_feats=out.get('pts_feats'))
         return loss, stats
 
 
@@ -321,8 +344,10 @@ WORKLOADS = {
                 name='FSD Waymo hot path: DynamicScatterVFE + SimpleSparseUNet segmentor (0.25 m) -> clustering -> SIR x 3 '
                      '-> point RoI pooling -> SIR x 2'),
     'fsdv2': dict(cls=FSDv2Path, points=300000, metric='LiDAR frames/sec (FSDv2 hot path fwd+bwd), nuScenes 10-sweep geometry',
-                  name='FSDv2 nuScenes 10-sweep hot path: segmentor U-Net at 0.2 m [40,512,512] -> virtual points -> '
-                       'DynamicScatterVFE at 0.4 m -> VirtualVoxelMixer [20,256,256]'),
+                  name='FSDv2 nuScenes 10-sweep hot path, the wiring of configs/fsdv2/fsdv2_nusc_1x.py: segmentor U-Net at 0.2 m '
+                       '[40,512,512] (return_multiscale_features) -> virtual points -> DynamicScatterVFE at 0.4 m -> '
+                       'multiscale fusion of decoder levels 0-2 (projectors [256,128],[128,128],[128,128], target '
+                       '[20,256,256], avg) -> VirtualVoxelMixer [20,256,256]'),
 }
 
 

@@ -35,7 +35,7 @@ from . import point_pool_oracle, spconv_oracle, voxel_oracle
 # ----------------------------------------------------------------------------------------------------------- primitives
 def voxelize(points_list, voxel_size, point_cloud_range):
     """-> (points [N, C] of all samples, coors [N, 4] int64 (b, z, y, x)); voxelization_cpu.cpp:7-41 via the oracle"""
-    coors = [np.pad(voxel_oracle.dynamic_voxelize(p[:, :3].contiguous().numpy(), voxel_size, point_cloud_range),
+    coors = [np.pad(voxel_oracle.dynamic_voxelize(p[:, :3].float().contiguous().numpy(), voxel_size, point_cloud_range),
                     ((0, 0), (1, 0)), constant_values=b) for b, p in enumerate(points_list)]
     return torch.cat(points_list), torch.from_numpy(np.concatenate(coors)).long()
 
@@ -348,6 +348,7 @@ class _UNet(nn.Module):
             for module in getattr(self.encoder_layers, f'encoder_layer{level}'):
                 x = module(x)
             levels.append(x)
+        self.decoder_features = []                        # every decoder level's output, coarsest first (:367-370)
         for level in range(self.stage_num, 0, -1):      # decoder_layer_forward, sparse_unet.py:161-202
             lat = getattr(self, f'lateral_layer{level}')(levels[level - 1])
             cat = lat.replace_feature(torch.cat([x.features, lat.features], 1))
@@ -355,10 +356,15 @@ class _UNet(nn.Module):
             n, c_out = merged.features.shape
             folded = cat.features.view(n, c_out, -1).sum(2)
             x = getattr(self, f'upsample_layer{level}')(cat.replace_feature(merged.features + folded))
+            self.decoder_features.append(x)
         return x
 
 
 class SimpleSparseUNet(_UNet):
+
+    def __init__(self, *args, return_multiscale_features=False, **kw):
+        super().__init__(*args, **kw)
+        self.return_multiscale_features = return_multiscale_features
 
     def forward(self, voxel_info):
         coors = voxel_info['voxel_coors']
@@ -367,7 +373,8 @@ class SimpleSparseUNet(_UNet):
         batch_size = voxel_info.get('batch_size') or int(coors[:, 0].max()) + 1
         x = self._run(voxel_info['voxel_feats'], coors, batch_size)
         return [{'voxel_feats': x.features, 'voxel_coors': x.indices, 'sparse_shape': x.spatial_shape,
-                 'batch_size': x.batch_size}]
+                 'batch_size': x.batch_size,
+                 'decoder_features': list(self.decoder_features) if self.return_multiscale_features else []}]
 
 
 class VirtualVoxelMixer(_UNet):
@@ -431,6 +438,7 @@ class ClusterAssigner(nn.Module):
         inds, valids = [], []
         for c, (points, batch_idx, name) in enumerate(zip(points_list, batch_idx_list, self.class_names)):
             batch_idx = batch_idx.int()
+            points = points.float()               # integer stage: fp32 arithmetic whatever the dtype of the evaluation
             vs = torch.tensor(self._pick(self.cluster_voxel_size, name))
             lo = torch.tensor(self.point_cloud_range[:3], dtype=points.dtype)
             coors = torch.div(points - lo[None], vs[None], rounding_mode='floor').int()
@@ -482,9 +490,9 @@ class VirtualVoxelExtractor(nn.Module):
     """SingleStageFSDV2.extract_feat, non-baseline mode (single_stage_fsd_v2.py:159-271) with voxelize_with_batch_idx
     :107-121 and clip_points :124-129; constructor = the detector's sub-configs"""
 
-    def __init__(self, backbone, voxel_encoder, virtual_point_projector, train_cfg=None, test_cfg=None, multiscale_cfg=None):
+    def __init__(self, backbone, voxel_encoder, virtual_point_projector, train_cfg=None, test_cfg=None, multiscale_cfg=None,
+                 bbox_head=None, as_rpn=None):
         super().__init__()
-        assert multiscale_cfg is None
         ve = dict(voxel_encoder)
         assert ve.pop('type') == 'DynamicScatterVFE'
         self.voxel_encoder = DynamicScatterVFE(**ve)
@@ -497,14 +505,51 @@ class VirtualVoxelExtractor(nn.Module):
         self.ori_proj = build_mlp(vpp['ori_in_channels'], vpp['ori_hidden_dims'], vpp['norm_cfg'])
         self.zero_virtual_feature = vpp.get('zero_virtual_feature', False)
         self.only_virtual = vpp.get('only_virtual', False)
+        self.as_rpn = bool((bbox_head or {}).get('as_rpn', False)) if as_rpn is None else bool(as_rpn)
+        if self.as_rpn:                                                                    # :92-93
+            self.recover_proj = build_mlp(vpp['recover_in_channels'], vpp['recover_hidden_dims'], vpp['norm_cfg'])
+        self.multiscale_cfg = multiscale_cfg
+        if multiscale_cfg is not None:                                                     # :99-105
+            self.ms_projectors = nn.ModuleList([build_mlp(p[0], p[1:], multiscale_cfg['norm_cfg'])
+                                                for p in multiscale_cfg['projector_hiddens']])
+
+    def ms_coors_proj(self, coors, sparse_shape):
+        """single_stage_fsd_v2.py:399-433"""
+        tgt = self.multiscale_cfg['target_sparse_shape']
+        bev_stride, z_stride = tgt[1] // sparse_shape[1], tgt[0] // sparse_shape[0]
+        assert bev_stride == tgt[2] / sparse_shape[2] and z_stride >= 1 and bev_stride >= 1
+        out = coors.clone()
+        out[:, 1] = coors[:, 1] * z_stride + z_stride // 2
+        out[:, 2] = coors[:, 2] * bev_stride + bev_stride // 2
+        out[:, 3] = coors[:, 3] * bev_stride + bev_stride // 2
+        assert int(out[:, 1].max()) < tgt[0] and int(out[:, 2].max()) < tgt[1] and int(out[:, 3].max()) < tgt[2]
+        return out
+
+    def multiscale_fusion(self, ms_data, voxel_feats, coors):
+        """single_stage_fsd_v2.py:375-397: projected decoder features of the segmentor join the virtual voxels; two
+        groupings of the concatenated coordinates (feature average, indicator maximum), as the reference does"""
+        cfg = self.multiscale_cfg
+        ms_data = [ms_data[lvl] for lvl in cfg['multiscale_levels']]
+        ms_feats = [self.ms_projectors[i](d.features) for i, d in enumerate(ms_data)]
+        ms_coors = [self.ms_coors_proj(d.indices, d.spatial_shape) for d in ms_data]
+        n_add = sum(len(f) for f in ms_feats)
+        cat_feats = torch.cat([voxel_feats] + ms_feats, 0)
+        cat_coors = torch.cat([coors] + ms_coors, 0)
+        indicators = torch.cat([voxel_feats.new_ones(len(voxel_feats), 1), voxel_feats.new_zeros(n_add, 1)], 0)
+        out_feats, out_coors = scatter_v2(cat_feats, cat_coors, cfg['fusion_mode'], return_inv=False)
+        out_ind, _ = scatter_v2(indicators, cat_coors, 'max', return_inv=False)
+        mask = out_ind.squeeze(1) == 1
+        assert int(mask.sum()) == len(voxel_feats)
+        return out_feats, out_coors, mask
 
     def voxelize_with_batch_idx(self, points, batch_idx):
-        vs = points.new_tensor(self.virtual_voxel_size)
-        lo = points.new_tensor(self.point_cloud_range[:3])
-        cells = torch.div(points[:, :3] - lo[None], vs[None], rounding_mode='floor').long()
+        xyz = points[:, :3].float()                       # @force_fp32 in the reference; a float64 evaluation of the port
+        vs = xyz.new_tensor(self.virtual_voxel_size)      # (the gradient adjudication) keeps the integer stage of the f32 run
+        lo = xyz.new_tensor(self.point_cloud_range[:3])
+        cells = torch.div(xyz - lo[None], vs[None], rounding_mode='floor').long()
         return torch.cat([batch_idx[:, None], cells[:, [2, 1, 0]]], 1)
 
-    def forward(self, sampled_dict, origin_dict):
+    def forward(self, sampled_dict, origin_dict, gt_bboxes_3d=None, multiscale_features=None):
         fg_pts, fg_batch = sampled_dict['seg_points'], sampled_dict['batch_idx']
         r = self.point_cloud_range
         centers = sampled_dict['center_preds']
@@ -521,15 +566,22 @@ class VirtualVoxelExtractor(nn.Module):
         cat_feat = torch.cat([ori_feat, vir_feat], 0)
         cat_batch = torch.cat([origin_dict['batch_idx'], fg_batch], 0)
         coors = self.voxelize_with_batch_idx(cat_pts, cat_batch)
-        voxel_feats, voxel_coors, _ = self.voxel_encoder(torch.cat([cat_pts, cat_feat], 1), coors, return_inv=True)
+        voxel_feats, voxel_coors, unq_inv = self.voxel_encoder(torch.cat([cat_pts, cat_feat], 1), coors, return_inv=True)
+        encoder_coors = voxel_coors
         indicator = torch.cat([cat_pts.new_zeros(ori_pts.size(0)), cat_pts.new_ones(centers.size(0))])
         share, scoors = scatter_v2(indicator[:, None], coors, 'avg', return_inv=False)
         assert bool((scoors == voxel_coors).all())
         virtual = share[:, 0] > 0
         batch_size = int(voxel_coors[:, 0].max()) + 1
+        single = None
+        if multiscale_features is not None:                                                # :208-209
+            voxel_feats, voxel_coors, single = self.multiscale_fusion(multiscale_features, voxel_feats, voxel_coors)
         if self.only_virtual:
+            assert multiscale_features is None
             voxel_feats, voxel_coors = voxel_feats[virtual], voxel_coors[virtual]
         out_feats, out_coors, sparse_shape = self.backbone(voxel_feats, voxel_coors, batch_size)
+        if single is not None:                                                             # :218-221
+            out_feats, out_coors = out_feats[single], out_coors[single]
         vs = cat_pts.new_tensor(self.virtual_voxel_size)
         lo = cat_pts.new_tensor(self.point_cloud_range[:3])
         voxel_centers = (out_coors[:, [3, 2, 1]] + 0.5) * vs[None] + lo[None]
@@ -539,4 +591,10 @@ class VirtualVoxelExtractor(nn.Module):
         if self.training:
             centroid, _ = scatter_v2(cat_pts[:, :3], coors, 'avg', return_inv=False)
             out['virtual_centroid'] = centroid[virtual]
+        if self.as_rpn:                                                                    # :131-155, 263-270
+            assert bool((out_coors == encoder_coors).all())
+            center_per_pts = (out_coors[unq_inv][:, [3, 2, 1]] + 0.5) * vs[None] + lo[None]
+            offset = (center_per_pts - cat_pts) / vs[None] * 2
+            out['pts_feats'] = self.recover_proj(torch.cat([out_feats[unq_inv], offset], 1))
+            out['pts_xyz'], out['pts_indicators'], out['pts_batch_inds'] = cat_pts, indicator, cat_batch
         return out

@@ -45,14 +45,25 @@ def reference_ops():
     extract = ref_loader.load_reference_method(_FSD2, 'SingleStageFSDV2', 'extract_feat', glb2)
     vox_with_batch = ref_loader.load_reference_method(_FSD2, 'SingleStageFSDV2', 'voxelize_with_batch_idx', glb2)
     clip = ref_loader.load_reference_method(_FSD2, 'SingleStageFSDV2', 'clip_points', glb2)
+    fusion = ref_loader.load_reference_method(_FSD2, 'SingleStageFSDV2', 'multiscale_fusion', glb2)
+    coors_proj = ref_loader.load_reference_method(_FSD2, 'SingleStageFSDV2', 'ms_coors_proj', glb2)
+    recover = ref_loader.load_reference_method(_FSD2, 'SingleStageFSDV2', 'recover_point_features', glb2)
 
     class VirtualVoxelExtractor(nn.Module):
         """the attributes SingleStageFSDV2.__init__ sets up (single_stage_fsd_v2.py:60-105) around its own extract_feat"""
 
-        def __init__(self, backbone, voxel_encoder, virtual_point_projector, train_cfg=None, test_cfg=None):
+        def __init__(self, backbone, voxel_encoder, virtual_point_projector, train_cfg=None, test_cfg=None,
+                     multiscale_cfg=None, bbox_head=None, as_rpn=None):
             super().__init__()
             vpp = virtual_point_projector
-            self.baseline_mode, self.as_rpn, self.train_cfg, self.print_info = False, False, {}, {}
+            self.baseline_mode, self.train_cfg, self.print_info = False, {}, {}
+            self.as_rpn = bool((bbox_head or {}).get('as_rpn', False)) if as_rpn is None else bool(as_rpn)
+            if self.as_rpn:                                                  # single_stage_fsd_v2.py:92-93
+                self.recover_proj = ref.sst_ops.build_mlp(vpp['recover_in_channels'], vpp['recover_hidden_dims'], vpp['norm_cfg'])
+            self.multiscale_cfg = multiscale_cfg
+            if multiscale_cfg is not None:                                   # :99-105
+                self.ms_projectors = nn.ModuleList([ref.sst_ops.build_mlp(p[0], p[1:], multiscale_cfg['norm_cfg'])
+                                                    for p in multiscale_cfg['projector_hiddens']])
             self.zero_virtual_feature, self.only_virtual = vpp.get('zero_virtual_feature', False), vpp.get('only_virtual', False)
             self.virtual_voxel_size, self.point_cloud_range = voxel_encoder['voxel_size'], voxel_encoder['point_cloud_range']
             self.virtual_proj = ref.sst_ops.build_mlp(vpp['in_channels'], vpp['hidden_dims'], vpp['norm_cfg'])
@@ -65,9 +76,12 @@ def reference_ops():
             self.backbone = R.sparse_unet.VirtualVoxelMixer(**bb)
             self.voxelize_with_batch_idx = types.MethodType(vox_with_batch, self)
             self.clip_points = types.MethodType(clip, self)
+            self.multiscale_fusion = types.MethodType(fusion, self)
+            self.ms_coors_proj = types.MethodType(coors_proj, self)
+            self.recover_point_features = types.MethodType(recover, self)
 
-        def forward(self, sampled_dict, origin_dict):
-            return extract(self, sampled_dict, origin_dict)
+        def forward(self, sampled_dict, origin_dict, gt_bboxes_3d=None, multiscale_features=None):
+            return extract(self, sampled_dict, origin_dict, gt_bboxes_3d, multiscale_features)
 
     return types.SimpleNamespace(
         name='reference', voxelize=voxelize, scatter_v2=ref.sst_ops.scatter_v2,

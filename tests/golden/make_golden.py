@@ -568,20 +568,32 @@ VIRTUAL_VOXEL_CFG = dict(
     backbone=dict(type='VirtualVoxelMixer', **VOXEL_MIXER_CFG))
 
 
-def gen_virtual_voxel():
+VIRTUAL_VOXEL_MS_CFG = dict(
+    VIRTUAL_VOXEL_CFG,
+    virtual_point_projector=dict(VIRTUAL_VOXEL_CFG['virtual_point_projector'], recover_in_channels=24 + 3,
+                                 recover_hidden_dims=[16, 16]),
+    multiscale_cfg=dict(multiscale_levels=[0, 1], projector_hiddens=[[12, 8], [8, 16, 8]], fusion_mode='avg',
+                        target_sparse_shape=[16, 40, 40], norm_cfg=dict(type='naiveSyncBN1d')))
+
+
+def gen_virtual_voxel(multiscale=False):
     """FSDv2's virtual-voxel chain: SingleStageFSDV2.extract_feat (single_stage_fsd_v2.py:159-271, non-baseline mode,
     training), the method's own source executed on a stand-in ``self`` that carries the reference's own submodules
-    (build_mlp projectors, DynamicScatterVFE, VirtualVoxelMixer over the vendored spconv package) on CPU."""
+    (build_mlp projectors, DynamicScatterVFE, VirtualVoxelMixer over the vendored spconv package) on CPU.
+    ``multiscale``: the second fixture (virtual_voxel_ms.npz) - the same inputs plus two coarser levels of "decoder features"
+    (objects with features / indices / spatial_shape, as the segmentor's SparseConvTensors) fused in by the reference's own
+    multiscale_fusion / ms_coors_proj (:375-433), and ``as_rpn`` on: recover_point_features and the pts_* outputs (:131-155,
+    263-270)."""
     import types
     R = ref_loader.load_reference_spconv()
     ref = ref_loader.load_reference()
     rel = 'mmdet3d/models/detectors/single_stage_fsd_v2.py'
     glb = {'scatter_v2': ref.sst_ops.scatter_v2}
-    cfg = VIRTUAL_VOXEL_CFG
+    cfg = VIRTUAL_VOXEL_MS_CFG if multiscale else VIRTUAL_VOXEL_CFG
     vpp = cfg['virtual_point_projector']
     torch.manual_seed(21)
     me = types.SimpleNamespace()
-    me.baseline_mode, me.zero_virtual_feature, me.only_virtual, me.training, me.as_rpn = False, False, False, True, False
+    me.baseline_mode, me.zero_virtual_feature, me.only_virtual, me.training, me.as_rpn = False, False, False, True, multiscale
     me.train_cfg, me.print_info = {}, {}
     me.virtual_voxel_size, me.point_cloud_range = cfg['voxel_encoder']['voxel_size'], cfg['voxel_encoder']['point_cloud_range']
     me.virtual_proj = ref.sst_ops.build_mlp(vpp['in_channels'], vpp['hidden_dims'], vpp['norm_cfg'])
@@ -590,9 +602,19 @@ def gen_virtual_voxel():
     vfe_cfg.pop('type')
     me.voxel_encoder = ref.voxel_encoder.DynamicScatterVFE(**vfe_cfg)
     me.backbone = R.sparse_unet.VirtualVoxelMixer(**VOXEL_MIXER_CFG)
-    for m in (me.virtual_proj, me.ori_proj, me.voxel_encoder, me.backbone):
+    mods = [('virtual_proj', me.virtual_proj), ('ori_proj', me.ori_proj), ('voxel_encoder', me.voxel_encoder),
+            ('backbone', me.backbone)]
+    methods = ['voxelize_with_batch_idx', 'clip_points']
+    if multiscale:
+        ms_cfg = me.multiscale_cfg = cfg['multiscale_cfg']
+        me.recover_proj = ref.sst_ops.build_mlp(vpp['recover_in_channels'], vpp['recover_hidden_dims'], vpp['norm_cfg'])
+        me.ms_projectors = torch.nn.ModuleList([ref.sst_ops.build_mlp(p[0], p[1:], ms_cfg['norm_cfg'])
+                                                for p in ms_cfg['projector_hiddens']])
+        mods += [('recover_proj', me.recover_proj), ('ms_projectors', me.ms_projectors)]
+        methods += ['multiscale_fusion', 'ms_coors_proj', 'recover_point_features']
+    for _, m in mods:
         m.train()
-    for fn in ('voxelize_with_batch_idx', 'clip_points'):
+    for fn in methods:
         f = ref_loader.load_reference_method(rel, 'SingleStageFSDV2', fn, glb)
         setattr(me, fn, types.MethodType(f, me))
     extract = ref_loader.load_reference_method(rel, 'SingleStageFSDV2', 'extract_feat', glb)
@@ -611,24 +633,50 @@ def gen_virtual_voxel():
                                                              ('smp_logits', smp['seg_logits']))}
     ori_in = dict(ori, seg_feats=leaves['ori_feats'])
     smp_in = dict(smp, seg_feats=leaves['smp_feats'], seg_logits=leaves['smp_logits'], center_preds=centers.clone())
-    out = extract(me, smp_in, ori_in)
+    arrays = {}
+    ms_features = None
+    if multiscale:
+        # two coarser levels: distinct random cells of a [8, 20, 20] grid (strides 2, 2 against the [16, 40, 40] target) and
+        # of a [16, 40, 40] grid (strides 1, 1: lands ON virtual voxels), int32 (b, z, y, x) like SparseConvTensor.indices
+        ms_features = []
+        for lvl, (shape, n_vox, width) in enumerate((([8, 20, 20], 500, 12), ([16, 40, 40], 700, 8))):
+            cells = torch.randperm(batch * shape[0] * shape[1] * shape[2], generator=g)[:n_vox].sort()[0]
+            b, rem = cells // (shape[0] * shape[1] * shape[2]), cells % (shape[0] * shape[1] * shape[2])
+            ind = torch.stack([b, rem // (shape[1] * shape[2]), rem // shape[2] % shape[1], rem % shape[2]], 1).int()
+            feats = torch.randn(n_vox, width, generator=g).requires_grad_(True)
+            ms_features.append(types.SimpleNamespace(features=feats, indices=ind, spatial_shape=shape))
+            arrays[f'in::ms{lvl}::features'], arrays[f'in::ms{lvl}::indices'] = t2n(feats), t2n(ind)
+            arrays[f'in::ms{lvl}::spatial_shape'] = np.asarray(shape)
+    out = extract(me, smp_in, ori_in, None, ms_features)
     gy = torch.randn(out['virtual_feats'].shape, generator=g)
-    (out['virtual_feats'] * gy).sum().backward()
-    arrays = {'in::ori_points': t2n(ori['seg_points']), 'in::ori_feats': t2n(ori['seg_feats']),
-              'in::ori_batch_idx': t2n(ori['batch_idx']), 'in::smp_points': t2n(smp['seg_points']),
-              'in::smp_centers': t2n(centers), 'in::smp_logits': t2n(smp['seg_logits']), 'in::smp_feats': t2n(smp['seg_feats']),
-              'in::smp_batch_idx': t2n(smp['batch_idx']), 'in::grad_out': t2n(gy),
-              'out::virtual_feats': t2n(out['virtual_feats']), 'out::virtual_coors': t2n(out['virtual_coors']),
-              'out::virtual_centers': t2n(out['virtual_centers']), 'out::virtual_centroid': t2n(out['virtual_centroid']),
-              'out::sparse_shape': np.asarray(out['sparse_shape']),
-              'out::grad_ori_feats': t2n(leaves['ori_feats'].grad), 'out::grad_smp_feats': t2n(leaves['smp_feats'].grad),
-              'out::grad_smp_logits': t2n(leaves['smp_logits'].grad)}
-    for prefix, mod in (('virtual_proj', me.virtual_proj), ('ori_proj', me.ori_proj), ('voxel_encoder', me.voxel_encoder),
-                        ('backbone', me.backbone)):
+    loss = (out['virtual_feats'] * gy).sum()
+    if multiscale:
+        gp = torch.randn(out['pts_feats'].shape, generator=g)
+        loss = loss + (out['pts_feats'] * gp).sum()
+        arrays['in::grad_pts'] = t2n(gp)
+    loss.backward()
+    arrays.update({'in::ori_points': t2n(ori['seg_points']), 'in::ori_feats': t2n(ori['seg_feats']),
+                   'in::ori_batch_idx': t2n(ori['batch_idx']), 'in::smp_points': t2n(smp['seg_points']),
+                   'in::smp_centers': t2n(centers), 'in::smp_logits': t2n(smp['seg_logits']), 'in::smp_feats': t2n(smp['seg_feats']),
+                   'in::smp_batch_idx': t2n(smp['batch_idx']), 'in::grad_out': t2n(gy),
+                   'out::virtual_feats': t2n(out['virtual_feats']), 'out::virtual_coors': t2n(out['virtual_coors']),
+                   'out::virtual_centers': t2n(out['virtual_centers']), 'out::virtual_centroid': t2n(out['virtual_centroid']),
+                   'out::sparse_shape': np.asarray(out['sparse_shape']),
+                   'out::grad_ori_feats': t2n(leaves['ori_feats'].grad), 'out::grad_smp_feats': t2n(leaves['smp_feats'].grad),
+                   'out::grad_smp_logits': t2n(leaves['smp_logits'].grad)})
+    for prefix, mod in mods:
         arrays.update({f'w::{prefix}.{k}': t2n(v.float()) for k, v in mod.state_dict().items()})
     arrays['out::grad::virtual_proj.0.0.weight'] = t2n(me.virtual_proj[0][0].weight.grad)
     arrays['out::grad::ori_proj.1.0.weight'] = t2n(me.ori_proj[1][0].weight.grad)
-    save('virtual_voxel.npz', **arrays)
+    if multiscale:
+        for key in ('pts_feats', 'pts_xyz', 'pts_indicators', 'pts_batch_inds'):
+            arrays['out::' + key] = t2n(out[key])
+        for lvl, d in enumerate(ms_features):
+            arrays[f'out::grad_ms{lvl}'] = t2n(d.features.grad)
+        arrays['out::grad::ms_projectors.0.0.0.weight'] = t2n(me.ms_projectors[0][0][0].weight.grad)
+        arrays['out::grad::ms_projectors.1.1.0.weight'] = t2n(me.ms_projectors[1][1][0].weight.grad)
+        arrays['out::grad::recover_proj.0.0.weight'] = t2n(me.recover_proj[0][0].weight.grad)
+    save('virtual_voxel_ms.npz' if multiscale else 'virtual_voxel.npz', **arrays)
 
 
 CHAIN_GRAD_KEYS = {
@@ -639,7 +687,9 @@ CHAIN_GRAD_KEYS = {
     'fsdv2': ['voxel_encoder.vfe_layers.1.linear.weight', 'seg_backbone.encoder_layers.encoder_layer3.0.0.weight',
               'seg_backbone.merge_layer1.0.weight', 'seg_head.weight', 'virtual_stage.virtual_proj.0.0.weight',
               'virtual_stage.ori_proj.1.0.weight', 'virtual_stage.voxel_encoder.vfe_layers.0.linear.weight',
-              'virtual_stage.backbone.conv_out.0.weight', 'virtual_stage.backbone.encoder_layers.encoder_layer2.0.0.weight'],
+              'virtual_stage.backbone.conv_out.0.weight', 'virtual_stage.backbone.encoder_layers.encoder_layer2.0.0.weight',
+              'virtual_stage.ms_projectors.0.0.0.weight', 'virtual_stage.ms_projectors.1.0.0.weight',
+              'virtual_stage.recover_proj.0.0.weight', 'seg_backbone.upsample_layer4.0.weight'],
 }
 
 
@@ -722,6 +772,10 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'virtual_voxel':
         gen_virtual_voxel()
+        gen_virtual_voxel(multiscale=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'virtual_voxel_ms':
+        gen_virtual_voxel(multiscale=True)
         return
     gen_voxelize()
     gen_hard_voxelize()
@@ -740,6 +794,7 @@ def main():
     gen_spconv()
     gen_sparse_unet()
     gen_virtual_voxel()
+    gen_virtual_voxel(multiscale=True)
     gen_fsd_chains()
 
 

@@ -99,13 +99,23 @@ def test_cpu_port_chain_matches_live_reference(tag, train):
     if train:
         lr.backward()
         lp.backward()
-        theirs, ours = dict(ref.named_parameters()), dict(port.named_parameters())
+        # two fp32 evaluations of one function agree to the fp32 evaluation noise of that function, which is NOT 1e-4 for
+        # every parameter of these chains: batch norm over a few thousand rows followed by ReLU / max pooling makes single
+        # parameters' gradients sensitive to a handful of decisions (tools/fsd_grad_adjudicate.py).  The noise is measured:
+        # the same port evaluated in float64 (integer stages in fp32, so the decisions upstream are the same).
+        port64 = cls(fsd_cpu, cfg, **kw).double()
+        port64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in ref.state_dict().items()}, strict=True)
+        port64.train(train)
+        port64([c.double() for c in clouds])[0].backward()
+        theirs, ours, exact = dict(ref.named_parameters()), dict(port.named_parameters()), dict(port64.named_parameters())
         checked = 0
         for name, p in theirs.items():
             if p.grad is None:
                 assert ours[name].grad is None, name
                 continue
-            assert float((p.grad - ours[name].grad).abs().max()) <= 1e-4 * max(1.0, float(p.grad.abs().max())), name
+            scale = max(1.0, float(p.grad.abs().max()))
+            noise = float((ours[name].grad.double() - exact[name].grad).abs().max())
+            assert float((p.grad - ours[name].grad).abs().max()) <= max(1e-4 * scale, 2.0 * noise), name
             checked += 1
         assert checked > 40
 
