@@ -111,6 +111,20 @@ def _const(values, dev):
     return _CONSTS[key]
 
 
+def mixed_sum(t, scale=1.0):
+    """the scalar the chains backpropagate from: sum(t * w) with a FIXED sign-changing weight w[n, c] = a[n] + b[c] built from
+    integer arithmetic (identical on every device, no RNG).  A plain t.sum() is the wrong probe for these networks: the
+    outputs sit behind batch / layer normalisation, whose column (row) sums are constants - d sum(LN(x)) / dx is exactly 0
+    and d sum(BN(x)) / dx cancels over the batch - so the parameter gradients of a plain sum are small residues of large
+    cancelling terms and two correct fp32 evaluations of them differ by percents (tests/adjudicate_fsd_grads.py: the CPU
+    port in fp32 against itself in float64, 5.6e-2 on a 20 k-point frame).  bench.py's SST step starts from a fixed random
+    upstream gradient for the same reason."""
+    n, c = t.shape
+    a = ((torch.arange(n, device=t.device) % 13) - 6).to(t.dtype) / 6
+    b = ((torch.arange(c, device=t.device) * 7 % 11) - 5).to(t.dtype) / 5
+    return (t * (a[:, None] + b[None, :])).sum() * scale
+
+
 def fsd_foreground_stand_in(batch_points, votes, z_cut=-1.4):
     """STAND-IN for the segmentation decision and the vote decoding of VoteSegHead (out of scope): foreground = points
     above the ground plane, class by a position hash, voted centre = point + 0.05 tanh(vote of its class).  Shared by the
@@ -200,7 +214,7 @@ class FSDPath(nn.Module):
         pts_out, cluster_feats, cluster_coors = self.backbone(points, feats, cluster_inds, f_cluster)
         stats = dict(points=batch_points.size(0), voxels=voxel_feats.size(0), fg_points=points.size(0),
                      clusters=cluster_feats.size(0))
-        loss = cluster_feats.sum() * 1e-3 + logits.sum() * 1e-3
+        loss = mixed_sum(cluster_feats, 1e-3) + mixed_sum(logits, 1e-3)
         tensors = dict(voxel_coors=voxel_coors, voxel_feats=voxel_feats, unet_feats=x['voxel_feats'], seg_feats=seg_feats,
                        head=head, sel=sel, cluster_inds=cluster_inds, pts_out=pts_out, cluster_feats=cluster_feats,
                        cluster_coors=cluster_coors, cluster_xyz=cluster_xyz)
@@ -225,7 +239,7 @@ class FSDPath(nn.Module):
         _, roi_cluster_feats, _ = self.roi_backbone(geo, roi_feats, roi_coors, geo[:, :3].contiguous())
         stats['pooled_pairs'] = roi_feats.size(0)
         tensors['roi_cluster_feats'] = roi_cluster_feats
-        loss = loss + roi_cluster_feats.sum()
+        loss = loss + mixed_sum(roi_cluster_feats, 1e-2)
         return (loss, stats, tensors) if return_tensors else (loss, stats)
 
 
@@ -328,9 +342,9 @@ class FSDv2Path(nn.Module):
                      virtual_voxels=out['virtual_feats'].size(0))
         if ms is not None:
             stats['multiscale_voxels'] = sum(int(ms[lvl].features.size(0)) for lvl in self.multiscale['multiscale_levels'])
-        loss = out['virtual_feats'].sum() + logits.sum() * 1e-3
+        loss = mixed_sum(out['virtual_feats'], 1e-2) + mixed_sum(logits, 1e-3)
         if self.as_rpn:
-            loss = loss + out['pts_feats'].sum() * 1e-2
+            loss = loss + mixed_sum(out['pts_feats'], 1e-3)
         if return_tensors:
             return loss, stats, dict(voxel_coors=voxel_coors, voxel_feats=voxel_feats, unet_feats=x['voxel_feats'],
                                      seg_feats=seg_feats, head=head, virtual_feats=out['virtual_feats'],

@@ -473,7 +473,8 @@ class DynamicPointROIExtractor(nn.Module):
             p_sel = torch.nonzero(batch_inds == b).squeeze(1)
             r_sel = torch.nonzero(rois[:, 0].long() == b).squeeze(1)
             if len(p_sel) and len(r_sel):
-                pi, ri, ft = point_pool_oracle.dynamic_point_pool(rois[r_sel, 1:].numpy(), pts_xyz[p_sel].numpy(),
+                # fp32 whatever the dtype of the evaluation: membership is a decision, the oracle's arithmetic is fp32
+                pi, ri, ft = point_pool_oracle.dynamic_point_pool(rois[r_sel, 1:].float().numpy(), pts_xyz[p_sel].float().numpy(),
                                                                   self.extra_wlh, cap, self.max_all_pts)
                 if len(pi) and pi[0] >= 0:
                     pieces.append((p_sel[torch.from_numpy(np.asarray(pi)).long()], r_sel[torch.from_numpy(np.asarray(ri)).long()],
@@ -482,6 +483,7 @@ class DynamicPointROIExtractor(nn.Module):
             pieces.append((torch.full((1,), -1, dtype=torch.long), torch.full((1,), -1, dtype=torch.long),
                            torch.zeros((1, 13))))
         inds, roi_inds, info = (torch.cat(col) for col in zip(*pieces))
+        info = info.to(pts_xyz.dtype)
         return inds, roi_inds, dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])
 
 

@@ -726,6 +726,20 @@ def gen_fsd_chains():
         params = dict(net.named_parameters())
         for k in CHAIN_GRAD_KEYS[tag]:
             arrays['grad::' + k] = t2n(params[k].grad)
+        # the adjudicator for the gradients: the CPU port of the same chain evaluated in float64 on the same weights and
+        # clouds (integer stages in fp32).  The reference's own fp32 backward is up to ~7e-3 away from it at this size
+        # (naiveSyncBN differentiates var = E[x^2] - mean^2 in fp32); tests compare against grad64 with a bar that knows that.
+        from oracle import fsd_cpu
+        port64 = cls(fsd_cpu, cfg, **kw).double().train()
+        port64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in state.items()}, strict=True)
+        loss64, stats64 = port64([c.double() for c in clouds])
+        assert {k: int(v) for k, v in stats64.items()} == {k: int(v) for k, v in stats.items()}
+        loss64.backward()
+        params64 = dict(port64.named_parameters())
+        for k in CHAIN_GRAD_KEYS[tag]:
+            arrays['grad64::' + k] = params64[k].grad.numpy().astype(np.float64)
+            print('   ', k, 'reference fp32 vs float64: %.2e' % (np.abs(arrays['grad::' + k] - arrays['grad64::' + k]).max()
+                                                                 / max(1.0, np.abs(arrays['grad64::' + k]).max())))
         arrays.update(state_to_np(state))
         print(tag, stats)
         save(f'{tag}_chain.npz', **arrays)
