@@ -448,16 +448,29 @@ def cpu_chain_leg(spec, model, clouds):
         foreground selection, cluster assignment / virtual voxels) and the features along the chain; gradients of three
         parameters at the ends and the middle of the chain."""
     from oracle import fsd_cpu
-    threads = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
     port = spec['cls'](fsd_cpu).train()
     port.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
-    port(([model.make_cloud(20000, 7, 'cpu')]))[0].backward()                  # warm-up, untimed
+    # thread sweep on a 20 000-point cloud (the SST leg showed 128 threads to be 3.5 x slower than 16-32 for this kind of
+    # work: many small ops): one untimed warm-up pass, then one timed forward + backward per candidate thread count
+    probe = [model.make_cloud(20000, 7, 'cpu')]
+    port(probe)[0].backward()
     port.zero_grad(set_to_none=True)
+    sweep = {}
+    for t in sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads}):
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        port(probe)[0].backward()
+        sweep[t] = round(time.perf_counter() - t0, 2)
+        port.zero_grad(set_to_none=True)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     frame = [clouds[0].cpu()]
     t0 = time.perf_counter()
     loss_c, _, tc = port(frame, return_tensors=True)
     loss_c.backward()
     cpu_s = time.perf_counter() - t0
+    torch.set_num_threads(all_threads)
     model.zero_grad(set_to_none=True)
     loss_g, stats, tg = model([clouds[0]], return_tensors=True)
     loss_g.backward()
@@ -482,12 +495,19 @@ def cpu_chain_leg(spec, model, clouds):
               'max_abs_err_overall': max(finite) if finite else None, 'max_rel_grad_err': grads, 'feature_tolerance': 1e-3,
               'what': 'GPU chain (fp32) vs the CPU port of the reference chain, same weights, first bench frame, training '
                       'mode; a feature entry is null when an integer stage upstream of it differs (its rows are then not '
-                      'comparable); the RoI stage rides on the point pool, whose features are unpinned (TorchEx absent); '
-                      'gradient entries = max |difference| / max |gradient| of a parameter between two fp32 evaluations with '
-                      'different summation orders through the whole chain (reported, the 1e-3 bar is stated for features)'}
+                      'comparable); roi_stage: the second stage rides on the point pool, whose 13 features and cap survivors '
+                      'are UNPINNED (TorchEx source absent: SURVEY.md section 8 f3) - its membership is pinned to the '
+                      'reference\'s points_in_boxes_cpu.cpp; gradient entries = max |difference| / max |gradient| of a parameter '
+                      'between two fp32 evaluations.  These gradients are ill-conditioned (training-mode batch norm over few '
+                      'rows + ReLU / max decisions): the float64 evaluation of the port puts the fp32 PORT ITSELF 1e-3..3e-2 '
+                      'from the exact gradient on these frames and the GPU path no further (profiles/r04/'
+                      '*_grad_adjudication.json, tests/adjudicate_fsd_grads.py, tests/test_fsd_chain.py::'
+                      'test_gpu_gradients_within_fp32_noise_at_40k); the 1e-3 bar is stated for features'}
     base = {'value': round(1.0 / cpu_s, 5), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 timed pass of 1 frame ({frame[0].size(0)} points), forward + backward, {cpu_s:.1f} s, after one '
-                      'untimed warm-up pass on a 20 000-point cloud; CPU port of the reference chain (oracle/fsd_cpu.py: '
+            'thread_sweep_20k_points_s': sweep,
+            'sample': f'1 timed pass of 1 frame ({frame[0].size(0)} points), forward + backward, {cpu_s:.1f} s at {threads} threads '
+                      '(the fastest of a sweep on a 20 000-point cloud, after one untimed warm-up pass); CPU port of the '
+                      'reference chain (oracle/fsd_cpu.py: '
                       'torch.unique + scatter_reduce, per-offset gather / mm / index_add sparse convolutions, dense-adjacency '
                       'scipy connected components, numpy point pool)'}
     return base, parity

@@ -810,7 +810,8 @@ int sst_add_layernorm_fwd_bf16(const void* d_x, const void* d_res, const float* 
 int sst_add_layernorm_bwd_bf16(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
                                const float* d_weight, int64_t m, int c, void* d_dx, float* d_dweight, float* d_dbias,
                                void* d_workspace, void* stream) {
-  if (m < 0 || c < 1 || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  // 4-wide bf16 row accesses (col = k * 128 + lane * 4 under a `col < c` check): c must be a multiple of 4, like the forward
+  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
   if (!d_dweight || !d_dbias) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (m == 0) {

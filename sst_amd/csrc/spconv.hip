@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct SpGeom {
   int in_shape[3], out_shape[3], ks[3], st[3], pd[3], dl[3];
   int kvol;
+  int batch;   // dense-grid builders only: number of samples the cell grid was sized for
 };
 
 // kernel offset k -> (kz, ky, kx), row-major as geometry.h:66-70 composes `offset`
@@ -133,13 +134,22 @@ __device__ __forceinline__ int64_t sp_cell(int b, const int (&p)[3], const int* 
   return (((int64_t)b * shape[0] + p[0]) * shape[1] + p[1]) * shape[2] + p[2];
 }
 
+// The cell grids are sized batch x in_shape (x out_shape): a row whose sample index or coordinates lie outside would index
+// past them (the sort-based builder only produced wrong keys for such a row).  Such rows take no part: no cell, no pairs
+// (-1 in both maps) - ADVICE round 3.  Preconditions that stay the caller's (spconv's own): unique voxels; with duplicates
+// the highest row index owns the cell (atomicMax: deterministic), the other rows still read their neighbours.
+__device__ __forceinline__ bool sp_row_in_grid(const int4& c, const SpGeom& g) {
+  return (unsigned)c.x < (unsigned)g.batch && (unsigned)c.y < (unsigned)g.in_shape[0] &&
+         (unsigned)c.z < (unsigned)g.in_shape[1] && (unsigned)c.w < (unsigned)g.in_shape[2];
+}
+
 // grid[cell of row j] = j
 __global__ __launch_bounds__(256) void sp_grid_rows_k(const int32_t* __restrict__ coors, int64_t n, SpGeom g,
                                                       int32_t* __restrict__ grid) {
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
     const int4 c = ((const int4*)coors)[j];
     const int p[3] = {c.y, c.z, c.w};
-    grid[sp_cell(c.x, p, g.in_shape)] = (int32_t)j;
+    if (sp_row_in_grid(c, g)) atomicMax(&grid[sp_cell(c.x, p, g.in_shape)], (int32_t)j);
   }
 }
 
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void sp_grid_subm_k(const int32_t* __restrict_
     int ko[3];
     sp_koff(g, k, ko);
     int fwd[3], bwd[3];
-    bool okf = true, okb = true;
+    bool okf = sp_row_in_grid(c, g), okb = okf;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       fwd[d] = pos[d] + g.pd[d] - ko[d] * g.dl[d];
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(256) void sp_grid_mark_k(const int32_t* __restrict_
     const int in[3] = {c.y, c.z, c.w};
     int ko[3], out[3];
     sp_koff(g, k, ko);
-    if (sp_out_pos(g, in, ko, transpose != 0, out)) flags[sp_cell(c.x, out, g.out_shape)] = 1;
+    if (sp_row_in_grid(c, g) && sp_out_pos(g, in, ko, transpose != 0, out)) flags[sp_cell(c.x, out, g.out_shape)] = 1;
   }
 }
 
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void sp_grid_conv_maps_k(const int32_t* __rest
     int ko[3], out[3];
     sp_koff(g, k, ko);
     int res = -1;
-    if (sp_out_pos(g, in, ko, transpose != 0, out)) {
+    if (sp_row_in_grid(c, g) && sp_out_pos(g, in, ko, transpose != 0, out)) {
       res = pos[sp_cell(c.x, out, g.out_shape)];
       out2in[(int64_t)k * m + res] = (int32_t)j;
     }
@@ -814,6 +824,7 @@ bool sp_geom(const int32_t* in_shape, const int32_t* out_shape, const int32_t* k
              const int32_t* pd, const int32_t* dl, SpGeom* g) {
   if (!in_shape || !out_shape || !ks || !st || !pd || !dl) return false;
   g->kvol = 1;
+  g->batch = 1 << 30;   // set by the dense-grid entry points
   for (int d = 0; d < 3; ++d) {
     g->in_shape[d] = in_shape[d];
     g->out_shape[d] = out_shape[d];
@@ -856,6 +867,7 @@ int sst_spconv_grid_subm_i32(const int32_t* d_coors, int64_t n, int batch, const
   SpGeom g;
   if (n < 0 || !sp_geom(shape, shape, ksize, st, pd, dilation, &g)) return SST_ERR_ARG;
   if ((int64_t)g.kvol * n > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
+  g.batch = batch;
   if (n == 0) return SST_OK;
   if (!d_coors || !d_grid || !d_in2out || !d_out2in || (((uintptr_t)d_coors) & 15)) return SST_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -882,6 +894,7 @@ int sst_spconv_grid_conv_count_i32(const int32_t* d_coors, int64_t n, int batch,
   if (n < 0 || batch < 1 || !sp_geom(in_shape, out_shape, ksize, stride, padding, dilation, &g)) return SST_ERR_ARG;
   if ((int64_t)g.kvol * n > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
   if (!d_workspace || !d_num_out || (n > 0 && (!d_coors || (((uintptr_t)d_coors) & 15)))) return SST_ERR_ARG;
+  g.batch = batch;
   hipStream_t s = (hipStream_t)stream;
   const int64_t cells = (int64_t)batch * out_shape[0] * out_shape[1] * out_shape[2];
   if (cells > (1ll << 31) - 2) return SST_ERR_UNSUPPORTED;
@@ -905,6 +918,7 @@ int sst_spconv_grid_conv_maps_i32(const int32_t* d_coors, int64_t n, int batch, 
   SpGeom g;
   if (n < 0 || m < 0 || batch < 1 || !sp_geom(in_shape, out_shape, ksize, stride, padding, dilation, &g)) return SST_ERR_ARG;
   if (n == 0 || m == 0) return SST_OK;
+  g.batch = batch;
   if (!d_workspace || !d_coors || !d_outids || !d_in2out || !d_out2in || (((uintptr_t)d_outids) & 15)) return SST_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int64_t cells = (int64_t)batch * out_shape[0] * out_shape[1] * out_shape[2];

@@ -334,9 +334,13 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cf
             and x.data_ptr() % 16 == 0):
         ws = _lib.workspace(lib.sst_spconv_conv_os_workspace_bytes(kvol, cin, cout), x.device)
         order = None
+        x3 = _CONV_PRECISION == 'f32x3' and int(tile_cfg) == 0
         if isinstance(density, Rulebook) and rows >= _OS_ORDER_MIN_ROWS and _os_tile_order_enabled():
-            order = density.tile_order(mapping, rows, lib.sst_spconv_conv_os_tile_rows(rows, cout, int(tile_cfg)))
-        entry = lib.sst_spconv_conv_os_f32x3 if (_CONV_PRECISION == 'f32x3' and int(tile_cfg) == 0) else lib.sst_spconv_conv_os_f32
+            # the split-precision kernel always works on 64-row tiles (it ignores the SST_SPCONV_OS_TILE override the exact
+            # kernel's os_pick honours): its launch order must be computed for ITS tile height
+            tile_rows = 64 if x3 else lib.sst_spconv_conv_os_tile_rows(rows, cout, int(tile_cfg))
+            order = density.tile_order(mapping, rows, tile_rows)
+        entry = lib.sst_spconv_conv_os_f32x3 if x3 else lib.sst_spconv_conv_os_f32
         rc = entry(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin, cout, int(trans_w), None,
                    _lib.ptr(y), y.stride(0), int(tile_cfg), _lib.ptr(order) if order is not None else None, _lib.ptr(ws),
                    _lib.stream_ptr())

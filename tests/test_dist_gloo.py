@@ -74,6 +74,44 @@ def _worker(rank, world, port, ret):
             red.remove()
         assert torch.equal(results['overlap3'], results['flat'])
         assert float(results['flat'][:12].abs().sum()) == 0.0      # the unused layer (registered last) sits first
+        # the set of parameters WITHOUT a gradient differs between the ranks (a class head without points on
+        # one of them).  Rank 0 skips the LAST layer's branch, rank 1 the FIRST one's: without the strict index order rank 0
+        # would put its bucket 1 on the wire mid-backward while rank 1 holds it back until finish() - collectives matched by
+        # order would pair different buckets.  Both orders must be 0, 1, 2 and the averages right.
+        torch.manual_seed(2)
+        heads = torch.nn.ModuleList([torch.nn.Linear(8, 4) for _ in range(3)])
+        hp = list(heads.parameters())
+        red = GradBucketReducer(hp, n_buckets=3, overlap=True)
+        sent = []
+        orig_send = red._send
+        red._send = lambda b: (sent.append(b), orig_send(b))[1]
+        for p in hp:
+            p.grad = None
+        xin = full[start:start + sizes[rank]]
+        use = [0, 1] if rank == 0 else [1, 2]
+        sum((heads[k](xin) ** 2).sum() for k in use).backward()
+        local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in hp]
+        red.finish()
+        assert sent == [0, 1, 2], sent
+        first_order = list(sent)
+        for p, g_local in zip(hp, local):
+            both = [torch.zeros_like(g_local) for _ in range(world)]
+            dist.all_gather(both, g_local)
+            assert torch.allclose(p.grad, sum(both) / world, atol=1e-6)
+        # a second backward pass before finish() must not lose gradients silently
+        for p in hp:
+            p.grad = None
+        sum((heads[k](xin) ** 2).sum() for k in range(3)).backward()
+        try:
+            sum((heads[k](xin) ** 2).sum() for k in range(3)).backward()
+            raised = False
+        except RuntimeError as e:
+            raised = 'one backward pass per finish' in str(e)
+        assert raised
+        red._work, red._sent, red._next = [w.wait() for w in red._work] and [], [False] * 3, 0   # drain the aborted step
+        red._pending = [len(idx) for _, _, idx in red.buckets]
+        red.remove()
+        ret[f'order{rank}'] = first_order
     finally:
         dist.destroy_process_group()
 
@@ -84,7 +122,7 @@ def test_sync_bn_and_flat_grad_allreduce_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert len(ret) == 2
+    assert 0 in ret and 1 in ret and ret['order0'] == ret['order1'] == [0, 1, 2]
     # the flat gradient bucket is identical on both ranks after the all-reduce
     assert torch.equal(ret[0]['flat'], ret[1]['flat'])
     assert torch.equal(ret[0]['gw'], ret[1]['gw'])
