@@ -112,17 +112,18 @@ def _const(values, dev):
 
 
 def mixed_sum(t, scale=1.0):
-    """the scalar the chains backpropagate from: sum(t * w) with a FIXED sign-changing weight w[n, c] = a[n] + b[c] built from
-    integer arithmetic (identical on every device, no RNG).  A plain t.sum() is the wrong probe for these networks: the
-    outputs sit behind batch / layer normalisation, whose column (row) sums are constants - d sum(LN(x)) / dx is exactly 0
-    and d sum(BN(x)) / dx cancels over the batch - so the parameter gradients of a plain sum are small residues of large
-    cancelling terms and two correct fp32 evaluations of them differ by percents (tests/adjudicate_fsd_grads.py: the CPU
-    port in fp32 against itself in float64, 5.6e-2 on a 20 k-point frame).  bench.py's SST step starts from a fixed random
-    upstream gradient for the same reason."""
+    """the scalar the chains backpropagate from: sum(t * w) with a FIXED weight w[n, c] = a[n] * b[c] built from integer
+    arithmetic (identical on every device, no RNG): a changes sign from row to row (period 13, zero mean), b in [0.25, 1.25].
+    A plain t.sum() - or any weight with a column-constant part - is the wrong probe for these networks: the outputs sit
+    behind batch / layer normalisation, whose backward pass REMOVES the column mean of the upstream gradient
+    (d sum(LN(x)) / dx is exactly 0, d sum(BN(x)) / dx cancels over the batch), so the parameter gradients of such a probe
+    are small residues of large cancelling terms and two correct fp32 evaluations of them differ by percents
+    (tests/adjudicate_fsd_grads.py: the CPU port in fp32 against itself in float64).  bench.py's SST step starts from a fixed
+    random upstream gradient for the same reason."""
     n, c = t.shape
     a = ((torch.arange(n, device=t.device) % 13) - 6).to(t.dtype) / 6
-    b = ((torch.arange(c, device=t.device) * 7 % 11) - 5).to(t.dtype) / 5
-    return (t * (a[:, None] + b[None, :])).sum() * scale
+    b = (torch.arange(c, device=t.device) * 7 % 11).to(t.dtype) / 10 + 0.25
+    return (t * (a[:, None] * b[None, :])).sum() * scale
 
 
 def fsd_foreground_stand_in(batch_points, votes, z_cut=-1.4):

@@ -15,7 +15,7 @@ and two correct fp32 evaluations differ by O(flips / rows), not by O(eps).
   python tests/adjudicate_fsd_grads.py cpu --in gpurun_out/adj_fsd.pt --out profiles/r04/fsd_grad_adjudication.json
 
 The gpu stage stores gradients only (weights and cloud are re-created from the seeds; a checksum guards it); parameters
-above 400 k elements are stored as a strided subsample (the statistic is a maximum: a subsample bounds it from below and is
+above 20 k elements are stored as a strided subsample (the statistic is a maximum: a subsample bounds it from below and is
 compared like for like).  tests/test_fsd_chain.py::test_gpu_gradients_within_fp32_noise_at_40k runs the same functions."""
 import argparse
 import json
@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SUBSAMPLE_ABOVE = 400_000
+SUBSAMPLE_ABOVE = 20_000
 
 
 def _sub(t):

@@ -135,7 +135,14 @@ def test_cpu_port_chain_matches_live_reference(tag, train):
 @pytest.mark.parametrize('tag', ['fsd', 'fsdv2'])
 def test_gpu_chain_matches_reference_golden(tag):
     g = load_golden(f'{tag}_chain.npz')
-    _check_against_golden(tag, _build(tag, BW.GpuOps, g, 'cuda:0'), g, 'cuda:0', 1e-3, 1e-3)
+    # features 1e-3 (measured <= 3e-5).  Gradients 5e-3: the kernels reproduce every module's gradient to ~1e-6 GIVEN the module's
+    # inputs (profiles/r04/chain_grad_isolation.txt: recover_proj evaluated in float64 on the GPU's own input and upstream
+    # gradient), but a forward difference of 2-3e-5 - the output-stationary convolution sums 27 x C_in products in one fp32
+    # chain, the CPU formulation per offset - flips the sign of a handful of ReLU inputs next to zero, and each flip moves a
+    # gradient entry by |dy| |x|: 1e-3-class differences on single parameters, in either direction (the reference's own fp32
+    # gradients sit up to 3e-3 from float64 on this fixture, stored beside them as grad64).  The statistical statement over
+    # ALL parameters at 40 000 points is test_gpu_gradients_within_fp32_noise_at_40k.
+    _check_against_golden(tag, _build(tag, BW.GpuOps, g, 'cuda:0'), g, 'cuda:0', 1e-3, 5e-3)
 
 
 @pytest.mark.gpu

@@ -301,3 +301,35 @@ def test_sparse_maxpool_module():
     want = torch.nn.functional.max_pool3d(dense_in, 3, 2, 1)       # zeros where nothing is active, like the sparse op
     got = out.dense()
     assert torch.equal(got, want * (got != 0)) or torch.allclose(got[got != 0], want[got != 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('subm', [True, False])
+def test_grid_rulebook_ignores_rows_outside_the_grid(subm):
+    """the dense-grid builders index batch x shape cell arrays with the input coordinates - a sample index
+    >= batch_size, a negative coordinate or one >= spatial_shape must not write out of bounds.  Such rows take no part: the
+    valid rows get exactly the rulebook they get alone, the bad rows no pair."""
+    from sst_amd import spconv
+    rng = np.random.RandomState(5)
+    shape, batch = [8, 12, 12], 2
+    cells = rng.choice(batch * 8 * 12 * 12, 300, replace=False)
+    good = np.stack([cells // 1152, cells // 144 % 8, cells // 12 % 12, cells % 12], 1).astype(np.int32)
+    bad = np.array([[2, 1, 1, 1], [0, 8, 0, 0], [1, 0, 12, 3], [0, 0, 0, -1], [-1, 2, 2, 2], [0, 0, 0, 4000]], dtype=np.int32)
+    mixed = np.concatenate([good[:150], bad[:3], good[150:], bad[3:]])
+    pos_good = np.concatenate([np.arange(150), np.arange(153, 303)])
+    kw = dict(ksize=3, stride=1 if subm else 2, padding=1, subm=subm)
+    out_a, pairs_a, num_a = spconv.get_indice_pairs(torch.from_numpy(good).to(DEV), batch, shape, **kw)
+    out_b, pairs_b, num_b = spconv.get_indice_pairs(torch.from_numpy(mixed).to(DEV), batch, shape, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(num_a, num_b)
+    if not subm:
+        assert torch.equal(out_a, out_b)
+    remap = torch.from_numpy(pos_good).to(DEV)
+    for k in range(27):
+        c = int(num_a[k])
+        a_in, b_in = remap[pairs_a[k, 0, :c].long()], pairs_b[k, 0, :c].long()
+        assert torch.equal(a_in, b_in)
+        if subm:      # output rows = input rows: renumbered the same way
+            assert torch.equal(remap[pairs_a[k, 1, :c].long()], pairs_b[k, 1, :c].long())
+        else:
+            assert torch.equal(pairs_a[k, 1, :c], pairs_b[k, 1, :c])
