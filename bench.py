@@ -394,6 +394,10 @@ def main():
                     help='take roofline.traffic from profiles/latest_sra_traffic.json instead of two rocprofv3 --pmc passes now')
     ap.add_argument('--no-lidar-leg', action='store_true', help='skip the LiDAR-like / pathological frame beside the headline')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the reduced-precision (bf16) measurement')
+    ap.add_argument('--matmul', default='f32x6', choices=('f32', 'f32x6'),
+                    help="how the fp32 encoder layers multiply in the TIMED region: 'f32x6' = exact three-way bf16 split, six "
+                         "products on the bf16 matrix pipe (csrc/dense_f32x6.hip; admissible as exact fp32: tests/"
+                         "test_gpu_dense_f32x6.py), 'f32' = the fp32 matrix pipe (csrc/dense_f32.hip)")
     ap.add_argument('--precision', default='f32', choices=('f32', 'bf16'),
                     help="precision of the encoder layers in the TIMED region; the contract's headline is f32 (default), "
                          "bf16 makes the reduced-precision mode the measured one (profiling)")
@@ -460,6 +464,8 @@ def main():
     if args.precision == 'bf16':
         model.backbone.set_precision('bf16')
         args.no_bf16_leg = True
+    elif args.matmul == 'f32x6':
+        model.backbone.set_precision('f32x6')
     params = [p for p in model.parameters() if p.requires_grad]
     frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
     torch.manual_seed(1234 + rank)            # per-rank voxel shuffles

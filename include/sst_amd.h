@@ -572,6 +572,25 @@ int sst_tall_linear_ln_f32x3(const float* d_x, int64_t ldx, const float* d_w, in
                              const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
                              float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
                              float* d_y_plus_pos, void* stream);
+/* sst_tall_linear_epi_f32x6 / sst_tall_linear_ln_f32x6 (csrc/dense_f32x6.hip): the same two entry points again, fp32 tensors,
+ * the product evaluated on the bf16 matrix pipe from an EXACT three-way split of both operands (x = x0 + x1 + x2, 8 + 8 + 8
+ * significand bits) with the six products x_i w_j, i + j <= 2, accumulated in fp32: what is dropped is below 2^-24 |x w| per
+ * product, i.e. below the rounding of an fp32 FMA chain - the arithmetic class of the reference's nn.Linear in fp32
+ * (sst_basic_block_v2.py:41-126), at 6 x 16 instead of 8 x 32 matrix-pipe cycles per 16 x 16 x 32 block.  (k, n) in
+ * {(128,128), (128,256), (128,384), (256,128)}; the LayerNorm entry takes k = 128 only (SST_ERR_UNSUPPORTED for 256: the
+ * caller runs epilogue 5 + sst_add_layernorm_act_fwd_f32).  Selected by SSTv2.set_precision('f32x6').
+ * sst_tall_linear_epi2_f32x6: the same with a second input matrix d_x2 (same ldx) for the output columns >= x2_from_col (a
+ * multiple of 128): q | k | v of an encoder layer in ONE launch, q = k = (x + pos) W, v = x W (sst_basic_block_v2.py:56-62). */
+int sst_tall_linear_epi_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int trans_w, const float* d_bias,
+                              int64_t m, int k, int n, int epilogue, const float* d_aux_in, float* d_aux_out, int64_t ldaux,
+                              float* d_y, int64_t ldy, void* stream);
+int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_col, int64_t ldx, const float* d_w, int64_t ldw,
+                               int trans_w, const float* d_bias, int64_t m, int k, int n, int epilogue, const float* d_aux_in,
+                               float* d_aux_out, int64_t ldaux, float* d_y, int64_t ldy, void* stream);
+int sst_tall_linear_ln_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias, int64_t m, int k,
+                             const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
+                             float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
+                             float* d_y_plus_pos, void* stream);
 int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
                                const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
                                void* d_workspace, void* stream);

@@ -106,6 +106,12 @@ _SIGNATURES = {
                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_tall_linear_epi_f32x3': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr,
                                           c_i64, c_ptr, c_i64, c_ptr]),
+    'sst_tall_linear_ln_f32x6': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr,
+                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_tall_linear_epi_f32x6': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr,
+                                          c_i64, c_ptr, c_i64, c_ptr]),
+    'sst_tall_linear_epi2_f32x6': (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_i32,
+                                           c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'sst_add_layernorm_bwd2_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_tall_linear_epi_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr,
                                         c_i64, c_ptr, c_i64, c_ptr]),

@@ -152,15 +152,19 @@ class _WindowTransformer(nn.Module):
         """'fp32' (default; the parity mode) or 'bf16': reduced-precision encoder layers (sst_amd/bf16.py) - what the
         reference's fp16 training (Fp16OptimizerHook) corresponds to on this hardware.  Layers the bf16 kernels do not
         cover (cosine attention, batch-norm layers, pre-norm) keep running in fp32."""
-        if precision not in ('fp32', 'bf16', 'f32x3'):
+        if precision not in ('fp32', 'bf16', 'f32x3', 'f32x6'):
             raise ValueError(precision)
         # 'f32x3': fp32 storage everywhere, the projections / FFN products as three bf16 products of split operands with fp32
         # accumulation (csrc/dense_f32x3.hip): ~1e-5 relative - tighter than the TF32 the reference's torch 1.8 used for
         # these products on Ampere.  The attention core, LayerNorm and the weight gradients stay exact fp32.
+        # 'f32x6': the same fp32 tensors and results (to fp32 rounding), the products from an EXACT three-way bf16 split, six
+        # products with fp32 accumulation (csrc/dense_f32x6.hip): same arithmetic class as exact fp32, 2.7 x less matrix-pipe
+        # time.  NOTE: the switch is process-global (dense.set_matmul_mode): every model of the process follows the last call.
         from . import dense
-        dense.set_matmul_mode('f32x3' if precision == 'f32x3' else 'f32')
-        self.precision = 'fp32' if precision == 'f32x3' else precision
-        self.matmul = 'f32x3' if precision == 'f32x3' else 'f32'
+        split = precision if precision in ('f32x3', 'f32x6') else None
+        dense.set_matmul_mode(split or 'f32')
+        self.precision = 'fp32' if split else precision
+        self.matmul = split or 'f32'
         return self
 
     def run_blocks(self, feats, pos, plans, masks=None, pos_lookup=None):

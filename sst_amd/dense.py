@@ -113,15 +113,22 @@ def tall_gemm(x, w, bias=None, trans_w=False, out=None, accumulate=False):
 
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_ADD = range(6)
 _LDS_LINEAR_SHAPES = ((128, 128), (128, 256), (256, 128))
-# How the LDS-resident linears multiply: 'f32' = exact fp32 (v_mfma_f32_16x16x4_f32, csrc/dense_f32.hip; the parity mode and
-# the headline) or 'f32x3' = three bf16 products of split operands with fp32 accumulation (csrc/dense_f32x3.hip; ~1e-5
-# relative, tighter than the TF32 products of the reference's own torch 1.8 on Ampere).  SSTv2.set_precision switches it.
+# How the LDS-resident linears multiply:
+#   'f32'   exact fp32 on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, csrc/dense_f32.hip);
+#   'f32x6' exact three-way bf16 split of both operands, the six products x_i w_j with i + j <= 2 on the bf16 matrix pipe with
+#           fp32 accumulation (csrc/dense_f32x6.hip): what is dropped is below the rounding of an fp32 FMA chain - same
+#           arithmetic class, 2.7 x less matrix-pipe time; admissible as the headline only while tests/test_gpu_dense_f32x6.py
+#           holds (error against float64 <= 2 x the fp32 kernel's, every shape and the 12-layer stack);
+#   'f32x3' two-way split, three products (csrc/dense_f32x3.hip; ~1e-5 relative, tighter than the TF32 products of the
+#           reference's own torch 1.8 on Ampere): a leg beside the headline, never the headline.
+# SSTv2.set_precision switches it.  PROCESS-GLOBAL: models built side by side (an EMA copy, a two-stage detector) share it.
 _MATMUL_MODE = 'f32'
+_MATMUL_MODES = ('f32', 'f32x3', 'f32x6')
 
 
 def set_matmul_mode(mode):
     global _MATMUL_MODE
-    if mode not in ('f32', 'f32x3'):
+    if mode not in _MATMUL_MODES:
         raise ValueError(mode)
     _MATMUL_MODE = mode
 
@@ -150,12 +157,29 @@ def lds_linear(x, w, bias=None, epilogue=EPI_BIAS, trans_w=False, aux_in=None, w
     if aux is not None and (aux.stride(1) != 1 or aux.data_ptr() % 16 or aux.stride(0) % 4):
         raise RuntimeError('sst_amd.dense.lds_linear: aux tensor must be row-major and 16-byte aligned')
     lib = _lib.load()
-    entry = lib.sst_tall_linear_epi_f32x3 if _MATMUL_MODE == 'f32x3' else lib.sst_tall_linear_epi_f32
+    entry = getattr(lib, 'sst_tall_linear_epi_' + _MATMUL_MODE)
     rc = entry(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), int(trans_w), _lib.ptr(bias), m, k, n, int(epilogue),
                _lib.ptr(aux_in), _lib.ptr(pre), aux.stride(0) if aux is not None else 0, _lib.ptr(y), y.stride(0),
                _lib.stream_ptr())
     _lib.check(rc, 'sst_tall_linear_epi_' + _MATMUL_MODE)
     return (y, pre) if want_pre else y
+
+
+def lds_linear_qkv_ok(xp, x, w_in):
+    """q | k | v as ONE launch: the f32x6 kernel's column groups may read different inputs (csrc/dense_f32x6.hip)"""
+    return (_MATMUL_MODE == 'f32x6' and w_in.shape == (384, 128) and lds_linear_ok(xp, w_in[:256]) and lds_linear_ok(x, w_in[256:])
+            and xp.shape == x.shape and xp.stride(0) == x.stride(0) and w_in.is_contiguous())
+
+
+def lds_linear_qkv(xp, x, w_in, b_in):
+    """[M, 384] = [(xp W_q^T | xp W_k^T) | x W_v^T] + b: q = k = feat + pos, v = feat (sst_basic_block_v2.py:56-62)"""
+    m = x.size(0)
+    y = torch.empty((m, 384), dtype=torch.float32, device=x.device)
+    rc = _lib.load().sst_tall_linear_epi2_f32x6(_lib.ptr(xp), _lib.ptr(x), 256, x.stride(0), _lib.ptr(w_in), w_in.stride(0), 0,
+                                               _lib.ptr(b_in), m, 128, 384, EPI_BIAS, None, None, 0, _lib.ptr(y), 384,
+                                               _lib.stream_ptr())
+    _lib.check(rc, 'sst_tall_linear_epi2_f32x6')
+    return y
 
 
 def _gelu_gemm_ok(x, w, n, k):
@@ -300,7 +324,11 @@ def lds_linear_add_ln(x, w, bias, res, ln_weight, ln_bias, eps, save_sum=True, p
     stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
     yp = torch.empty((m, 128), dtype=torch.float32, device=x.device) if pos is not None else None
     lib = _lib.load()
-    entry = lib.sst_tall_linear_ln_f32x3 if _MATMUL_MODE == 'f32x3' else lib.sst_tall_linear_ln_f32
+    # f32x6 at K = 256: three bf16 images of a 128-column group (203 KB) exceed the LDS, and a LayerNorm epilogue needs the whole
+    # row in one workgroup: that one product stays on the fp32 matrix pipe (same arithmetic class; 68 us either way - the split
+    # kernel over 64-column groups + a LayerNorm pass measured 48 + 20 us)
+    mode = 'f32' if (_MATMUL_MODE == 'f32x6' and k != 128) else _MATMUL_MODE
+    entry = getattr(lib, 'sst_tall_linear_ln_' + mode)
     rc = entry(
         _lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), m, k, _lib.ptr(res), 128, _lib.ptr(ln_weight),
         _lib.ptr(ln_bias), float(eps), _lib.ptr(y), _lib.ptr(s), _lib.ptr(stats),

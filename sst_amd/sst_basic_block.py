@@ -20,7 +20,7 @@ from torch.utils.checkpoint import checkpoint
 from . import kernels as K
 from .sra_composed import sra_attention_composed
 from .dense import (EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
-                    lds_linear_add_ln, lds_linear_add_ln_ok, weight_bias_grad_group,
+                    lds_linear_add_ln, lds_linear_add_ln_ok, lds_linear_qkv, lds_linear_qkv_ok, weight_bias_grad_group,
                     tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
                     weight_bias_grad)
 from .norm import build_norm_layer
@@ -204,8 +204,12 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         ctx.split_input = xp is not None
         if xp is None:
             xp = x + pos if pos is not None else x
-        qk = _linear_fwd(xp, w_in[:2 * c], b_in[:2 * c])
-        v = _linear_fwd(x, w_in[2 * c:], b_in[2 * c:])
+        if _LDS_LINEAR and c == 128 and lds_linear_qkv_ok(xp, x, w_in):     # one launch, two inputs (csrc/dense_f32x6.hip)
+            qkv = lds_linear_qkv(xp, x, w_in, b_in)
+            qk, v = qkv[:, :2 * c], qkv[:, 2 * c:]
+        else:
+            qk = _linear_fwd(xp, w_in[:2 * c], b_in[:2 * c])
+            v = _linear_fwd(x, w_in[2 * c:], b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
         o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
@@ -226,6 +230,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         y2p = None
         if fuse_ln and lds_linear_add_ln_ok(h, w2, y1, c):
             y2, s2, st2, y2p = lds_linear_add_ln(h, w2, b2, y1, n2w, n2b, eps, save_sum=need_bwd, pos=pos_next)
+        elif _LDS_LINEAR and lds_linear_ok(h, w2):
+            # residual in the projection's epilogue, LayerNorm as its own pass over the sum (f32x6 at K = 256: see dense.py)
+            s2 = lds_linear(h, w2, b2, EPI_ADD, aux_in=y1)
+            y2, _, st2 = add_ln_fwd(s2, None, n2w, n2b, eps)
         else:
             f = _linear_fwd(h, w2, b2)
             y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd)
