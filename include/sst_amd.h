@@ -476,6 +476,13 @@ typedef struct sst_wgrad_problem_f32 {
 } sst_wgrad_problem_f32;
 int64_t sst_weight_grad_group_workspace_bytes(const sst_wgrad_problem_f32* problems, int n);
 int sst_weight_grad_group_f32(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream);
+/* The same gradients from the EXACT three-way bf16 split of both operands, six products on the bf16 matrix pipe with fp32
+ * accumulation (csrc/wgrad_x6.hip; the arithmetic class of the fp32 kernel, see sst_tall_linear_epi_f32x6): ONE launch for all
+ * problems (128 x 128 tiles of every dW x token slices) + one reduction.  All problems share m; out, in multiples of 128; row
+ * strides % 4 == 0, 16-byte aligned operands; otherwise the workspace query returns SST_ERR_UNSUPPORTED (< 0) and the caller
+ * uses sst_weight_grad_group_f32. */
+int64_t sst_weight_grad_group_f32x6_workspace_bytes(const sst_wgrad_problem_f32* problems, int n);
+int sst_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a11/a12, §8 f1) BatchNorm1d (+ ReLU) of the point-wise "Linear -> norm -> ReLU" layers of DynamicVFE / SIR

@@ -100,6 +100,8 @@ _SIGNATURES = {
     'sst_cast_add_pos_bf16': (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_weight_grad_group_workspace_bytes': (c_i64, [c_ptr, c_i32]),
     'sst_weight_grad_group_f32': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
+    'sst_weight_grad_group_f32x6_workspace_bytes': (c_i64, [c_ptr, c_i32]),
+    'sst_weight_grad_group_f32x6': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
     'sst_tall_linear_ln_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr,
                                        c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sst_tall_linear_ln_f32x3': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_f32, c_ptr,

@@ -87,6 +87,13 @@ def weight_bias_grad_group(problems):
     for q, (dy, x, ow, ob) in zip(arr, problems):
         q.dy, q.x, q.m, q.ld_dy, q.ld_x = dy.data_ptr(), x.data_ptr(), dy.size(0), dy.stride(0), x.stride(0)
         q.dw, q.db, q.out, q.inn = ow.data_ptr(), (ob.data_ptr() if ob is not None else None), dy.size(1), x.size(1)
+    if _MATMUL_MODE == 'f32x6':       # exact three-way bf16 split on the bf16 matrix pipe (csrc/wgrad_x6.hip), one launch for the group
+        need = lib.sst_weight_grad_group_f32x6_workspace_bytes(arr, len(problems))
+        if need >= 0:
+            ws = _lib.workspace(need, problems[0][0].device)
+            _lib.check(lib.sst_weight_grad_group_f32x6(arr, len(problems), _lib.ptr(ws), _lib.stream_ptr()),
+                       'sst_weight_grad_group_f32x6')
+            return
     ws = _lib.workspace(lib.sst_weight_grad_group_workspace_bytes(arr, len(problems)), problems[0][0].device)
     _lib.check(lib.sst_weight_grad_group_f32(arr, len(problems), _lib.ptr(ws), _lib.stream_ptr()), 'sst_weight_grad_group_f32')
 

@@ -202,3 +202,52 @@ def test_sst_block_f32x6_training_step_vs_exact():
     for name, grad in p6.items():
         s_ = max(1.0, float(p32[name].abs().max()))
         assert float((grad - p32[name]).abs().max()) <= 1e-5 * s_, name
+
+
+@pytest.mark.parametrize('m', [4096, 5001, 90107])
+def test_weight_gradients_admissible(m):
+    """the five parameter gradients of an encoder layer as the backward pass groups them (csrc/wgrad_x6.hip): against float64,
+    beside the fp32-pipe kernel (csrc/wgrad.hip) on the same operands - strided views of a [M, 384] buffer included"""
+    from sst_amd import dense as D
+    g = torch.Generator().manual_seed(m)
+    dev = DEV
+    dqkv = torch.randn(m, 384, generator=g).to(dev)
+    ds2, ds1 = torch.randn(m, 128, generator=g).to(dev), torch.randn(m, 128, generator=g).to(dev)
+    dpre = torch.randn(m, 256, generator=g).to(dev)
+    h = torch.randn(m, 256, generator=g).to(dev)
+    y1, o, xp, x = (torch.randn(m, 128, generator=g).to(dev) for _ in range(4))
+    groups = [[(ds2, h), (dpre, y1)], [(ds1, o), (dqkv[:, :256], xp), (dqkv[:, 256:], x)]]
+
+    def run():
+        outs = []
+        for grp in groups:
+            probs = [(dy, xx, torch.empty(dy.size(1), xx.size(1), device=dev), torch.empty(dy.size(1), device=dev)) for dy, xx in grp]
+            D.weight_bias_grad_group(probs)
+            outs += [(p[2], p[3]) for p in probs]
+        return outs
+
+    nat, spl = _both(D, run)
+    flat = [p for grp in groups for p in grp]
+    for (dy, xx), (wn, bn), (ws, bs) in zip(flat, nat, spl):
+        want_w = dy.double().t() @ xx.double()
+        want_b = dy.double().sum(0)
+        # the reference scale of a contraction over m tokens: sum |dy| |x| ~ m
+        _admissible(wn, ws, want_w, 'dW %s' % (tuple(want_w.shape),), floor=2e-7)
+        _admissible(bn, bs, want_b, 'db', floor=1e-6)
+        assert not torch.equal(wn, ws)
+
+
+def test_weight_gradients_small_and_unsupported_shapes_fall_back():
+    """fewer than 4096 rows or widths that are not multiples of 128: the exact-fp32 kernels (same results as outside the mode)"""
+    from sst_amd import dense as D
+    g = torch.Generator().manual_seed(3)
+    dy, x = torch.randn(5000, 64, generator=g).to(DEV), torch.randn(5000, 128, generator=g).to(DEV)
+
+    def run():
+        w, b = torch.empty(64, 128, device=DEV), torch.empty(64, device=DEV)
+        D.weight_bias_grad_group([(dy, x, w, b)])
+        return w, b
+
+    (wn, bn), (ws, bs) = _both(D, run)
+    assert torch.equal(wn, ws) and torch.equal(bn, bs)
+    assert float((wn.double() - dy.double().t() @ x.double()).abs().max()) <= 1e-3

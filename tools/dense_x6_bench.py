@@ -54,6 +54,20 @@ w = (torch.randn(384, 128, generator=g) * 0.1).to(dev)
 b = torch.randn(384, generator=g).to(dev)
 print({'qkv one launch': timeit(lambda: D.lds_linear_qkv(xp, x, w, b)),
        'qk + v': timeit(lambda: (D.lds_linear(xp, w[:256], b[:256]), D.lds_linear(x, w[256:], b[256:])))})
+# the five weight gradients of a layer, as the backward pass groups them
+dqkv = torch.randn(M, 384, generator=g).to(dev)
+ds2, ds1 = torch.randn(M, 128, generator=g).to(dev), torch.randn(M, 128, generator=g).to(dev)
+dpre, h = torch.randn(M, 256, generator=g).to(dev), torch.randn(M, 256, generator=g).to(dev)
+y1, o = torch.randn(M, 128, generator=g).to(dev), torch.randn(M, 128, generator=g).to(dev)
+grp1 = [(ds2, h, torch.empty(128, 256, device=dev), torch.empty(128, device=dev)),
+        (dpre, y1, torch.empty(256, 128, device=dev), torch.empty(256, device=dev))]
+grp2 = [(ds1, o, torch.empty(128, 128, device=dev), torch.empty(128, device=dev)),
+        (dqkv[:, :256], xp, torch.empty(256, 128, device=dev), torch.empty(256, device=dev)),
+        (dqkv[:, 256:], x, torch.empty(128, 128, device=dev), torch.empty(128, device=dev))]
+for mode in ('f32', 'f32x6'):
+    D.set_matmul_mode(mode)
+    print({'wgrad mode': mode, 'group1 (dW2, dW1)': timeit(lambda: D.weight_bias_grad_group(grp1)),
+           'group2 (dWo, dWqk, dWv)': timeit(lambda: D.weight_bias_grad_group(grp2))})
 res = torch.randn(M, 128, generator=g).to(dev)
 lw, lb = torch.ones(128, device=dev), torch.zeros(128, device=dev)
 print({'add_ln_fwd pass (fp32)': timeit(lambda: D.add_ln_fwd(res, None, lw, lb, 1e-5))})
