@@ -303,6 +303,15 @@ def cpu_reference_leg(model, frame_cpu, num_blocks, budget_s=75.0):
             if out_first is None:
                 out_first = out.detach()
                 grads_first = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        # the same port in float64 (integer stages in fp32): the adjudicator for `max_abs_err_vs_float64` - how far the GPU forward
+        # is from the exact result of the network, in the headline arithmetic (dense products as the exact bf16 split) and with
+        # the fp32 matrix pipe, beside the fp32 CPU port itself
+        import copy
+        net64 = copy.deepcopy(net).double()
+        with torch.no_grad():
+            out64 = net64([frame_cpu.double()])
+        same64 = torch.equal(voxel_sort_key(net64.last_voxel_coors), voxel_sort_key(net.last_voxel_coors))
+        del net64
     finally:
         torch.set_num_threads(all_threads)
     med = _median(times)
@@ -312,6 +321,18 @@ def cpu_reference_leg(model, frame_cpu, num_blocks, budget_s=75.0):
     key_c = voxel_sort_key(net.last_voxel_coors)   # rows of the CPU output are in sorted-unique voxel order
     out_g, key_g = gpu_forward_sorted(model, [frame_cpu.to(dev)])
     voxels_equal = bool(key_c.numel() == key_g.numel() and torch.equal(key_c, key_g))
+    vs64 = None
+    if voxels_equal and same64:
+        from sst_amd import dense as _dense
+        mode_now = _dense.matmul_mode()
+        vs64 = {f'gpu, dense products {mode_now} (the timed mode)': float((out_g.double() - out64).abs().max()),
+                'cpu port, fp32': float((out_first.double() - out64).abs().max())}
+        other = 'f32' if mode_now != 'f32' else 'f32x6'
+        try:
+            _dense.set_matmul_mode(other)
+            vs64[f'gpu, dense products {other}'] = float((gpu_forward_sorted(model, [frame_cpu.to(dev)])[0].double() - out64).abs().max())
+        finally:
+            _dense.set_matmul_mode(mode_now)
     grad_err = None
     if voxels_equal:
         gpu_forward_sorted(model, [frame_cpu.to(dev)], upstream_sorted=up)
@@ -328,6 +349,7 @@ def cpu_reference_leg(model, frame_cpu, num_blocks, budget_s=75.0):
         model.zero_grad(set_to_none=True)
     parity = {'voxels_equal': voxels_equal, 'voxels': int(key_g.numel()),
               'max_abs_err': float((out_g - out_first).abs().max()) if voxels_equal else None,
+              'max_abs_err_vs_float64': vs64,
               'max_rel_grad_err': grad_err, 'tolerance': 1e-3,
               'what': 'GPU forward + backward (fp32, no voxel shuffle, training-mode drop + batch-norm statistics, a fixed '
                       'random upstream gradient) vs the CPU port of the reference data flow with the same weights on the '
@@ -563,15 +585,16 @@ def main():
     # bf16 products of split fp32 operands with fp32 accumulation (csrc/dense_f32x3.hip; everything stays fp32 in HBM, the
     # attention core, LayerNorm and the weight gradients stay exact fp32).  ~1e-5 relative per product - tighter than the TF32
     # tensor-core products torch 1.8 (the reference's pinned version) uses for these layers by default on Ampere.
-    x3_leg = None
-    if not args.fwd_only and not args.no_f32x3_leg and args.precision == 'f32':
+    def matmul_leg(mode, dtype, what):
+        """the same step with the dense products of the encoder layers in another multiply mode (sst_amd/dense.py), beside
+        `value`: W warm-up steps, K timed; its forward output against the timed mode's on the same frame"""
         with torch.no_grad():
             ref_out, ref_key = gpu_forward_sorted(model, frames)
-        model.backbone.set_precision('f32x3')
+        model.backbone.set_precision(mode)
         try:
             with torch.no_grad():
-                x3_out, x3_key = gpu_forward_sorted(model, frames)
-            same = torch.equal(ref_key, x3_key)
+                alt_out, alt_key = gpu_forward_sorted(model, frames)
+            same = torch.equal(ref_key, alt_key)
             for _ in range(3):
                 step()
             sync()
@@ -581,18 +604,27 @@ def main():
             sync()
             el = time.perf_counter() - t4
         finally:
-            model.backbone.set_precision('fp32')
+            model.backbone.set_precision('f32x6' if args.matmul == 'f32x6' else 'fp32')
         if world > 1:
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-        x3_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
-                  'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': 'f32 storage, bf16 x 3 products',
-                  'max_abs_err_vs_exact_fp32_forward': float((x3_out - ref_out).abs().max()) if same else None,
-                  'voxels_equal': bool(same),
-                  'what': 'same step; q|k, v, out-proj, FFN products and their data gradients as x_hi w_hi + x_lo w_hi + x_hi w_lo '
-                          'on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (12 layers: error of the whole forward vs the '
-                          'exact-fp32 forward in max_abs_err_vs_exact_fp32_forward); not part of `value`'}
+        return {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': dtype,
+                'max_abs_err_vs_timed_mode_forward': float((alt_out - ref_out).abs().max()) if same else None,
+                'voxels_equal': bool(same), 'what': what}
+
+    x3_leg = mfma_leg = None
+    if not args.fwd_only and not args.no_f32x3_leg and args.precision == 'f32':
+        x3_leg = matmul_leg('f32x3', 'f32 storage, bf16 x 3 products',
+                            'same step; q|k, v, out-proj, FFN products and their data gradients as x_hi w_hi + x_lo w_hi + x_hi w_lo '
+                            'on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (two-way split: ~1e-5 relative per product, NOT '
+                            'exact - a leg, never `value`); weight gradients on the fp32 matrix pipe')
+        if args.matmul == 'f32x6':
+            mfma_leg = matmul_leg('fp32', 'f32, fp32 matrix pipe',
+                                  'same step with every dense product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: '
+                                  'csrc/dense_f32.hip, csrc/wgrad.hip) - the arithmetic of rounds 1-3; the timed mode evaluates the '
+                                  'same products from the exact three-way bf16 split (csrc/dense_f32x6.hip, csrc/wgrad_x6.hip)')
 
     # Beside the headline (uniform cloud): the same step on a LiDAR-like frame with out-of-range points and duplicates
     lidar_leg = None
@@ -664,7 +696,7 @@ def main():
             el = time.perf_counter() - t2
             K.EVENT_SINK = None
         finally:
-            model.backbone.set_precision('fp32')
+            model.backbone.set_precision('f32x6' if args.matmul == 'f32x6' else 'fp32')
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -755,7 +787,12 @@ def main():
             else 'LiDAR frames/sec (SST backbone fwd-only) at Waymo 0.32m voxels',
             'value': round(total_frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': ('f32 (storage, accumulation, attention, LayerNorm, reductions: fp32; the dense products of the encoder '
+                      'layers from the EXACT three-way bf16 split of both fp32 operands, six bf16 MFMA products with fp32 '
+                      'accumulation - error vs float64 <= 2 x the fp32 matrix pipe\'s: tests/test_gpu_dense_f32x6.py)'
+                      if (args.precision == 'f32' and args.matmul == 'f32x6') else args.precision),
+            'data': 'synthetic',
             'gemm_tuning': 'off' if args.no_gemm_tuning else 'torch TunableOp (hipBLASLt/rocBLAS solution per shape)',
             'config': {'workload': ('SST-base Waymo training, bs=2/GPU, 0.32 m voxel: uniform synthetic cloud '
                                     if args.workload == 'sst_bs2' else
@@ -784,6 +821,8 @@ def main():
             res['lidar_like_cloud'] = lidar_leg
         if x3_leg is not None:
             res['precision_f32x3'] = x3_leg
+        if mfma_leg is not None:
+            res['precision_f32_mfma'] = mfma_leg
         if bf16_leg is not None:
             res['reduced_precision'] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:

@@ -75,7 +75,7 @@ class CpuEncoderLayer(nn.Module):
             pos3d = src.new_zeros((n_win * t, c))
             mask = torch.ones(n_win * t, dtype=torch.bool)
             feat3d[slot_idx] = src[vox_idx]
-            pos3d[slot_idx] = pos[vox_idx]
+            pos3d[slot_idx] = pos[vox_idx].to(src.dtype)
             mask[slot_idx] = False
             feat3d = feat3d.view(n_win, t, c).permute(1, 0, 2)
             qk = feat3d + pos3d.view(n_win, t, c).permute(1, 0, 2)
@@ -118,7 +118,7 @@ class CpuSSTBackbone(nn.Module):
         return torch.from_numpy(keep), shifts
 
     def forward(self, points_list):
-        coors = [np.pad(voxel_oracle.dynamic_voxelize(p.numpy(), self.voxel_size, self.pc_range), ((0, 0), (1, 0)),
+        coors = [np.pad(voxel_oracle.dynamic_voxelize(p.float().numpy(), self.voxel_size, self.pc_range), ((0, 0), (1, 0)),
                         constant_values=b) for b, p in enumerate(points_list)]
         coors = torch.from_numpy(np.concatenate(coors))
         pts = torch.cat(points_list)
