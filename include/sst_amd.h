@@ -448,6 +448,11 @@ int sst_add_layernorm_act_bwd_f32(const float* d_dy, const float* d_sum, const f
 int sst_add_layernorm_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias,
                               int64_t m, int c, float eps, float* d_y, float* d_sum, float* d_stats,
                               void* stream);
+/* the same with a second output d_y_plus_pos[row] = y[row] + d_pos_table[d_pos_idx[row]] (table rows of c floats): the next
+ * encoder layer's q / k input (sst_basic_block_v2.py:56-58: q = k = feat + pos) without an add pass; c % 4 == 0 */
+int sst_add_layernorm_pos_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias, int64_t m,
+                                  int c, float eps, float* d_y, float* d_sum, float* d_stats, const float* d_pos_table,
+                                  const int32_t* d_pos_idx, float* d_y_plus_pos, void* stream);
 int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c);
 int sst_add_layernorm_bwd_f32(const float* d_dy, const float* d_sum, const float* d_stats,
                               const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight,

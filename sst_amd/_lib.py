@@ -129,6 +129,8 @@ _SIGNATURES = {
     'sst_add_layernorm_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr,
                                           c_ptr]),
     'sst_add_layernorm_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
+    'sst_add_layernorm_pos_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                              c_ptr, c_ptr]),
     'sst_add_layernorm_act_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_i32, c_ptr, c_ptr, c_ptr,
                                               c_ptr]),
     'sst_add_layernorm_act_bwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr, c_ptr, c_ptr,

@@ -47,7 +47,10 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_k(const float* __restri
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            int64_t m, int c, float eps, int act,
                                                            float* __restrict__ y, float* __restrict__ sum_out,
-                                                           float2* __restrict__ stats) {
+                                                           float2* __restrict__ stats,
+                                                           const float* __restrict__ pos_table = nullptr,
+                                                           const int32_t* __restrict__ pos_idx = nullptr,
+                                                           float* __restrict__ y_plus_pos = nullptr) {
   const int lane = threadIdx.x & 31;
   const int sub = threadIdx.x >> 5;
   const int nvec = (c + 127) / 128;
@@ -96,6 +99,10 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_fwd_k(const float* __restri
         o.w = (v[k].w - mean) * rstd * wv.w + bv.w;
         if (act) o.x = ln_act(o.x, act), o.y = ln_act(o.y, act), o.z = ln_act(o.z, act), o.w = ln_act(o.w, act);
         *(float4*)(y + row * c + col) = o;
+        if (y_plus_pos != nullptr) {   // the next encoder layer's q / k input: y + positional embedding (row of a small table)
+          const float4 pv = *(const float4*)(pos_table + (size_t)pos_idx[row] * c + col);
+          *(float4*)(y_plus_pos + row * c + col) = make_float4(o.x + pv.x, o.y + pv.y, o.z + pv.z, o.w + pv.w);
+        }
       }
     }
     if (lane == 0) stats[row] = make_float2(mean, rstd);
@@ -722,6 +729,21 @@ int sst_add_layernorm_act_fwd_f32(const float* d_x, const float* d_res, const fl
   else
     hipLaunchKernelGGL(add_ln_fwd_any_k, dim3(grid), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res, d_weight,
                        d_bias, m, c, eps, act, d_y, d_sum, (float2*)d_stats);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_add_layernorm_pos_fwd_f32(const float* d_x, const float* d_res, const float* d_weight, const float* d_bias, int64_t m,
+                                  int c, float eps, float* d_y, float* d_sum, float* d_stats, const float* d_pos_table,
+                                  const int32_t* d_pos_idx, float* d_y_plus_pos, void* stream) {
+  if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_weight || !d_bias || !d_y || !d_stats || !d_pos_table || !d_pos_idx || !d_y_plus_pos) return SST_ERR_ARG;
+  if ((((uintptr_t)d_x | (uintptr_t)d_res | (uintptr_t)d_y | (uintptr_t)d_sum | (uintptr_t)d_weight | (uintptr_t)d_bias |
+        (uintptr_t)d_pos_table | (uintptr_t)d_y_plus_pos) & 15) != 0)
+    return SST_ERR_ARG;
+  hipLaunchKernelGGL(add_ln_fwd_k, dim3(sst_grid_1d(m, kLnRowsPerBlock)), dim3(kLnThreads), 0, (hipStream_t)stream, d_x, d_res,
+                     d_weight, d_bias, m, c, eps, 0, d_y, d_sum, (float2*)d_stats, d_pos_table, d_pos_idx, d_y_plus_pos);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

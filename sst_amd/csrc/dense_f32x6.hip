@@ -10,7 +10,7 @@
 // error of the v_mfma_f32_16x16x4_f32 kernel for every shape and through the 12-layer stack).
 //
 // for the projections and the FFN of an SRA encoder layer, forward and data gradient (sst_basic_block_v2.py:41-75, 104-126),
-// (K, N) in {(128,128), (128,256), (128,384), (256,128)}, fp32 operands in HBM, the epilogues of csrc/dense_f32.hip.
+// (K, N) in {(128,128), (128,256), (128,384), (256,128), (384,128)}, fp32 operands in HBM, the epilogues of csrc/dense_f32.hip.
 //
 // Why: six bf16 instructions per 16 x 16 x 32 block are 6 x 16 = 96 matrix-pipe cycles against 8 x 32 = 256 for the same block
 // on the fp32 pipe (MI355X_MICROARCH.md: 16x16x32 bf16 ~16 cycles, 16x16x4 f32 32 cycles per SIMD): the exact-fp32 kernels of
@@ -391,6 +391,12 @@ int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_
   } else if (k == 256 && n == 128) {
     if (d_x2 && (x2_from_col % 64)) return SST_ERR_ARG;
     rc = dispatch_x6<256, 64>(epilogue, d_x, d_x2, x2_from_col / 64, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in,
+                              d_aux_out, ldaux, st);
+  } else if (k == 384 && n == 128) {
+    // d(x) of the whole in-projection as ONE product: [dq | dk | dv] (M x 384) times in_proj_weight (384 x 128), the residual
+    // branch's gradient in the epilogue (three images of a 64-column group: 150.5 KB of LDS)
+    if (d_x2 && (x2_from_col % 64)) return SST_ERR_ARG;
+    rc = dispatch_x6<384, 64>(epilogue, d_x, d_x2, x2_from_col / 64, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in,
                               d_aux_out, ldaux, st);
   } else {
     return SST_ERR_UNSUPPORTED;

@@ -234,22 +234,32 @@ __global__ __launch_bounds__(512, 2) void wgrad_x6_k(const x6_group G, float* __
   }
 }
 
-// dW[problem][n][k] = sum over slices of the partial tiles (slice order: deterministic); one thread per 4 outputs
+// dW[problem][n][k] = sum over slices of the partial tiles, in float64 (one rounding at the end; slice order fixed:
+// deterministic).  Workgroup = 64 output quads (16 bytes each) x 4 slice groups: thread (quad, group) sums the slices group,
+// group + 4, ... with every load independent (the first version - one thread walking all slices of its quad, 64 workgroups in
+// all - took 26 us for 17 MB), the four groups meet in LDS.
 __global__ __launch_bounds__(256) void wgrad_x6_reduce_k(const x6_group G, const float* __restrict__ part,
                                                          const float* __restrict__ dbp) {
-  const int64_t quad = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over tiles x 128 x 32
+  __shared__ double red[4][64][4];
+  const int ql = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int64_t quad = (int64_t)blockIdx.x * 64 + ql;          // over tiles x 128 x 32
   const int64_t tile = quad / (kTile * kTile / 4);
+  const int e4 = (int)(quad - tile * (kTile * kTile / 4));
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
   if (tile < G.tiles) {
-    const int e4 = (int)(quad - tile * (kTile * kTile / 4));
     const float* src = part + tile * G.slices * (int64_t)(kTile * kTile) + 4 * e4;
-    // float64: the sum over the slices is then ONE rounding (a sequential fp32 sum of 64-128 partials was the largest error of
-    // the first version: 2.2 x the fp32-pipe kernel's against float64; the reduction is 5 % of the traffic, the adds are free)
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-    for (int q = 0; q < G.slices; ++q) {
+#pragma unroll 8
+    for (int q = sg; q < G.slices; q += 4) {
       const f32x4 v = *(const f32x4*)(src + (int64_t)q * (kTile * kTile));
       d0 += v[0], d1 += v[1], d2 += v[2], d3 += v[3];
     }
-    const f32x4 s = (f32x4){(float)d0, (float)d1, (float)d2, (float)d3};
+  }
+  red[sg][ql][0] = d0, red[sg][ql][1] = d1, red[sg][ql][2] = d2, red[sg][ql][3] = d3;
+  __syncthreads();
+  if (sg == 0 && tile < G.tiles) {
+    f32x4 s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = (float)(((red[0][ql][r] + red[1][ql][r]) + red[2][ql][r]) + red[3][ql][r]);
     int pi = 0;
 #pragma unroll
     for (int q = 1; q < kMaxProblems; ++q)
@@ -344,7 +354,7 @@ int sst_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, vo
   }
   hipLaunchKernelGGL(wgrad_x6_k, dim3((unsigned)(plan.g.tiles * plan.g.slices)), dim3(512), kLdsBytes, st, plan.g, part, dbp);
   const int64_t quads = (int64_t)plan.g.tiles * (kTile * kTile / 4);
-  hipLaunchKernelGGL(wgrad_x6_reduce_k, dim3((unsigned)sst_div_up(quads, (int64_t)256)), dim3(256), 0, st, plan.g, part, dbp);
+  hipLaunchKernelGGL(wgrad_x6_reduce_k, dim3((unsigned)sst_div_up(quads, (int64_t)64)), dim3(256), 0, st, plan.g, part, dbp);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

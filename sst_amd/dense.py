@@ -172,6 +172,13 @@ def lds_linear(x, w, bias=None, epilogue=EPI_BIAS, trans_w=False, aux_in=None, w
     return (y, pre) if want_pre else y
 
 
+def lds_linear_dqkv_ok(dqkv, w_in):
+    """d(x) of the whole in-projection as one product over K = 384 (f32x6 mode only: csrc/dense_f32x6.hip)"""
+    return (_MATMUL_MODE == 'f32x6' and w_in.shape == (384, 128) and w_in.is_contiguous() and dqkv.is_cuda
+            and dqkv.dtype == torch.float32 and dqkv.dim() == 2 and dqkv.size(1) == 384 and dqkv.is_contiguous()
+            and dqkv.data_ptr() % 16 == 0 and w_in.data_ptr() % 16 == 0)
+
+
 def lds_linear_qkv_ok(xp, x, w_in):
     """q | k | v as ONE launch: the f32x6 kernel's column groups may read different inputs (csrc/dense_f32x6.hip)"""
     return (_MATMUL_MODE == 'f32x6' and w_in.shape == (384, 128) and lds_linear_ok(xp, w_in[:256]) and lds_linear_ok(x, w_in[256:])
@@ -263,10 +270,11 @@ def tall_linear(x, weight, bias=None):
 _LN_ACTS = {None: 0, 'gelu': 1, 'relu': 2}
 
 
-def add_ln_fwd(x, res, weight, bias, eps, save_sum=True, act=None):
+def add_ln_fwd(x, res, weight, bias, eps, save_sum=True, act=None, pos=None):
     """-> (y, s, stats) with s = x + res (== x when res is None), stats [M,2] = (mean, rstd).
     save_sum=False (inference): the sum is not written (s is None), a quarter of the kernel's traffic.
-    act: None | 'gelu' | 'relu' applied to the norm's output in the same pass."""
+    act: None | 'gelu' | 'relu' applied to the norm's output in the same pass.
+    pos = (table [P, C], row index int32 [M]): -> (y, s, stats, y + table[index]) from the same pass (act None, C % 4 == 0)."""
     x = x.contiguous()
     m, c = x.shape
     if res is not None:
@@ -274,6 +282,15 @@ def add_ln_fwd(x, res, weight, bias, eps, save_sum=True, act=None):
     y = torch.empty_like(x)
     s = (torch.empty_like(x) if save_sum else None) if res is not None else x
     stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
+    if pos is not None:
+        assert act is None
+        yp = torch.empty_like(x)
+        rc = _lib.load().sst_add_layernorm_pos_fwd_f32(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), m, c, float(eps),
+                                                       _lib.ptr(y), _lib.ptr(s) if (res is not None and save_sum) else None,
+                                                       _lib.ptr(stats), _lib.ptr(pos[0]), _lib.ptr(pos[1]), _lib.ptr(yp),
+                                                       _lib.stream_ptr())
+        _lib.check(rc, 'sst_add_layernorm_pos_fwd_f32')
+        return y, s, stats, yp
     rc = _lib.load().sst_add_layernorm_act_fwd_f32(_lib.ptr(x), _lib.ptr(res), _lib.ptr(weight), _lib.ptr(bias), m, c,
                                                    float(eps), _LN_ACTS[act], _lib.ptr(y),
                                                    _lib.ptr(s) if (res is not None and save_sum) else None,
@@ -331,11 +348,15 @@ def lds_linear_add_ln(x, w, bias, res, ln_weight, ln_bias, eps, save_sum=True, p
     stats = torch.empty((m, 2), dtype=torch.float32, device=x.device)
     yp = torch.empty((m, 128), dtype=torch.float32, device=x.device) if pos is not None else None
     lib = _lib.load()
-    # f32x6 at K = 256: three bf16 images of a 128-column group (203 KB) exceed the LDS, and a LayerNorm epilogue needs the whole
-    # row in one workgroup: that one product stays on the fp32 matrix pipe (same arithmetic class; 68 us either way - the split
-    # kernel over 64-column groups + a LayerNorm pass measured 48 + 20 us)
-    mode = 'f32' if (_MATMUL_MODE == 'f32x6' and k != 128) else _MATMUL_MODE
-    entry = getattr(lib, 'sst_tall_linear_ln_' + mode)
+    if _MATMUL_MODE == 'f32x6' and k != 128:
+        # three bf16 images of a 128-column group at K = 256 (203 KB) exceed the LDS and a LayerNorm epilogue needs the whole row
+        # in one workgroup: the product runs over 64-column groups with the residual in its epilogue (53 us in the step), the
+        # LayerNorm (+ the next layer's positional input) as one pass over the sum (~20 us) - against 95 us for the fused
+        # kernel on the fp32 matrix pipe
+        s = lds_linear(x, w, bias, EPI_ADD, aux_in=res)
+        out = add_ln_fwd(s, None, ln_weight, ln_bias, eps, pos=pos)
+        return out[0], s, out[2], (out[3] if pos is not None else None)
+    entry = getattr(lib, 'sst_tall_linear_ln_' + _MATMUL_MODE)
     rc = entry(
         _lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(bias), m, k, _lib.ptr(res), 128, _lib.ptr(ln_weight),
         _lib.ptr(ln_bias), float(eps), _lib.ptr(y), _lib.ptr(s), _lib.ptr(stats),

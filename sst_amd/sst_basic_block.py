@@ -20,7 +20,8 @@ from torch.utils.checkpoint import checkpoint
 from . import kernels as K
 from .sra_composed import sra_attention_composed
 from .dense import (EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
-                    lds_linear_add_ln, lds_linear_add_ln_ok, lds_linear_qkv, lds_linear_qkv_ok, weight_bias_grad_group,
+                    lds_linear_add_ln, lds_linear_add_ln_ok, lds_linear_dqkv_ok, lds_linear_qkv, lds_linear_qkv_ok,
+                    weight_bias_grad_group,
                     tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
                     weight_bias_grad)
 from .norm import build_norm_layer
@@ -201,6 +202,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         ignored; pos_next = (table, row index): also return y + table[index], the next layer's xp."""
         c = x.size(1)
         x = x.contiguous()
+        ctx.set_materialize_grads(False)     # an output nobody differentiates (y2p when its gradient was folded into y2's) stays None
         ctx.split_input = xp is not None
         if xp is None:
             xp = x + pos if pos is not None else x
@@ -249,6 +251,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
     def backward(ctx, dy2, dy2p=None):
         x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
         c = x.size(1)
+        if dy2 is None:           # only the second output was differentiated
+            dy2, dy2p = dy2p, None
         ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
         ds2_for_w2 = ds2
         dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
@@ -281,7 +285,12 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         # second group (3 problems), before ds1 is accumulated into in place
         weight_bias_grad_group([(ds1, o, dwo, dbo), (dqk, xp, dw_in[:2 * c], db_in[:2 * c]), (dv, x, dw_in[2 * c:], db_in[2 * c:])])
         dxp = None
-        if ctx.split_input:      # x and xp are separate inputs: their gradients leave separately
+        if _LDS_LINEAR and c == 128 and lds_linear_dqkv_ok(dqkv, w_in):
+            # xp = x + pos with a constant pos: d(x) += d(xp), so the residual branch and all three projections leave as ONE
+            # product over K = 384 with the residual in the epilogue; the gradient of xp is folded in (None): the producer's
+            # LayerNorm backward then reads one upstream gradient instead of two
+            dx = lds_linear(dqkv, w_in, None, EPI_ADD, trans_w=True, aux_in=ds1, out=ds1)
+        elif ctx.split_input:      # x and xp are separate inputs: their gradients leave separately
             dxp = _linear_dgrad(dqk, w_in[:2 * c])
             dx = _linear_dgrad(dv, w_in[2 * c:], out=ds1)
         elif _LDS_LINEAR and lds_linear_ok(dqk, w_in[:2 * c], trans_w=True) and lds_linear_ok(dv, w_in[2 * c:], trans_w=True):

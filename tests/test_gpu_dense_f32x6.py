@@ -251,3 +251,27 @@ def test_weight_gradients_small_and_unsupported_shapes_fall_back():
     (wn, bn), (ws, bs) = _both(D, run)
     assert torch.equal(wn, ws) and torch.equal(bn, bs)
     assert float((wn.double() - dy.double().t() @ x.double()).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize('m', [77, 20000, 90107])
+def test_in_projection_data_gradient_as_one_product(m):
+    """d(x) = ds1 + [dq | dk | dv] in_proj_weight over K = 384 in one launch (residual in the epilogue): against float64 and
+    beside the two fp32-pipe products it replaces"""
+    from sst_amd import dense as D
+    g = torch.Generator().manual_seed(m)
+    dqkv = torch.randn(m, 384, generator=g).to(DEV)
+    w = (torch.randn(384, 128, generator=g) * 0.2).to(DEV)
+    ds1 = torch.randn(m, 128, generator=g).to(DEV)
+    want = ds1.double() + dqkv.double() @ w.double()
+    D.set_matmul_mode('f32x6')
+    try:
+        assert D.lds_linear_dqkv_ok(dqkv, w)
+        out = ds1.clone()
+        got = D.lds_linear(dqkv, w, None, D.EPI_ADD, trans_w=True, aux_in=out, out=out)
+    finally:
+        D.set_matmul_mode('f32')
+    assert not D.lds_linear_dqkv_ok(dqkv, w)
+    nat = ds1.clone()
+    D.lds_linear(dqkv[:, :256].contiguous(), w[:256], None, D.EPI_ADD, trans_w=True, aux_in=nat, out=nat)
+    D.lds_linear(dqkv[:, 256:].contiguous(), w[256:], None, D.EPI_ADD, trans_w=True, aux_in=nat, out=nat)
+    _admissible(nat, got, want, 'K = 384 data gradient')
