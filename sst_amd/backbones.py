@@ -175,12 +175,15 @@ class _WindowTransformer(nn.Module):
             if all(bf16.layer_supported(enc, plans[i % 2], x.size(0)) for i, enc in enumerate(layers)):
                 return bf16.run_encoder_stack(self.block_list, x, plans, pos_lookup)
         if (self.precision == 'fp32' and pos_lookup is not None and x.is_cuda and x.dtype == torch.float32
-                and not self.checkpoint_blocks and x.size(1) == 128):
-            # fp32 chain: every layer hands (x, x + positional embedding) to the next one (sst_basic_block.py)
+                and x.size(1) == 128):
+            # fp32 chain: every layer hands (x, x + positional embedding) to the next one (sst_basic_block.py); blocks listed
+            # in checkpoint_blocks (sst_v2.py:131-133, torch.utils.checkpoint per block when training) are recomputed INSIDE
+            # the chain instead of sending all layers to the per-layer path
             from .sst_basic_block import run_encoder_stack_fp32
             layers = [enc for block in self.block_list for enc in block.encoder_list]
             if all(enc._can_fuse(x, None, plans[i % 2]) for i, enc in enumerate(layers)):
-                return run_encoder_stack_fp32(self.block_list, x, plans, pos_lookup)
+                ckpt = self.checkpoint_blocks if self.training else ()
+                return run_encoder_stack_fp32(self.block_list, x, plans, pos_lookup, checkpoint_blocks=ckpt)
         if pos_lookup is not None and any(p is None for p in pos):
             # the caller skipped the [M, C] positional tensors (frame plan with want_pos_rows = False): form them here
             pos = [t.index_select(0, idx.long()) for t, idx in pos_lookup]

@@ -174,21 +174,21 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_k(const float* __restri
       }
     }
   }
+  // the row groups of the block add their column sums one after the other (a float atomicAdd into LDS made the order - and
+  // the last bits of d(gamma), d(beta) - depend on the schedule)
+  for (int turn = 0; turn < kLnRowsPerBlock; ++turn) {
+    if (sub == turn) {
 #pragma unroll
-  for (int k = 0; k < kLnMaxVec; ++k) {
-    const int col = k * 128 + lane * 4;
-    if (k < nvec && col < c) {
-      atomicAdd(&part[col + 0], aw[k].x);
-      atomicAdd(&part[col + 1], aw[k].y);
-      atomicAdd(&part[col + 2], aw[k].z);
-      atomicAdd(&part[col + 3], aw[k].w);
-      atomicAdd(&part[c + col + 0], ab[k].x);
-      atomicAdd(&part[c + col + 1], ab[k].y);
-      atomicAdd(&part[c + col + 2], ab[k].z);
-      atomicAdd(&part[c + col + 3], ab[k].w);
+      for (int k = 0; k < kLnMaxVec; ++k) {
+        const int col = k * 128 + lane * 4;
+        if (k < nvec && col < c) {
+          part[col + 0] += aw[k].x, part[col + 1] += aw[k].y, part[col + 2] += aw[k].z, part[col + 3] += aw[k].w;
+          part[c + col + 0] += ab[k].x, part[c + col + 1] += ab[k].y, part[c + col + 2] += ab[k].z, part[c + col + 3] += ab[k].w;
+        }
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   // block partials [gridDim.x][2c]; reduced by colsum_partials_k (no global atomics, deterministic)
   float* dst = partials + (int64_t)blockIdx.x * 2 * c;
   for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
@@ -271,15 +271,16 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_any_k(const float* __re
       if (col < c) dx[row * c + col] = st.y * (g[k] - mg - xh[k] * mgx);
     }
   }
+  for (int turn = 0; turn < kLnRowsPerBlock; ++turn) {   // row groups in a fixed order: deterministic to the last bit
+    if (sub == turn) {
 #pragma unroll
-  for (int k = 0; k < kLnMaxScalar; ++k) {
-    const int col = k * 32 + lane;
-    if (col < c) {
-      atomicAdd(&part[col], aw[k]);       // LDS: the 8 row groups of the block (order-dependent only in the last bit)
-      atomicAdd(&part[c + col], ab[k]);
+      for (int k = 0; k < kLnMaxScalar; ++k) {
+        const int col = k * 32 + lane;
+        if (col < c) part[col] += aw[k], part[c + col] += ab[k];
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* dst = partials + (int64_t)blockIdx.x * 2 * c;
   for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
 }
@@ -356,15 +357,13 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_c128_k(const float* __r
       }
     }
   }
-  atomicAdd(&part[col + 0], aw.x);
-  atomicAdd(&part[col + 1], aw.y);
-  atomicAdd(&part[col + 2], aw.z);
-  atomicAdd(&part[col + 3], aw.w);
-  atomicAdd(&part[C + col + 0], ab.x);
-  atomicAdd(&part[C + col + 1], ab.y);
-  atomicAdd(&part[C + col + 2], ab.z);
-  atomicAdd(&part[C + col + 3], ab.w);
-  __syncthreads();
+  for (int turn = 0; turn < kLnRowsPerBlock; ++turn) {   // row groups in a fixed order: deterministic to the last bit
+    if (sub == turn) {
+      part[col + 0] += aw.x, part[col + 1] += aw.y, part[col + 2] += aw.z, part[col + 3] += aw.w;
+      part[C + col + 0] += ab.x, part[C + col + 1] += ab.y, part[C + col + 2] += ab.z, part[C + col + 3] += ab.w;
+    }
+    __syncthreads();
+  }
   float* dst = partials + (int64_t)blockIdx.x * 2 * C;
   for (int i = threadIdx.x; i < 2 * C; i += kLnThreads) dst[i] = part[i];
 }
@@ -395,9 +394,7 @@ __global__ __launch_bounds__(1024) void colsum_partials_k(const float* __restric
 // out[col] += sum over rows of x[row, col]; out must be zero on entry.  c % 4 == 0, c <= 1024.
 __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int64_t m, int c, int64_t ld,
                                                 int64_t rows_per_block, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float part[];  // [c]
-  for (int i = threadIdx.x; i < c; i += 256) part[i] = 0.f;
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) float slots[1024];   // [rows per iteration][c]: (256 / c4) * c <= 1024
   const int c4 = c >> 2;
   const int rpi = 256 / c4 > 0 ? 256 / c4 : 1;  // rows per iteration
   const int ry = threadIdx.x / c4, cx = threadIdx.x - ry * c4;
@@ -414,14 +411,16 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int
         acc.w += v.w;
       }
     }
-    atomicAdd(&part[cx * 4 + 0], acc.x);
-    atomicAdd(&part[cx * 4 + 1], acc.y);
-    atomicAdd(&part[cx * 4 + 2], acc.z);
-    atomicAdd(&part[cx * 4 + 3], acc.w);
+    *(float4*)(slots + ry * c + cx * 4) = acc;
   }
   __syncthreads();
-  float* dst = out + (int64_t)blockIdx.x * c;  // block partials, reduced by colsum_partials2d_k
-  for (int i = threadIdx.x; i < c; i += 256) dst[i] = part[i];
+  float* dst = out + (int64_t)blockIdx.x * c;  // block partials, reduced by colsum_partials_k; row groups summed in order
+  const int used = rpi < 256 / c4 ? rpi : 256 / c4;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < used; ++r) t += slots[r * c + i];
+    dst[i] = t;
+  }
 }
 
 // out[i] += sum over a 64-row slice of partials[nb][width]; grid = (ceil(width/32), ceil(nb/64)); out zeroed before
@@ -578,21 +577,21 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_bf16_k(const unsigned s
       }
     }
   }
+  // the row groups of the block add their column sums one after the other (a float atomicAdd into LDS made the order - and
+  // the last bits of d(gamma), d(beta) - depend on the schedule)
+  for (int turn = 0; turn < kLnRowsPerBlock; ++turn) {
+    if (sub == turn) {
 #pragma unroll
-  for (int k = 0; k < kLnMaxVec; ++k) {
-    const int col = k * 128 + lane * 4;
-    if (k < nvec && col < c) {
-      atomicAdd(&part[col + 0], aw[k].x);
-      atomicAdd(&part[col + 1], aw[k].y);
-      atomicAdd(&part[col + 2], aw[k].z);
-      atomicAdd(&part[col + 3], aw[k].w);
-      atomicAdd(&part[c + col + 0], ab[k].x);
-      atomicAdd(&part[c + col + 1], ab[k].y);
-      atomicAdd(&part[c + col + 2], ab[k].z);
-      atomicAdd(&part[c + col + 3], ab[k].w);
+      for (int k = 0; k < kLnMaxVec; ++k) {
+        const int col = k * 128 + lane * 4;
+        if (k < nvec && col < c) {
+          part[col + 0] += aw[k].x, part[col + 1] += aw[k].y, part[col + 2] += aw[k].z, part[col + 3] += aw[k].w;
+          part[c + col + 0] += ab[k].x, part[c + col + 1] += ab[k].y, part[c + col + 2] += ab[k].z, part[c + col + 3] += ab[k].w;
+        }
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* dst = partials + (int64_t)blockIdx.x * 2 * c;
   for (int i = threadIdx.x; i < 2 * c; i += kLnThreads) dst[i] = part[i];
 }
@@ -673,15 +672,13 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_bwd_bf16_c128_k(const unsig
       }
     }
   }
-  atomicAdd(&part[col + 0], aw.x);
-  atomicAdd(&part[col + 1], aw.y);
-  atomicAdd(&part[col + 2], aw.z);
-  atomicAdd(&part[col + 3], aw.w);
-  atomicAdd(&part[C + col + 0], ab.x);
-  atomicAdd(&part[C + col + 1], ab.y);
-  atomicAdd(&part[C + col + 2], ab.z);
-  atomicAdd(&part[C + col + 3], ab.w);
-  __syncthreads();
+  for (int turn = 0; turn < kLnRowsPerBlock; ++turn) {   // row groups in a fixed order: deterministic to the last bit
+    if (sub == turn) {
+      part[col + 0] += aw.x, part[col + 1] += aw.y, part[col + 2] += aw.z, part[col + 3] += aw.w;
+      part[C + col + 0] += ab.x, part[C + col + 1] += ab.y, part[C + col + 2] += ab.z, part[C + col + 3] += ab.w;
+    }
+    __syncthreads();
+  }
   float* dst = partials + (int64_t)blockIdx.x * 2 * C;
   for (int i = threadIdx.x; i < 2 * C; i += kLnThreads) dst[i] = part[i];
 }
@@ -895,10 +892,10 @@ int sst_colsum_f32(const float* d_x, int64_t m, int c, int64_t ld, float* d_out,
     grid = sst_div_up(m, rows_per_block);
   }
   float* partials = (float*)d_workspace;
-  hipLaunchKernelGGL(colsum_k, dim3((unsigned)grid), dim3(256), c * sizeof(float), st, d_x, m, c, ld, rows_per_block,
-                     partials);
-  hipLaunchKernelGGL(colsum_partials2d_k, dim3((c + 31) / 32, (unsigned)((grid + 63) / 64)), dim3(256), 0, st, partials,
-                     (int)grid, c, d_out);
+  hipLaunchKernelGGL(colsum_k, dim3((unsigned)grid), dim3(256), 0, st, d_x, m, c, ld, rows_per_block, partials);
+  // one block per 32 columns walks ALL block partials in a fixed order (the 2-D variant added its 64-row slices into the
+  // output with float atomics: bias gradients differed in the last bits from launch to launch)
+  hipLaunchKernelGGL(colsum_partials_k, dim3((c + 31) / 32), dim3(1024), 0, st, partials, (int)grid, c, d_out, d_out, c);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -301,22 +301,39 @@ class FusedEncoderLayerFn(torch.autograd.Function):
                 None, dxp, None)
 
 
-def run_encoder_stack_fp32(blocks, feats, plans, pos_specs):
+def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()):
     """All encoder layers of the shift blocks as a chain of FusedEncoderLayerFn nodes that hand (x, x + positional embedding)
     to each other: "+ positional embedding" of layer i + 1 is the second output of layer i's last kernel, so no add pass and
-    no [M, C] positional tensor exist after the first layer.  pos_specs: per partition (table fp32 [P, C], row index int32)."""
-    layers = [enc for block in blocks for enc in block.encoder_list]
-    x = feats.contiguous()
-    xp = x + pos_specs[0][0].index_select(0, pos_specs[0][1].long())
-    for li, enc in enumerate(layers):
+    no [M, C] positional tensor exist after the first layer.  pos_specs: per partition (table fp32 [P, C], row index int32).
+    checkpoint_blocks: indices of the shift blocks whose two layers keep no activations and are recomputed in the backward pass
+    (the reference's torch.utils.checkpoint per block, sst_v2.py:131-133 / sst_basic_block_v2.py:164-165)."""
+    n_layers = 2 * len(blocks)
+
+    def layer(enc, li, x, xp):
         attn = enc.win_attn.self_attn
-        pos_next = pos_specs[(li + 1) % 2] if li + 1 < len(layers) else None
+        pos_next = pos_specs[(li + 1) % 2] if li + 1 < n_layers else None
         out = FusedEncoderLayerFn.apply(
             x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
             attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
             enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
             enc.norm1.eps, xp, pos_next)
-        x, xp = out if pos_next is not None else (out, None)
+        return out if pos_next is not None else (out, None)
+
+    def block_fn(bi):
+        def run(x, xp):
+            for j, enc in enumerate(blocks[bi].encoder_list):
+                x, xp = layer(enc, 2 * bi + j, x, xp)
+            return (x, xp) if xp is not None else (x,)
+        return run
+
+    x = feats.contiguous()
+    xp = x + pos_specs[0][0].index_select(0, pos_specs[0][1].long())
+    for bi in range(len(blocks)):
+        if bi in checkpoint_blocks and torch.is_grad_enabled():
+            out = checkpoint(block_fn(bi), x, xp, use_reentrant=False)
+        else:
+            out = block_fn(bi)(x, xp)
+        x, xp = (out[0], out[1]) if len(out) > 1 else (out[0], None)
     return x
 
 

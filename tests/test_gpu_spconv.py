@@ -333,3 +333,35 @@ def test_grid_rulebook_ignores_rows_outside_the_grid(subm):
             assert torch.equal(remap[pairs_a[k, 1, :c].long()], pairs_b[k, 1, :c].long())
         else:
             assert torch.equal(pairs_a[k, 1, :c], pairs_b[k, 1, :c])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,cout', [(64, 64), (128, 128)])
+def test_sparse_filter_gradient_bit_reproducible(cin, cout):
+    """the 300-launch loop over the second cross-workgroup hand-over of the library - the chunk partials of the
+    output-stationary filter gradient and their reduction (sp_wgrad_os_k / sp_wgrad_os_reduce_k, csrc/spconv_os.hip) - on a
+    LiDAR-like voxel set large enough for several chunks per offset: forward, data gradient and filter gradient, same bits"""
+    from sst_amd import spconv
+    rng = np.random.RandomState(7)
+    shape, batch = [16, 200, 200], 2
+    cells = rng.choice(batch * 16 * 200 * 200, 60000, replace=False)
+    cells.sort()
+    ind = np.stack([cells // (16 * 200 * 200), cells // 40000 % 16, cells // 200 % 200, cells % 200], 1).astype(np.int32)
+    # concentrate the voxels near the ground (z < 4) so that the submanifold rulebook has populated offsets
+    ind[:, 1] = ind[:, 1] % 4
+    ind = np.unique(ind, axis=0)
+    outids, pairs, num = spconv.get_indice_pairs(torch.from_numpy(ind).to(DEV), batch, shape, 3, subm=True)
+    gen = torch.Generator().manual_seed(cin)
+    x = torch.randn(len(ind), cin, generator=gen).to(DEV)
+    w = (torch.randn(3, 3, 3, cin, cout, generator=gen) * 0.2).to(DEV)
+    gy = torch.randn(len(ind), cout, generator=gen).to(DEV)
+    ref = None
+    for _ in range(300):
+        xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = spconv.indice_subm_conv(xa, wa, pairs, num, len(ind))
+        y.backward(gy)
+        cur = (y.detach(), xa.grad, wa.grad)
+        if ref is None:
+            ref = tuple(t.clone() for t in cur)
+            assert int(num.sum()) > 200000        # several 2048-pair chunks per offset
+        assert all(torch.equal(a, b) for a, b in zip(ref, cur))

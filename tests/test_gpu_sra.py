@@ -356,3 +356,42 @@ def test_encoder_layer_attention_dropout_and_head_dim_32():
     y = wide(xb, pos, plan)
     y.square().sum().backward()
     assert y.shape == x.shape and torch.isfinite(xb.grad).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['fp32', 'f32x6'])
+def test_checkpoint_blocks_recompute_inside_the_fused_chain(mode, monkeypatch):
+    """configs with checkpoint_blocks (sst_v2.py:131-133: torch.utils.checkpoint per shift block when training) stay on the
+    chain of fused layer nodes - the listed blocks are recomputed in the backward pass - instead of falling back to the
+    per-layer path: same outputs and gradients as without checkpointing, bit for bit (deterministic kernels)"""
+    import sst_amd
+    from conftest import DROP_TEST, DROP_TRAIN
+    from sst_amd import sst_basic_block as SB
+    g = torch.Generator().manual_seed(4)
+    side = 60
+    cells = torch.randperm(2 * side * side, generator=g)[:2500].sort()[0]
+    coors = torch.stack([cells // (side * side), torch.zeros_like(cells), cells // side % side + 50, cells % side + 50], 1).to(DEV)
+    feats0 = torch.randn(2500, 128, generator=g).to(DEV)
+    up = torch.randn(2500, 128, generator=g).to(DEV)
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False, debug=False,
+                                    mute=True, reference_outputs=False).eval()
+    results = {}
+    for ckpt in ([], [0, 2]):
+        torch.manual_seed(9)
+        net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128] * 3, nhead=[8] * 3, num_blocks=3, dim_feedforward=[256] * 3,
+                                          output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=False,
+                                          checkpoint_blocks=ckpt)).to(DEV).train()
+        net.set_precision(mode)
+        try:
+            if ckpt:   # the per-layer path must not be taken
+                monkeypatch.setattr(SB.BasicShiftBlockV2, 'forward', lambda *a, **k: (_ for _ in ()).throw(AssertionError('per-layer path')))
+            feats = feats0.clone().requires_grad_(True)
+            out = net(layer(feats, coors, 2))[0]['voxel_feats']
+            (out * up[:out.size(0)]).sum().backward()
+        finally:
+            net.set_precision('fp32')
+        results[bool(ckpt)] = (out.detach().clone(), feats.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()})
+    (o0, g0, p0), (o1, g1, p1) = results[False], results[True]
+    assert torch.equal(o0, o1) and torch.equal(g0, g1)
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
