@@ -262,7 +262,15 @@ def check(rc, what):
         raise SSTError(f'{what} failed: {msg}')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr():
+    """torch's current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() builds a Python Stream
+    object per call (~9 us: 0.8 ms per fp32 step, 2.6 ms per bf16 step of pure launch-path overhead - the reduced-precision leg
+    was host-bound on slower hosts); the raw accessor answers in ~0.3 us."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
