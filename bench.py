@@ -409,9 +409,11 @@ def main():
     ap.add_argument('--no-time-sra-bwd', action='store_true', help='do not attach events to the SRA backward launches')
     ap.add_argument('--no-forward-only-leg', action='store_true', help='skip the extra forward-only measurement')
     ap.add_argument('--no-f32x3-leg', action='store_true', help='skip the split-precision (bf16 x 3) leg beside the headline')
-    ap.add_argument('--conv-precision', choices=['f32', 'f32x3'], default='f32',
-                    help='--workload fsd | fsdv2: run the TIMED steps with the sparse convolutions in split precision (for profiles '
-                         'of that mode; the line then says so in dtype and is not the headline)')
+    ap.add_argument('--conv-precision', choices=['f32', 'f32x6', 'f32x3'], default='f32x6',
+                    help="--workload fsd | fsdv2: how the sparse convolutions (forward + data gradient) multiply in the TIMED steps: "
+                         "'f32x6' (default) = exact three-way bf16 split, six products (csrc/spconv_os_x6.hip; admissible as exact fp32: "
+                         "tests/test_gpu_spconv.py), 'f32' = the fp32 matrix pipe, 'f32x3' = the two-way split (a leg, never the "
+                         "headline: the line then says so in dtype)")
     ap.add_argument('--no-traffic-remeasure', action='store_true',
                     help='take roofline.traffic from profiles/latest_sra_traffic.json instead of two rocprofv3 --pmc passes now')
     ap.add_argument('--no-lidar-leg', action='store_true', help='skip the LiDAR-like / pathological frame beside the headline')

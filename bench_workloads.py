@@ -514,24 +514,32 @@ def cpu_chain_leg(spec, model, clouds):
     return base, parity
 
 
-def _f32x3_leg(model, clouds, step, sync, args, world, dev):
-    """the same step with the sparse convolutions (forward contraction and data gradient) in split precision: three bf16
-    products of split fp32 operands, fp32 accumulation, fp32 in memory (csrc/spconv_os_x3.hip); reported BESIDE the exact-fp32
-    headline, with the forward deviation from it on the same frame"""
+_CONV_MODE_WHAT = {
+    'f32x3': 'same step, sparse convolutions (forward + data gradient) as three bf16 MFMA products of two-way split fp32 operands '
+             'with fp32 accumulation (csrc/spconv_os_x3.hip; NOT exact: ~1e-5 of the output scale per layer - a leg, never `value`); '
+             'filter gradients, everything else and all tensors fp32',
+    'f32': 'same step with the sparse convolutions on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, csrc/spconv_os.hip) - the '
+           'arithmetic of rounds 1-3; the timed mode evaluates the same products from the exact three-way bf16 split',
+    'f32x6': 'same step, sparse convolutions from the exact three-way bf16 split (csrc/spconv_os_x6.hip)'}
+
+
+def _conv_precision_leg(mode, timed_mode, model, clouds, step, sync, args, world, dev):
+    """the same step with the sparse convolutions (forward contraction and data gradient) in another multiply mode, reported
+    BESIDE `value`, with the forward deviation from the timed mode on the same frame"""
     from sst_amd import spconv
     with torch.no_grad():                               # training mode as in the step: batch statistics in both passes
         _, _, ref = model(clouds, return_tensors=True)
-        spconv.set_conv_precision('f32x3')
+        spconv.set_conv_precision(mode)
         try:
             _, _, got = model(clouds, return_tensors=True)
         finally:
-            spconv.set_conv_precision('f32')
+            spconv.set_conv_precision(timed_mode)
     errs = {}
     for key in ('unet_feats', 'seg_feats', 'cluster_feats', 'virtual_feats'):
         if key in ref and key in got and ref[key].shape == got[key].shape and ref[key].is_floating_point():
             scale = max(1.0, float(ref[key].abs().max()))
             errs[key] = round(float((ref[key] - got[key]).abs().max()) / scale, 8)
-    spconv.set_conv_precision('f32x3')
+    spconv.set_conv_precision(mode)
     try:
         for _ in range(2):
             step()
@@ -542,16 +550,14 @@ def _f32x3_leg(model, clouds, step, sync, args, world, dev):
         sync()
         elapsed = time.perf_counter() - t0
     finally:
-        spconv.set_conv_precision('f32')
+        spconv.set_conv_precision(timed_mode)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return {'value': round(world * args.frames_per_gpu * args.steps / elapsed, 3), 'unit': 'frames/s',
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'steps': args.steps,
-            'what': 'same step, sparse convolutions (forward + data gradient) as three bf16 MFMA products of split fp32 operands '
-                    'with fp32 accumulation; filter gradients, everything else and all tensors exact fp32',
-            'max_err_vs_exact_fp32_forward_rel_to_output_scale': errs}
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'steps': args.steps, 'what': _CONV_MODE_WHAT[mode],
+            'max_err_vs_timed_mode_forward_rel_to_output_scale': errs}
 
 
 def run(args, rank, world, dev, make_reducer):
@@ -571,10 +577,10 @@ def run(args, rank, world, dev, make_reducer):
         tunable.enable(True)
         tunable.tuning_enable(True)
         tunable.set_filename(work_file)
-    conv_prec = getattr(args, 'conv_precision', 'f32')
-    if conv_prec != 'f32':
-        from sst_amd import spconv
-        spconv.set_conv_precision(conv_prec)
+    conv_prec = getattr(args, 'conv_precision', 'f32x6')
+    from sst_amd import spconv
+    spconv.set_conv_precision(conv_prec)
+    if conv_prec == 'f32x3':               # profiling the two-way split: not a headline, no parity legs
         args.no_f32x3_leg = args.no_cpu_baseline = True
     torch.manual_seed(0)
     model = spec['cls']().to(dev).train()
@@ -612,9 +618,11 @@ def run(args, rank, world, dev, make_reducer):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     conv, seg = _conv_roofline(model, clouds)
-    x3 = None
+    x3 = mfma_leg = None
     if not getattr(args, 'no_f32x3_leg', False):
-        x3 = _f32x3_leg(model, clouds, step, sync, args, world, dev)
+        x3 = _conv_precision_leg('f32x3', conv_prec, model, clouds, step, sync, args, world, dev)
+        if conv_prec == 'f32x6':
+            mfma_leg = _conv_precision_leg('f32', conv_prec, model, clouds, step, sync, args, world, dev)
     cpu_base = parity = None
     if rank == 0 and world == 1 and not getattr(args, 'no_cpu_baseline', False):
         cpu_base, parity = cpu_chain_leg(spec, model, clouds)
@@ -623,7 +631,12 @@ def run(args, rank, world, dev, make_reducer):
         res = {'metric': spec['metric'], 'value': round(frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if conv_prec == 'f32' else 'f32 storage, sparse convolutions as 3 bf16 products (NOT the headline mode)',
+               'dtype': {'f32': 'f32',
+                         'f32x6': 'f32 (storage, accumulation, norms, reductions, filter gradients: fp32; the sparse convolutions\' '
+                                  'forward and data-gradient products from the EXACT three-way bf16 split of both fp32 operands, six '
+                                  'bf16 MFMA products with fp32 accumulation - error vs float64 <= 2 x the fp32 matrix pipe\'s: '
+                                  'tests/test_gpu_spconv.py::test_exact_split_convolution_kernel)',
+                         'f32x3': 'f32 storage, sparse convolutions as 3 bf16 products (NOT the headline mode)'}[conv_prec],
                'data': 'synthetic',
                'config': {'workload': spec['name'] + f'; {n_pts} points/frame (ground plane + boxes), fwd+bwd',
                           'frames_per_gpu': args.frames_per_gpu, 'points_per_frame': n_pts, 'parallelism': f'dp{world}',
@@ -634,4 +647,6 @@ def run(args, rank, world, dev, make_reducer):
                'parity': parity}
         if x3 is not None:
             res['precision_f32x3'] = x3
+        if mfma_leg is not None:
+            res['precision_f32_mfma'] = mfma_leg
         print(json.dumps(res))

@@ -764,6 +764,14 @@ int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, 
 int sst_spconv_conv_os_f32x3(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
                              int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
                              const int32_t* d_tile_order, void* d_workspace, void* stream);
+/*   sst_spconv_conv_os_f32x6: the same contraction from the EXACT three-way bf16 split of both operands, six products per
+ *     fp32 product on v_mfma_f32_16x16x32_bf16 with fp32 accumulation in two accumulator sets (csrc/spconv_os_x6.hip; the
+ *     arithmetic class of the fp32 kernel: error vs float64 <= 2 x its error, tests/test_gpu_spconv.py).  Same arguments and
+ *     launch order; workspace: sst_spconv_conv_os_f32x6_workspace_bytes (6 bytes per packed weight element); tile_cfg = 0. */
+int64_t sst_spconv_conv_os_f32x6_workspace_bytes(int kvol, int cin, int cout);
+int sst_spconv_conv_os_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
+                             int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
+                             const int32_t* d_tile_order, void* d_workspace, void* stream);
 /*   sst_spconv_wgrad_os_f32: the same filter gradient as sst_spconv_wgrad_f32 (indiceConvBackward, spconv_ops.h:359-446)
  *     with the gathered rows staged through LDS transposed, 64 x 64 blocks of dW[k], 2048-pair chunks (csrc/spconv_os.hip).
  *     cin % 4 == 0, cout % 4 == 0, row strides % 4 == 0, 16-byte aligned operands; SST_ERR_UNSUPPORTED otherwise. */

@@ -305,11 +305,15 @@ _CONV_PRECISION = 'f32'
 
 
 def set_conv_precision(mode):
-    """'f32' (default: exact fp32 products, the parity mode) or 'f32x3': the forward contraction and the data gradient of
-    every sparse convolution as three bf16 products of split fp32 operands with fp32 accumulation
-    (csrc/spconv_os_x3.hip; ~1e-5 of the output scale per layer).  Filter gradients stay exact fp32."""
+    """How the forward contraction and the data gradient of every sparse convolution multiply (filter gradients stay on the
+    fp32 matrix pipe: they are gather-bound):
+      'f32'    fp32 matrix pipe (csrc/spconv_os.hip);
+      'f32x6'  exact three-way bf16 split of both operands, six products, fp32 accumulation (csrc/spconv_os_x6.hip): the same
+               arithmetic class (error vs float64 <= 2 x the fp32 kernel's, tests/test_gpu_spconv.py), 2.7 x less pipe time;
+      'f32x3'  two-way split, three products (csrc/spconv_os_x3.hip; ~1e-5 of the output scale per layer): a leg only.
+    PROCESS-GLOBAL, like sst_amd.dense.set_matmul_mode."""
     global _CONV_PRECISION
-    if mode not in ('f32', 'f32x3'):
+    if mode not in ('f32', 'f32x3', 'f32x6'):
         raise ValueError(mode)
     _CONV_PRECISION = mode
 
@@ -332,15 +336,17 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cf
     weight3 = weight3 if weight3.is_contiguous() else weight3.contiguous()
     if (_conv_kernel_choice() == 'os' and kvol <= 32 and cin % 4 == 0 and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0):
-        ws = _lib.workspace(lib.sst_spconv_conv_os_workspace_bytes(kvol, cin, cout), x.device)
+        split = _CONV_PRECISION if (_CONV_PRECISION != 'f32' and int(tile_cfg) == 0) else None
+        ws_bytes = (lib.sst_spconv_conv_os_f32x6_workspace_bytes if split == 'f32x6' else lib.sst_spconv_conv_os_workspace_bytes)
+        ws = _lib.workspace(ws_bytes(kvol, cin, cout), x.device)
         order = None
-        x3 = _CONV_PRECISION == 'f32x3' and int(tile_cfg) == 0
+        x3 = split is not None
         if isinstance(density, Rulebook) and rows >= _OS_ORDER_MIN_ROWS and _os_tile_order_enabled():
             # the split-precision kernel always works on 64-row tiles (it ignores the SST_SPCONV_OS_TILE override the exact
             # kernel's os_pick honours): its launch order must be computed for ITS tile height
             tile_rows = 64 if x3 else lib.sst_spconv_conv_os_tile_rows(rows, cout, int(tile_cfg))
             order = density.tile_order(mapping, rows, tile_rows)
-        entry = lib.sst_spconv_conv_os_f32x3 if x3 else lib.sst_spconv_conv_os_f32
+        entry = getattr(lib, 'sst_spconv_conv_os_' + (split or 'f32'))
         rc = entry(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin, cout, int(trans_w), None,
                    _lib.ptr(y), y.stride(0), int(tile_cfg), _lib.ptr(order) if order is not None else None, _lib.ptr(ws),
                    _lib.stream_ptr())

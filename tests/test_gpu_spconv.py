@@ -163,6 +163,45 @@ def test_split_precision_convolution_kernel(cin, cout):
         spconv.set_conv_precision('f32')
 
 
+@pytest.mark.parametrize('cin,cout', [(64, 64), (16, 32), (128, 160), (192, 256), (64, 128), (256, 256)])
+def test_exact_split_convolution_kernel(cin, cout):
+    """csrc/spconv_os_x6.hip: the contraction from the EXACT three-way bf16 split (six products, two accumulator sets), forward
+    orientation and the transposed-weight orientation of the data gradient, against the float64 restatement of indiceConv
+    (spconv_ops.h:256-357) BESIDE the fp32-pipe kernel on the same operands: its error may be at most twice the fp32 kernel's
+    (the admissibility bar of the dense layers, tests/test_gpu_dense_f32x6.py) - then it is the same arithmetic class and may
+    carry the FSD / FSDv2 lines."""
+    from oracle import spconv_oracle as O
+    from sst_amd import spconv
+    rng = np.random.default_rng(cin + cout)
+    batch, shape, n = 2, [6, 40, 44], 6000
+    ind = _cloud(rng, n, batch, shape)
+    try:
+        for subm, st in ((True, 1), (False, 2)):
+            outids, pairs, num, rb = _rulebook(ind, batch, shape, [3] * 3, [st] * 3, [1] * 3, [1] * 3, subm, False)
+            m = len(outids)
+            gen = torch.Generator().manual_seed(7)
+            x = torch.randn(n, cin, generator=gen) * 3
+            w = torch.randn(27, cin, cout, generator=gen) * 0.2
+            gy = torch.randn(m, cout, generator=gen)
+            p_np, n_np = pairs.cpu().numpy(), num.cpu().numpy()
+            y_ref = O.indice_conv(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), p_np, n_np, m)
+            dx_ref, _ = O.indice_conv_backward(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), gy.numpy(), p_np, n_np)
+            errs, outs = {}, {}
+            for mode in ('f32', 'f32x6'):
+                spconv.set_conv_precision(mode)
+                y = spconv._gather_gemm(x.to(DEV), rb.out2in, m, w.to(DEV), False, cout, rb)
+                dx = spconv._gather_gemm(gy.to(DEV), rb.in2out, n, w.to(DEV), True, cin, rb)
+                outs[mode] = y
+                errs[mode] = (np.abs(y.cpu().numpy() - y_ref).max(), np.abs(dx.cpu().numpy() - dx_ref).max())
+            sy, sx = max(1.0, np.abs(y_ref).max()), max(1.0, np.abs(dx_ref).max())
+            assert errs['f32x6'][0] <= max(2.0 * errs['f32'][0], 2e-7 * sy), (errs, sy)
+            assert errs['f32x6'][1] <= max(2.0 * errs['f32'][1], 2e-7 * sx), (errs, sx)
+            assert errs['f32x6'][0] <= 5e-6 * sy and errs['f32x6'][1] <= 5e-6 * sx
+            assert not torch.equal(outs['f32'], outs['f32x6'])
+    finally:
+        spconv.set_conv_precision('f32')
+
+
 def test_inverse_conv_matches_oracle_and_modules_chain():
     """SubMConv3d -> SparseConv3d (stride 2, indice_key) -> SubMConv3d -> SparseInverseConv3d back to the input voxels
     (the down / up pattern of middle_encoders/sparse_unet.py), forward and all gradients against the oracle."""
