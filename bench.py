@@ -416,6 +416,9 @@ def main():
                          "headline: the line then says so in dtype)")
     ap.add_argument('--no-traffic-remeasure', action='store_true',
                     help='take roofline.traffic from profiles/latest_sra_traffic.json instead of two rocprofv3 --pmc passes now')
+    ap.add_argument('--cloud', default='uniform', choices=('uniform', 'lidar'),
+                    help='diagnostic: lidar = the MAIN loop on the LiDAR-like frame of the lidar_like_cloud leg (for profiles of '
+                         'that frame; the line then names it in config.workload and is not the headline)')
     ap.add_argument('--no-lidar-leg', action='store_true', help='skip the LiDAR-like / pathological frame beside the headline')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the reduced-precision (bf16) measurement')
     ap.add_argument('--matmul', default='f32x6', choices=('f32', 'f32x6'),
@@ -492,6 +495,10 @@ def main():
         model.backbone.set_precision('f32x6')
     params = [p for p in model.parameters() if p.requires_grad]
     frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
+    if args.cloud == 'lidar':
+        frames = [make_lidar_cloud(2000 * rank + i, dev) for i in range(args.frames_per_gpu)]
+        args.points = int(frames[0].size(0))
+        args.no_lidar_leg = args.no_cpu_baseline = True
     torch.manual_seed(1234 + rank)            # per-rank voxel shuffles
     reducer = make_reducer(params, world, args)
 
@@ -796,7 +803,8 @@ def main():
                       if (args.precision == 'f32' and args.matmul == 'f32x6') else args.precision),
             'data': 'synthetic',
             'gemm_tuning': 'off' if args.no_gemm_tuning else 'torch TunableOp (hipBLASLt/rocBLAS solution per shape)',
-            'config': {'workload': ('SST-base Waymo training, bs=2/GPU, 0.32 m voxel: uniform synthetic cloud '
+            'config': {'workload': ('NOT THE HEADLINE WORKLOAD (--cloud lidar): LiDAR-like synthetic sweep, ' if args.cloud == 'lidar'
+                                    else 'SST-base Waymo training, bs=2/GPU, 0.32 m voxel: uniform synthetic cloud '
                                     if args.workload == 'sst_bs2' else
                                     'SST-base Waymo single-frame, 0.32 m voxel: uniform synthetic cloud ') +
                                    f'{args.points} points/frame -> {n_voxels // args.frames_per_gpu} non-empty '

@@ -108,13 +108,25 @@ int sst_unpack_keys(const uint64_t* d_ukeys, int64_t m, int ncols, const int64_t
  *   MAX of an empty group is -inf, SUM/MEAN is 0.  MEAN = sum / (float)count (cuda.cu:228-229).
  *   d_argmax (optional, [m, c] int32): row index of the FIRST (smallest index) row attaining the max
  *   (the tie rule of max_reduce_traceback_scatter_idx_kernel, cuda.cu:135-160); n for empty groups.
- *   d_group_index (optional, [m] int32): output row g reduces CSR group d_group_index[g] instead of group g
+ *   d_group_index (optional, [m] int32): output row g reduces CSR group d_group_index[g] instead of group g (a negative
+ *   entry: an empty group)
  *   (a subset / re-ordering of the groups without gathering the result: the batched DynamicScatter keeps all but
  *   the first sorted-unique row of every sample).
  * ---------------------------------------------------------------------------------------------- */
 int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream);
+/* sst_segment_reduce_fwd_work_f32: sst_segment_reduce_fwd_f32 made robust against a few very long groups among many short
+ * ones (the voxels next to the sensor of a real LiDAR sweep hold thousands of points while the average voxel holds 1-10:
+ * voxel_encoder.py:185-298 reduces them with the same DynamicScatter).  Groups of more than 32 rows are put on the work
+ * list d_work by the element kernel and reduced by one workgroup each in a second launch of fixed size; same results, same
+ * tie rule.  d_work: int32 [work_capacity], work_capacity >= m + 4, its first 4 entries ZEROED ONCE by the caller; the second
+ * kernel leaves them zeroed (reusable by every later call on the same stream).  d_work == NULL: exactly
+ * sst_segment_reduce_fwd_f32. */
+int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
+                                    const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
+                                    float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, int32_t* d_work,
+                                    int64_t work_capacity, void* stream);
 /* sst_segment_reduce_long_f32: the same reduction (all three modes, the arg-max tie rule) for groupings whose groups are
  * long and uneven (FSD's clusters, voxel_encoder.py:696-764 / backbones/sir.py:67-88: torch_scatter.scatter_max / scatter over
  * cluster ids): work is cut into tiles of sorted positions whatever group they belong to, groups inside a tile are written
@@ -241,11 +253,15 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
  * (middle_encoders/sst_input_layer_v2.py:128-236, ops/sst/sst_ops.py:26-64, 266-331).
  *
  * sst_frame_voxels_i32: from the sorted-unique groups of the point coordinates (sst_unique_rows with
- *   invalid_if_negative = 2, mins (0,-1,-1,-1), extents (B, gz+1, gy+1, gx+1); d_num_groups = its device count):
+ *   invalid_if_negative = 2, mins (0,-1,-1,-1), extents (B, gz+1, gy+1, gx+1); d_ukeys / d_inverse = its sorted keys and its
+ *   point -> group map, d_num_groups = its device count):
  *   drop_mode 1: the first group of every sample is discarded (the reference's unconditional out_coors[1:]),
  *   drop_mode 0: only the group of invalid rows.  Kept groups are the voxels v = 0..M-1 (ascending key):
  *     d_vcoors [n_points, 4] int32 (b,z,y,x), d_gidx [n_points] group of voxel v, d_coors_map [n_points] voxel of every
- *     point (-1: dropped), d_grid [B*gz*gy*gx] dense cell -> voxel map (-1: empty), d_counts[0] = M.
+ *     point (-1: dropped), d_grid [B*gz*gy*gx] dense cell -> voxel map (-1: empty), d_counts[0] = M,
+ *     d_dropped_groups (optional, [B]): the discarded group of every sample, -1 where a sample has none (its points read
+ *     voxel row 0 through map_voxel_center_to_point's zero-initialised canvas, voxel_encoder.py:246-270, and hand their
+ *     gradient to that row: sst_segment_reduce_fwd_f32 with this array as d_group_index gives that sum without atomics).
  * sst_window_plan_i32: window / shifted-window bucketing, drop levels (h_levels: n_levels x (max_tokens, lo, hi)), the
  *   three passes of drop_voxel, window CSR.  seed = 0: survivors of an over-full window are its first voxels in
  *   ascending voxel order; seed != 0: a uniformly random subset (the reference's shuffle_voxels).  Outputs, kept voxels
@@ -258,10 +274,9 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
  *   B * cells <= 2^28 (otherwise SST_ERR_UNSUPPORTED: callers use the piecewise entry points).
  * ---------------------------------------------------------------------------------------------- */
 int64_t sst_frame_windows_per_sample(const int32_t grid_zyx[3], const int32_t window_shape[3]);
-int sst_frame_voxels_i32(const uint64_t* d_ukeys, const int32_t* d_offsets, const uint32_t* d_perm,
-                         const int32_t* d_num_groups, int64_t n_points, int batch_size, const int32_t grid_zyx[3],
+int sst_frame_voxels_i32(const uint64_t* d_ukeys, const int32_t* d_inverse, const int32_t* d_num_groups, int64_t n_points, int batch_size, const int32_t grid_zyx[3],
                          int drop_mode, int32_t* d_vcoors, int32_t* d_gidx, int32_t* d_coors_map, int32_t* d_grid,
-                         int32_t* d_counts, void* stream);
+                         int32_t* d_counts, int32_t* d_dropped_groups, void* stream);
 int64_t sst_window_plan_workspace_bytes(int64_t n_upper, int64_t n_windows);
 int sst_window_plan_i32(const int32_t* d_vcoors, const int32_t* d_grid, int64_t n_upper, int batch_size,
                         const int32_t grid_zyx[3], const int32_t window_shape[3], const int32_t* h_levels, int n_levels,

@@ -57,6 +57,8 @@ _SIGNATURES = {
     'sst_unpack_keys': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr]),
     'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                            c_ptr, c_ptr]),
+    'sst_segment_reduce_fwd_work_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
+                                                c_ptr, c_ptr, c_i64, c_ptr]),
     'sst_segment_long_scratch_bytes': (c_i64, [c_i64, c_i64, c_i32]),
     'sst_segment_reduce_long_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr,
                                             c_ptr]),
@@ -69,8 +71,8 @@ _SIGNATURES = {
     'sst_region_batching_workspace_bytes': (c_i64, [c_i64]),
     'sst_region_batching': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32] + [c_ptr] * 15 + [c_ptr, c_ptr]),
     'sst_frame_windows_per_sample': (c_i64, [c_ptr, c_ptr]),
-    'sst_frame_voxels_i32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
-                                     c_ptr, c_ptr]),
+    'sst_frame_voxels_i32': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                     c_ptr, c_ptr, c_ptr]),
     'sst_window_plan_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sst_window_plan_i32': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, ctypes.c_uint32] + [c_ptr] * 11),
     'sst_sra_attn_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32,

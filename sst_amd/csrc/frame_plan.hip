@@ -63,11 +63,14 @@ __device__ int fp_lower_bound(const uint64_t* __restrict__ ukeys, int m_all, uin
 // One thread per sorted-unique group g.  drop_mode 1: the first group of every sample is discarded (the reference's
 // unconditional out_coors[1:], once per sample); drop_mode 0: only the group of the invalid rows (b, -1, -1, -1).
 // Kept group -> voxel v (ascending): vcoors[v], gidx[v] = g, grid[cell] = v, coors_map[point] = v (-1 if dropped).
-__global__ __launch_bounds__(256) void fp_voxels_k(const uint64_t* __restrict__ ukeys, const int32_t* __restrict__ offsets,
-                                                   const uint32_t* __restrict__ perm, const int32_t* __restrict__ d_num,
+// coors_map is written per POINT (group of the point -> its voxel), not per group: the group of the clamped out-of-range
+// points of a real sweep holds thousands of points, which one thread walked for 0.17 ms.
+__global__ __launch_bounds__(256) void fp_voxels_k(const uint64_t* __restrict__ ukeys, const int32_t* __restrict__ inverse,
+                                                   int n_points, const int32_t* __restrict__ d_num,
                                                    fp_geom G, int drop_mode, int32_t* __restrict__ vcoors,
                                                    int32_t* __restrict__ gidx, int32_t* __restrict__ coors_map,
-                                                   int32_t* __restrict__ grid, int32_t* __restrict__ d_counts) {
+                                                   int32_t* __restrict__ grid, int32_t* __restrict__ d_counts,
+                                                   int32_t* __restrict__ dropped_gidx) {
   __shared__ int dropped_upto[65];  // dropped groups among samples < bb
   const int m_all = *d_num;
   const uint64_t sample_stride = (uint64_t)(G.gz + 1) * (G.gy + 1) * (G.gx + 1);
@@ -81,6 +84,8 @@ __global__ __launch_bounds__(256) void fp_voxels_k(const uint64_t* __restrict__ 
         fp_decode(ukeys[p], G, b, z, y, x);
         if (b == bb) d = drop_mode == 1 ? 1 : (z < 0 ? 1 : 0);
       }
+      // the discarded group of the sample (its points read voxel row 0 and hand their gradient to it), -1: none
+      if (blockIdx.x == 0 && dropped_gidx != nullptr) dropped_gidx[bb] = d ? p : -1;
     }
     // inclusive scan over the 64 lanes of wave 0, then shifted to exclusive
     const int incl = sst_wave_incl_scan(d);
@@ -109,8 +114,19 @@ __global__ __launch_bounds__(256) void fp_voxels_k(const uint64_t* __restrict__ 
       gidx[v] = g;
       if (z >= 0) grid[(((int64_t)b * G.gz + z) * G.gy + y) * G.gx + x] = v;
     }
-    const int beg = offsets[g], end = offsets[g + 1];
-    for (int p = beg; p < end; ++p) coors_map[perm[p]] = v;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_points; i += gridDim.x * blockDim.x) {
+    const int g = inverse[i];
+    int b, z, y, x;
+    fp_decode(ukeys[g], G, b, z, y, x);
+    bool first = true;
+    if (g > 0) {
+      int pb, pz, py, px;
+      fp_decode(ukeys[g - 1], G, pb, pz, py, px);
+      first = pb != b;
+    }
+    const bool dropped = drop_mode == 1 ? first : (z < 0);
+    coors_map[i] = dropped ? -1 : g - dropped_upto[b + 1];
   }
 }
 
@@ -374,10 +390,9 @@ int64_t sst_frame_windows_per_sample(const int32_t grid_zyx[3], const int32_t wi
   return (int64_t)G.nwx * G.nwy * G.nwz;
 }
 
-int sst_frame_voxels_i32(const uint64_t* d_ukeys, const int32_t* d_offsets, const uint32_t* d_perm,
-                         const int32_t* d_num_groups, int64_t n_points, int batch_size, const int32_t grid_zyx[3],
+int sst_frame_voxels_i32(const uint64_t* d_ukeys, const int32_t* d_inverse, const int32_t* d_num_groups, int64_t n_points, int batch_size, const int32_t grid_zyx[3],
                          int drop_mode, int32_t* d_vcoors, int32_t* d_gidx, int32_t* d_coors_map, int32_t* d_grid,
-                         int32_t* d_counts, void* stream) {
+                         int32_t* d_counts, int32_t* d_dropped_groups, void* stream) {
   if (n_points < 0 || (drop_mode != 0 && drop_mode != 1)) return SST_ERR_ARG;
   const int32_t win1[3] = {1, 1, 1};
   fp_geom G;
@@ -387,10 +402,12 @@ int sst_frame_voxels_i32(const uint64_t* d_ukeys, const int32_t* d_offsets, cons
   hipStream_t st = (hipStream_t)stream;
   SST_HIP(hipMemsetAsync(d_counts, 0, 8 * sizeof(int32_t), st));
   SST_HIP(hipMemsetAsync(d_grid, 0xff, sizeof(int32_t) * (size_t)G.B * G.gz * G.gy * G.gx, st));
+  if (d_dropped_groups) SST_HIP(hipMemsetAsync(d_dropped_groups, 0xff, sizeof(int32_t) * (size_t)G.B, st));
   if (n_points == 0) return SST_OK;
-  if (!d_ukeys || !d_offsets || !d_perm || !d_num_groups || !d_vcoors || !d_gidx || !d_coors_map) return SST_ERR_ARG;
-  hipLaunchKernelGGL(fp_voxels_k, dim3(sst_grid_1d(n_points, 256)), dim3(256), 0, st, d_ukeys, d_offsets, d_perm,
-                     d_num_groups, G, drop_mode, d_vcoors, d_gidx, d_coors_map, d_grid, d_counts);
+  if (!d_ukeys || !d_inverse || !d_num_groups || !d_vcoors || !d_gidx || !d_coors_map) return SST_ERR_ARG;
+  if (n_points > 0x7fffffff) return SST_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fp_voxels_k, dim3(sst_grid_1d(n_points, 256)), dim3(256), 0, st, d_ukeys, d_inverse, (int)n_points,
+                     d_num_groups, G, drop_mode, d_vcoors, d_gidx, d_coors_map, d_grid, d_counts, d_dropped_groups);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -17,20 +17,30 @@
 
 namespace {
 
+// Work list of the long groups of a call (sst_segment_reduce_fwd_work_f32): [0] entries, [1] next entry to take, [2] workgroups
+// done, [3] unused, then the output rows of the long groups in the order the first kernel met them (the order has no
+// influence on the result: a group is reduced by one workgroup in a fixed order).
+constexpr int kSegWorkHdr = 4;
+
 // one thread per (group, channel) element; consecutive threads -> consecutive channels of one group
 __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict__ feats, int c,
                                                         const uint32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ offsets,
                                                         const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                         float* __restrict__ out, int32_t* __restrict__ argmax,
-                                                        int32_t n_rows, const int32_t* __restrict__ d_mlim) {
+                                                        int32_t n_rows, const int32_t* __restrict__ d_mlim, int skip_len,
+                                                        int32_t* __restrict__ work) {
   if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int64_t total = m * c;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t g = e / c;
     const int ch = (int)(e - g * c);
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
-    const int beg = offsets[gs], end = offsets[gs + 1];
+    const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
+    if (skip_len > 0 && end - beg > skip_len) {  // long group: seg_reduce_fwd_work_k takes it from the work list
+      if (ch == 0) work[kSegWorkHdr + atomicAdd(&work[0], 1)] = (int32_t)g;
+      continue;
+    }
     if (mode == SST_REDUCE_MAX) {
       float acc = -INFINITY;
       int32_t arg = n_rows;
@@ -61,7 +71,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
                                                            const int32_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
-                                                           int32_t n_rows, const int32_t* __restrict__ d_mlim, int skip_len) {
+                                                           int32_t n_rows, const int32_t* __restrict__ d_mlim, int skip_len,
+                                                           int32_t* __restrict__ work) {
   if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int c4 = c >> 2;
   const int64_t total = m * c4;
@@ -69,8 +80,11 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
     const int64_t g = e / c4;
     const int ch = (int)(e - g * c4) * 4;
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
-    const int beg = offsets[gs], end = offsets[gs + 1];
-    if (skip_len > 0 && end - beg > skip_len) continue;  // long group: seg_reduce_fwd_block_k takes it
+    const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
+    if (skip_len > 0 && end - beg > skip_len) {  // long group: seg_reduce_fwd_block_k / seg_reduce_fwd_work_k takes it
+      if (work != nullptr && ch == 0) work[kSegWorkHdr + atomicAdd(&work[0], 1)] = (int32_t)g;
+      continue;
+    }
     float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
     int32_t a0 = n_rows, a1 = n_rows, a2 = n_rows, a3 = n_rows;
@@ -114,6 +128,124 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
 // group serially behind one load latency per 4 points (measured on FSD's clusters: 0.34 TB/s).  Launched beside it when
 // the average group has at least 8 points: groups of more than kLongGroup (16) points are skipped there and taken here.  Ties of the maximum: smallest row index, as above (every half sees its rows
 // in ascending order, the halves are combined with value first, then the smaller index).
+// one group by the whole workgroup: float4 channel quads (c % 4 == 0).  A row is read by L = 8 / 16 / 32 lanes (the power of
+// two that covers its quads), the 256 / L row parts stride over the group's rows with four rows in flight each, and meet in
+// LDS in a fixed order.
+__device__ __forceinline__ void seg_block_group_v4(const float* __restrict__ feats, int c, const uint32_t* __restrict__ perm,
+                                                   int beg, int end, int64_t g, int mode, float* __restrict__ out,
+                                                   int32_t* __restrict__ argmax, int32_t n_rows, float4 (*lds_v2)[32],
+                                                   int4 (*lds_a2)[32]) {
+  float4* lds_v = &lds_v2[0][0];
+  int4* lds_a = &lds_a2[0][0];
+  const int c4 = c >> 2;
+  const int L = c4 <= 8 ? 8 : (c4 <= 16 ? 16 : 32);
+  const int parts = 256 / L, part = threadIdx.x / L, l = threadIdx.x - part * L;
+  for (int q0 = 0; q0 < c4; q0 += L) {  // L channel quads per pass (c <= 128: one pass)
+    const int q = q0 + l;
+    const bool live = q < c4;
+    float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 arg = make_int4(n_rows, n_rows, n_rows, n_rows);
+    for (int p = beg + part; p < end; p += 4 * parts) {
+      uint32_t r[4];
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = perm[p + u * parts < end ? p + u * parts : p];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = live ? *(const float4*)(feats + (int64_t)r[u] * c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (p + u * parts < end) {   // rows of a part are visited in ascending order: strict '>' keeps the smallest row on ties
+          if (mode == SST_REDUCE_MAX) {
+            if (x[u].x > acc.x) acc.x = x[u].x, arg.x = (int)r[u];
+            if (x[u].y > acc.y) acc.y = x[u].y, arg.y = (int)r[u];
+            if (x[u].z > acc.z) acc.z = x[u].z, arg.z = (int)r[u];
+            if (x[u].w > acc.w) acc.w = x[u].w, arg.w = (int)r[u];
+          } else {
+            acc.x += x[u].x, acc.y += x[u].y, acc.z += x[u].z, acc.w += x[u].w;
+          }
+        }
+      }
+    }
+    lds_v[threadIdx.x] = acc;
+    lds_a[threadIdx.x] = arg;
+    __syncthreads();
+    if (part == 0 && live) {
+      float4 r = acc;
+      int4 a = arg;
+      for (int h = 1; h < parts; ++h) {
+        const float4 v = lds_v[h * L + l];
+        const int4 b = lds_a[h * L + l];
+        if (mode == SST_REDUCE_MAX) {
+          // a part that saw no point holds (-inf, n_rows): never wins; -inf values of real rows keep the smaller index
+          if (v.x > r.x || (v.x == r.x && b.x < a.x)) r.x = v.x, a.x = b.x;
+          if (v.y > r.y || (v.y == r.y && b.y < a.y)) r.y = v.y, a.y = b.y;
+          if (v.z > r.z || (v.z == r.z && b.z < a.z)) r.z = v.z, a.z = b.z;
+          if (v.w > r.w || (v.w == r.w && b.w < a.w)) r.w = v.w, a.w = b.w;
+        } else {
+          r.x += v.x, r.y += v.y, r.z += v.z, r.w += v.w;
+        }
+      }
+      if (mode == SST_REDUCE_MEAN && end > beg) {
+        const float cnt = (float)(end - beg);
+        r.x = r.x / cnt, r.y = r.y / cnt, r.z = r.z / cnt, r.w = r.w / cnt;
+      }
+      if (end <= beg) r = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(out + g * c + 4 * q) = r;
+      if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + 4 * q) = a;
+    }
+    __syncthreads();
+  }
+}
+
+// one group by the whole workgroup, any width: thread = (row part, channel); cp = channels rounded up to a power of two
+// (<= 256), 256 / cp row parts stride over the group's rows, the parts meet in LDS in a fixed order
+__device__ __forceinline__ void seg_block_group_v1(const float* __restrict__ feats, int c, const uint32_t* __restrict__ perm,
+                                                   int beg, int end, int64_t g, int mode, float* __restrict__ out,
+                                                   int32_t* __restrict__ argmax, int32_t n_rows, float* lds_v, int* lds_a) {
+  for (int c0 = 0; c0 < c; c0 += 256) {
+    const int cw = c - c0 < 256 ? c - c0 : 256;
+    int cp = 1;
+    while (cp < cw) cp <<= 1;
+    const int parts = 256 / cp, part = threadIdx.x / cp, ch = threadIdx.x - part * cp;
+    const bool live = ch < cw;
+    float acc = mode == SST_REDUCE_MAX ? -INFINITY : 0.f;
+    int arg = n_rows;
+    if (live) {
+      for (int p = beg + part; p < end; p += parts) {
+        const uint32_t r = perm[p];
+        const float x = feats[(int64_t)r * c + c0 + ch];
+        if (mode == SST_REDUCE_MAX) {
+          if (x > acc) acc = x, arg = (int)r;
+        } else {
+          acc += x;
+        }
+      }
+    }
+    lds_v[threadIdx.x] = acc;
+    lds_a[threadIdx.x] = arg;
+    __syncthreads();
+    if (part == 0 && live) {
+      float r = acc;
+      int a = arg;
+      for (int h = 1; h < parts; ++h) {
+        const float v = lds_v[h * cp + ch];
+        const int b = lds_a[h * cp + ch];
+        if (mode == SST_REDUCE_MAX) {
+          if (v > r || (v == r && b < a)) r = v, a = b;
+        } else {
+          r += v;
+        }
+      }
+      if (mode == SST_REDUCE_MEAN && end > beg) r = r / (float)(end - beg);
+      if (end <= beg) r = 0.f;
+      out[g * c + c0 + ch] = r;
+      if (mode == SST_REDUCE_MAX && argmax != nullptr) argmax[g * c + c0 + ch] = a;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void seg_reduce_fwd_block_k(const float* __restrict__ feats, int c,
                                                               const uint32_t* __restrict__ perm,
                                                               const int32_t* __restrict__ offsets,
@@ -123,71 +255,51 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_block_k(const float* __res
   __shared__ float4 lds_v[8][32];
   __shared__ int4 lds_a[8][32];
   if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;
-  const int half = threadIdx.x >> 5, l = threadIdx.x & 31;
-  const int c4 = c >> 2;
   for (int64_t g = blockIdx.x; g < m; g += gridDim.x) {
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
-    const int beg = offsets[gs], end = offsets[gs + 1];
+    const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
     if (end - beg <= min_len) continue;     // short group: the thread-per-(group, 4 channels) kernel took it (uniform)
-    for (int q0 = 0; q0 < c4; q0 += 32) {  // 32 channel quads per pass (c = 128: one pass)
-      const int q = q0 + l;
-      const bool live = q < c4;
-      float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-      int4 arg = make_int4(n_rows, n_rows, n_rows, n_rows);
-      for (int p = beg + half; p < end; p += 16) {
-        const bool two = p + 8 < end;
-        const uint32_t r0 = perm[p], r1 = perm[two ? p + 8 : p];
-        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-        if (live) {
-          x0 = *(const float4*)(feats + (int64_t)r0 * c + 4 * q);
-          x1 = *(const float4*)(feats + (int64_t)r1 * c + 4 * q);
-        }
-        if (mode == SST_REDUCE_MAX) {
-          if (x0.x > acc.x) acc.x = x0.x, arg.x = (int)r0;
-          if (x0.y > acc.y) acc.y = x0.y, arg.y = (int)r0;
-          if (x0.z > acc.z) acc.z = x0.z, arg.z = (int)r0;
-          if (x0.w > acc.w) acc.w = x0.w, arg.w = (int)r0;
-          if (two) {
-            if (x1.x > acc.x) acc.x = x1.x, arg.x = (int)r1;
-            if (x1.y > acc.y) acc.y = x1.y, arg.y = (int)r1;
-            if (x1.z > acc.z) acc.z = x1.z, arg.z = (int)r1;
-            if (x1.w > acc.w) acc.w = x1.w, arg.w = (int)r1;
-          }
-        } else {
-          acc.x += x0.x, acc.y += x0.y, acc.z += x0.z, acc.w += x0.w;
-          if (two) acc.x += x1.x, acc.y += x1.y, acc.z += x1.z, acc.w += x1.w;
-        }
-      }
-      lds_v[half][l] = acc;
-      lds_a[half][l] = arg;
-      __syncthreads();
-      if (half == 0 && live) {
-        float4 r = lds_v[0][l];
-        int4 a = lds_a[0][l];
-#pragma unroll
-        for (int h = 1; h < 8; ++h) {
-          const float4 v = lds_v[h][l];
-          const int4 b = lds_a[h][l];
-          if (mode == SST_REDUCE_MAX) {
-            // a half that saw no point holds (-inf, n_rows): never wins; -inf values of real rows keep the smaller index
-            if (v.x > r.x || (v.x == r.x && b.x < a.x)) r.x = v.x, a.x = b.x;
-            if (v.y > r.y || (v.y == r.y && b.y < a.y)) r.y = v.y, a.y = b.y;
-            if (v.z > r.z || (v.z == r.z && b.z < a.z)) r.z = v.z, a.z = b.z;
-            if (v.w > r.w || (v.w == r.w && b.w < a.w)) r.w = v.w, a.w = b.w;
-          } else {
-            r.x += v.x, r.y += v.y, r.z += v.z, r.w += v.w;
-          }
-        }
-        if (mode == SST_REDUCE_MEAN && end > beg) {
-          const float cnt = (float)(end - beg);
-          r.x = r.x / cnt, r.y = r.y / cnt, r.z = r.z / cnt, r.w = r.w / cnt;
-        }
-        if (end <= beg) r = make_float4(0.f, 0.f, 0.f, 0.f);
-        *(float4*)(out + g * c + 4 * q) = r;
-        if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + 4 * q) = a;
-      }
-      __syncthreads();
+    seg_block_group_v4(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, lds_v, lds_a);
+  }
+}
+
+// The long groups of a call whose AVERAGE group is short (voxel grouping of a real LiDAR sweep: 1-10 points per voxel on
+// average, thousands in the voxels next to the sensor): the thread-per-element kernels above put them on a work list instead
+// of walking them serially (a 3 000-point voxel took 0.4-0.5 ms there, longer than the rest of the launch by 20 x); a fixed
+// grid of workgroups takes the entries by ticket, one workgroup per group.  The last workgroup to finish zeroes the three
+// counters: the list is reusable without a fill.  Nothing spins, no float atomics; the order of the list does not matter.
+template <int V>
+__global__ __launch_bounds__(256) void seg_reduce_fwd_work_k(const float* __restrict__ feats, int c,
+                                                             const uint32_t* __restrict__ perm,
+                                                             const int32_t* __restrict__ offsets,
+                                                             const int32_t* __restrict__ gidx, int mode,
+                                                             float* __restrict__ out, int32_t* __restrict__ argmax,
+                                                             int32_t n_rows, int32_t* __restrict__ work) {
+  __shared__ float4 lds_v[8][32];
+  __shared__ int4 lds_a[8][32];
+  __shared__ int s_take;
+  const int count = __atomic_load_n(&work[0], __ATOMIC_RELAXED);
+  for (;;) {
+    if (threadIdx.x == 0) s_take = atomicAdd(&work[1], 1);
+    __syncthreads();
+    const int take = s_take;
+    __syncthreads();
+    if (take >= count) break;
+    const int64_t g = work[kSegWorkHdr + take];
+    const int64_t gs = gidx != nullptr ? gidx[g] : g;
+    const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
+    if (V == 4)
+      seg_block_group_v4(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, lds_v, lds_a);
+    else
+      seg_block_group_v1(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, (float*)&lds_v[0][0], (int*)&lds_a[0][0]);
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&work[2], 1) == (int)gridDim.x - 1) {   // every workgroup has left its loop: nobody reads the counters again
+      work[0] = 0;
+      work[1] = 0;
+      __threadfence();
+      work[2] = 0;
     }
   }
 }
@@ -747,28 +859,70 @@ int sst_segment_reduce_profile_next(void* start, void* stop) {
   return SST_OK;
 }
 
-int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
-                               const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
-                               float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream) {
+int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
+                                    const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
+                                    float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, int32_t* d_work,
+                                    int64_t work_capacity, void* stream) {
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_offsets || !d_out || (n > 0 && (!d_feats || !d_perm))) return SST_ERR_ARG;
+  if (d_work != nullptr && work_capacity < m + kSegWorkHdr) return SST_ERR_ARG;
   hipEvent_t e0 = g_seg_ev[0], e1 = g_seg_ev[1];
   g_seg_ev[0] = g_seg_ev[1] = nullptr;
   const bool timed = e0 != nullptr && e1 != nullptr;
-  if ((c & 3) == 0 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15) == 0 && n > 0) {
+  const bool v4 = (c & 3) == 0 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15) == 0 && n > 0;
+  constexpr int kLongGroup = 16;       // without a work list: groups longer than this go to one workgroup each when n >= 8 m
+  constexpr int kWorkGroupLen = 32;    // with a work list: groups longer than this, whatever the average
+  constexpr int kWorkGrid = 512;
+  if (d_work != nullptr && n > 0) {
+    // robust form: the element kernel lists the long groups, a fixed grid of workgroups reduces them
+    if (v4) {
+      const int grid = sst_grid_1d(m * (c >> 2), 256);
+      if (timed)
+        hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0, d_feats, c,
+                              d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen,
+                              d_work);
+      else
+        hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
+                           d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, d_work);
+      if (timed)
+        hipExtLaunchKernelGGL(seg_reduce_fwd_work_k<4>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
+                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+      else
+        hipLaunchKernelGGL(seg_reduce_fwd_work_k<4>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
+                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+    } else {
+      const int grid = sst_grid_1d(m * c, 256);
+      if (timed)
+        hipExtLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0, d_feats, c,
+                              d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen,
+                              d_work);
+      else
+        hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
+                           d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, d_work);
+      if (timed)
+        hipExtLaunchKernelGGL(seg_reduce_fwd_work_k<1>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
+                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+      else
+        hipLaunchKernelGGL(seg_reduce_fwd_work_k<1>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
+                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+    }
+    SST_LAUNCH_CHECK();
+    return SST_OK;
+  }
+  if (v4) {
     // groups of many points can only exist when the average is not tiny: the second kernel (one workgroup per LONG group,
     // every other block leaves at once) is launched when n >= 8 m - never for voxel grouping at 1-6 points per voxel
-    constexpr int kLongGroup = 16;
     const bool split = n >= 8 * m;
     const int grid = sst_grid_1d(m * (c >> 2), 256);
     if (timed)
       hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, split ? nullptr : e1, 0,
                             d_feats, c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit,
-                            split ? kLongGroup : 0);
+                            split ? kLongGroup : 0, (int32_t*)nullptr);
     else
       hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                         d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, split ? kLongGroup : 0);
+                         d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, split ? kLongGroup : 0,
+                         (int32_t*)nullptr);
     if (split) {
       const int grid_b = (int)(m < 65536 ? m : 65536);
       if (timed)
@@ -784,12 +938,19 @@ int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uin
   const int grid = sst_grid_1d(m * c, 256);
   if (timed)
     hipExtLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, d_feats, c, d_perm,
-                          d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
+                          d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, 0, (int32_t*)nullptr);
   else
     hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                       d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit);
+                       d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, 0, (int32_t*)nullptr);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
+                               const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
+                               float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream) {
+  return sst_segment_reduce_fwd_work_f32(d_feats, n, c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax,
+                                         d_m_limit, nullptr, 0, stream);
 }
 
 // geometry of seg_tiles_k for a width: channel vectors, row lanes per workgroup

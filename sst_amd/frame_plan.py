@@ -32,6 +32,18 @@ class FramePlan(object):
         return K.segment_reduce(feats, self.groups, mode, group_index=self.gidx, inverse=self.coors_map,
                                 m_limit=self.d_counts[0:1])
 
+    def group_sum(self, part):
+        """Gradient of the hand-back ``pooled[coors_map]`` (points of a discarded group read row 0): the CSR sum over the kept
+        voxels, plus the rows of the discarded groups added to row 0 - in a fixed order, where an index_add with float
+        atomics is neither reproducible nor fast on the crowded voxels of a real sweep."""
+        dg = self.reduce(part, 'sum')
+        m = getattr(self, 'num_voxels', None)
+        if m is None:
+            m = int(self.d_counts[0].item())
+        if m < dg.size(0):
+            dg[m:].zero_()
+        return K.add_group_rows_to_row0(dg, part, self.groups, self.dropped_gidx)
+
     @property
     def voxel_coors(self):
         return self.vcoors
@@ -128,12 +140,12 @@ class FramePlanner(object):
         plan.vcoors = torch.empty((n_up, 4), dtype=torch.int32, device=dev)
         plan.gidx, plan.coors_map = e32(n_up), e32(n_up)
         plan.d_counts = e32(8)
+        plan.dropped_gidx = e32(bsz)
         grid = e32(bsz * gz * gy * gx)
-        rc = lib.sst_frame_voxels_i32(_lib.ptr(groups.ukeys), _lib.ptr(groups.offsets), _lib.ptr(groups.perm),
-                                      _lib.ptr(groups.num), n, bsz, _lib.i32array(self.grid_zyx),
+        rc = lib.sst_frame_voxels_i32(_lib.ptr(groups.ukeys), _lib.ptr(groups.inverse), _lib.ptr(groups.num), n, bsz, _lib.i32array(self.grid_zyx),
                                       1 if vfe.reference_compat else 0, _lib.ptr(plan.vcoors), _lib.ptr(plan.gidx),
                                       _lib.ptr(plan.coors_map), _lib.ptr(grid), _lib.ptr(plan.d_counts),
-                                      _lib.stream_ptr())
+                                      _lib.ptr(plan.dropped_gidx), _lib.stream_ptr())
         _lib.check(rc, 'sst_frame_voxels_i32')
         plan.coors_map = plan.coors_map[:n]
         # 2. window bucketing, drop, window CSR of both partitions

@@ -174,14 +174,32 @@ def unpack_unique_rows(plan, dtype, first=0, count=None, out_cols=None, col0=0, 
 # ----------------------------------------------------------------------------------------------
 # (a3/a5/a15) segmented reduce with autograd
 # ----------------------------------------------------------------------------------------------
-def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=None, m_limit=None):
+def _long_work_list(plan, m, dev):
+    """work list of the long groups of a grouping (csrc/scatter.hip seg_reduce_fwd_work_k): counters zeroed once per plan, the
+    kernel leaves them zeroed; one list per stream, as launches on different streams may overlap"""
+    cache = getattr(plan, 'scratch', None)
+    if cache is None:
+        cache = plan.scratch = {}
+    key = ('work', _lib.stream_ptr().value)
+    buf = cache.get(key)
+    if buf is None or buf.numel() < m + 4:
+        buf = cache[key] = torch.zeros(max(int(m), int(getattr(plan, 'm', 0) or 0)) + 4, dtype=torch.int32, device=dev)
+    return buf
+
+
+def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=None, m_limit=None, plan=None):
     n, c = feats.shape
     out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
     argmax = torch.empty((m, c), dtype=torch.int32, device=feats.device) if want_argmax else None
-    rc = _lib.load().sst_segment_reduce_fwd_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets),
-                                                _lib.ptr(group_index), m, mode, _lib.ptr(out), _lib.ptr(argmax),
-                                                _lib.ptr(m_limit), _lib.stream_ptr())
-    _lib.check(rc, 'sst_segment_reduce_fwd_f32')
+    # with a plan to keep the work list on: long groups (a voxel next to the sensor holds thousands of points of a real sweep)
+    # are reduced by a workgroup each instead of by one thread per channel vector
+    work = _long_work_list(plan, m, feats.device) if (plan is not None and n > 0
+                                                      and os.environ.get('SST_SEG_WORK', '1') != '0') else None
+    rc = _lib.load().sst_segment_reduce_fwd_work_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets),
+                                                     _lib.ptr(group_index), m, mode, _lib.ptr(out), _lib.ptr(argmax),
+                                                     _lib.ptr(m_limit), _lib.ptr(work), 0 if work is None else work.numel(),
+                                                     _lib.stream_ptr())
+    _lib.check(rc, 'sst_segment_reduce_fwd_work_f32')
     return out, argmax
 
 
@@ -228,7 +246,7 @@ class SegmentReduce(Function):
                                                          _lib.ptr(out), _lib.ptr(argmax), _lib.stream_ptr())
             _lib.check(rc, 'sst_segment_reduce_long_f32')
         else:
-            out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2, group_index, m_limit)
+            out, argmax = _segment_reduce_fwd(feats, perm, offsets, m, mode, mode == 2, group_index, m_limit, plan)
         ctx.mode, ctx.m, ctx.shift = mode, m, inverse_shift
         ctx.shape = feats.shape
         ctx.has_gidx = group_index is not None
@@ -259,16 +277,27 @@ def segment_reduce(feats, plan, mode, first=0, group_index=None, inverse=None, m
     knows it; the output then has group_index.numel() rows of which the first *m_limit are written."""
     if group_index is not None:
         return SegmentReduce.apply(feats, plan.perm, plan.offsets, inverse, group_index.numel(), REDUCE[mode], 0,
-                                   group_index, m_limit)
+                                   group_index, m_limit, plan)
     m = plan.m - first
     offsets = plan.offsets[first:]
     return SegmentReduce.apply(feats, plan.perm, offsets, plan.inverse, m, REDUCE[mode], -first, None, None, plan)
 
 
+def add_group_rows_to_row0(dg, feats, plan, groups_i32):
+    """dg[0] += sum of the rows of ``feats`` that belong to the CSR groups ``groups_i32`` (negative entries: none), in a fixed
+    order: the share of the points of discarded voxels in the gradient of a gather that sent them to row 0."""
+    if groups_i32 is None or groups_i32.numel() == 0 or dg.size(0) == 0:
+        return dg
+    extra, _ = _segment_reduce_fwd(feats.contiguous(), plan.perm, plan.offsets, groups_i32.numel(), REDUCE['sum'], False,
+                                   groups_i32, None, plan)
+    dg[0] += extra[0] if extra.size(0) == 1 else extra.sum(0)
+    return dg
+
+
 def segment_argmax(feats, plan, first=0):
     """(max, argmax row index) per group — torch_scatter.scatter_max's second output."""
     feats = feats.contiguous()
-    return _segment_reduce_fwd(feats, plan.perm, plan.offsets[first:], plan.m - first, 2, True)
+    return _segment_reduce_fwd(feats, plan.perm, plan.offsets[first:], plan.m - first, 2, True, plan=plan)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -81,7 +81,7 @@ class ScatterPlan(object):
     """Grouping of N points into voxels, computed ONCE per frame batch and shared by every scatter call
     on the same coordinates (the reference re-runs at::unique_dim in each of DynamicVFE's 3 scatters)."""
 
-    def __init__(self, plan, first, keep_idx, voxel_coors, coors_map, reduce_count):
+    def __init__(self, plan, first, keep_idx, voxel_coors, coors_map, reduce_count, dropped_idx=None):
         self.plan = plan                # kernels.UniquePlan over ALL sorted-unique rows
         self.first = first              # groups [first, plan.m) are kept when keep_idx is None
         self.keep_idx = keep_idx        # int64 indices of kept groups (batched case) or None
@@ -90,6 +90,12 @@ class ScatterPlan(object):
         self.reduce_count = reduce_count  # [M] int32
         self.num_voxels = voxel_coors.size(0)
         self._keep_i32 = keep_idx.to(torch.int32) if keep_idx is not None else None
+        self._dropped_i32 = dropped_idx   # int32 indices of the discarded groups (their points read voxel row 0), or None
+
+    def group_sum(self, part):
+        """gradient of ``pooled[coors_map]`` without atomics: CSR sum over the kept voxels + the discarded groups' rows on
+        row 0 (frame_plan.FramePlan.group_sum)"""
+        return K.add_group_rows_to_row0(self.reduce(part, 'sum'), part, self.plan, self._dropped_i32)
 
     def reduce(self, feats, mode):
         if self.keep_idx is None:
@@ -143,11 +149,13 @@ def build_scatter_plan(coors, grid_zyx=None, reference_compat=True):
             first = 1
         else:
             first = 1 if bool((plan.ukeys[0] == 0).item()) else 0
-        return ScatterPlan(plan, first, None, all_coors[first:], plan.inverse - first, counts[first:].contiguous())
+        return ScatterPlan(plan, first, None, all_coors[first:], plan.inverse - first, counts[first:].contiguous(),
+                           torch.arange(first, dtype=torch.int32, device=dev))
     if reference_compat and bmax_known == 0:
         # a single sample: "drop the first row of every sample" is the contiguous first = 1 case (no keep index,
         # no compaction, no extra readback)
-        return ScatterPlan(plan, 1, None, all_coors[1:], plan.inverse - 1, counts[1:].contiguous())
+        return ScatterPlan(plan, 1, None, all_coors[1:], plan.inverse - 1, counts[1:].contiguous(),
+                           torch.zeros(1, dtype=torch.int32, device=dev))
     # batched: the reference loops over samples, so the "first row" is dropped once PER SAMPLE
     b = all_coors[:, 0]
     is_first = torch.ones_like(b, dtype=torch.bool)
@@ -161,7 +169,8 @@ def build_scatter_plan(coors, grid_zyx=None, reference_compat=True):
     newid = torch.where(keep, newid, torch.full_like(newid, -1))
     keep_idx = torch.nonzero(keep).squeeze(1)
     coors_map = newid[plan.inverse.long()]
-    return ScatterPlan(plan, 0, keep_idx, all_coors[keep_idx], coors_map, counts[keep_idx].contiguous())
+    return ScatterPlan(plan, 0, keep_idx, all_coors[keep_idx], coors_map, counts[keep_idx].contiguous(),
+                       torch.nonzero(drop).squeeze(1).to(torch.int32))
 
 
 def dynamic_point_to_voxel_forward(feats, coors, reduce_type, reference_compat=True):

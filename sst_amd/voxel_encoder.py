@@ -85,7 +85,8 @@ class _VoxelGrouping(object):
         self.plan = plan
         self.index = plan.coors_map
         self.coors = plan.voxel_coors
-        self.group_sum = None      # points of a discarded voxel hand their gradient to row 0: not a CSR member
+        # points of a discarded voxel hand their gradient to row 0 (not a CSR member of it): the plan adds their rows in
+        self.group_sum = getattr(plan, 'group_sum', None)
 
     def reduce(self, feats, mode):
         return self.plan.reduce(feats, mode)

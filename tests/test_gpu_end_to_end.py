@@ -103,6 +103,33 @@ def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks, fused
         assert errs[name] < tol, f'relative parameter gradient errors {errs} ({flips} flipped pooling decisions)'
 
 
+@pytest.mark.parametrize('fused_index', [True, False])
+def test_whole_step_is_bit_reproducible_on_a_crowded_sweep(fused_index):
+    """LiDAR-like frame (thousands of points in the voxels next to the sensor, 5 % of the points clamped into one out-of-range
+    group, exact duplicates): two runs of forward + backward from the same seed give the same bits in the output and in every
+    parameter gradient - the path has no float atomics (the hand-back gradient of DynamicVFE included), and its long voxel
+    groups go through the work-list reduction (csrc/scatter.hip seg_reduce_fwd_work_k)."""
+    import bench
+    torch.manual_seed(0)
+    gpu = bench.Pipeline(2).to(DEV).train()
+    gpu.fused_index = fused_index
+    frames = [bench.make_lidar_cloud(11, DEV, beams=32, azimuth_steps=1800), bench.make_lidar_cloud(12, DEV, beams=24, azimuth_steps=900)]
+    runs = []
+    for _ in range(3):
+        torch.manual_seed(77)                      # the voxel shuffle / drop draws from torch's generator
+        for p in gpu.parameters():
+            p.grad = None
+        out = gpu(frames)
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        out.backward(torch.randn(out.shape, device=DEV, generator=gen))
+        runs.append((out.detach().clone(), {n: p.grad.clone() for n, p in gpu.named_parameters() if p.grad is not None}))
+    assert len(runs[0][1]) > 20
+    for out, grads in runs[1:]:
+        assert torch.equal(out, runs[0][0])
+        for n, g in grads.items():
+            assert torch.equal(g, runs[0][1][n]), n
+
+
 def test_headline_config_forward_parity():
     """BASELINE.json configs[1] itself: 116 000 points -> ~90 k voxels, 6 SRA blocks, forward; the GPU pipeline against
     the CPU port of the reference data flow with the same weights (what bench.py reports as `parity`)."""

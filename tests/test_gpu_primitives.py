@@ -148,3 +148,62 @@ def test_long_group_reduce_gives_the_same_answer_every_launch(n, k, c):
         bad += int(not torch.equal(K.segment_reduce(feats, plan, 'sum').double(), ref_sum))   # small integers: exact
     assert bad == 0
 
+
+
+@pytest.mark.parametrize('c', [128, 64, 3, 11])
+@pytest.mark.parametrize('subset', [False, True])
+def test_voxel_grouping_with_a_few_huge_voxels(c, subset, monkeypatch):
+    """A real sweep's voxel grouping: 1-3 points in most voxels, thousands in the voxels next to the sensor (n < 8 m, so
+    the long-group kernels chosen by the AVERAGE never run).  The work-list form (long groups listed by the element kernel,
+    one workgroup each) against the serial walk: MAX bit-identical incl. arg-max rows, SUM / MEAN against float64, every
+    launch the same, the list cleans itself; `subset`: through group_index + a device-side row limit (the batched
+    DynamicScatter form)."""
+    from sst_amd import kernels as K
+    rng = np.random.default_rng(c + subset)
+    k, n_short, huge = 20000, 30000, [5000, 3000, 2000, 700, 300, 100, 40, 33]
+    ids = np.concatenate([np.arange(k), rng.integers(0, k, n_short - k)] + [np.full(h, 17 + 1000 * i) for i, h in enumerate(huge)])
+    rng.shuffle(ids)
+    n = ids.size
+    assert n < 8 * k
+    coors = torch.from_numpy(np.stack([np.zeros(n, np.int64), ids // 200, ids % 200], 1)).to(_dev())
+    plan = K.unique_rows(coors)
+    assert plan.m == k
+    feats = torch.from_numpy(rng.integers(-3, 4, size=(n, c)).astype(np.float32)).to(_dev())
+    real = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(_dev())
+    if subset:
+        gidx = torch.arange(1, k, dtype=torch.int32, device=_dev())        # all but the first group
+        inverse = plan.inverse - 1
+        m_limit = torch.tensor([k - 5], dtype=torch.int32, device=_dev())  # the last 4 rows are not written
+        kw = dict(group_index=gidx, inverse=inverse, m_limit=m_limit)
+        rows = slice(1, k - 4)
+        nrows = k - 5
+    else:
+        kw = {}
+        rows = slice(0, k)
+        nrows = k
+    res = {}
+    for flag in ('1', '0', '1'):
+        monkeypatch.setenv('SST_SEG_WORK', flag)
+        x = feats.clone().requires_grad_(True)
+        y = K.segment_reduce(x, plan, 'max', **kw)
+        y[:nrows].backward(torch.ones_like(y[:nrows]) * torch.arange(1, c + 1, device=_dev()))
+        res.setdefault(flag, []).append((y.detach()[:nrows].clone(), x.grad.clone()))
+    (y_new, g_new), (y_again, g_again) = res['1']
+    (y_old, g_old), = res['0']
+    assert torch.equal(y_new, y_old) and torch.equal(g_new, g_old)
+    assert torch.equal(y_new, y_again) and torch.equal(g_new, g_again)
+    inv = plan.inverse.long()[:, None].expand(n, c)
+    ref = torch.full((k, c), float('-inf'), device=_dev()).scatter_reduce(0, inv, feats, reduce='amax')
+    assert torch.equal(y_new, ref[rows])
+    monkeypatch.setenv('SST_SEG_WORK', '1')
+    want = torch.zeros((k, c), dtype=torch.float64, device=_dev()).index_add_(0, plan.inverse.long(), real.double())
+    cnt = torch.bincount(plan.inverse.long(), minlength=k).double()[:, None]
+    got_sum = K.segment_reduce(real, plan, 'sum', **kw)[:nrows]
+    got_mean = K.segment_reduce(real, plan, 'mean', **kw)[:nrows]
+    assert float((got_sum.double() - want[rows]).abs().max()) < 2e-3
+    assert float((got_mean.double() - (want / cnt)[rows]).abs().max()) < 1e-5
+    for _ in range(20):
+        assert torch.equal(got_sum, K.segment_reduce(real, plan, 'sum', **kw)[:nrows])
+    val, arg = K.segment_argmax(feats, plan)
+    assert torch.equal(val, ref)
+    assert torch.equal(feats.gather(0, arg.long()), ref)
