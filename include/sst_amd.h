@@ -122,11 +122,13 @@ int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uin
  * list d_work by the element kernel and reduced by one workgroup each in a second launch of fixed size; same results, same
  * tie rule.  d_work: int32 [work_capacity], work_capacity >= m + 4, its first 4 entries ZEROED ONCE by the caller; the second
  * kernel leaves them zeroed (reusable by every later call on the same stream).  d_work == NULL: exactly
- * sst_segment_reduce_fwd_f32. */
+ * sst_segment_reduce_fwd_f32.  d_scale / d_shift (optional, [c], c % 4 == 0, with a work list): every value is read as
+ * relu(x * scale + shift) - the BatchNorm + ReLU of DynamicVFE's last layer applied while its output is pooled
+ * (voxel_encoder.py:286-296), whose activated [n, c] matrix is then never written. */
 int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                     const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                     float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, int32_t* d_work,
-                                    int64_t work_capacity, void* stream);
+                                    int64_t work_capacity, const float* d_scale, const float* d_shift, void* stream);
 /* sst_segment_reduce_long_f32: the same reduction (all three modes, the arg-max tie rule) for groupings whose groups are
  * long and uneven (FSD's clusters, voxel_encoder.py:696-764 / backbones/sir.py:67-88: torch_scatter.scatter_max / scatter over
  * cluster ids): work is cut into tiles of sorted positions whatever group they belong to, groups inside a tile are written
@@ -544,6 +546,36 @@ int sst_bn_prepare_tracked_f32(const float* d_x, int64_t n, int c, int64_t ld, c
                                const float* d_bias, float eps, float* d_running_mean, float* d_running_var,
                                float factor, int64_t* d_num_batches_tracked, float* d_out4, void* d_workspace,
                                void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * (f1) DynamicVFE's layer stack with its passes fused into their neighbours (voxel_encoder.py:185-298, utils.py:107-144:
+ * per layer Linear(bias=False) -> BN -> ReLU -> scatter max -> cat with the pooled feature of the point's voxel).  Host side:
+ * sst_amd/voxel_encoder.py FusedVFE2.
+ *   sst_vfe_linear_moments_f32: first layer, y = x W^T for the K <= 16 decorated point channels (C % 4 == 0, C <= 256)
+ *     and the block partials of the batch-norm moments of y in d_workspace (sst_bn_workspace_bytes(n, c)) from the same pass;
+ *   sst_bn_prepare_from_partials_f32 / sst_bn_stats_from_partials_f32: the second halves of sst_bn_prepare_tracked_f32 /
+ *     sst_bn_stats_f32 on those partials (the naiveSyncBN all-reduce of ops/norm.py:50-58 sits between the halves);
+ *   sst_tall_linear_add_rows_f32x6 (below): second layer in its split-weight form;
+ *   sst_segment_reduce_fwd_work_f32 with d_scale / d_shift: BN + ReLU of the last layer applied while it is pooled;
+ *   sst_bn_act_pool_bwd_reduce_f32 / _apply_f32: sst_bn_act_bwd_reduce_f32 / _apply_f32 whose incoming gradient is
+ *     d_dy (dense, may be NULL) + the gradient d_dpool [G, ldp] of the max pooling, routed to the recorded arg-max rows
+ *     d_arg [G, c] through the point -> group map d_group [n] (negative: none): the dense matrix of the pooling's gradient
+ *     (scatter_points_cuda.cu:135-179) is never written.
+ * ---------------------------------------------------------------------------------------------- */
+int sst_vfe_linear_moments_f32(const float* d_x, int64_t ldx, int64_t n, int k, const float* d_w, int64_t ldw, int c,
+                               float* d_y, int64_t ldy, void* d_workspace, void* stream);
+int sst_bn_prepare_from_partials_f32(int64_t n, int c, const float* d_weight, const float* d_bias, float eps,
+                                     float* d_running_mean, float* d_running_var, float factor,
+                                     int64_t* d_num_batches_tracked, float* d_out4, void* d_workspace, void* stream);
+int sst_bn_stats_from_partials_f32(int64_t n, int c, float* d_mean, float* d_var, void* d_workspace, void* stream);
+int sst_bn_act_pool_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                                   const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
+                                   int act, const int32_t* d_group, const int32_t* d_arg, const float* d_dpool, int64_t ldp,
+                                   float* d_sum_g, float* d_sum_gxhat, void* d_workspace, void* stream);
+int sst_bn_act_pool_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                                  const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
+                                  const float* d_coef_a, const float* d_coef_b, float coef_scale, int act,
+                                  const int32_t* d_group, const int32_t* d_arg, const float* d_dpool, int64_t ldp, float* d_dx,
+                                  int64_t lddx, void* stream);
 /* The residual tail of a sparse basic block (mmdet3d/ops/spconv/... sparse_block.py:127-139: bn2 -> += identity -> ReLU)
  * in the batch-norm passes: y = act(x * scale + shift + res).  The *_res_* entries are the calls above with the identity
  * branch d_res [n, c] (row stride ldr; NULL = none) inside the activation; the backward apply also writes the gradient of
@@ -614,6 +646,12 @@ int sst_tall_linear_epi_f32x6(const float* d_x, int64_t ldx, const float* d_w, i
 int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_col, int64_t ldx, const float* d_w, int64_t ldw,
                                int trans_w, const float* d_bias, int64_t m, int k, int n, int epilogue, const float* d_aux_in,
                                float* d_aux_out, int64_t ldaux, float* d_y, int64_t ldy, void* stream);
+/* y = x W^T + rows[row_index[r]] (negative index: row 0), (k, n) = (64, 128): DynamicVFE's second layer on [point feature |
+ * pooled feature of the point's voxel] (voxel_encoder.py:286-294: cat + Linear(128 -> 128)) as point_feats W[:, :64]^T +
+ * (pooled W[:, 64:]^T)[voxel of the point].  sst_tall_linear_epi_f32x6 also takes (k, n) = (64, 128) and (128, 64). */
+int sst_tall_linear_add_rows_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int64_t m, int k, int n,
+                                   const float* d_rows, int64_t ldrows, const int32_t* d_row_index, float* d_y, int64_t ldy,
+                                   void* stream);
 int sst_tall_linear_ln_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias, int64_t m, int k,
                              const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
                              float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,

@@ -58,7 +58,17 @@ _SIGNATURES = {
     'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                            c_ptr, c_ptr]),
     'sst_segment_reduce_fwd_work_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
-                                                c_ptr, c_ptr, c_i64, c_ptr]),
+                                                c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sst_vfe_linear_moments_f32': (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_bn_prepare_from_partials_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr,
+                                                 c_ptr]),
+    'sst_bn_stats_from_partials_f32': (c_i32, [c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_bn_act_pool_bwd_reduce_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i32,
+                                               c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_bn_act_pool_bwd_apply_f32': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                              c_ptr, c_f32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'sst_tall_linear_add_rows_f32x6': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr,
+                                               c_i64, c_ptr]),
     'sst_segment_long_scratch_bytes': (c_i64, [c_i64, c_i64, c_i32]),
     'sst_segment_reduce_long_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr,
                                             c_ptr]),

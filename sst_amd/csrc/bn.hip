@@ -13,6 +13,30 @@ namespace {
 
 constexpr int kBnThreads = 256;
 
+// Optional SPARSE part of the incoming gradient: the gradient of a max pooling over point groups that sits right behind
+// this norm + activation (DynamicVFE: vfe layer -> scatter max, voxel_encoder.py:286-296).  Point `row` receives
+// dpool[v][ch] where v = group[row] >= 0 and arg[v][ch] == row (the arg-max rows the pooling recorded), nothing elsewhere;
+// the dense [N, C] matrix of that gradient (mostly zeros) is never written.  The dense part (dy) may then be absent.
+struct bn_pool_grad {
+  const int32_t* group;   // [N]
+  const int32_t* arg;     // [G, C]
+  const float* dpool;     // [G, ldp]
+  int64_t ldp;
+};
+__device__ __forceinline__ float4 bn_pool_part(const bn_pool_grad& pg, int64_t row, int c, int cc) {
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int v = pg.group[row];
+  if (v >= 0) {
+    const int4 a = *(const int4*)(pg.arg + (int64_t)v * c + cc * 4);
+    const float4 d = *(const float4*)(pg.dpool + (int64_t)v * pg.ldp + cc * 4);
+    g.x = a.x == (int)row ? d.x : 0.f;
+    g.y = a.y == (int)row ? d.y : 0.f;
+    g.z = a.z == (int)row ? d.z : 0.f;
+    g.w = a.w == (int)row ? d.w : 0.f;
+  }
+  return g;
+}
+
 // Block partials of two column moments.  MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g * xhat) with
 // g = dy * [act(x*scale+shift (+ res)) > 0 or no act], xhat = (x - mean) * invstd.
 // Thread (ry, cx) owns float4 column group cx and rows ry, ry + rpi, ...; partial[block][2c] doubles.
@@ -24,7 +48,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_moments_k(const float* __restri
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int act,
                                                           const float* __restrict__ res, int64_t ldr,
-                                                          int64_t rows_per_block, double* __restrict__ partial) {
+                                                          int64_t rows_per_block, double* __restrict__ partial,
+                                                          const bn_pool_grad pg) {
   extern __shared__ __attribute__((aligned(16))) double red[];  // [rpi][2c]
   const int c4 = c >> 2;
   const int rpi = kBnThreads / c4 > 0 ? kBnThreads / c4 : 1;
@@ -48,7 +73,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_moments_k(const float* __restri
           s2[0] += (double)v.x * v.x, s2[1] += (double)v.y * v.y;
           s2[2] += (double)v.z * v.z, s2[3] += (double)v.w * v.w;
         } else {
-          float4 g = *(const float4*)(dy + row * lddy + cc * 4);
+          float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (dy != nullptr) g = *(const float4*)(dy + row * lddy + cc * 4);
+          if (pg.group != nullptr) {
+            const float4 sp = bn_pool_part(pg, row, c, cc);
+            g.x += sp.x, g.y += sp.y, g.z += sp.z, g.w += sp.w;
+          }
           if (act) {
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (res != nullptr) r = *(const float4*)(res + row * ldr + cc * 4);
@@ -196,14 +226,19 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_k(const float* __restri
                                                           const float* __restrict__ ca, const float* __restrict__ cb,
                                                           float coef_scale, int act, const float* __restrict__ res,
                                                           int64_t ldr, float* __restrict__ dres, int64_t lddres,
-                                                          float* __restrict__ dx, int64_t lddx) {
+                                                          float* __restrict__ dx, int64_t lddx, const bn_pool_grad pg) {
   const int c4 = c >> 2;
   const int64_t total = n * c4;
   for (int64_t i = (int64_t)blockIdx.x * kBnThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBnThreads) {
     const int64_t row = i / c4;
     const int cc = (int)(i - row * c4);
     const float4 v = *(const float4*)(x + row * ldx + cc * 4);
-    float4 g = *(const float4*)(dy + row * lddy + cc * 4);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dy != nullptr) g = *(const float4*)(dy + row * lddy + cc * 4);
+    if (pg.group != nullptr) {
+      const float4 sp = bn_pool_part(pg, row, c, cc);
+      g.x += sp.x, g.y += sp.y, g.z += sp.z, g.w += sp.w;
+    }
     const float4 sc = *(const float4*)(scale + cc * 4);
     const float4 sh = *(const float4*)(shift + cc * 4);
     const float4 mu = *(const float4*)(mean + cc * 4);
@@ -227,6 +262,57 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_k(const float* __restri
     o.z = sc.z * (g.z - a.z - (v.z - mu.z) * is.z * b.z);
     o.w = sc.w * (g.w - a.w - (v.w - mu.w) * is.w * b.w);
     *(float4*)(dx + row * lddx + cc * 4) = o;
+  }
+}
+
+// y[N, C] = x[N, K] W^T for the FIRST layer of a point encoder (K = 10 / 11 decorated point channels, voxel_encoder.py:
+// 258-286; utils.py:107-144 Linear(bias=False) -> norm -> ReLU) together with the block partials of the batch-norm moments
+// of y - the matrix is written once and not read again for its statistics.  K <= 16: no matrix instruction pays (a 16 x 16 x 4
+// tile would be 60 % padding and the kernel is bound by the 4 C bytes it writes per point); W^T sits in LDS, thread (ry, cx)
+// owns float4 column group cx of the rows ry, ry + rpi, ... exactly like bn_moments_k, so the partials have its layout.
+__global__ __launch_bounds__(kBnThreads) void vfe_linear_smallk_k(const float* __restrict__ x, int64_t ldx, int64_t n, int k,
+                                                                 const float* __restrict__ w, int64_t ldw, int c,
+                                                                 float* __restrict__ y, int64_t ldy, int64_t rows_per_block,
+                                                                 double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double red[];  // [rpi][2c] doubles, then W^T [k][c] floats
+  const int c4 = c >> 2;
+  const int rpi = kBnThreads / c4;
+  float* wt = (float*)(red + (size_t)rpi * 2 * c);
+  for (int i = threadIdx.x; i < k * c; i += kBnThreads) {
+    const int kk = i / c, ch = i - kk * c;
+    wt[i] = w[(int64_t)ch * ldw + kk];
+  }
+  __syncthreads();
+  const int ry = threadIdx.x / c4, cx = threadIdx.x - ry * c4;
+  const int64_t beg = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t end = beg + rows_per_block < n ? beg + rows_per_block : n;
+  double s1[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
+  if (ry < rpi) {
+    for (int64_t row = beg + ry; row < end; row += rpi) {
+      const float* xr = x + row * ldx;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kk = 0; kk < k; ++kk) {
+        const float xv = xr[kk];
+        const float4 wv = *(const float4*)(wt + kk * c + cx * 4);
+        acc.x = fmaf(xv, wv.x, acc.x), acc.y = fmaf(xv, wv.y, acc.y), acc.z = fmaf(xv, wv.z, acc.z), acc.w = fmaf(xv, wv.w, acc.w);
+      }
+      *(float4*)(y + row * ldy + cx * 4) = acc;
+      s1[0] += acc.x, s1[1] += acc.y, s1[2] += acc.z, s1[3] += acc.w;
+      s2[0] += (double)acc.x * acc.x, s2[1] += (double)acc.y * acc.y;
+      s2[2] += (double)acc.z * acc.z, s2[3] += (double)acc.w * acc.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[(size_t)ry * 2 * c + cx * 4 + q] = s1[q];
+      red[(size_t)ry * 2 * c + c + cx * 4 + q] = s2[q];
+    }
+  }
+  __syncthreads();
+  double* dst = partial + (int64_t)blockIdx.x * 2 * c;
+  for (int i = threadIdx.x; i < 2 * c; i += kBnThreads) {
+    double t = 0.;
+    for (int r = 0; r < rpi; ++r) t += red[(size_t)r * 2 * c + i];
+    dst[i] = t;
   }
 }
 
@@ -263,7 +349,7 @@ int sst_bn_stats_f32(const float* d_x, int64_t n, int c, int64_t ld, float* d_me
   double* partial = (double*)d_workspace;
   const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
   hipLaunchKernelGGL(bn_moments_k<0>, dim3(grid), dim3(kBnThreads), lds, st, d_x, nullptr, n, c, ld, 0, nullptr,
-                     nullptr, nullptr, nullptr, 0, nullptr, 0, rpb, partial);
+                     nullptr, nullptr, nullptr, 0, nullptr, 0, rpb, partial, bn_pool_grad{nullptr, nullptr, nullptr, 0});
   hipLaunchKernelGGL(bn_finish_k<0>, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 1.0 / (double)n,
                      d_mean, d_var);
   SST_LAUNCH_CHECK();
@@ -313,7 +399,7 @@ int sst_bn_act_res_bwd_reduce_f32(const float* d_dy, const float* d_x, const flo
   double* partial = (double*)d_workspace;
   const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
   hipLaunchKernelGGL(bn_moments_k<1>, dim3(grid), dim3(kBnThreads), lds, st, d_x, d_dy, n, c, ldx, lddy, d_mean,
-                     d_invstd, d_scale, d_shift, act, d_res, ldr, rpb, partial);
+                     d_invstd, d_scale, d_shift, act, d_res, ldr, rpb, partial, bn_pool_grad{nullptr, nullptr, nullptr, 0});
   hipLaunchKernelGGL(bn_finish_k<1>, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 0.0, d_sum_g,
                      d_sum_gxhat);
   SST_LAUNCH_CHECK();
@@ -346,7 +432,7 @@ int sst_bn_act_res_bwd_apply_f32(const float* d_dy, const float* d_x, const floa
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(bn_act_bwd_k, dim3((unsigned)grid), dim3(kBnThreads), 0, (hipStream_t)stream, d_dy, d_x, n, c,
                      lddy, ldx, d_mean, d_invstd, d_scale, d_shift, d_coef_a, d_coef_b, coef_scale, act, d_res, ldr,
-                     d_dres, lddres, d_dx, lddx);
+                     d_dres, lddres, d_dx, lddx, bn_pool_grad{nullptr, nullptr, nullptr, 0});
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
@@ -372,7 +458,7 @@ int sst_bn_prepare_tracked_f32(const float* d_x, int64_t n, int c, int64_t ld, c
   double* partial = (double*)d_workspace;
   const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
   hipLaunchKernelGGL(bn_moments_k<0>, dim3(grid), dim3(kBnThreads), lds, st, d_x, nullptr, n, c, ld, 0, nullptr,
-                     nullptr, nullptr, nullptr, 0, nullptr, 0, rpb, partial);
+                     nullptr, nullptr, nullptr, 0, nullptr, 0, rpb, partial, bn_pool_grad{nullptr, nullptr, nullptr, 0});
   const float unbiased = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
   hipLaunchKernelGGL(bn_prepare_finish_k, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 1.0 / (double)n,
                      d_weight, d_bias, eps, d_running_mean, d_running_var, factor, unbiased, d_num_batches_tracked,
@@ -386,6 +472,108 @@ int sst_bn_prepare_f32(const float* d_x, int64_t n, int c, int64_t ld, const flo
                        void* d_workspace, void* stream) {
   return sst_bn_prepare_tracked_f32(d_x, n, c, ld, d_weight, d_bias, eps, d_running_mean, d_running_var, factor, nullptr,
                                     d_out4, d_workspace, stream);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Passes of DynamicVFE's layer stack fused with their neighbours (sst_amd/voxel_encoder.py: FusedVFE2).
+ * sst_vfe_linear_moments_f32: y = x W^T (K <= 16, C % 4 == 0, C <= 256) + the block partials of the column moments of y in
+ *   d_workspace (sst_bn_workspace_bytes(n, c) bytes), to be finished by one of the two entries below.
+ * sst_bn_prepare_from_partials_f32 / sst_bn_stats_from_partials_f32: the second halves of sst_bn_prepare_tracked_f32 /
+ *   sst_bn_stats_f32 on those partials (n = the row count the partials were taken over).
+ * ---------------------------------------------------------------------------------------------- */
+int sst_vfe_linear_moments_f32(const float* d_x, int64_t ldx, int64_t n, int k, const float* d_w, int64_t ldw, int c,
+                               float* d_y, int64_t ldy, void* d_workspace, void* stream) {
+  if (n < 0 || k < 1 || k > 16 || c < 4 || (c & 3) || c > 256 || ldx < k || ldw < k || ldy < c || (ldy & 3))
+    return SST_ERR_UNSUPPORTED;
+  if (n == 0) return SST_ERR_ARG;
+  if (!d_x || !d_w || !d_y || !d_workspace || ((uintptr_t)d_y & 15)) return SST_ERR_ARG;
+  int64_t rpb;
+  const int grid = moments_grid(n, &rpb);
+  const int rpi = kBnThreads / (c >> 2);
+  const size_t lds = (size_t)rpi * 2 * c * sizeof(double) + (size_t)k * c * sizeof(float);
+  hipLaunchKernelGGL(vfe_linear_smallk_k, dim3(grid), dim3(kBnThreads), lds, (hipStream_t)stream, d_x, ldx, n, k, d_w, ldw, c,
+                     d_y, ldy, rpb, (double*)d_workspace);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_bn_prepare_from_partials_f32(int64_t n, int c, const float* d_weight, const float* d_bias, float eps,
+                                     float* d_running_mean, float* d_running_var, float factor,
+                                     int64_t* d_num_batches_tracked, float* d_out4, void* d_workspace, void* stream) {
+  if (!bn_shape_ok(n, c)) return SST_ERR_UNSUPPORTED;
+  if (n == 0 || !d_out4 || !d_workspace) return SST_ERR_ARG;
+  int64_t rpb;
+  const int grid = moments_grid(n, &rpb);
+  const float unbiased = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_prepare_finish_k, dim3((c + 31) / 32), dim3(1024), 0, (hipStream_t)stream, (const double*)d_workspace,
+                     grid, c, 1.0 / (double)n, d_weight, d_bias, eps, d_running_mean, d_running_var, factor, unbiased,
+                     d_num_batches_tracked, d_out4);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_bn_stats_from_partials_f32(int64_t n, int c, float* d_mean, float* d_var, void* d_workspace, void* stream) {
+  if (!bn_shape_ok(n, c)) return SST_ERR_UNSUPPORTED;
+  if (n == 0 || !d_mean || !d_var || !d_workspace) return SST_ERR_ARG;
+  int64_t rpb;
+  const int grid = moments_grid(n, &rpb);
+  hipLaunchKernelGGL(bn_finish_k<0>, dim3((c + 31) / 32), dim3(1024), 0, (hipStream_t)stream, (const double*)d_workspace, grid,
+                     c, 1.0 / (double)n, d_mean, d_var);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+/* Backward of y = act(bn(x)) whose output was max-pooled over point groups right away: the incoming gradient is
+ * d_dy (dense, optional) + the pooled gradient d_dpool [G, ldp] routed to the recorded arg-max rows d_arg [G, c] through the
+ * point -> group map d_group [n] (negative: no group) - sst_bn_act_bwd_reduce_f32 / _apply_f32 without the dense [n, c]
+ * matrix of the pooling's gradient (scatter_points_cuda.cu:135-179 writes it; voxel_encoder.py:286-296). */
+int sst_bn_act_pool_bwd_reduce_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                                   const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
+                                   int act, const int32_t* d_group, const int32_t* d_arg, const float* d_dpool, int64_t ldp,
+                                   float* d_sum_g, float* d_sum_gxhat, void* d_workspace, void* stream) {
+  if (!bn_shape_ok(n, c) || ldx < c || (ldx & 3) || act < 0 || act > 1 || ldp < c || (ldp & 3)) return SST_ERR_UNSUPPORTED;
+  if (d_dy && (lddy < c || (lddy & 3) || ((uintptr_t)d_dy & 15))) return SST_ERR_UNSUPPORTED;
+  if (!d_sum_g || !d_sum_gxhat) return SST_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    SST_HIP(hipMemsetAsync(d_sum_g, 0, sizeof(float) * c, st));
+    SST_HIP(hipMemsetAsync(d_sum_gxhat, 0, sizeof(float) * c, st));
+    return SST_OK;
+  }
+  if (!d_x || !d_mean || !d_invstd || !d_scale || !d_shift || !d_workspace || !d_group || !d_arg || !d_dpool ||
+      ((uintptr_t)d_x & 15) || ((uintptr_t)d_arg & 15) || ((uintptr_t)d_dpool & 15))
+    return SST_ERR_ARG;
+  int64_t rpb;
+  const int grid = moments_grid(n, &rpb);
+  double* partial = (double*)d_workspace;
+  const size_t lds = (size_t)kBnThreads * 8 * sizeof(double);
+  hipLaunchKernelGGL(bn_moments_k<1>, dim3(grid), dim3(kBnThreads), lds, st, d_x, d_dy, n, c, ldx, lddy, d_mean, d_invstd,
+                     d_scale, d_shift, act, nullptr, 0, rpb, partial, bn_pool_grad{d_group, d_arg, d_dpool, ldp});
+  hipLaunchKernelGGL(bn_finish_k<1>, dim3((c + 31) / 32), dim3(1024), 0, st, partial, grid, c, 0.0, d_sum_g, d_sum_gxhat);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_bn_act_pool_bwd_apply_f32(const float* d_dy, const float* d_x, int64_t n, int c, int64_t lddy, int64_t ldx,
+                                  const float* d_mean, const float* d_invstd, const float* d_scale, const float* d_shift,
+                                  const float* d_coef_a, const float* d_coef_b, float coef_scale, int act,
+                                  const int32_t* d_group, const int32_t* d_arg, const float* d_dpool, int64_t ldp, float* d_dx,
+                                  int64_t lddx, void* stream) {
+  if (!bn_shape_ok(n, c) || ldx < c || lddx < c || (ldx & 3) || (lddx & 3) || act < 0 || act > 1 || ldp < c || (ldp & 3))
+    return SST_ERR_UNSUPPORTED;
+  if (d_dy && (lddy < c || (lddy & 3) || ((uintptr_t)d_dy & 15))) return SST_ERR_UNSUPPORTED;
+  if (n == 0) return SST_OK;
+  if (!d_x || !d_mean || !d_invstd || !d_scale || !d_shift || !d_coef_a || !d_coef_b || !d_dx || !d_group || !d_arg ||
+      !d_dpool || ((uintptr_t)d_x & 15) || ((uintptr_t)d_dx & 15) || ((uintptr_t)d_arg & 15) || ((uintptr_t)d_dpool & 15))
+    return SST_ERR_ARG;
+  const int64_t total = n * (c >> 2);
+  int64_t grid = sst_div_up(total, kBnThreads);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(bn_act_bwd_k, dim3((unsigned)grid), dim3(kBnThreads), 0, (hipStream_t)stream, d_dy, d_x, n, c, lddy, ldx,
+                     d_mean, d_invstd, d_scale, d_shift, d_coef_a, d_coef_b, coef_scale, act, nullptr, 0, nullptr, 0, d_dx, lddx,
+                     bn_pool_grad{d_group, d_arg, d_dpool, ldp});
+  SST_LAUNCH_CHECK();
+  return SST_OK;
 }
 
 }  // extern "C"

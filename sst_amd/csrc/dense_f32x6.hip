@@ -82,7 +82,8 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.3989422804014327f, e, phi);
 }
 
-enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5, kEpiAddLN = 6 };
+enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5, kEpiAddLN = 6,
+       kEpiAddRows = 7 };   // kEpiAddRows: + aux_in[row_index[row]] (ln.pos_idx; negative -> row 0): the split-weight VFE layer
 
 struct ln_epi {   // see csrc/dense_f32.hip
   const float* w;
@@ -260,11 +261,17 @@ __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
       v0 += *(const f32x4*)(aux_in + row * ldaux + n0);
       v1 += *(const f32x4*)(aux_in + row * ldaux + n0 + 4);
     }
+    if (EPI == kEpiAddRows) {
+      const int32_t src = ln.pos_idx[row];
+      const float* arow = aux_in + (int64_t)(src < 0 ? 0 : src) * ldaux + n0;
+      v0 += *(const f32x4*)(arow);
+      v1 += *(const f32x4*)(arow + 4);
+    }
     *(f32x4*)(Y + row * ldy + n0) = v0;
     *(f32x4*)(Y + row * ldy + n0 + 4) = v1;
   };
 
-  constexpr bool PREFETCH = K == 128;   // K = 256: no room for a second X tile beside three weight fragment sets
+  constexpr bool PREFETCH = K <= 128;   // K = 256: no room for a second X tile beside three weight fragment sets
   for (; r0 < r1; r0 += 16) {
     asm volatile("" ::: "memory");  // W fragments are re-read from LDS per row tile (never hoisted into registers)
     const bool more = r0 + 16 < r1;
@@ -388,6 +395,12 @@ int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_
     if (d_x2 && (x2_from_col % 128)) return SST_ERR_ARG;
     rc = dispatch_x6<128, 128>(epilogue, d_x, d_x2, x2_from_col / 128, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in,
                                d_aux_out, ldaux, st);
+  } else if (k == 64 && n == 128 && !d_x2) {      // the voxel encoder's second layer in its split-weight form
+    rc = dispatch_x6<64, 128>(epilogue, d_x, nullptr, 0, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in, d_aux_out, ldaux,
+                              st);
+  } else if (k == 128 && n == 64 && !d_x2) {      // ... and its data gradient
+    rc = dispatch_x6<128, 64>(epilogue, d_x, nullptr, 0, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in, d_aux_out, ldaux,
+                              st);
   } else if (k == 256 && n == 128) {
     if (d_x2 && (x2_from_col % 64)) return SST_ERR_ARG;
     rc = dispatch_x6<256, 64>(epilogue, d_x, d_x2, x2_from_col / 64, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in,
@@ -411,6 +424,28 @@ int sst_tall_linear_epi_f32x6(const float* d_x, int64_t ldx, const float* d_w, i
                               float* d_y, int64_t ldy, void* stream) {
   return sst_tall_linear_epi2_f32x6(d_x, nullptr, 0, ldx, d_w, ldw, trans_w, d_bias, m, k, n, epilogue, d_aux_in, d_aux_out, ldaux,
                                     d_y, ldy, stream);
+}
+
+/* y = x W^T + rows[row_index[r]] (negative index: row 0), (K, N) = (64, 128): DynamicVFE's second layer on
+ * [point feature | pooled feature of the point's voxel] (voxel_encoder.py:286-294: cat + Linear(128 -> 128)) as
+ * point_feats W[:, :64]^T + (pooled W[:, 64:]^T)[voxel of the point] - the concatenated matrix is never formed and the pooled half
+ * is multiplied once per voxel instead of once per point. */
+int sst_tall_linear_add_rows_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int64_t m, int k, int n,
+                                   const float* d_rows, int64_t ldrows, const int32_t* d_row_index, float* d_y, int64_t ldy,
+                                   void* stream) {
+  if (m < 0 || !d_w) return SST_ERR_ARG;
+  if (k != 64 || n != 128) return SST_ERR_UNSUPPORTED;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_y || !d_rows || !d_row_index || (ldx & 3) || (ldy & 3) || (ldw & 3) || (ldrows & 3) || !aligned16(d_x) ||
+      !aligned16(d_y) || !aligned16(d_w) || !aligned16(d_rows))
+    return SST_ERR_ARG;
+  ln_epi ln = ln_epi();
+  ln.pos_idx = d_row_index;
+  const int rc = launch_x6<64, 128, kEpiAddRows>(d_x, nullptr, 0, ldx, d_w, ldw, 0, nullptr, m, 128, d_y, ldy, d_rows, nullptr,
+                                                 ldrows, (hipStream_t)stream, ln);
+  if (rc) return rc;
+  SST_LAUNCH_CHECK();
+  return SST_OK;
 }
 
 int sst_tall_linear_ln_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias, int64_t m, int k,

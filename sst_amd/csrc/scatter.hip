@@ -17,6 +17,19 @@
 
 namespace {
 
+// Optional transform of every loaded value: relu(x * scale[ch] + shift[ch]) - the BatchNorm + ReLU of a DynamicVFE layer
+// applied while its output is pooled (voxel_encoder.py:286-296: vfe -> scatter max), so that the activated [N, C] matrix of
+// the LAST layer is never written (its backward pass recomputes the mask from the same expression: csrc/bn.hip).
+struct seg_xf {
+  const float* scale;
+  const float* shift;
+};
+__device__ __forceinline__ float4 seg_xf_apply(float4 x, const float4 sc, const float4 sh) {
+  x.x = x.x * sc.x + sh.x, x.y = x.y * sc.y + sh.y, x.z = x.z * sc.z + sh.z, x.w = x.w * sc.w + sh.w;
+  x.x = x.x > 0.f ? x.x : 0.f, x.y = x.y > 0.f ? x.y : 0.f, x.z = x.z > 0.f ? x.z : 0.f, x.w = x.w > 0.f ? x.w : 0.f;
+  return x;
+}
+
 // Work list of the long groups of a call (sst_segment_reduce_fwd_work_f32): [0] entries, [1] next entry to take, [2] workgroups
 // done, [3] unused, then the output rows of the long groups in the order the first kernel met them (the order has no
 // influence on the result: a group is reduced by one workgroup in a fixed order).
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
                                                            const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
                                                            int32_t n_rows, const int32_t* __restrict__ d_mlim, int skip_len,
-                                                           int32_t* __restrict__ work) {
+                                                           int32_t* __restrict__ work, const seg_xf xf) {
   if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int c4 = c >> 2;
   const int64_t total = m * c4;
@@ -89,6 +102,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
     int32_t a0 = n_rows, a1 = n_rows, a2 = n_rows, a3 = n_rows;
     bool first = true;
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xf.scale != nullptr) xsc = *(const float4*)(xf.scale + ch), xsh = *(const float4*)(xf.shift + ch);
     for (int p = beg; p < end; p += 4) {
       uint32_t row[4];
       float4 x[4];
@@ -96,6 +111,10 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
       for (int u = 0; u < 4; ++u) row[u] = perm[p + u < end ? p + u : end - 1];
 #pragma unroll
       for (int u = 0; u < 4; ++u) x[u] = *(const float4*)(feats + (int64_t)row[u] * c + ch);
+      if (xf.scale != nullptr) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = seg_xf_apply(x[u], xsc, xsh);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (p + u < end) {
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
 __device__ __forceinline__ void seg_block_group_v4(const float* __restrict__ feats, int c, const uint32_t* __restrict__ perm,
                                                    int beg, int end, int64_t g, int mode, float* __restrict__ out,
                                                    int32_t* __restrict__ argmax, int32_t n_rows, float4 (*lds_v2)[32],
-                                                   int4 (*lds_a2)[32]) {
+                                                   int4 (*lds_a2)[32], const seg_xf xf = seg_xf{nullptr, nullptr}) {
   float4* lds_v = &lds_v2[0][0];
   int4* lds_a = &lds_a2[0][0];
   const int c4 = c >> 2;
@@ -146,6 +165,8 @@ __device__ __forceinline__ void seg_block_group_v4(const float* __restrict__ fea
     float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
     int4 arg = make_int4(n_rows, n_rows, n_rows, n_rows);
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xf.scale != nullptr && live) xsc = *(const float4*)(xf.scale + 4 * q), xsh = *(const float4*)(xf.shift + 4 * q);
     for (int p = beg + part; p < end; p += 4 * parts) {
       uint32_t r[4];
       float4 x[4];
@@ -153,6 +174,10 @@ __device__ __forceinline__ void seg_block_group_v4(const float* __restrict__ fea
       for (int u = 0; u < 4; ++u) r[u] = perm[p + u * parts < end ? p + u * parts : p];
 #pragma unroll
       for (int u = 0; u < 4; ++u) x[u] = live ? *(const float4*)(feats + (int64_t)r[u] * c + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xf.scale != nullptr) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = seg_xf_apply(x[u], xsc, xsh);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (p + u * parts < end) {   // rows of a part are visited in ascending order: strict '>' keeps the smallest row on ties
@@ -274,11 +299,12 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_work_k(const float* __rest
                                                              const int32_t* __restrict__ offsets,
                                                              const int32_t* __restrict__ gidx, int mode,
                                                              float* __restrict__ out, int32_t* __restrict__ argmax,
-                                                             int32_t n_rows, int32_t* __restrict__ work) {
+                                                             int32_t n_rows, int32_t* __restrict__ work, const seg_xf xf) {
   __shared__ float4 lds_v[8][32];
   __shared__ int4 lds_a[8][32];
   __shared__ int s_take;
   const int count = __atomic_load_n(&work[0], __ATOMIC_RELAXED);
+  if (count == 0) return;   // no long group (the usual voxel grouping): the counters are zero as they stand, nothing to take or reset
   for (;;) {
     if (threadIdx.x == 0) s_take = atomicAdd(&work[1], 1);
     __syncthreads();
@@ -289,7 +315,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_work_k(const float* __rest
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
     const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
     if (V == 4)
-      seg_block_group_v4(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, lds_v, lds_a);
+      seg_block_group_v4(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, lds_v, lds_a, xf);
     else
       seg_block_group_v1(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, (float*)&lds_v[0][0], (int*)&lds_a[0][0]);
   }
@@ -862,15 +888,20 @@ int sst_segment_reduce_profile_next(void* start, void* stop) {
 int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                     const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                     float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, int32_t* d_work,
-                                    int64_t work_capacity, void* stream) {
+                                    int64_t work_capacity, const float* d_scale, const float* d_shift, void* stream) {
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_offsets || !d_out || (n > 0 && (!d_feats || !d_perm))) return SST_ERR_ARG;
   if (d_work != nullptr && work_capacity < m + kSegWorkHdr) return SST_ERR_ARG;
+  if ((d_scale != nullptr) != (d_shift != nullptr)) return SST_ERR_ARG;
+  const seg_xf xf{d_scale, d_shift};
+  const seg_xf no_xf{nullptr, nullptr};
   hipEvent_t e0 = g_seg_ev[0], e1 = g_seg_ev[1];
   g_seg_ev[0] = g_seg_ev[1] = nullptr;
   const bool timed = e0 != nullptr && e1 != nullptr;
   const bool v4 = (c & 3) == 0 && (((uintptr_t)d_feats | (uintptr_t)d_out | (uintptr_t)d_argmax) & 15) == 0 && n > 0;
+  // the transform exists in the float4 kernels with the work list only (what the voxel encoders call)
+  if (d_scale != nullptr && (!v4 || d_work == nullptr || (((uintptr_t)d_scale | (uintptr_t)d_shift) & 15))) return SST_ERR_UNSUPPORTED;
   constexpr int kLongGroup = 16;       // without a work list: groups longer than this go to one workgroup each when n >= 8 m
   constexpr int kWorkGroupLen = 32;    // with a work list: groups longer than this, whatever the average
   constexpr int kWorkGrid = 512;
@@ -881,16 +912,16 @@ int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, cons
       if (timed)
         hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0, d_feats, c,
                               d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen,
-                              d_work);
+                              d_work, xf);
       else
         hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                           d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, d_work);
+                           d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, d_work, xf);
       if (timed)
         hipExtLaunchKernelGGL(seg_reduce_fwd_work_k<4>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
-                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, xf);
       else
         hipLaunchKernelGGL(seg_reduce_fwd_work_k<4>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, xf);
     } else {
       const int grid = sst_grid_1d(m * c, 256);
       if (timed)
@@ -902,10 +933,10 @@ int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, cons
                            d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, d_work);
       if (timed)
         hipExtLaunchKernelGGL(seg_reduce_fwd_work_k<1>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
-                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, no_xf);
       else
         hipLaunchKernelGGL(seg_reduce_fwd_work_k<1>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work);
+                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, no_xf);
     }
     SST_LAUNCH_CHECK();
     return SST_OK;
@@ -918,11 +949,11 @@ int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, cons
     if (timed)
       hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, split ? nullptr : e1, 0,
                             d_feats, c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit,
-                            split ? kLongGroup : 0, (int32_t*)nullptr);
+                            split ? kLongGroup : 0, (int32_t*)nullptr, no_xf);
     else
       hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
                          d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, split ? kLongGroup : 0,
-                         (int32_t*)nullptr);
+                         (int32_t*)nullptr, no_xf);
     if (split) {
       const int grid_b = (int)(m < 65536 ? m : 65536);
       if (timed)
@@ -950,7 +981,7 @@ int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uin
                                const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, void* stream) {
   return sst_segment_reduce_fwd_work_f32(d_feats, n, c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax,
-                                         d_m_limit, nullptr, 0, stream);
+                                         d_m_limit, nullptr, 0, nullptr, nullptr, stream);
 }
 
 // geometry of seg_tiles_k for a width: channel vectors, row lanes per workgroup

@@ -32,6 +32,12 @@ class FramePlan(object):
         return K.segment_reduce(feats, self.groups, mode, group_index=self.gidx, inverse=self.coors_map,
                                 m_limit=self.d_counts[0:1])
 
+    def raw_max(self, feats, scale_shift=None):
+        """(max, arg-max rows) over the kept voxels without an autograd node; scale_shift: values are read as
+        relu(x * scale + shift) (vfe_fused.FusedVFE2)"""
+        return K._segment_reduce_fwd(feats, self.groups.perm, self.groups.offsets, self.gidx.numel(), K.REDUCE['max'], True,
+                                     self.gidx, self.d_counts[0:1], self.groups, scale_shift)
+
     def group_sum(self, part):
         """Gradient of the hand-back ``pooled[coors_map]`` (points of a discarded group read row 0): the CSR sum over the kept
         voxels, plus the rows of the discarded groups added to row 0 - in a fixed order, where an index_add with float

@@ -187,7 +187,9 @@ def _long_work_list(plan, m, dev):
     return buf
 
 
-def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=None, m_limit=None, plan=None):
+def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=None, m_limit=None, plan=None,
+                        scale_shift=None):
+    """scale_shift = (scale [c], shift [c]): values are read as relu(x * scale + shift) (needs a plan and c % 4 == 0)"""
     n, c = feats.shape
     out = torch.empty((m, c), dtype=torch.float32, device=feats.device)
     argmax = torch.empty((m, c), dtype=torch.int32, device=feats.device) if want_argmax else None
@@ -198,6 +200,8 @@ def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=
     rc = _lib.load().sst_segment_reduce_fwd_work_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets),
                                                      _lib.ptr(group_index), m, mode, _lib.ptr(out), _lib.ptr(argmax),
                                                      _lib.ptr(m_limit), _lib.ptr(work), 0 if work is None else work.numel(),
+                                                     _lib.ptr(scale_shift[0]) if scale_shift is not None else None,
+                                                     _lib.ptr(scale_shift[1]) if scale_shift is not None else None,
                                                      _lib.stream_ptr())
     _lib.check(rc, 'sst_segment_reduce_fwd_work_f32')
     return out, argmax

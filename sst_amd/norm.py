@@ -124,24 +124,11 @@ def _bn_kernel_ok(bn, x):
             and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
-def batch_norm_act(bn, x, relu=False, residual=None):
-    """``relu(bn(x))`` / ``bn(x)`` / ``relu(bn(x) + residual)`` for a BatchNorm1d-family module on [N, C] point features.
-
-    CUDA float32 inputs go through the fused kernels (csrc/bn.hip) with the module's exact bookkeeping:
-    nn.BatchNorm1d (torch/nn/modules/batchnorm.py: biased batch variance for the output, unbiased for
-    running_var, num_batches_tracked) or, for NaiveSyncBatchNorm1d in distributed training, the reference's
-    averaging of per-rank [mean || meansqr] and its ``running += momentum * (stat - running)`` update
-    (mmdet3d/ops/norm.py:50-66).  Anything else (CPU tensors, 3-D inputs) takes the module's own forward."""
-    if residual is not None and not (residual.shape == x.shape and residual.dtype == torch.float32 and residual.is_cuda
-                                     and residual.stride(1) == 1 and residual.stride(0) % 4 == 0
-                                     and residual.data_ptr() % 16 == 0):
-        y = batch_norm_act(bn, x, relu=False) + residual
-        return torch.relu(y) if relu else y
-    if not _bn_kernel_ok(bn, x):
-        y = bn(x)
-        if residual is not None:
-            y = y + residual
-        return torch.relu(y) if relu else y
+def bn_prepare(bn, x, partials=None):
+    """The statistics half of ``batch_norm_act``: -> (prep [4, C] = mean, invstd, scale, shift; batch_stats; count; sync) with
+    the module's bookkeeping (running statistics, num_batches_tracked, naiveSyncBN's cross-rank average).
+    ``partials``: a workspace that already holds the block partials of the column moments of ``x`` (written by the kernel that
+    produced x: sst_vfe_linear_moments_f32) - x is then not read again for them."""
     from . import _lib
     n, c = x.shape
     world = _dist_world()
@@ -168,24 +155,34 @@ def batch_norm_act(bn, x, relu=False, residual=None):
                 else:
                     with torch.no_grad():
                         bn.num_batches_tracked.add_(1)
-        xd = x.detach()
-        ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
-        rc = lib.sst_bn_prepare_tracked_f32(_lib.ptr(xd), n, c, xd.stride(0),
-                                            _lib.ptr(bn.weight.detach()) if bn.weight is not None else None,
-                                            _lib.ptr(bn.bias.detach()) if bn.bias is not None else None, float(bn.eps),
-                                            _lib.ptr(bn.running_mean) if update else None,
-                                            _lib.ptr(bn.running_var) if update else None, float(factor),
-                                            _lib.ptr(tracked) if tracked is not None else None, _lib.ptr(prep),
-                                            _lib.ptr(ws), _lib.stream_ptr())
-        _lib.check(rc, 'sst_bn_prepare_tracked_f32')
+        w_p = _lib.ptr(bn.weight.detach()) if bn.weight is not None else None
+        b_p = _lib.ptr(bn.bias.detach()) if bn.bias is not None else None
+        rm_p, rv_p = (_lib.ptr(bn.running_mean), _lib.ptr(bn.running_var)) if update else (None, None)
+        if partials is not None:
+            rc = lib.sst_bn_prepare_from_partials_f32(n, c, w_p, b_p, float(bn.eps), rm_p, rv_p, float(factor),
+                                                      _lib.ptr(tracked) if tracked is not None else None, _lib.ptr(prep),
+                                                      _lib.ptr(partials), _lib.stream_ptr())
+            _lib.check(rc, 'sst_bn_prepare_from_partials_f32')
+        else:
+            xd = x.detach()
+            ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
+            rc = lib.sst_bn_prepare_tracked_f32(_lib.ptr(xd), n, c, xd.stride(0), w_p, b_p, float(bn.eps), rm_p, rv_p,
+                                                float(factor), _lib.ptr(tracked) if tracked is not None else None,
+                                                _lib.ptr(prep), _lib.ptr(ws), _lib.stream_ptr())
+            _lib.check(rc, 'sst_bn_prepare_tracked_f32')
     else:
         if batch_stats:  # naiveSyncBN across ranks
-            xd = x.detach()
             stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
-            ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
-            rc = lib.sst_bn_stats_f32(_lib.ptr(xd), n, c, xd.stride(0), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
-                                      _lib.ptr(ws), _lib.stream_ptr())
-            _lib.check(rc, 'sst_bn_stats_f32')
+            if partials is not None:
+                rc = lib.sst_bn_stats_from_partials_f32(n, c, _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(partials),
+                                                        _lib.stream_ptr())
+                _lib.check(rc, 'sst_bn_stats_from_partials_f32')
+            else:
+                xd = x.detach()
+                ws = _lib.workspace(lib.sst_bn_workspace_bytes(n, c), x.device)
+                rc = lib.sst_bn_stats_f32(_lib.ptr(xd), n, c, xd.stride(0), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
+                                          _lib.ptr(ws), _lib.stream_ptr())
+                _lib.check(rc, 'sst_bn_stats_f32')
             mean, var = stats[0], stats[1]
             vec = torch.cat([mean, var + mean * mean], dim=0)  # [mean || meansqr], ops/norm.py:53
             dist.all_reduce(vec, async_op=False)
@@ -203,6 +200,28 @@ def batch_norm_act(bn, x, relu=False, residual=None):
             scale = invstd if bn.weight is None else bn.weight * invstd
             shift = -mean * scale if bn.bias is None else bn.bias - mean * scale
             prep[0], prep[1], prep[2], prep[3] = mean, invstd, scale, shift
+    return prep, batch_stats, count, sync
+
+
+def batch_norm_act(bn, x, relu=False, residual=None):
+    """``relu(bn(x))`` / ``bn(x)`` / ``relu(bn(x) + residual)`` for a BatchNorm1d-family module on [N, C] point features.
+
+    CUDA float32 inputs go through the fused kernels (csrc/bn.hip) with the module's exact bookkeeping:
+    nn.BatchNorm1d (torch/nn/modules/batchnorm.py: biased batch variance for the output, unbiased for
+    running_var, num_batches_tracked) or, for NaiveSyncBatchNorm1d in distributed training, the reference's
+    averaging of per-rank [mean || meansqr] and its ``running += momentum * (stat - running)`` update
+    (mmdet3d/ops/norm.py:50-66).  Anything else (CPU tensors, 3-D inputs) takes the module's own forward."""
+    if residual is not None and not (residual.shape == x.shape and residual.dtype == torch.float32 and residual.is_cuda
+                                     and residual.stride(1) == 1 and residual.stride(0) % 4 == 0
+                                     and residual.data_ptr() % 16 == 0):
+        y = batch_norm_act(bn, x, relu=False) + residual
+        return torch.relu(y) if relu else y
+    if not _bn_kernel_ok(bn, x):
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+    prep, batch_stats, count, sync = bn_prepare(bn, x)
     return _BatchNormActFn.apply(x, bn.weight, bn.bias, prep, bool(relu), batch_stats, count, sync, residual)
 
 

@@ -92,6 +92,14 @@ class ScatterPlan(object):
         self._keep_i32 = keep_idx.to(torch.int32) if keep_idx is not None else None
         self._dropped_i32 = dropped_idx   # int32 indices of the discarded groups (their points read voxel row 0), or None
 
+    def raw_max(self, feats, scale_shift=None):
+        """(max, arg-max rows) over the kept voxels without an autograd node (vfe_fused.FusedVFE2)"""
+        if self.keep_idx is None:
+            return K._segment_reduce_fwd(feats, self.plan.perm, self.plan.offsets[self.first:], self.plan.m - self.first,
+                                         K.REDUCE['max'], True, None, None, self.plan, scale_shift)
+        return K._segment_reduce_fwd(feats, self.plan.perm, self.plan.offsets, self._keep_i32.numel(), K.REDUCE['max'], True,
+                                     self._keep_i32, None, self.plan, scale_shift)
+
     def group_sum(self, part):
         """gradient of ``pooled[coors_map]`` without atomics: CSR sum over the kept voxels + the discarded groups' rows on
         row 0 (frame_plan.FramePlan.group_sum)"""

@@ -28,6 +28,7 @@ from .dense import add_layer_norm, tall_linear
 from .norm import batch_norm_act, build_norm_layer
 from .registry import VOXEL_ENCODERS
 from .sst_ops import build_mlp, get_activation_layer, plan_of_inverse, unique_with_plan
+from .vfe_fused import fused_vfe2, fused_vfe2_ok
 from .voxel import DynamicScatter, build_scatter_plan
 
 
@@ -194,6 +195,7 @@ class DynamicVFE(_PointGroupEncoder):
         self._init_common(in_channels, feat_channels, with_distance, with_cluster_center, with_voxel_center, voxel_size,
                           point_cloud_range, mode, return_point_feats, fusion_layer)
         self.reference_compat = reference_compat
+        self.fused_stack = True     # False: layer by layer through the modules (what the fused node is tested against)
         self.vfe_layers = nn.ModuleList([DynamicVFELayer(cin, cout, norm_cfg)
                                          for cin, cout in self._layer_widths(feat_channels)])
         self.num_vfe = len(self.vfe_layers)
@@ -229,6 +231,10 @@ class DynamicVFE(_PointGroupEncoder):
         coors = coors.contiguous()
         grouping = _VoxelGrouping(scatter_plan if scatter_plan is not None else self.scatter_plan(coors))
         x = self._decorate(features, coors, grouping)
+        if self.fused_stack and fused_vfe2_ok(self, x, grouping.plan):
+            # the two-layer stack as one node over fused passes (vfe_fused.py): split-weight second layer, norm + activation
+            # applied while pooling, the pooling's gradient routed inside the batch-norm backward
+            return fused_vfe2(self, x, grouping.plan), grouping.coors
         point_feats, pooled = self._encode(x, grouping, 'max' if self.mode == 'max' else 'mean')
         if self.return_point_feats:
             return point_feats
