@@ -298,6 +298,9 @@ int sst_window_plan_i32(const int32_t* d_vcoors, const int32_t* d_grid, int64_t 
  * Q,K,V,O: [M, n_heads*16] fp32 with row strides ldq/ldk/ldv/ldo (elements, multiples of 4; base
  * pointers 16-byte aligned).  d_lse [M, n_heads] fp32: log-sum-exp of each softmax row (for backward).
  *   max_tokens: upper bound on tokens per window the caller guarantees (0 = unknown).
+ *   d_tok == NULL: the tokens of window w are the rows winoff[w] .. winoff[w+1] - 1 themselves (feature rows kept in
+ *     window order, as sst_window_plan_i32 numbers them for the unshifted partition): no token list is read; taken by the
+ *     register-resident kernels only (impl 0 / 3, 0 < max_tokens <= 144, aligned operands), else SST_ERR_UNSUPPORTED.
  *   impl: 0 = auto: register-resident MFMA kernels (wave = window x head, no LDS) for windows <= 144
  *             tokens, generic VALU kernel above that;
  *         1 = generic VALU kernel for every window (validation path);

@@ -268,6 +268,7 @@ class SSTError(RuntimeError):
     pass
 
 
+SST_ERR_ARG, SST_ERR_UNSUPPORTED, SST_ERR_KEYSPACE = -1, -2, -3
 _ERR = {-1: 'SST_ERR_ARG (invalid argument)', -2: 'SST_ERR_UNSUPPORTED', -3: 'SST_ERR_KEYSPACE'}
 
 

@@ -325,7 +325,7 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = tok[beg + (p < t ? p : t - 1)];
+    tk[i] = tok != nullptr ? tok[beg + (p < t ? p : t - 1)] : beg + (p < t ? p : t - 1);   // no list: the window's rows are beg .. beg + t - 1
   }
   float4 kf[NT];
   float vf[NT][4];
@@ -638,7 +638,7 @@ __device__ __forceinline__ void sra_bwd_dq_body(const float* __restrict__ Q, con
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = tok[beg + (p < t ? p : t - 1)];  // padded positions repeat the last token: loads are unconditional
+    tk[i] = tok != nullptr ? tok[beg + (p < t ? p : t - 1)] : beg + (p < t ? p : t - 1);   // no list: the window's rows are beg .. beg + t - 1
   }
   float4 kf[NT], vf[NT];
   float kc[NT][4];
@@ -729,7 +729,7 @@ __device__ __forceinline__ void sra_bwd_dkv_body(const float* __restrict__ Q, co
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = tok[beg + (p < t ? p : t - 1)];
+    tk[i] = tok != nullptr ? tok[beg + (p < t ? p : t - 1)] : beg + (p < t ? p : t - 1);   // no list: the window's rows are beg .. beg + t - 1
   }
   auto tok_at = [&](int i, int within) -> uint32_t {
     int sel = tk[0];
@@ -924,7 +924,7 @@ __device__ __forceinline__ void sra_bwd_fused_body(
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = tok[beg + (p < t ? p : t - 1)];  // padded positions repeat the last token: every load is unconditional
+    tk[i] = tok != nullptr ? tok[beg + (p < t ? p : t - 1)] : beg + (p < t ? p : t - 1);   // no list: the window's rows are beg .. beg + t - 1
   }
   auto tok_at = [&](int i, int within) -> uint32_t {  // token id of window position 16 i + within
     int sel = tk[0];
@@ -1191,10 +1191,14 @@ int sst_sra_attn_fwd_f32(const float* d_q, const float* d_k, const float* d_v, i
                          void* stream) {
   if (n_windows < 0 || n_heads < 1 || impl < 0 || impl > 3) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
-  if (!d_q || !d_k || !d_v || !d_tok || !d_winoff || !d_o || !d_lse) return SST_ERR_ARG;
+  if (!d_q || !d_k || !d_v || !d_winoff || !d_o || !d_lse) return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bool mfma_ok = (n_heads % kGH == 0) && ((ldq | ldk | ldv | ldo) % 4 == 0) && aligned16(d_q) &&
                        aligned16(d_k) && aligned16(d_v) && aligned16(d_o);
+  // d_tok == NULL: the rows of window w are d_winoff[w] .. d_winoff[w + 1] - 1 themselves (window-major feature rows: one
+  // dependent load less per wave); only the register-resident kernels take it
+  if (!d_tok && (!mfma_ok || (impl != 0 && impl != 3) || max_tokens <= 0 || max_tokens > kMaxTilesMfma * 16))
+    return SST_ERR_UNSUPPORTED;
   // (the register-resident kernels use 32-bit element offsets: callers keep n_tokens * ld < 2^31)
   if (impl == 1 || !mfma_ok) {
     hipLaunchKernelGGL(sra_fwd_generic_k, dim3((unsigned)n_windows), dim3(256), 0, st, d_q, d_k, d_v, ldq, ldk, ldv,
@@ -1257,11 +1261,13 @@ int sst_sra_attn_bwd_f32(const float* d_q, const float* d_k, const float* d_v, c
                          int64_t lddq, int64_t lddk, int64_t lddv, void* d_workspace, void* stream) {
   if (n_windows < 0 || n_tokens < 0 || n_heads < 1 || impl < 0 || impl > 3) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
-  if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_tok || !d_winoff || !d_dq || !d_dk || !d_dv)
+  if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_winoff || !d_dq || !d_dk || !d_dv)
     return SST_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const bool mfma_ok = (n_heads % kGH == 0) && ((ldq | ldk | ldv | ldo | lddo) % 4 == 0) && aligned16(d_q) &&
                        aligned16(d_k) && aligned16(d_v) && aligned16(d_o) && aligned16(d_do);
+  if (!d_tok && (!mfma_ok || (impl != 0 && impl != 3) || max_tokens <= 0 || max_tokens > kMaxTilesMfma * 16))
+    return SST_ERR_UNSUPPORTED;   // see sst_sra_attn_fwd_f32
   const bool out_vec_ok = ((lddq | lddk | lddv) % 4 == 0) && aligned16(d_dq) && aligned16(d_dk) && aligned16(d_dv);
   const int cap_tiles = max_tokens > 0 ? (max_tokens + 15) / 16 : 1 << 30;
   const bool all_generic = (impl == 1) || !mfma_ok;

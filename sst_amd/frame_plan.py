@@ -78,7 +78,7 @@ class FramePlan(object):
         table = input_layer.pos_table_cached(dim, voxel_feats.dtype, dev)
         for i in range(2):
             info[f'sra_plan_shift{i}'] = K.WindowPlan(toks[i], winoffs[i], n_win[i], m_keep,
-                                                      min(cap, max(1, t_max[i])))
+                                                      min(cap, max(1, t_max[i])), rows_in_window_order=(i == 0))
             info[f'pos_index_shift{i}'] = (self.posidx0, self.posidx1)[i][:m_keep]
             info[f'pos_embed_shift{i}'] = K.gather_rows(table, info[f'pos_index_shift{i}']) if self.want_pos_rows else None
         info['pos_table'] = table

@@ -383,12 +383,21 @@ def region_batching(win0, win1, win_bits, levels):
 # ----------------------------------------------------------------------------------------------
 class WindowPlan(object):
     """Window CSR consumed by the SRA kernels: tokens of window w are tok[winoff[w]:winoff[w+1]]."""
-    __slots__ = ('tok', 'winoff', 'n_windows', 'n_tokens', 'max_tokens', '_order')
+    __slots__ = ('tok', 'winoff', 'n_windows', 'n_tokens', 'max_tokens', '_order', 'rows_in_window_order')
 
-    def __init__(self, tok, winoff, n_windows, n_tokens, max_tokens):
+    def __init__(self, tok, winoff, n_windows, n_tokens, max_tokens, rows_in_window_order=False):
         self.tok, self.winoff = tok, winoff
         self.n_windows, self.n_tokens, self.max_tokens = int(n_windows), int(n_tokens), int(max_tokens)
         self._order = None
+        # tok == arange(n_tokens): the feature rows themselves are in window order (the frame plan numbers the kept voxels by
+        # their place in the unshifted partition), so the fp32 register-resident kernels skip the token list - one dependent
+        # load less at the head of every wave
+        self.rows_in_window_order = bool(rows_in_window_order)
+
+    def tok_ptr(self, impl):
+        if self.rows_in_window_order and impl in (0, 3) and 0 < self.max_tokens <= 144:
+            return None
+        return _lib.ptr(self.tok)
 
     @property
     def order(self):
@@ -471,10 +480,16 @@ def _sra_fwd(q, k, v, plan, n_heads, scale, impl):
         o = torch.empty((m, c), dtype=torch.float32, device=q.device)
     lse = torch.empty((m, n_heads), dtype=torch.float32, device=q.device)
     order = plan.order
-    rc = _bracket('sra_fwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_fwd_ord_f32(
-        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _row_stride(q), _row_stride(k), _row_stride(v),
-        _lib.ptr(plan.tok), _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None, plan.n_windows,
-        n_heads, float(scale), plan.max_tokens, impl, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr()))
+
+    def call(tok_p):
+        return _bracket('sra_fwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_fwd_ord_f32(
+            _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _row_stride(q), _row_stride(k), _row_stride(v),
+            tok_p, _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None, plan.n_windows,
+            n_heads, float(scale), plan.max_tokens, impl, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr()))
+    tok_p = plan.tok_ptr(impl)
+    rc = call(tok_p)
+    if rc == _lib.SST_ERR_UNSUPPORTED and tok_p is None:   # layouts only the generic kernels take: they want the list
+        rc = call(_lib.ptr(plan.tok))
     _lib.check(rc, 'sst_sra_attn_fwd_ord_f32')
     return o, lse
 
@@ -484,12 +499,18 @@ def _sra_bwd(q, k, v, o, lse, grad_o, plan, n_heads, scale, impl, dq, dk, dv):
     lib = _lib.load()
     ws = _lib.workspace(lib.sst_sra_attn_bwd_workspace_bytes(m, n_heads), q.device)
     order = plan.order
-    rc = _bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_sra_attn_bwd_ord_f32(
-        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(grad_o), _lib.ptr(lse), _row_stride(q),
-        _row_stride(k), _row_stride(v), o.stride(0), grad_o.stride(0), _lib.ptr(plan.tok),
-        _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None, plan.n_windows, m, n_heads, scale,
-        plan.max_tokens, impl, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk),
-        _row_stride(dv), _lib.ptr(ws), _lib.stream_ptr()))
+
+    def call(tok_p):
+        return _bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_sra_attn_bwd_ord_f32(
+            _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(grad_o), _lib.ptr(lse), _row_stride(q),
+            _row_stride(k), _row_stride(v), o.stride(0), grad_o.stride(0), tok_p,
+            _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None, plan.n_windows, m, n_heads, scale,
+            plan.max_tokens, impl, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk),
+            _row_stride(dv), _lib.ptr(ws), _lib.stream_ptr()))
+    tok_p = plan.tok_ptr(impl)
+    rc = call(tok_p)
+    if rc == _lib.SST_ERR_UNSUPPORTED and tok_p is None:
+        rc = call(_lib.ptr(plan.tok))
     _lib.check(rc, 'sst_sra_attn_bwd_ord_f32')
 
 

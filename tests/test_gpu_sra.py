@@ -395,3 +395,28 @@ def test_checkpoint_blocks_recompute_inside_the_fused_chain(mode, monkeypatch):
     assert torch.equal(o0, o1) and torch.equal(g0, g1)
     for n in p0:
         assert torch.equal(p0[n], p1[n]), n
+
+
+@pytest.mark.parametrize('cap', [60, 80, 100, 144])
+def test_window_ordered_rows_need_no_token_list(cap):
+    """feature rows already in window order (the frame plan's unshifted partition): the kernels take d_tok = NULL and return
+    the same bits as with the explicit list arange(M), forward and backward"""
+    from sst_amd import kernels as K
+    torch.manual_seed(cap)
+    sizes = torch.randint(1, cap + 1, (300,))
+    winoff = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(torch.int32).to(DEV)
+    m = int(sizes.sum())
+    tok = torch.arange(m, dtype=torch.int32, device=DEV)
+    qkv = torch.randn(m, 384, device=DEV)
+    do = torch.randn(m, 128, device=DEV)
+    q, k, v = qkv[:, :128], qkv[:, 128:256], qkv[:, 256:]
+    outs = []
+    for flag in (False, True):
+        plan = K.WindowPlan(tok, winoff, 300, m, cap, rows_in_window_order=flag)
+        assert (plan.tok_ptr(0) is None) == flag
+        o, lse = K._sra_fwd(q, k, v, plan, 8, 0.25, 0)
+        dqkv = torch.empty_like(qkv)
+        K._sra_bwd(q, k, v, o, lse, do, plan, 8, 0.25, 0, dqkv[:, :128], dqkv[:, 128:256], dqkv[:, 256:])
+        outs.append((o, lse, dqkv))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
