@@ -100,8 +100,17 @@ class GradBucketReducer(object):
         self._sent[b] = True
         self._next = b + 1
         if self.world > 1:
+            chunk = self.flat[start:end]
+            if self._avg and b == 0:
+                # ReduceOp.AVG exists in RCCL builds that follow NCCL >= 2.10; one that lacks it refuses at the call: sum and
+                # divide instead (decided on the FIRST bucket of a step, so every bucket of the step is treated alike)
+                try:
+                    self._work.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                    return
+                except (RuntimeError, ValueError, TypeError):
+                    self._avg = False
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            self._work.append(dist.all_reduce(self.flat[start:end], op=op, group=self.group, async_op=True))
+            self._work.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
 
     def finish(self):
         """send what is left, wait for every bucket, average, point every ``p.grad`` at its slot"""
