@@ -29,11 +29,11 @@ prof sst python $R/bench.py --steps 16 --warmup 6 $SIDE --no-bf16-leg
 python $R/tools/front_of_step.py /tmp/pp_sst/p_kernel_trace.csv > $OUT/sst_front_of_step.txt 2>&1
 prof sst_bf16 python $R/bench.py --precision bf16 --steps 16 --warmup 6 $SIDE
 prof sst_lidar python $R/bench.py --cloud lidar --steps 16 --warmup 6 $SIDE --no-bf16-leg
-prof fsd python $R/bench.py --workload fsd --steps 5 --warmup 3 --no-cpu-baseline
+prof fsd python $R/bench.py --workload fsd --steps 5 --warmup 3 --no-cpu-baseline --no-f32x3-leg
 gzip -c /tmp/pp_fsd/p_kernel_trace.csv > $OUT/fsd_kernel_trace.csv.gz
 python $R/tools/family_cost.py $OUT/fsd_kernel_trace.csv.gz 9 0.0 45 > $OUT/fsd_family_cost.txt 2>&1
 rm -f $OUT/fsd_kernel_trace.csv.gz
-prof fsdv2 python $R/bench.py --workload fsdv2 --steps 5 --warmup 3 --no-cpu-baseline
+prof fsdv2 python $R/bench.py --workload fsdv2 --steps 5 --warmup 3 --no-cpu-baseline --no-f32x3-leg
 cd $R
 bash tools/collect_sra_traffic.sh gpurun_out/$TAG/traffic > $OUT/traffic.log 2>&1
 ls -la $OUT | head -50
