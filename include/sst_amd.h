@@ -649,9 +649,9 @@ int sst_tall_linear_epi_f32x6(const float* d_x, int64_t ldx, const float* d_w, i
 int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_col, int64_t ldx, const float* d_w, int64_t ldw,
                                int trans_w, const float* d_bias, int64_t m, int k, int n, int epilogue, const float* d_aux_in,
                                float* d_aux_out, int64_t ldaux, float* d_y, int64_t ldy, void* stream);
-/* y = x W^T + rows[row_index[r]] (negative index: row 0), (k, n) = (64, 128): DynamicVFE's second layer on [point feature |
+/* y = x W^T + rows[row_index[r]] (negative index: row 0), (k, n) = (64, 128) or (64, 64): DynamicVFE's second layer on [point feature |
  * pooled feature of the point's voxel] (voxel_encoder.py:286-294: cat + Linear(128 -> 128)) as point_feats W[:, :64]^T +
- * (pooled W[:, 64:]^T)[voxel of the point].  sst_tall_linear_epi_f32x6 also takes (k, n) = (64, 128) and (128, 64). */
+ * (pooled W[:, 64:]^T)[voxel of the point].  sst_tall_linear_epi_f32x6 also takes (k, n) = (64, 128), (64, 64) and (128, 64). */
 int sst_tall_linear_add_rows_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int64_t m, int k, int n,
                                    const float* d_rows, int64_t ldrows, const int32_t* d_row_index, float* d_y, int64_t ldy,
                                    void* stream);

@@ -398,6 +398,9 @@ int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_
   } else if (k == 64 && n == 128 && !d_x2) {      // the voxel encoder's second layer in its split-weight form
     rc = dispatch_x6<64, 128>(epilogue, d_x, nullptr, 0, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in, d_aux_out, ldaux,
                               st);
+  } else if (k == 64 && n == 64 && !d_x2) {       // ... with 64 output channels (FSD's DynamicScatterVFE, feat_channels [64, 64])
+    rc = dispatch_x6<64, 64>(epilogue, d_x, nullptr, 0, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in, d_aux_out, ldaux,
+                             st);
   } else if (k == 128 && n == 64 && !d_x2) {      // ... and its data gradient
     rc = dispatch_x6<128, 64>(epilogue, d_x, nullptr, 0, ldx, d_w, ldw, trans_w, d_bias, m, n, d_y, ldy, d_aux_in, d_aux_out, ldaux,
                               st);
@@ -427,22 +430,24 @@ int sst_tall_linear_epi_f32x6(const float* d_x, int64_t ldx, const float* d_w, i
 }
 
 /* y = x W^T + rows[row_index[r]] (negative index: row 0), (K, N) = (64, 128): DynamicVFE's second layer on
- * [point feature | pooled feature of the point's voxel] (voxel_encoder.py:286-294: cat + Linear(128 -> 128)) as
+ * [point feature | pooled feature of the point's voxel] (voxel_encoder.py:286-294: cat + Linear(128 -> 128 or 64)) as
  * point_feats W[:, :64]^T + (pooled W[:, 64:]^T)[voxel of the point] - the concatenated matrix is never formed and the pooled half
  * is multiplied once per voxel instead of once per point. */
 int sst_tall_linear_add_rows_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int64_t m, int k, int n,
                                    const float* d_rows, int64_t ldrows, const int32_t* d_row_index, float* d_y, int64_t ldy,
                                    void* stream) {
   if (m < 0 || !d_w) return SST_ERR_ARG;
-  if (k != 64 || n != 128) return SST_ERR_UNSUPPORTED;
+  if (k != 64 || (n != 128 && n != 64)) return SST_ERR_UNSUPPORTED;
   if (m == 0) return SST_OK;
   if (!d_x || !d_y || !d_rows || !d_row_index || (ldx & 3) || (ldy & 3) || (ldw & 3) || (ldrows & 3) || !aligned16(d_x) ||
       !aligned16(d_y) || !aligned16(d_w) || !aligned16(d_rows))
     return SST_ERR_ARG;
   ln_epi ln = ln_epi();
   ln.pos_idx = d_row_index;
-  const int rc = launch_x6<64, 128, kEpiAddRows>(d_x, nullptr, 0, ldx, d_w, ldw, 0, nullptr, m, 128, d_y, ldy, d_rows, nullptr,
-                                                 ldrows, (hipStream_t)stream, ln);
+  const int rc = n == 128 ? launch_x6<64, 128, kEpiAddRows>(d_x, nullptr, 0, ldx, d_w, ldw, 0, nullptr, m, 128, d_y, ldy, d_rows,
+                                                            nullptr, ldrows, (hipStream_t)stream, ln)
+                          : launch_x6<64, 64, kEpiAddRows>(d_x, nullptr, 0, ldx, d_w, ldw, 0, nullptr, m, 64, d_y, ldy, d_rows,
+                                                           nullptr, ldrows, (hipStream_t)stream, ln);
   if (rc) return rc;
   SST_LAUNCH_CHECK();
   return SST_OK;

@@ -45,7 +45,7 @@ def _float_ptr(t, offset_elems=0):
 
 
 def fused_vfe2_ok(encoder, x, plan):
-    """two layers Linear(k <= 16 -> 64) / Linear(128 -> 128), BatchNorm1d-family norms with affine parameters, ReLU, max
+    """two layers Linear(k <= 16 -> 64) / Linear(128 -> 128 or 64), BatchNorm1d-family norms with affine parameters, ReLU, max
     pooling, fp32 CUDA input without a gradient, a plan that offers the raw pooling and the hand-back gradient"""
     layers = getattr(encoder, 'vfe_layers', None)
     if layers is None or len(layers) != 2 or encoder.mode != 'max' or encoder.return_point_feats:
@@ -59,7 +59,7 @@ def fused_vfe2_ok(encoder, x, plan):
             return False
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(0) > 0 and not x.requires_grad
             and x.size(1) == l0.linear.in_features and x.size(1) <= 16 and l0.linear.out_features == 64
-            and l1.linear.in_features == 128 and l1.linear.out_features == 128
+            and l1.linear.in_features == 128 and l1.linear.out_features in (64, 128)
             and l0.linear.weight.is_contiguous() and l1.linear.weight.is_contiguous()
             and hasattr(plan, 'raw_max') and hasattr(plan, 'group_sum'))
 
@@ -155,3 +155,20 @@ def fused_vfe2(encoder, x, plan):
     l0, l1 = encoder.vfe_layers
     return FusedVFE2.apply(x, l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight, l1.norm.bias,
                            plan, l0.norm, l1.norm)
+
+
+class UniquePlanAdapter(object):
+    """what FusedVFE2 needs of a grouping, on a plain sorted-unique (kernels.UniquePlan): the grouping of scatter_v2 /
+    DynamicScatterVFE (ops/sst/sst_ops.py:151-182) - every group is kept, no point is discarded"""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.coors_map = plan.inverse
+        self.num_voxels = plan.m
+
+    def raw_max(self, feats, scale_shift=None):
+        p = self.plan
+        return K._segment_reduce_fwd(feats, p.perm, p.offsets, p.m, K.REDUCE['max'], True, None, None, p, scale_shift)
+
+    def group_sum(self, part):
+        return K.segment_reduce(part, self.plan, 'sum')

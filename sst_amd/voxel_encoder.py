@@ -28,7 +28,7 @@ from .dense import add_layer_norm, tall_linear
 from .norm import batch_norm_act, build_norm_layer
 from .registry import VOXEL_ENCODERS
 from .sst_ops import build_mlp, get_activation_layer, plan_of_inverse, unique_with_plan
-from .vfe_fused import fused_vfe2, fused_vfe2_ok
+from .vfe_fused import UniquePlanAdapter, fused_vfe2, fused_vfe2_ok
 from .voxel import DynamicScatter, build_scatter_plan
 
 
@@ -264,6 +264,12 @@ class DynamicScatterVFE(DynamicVFE):
         features = features.float()
         grouping = _UniqueGrouping(coors)   # one sorted-unique whether or not unique_once is set: it is never redone
         x = self._decorate(features, coors, grouping, cluster_div=self.rel_dist_scaler, mean_of_xyz_only=True)
+        fused_plan = UniquePlanAdapter(grouping.plan) if self.fused_stack else None
+        if fused_plan is not None and fused_vfe2_ok(self, x, fused_plan):
+            voxel_feats = fused_vfe2(self, x, fused_plan)      # the layer stack as one node (vfe_fused.py)
+            if return_inv:
+                return voxel_feats, grouping.coors, grouping.unq_inv
+            return voxel_feats, grouping.coors
         point_feats, pooled = self._encode(x, grouping, self.mode)
         if self.return_point_feats:
             return point_feats

@@ -216,3 +216,75 @@ def test_split_weight_second_layer(m, rows):
         f32 = dy @ w[:, off:off + 64]
         err = float((dx.double() - ref).abs().max())
         assert err <= 2.0 * max(float((f32.double() - ref).abs().max()), 1e-6), (off, err)
+
+
+@pytest.mark.parametrize('feat_channels', [[64, 64], [64, 128]])
+@pytest.mark.parametrize('train', [True, False])
+def test_scatter_vfe_fused_equals_layerwise(feat_channels, train):
+    """DynamicScatterVFE (FSD's voxel encoder: plain sorted-unique grouping, every group kept; configs/fsd: [64, 64],
+    FSDv2's virtual-voxel encoder: [64, 128]) through the fused node against its layer-wise modules"""
+    import sst_amd
+    torch.manual_seed(5)
+    vs, rng = (0.25, 0.25, 0.2), [-40.0, -40.0, -2.0, 40.0, 40.0, 4.0]
+    fused = sst_amd.build_voxel_encoder(dict(
+        type='DynamicScatterVFE', in_channels=5, feat_channels=feat_channels, voxel_size=vs, with_cluster_center=True,
+        with_voxel_center=True, point_cloud_range=rng, norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01),
+        unique_once=True)).to(DEV)
+    plain = copy.deepcopy(fused)
+    plain.fused_stack = False
+    fused.train(train), plain.train(train)
+    n = 50000
+    pts = torch.rand(n, 5, device=DEV) * torch.tensor([80.0, 80.0, 6.0, 1.0, 1.0], device=DEV) \
+        + torch.tensor([-40.0, -40.0, -2.0, 0.0, 0.0], device=DEV)
+    pts[:8000, :3] = pts[:8000, :3] * 0.02 + 3.0                                  # a crowded corner: long groups
+    coors = torch.cat([torch.zeros(n, 1, device=DEV), ((pts[:, [2, 1, 0]] - torch.tensor([-2.0, -40.0, -40.0], device=DEV))
+                                                         / torch.tensor([0.2, 0.25, 0.25], device=DEV)).floor()], 1).long()
+    out_f, vc_f, inv_f = fused(pts, coors, return_inv=True)
+    out_p, vc_p, inv_p = plain(pts, coors, return_inv=True)
+    assert 'FusedVFE2' in type(out_f.grad_fn).__name__ and 'FusedVFE2' not in type(out_p.grad_fn).__name__
+    assert torch.equal(vc_f, vc_p) and torch.equal(inv_f, inv_p) and out_f.shape == out_p.shape
+    scale = float(out_p.detach().abs().max())
+    assert float((out_f - out_p).detach().abs().max()) <= 2e-5 * max(scale, 1.0)
+    g = torch.randn(out_p.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    (out_f * g).sum().backward()
+    (out_p * g).sum().backward()
+    for (name, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+        ref = float(pb.grad.abs().max())
+        assert float((pa.grad - pb.grad).abs().max()) <= 1e-2 * max(ref, 1e-6), name    # see the DynamicVFE case above
+
+
+@pytest.mark.parametrize('c1', [64, 128])
+def test_scatter_vfe_fused_routes_gradients_exactly(c1):
+    """the bit-for-bit routing check (integer data, evaluation-mode norms with unit variance) on the sorted-unique grouping"""
+    import sst_amd
+    from sst_amd import voxel_encoder as VE
+    from sst_amd.vfe_fused import UniquePlanAdapter, fused_vfe2
+    torch.manual_seed(c1)
+    fused = sst_amd.build_voxel_encoder(dict(
+        type='DynamicScatterVFE', in_channels=5, feat_channels=[64, c1], voxel_size=(0.25, 0.25, 0.2), with_cluster_center=True,
+        with_voxel_center=True, point_cloud_range=[-40.0, -40.0, -2.0, 40.0, 40.0, 4.0],
+        norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01), unique_once=True)).to(DEV).eval()
+    gen = torch.Generator().manual_seed(c1)
+    with torch.no_grad():
+        for l in fused.vfe_layers:
+            l.linear.weight.copy_(torch.randint(-2, 3, l.linear.weight.shape, generator=gen).float())
+            l.norm.weight.copy_(torch.randint(1, 3, l.norm.weight.shape, generator=gen).float())
+            l.norm.bias.copy_(torch.randint(-3, 4, l.norm.bias.shape, generator=gen).float())
+            l.norm.running_mean.copy_(torch.randint(-2, 3, l.norm.running_mean.shape, generator=gen).float())
+            l.norm.running_var.fill_(1.0)
+            l.norm.eps = 0.0
+    plain = copy.deepcopy(fused)
+    n = 30000
+    ids = torch.cat([torch.randint(0, 9000, (n - 6000,), generator=gen), torch.full((6000,), 17)])      # one group of 6 000
+    coors = torch.stack([torch.zeros(n, dtype=torch.long), ids // 100, ids % 100, torch.zeros(n, dtype=torch.long)], 1).to(DEV)
+    grouping = VE._UniqueGrouping(coors)
+    x = torch.randint(-3, 4, (n, fused.vfe_layers[0].linear.in_features), generator=gen).float().to(DEV)
+    out_f = fused_vfe2(fused, x, UniquePlanAdapter(grouping.plan))
+    _, pooled = plain._encode(x, grouping, 'max')
+    assert torch.equal(out_f, pooled[-1])
+    g = torch.randint(-2, 3, out_f.shape, generator=gen).float().to(DEV)
+    out_f.backward(g)
+    pooled[-1].backward(g)
+    for (name, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+        assert float(pb.grad.abs().max()) < 2 ** 24, name
+        assert torch.equal(pa.grad, pb.grad), (name, float((pa.grad - pb.grad).abs().max()))
