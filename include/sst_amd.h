@@ -828,6 +828,15 @@ int64_t sst_spconv_conv_os_f32x6_workspace_bytes(int kvol, int cin, int cout);
 int sst_spconv_conv_os_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
                              int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
                              const int32_t* d_tile_order, void* d_workspace, void* stream);
+/* sst_spconv_conv_os_rows_f32x6: the same call, told the size of its workspace.  With
+ * sst_spconv_conv_os_f32x6_workspace_bytes_rows(kvol, cin, cout, m) bytes (packed weights + partial tiles) a THIN level - a few
+ * thousand rows: 30-200 (row tile, column group) units for 256 CUs, each walking all 27 offsets alone - has its offsets dealt
+ * out over up to 8 workgroups per unit, whose partial tiles are added in a fixed order by a second launch (deterministic; same
+ * results up to the association of the per-offset sums).  d_workspace 256-byte aligned. */
+int64_t sst_spconv_conv_os_f32x6_workspace_bytes_rows(int kvol, int cin, int cout, int64_t m);
+int sst_spconv_conv_os_rows_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
+                                  int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
+                                  const int32_t* d_tile_order, void* d_workspace, int64_t workspace_bytes, void* stream);
 /*   sst_spconv_wgrad_os_f32: the same filter gradient as sst_spconv_wgrad_f32 (indiceConvBackward, spconv_ops.h:359-446)
  *     with the gathered rows staged through LDS transposed, 64 x 64 blocks of dW[k], 2048-pair chunks (csrc/spconv_os.hip).
  *     cin % 4 == 0, cout % 4 == 0, row strides % 4 == 0, 16-byte aligned operands; SST_ERR_UNSUPPORTED otherwise. */

@@ -184,6 +184,9 @@ _SIGNATURES = {
                                          c_i32, c_ptr, c_ptr, c_ptr]),
     'sst_spconv_conv_os_f32x6': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i64,
                                          c_i32, c_ptr, c_ptr, c_ptr]),
+    'sst_spconv_conv_os_rows_f32x6': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_i64,
+                                              c_i32, c_ptr, c_ptr, c_i64, c_ptr]),
+    'sst_spconv_conv_os_f32x6_workspace_bytes_rows': (c_i64, [c_i32, c_i32, c_i32, c_i64]),
     'sst_spconv_conv_os_f32x6_workspace_bytes': (c_i64, [c_i32, c_i32, c_i32]),
     'sst_spconv_os_tile_work_i32': (c_i32, [c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     'sst_spconv_maxpool_fwd_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),

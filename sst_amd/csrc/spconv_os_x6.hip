@@ -97,7 +97,8 @@ template <int NCT>
 __global__ __launch_bounds__(256, NCT == 4 ? 2 : 1) void sp_conv_os_x6_k(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ map, int64_t m, int kvol,
     const unsigned* __restrict__ wp, int cin, int cout, const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
-    int n_units, int n_cg, int n_cc, int xcd_chunk, int vec_store, const int32_t* __restrict__ tile_order) {
+    int n_units, int n_cg, int n_cc, int xcd_chunk, int vec_store, const int32_t* __restrict__ tile_order, int n_split,
+    float* __restrict__ partial) {
   constexpr int ROWS = 64;
   constexpr int SLAB = 64 * 4 * 2 * NCT * 3;   // 32-bit words of one packed W slab (three part images)
   constexpr int WREG = SLAB / 4 / 256;   // 16-byte pieces of a slab per thread
@@ -108,8 +109,12 @@ __global__ __launch_bounds__(256, NCT == 4 ? 2 : 1) void sp_conv_os_x6_k(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int unit = ((slot / xcd_chunk) * 8 + xcd) * xcd_chunk + slot % xcd_chunk;
-  if (unit >= n_units) return;  // uniform
+  const int unit_s = ((slot / xcd_chunk) * 8 + xcd) * xcd_chunk + slot % xcd_chunk;
+  if (unit_s >= n_units * n_split) return;  // uniform
+  // THIN levels (a few thousand rows: 30-200 (tile, column group) units for 256 CUs, each walking 27 offsets x the channel
+  // chunks alone): the offsets are dealt out over n_split workgroups per unit (offset k belongs to workgroup k % n_split), which
+  // write partial tiles that sp_x6_split_reduce_k adds in a fixed order.  n_split = 1: the plain kernel.
+  const int unit = unit_s / n_split, split = unit_s - unit * n_split;
   const int pos = unit / n_cg, cg = unit - pos * n_cg;
   const int tile = tile_order ? tile_order[pos] : pos;
   const int64_t r0 = (int64_t)tile * ROWS;
@@ -136,8 +141,13 @@ __global__ __launch_bounds__(256, NCT == 4 ? 2 : 1) void sp_conv_os_x6_k(
     }
   }
   __syncthreads();
-  const unsigned wave_live = live_w[wave];
-  const unsigned live = live_w[0] | live_w[1] | live_w[2] | live_w[3];
+  unsigned mine = 0xffffffffu;
+  if (n_split > 1) {
+    mine = 0u;
+    for (int k = split; k < 32; k += n_split) mine |= 1u << k;
+  }
+  const unsigned wave_live = live_w[wave] & mine;
+  const unsigned live = (live_w[0] | live_w[1] | live_w[2] | live_w[3]) & mine;
   const int wave_row = wave * 16;
 
   f32x4 acc[NCT], acl[NCT];      // leading product | the five corrections
@@ -224,6 +234,16 @@ __global__ __launch_bounds__(256, NCT == 4 ? 2 : 1) void sp_conv_os_x6_k(
   // ---- epilogue: lane = (row l15 of the wave's block, 4 consecutive columns at 4 kq of every column tile) ----
   const int64_t row = r0 + wave_row + l15;
   if (row >= m) return;
+  if (n_split > 1) {   // partial tile of this workgroup's offsets: [split][row][cout padded to 4], no bias
+    const int64_t cpad = (int64_t)((cout + 3) & ~3);
+    float* dst = partial + ((int64_t)split * m + row) * cpad;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int n = cg * 16 * NCT + 16 * ct + 4 * kq;
+      if (n < cout) *(f32x4*)(dst + n) = acc[ct] + acl[ct];
+    }
+    return;
+  }
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
     const int n = cg * 16 * NCT + 16 * ct + 4 * kq;
@@ -240,6 +260,50 @@ __global__ __launch_bounds__(256, NCT == 4 ? 2 : 1) void sp_conv_os_x6_k(
   }
 }
 
+// y[row][n] = bias[n] + sum over the splits, in split order (deterministic)
+__global__ __launch_bounds__(256) void sp_x6_split_reduce_k(const float* __restrict__ partial, int64_t m, int cout, int n_split,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int64_t ldy) {
+  const int64_t cpad = (int64_t)((cout + 3) & ~3), c4 = cpad >> 2;
+  const int64_t total = m * c4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / c4;
+    const int n = (int)(e - row * c4) * 4;
+    f32x4 v = *(const f32x4*)(partial + row * cpad + n);
+    for (int sp = 1; sp < n_split; ++sp) v += *(const f32x4*)(partial + ((int64_t)sp * m + row) * cpad + n);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (n + t < cout) y[row * ldy + n + t] = v[t] + (bias ? bias[n + t] : 0.f);
+  }
+}
+
+// tile shape and offset split of a call
+struct x6_cfg {
+  int nct, n_cg, n_cc, n_split;
+  int64_t n_tiles, pack_words;
+};
+x6_cfg x6_pick(int64_t m, int kvol, int cin, int cout) {
+  x6_cfg c;
+  c.n_tiles = sst_div_up(m, 64);
+  c.nct = cout <= 64 ? 4 : 8;
+  if (c.nct == 8 && c.n_tiles * sst_div_up(cout, 128) < 2048) c.nct = 4;   // as sp_conv_os_k's os_pick
+  c.n_cg = (int)sst_div_up(cout, 16 * c.nct);
+  c.n_cc = (int)sst_div_up(cin, kX6Chunk);
+  c.pack_words = (int64_t)kvol * c.n_cg * c.n_cc * (64 * 4 * 2 * c.nct * 3);
+  // offsets dealt out over workgroups while the launch has fewer than ~3 workgroups per CU and an offset's worth of work is
+  // left to each (SST_SPCONV_X6_SPLIT overrides: 1 = never)
+  static int env = -1;
+  if (env < 0) {
+    const char* e = getenv("SST_SPCONV_X6_SPLIT");
+    env = e ? atoi(e) : 0;
+  }
+  const int64_t units = c.n_tiles * c.n_cg;
+  int s = 1;
+  while (s < 8 && units * s * 2 <= 1024 && kvol >= 2 * s * 2) s *= 2;
+  if (env >= 1 && env <= 16) s = env < kvol ? env : kvol;
+  c.n_split = s;
+  return c;
+}
+
 }  // namespace
 
 extern "C" {
@@ -251,30 +315,45 @@ int64_t sst_spconv_conv_os_f32x6_workspace_bytes(int kvol, int cin, int cout) {
   const int64_t slabs8 = (int64_t)kvol * sst_div_up(cout, 128) * sst_div_up(cin, kX6Chunk) * (64 * 4 * 2 * 8 * 3);
   return (slabs4 > slabs8 ? slabs4 : slabs8) * 4 + 256;
 }
+// ... plus the partial tiles of a call on m rows when its offsets are dealt out over several workgroups (thin levels):
+// what sst_spconv_conv_os_rows_f32x6 wants for its own choice of the split
+int64_t sst_spconv_conv_os_f32x6_workspace_bytes_rows(int kvol, int cin, int cout, int64_t m) {
+  const int64_t pack = sst_spconv_conv_os_f32x6_workspace_bytes(kvol, cin, cout);
+  if (pack < 0 || m < 0) return SST_ERR_ARG;
+  const x6_cfg c = x6_pick(m > 0 ? m : 1, kvol, cin, cout);
+  const int64_t part = c.n_split > 1 ? (int64_t)c.n_split * m * ((cout + 3) & ~3) * 4 : 0;
+  return sst_align_up(pack, 256) + part + 256;
+}
 
-// same arguments as sst_spconv_conv_os_f32 (workspace: sst_spconv_conv_os_f32x6_workspace_bytes); tile_cfg must be 0
-int sst_spconv_conv_os_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
-                             int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
-                             const int32_t* d_tile_order, void* d_workspace, void* stream) {
+// same arguments as sst_spconv_conv_os_f32 + the size of the workspace: sst_spconv_conv_os_f32x6_workspace_bytes_rows bytes let
+// the call deal the offsets of a thin level out over several workgroups; with less (sst_spconv_conv_os_f32x6_workspace_bytes:
+// the packed weights alone) it runs unsplit.  tile_cfg must be 0.
+int sst_spconv_conv_os_rows_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
+                                  int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
+                                  const int32_t* d_tile_order, void* d_workspace, int64_t workspace_bytes, void* stream) {
   if (m < 0 || kvol < 1 || cin < 1 || cout < 1 || ldx < cin || ldy < cout || tile_cfg != 0) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_x || !d_map || !d_w || !d_y || !d_workspace) return SST_ERR_ARG;
-  if (kvol > kX6MaxK || (cin & 3) || (ldx & 3) || (((uintptr_t)d_x) & 15) || (((uintptr_t)d_workspace) & 15) ||
+  if (kvol > kX6MaxK || (cin & 3) || (ldx & 3) || (((uintptr_t)d_x) & 15) || (((uintptr_t)d_workspace) & 255) ||
       m > 0x3fffffff)
     return SST_ERR_UNSUPPORTED;
-  const int64_t n_tiles = sst_div_up(m, 64);
-  int nct = cout <= 64 ? 4 : 8;
-  if (nct == 8 && n_tiles * sst_div_up(cout, 128) < 2048) nct = 4;   // as sp_conv_os_k's os_pick
-  const int n_cg = (int)sst_div_up(cout, 16 * nct), n_cc = (int)sst_div_up(cin, kX6Chunk);
-  const int64_t n_units = n_tiles * n_cg;
-  if (n_units > 0x3fffffff) return SST_ERR_UNSUPPORTED;
+  x6_cfg c = x6_pick(m, kvol, cin, cout);
+  const int64_t pack_bytes = sst_align_up(sst_spconv_conv_os_f32x6_workspace_bytes(kvol, cin, cout), 256);
+  const int64_t cpad = (cout + 3) & ~3;
+  while (c.n_split > 1 && pack_bytes + (int64_t)c.n_split * m * cpad * 4 > workspace_bytes) c.n_split >>= 1;
+  if (workspace_bytes < c.pack_words * 4) return SST_ERR_ARG;
+  const int nct = c.nct, n_cg = c.n_cg, n_cc = c.n_cc;
+  const int64_t n_units = c.n_tiles * n_cg;
+  if (n_units * c.n_split > 0x3fffffff) return SST_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   unsigned* wp = (unsigned*)d_workspace;
+  float* partial = c.n_split > 1 ? (float*)((char*)d_workspace + pack_bytes) : nullptr;
   const int64_t lanes = (int64_t)kvol * n_cg * n_cc * 2 * nct * 64;
   hipLaunchKernelGGL(sp_x6_pack_w_k, dim3(sst_grid_1d(lanes, 256)), dim3(256), 0, st, d_w, kvol, cin, cout, trans_w, nct, n_cg,
                      n_cc, wp);
-  const int chunk = n_units >= 64 * (int64_t)kX6XcdChunk ? kX6XcdChunk : 1;
-  const dim3 grid((unsigned)(sst_div_up(n_units, 8 * chunk) * 8 * chunk));
+  const int64_t wgs = n_units * c.n_split;
+  const int chunk = wgs >= 64 * (int64_t)kX6XcdChunk ? kX6XcdChunk : 1;
+  const dim3 grid((unsigned)(sst_div_up(wgs, 8 * chunk) * 8 * chunk));
   const int vec_store = ((ldy & 3) == 0 && (((uintptr_t)d_y) & 15) == 0 && (!d_bias || (((uintptr_t)d_bias) & 15) == 0)) ? 1 : 0;
   const int lds = (2 * 64 * 4 * 2 * nct * 3 + kvol * 64 + 4) * (int)sizeof(unsigned);
   if (nct == 4) {
@@ -285,7 +364,7 @@ int sst_spconv_conv_os_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map
       attr4 = true;
     }
     hipLaunchKernelGGL(sp_conv_os_x6_k<4>, grid, dim3(256), lds, st, d_x, ldx, d_map, m, kvol, wp, cin, cout, d_bias, d_y, ldy,
-                       (int)n_units, n_cg, n_cc, chunk, vec_store, d_tile_order);
+                       (int)n_units, n_cg, n_cc, chunk, vec_store, d_tile_order, c.n_split, partial);
   } else {
     static bool attr8 = false;
     if (!attr8) {
@@ -294,10 +373,24 @@ int sst_spconv_conv_os_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map
       attr8 = true;
     }
     hipLaunchKernelGGL(sp_conv_os_x6_k<8>, grid, dim3(256), lds, st, d_x, ldx, d_map, m, kvol, wp, cin, cout, d_bias, d_y, ldy,
-                       (int)n_units, n_cg, n_cc, chunk, vec_store, d_tile_order);
+                       (int)n_units, n_cg, n_cc, chunk, vec_store, d_tile_order, c.n_split, partial);
   }
+  if (c.n_split > 1)
+    hipLaunchKernelGGL(sp_x6_split_reduce_k, dim3(sst_grid_1d(m * (cpad >> 2), 256)), dim3(256), 0, st, partial, m, cout, c.n_split,
+                       d_bias, d_y, ldy);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+// the unsplit call (workspace: sst_spconv_conv_os_f32x6_workspace_bytes)
+int sst_spconv_conv_os_f32x6(const float* d_x, int64_t ldx, const int32_t* d_map, int64_t m, int kvol, const float* d_w,
+                             int cin, int cout, int trans_w, const float* d_bias, float* d_y, int64_t ldy, int tile_cfg,
+                             const int32_t* d_tile_order, void* d_workspace, void* stream) {
+  return sst_spconv_conv_os_rows_f32x6(d_x, ldx, d_map, m, kvol, d_w, cin, cout, trans_w, d_bias, d_y, ldy, tile_cfg, d_tile_order,
+                                       d_workspace, kvol > 0 && cin > 0 && cout > 0
+                                                        ? sst_align_up(sst_spconv_conv_os_f32x6_workspace_bytes(kvol, cin, cout), 256)
+                                                        : 0,
+                                       stream);
 }
 
 }  // extern "C"

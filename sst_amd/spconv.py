@@ -337,8 +337,10 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cf
     if (_conv_kernel_choice() == 'os' and kvol <= 32 and cin % 4 == 0 and x.stride(0) % 4 == 0
             and x.data_ptr() % 16 == 0):
         split = _CONV_PRECISION if (_CONV_PRECISION != 'f32' and int(tile_cfg) == 0) else None
-        ws_bytes = (lib.sst_spconv_conv_os_f32x6_workspace_bytes if split == 'f32x6' else lib.sst_spconv_conv_os_workspace_bytes)
-        ws = _lib.workspace(ws_bytes(kvol, cin, cout), x.device)
+        if split == 'f32x6':     # room for the partial tiles of a thin level too (csrc/spconv_os_x6.hip: offsets dealt out)
+            ws = _lib.workspace(lib.sst_spconv_conv_os_f32x6_workspace_bytes_rows(kvol, cin, cout, rows), x.device)
+        else:
+            ws = _lib.workspace(lib.sst_spconv_conv_os_workspace_bytes(kvol, cin, cout), x.device)
         order = None
         x3 = split is not None
         if isinstance(density, Rulebook) and rows >= _OS_ORDER_MIN_ROWS and _os_tile_order_enabled():
@@ -346,6 +348,13 @@ def _gather_gemm(x, mapping, rows, weight3, trans_w, cout, density=None, tile_cf
             # kernel's os_pick honours): its launch order must be computed for ITS tile height
             tile_rows = 64 if x3 else lib.sst_spconv_conv_os_tile_rows(rows, cout, int(tile_cfg))
             order = density.tile_order(mapping, rows, tile_rows)
+        if split == 'f32x6':
+            rc = lib.sst_spconv_conv_os_rows_f32x6(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin,
+                                                   cout, int(trans_w), None, _lib.ptr(y), y.stride(0), 0,
+                                                   _lib.ptr(order) if order is not None else None, _lib.ptr(ws), ws.numel(),
+                                                   _lib.stream_ptr())
+            _lib.check(rc, 'sst_spconv_conv_os_rows_f32x6')
+            return y
         entry = getattr(lib, 'sst_spconv_conv_os_' + (split or 'f32'))
         rc = entry(_lib.ptr(x), x.stride(0), _lib.ptr(mapping), rows, kvol, _lib.ptr(weight3), cin, cout, int(trans_w), None,
                    _lib.ptr(y), y.stride(0), int(tile_cfg), _lib.ptr(order) if order is not None else None, _lib.ptr(ws),

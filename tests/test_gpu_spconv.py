@@ -404,3 +404,38 @@ def test_sparse_filter_gradient_bit_reproducible(cin, cout):
             ref = tuple(t.clone() for t in cur)
             assert int(num.sum()) > 200000        # several 2048-pair chunks per offset
         assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+
+
+@pytest.mark.parametrize('cin,cout,n', [(256, 256, 1866), (128, 128, 6542), (64, 128, 700), (256, 128, 3000)])
+def test_thin_levels_deal_their_offsets_out(cin, cout, n):
+    """csrc/spconv_os_x6.hip on a THIN level (the two deepest levels of FSD's U-Net: 1 866 / 6 542 rows): with room for partial
+    tiles in its workspace the call splits the 27 offsets over up to 8 workgroups per (row tile, column group) and adds the
+    partials in a fixed order - same values as the unsplit call up to the association of the per-offset sums, the same bits
+    every launch, bias included."""
+    from sst_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    batch, shape = 1, [8, 48, 48]
+    ind = _cloud(rng, n, batch, shape)
+    outids, pairs, num, rb = _rulebook(ind, batch, shape, [3] * 3, [1] * 3, [1] * 3, [1] * 3, True, False)
+    m = len(outids)
+    gen = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, cin, generator=gen) * 2).to(DEV)
+    w = (torch.randn(27, cin, cout, generator=gen) * 0.1).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    outs = []
+    for rows_ws in (False, True, True):
+        y = torch.empty(m, cout, device=DEV)
+        nbytes = (lib.sst_spconv_conv_os_f32x6_workspace_bytes_rows(27, cin, cout, m) if rows_ws
+                  else lib.sst_spconv_conv_os_f32x6_workspace_bytes(27, cin, cout))
+        ws = _lib.workspace(nbytes, x.device)
+        rc = lib.sst_spconv_conv_os_rows_f32x6(_lib.ptr(x), cin, _lib.ptr(rb.out2in), m, 27, _lib.ptr(w), cin, cout, 0,
+                                               _lib.ptr(bias), _lib.ptr(y), cout, 0, None, _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr())
+        assert rc == 0
+        outs.append(y)
+    assert lib.sst_spconv_conv_os_f32x6_workspace_bytes_rows(27, cin, cout, m) > \
+        lib.sst_spconv_conv_os_f32x6_workspace_bytes(27, cin, cout) + m * cout * 4       # the split is on at this size
+    scale = float(outs[0].abs().max())
+    assert float((outs[1] - outs[0]).abs().max()) <= 2e-6 * scale
+    assert torch.equal(outs[1], outs[2])
