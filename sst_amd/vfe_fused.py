@@ -61,7 +61,8 @@ def fused_vfe2_ok(encoder, x, plan):
             and x.size(1) == l0.linear.in_features and x.size(1) <= 16 and l0.linear.out_features == 64
             and l1.linear.in_features == 128 and l1.linear.out_features in (64, 128)
             and l0.linear.weight.is_contiguous() and l1.linear.weight.is_contiguous()
-            and hasattr(plan, 'raw_max') and hasattr(plan, 'group_sum'))
+            and hasattr(plan, 'raw_max') and hasattr(plan, 'group_sum')
+            and getattr(plan, 'num_voxels', 1) != 0)     # no kept voxel at all: the hand-back has no row 0 to read (layer-wise path)
 
 
 class FusedVFE2(Function):
