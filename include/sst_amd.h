@@ -119,12 +119,15 @@ int sst_segment_reduce_fwd_f32(const float* d_feats, int64_t n, int c, const uin
 /* sst_segment_reduce_fwd_work_f32: sst_segment_reduce_fwd_f32 made robust against a few very long groups among many short
  * ones (the voxels next to the sensor of a real LiDAR sweep hold thousands of points while the average voxel holds 1-10:
  * voxel_encoder.py:185-298 reduces them with the same DynamicScatter).  Groups of more than 32 rows are put on the work
- * list d_work by the element kernel and reduced by one workgroup each in a second launch of fixed size; same results, same
- * tie rule.  d_work: int32 [work_capacity], work_capacity >= m + 4, its first 4 entries ZEROED ONCE by the caller; the second
- * kernel leaves them zeroed (reusable by every later call on the same stream).  d_work == NULL: exactly
+ * list d_work by the element kernel - cut into chunks of 512 rows - and reduced by one workgroup per chunk in a second launch
+ * of fixed size; a third merges the chunks of the groups that were cut, in chunk order; same tie rule, same results up to the
+ * association of a cut group's sum.  d_work: int32 [work_capacity], 16-byte aligned, work_capacity >=
+ * sst_segment_reduce_work_words(n, m, c), its first 8 entries ZEROED ONCE by the caller; the kernels leave them zeroed (reusable
+ * by every later call on the same stream).  d_work == NULL: exactly
  * sst_segment_reduce_fwd_f32.  d_scale / d_shift (optional, [c], c % 4 == 0, with a work list): every value is read as
  * relu(x * scale + shift) - the BatchNorm + ReLU of DynamicVFE's last layer applied while its output is pooled
  * (voxel_encoder.py:286-296), whose activated [n, c] matrix is then never written. */
+int64_t sst_segment_reduce_work_words(int64_t n, int64_t m, int c);
 int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                     const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                     float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, int32_t* d_work,

@@ -57,6 +57,7 @@ _SIGNATURES = {
     'sst_unpack_keys': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr]),
     'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                            c_ptr, c_ptr]),
+    'sst_segment_reduce_work_words': (c_i64, [c_i64, c_i64, c_i32]),
     'sst_segment_reduce_fwd_work_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                                 c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     'sst_vfe_linear_moments_f32': (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),

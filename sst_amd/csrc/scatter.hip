@@ -30,10 +30,43 @@ __device__ __forceinline__ float4 seg_xf_apply(float4 x, const float4 sc, const 
   return x;
 }
 
-// Work list of the long groups of a call (sst_segment_reduce_fwd_work_f32): [0] entries, [1] next entry to take, [2] workgroups
-// done, [3] unused, then the output rows of the long groups in the order the first kernel met them (the order has no
-// influence on the result: a group is reduced by one workgroup in a fixed order).
-constexpr int kSegWorkHdr = 4;
+// Work list of the long groups of a call (sst_segment_reduce_fwd_work_f32), int32 words:
+//   header [8]: [0] entries, [1] next entry to take, [2] workgroups of the work kernel done, [3] partial slots handed out,
+//               [4] groups cut into several chunks, [5] workgroups of the merge kernel done
+//   entries [cap_e][3]: (output row g, chunk index, partial slot or -1) - a group of more than kSegChunk rows is cut into
+//               chunks of kSegChunk rows, one entry = one workgroup's worth (a real sweep has voxels with thousands of points
+//               and one group of all the clamped out-of-range points: one workgroup per group left 0.1 ms launches);
+//   multi [cap_m][3]: (g, first partial slot, chunks) of every group with more than one chunk, merged in chunk order by
+//               seg_reduce_merge_k; partial values [cap_p][cpad] floats, partial arg-max rows [cap_p][cpad] ints.
+// The order of the lists has no influence on the result: a chunk is reduced by one workgroup in a fixed order, the chunks of a
+// group are merged in chunk order.  Every kernel that is the last user of a counter zeroes it: the list is reusable as it is.
+constexpr int kSegWorkHdr = 8;
+constexpr int kSegChunk = 512;
+struct seg_work {
+  int32_t* w;
+  int cap_e, cap_m, cap_p, cpad;
+};
+__device__ __forceinline__ int32_t* seg_work_entries(const seg_work& W) { return W.w + kSegWorkHdr; }
+__device__ __forceinline__ int32_t* seg_work_multi(const seg_work& W) { return W.w + kSegWorkHdr + 3 * (int64_t)W.cap_e; }
+__device__ __forceinline__ float* seg_work_pvals(const seg_work& W) {
+  return (float*)(W.w + kSegWorkHdr + 3 * (int64_t)W.cap_e + 3 * (int64_t)W.cap_m);
+}
+__device__ __forceinline__ int32_t* seg_work_pargs(const seg_work& W) {
+  return W.w + kSegWorkHdr + 3 * (int64_t)W.cap_e + 3 * (int64_t)W.cap_m + (int64_t)W.cap_p * W.cpad;
+}
+// one thread of a long group lists it
+__device__ __forceinline__ void seg_work_push(const seg_work& W, int64_t g, int len) {
+  const int nch = (len + kSegChunk - 1) / kSegChunk;
+  const int s0 = atomicAdd(&W.w[0], nch);
+  int p0 = -1;
+  if (nch > 1) {
+    p0 = atomicAdd(&W.w[3], nch);
+    int32_t* mrec = seg_work_multi(W) + 3 * (int64_t)atomicAdd(&W.w[4], 1);
+    mrec[0] = (int32_t)g, mrec[1] = p0, mrec[2] = nch;
+  }
+  int32_t* e = seg_work_entries(W) + 3 * (int64_t)s0;
+  for (int i = 0; i < nch; ++i) e[3 * i] = (int32_t)g, e[3 * i + 1] = i, e[3 * i + 2] = nch > 1 ? p0 + i : -1;
+}
 
 // one thread per (group, channel) element; consecutive threads -> consecutive channels of one group
 __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict__ feats, int c,
@@ -42,7 +75,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict_
                                                         const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                         float* __restrict__ out, int32_t* __restrict__ argmax,
                                                         int32_t n_rows, const int32_t* __restrict__ d_mlim, int skip_len,
-                                                        int32_t* __restrict__ work) {
+                                                        const seg_work work) {
   if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int64_t total = m * c;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -51,7 +84,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_k(const float* __restrict_
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
     const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
     if (skip_len > 0 && end - beg > skip_len) {  // long group: seg_reduce_fwd_work_k takes it from the work list
-      if (ch == 0) work[kSegWorkHdr + atomicAdd(&work[0], 1)] = (int32_t)g;
+      if (ch == 0) seg_work_push(work, g, end - beg);
       continue;
     }
     if (mode == SST_REDUCE_MAX) {
@@ -85,7 +118,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
                                                            const int32_t* __restrict__ gidx, int64_t m, int mode,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
                                                            int32_t n_rows, const int32_t* __restrict__ d_mlim, int skip_len,
-                                                           int32_t* __restrict__ work, const seg_xf xf) {
+                                                           const seg_work work, const seg_xf xf) {
   if (d_mlim != nullptr && (int64_t)*d_mlim < m) m = *d_mlim;  // device-side row count (m is then an upper bound)
   const int c4 = c >> 2;
   const int64_t total = m * c4;
@@ -95,7 +128,7 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
     const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
     if (skip_len > 0 && end - beg > skip_len) {  // long group: seg_reduce_fwd_block_k / seg_reduce_fwd_work_k takes it
-      if (work != nullptr && ch == 0) work[kSegWorkHdr + atomicAdd(&work[0], 1)] = (int32_t)g;
+      if (work.w != nullptr && ch == 0) seg_work_push(work, g, end - beg);
       continue;
     }
     float4 acc = mode == SST_REDUCE_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
@@ -153,7 +186,8 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_v4_k(const float* __restri
 __device__ __forceinline__ void seg_block_group_v4(const float* __restrict__ feats, int c, const uint32_t* __restrict__ perm,
                                                    int beg, int end, int64_t g, int mode, float* __restrict__ out,
                                                    int32_t* __restrict__ argmax, int32_t n_rows, float4 (*lds_v2)[32],
-                                                   int4 (*lds_a2)[32], const seg_xf xf = seg_xf{nullptr, nullptr}) {
+                                                   int4 (*lds_a2)[32], const seg_xf xf = seg_xf{nullptr, nullptr},
+                                                   float* __restrict__ pval = nullptr, int32_t* __restrict__ parg = nullptr) {
   float4* lds_v = &lds_v2[0][0];
   int4* lds_a = &lds_a2[0][0];
   const int c4 = c >> 2;
@@ -211,13 +245,18 @@ __device__ __forceinline__ void seg_block_group_v4(const float* __restrict__ fea
           r.x += v.x, r.y += v.y, r.z += v.z, r.w += v.w;
         }
       }
-      if (mode == SST_REDUCE_MEAN && end > beg) {
-        const float cnt = (float)(end - beg);
-        r.x = r.x / cnt, r.y = r.y / cnt, r.z = r.z / cnt, r.w = r.w / cnt;
+      if (pval != nullptr) {   // a chunk of a group: the raw partial result, finished by seg_reduce_merge_k
+        *(float4*)(pval + 4 * q) = r;
+        *(int4*)(parg + 4 * q) = a;
+      } else {
+        if (mode == SST_REDUCE_MEAN && end > beg) {
+          const float cnt = (float)(end - beg);
+          r.x = r.x / cnt, r.y = r.y / cnt, r.z = r.z / cnt, r.w = r.w / cnt;
+        }
+        if (end <= beg) r = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(out + g * c + 4 * q) = r;
+        if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + 4 * q) = a;
       }
-      if (end <= beg) r = make_float4(0.f, 0.f, 0.f, 0.f);
-      *(float4*)(out + g * c + 4 * q) = r;
-      if (mode == SST_REDUCE_MAX && argmax != nullptr) *(int4*)(argmax + g * c + 4 * q) = a;
     }
     __syncthreads();
   }
@@ -227,7 +266,8 @@ __device__ __forceinline__ void seg_block_group_v4(const float* __restrict__ fea
 // (<= 256), 256 / cp row parts stride over the group's rows, the parts meet in LDS in a fixed order
 __device__ __forceinline__ void seg_block_group_v1(const float* __restrict__ feats, int c, const uint32_t* __restrict__ perm,
                                                    int beg, int end, int64_t g, int mode, float* __restrict__ out,
-                                                   int32_t* __restrict__ argmax, int32_t n_rows, float* lds_v, int* lds_a) {
+                                                   int32_t* __restrict__ argmax, int32_t n_rows, float* lds_v, int* lds_a,
+                                                   float* __restrict__ pval = nullptr, int32_t* __restrict__ parg = nullptr) {
   for (int c0 = 0; c0 < c; c0 += 256) {
     const int cw = c - c0 < 256 ? c - c0 : 256;
     int cp = 1;
@@ -262,10 +302,15 @@ __device__ __forceinline__ void seg_block_group_v1(const float* __restrict__ fea
           r += v;
         }
       }
-      if (mode == SST_REDUCE_MEAN && end > beg) r = r / (float)(end - beg);
-      if (end <= beg) r = 0.f;
-      out[g * c + c0 + ch] = r;
-      if (mode == SST_REDUCE_MAX && argmax != nullptr) argmax[g * c + c0 + ch] = a;
+      if (pval != nullptr) {
+        pval[c0 + ch] = r;
+        parg[c0 + ch] = a;
+      } else {
+        if (mode == SST_REDUCE_MEAN && end > beg) r = r / (float)(end - beg);
+        if (end <= beg) r = 0.f;
+        out[g * c + c0 + ch] = r;
+        if (mode == SST_REDUCE_MAX && argmax != nullptr) argmax[g * c + c0 + ch] = a;
+      }
     }
     __syncthreads();
   }
@@ -299,33 +344,90 @@ __global__ __launch_bounds__(256) void seg_reduce_fwd_work_k(const float* __rest
                                                              const int32_t* __restrict__ offsets,
                                                              const int32_t* __restrict__ gidx, int mode,
                                                              float* __restrict__ out, int32_t* __restrict__ argmax,
-                                                             int32_t n_rows, int32_t* __restrict__ work, const seg_xf xf) {
+                                                             int32_t n_rows, const seg_work work, const seg_xf xf) {
   __shared__ float4 lds_v[8][32];
   __shared__ int4 lds_a[8][32];
   __shared__ int s_take;
-  const int count = __atomic_load_n(&work[0], __ATOMIC_RELAXED);
+  int32_t* hdr = work.w;
+  const int count = __atomic_load_n(&hdr[0], __ATOMIC_RELAXED);
   if (count == 0) return;   // no long group (the usual voxel grouping): the counters are zero as they stand, nothing to take or reset
+  const int32_t* entries = seg_work_entries(work);
   for (;;) {
-    if (threadIdx.x == 0) s_take = atomicAdd(&work[1], 1);
+    if (threadIdx.x == 0) s_take = atomicAdd(&hdr[1], 1);
     __syncthreads();
     const int take = s_take;
     __syncthreads();
     if (take >= count) break;
-    const int64_t g = work[kSegWorkHdr + take];
+    const int64_t g = entries[3 * (int64_t)take];
+    const int chunk = entries[3 * (int64_t)take + 1], pslot = entries[3 * (int64_t)take + 2];
     const int64_t gs = gidx != nullptr ? gidx[g] : g;
-    const int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
+    int beg = gs < 0 ? 0 : offsets[gs], end = gs < 0 ? 0 : offsets[gs + 1];   // negative entry: an empty group
+    float* pv = nullptr;
+    int32_t* pa = nullptr;
+    if (pslot >= 0) {        // one chunk of a group that was cut: rows [beg + chunk * kSegChunk, + kSegChunk)
+      beg += chunk * kSegChunk;
+      end = beg + kSegChunk < end ? beg + kSegChunk : end;
+      pv = seg_work_pvals(work) + (int64_t)pslot * work.cpad;
+      pa = seg_work_pargs(work) + (int64_t)pslot * work.cpad;
+    }
     if (V == 4)
-      seg_block_group_v4(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, lds_v, lds_a, xf);
+      seg_block_group_v4(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, lds_v, lds_a, xf, pv, pa);
     else
-      seg_block_group_v1(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, (float*)&lds_v[0][0], (int*)&lds_a[0][0]);
+      seg_block_group_v1(feats, c, perm, beg, end, g, mode, out, argmax, n_rows, (float*)&lds_v[0][0], (int*)&lds_a[0][0], pv, pa);
   }
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(&work[2], 1) == (int)gridDim.x - 1) {   // every workgroup has left its loop: nobody reads the counters again
-      work[0] = 0;
-      work[1] = 0;
+    if (atomicAdd(&hdr[2], 1) == (int)gridDim.x - 1) {   // every workgroup has left its loop: nobody reads these counters again
+      hdr[0] = 0;
+      hdr[1] = 0;
       __threadfence();
-      work[2] = 0;
+      hdr[2] = 0;
+    }
+  }
+}
+
+// The groups that were cut into chunks: chunk partials merged in chunk order (MAX: value first, then the smaller row - the
+// chunks hold ascending rows, so this is the tie rule of the serial walk; SUM / MEAN: added in chunk order).  Launched behind
+// seg_reduce_fwd_work_k on the same stream; returns at once when no group was cut.
+__global__ __launch_bounds__(256) void seg_reduce_merge_k(int c, const int32_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ gidx, int mode, float* __restrict__ out,
+                                                          int32_t* __restrict__ argmax, const seg_work work) {
+  int32_t* hdr = work.w;
+  const int n_multi = __atomic_load_n(&hdr[4], __ATOMIC_RELAXED);
+  if (n_multi == 0) return;
+  const int32_t* multi = seg_work_multi(work);
+  const float* pv = seg_work_pvals(work);
+  const int32_t* pa = seg_work_pargs(work);
+  for (int mi = blockIdx.x; mi < n_multi; mi += gridDim.x) {
+    const int64_t g = multi[3 * (int64_t)mi];
+    const int p0 = multi[3 * (int64_t)mi + 1], nch = multi[3 * (int64_t)mi + 2];
+    const int64_t gs = gidx != nullptr ? gidx[g] : g;
+    const int len = offsets[gs + 1] - offsets[gs];
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+      float r = pv[(int64_t)p0 * work.cpad + ch];
+      int a = pa[(int64_t)p0 * work.cpad + ch];
+      for (int i = 1; i < nch; ++i) {
+        const float v = pv[(int64_t)(p0 + i) * work.cpad + ch];
+        const int b = pa[(int64_t)(p0 + i) * work.cpad + ch];
+        if (mode == SST_REDUCE_MAX) {
+          if (v > r || (v == r && b < a)) r = v, a = b;
+        } else {
+          r += v;
+        }
+      }
+      if (mode == SST_REDUCE_MEAN) r = r / (float)len;
+      out[g * c + ch] = r;
+      if (mode == SST_REDUCE_MAX && argmax != nullptr) argmax[g * c + ch] = a;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&hdr[5], 1) == (int)gridDim.x - 1) {
+      hdr[3] = 0;
+      hdr[4] = 0;
+      __threadfence();
+      hdr[5] = 0;
     }
   }
 }
@@ -885,6 +987,21 @@ int sst_segment_reduce_profile_next(void* start, void* stop) {
   return SST_OK;
 }
 
+// capacities of a work list for n rows in m groups of c channels
+static void seg_work_shape(int64_t n, int64_t m, int c, seg_work* W) {
+  const int64_t chunks = n / kSegChunk + 1;
+  W->cap_e = (int)(m + chunks);
+  W->cap_m = (int)chunks;
+  W->cap_p = (int)(2 * chunks);
+  W->cpad = (c + 3) & ~3;
+}
+int64_t sst_segment_reduce_work_words(int64_t n, int64_t m, int c) {
+  if (n < 0 || m < 0 || c < 1 || n > 0x3fffffff || m > 0x3fffffff) return SST_ERR_ARG;
+  seg_work W;
+  seg_work_shape(n, m, c, &W);
+  return kSegWorkHdr + 3 * (int64_t)W.cap_e + 3 * (int64_t)W.cap_m + 2 * (int64_t)W.cap_p * W.cpad;
+}
+
 int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, const uint32_t* d_perm,
                                     const int32_t* d_offsets, const int32_t* d_group_index, int64_t m, int mode,
                                     float* d_out, int32_t* d_argmax, const int32_t* d_m_limit, int32_t* d_work,
@@ -892,10 +1009,17 @@ int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, cons
   if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2) return SST_ERR_ARG;
   if (m == 0) return SST_OK;
   if (!d_offsets || !d_out || (n > 0 && (!d_feats || !d_perm))) return SST_ERR_ARG;
-  if (d_work != nullptr && work_capacity < m + kSegWorkHdr) return SST_ERR_ARG;
+  if (d_work != nullptr && (work_capacity < sst_segment_reduce_work_words(n, m, c) || (((uintptr_t)d_work) & 15)))
+    return SST_ERR_ARG;
   if ((d_scale != nullptr) != (d_shift != nullptr)) return SST_ERR_ARG;
   const seg_xf xf{d_scale, d_shift};
   const seg_xf no_xf{nullptr, nullptr};
+  seg_work work{nullptr, 0, 0, 0, 0};
+  const seg_work no_work{nullptr, 0, 0, 0, 0};
+  if (d_work != nullptr) {
+    seg_work_shape(n, m, c, &work);
+    work.w = d_work;
+  }
   hipEvent_t e0 = g_seg_ev[0], e1 = g_seg_ev[1];
   g_seg_ev[0] = g_seg_ev[1] = nullptr;
   const bool timed = e0 != nullptr && e1 != nullptr;
@@ -904,40 +1028,38 @@ int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, cons
   if (d_scale != nullptr && (!v4 || d_work == nullptr || (((uintptr_t)d_scale | (uintptr_t)d_shift) & 15))) return SST_ERR_UNSUPPORTED;
   constexpr int kLongGroup = 16;       // without a work list: groups longer than this go to one workgroup each when n >= 8 m
   constexpr int kWorkGroupLen = 32;    // with a work list: groups longer than this, whatever the average
-  constexpr int kWorkGrid = 512;
+  constexpr int kWorkGrid = 512, kMergeGrid = 64;
+  hipStream_t st = (hipStream_t)stream;
   if (d_work != nullptr && n > 0) {
-    // robust form: the element kernel lists the long groups, a fixed grid of workgroups reduces them
+    // robust form: the element kernel lists the long groups (cut into chunks of kSegChunk rows), a fixed grid of workgroups
+    // reduces the chunks, a third launch merges the chunks of the groups that were cut
     if (v4) {
       const int grid = sst_grid_1d(m * (c >> 2), 256);
       if (timed)
-        hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0, d_feats, c,
-                              d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen,
-                              d_work, xf);
+        hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, st, e0, nullptr, 0, d_feats, c, d_perm, d_offsets,
+                              d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, work, xf);
       else
-        hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                           d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, d_work, xf);
-      if (timed)
-        hipExtLaunchKernelGGL(seg_reduce_fwd_work_k<4>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
-                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, xf);
-      else
-        hipLaunchKernelGGL(seg_reduce_fwd_work_k<4>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, xf);
+        hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, st, d_feats, c, d_perm, d_offsets, d_group_index, m,
+                           mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, work, xf);
+      hipLaunchKernelGGL(seg_reduce_fwd_work_k<4>, dim3(kWorkGrid), dim3(256), 0, st, d_feats, c, d_perm, d_offsets,
+                         d_group_index, mode, d_out, d_argmax, (int32_t)n, work, xf);
     } else {
       const int grid = sst_grid_1d(m * c, 256);
       if (timed)
-        hipExtLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, nullptr, 0, d_feats, c,
-                              d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen,
-                              d_work);
+        hipExtLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, st, e0, nullptr, 0, d_feats, c, d_perm, d_offsets,
+                              d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, work);
       else
-        hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                           d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, d_work);
-      if (timed)
-        hipExtLaunchKernelGGL(seg_reduce_fwd_work_k<1>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0,
-                              d_feats, c, d_perm, d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, no_xf);
-      else
-        hipLaunchKernelGGL(seg_reduce_fwd_work_k<1>, dim3(kWorkGrid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                           d_offsets, d_group_index, mode, d_out, d_argmax, (int32_t)n, d_work, no_xf);
+        hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, st, d_feats, c, d_perm, d_offsets, d_group_index, m, mode,
+                           d_out, d_argmax, (int32_t)n, d_m_limit, kWorkGroupLen, work);
+      hipLaunchKernelGGL(seg_reduce_fwd_work_k<1>, dim3(kWorkGrid), dim3(256), 0, st, d_feats, c, d_perm, d_offsets,
+                         d_group_index, mode, d_out, d_argmax, (int32_t)n, work, no_xf);
     }
+    if (timed)
+      hipExtLaunchKernelGGL(seg_reduce_merge_k, dim3(kMergeGrid), dim3(256), 0, st, nullptr, e1, 0, c, d_offsets, d_group_index,
+                            mode, d_out, d_argmax, work);
+    else
+      hipLaunchKernelGGL(seg_reduce_merge_k, dim3(kMergeGrid), dim3(256), 0, st, c, d_offsets, d_group_index, mode, d_out,
+                         d_argmax, work);
     SST_LAUNCH_CHECK();
     return SST_OK;
   }
@@ -947,32 +1069,31 @@ int sst_segment_reduce_fwd_work_f32(const float* d_feats, int64_t n, int c, cons
     const bool split = n >= 8 * m;
     const int grid = sst_grid_1d(m * (c >> 2), 256);
     if (timed)
-      hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, split ? nullptr : e1, 0,
-                            d_feats, c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit,
-                            split ? kLongGroup : 0, (int32_t*)nullptr, no_xf);
+      hipExtLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, st, e0, split ? nullptr : e1, 0, d_feats, c, d_perm,
+                            d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, split ? kLongGroup : 0,
+                            no_work, no_xf);
     else
-      hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                         d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, split ? kLongGroup : 0,
-                         (int32_t*)nullptr, no_xf);
+      hipLaunchKernelGGL(seg_reduce_fwd_v4_k, dim3(grid), dim3(256), 0, st, d_feats, c, d_perm, d_offsets, d_group_index, m,
+                         mode, d_out, d_argmax, (int32_t)n, d_m_limit, split ? kLongGroup : 0, no_work, no_xf);
     if (split) {
       const int grid_b = (int)(m < 65536 ? m : 65536);
       if (timed)
-        hipExtLaunchKernelGGL(seg_reduce_fwd_block_k, dim3(grid_b), dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0, d_feats,
-                              c, d_perm, d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kLongGroup);
+        hipExtLaunchKernelGGL(seg_reduce_fwd_block_k, dim3(grid_b), dim3(256), 0, st, nullptr, e1, 0, d_feats, c, d_perm,
+                              d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kLongGroup);
       else
-        hipLaunchKernelGGL(seg_reduce_fwd_block_k, dim3(grid_b), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm,
-                           d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kLongGroup);
+        hipLaunchKernelGGL(seg_reduce_fwd_block_k, dim3(grid_b), dim3(256), 0, st, d_feats, c, d_perm, d_offsets, d_group_index,
+                           m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, kLongGroup);
     }
     SST_LAUNCH_CHECK();
     return SST_OK;
   }
   const int grid = sst_grid_1d(m * c, 256);
   if (timed)
-    hipExtLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, d_feats, c, d_perm,
-                          d_offsets, d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, 0, (int32_t*)nullptr);
+    hipExtLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, st, e0, e1, 0, d_feats, c, d_perm, d_offsets,
+                          d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, 0, no_work);
   else
-    hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_feats, c, d_perm, d_offsets,
-                       d_group_index, m, mode, d_out, d_argmax, (int32_t)n, d_m_limit, 0, (int32_t*)nullptr);
+    hipLaunchKernelGGL(seg_reduce_fwd_k, dim3(grid), dim3(256), 0, st, d_feats, c, d_perm, d_offsets, d_group_index, m, mode,
+                       d_out, d_argmax, (int32_t)n, d_m_limit, 0, no_work);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -174,16 +174,17 @@ def unpack_unique_rows(plan, dtype, first=0, count=None, out_cols=None, col0=0, 
 # ----------------------------------------------------------------------------------------------
 # (a3/a5/a15) segmented reduce with autograd
 # ----------------------------------------------------------------------------------------------
-def _long_work_list(plan, m, dev):
-    """work list of the long groups of a grouping (csrc/scatter.hip seg_reduce_fwd_work_k): counters zeroed once per plan, the
-    kernel leaves them zeroed; one list per stream, as launches on different streams may overlap"""
+def _long_work_list(plan, n, m, c, dev):
+    """work list of the long groups of a grouping (csrc/scatter.hip seg_reduce_fwd_work_k / seg_reduce_merge_k): counters zeroed
+    once per plan, the kernels leave them zeroed; one list per stream (launches on different streams may overlap) and width"""
     cache = getattr(plan, 'scratch', None)
     if cache is None:
         cache = plan.scratch = {}
-    key = ('work', _lib.stream_ptr().value)
+    key = ('work', _lib.stream_ptr().value, (c + 3) // 4)
     buf = cache.get(key)
-    if buf is None or buf.numel() < m + 4:
-        buf = cache[key] = torch.zeros(max(int(m), int(getattr(plan, 'm', 0) or 0)) + 4, dtype=torch.int32, device=dev)
+    need = int(_lib.load().sst_segment_reduce_work_words(n, max(int(m), int(getattr(plan, 'm', 0) or 0)), c))
+    if buf is None or buf.numel() < need:
+        buf = cache[key] = torch.zeros(need, dtype=torch.int32, device=dev)
     return buf
 
 
@@ -195,7 +196,7 @@ def _segment_reduce_fwd(feats, perm, offsets, m, mode, want_argmax, group_index=
     argmax = torch.empty((m, c), dtype=torch.int32, device=feats.device) if want_argmax else None
     # with a plan to keep the work list on: long groups (a voxel next to the sensor holds thousands of points of a real sweep)
     # are reduced by a workgroup each instead of by one thread per channel vector
-    work = _long_work_list(plan, m, feats.device) if (plan is not None and n > 0
+    work = _long_work_list(plan, n, m, c, feats.device) if (plan is not None and n > 0
                                                       and os.environ.get('SST_SEG_WORK', '1') != '0') else None
     rc = _lib.load().sst_segment_reduce_fwd_work_f32(_lib.ptr(feats), n, c, _lib.ptr(perm), _lib.ptr(offsets),
                                                      _lib.ptr(group_index), m, mode, _lib.ptr(out), _lib.ptr(argmax),
