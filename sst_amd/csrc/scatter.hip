@@ -990,8 +990,8 @@ int sst_segment_reduce_profile_next(void* start, void* stop) {
 // capacities of a work list for n rows in m groups of c channels
 static void seg_work_shape(int64_t n, int64_t m, int c, seg_work* W) {
   const int64_t chunks = n / kSegChunk + 1;
-  W->cap_e = (int)(m + chunks);
-  W->cap_m = (int)chunks;
+  W->cap_e = (int)sst_align_up(m + chunks, 4);   // multiples of 4: the partial records behind the lists stay 16-byte aligned
+  W->cap_m = (int)sst_align_up(chunks, 4);
   W->cap_p = (int)(2 * chunks);
   W->cpad = (c + 3) & ~3;
 }
