@@ -665,6 +665,47 @@ int sst_tall_linear_ln_f32x6(const float* d_x, int64_t ldx, const float* d_w, in
 int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
                                const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
                                void* d_workspace, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * One post-norm SRA encoder layer (sst_basic_block_v2.py:41-126, d_model 128, 8 heads, feed-forward 256) as ONE call forward
+ * and ONE call backward (csrc/layer_exec.hip): the entry points above issued in the order of
+ * sst_amd/sst_basic_block.py FusedEncoderLayerFn in its exact-split mode - nothing but the launch sequence moves from the
+ * interpreter into the library (15 foreign calls per layer and step become 2).  All tensors fp32, row-major, contiguous with
+ * the widths given; tok may be NULL (rows in window order), order may be NULL.
+ *   forward : qkv [m, 384] = [(xp W_q^T | xp W_k^T) | x W_v^T] + b_in;  o, lse = SRA(q, k, v);
+ *             y1 = LN1(x + o W_o^T + b_o) (s1 = the sum, st1 [m, 2] = mean, rstd; s1 may be NULL when nothing is kept);
+ *             pre = y1 W_1^T + b_1 [m, 256], h = act(pre) (act 1 = GELU(erf), 2 = ReLU);  s2 = y1 + h W_2^T + b_2;
+ *             y2 = LN2(s2), st2; y2p = y2 + pos_table[pos_idx] when pos_table != NULL (the next layer's x + pos).
+ *   backward: from dy2 (and dy2p, may be NULL) the gradients of every parameter and dx (returned in ds1: d(x) with the
+ *             gradient of xp folded in, xp = x + a constant); ds2, dpre, ds1, d_o, dqkv [m, 384] are scratch outputs of the
+ *             widths 128, 256, 128, 128, 384; workspace: sst_encoder_layer_bwd_workspace_bytes(m, n_heads), 256-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sst_encoder_layer_fwd_args {
+  int64_t m, n_windows;
+  int32_t n_heads, act, max_tokens, impl;
+  float eps, scale;
+  const float *x, *xp;
+  const float *w_in, *b_in, *w_out, *b_out, *w1, *b1, *w2, *b2, *n1w, *n1b, *n2w, *n2b;
+  const int32_t *tok, *winoff, *order;
+  const float* pos_table;
+  const int32_t* pos_idx;
+  float *qkv, *o, *lse, *y1, *s1, *st1, *pre, *h, *s2, *y2, *st2, *y2p;
+} sst_encoder_layer_fwd_args;
+typedef struct sst_encoder_layer_bwd_args {
+  int64_t m, n_windows;
+  int32_t n_heads, act, max_tokens, impl;
+  float eps, scale;
+  const float *dy2, *dy2p;
+  const float *x, *xp, *qkv, *o, *lse, *s1, *st1, *y1, *pre, *h, *s2, *st2;
+  const float *w_in, *w_out, *w1, *w2, *n1w, *n2w;
+  const int32_t *tok, *winoff, *order;
+  float *ds2, *dpre, *ds1, *d_o, *dqkv;
+  float *dw_in, *db_in, *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dn1w, *dn1b, *dn2w, *dn2b;
+  void* workspace;
+} sst_encoder_layer_bwd_args;
+int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads);
+int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* args, void* stream);
+int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* args, void* stream);
+
 /* sst_tall_linear_epi_f32 (csrc/dense_f32.hip): y[m, n] = epilogue(x[m, k] W^T + bias), exact fp32 (v_mfma_f32_16x16x4_f32),
  * the whole weight matrix resident in LDS; (k, n) in {(128,128), (128,256), (256,128)}.  trans_w = 0: d_w holds W as [n][k]
  * rows (F.linear's weight); trans_w = 1: d_w holds [k][n] rows - the data gradient dy[m, out] w[out, in] of a layer with

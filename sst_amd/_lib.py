@@ -42,6 +42,27 @@ class WgradProblemF32(ctypes.Structure):
                 ('out', ctypes.c_int32), ('inn', ctypes.c_int32)]
 
 
+def _struct(name, doc, fields):
+    return type(name, (ctypes.Structure,), {'__doc__': doc, '_fields_': fields})
+
+
+_P = ctypes.c_void_p
+EncoderLayerFwdArgs = _struct('EncoderLayerFwdArgs', 'sst_encoder_layer_fwd_args of include/sst_amd.h', (
+    [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'impl')]
+    + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
+    + [(k, _P) for k in ('x', 'xp', 'w_in', 'b_in', 'w_out', 'b_out', 'w1', 'b1', 'w2', 'b2', 'n1w', 'n1b', 'n2w', 'n2b',
+                         'tok', 'winoff', 'order', 'pos_table', 'pos_idx',
+                         'qkv', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'y2', 'st2', 'y2p')]))
+EncoderLayerBwdArgs = _struct('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args of include/sst_amd.h', (
+    [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'impl')]
+    + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
+    + [(k, _P) for k in ('dy2', 'dy2p', 'x', 'xp', 'qkv', 'o', 'lse', 's1', 'st1', 'y1', 'pre', 'h', 's2', 'st2',
+                         'w_in', 'w_out', 'w1', 'w2', 'n1w', 'n2w', 'tok', 'winoff', 'order',
+                         'ds2', 'dpre', 'ds1', 'd_o', 'dqkv',
+                         'dw_in', 'db_in', 'dwo', 'dbo', 'dw1', 'db1', 'dw2', 'db2', 'dn1w', 'dn1b', 'dn2w', 'dn2b',
+                         'workspace')]))
+
+
 # name -> (restype, argtypes); mirrors include/sst_amd.h one to one
 _SIGNATURES = {
     'sst_version': (ctypes.c_char_p, []),
@@ -57,6 +78,9 @@ _SIGNATURES = {
     'sst_unpack_keys': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_ptr]),
     'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                            c_ptr, c_ptr]),
+    'sst_encoder_layer_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
+    'sst_encoder_layer_fwd_f32x6': (c_i32, [c_ptr, c_ptr]),
+    'sst_encoder_layer_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_segment_reduce_work_words': (c_i64, [c_i64, c_i64, c_i32]),
     'sst_segment_reduce_fwd_work_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                                 c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -1,0 +1,135 @@
+// One post-norm SRA encoder layer (models/sst/sst_basic_block_v2.py:41-126: WindowAttention -> norm1(x + .) -> FFN ->
+// norm2(y1 + .)) as ONE call forward and ONE call backward: the launch sequence of sst_amd/sst_basic_block.py
+// FusedEncoderLayerFn in its exact-split mode (d_model 128, feed-forward 256, head dim 16), issued from C.
+//
+// Why: nothing here computes - every step is an entry point of this library - but the Python side of that sequence is
+// 6 + 9 foreign calls per layer with their argument marshalling, 2.6 + 2.7 ms of host time per training step on a fast host and
+// 3.8 + 5.4 ms on a slow one, against 11.4 ms (fp32) / 6.1 ms (bf16 storage) of kernels: frames with fewer voxels than the bench
+// frame (a real sweep keeps 20-50 k) were bound by the host.  One call per layer and direction leaves the allocations of
+// the tensors autograd keeps, and nothing else, to the interpreter.  Same kernels, same order, same bits as the Python sequence
+// (tests/test_gpu_layer_exec.py).
+#include <stdint.h>
+#include "common.h"
+
+namespace {
+
+enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5 };
+constexpr int kC = 128, kFF = 256;
+
+int64_t wg_ws(int64_t m, int which) {   // workspace of the two weight-gradient groups of a layer
+  sst_wgrad_problem_f32 p[3];
+  float* const any = (float*)(uintptr_t)256;   // the size query looks at shapes and alignment only; it wants non-null operands
+  for (auto& q : p) {
+    q.dy = q.x = any;
+    q.dw = q.db = any;
+    q.m = m;
+  }
+  if (which == 0) {
+    p[0].ld_dy = kC, p[0].ld_x = kFF, p[0].out = kC, p[0].in = kFF;    // dW2 = ds2^T h
+    p[1].ld_dy = kFF, p[1].ld_x = kC, p[1].out = kFF, p[1].in = kC;    // dW1 = dpre^T y1
+    return sst_weight_grad_group_f32x6_workspace_bytes(p, 2);
+  }
+  p[0].ld_dy = kC, p[0].ld_x = kC, p[0].out = kC, p[0].in = kC;              // dWo = ds1^T o
+  p[1].ld_dy = 3 * kC, p[1].ld_x = kC, p[1].out = 2 * kC, p[1].in = kC;      // dWq | dWk = [dq | dk]^T xp
+  p[2].ld_dy = 3 * kC, p[2].ld_x = kC, p[2].out = kC, p[2].in = kC;          // dWv = dv^T x
+  return sst_weight_grad_group_f32x6_workspace_bytes(p, 3);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads) {
+  if (m < 0 || n_heads < 1) return SST_ERR_ARG;
+  const int64_t a = sst_add_layernorm_bwd_workspace_bytes(m, kC), b = wg_ws(m, 0), c = wg_ws(m, 1),
+                d = sst_sra_attn_bwd_workspace_bytes(m, n_heads);
+  if (a < 0 || b < 0 || c < 0 || d < 0) return SST_ERR_UNSUPPORTED;
+  // the four users never overlap in time on the stream, but a kernel of one may still run when the next is queued: own pieces
+  return sst_align_up(a, 256) + sst_align_up(b, 256) + sst_align_up(c, 256) + sst_align_up(d, 256) + 256;
+}
+
+int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* a, void* stream) {
+  if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
+  if (a->m == 0) return SST_OK;
+  if (!a->x || !a->xp || !a->qkv || !a->o || !a->lse || !a->y1 || !a->st1 || !a->pre || !a->h || !a->s2 || !a->y2 || !a->st2)
+    return SST_ERR_ARG;
+  const int64_t m = a->m;
+  int rc;
+  // q | k = (x + pos) W_qk^T, v = x W_v^T: one launch over 384 columns (sst_basic_block_v2.py:56-62)
+  rc = sst_tall_linear_epi2_f32x6(a->xp, a->x, 2 * kC, kC, a->w_in, kC, 0, a->b_in, m, kC, 3 * kC, kEpiBias, nullptr, nullptr, 0,
+                                  a->qkv, 3 * kC, stream);
+  if (rc) return rc;
+  rc = sst_sra_attn_fwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->tok, a->winoff, a->order,
+                                a->n_windows, a->n_heads, a->scale, a->max_tokens, a->impl, a->o, kC, a->lse, stream);
+  if (rc) return rc;
+  // out-projection + residual + LayerNorm (:113-115)
+  rc = sst_tall_linear_ln_f32x6(a->o, kC, a->w_out, kC, a->b_out, m, kC, a->x, kC, a->n1w, a->n1b, a->eps, a->y1, a->s1, a->st1,
+                                nullptr, nullptr, nullptr, stream);
+  if (rc) return rc;
+  // linear1 + activation, pre-activation kept (:116)
+  rc = sst_tall_linear_epi_f32x6(a->y1, kC, a->w1, kC, 0, a->b1, m, kC, kFF, a->act == 1 ? kEpiGelu : kEpiRelu, nullptr, a->pre,
+                                 kFF, a->h, kFF, stream);
+  if (rc) return rc;
+  // linear2 + residual, then LayerNorm (+ the next layer's positional embedding) over the sum (:116-118)
+  rc = sst_tall_linear_epi_f32x6(a->h, kFF, a->w2, kFF, 0, a->b2, m, kFF, kC, kEpiAdd, a->y1, nullptr, kC, a->s2, kC, stream);
+  if (rc) return rc;
+  if (a->pos_table != nullptr)
+    return sst_add_layernorm_pos_fwd_f32(a->s2, nullptr, a->n2w, a->n2b, m, kC, a->eps, a->y2, nullptr, a->st2, a->pos_table,
+                                         a->pos_idx, a->y2p, stream);
+  return sst_add_layernorm_act_fwd_f32(a->s2, nullptr, a->n2w, a->n2b, m, kC, a->eps, 0, a->y2, nullptr, a->st2, stream);
+}
+
+int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* stream) {
+  if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
+  if (a->m == 0) return SST_OK;
+  if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->ds1 || !a->d_o || !a->dqkv) return SST_ERR_ARG;
+  const int64_t m = a->m;
+  char* ws = (char*)a->workspace;
+  void* ws_ln = ws;
+  ws += sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
+  void* ws_g1 = ws;
+  ws += sst_align_up(wg_ws(m, 0), 256);
+  void* ws_g2 = ws;
+  ws += sst_align_up(wg_ws(m, 1), 256);
+  void* ws_sra = ws;
+  int rc;
+  // norm2 backward: d(y1 residual) = d(FFN output); the next layer's x + pos output arrives as a second gradient
+  rc = sst_add_layernorm_bwd2_f32(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, a->dn2w, a->dn2b, ws_ln, stream);
+  if (rc) return rc;
+  // linear2's data gradient with the activation's derivative in the epilogue
+  rc = sst_tall_linear_epi_f32x6(a->ds2, kC, a->w2, kFF, 1, nullptr, m, kC, kFF, a->act == 1 ? kEpiMulGeluGrad : kEpiMulReluGrad,
+                                 a->pre, nullptr, kFF, a->dpre, kFF, stream);
+  if (rc) return rc;
+  sst_wgrad_problem_f32 g1[2];
+  g1[0].dy = a->ds2, g1[0].x = a->h, g1[0].m = m, g1[0].ld_dy = kC, g1[0].ld_x = kFF, g1[0].dw = a->dw2, g1[0].db = a->db2;
+  g1[0].out = kC, g1[0].in = kFF;
+  g1[1].dy = a->dpre, g1[1].x = a->y1, g1[1].m = m, g1[1].ld_dy = kFF, g1[1].ld_x = kC, g1[1].dw = a->dw1, g1[1].db = a->db1;
+  g1[1].out = kFF, g1[1].in = kC;
+  rc = sst_weight_grad_group_f32x6(g1, 2, ws_g1, stream);   // before ds2 is accumulated into
+  if (rc) return rc;
+  // residual + FFN branch: dy1 = ds2 + dpre W1 (in place)
+  rc = sst_tall_linear_epi_f32x6(a->dpre, kFF, a->w1, kC, 1, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, a->ds2, kC, stream);
+  if (rc) return rc;
+  rc = sst_add_layernorm_bwd2_f32(a->ds2, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, a->dn1w, a->dn1b, ws_ln, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_epi_f32x6(a->ds1, kC, a->w_out, kC, 1, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
+  if (rc) return rc;
+  rc = sst_sra_attn_bwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, a->o, a->d_o, a->lse, 3 * kC, 3 * kC, 3 * kC, kC, kC, a->tok,
+                                a->winoff, a->order, a->n_windows, m, a->n_heads, a->scale, a->max_tokens, a->impl, a->dqkv,
+                                a->dqkv + kC, a->dqkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, ws_sra, stream);
+  if (rc) return rc;
+  sst_wgrad_problem_f32 g2[3];
+  g2[0].dy = a->ds1, g2[0].x = a->o, g2[0].m = m, g2[0].ld_dy = kC, g2[0].ld_x = kC, g2[0].dw = a->dwo, g2[0].db = a->dbo;
+  g2[0].out = kC, g2[0].in = kC;
+  g2[1].dy = a->dqkv, g2[1].x = a->xp, g2[1].m = m, g2[1].ld_dy = 3 * kC, g2[1].ld_x = kC, g2[1].dw = a->dw_in, g2[1].db = a->db_in;
+  g2[1].out = 2 * kC, g2[1].in = kC;
+  g2[2].dy = a->dqkv + 2 * kC, g2[2].x = a->x, g2[2].m = m, g2[2].ld_dy = 3 * kC, g2[2].ld_x = kC;
+  g2[2].dw = a->dw_in + 2 * kC * kC, g2[2].db = a->db_in + 2 * kC, g2[2].out = kC, g2[2].in = kC;
+  rc = sst_weight_grad_group_f32x6(g2, 3, ws_g2, stream);   // before ds1 is accumulated into
+  if (rc) return rc;
+  // d(x) of the residual branch and of all three projections: one product over K = 384 (xp = x + constant: d(x) += d(xp))
+  return sst_tall_linear_epi_f32x6(a->dqkv, 3 * kC, a->w_in, kC, 1, nullptr, m, 3 * kC, kC, kEpiAdd, a->ds1, nullptr, kC, a->ds1, kC,
+                                   stream);
+}
+
+}  // extern "C"

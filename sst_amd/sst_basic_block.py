@@ -187,6 +187,94 @@ def _linear_dgrad(dy, w, out=None):
     return dy @ w
 
 
+# The whole layer as ONE library call per direction (csrc/layer_exec.hip: the launch sequence below issued from C) in the
+# exact-split mode at d_model 128 / feed-forward 256.  SST_AMD_LAYER_EXEC=0: the Python sequence (same kernels, same order, same
+# bits: tests/test_gpu_layer_exec.py); the module attribute can be flipped at run time.
+_LAYER_EXEC = int(_os.environ.get('SST_AMD_LAYER_EXEC', '1'))
+
+
+def _layer_exec_ok(x, xp, plan, nhead, act, params):
+    from . import dense
+    if not (_LAYER_EXEC and _LDS_LINEAR and dense.matmul_mode() == 'f32x6' and act in ('gelu', 'relu') and nhead == 8):
+        return False
+    w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b = params
+    if any(p is None for p in params):
+        return False
+    m = x.size(0)
+    shapes_ok = (x.shape == (m, 128) and xp.shape == (m, 128) and w_in.shape == (384, 128) and w_out.shape == (128, 128)
+                 and w1.shape == (256, 128) and w2.shape == (128, 256) and plan.n_tokens == m
+                 and m >= 4096)     # below: the Python sequence takes the library's split-K weight gradients (dense.py)
+    if not shapes_ok:
+        return False
+    for t in (x, xp) + tuple(params):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0):
+            return False
+    return True
+
+
+def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd):
+    from . import _lib
+    import ctypes
+    w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b = params
+    m = x.size(0)
+    dev = x.device
+
+    def e(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    qkv, o, lse, y1, st1 = e(m, 384), e(m, 128), e(m, nhead), e(m, 128), e(m, 2)
+    s1 = e(m, 128) if need_bwd else None
+    pre, h, s2, y2, st2 = e(m, 256), e(m, 256), e(m, 128), e(m, 128), e(m, 2)
+    y2p = e(m, 128) if pos_next is not None else None
+    order = plan.order
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    args = _lib.EncoderLayerFwdArgs(
+        m, plan.n_windows, nhead, 1 if act == 'gelu' else 2, plan.max_tokens, impl, float(eps), float(scale),
+        P(x), P(xp), P(w_in), P(b_in), P(w_out), P(b_out), P(w1), P(b1), P(w2), P(b2), P(n1w), P(n1b), P(n2w), P(n2b),
+        None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
+        P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
+        P(qkv), P(o), P(lse), P(y1), P(s1), P(st1), P(pre), P(h), P(s2), P(y2), P(st2), P(y2p))
+    lib = _lib.load()
+    rc = K._bracket('sra_fwd', plan.n_tokens, lambda: lib.sst_encoder_layer_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_encoder_layer_fwd_f32x6')
+    return qkv, o, lse, y1, s1, st1, pre, h, s2, y2, st2, y2p
+
+
+def _layer_exec_bwd(ctx, dy2, dy2p, saved):
+    from . import _lib
+    import ctypes
+    x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = saved
+    m = x.size(0)
+    dev = x.device
+    plan, nhead, impl = ctx.plan, ctx.nhead, ctx.impl
+
+    def e(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    dy2 = dy2.contiguous()
+    dy2p = dy2p.contiguous() if dy2p is not None else None
+    ds2, dpre, ds1, d_o, dqkv = e(m, 128), e(m, 256), e(m, 128), e(m, 128), e(m, 384)
+    dw_in, db_in, dwo, dbo = e(384, 128), e(384), e(128, 128), e(128)
+    dw1, db1, dw2, db2 = e(256, 128), e(256), e(128, 256), e(128)
+    dn1w, dn1b, dn2w, dn2b = e(128), e(128), e(128), e(128)
+    lib = _lib.load()
+    nbytes = lib.sst_encoder_layer_bwd_workspace_bytes(m, nhead)
+    if nbytes < 0:
+        _lib.check(int(nbytes), 'sst_encoder_layer_bwd_workspace_bytes')
+    ws = _lib.workspace(nbytes, dev)
+    order = plan.order
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    args = _lib.EncoderLayerBwdArgs(
+        m, plan.n_windows, nhead, 1 if ctx.act == 'gelu' else 2, plan.max_tokens, impl, 0.0, float(ctx.scale),
+        P(dy2), P(dy2p), P(x), P(xp), P(qk), P(o), P(lse), P(s1), P(st1), P(y1), P(pre), P(h), P(s2), P(st2),
+        P(w_in), P(w_out), P(w1), P(w2), P(n1w), P(n2w),
+        None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
+        P(ds2), P(dpre), P(ds1), P(d_o), P(dqkv),
+        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), P(dn1w), P(dn1b), P(dn2w), P(dn2b), P(ws))
+    rc = K._bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_encoder_layer_bwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
+    return (ds1, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b, None, None,
+            None)
+
+
 class FusedEncoderLayerFn(torch.autograd.Function):
     """One post-norm SRA encoder layer (sst_basic_block_v2.py:104-119) as a single autograd node.
 
@@ -206,6 +294,21 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         ctx.split_input = xp is not None
         if xp is None:
             xp = x + pos if pos is not None else x
+        params = (w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
+        ctx.exec = False
+        if c == 128 and _layer_exec_ok(x, xp, plan, nhead, act, params):
+            # the launch sequence below as ONE library call (csrc/layer_exec.hip)
+            need_bwd = any(ctx.needs_input_grad)
+            scale = 1.0 / math.sqrt(16.0)
+            qkv, o, lse, y1, s1, st1, pre, h, s2, y2, st2, y2p = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale,
+                                                                                pos_next, need_bwd)
+            if need_bwd:
+                ctx.save_for_backward(x, xp, qkv[:, :2 * c], qkv[:, 2 * c:], o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1,
+                                      w2, n1w, n2w)
+                ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
+                ctx.exec = True
+            ctx.two = pos_next is not None
+            return (y2, y2p) if ctx.two else y2
         if _LDS_LINEAR and c == 128 and lds_linear_qkv_ok(xp, x, w_in):     # one launch, two inputs (csrc/dense_f32x6.hip)
             qkv = lds_linear_qkv(xp, x, w_in, b_in)
             qk, v = qkv[:, :2 * c], qkv[:, 2 * c:]
@@ -253,6 +356,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         c = x.size(1)
         if dy2 is None:           # only the second output was differentiated
             dy2, dy2p = dy2p, None
+        if ctx.exec:
+            return _layer_exec_bwd(ctx, dy2, dy2p if ctx.two else None, ctx.saved_tensors)
         ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
         ds2_for_w2 = ds2
         dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
