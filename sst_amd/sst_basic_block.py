@@ -212,49 +212,69 @@ def _layer_exec_ok(x, xp, plan, nhead, act, params):
     return True
 
 
+# columns (fp32 words per token) of the tensors a layer keeps for its backward pass, in the order they sit in ONE allocation
+# (every piece padded to 256 bytes): ~20 tensor allocations per layer and step were the largest single item of the host time
+_SLAB = (('qkv', 384), ('o', 128), ('lse', 8), ('s1', 128), ('st1', 2), ('y1', 128), ('pre', 256), ('h', 256), ('s2', 128),
+         ('st2', 2))
+
+
+def _slab_offsets(m):
+    off, out = 0, {}
+    for name, cols in _SLAB:
+        out[name] = off
+        off += (m * cols * 4 + 255) // 256 * 256
+    return out, off
+
+
 def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd):
+    """-> (slab (uint8: the kept tensors at _slab_offsets), y2, y2p)"""
     from . import _lib
     import ctypes
     w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b = params
     m = x.size(0)
     dev = x.device
-
-    def e(*shape):
-        return torch.empty(shape, dtype=torch.float32, device=dev)
-    qkv, o, lse, y1, st1 = e(m, 384), e(m, 128), e(m, nhead), e(m, 128), e(m, 2)
-    s1 = e(m, 128) if need_bwd else None
-    pre, h, s2, y2, st2 = e(m, 256), e(m, 256), e(m, 128), e(m, 128), e(m, 2)
-    y2p = e(m, 128) if pos_next is not None else None
+    offs, total = _slab_offsets(m)
+    slab = torch.empty(total, dtype=torch.uint8, device=dev)
+    base = slab.data_ptr()
+    y2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
+    y2p = torch.empty((m, 128), dtype=torch.float32, device=dev) if pos_next is not None else None
     order = plan.order
     P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    S = lambda name: base + offs[name]                   # noqa: E731
     args = _lib.EncoderLayerFwdArgs(
         m, plan.n_windows, nhead, 1 if act == 'gelu' else 2, plan.max_tokens, impl, float(eps), float(scale),
         P(x), P(xp), P(w_in), P(b_in), P(w_out), P(b_out), P(w1), P(b1), P(w2), P(b2), P(n1w), P(n1b), P(n2w), P(n2b),
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
-        P(qkv), P(o), P(lse), P(y1), P(s1), P(st1), P(pre), P(h), P(s2), P(y2), P(st2), P(y2p))
+        S('qkv'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'), S('s2'), P(y2), S('st2'),
+        P(y2p))
     lib = _lib.load()
     rc = K._bracket('sra_fwd', plan.n_tokens, lambda: lib.sst_encoder_layer_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_fwd_f32x6')
-    return qkv, o, lse, y1, s1, st1, pre, h, s2, y2, st2, y2p
+    return slab, y2, y2p
 
 
 def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     from . import _lib
     import ctypes
-    x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = saved
+    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w = saved
     m = x.size(0)
     dev = x.device
     plan, nhead, impl = ctx.plan, ctx.nhead, ctx.impl
+    offs, _ = _slab_offsets(m)
+    base = slab.data_ptr()
 
     def e(*shape):
         return torch.empty(shape, dtype=torch.float32, device=dev)
     dy2 = dy2.contiguous()
     dy2p = dy2p.contiguous() if dy2p is not None else None
-    ds2, dpre, ds1, d_o, dqkv = e(m, 128), e(m, 256), e(m, 128), e(m, 128), e(m, 384)
+    ds1 = e(m, 128)                                    # leaves as d(x)
+    scratch = e(m, 128 + 256 + 128 + 384)              # ds2 | dpre | d_o | dqkv, one after the other (not interleaved)
+    sb = scratch.data_ptr()
+    p_ds2, p_dpre, p_do, p_dqkv = sb, sb + 4 * m * 128, sb + 4 * m * 384, sb + 4 * m * 512
     dw_in, db_in, dwo, dbo = e(384, 128), e(384), e(128, 128), e(128)
     dw1, db1, dw2, db2 = e(256, 128), e(256), e(128, 256), e(128)
-    dn1w, dn1b, dn2w, dn2b = e(128), e(128), e(128), e(128)
+    dn = e(4, 128)
     lib = _lib.load()
     nbytes = lib.sst_encoder_layer_bwd_workspace_bytes(m, nhead)
     if nbytes < 0:
@@ -262,16 +282,18 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     ws = _lib.workspace(nbytes, dev)
     order = plan.order
     P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    S = lambda name: base + offs[name]                   # noqa: E731
+    dnp = dn.data_ptr()
     args = _lib.EncoderLayerBwdArgs(
         m, plan.n_windows, nhead, 1 if ctx.act == 'gelu' else 2, plan.max_tokens, impl, 0.0, float(ctx.scale),
-        P(dy2), P(dy2p), P(x), P(xp), P(qk), P(o), P(lse), P(s1), P(st1), P(y1), P(pre), P(h), P(s2), P(st2),
+        P(dy2), P(dy2p), P(x), P(xp), S('qkv'), S('o'), S('lse'), S('s1'), S('st1'), S('y1'), S('pre'), S('h'), S('s2'), S('st2'),
         P(w_in), P(w_out), P(w1), P(w2), P(n1w), P(n2w),
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
-        P(ds2), P(dpre), P(ds1), P(d_o), P(dqkv),
-        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), P(dn1w), P(dn1b), P(dn2w), P(dn2b), P(ws))
+        p_ds2, p_dpre, P(ds1), p_do, p_dqkv,
+        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 512, dnp + 1024, dnp + 1536, P(ws))
     rc = K._bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_encoder_layer_bwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
-    return (ds1, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b, None, None,
+    return (ds1, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3], None, None,
             None)
 
 
@@ -300,11 +322,9 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             # the launch sequence below as ONE library call (csrc/layer_exec.hip)
             need_bwd = any(ctx.needs_input_grad)
             scale = 1.0 / math.sqrt(16.0)
-            qkv, o, lse, y1, s1, st1, pre, h, s2, y2, st2, y2p = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale,
-                                                                                pos_next, need_bwd)
+            slab, y2, y2p = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd)
             if need_bwd:
-                ctx.save_for_backward(x, xp, qkv[:, :2 * c], qkv[:, 2 * c:], o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1,
-                                      w2, n1w, n2w)
+                ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w)
                 ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
                 ctx.exec = True
             ctx.two = pos_next is not None
@@ -352,12 +372,14 @@ class FusedEncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy2, dy2p=None):
+        if ctx.exec:
+            if dy2 is None:       # only the second output was differentiated
+                dy2, dy2p = dy2p, None
+            return _layer_exec_bwd(ctx, dy2, dy2p if ctx.two else None, ctx.saved_tensors)
         x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
         c = x.size(1)
         if dy2 is None:           # only the second output was differentiated
             dy2, dy2p = dy2p, None
-        if ctx.exec:
-            return _layer_exec_bwd(ctx, dy2, dy2p if ctx.two else None, ctx.saved_tensors)
         ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
         ds2_for_w2 = ds2
         dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
