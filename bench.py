@@ -514,6 +514,33 @@ def main():
             return None
         return ahead.pop() if ahead else model.prepare(frames)
 
+    def host_ms_per_step(n=3):
+        """Interpreter + launch time of one step: forward and backward each timed on the host with the device idle at their
+        start (a full synchronisation in between), so that nothing waits for a kernel except the forward's one size
+        read-back.  A step whose kernels take less than this is bound by the host, whatever the kernels do."""
+        if args.fwd_only:
+            return None
+        tot = 0.0
+        for _ in range(n):
+            for p in params:
+                p.grad = None
+            sync()
+            t_a = time.perf_counter()
+            out = model(frames)
+            t_b = time.perf_counter()
+            g = seed_grad.get(out.shape)
+            if g is None:
+                g = seed_grad[out.shape] = torch.randn(out.shape, device=out.device, dtype=out.dtype)
+            sync()
+            t_c = time.perf_counter()
+            out.backward(g)
+            t_d = time.perf_counter()
+            sync()
+            if reducer is not None:
+                reducer.finish()
+            tot += (t_b - t_a) + (t_d - t_c)
+        return round(tot / n * 1e3, 3)
+
     def step():
         if args.fwd_only:
             with torch.no_grad():
@@ -568,6 +595,7 @@ def main():
         elapsed = float(t.item())
 
     comm = collective_costs(reducer, dev) if reducer is not None else None   # every rank takes part
+    main_host_ms = host_ms_per_step() if world == 1 else None                 # outside the timed region
 
     # Outside the timed region: the forward-only rate of the same workload (BASELINE.json configs[1] is quoted
     # forward-only, the metric forward + backward; `value` is the harder one, this is reported beside it).
@@ -704,6 +732,7 @@ def main():
             sync()
             el = time.perf_counter() - t2
             K.EVENT_SINK = None
+            bf16_host_ms = host_ms_per_step()      # still in the bf16 mode
         finally:
             model.backbone.set_precision('f32x6' if args.matmul == 'f32x6' else 'fp32')
         if world > 1:
@@ -732,6 +761,8 @@ def main():
                                  'sra_bwd': bstats('sra_bwd_bf16', 8 * 128 * 2 + 8)},
                     'vs_fp32_forward': None if diff is None else {'max_abs': float(diff.max()), 'mean_abs': float(diff.mean()),
                                                                   'voxels_equal': True}}
+        bf16_leg['host_ms_per_step'] = bf16_host_ms
+        bf16_leg['host_bound'] = bool(bf16_host_ms is not None and bf16_host_ms > 0.9 * bf16_leg['ms_per_step'])
 
     # roofline of the dominant kernel group (SRA attention core, forward)
     def group_stats(kind):
@@ -797,6 +828,8 @@ def main():
             'value': round(total_frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
+            'host_ms_per_step': main_host_ms,   # interpreter + launch time of a step (forward and backward timed with the device
+                                                # idle at their start): the step is bound by the kernels while this stays below ms_per_step
             'dtype': ('f32 (storage, accumulation, attention, LayerNorm, reductions: fp32; the dense products of the encoder '
                       'layers from the EXACT three-way bf16 split of both fp32 operands, six bf16 MFMA products with fp32 '
                       'accumulation - error vs float64 <= 2 x the fp32 matrix pipe\'s: tests/test_gpu_dense_f32x6.py)'
