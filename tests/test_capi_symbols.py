@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -103,3 +105,17 @@ def test_bf16_shadow_slots_follow_the_parameter_object():
     bf16.invalidate_shadows()
     assert len(bf16._shadows) == 0
 
+
+
+def test_header_is_plain_c_and_cpp(tmp_path):
+    """include/sst_amd.h is the drop-in boundary: it must compile on its own as C99 and as C++ (extern "C", plain pointers and
+    sizes, the argument structs of the layer entry points), with nothing but <stdint.h> behind it"""
+    import shutil
+    import subprocess
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "sst_amd.h"\nint main(void) { return (int)sizeof(sst_encoder_layer_fwd_args) == 0; }\n')
+    inc = os.path.join(ROOT, 'include')
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-I', inc, str(src)], check=True)
+    subprocess.run(['g++', '-std=c++17', '-Wall', '-Werror', '-fsyntax-only', '-I', inc, '-x', 'c++', str(src)], check=True)
