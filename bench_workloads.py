@@ -142,6 +142,24 @@ def fsd_foreground_stand_in(batch_points, votes, z_cut=-1.4):
     return sel_l, pts_l
 
 
+def prepare_index_phase(path, points_list):
+    """The part of a chain's forward pass that depends on the point clouds alone - voxelisation, the sorted-unique grouping of the
+    voxel encoder, every rulebook of the segmentor's sparse U-Net (each with a size read-back) - built AHEAD: a training loop
+    calls this for its next batch between the forward and the backward pass of the current one (what a data loader's worker
+    does with collation), so that those read-backs wait for the short forward kernels instead of sitting, at the head of the
+    next step, behind the whole backward pass.  -> what forward(..., prepared=...) takes; None for providers without the
+    split (the CPU port, the reference)."""
+    if path.ops is not GpuOps:
+        return None
+    with torch.no_grad():
+        batch_points, coors = path.ops.voxelize(points_list, path.SEG_VOXEL, path.PC_RANGE)
+        grouping = path.voxel_encoder.grouping_of(coors)
+        uc = grouping.coors
+        keep = getattr(path.seg_backbone, 'keep_coors_dims', None)
+        rules = path.seg_backbone.build_rulebooks(uc if keep is None else uc[:, keep], len(points_list))
+    return dict(batch_points=batch_points, coors=coors, grouping=grouping, indice_dict=rules)
+
+
 class FSDPath(nn.Module):
     """configs/fsd/fsd_waymoD1_1x.py at hot-path level, over a module provider `ops` (GpuOps = sst_amd; oracle.fsd_cpu = the
     CPU port; oracle.ref_fsd = the reference's own Python in the build container): the SAME wiring for all three.
@@ -181,12 +199,21 @@ class FSDPath(nn.Module):
     def make_cloud(self, n, seed, dev):
         return lidar_like_cloud(n, seed, dev)[0]
 
-    def forward(self, points_list, return_tensors=False):
+    def prepare(self, points_list):
+        return prepare_index_phase(self, points_list)
+
+    def forward(self, points_list, return_tensors=False, prepared=None):
         ops = self.ops
         dev = points_list[0].device
-        batch_points, coors = ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
-        voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
+        if prepared is not None:     # the index phase of this batch was built ahead (prepare_index_phase)
+            batch_points, coors = prepared['batch_points'], prepared['coors']
+            voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True, grouping=prepared['grouping'])
+        else:
+            batch_points, coors = ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
+            voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
         info = self.middle_encoder(voxel_feats, voxel_coors)
+        if prepared is not None:
+            info['indice_dict'] = prepared['indice_dict']
         info.setdefault('batch_size', len(points_list))       # known here: spares the U-Net its read-back of coors[:, 0].max()
         x = self.seg_backbone(info)[0]
         # Voxel2PointScatterNeck (necks/voxel2point_neck.py:28-63)
@@ -320,11 +347,20 @@ class FSDv2Path(nn.Module):
     def make_cloud(self, n, seed, dev):
         return lidar_like_cloud(n, seed, dev, half_extent=50.0, z_ground=-1.8)[0]
 
-    def forward(self, points_list, return_tensors=False):
+    def prepare(self, points_list):
+        return prepare_index_phase(self, points_list)
+
+    def forward(self, points_list, return_tensors=False, prepared=None):
         dev = points_list[0].device
-        batch_points, coors = self.ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
-        voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
+        if prepared is not None:     # the index phase of this batch was built ahead (prepare_index_phase)
+            batch_points, coors = prepared['batch_points'], prepared['coors']
+            voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True, grouping=prepared['grouping'])
+        else:
+            batch_points, coors = self.ops.voxelize(points_list, self.SEG_VOXEL, self.PC_RANGE)
+            voxel_feats, voxel_coors, v2p = self.voxel_encoder(batch_points, coors, return_inv=True)
         info = self.middle_encoder(voxel_feats, voxel_coors)
+        if prepared is not None:
+            info['indice_dict'] = prepared['indice_dict']
         info.setdefault('batch_size', len(points_list))
         x = self.seg_backbone(info)[0]
         pts_feats = x['voxel_feats'][v2p]                                               # Voxel2PointScatterNeck
@@ -590,11 +626,18 @@ def run(args, rank, world, dev, make_reducer):
     stats = {}
     reducer = make_reducer(params, world, args)
 
+    prefetch = not getattr(args, 'no_plan_prefetch', False)
+    ahead = []      # the index phase of the NEXT batch (depends on the point clouds only: no parameters, no features)
+
     def step():
         for p in params:
             p.grad = None
-        loss, st = model(clouds)
+        loss, st = model(clouds, prepared=ahead.pop() if ahead else None)
         stats.update(st)
+        if prefetch:
+            # between the forward and the backward pass: its read-backs wait for the (short, host-bound) forward kernels, and the
+            # next step's forward is then issued without a stop while the device still works through this backward pass
+            ahead.append(model.prepare(clouds))
         loss.backward()
         if reducer is not None:
             reducer.finish()        # parameters without a gradient this step (an empty stage) travel as zeros
@@ -640,6 +683,10 @@ def run(args, rank, world, dev, make_reducer):
                'data': 'synthetic',
                'config': {'workload': spec['name'] + f'; {n_pts} points/frame (ground plane + boxes), fwd+bwd',
                           'frames_per_gpu': args.frames_per_gpu, 'points_per_frame': n_pts, 'parallelism': f'dp{world}',
+                          'index_plan': ('voxelisation, voxel grouping and the rulebooks of the segmentor U-Net of the next batch built '
+                                         'between the forward and the backward pass of the current one (they depend on the point '
+                                         'cloud only; the cluster / virtual-voxel stages, which depend on the network, stay inside '
+                                         'the forward pass)') if prefetch else 'built at the head of its step',
                           'sizes': {k: int(v) for k, v in stats.items()},
                           'stand_ins': 'segmentation / box heads = linear layers, foreground = geometric rule '
                                        '(detector glue is out of scope)'},

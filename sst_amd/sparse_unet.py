@@ -150,9 +150,26 @@ class _UNetStages(nn.Module):
             setattr(self, f'upsample_layer{level}', make_sparse_convmodule(width, c_up, 3, **up, **common))
             width = c_up
 
-    def encode(self, voxel_features, coors, batch_size):
-        """-> the feature of every encoder level, finest first"""
-        x = self.conv_input(SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size))
+    def build_rulebooks(self, coors, batch_size):
+        """Every rulebook of the network for the voxel set ``coors`` [N, 4] (b, z, y, x), WITHOUT features: the index half of
+        encode() (the decoder re-uses the encoder's keys).  They depend on the coordinates alone, so a training loop can
+        build them for the NEXT batch while the current one is still being differentiated - each rulebook costs a size
+        read-back, and inside the forward pass every one of them waits for all the kernels queued before it.  -> the
+        ``indice_dict`` to hand to encode() / forward()."""
+        from .spconv import SparseConvolution
+        x = SparseConvTensor(None, coors.int(), self.sparse_shape, batch_size)
+        for m in list(self.conv_input.modules()) + list(self.encoder_layers.modules()):
+            if isinstance(m, SparseConvolution):
+                x = m.dry(x)
+        return x.indice_dict
+
+    def encode(self, voxel_features, coors, batch_size, indice_dict=None):
+        """-> the feature of every encoder level, finest first; indice_dict: rulebooks built ahead (build_rulebooks) for
+        exactly these coordinates"""
+        first = SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
+        if indice_dict is not None:
+            first.indice_dict = indice_dict
+        x = self.conv_input(first)
         levels = []
         for stage in self.encoder_layers:
             x = stage(x)
@@ -242,7 +259,7 @@ class SimpleSparseUNet(_UNetStages):
         batch_size = voxel_info.get('batch_size')
         if batch_size is None:   # the reference reads it off the coordinates (one read-back, sparse_unet.py:382)
             batch_size = int(coors[:, 0].max().item()) + 1
-        finest, every = self.decode(self.encode(voxel_info['voxel_feats'], coors, batch_size),
+        finest, every = self.decode(self.encode(voxel_info['voxel_feats'], coors, batch_size, voxel_info.get('indice_dict')),
                                     keep_all=self.return_multiscale_features)
         return [{'voxel_feats': finest.features, 'voxel_coors': finest.indices, 'sparse_shape': finest.spatial_shape,
                  'batch_size': finest.batch_size, 'decoder_features': every}]

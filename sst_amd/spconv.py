@@ -688,9 +688,9 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, input):
-        assert isinstance(input, SparseConvTensor)
-        features = input.features
+    def _geometry(self, input):
+        """-> (outids, indice_pairs, indice_pair_num, out_spatial_shape): the index half of forward() - output voxels and the
+        rulebook, found under ``indice_key`` in the tensor's ``indice_dict`` or built (and filed there) - features untouched"""
         indices = input.indices
         spatial_shape = input.spatial_shape
         batch_size = input.batch_size
@@ -703,14 +703,6 @@ class SparseConvolution(SparseModule):
                                                          self.dilation)
         else:
             out_spatial_shape = spatial_shape
-        if self.conv1x1:
-            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
-            if self.bias is not None:
-                features += self.bias
-            out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
-            out_tensor.indice_dict = input.indice_dict
-            out_tensor.grid = input.grid
-            return out_tensor
         datas = input.find_indice_pair(self.indice_key)
         if self.inverse:
             assert datas is not None and self.indice_key is not None
@@ -725,6 +717,33 @@ class SparseConvolution(SparseModule):
                     indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation,
                     self.output_padding, self.subm, self.transposed, grid=input.grid)
                 input.indice_dict[self.indice_key] = (outids, indices, indice_pairs, indice_pair_num, spatial_shape)
+        return outids, indice_pairs, indice_pair_num, out_spatial_shape
+
+    def dry(self, input):
+        """The layer on the voxel SET of ``input`` only: its output voxels, with the rulebook filed under ``indice_key`` - for
+        building the rulebooks of a network ahead of its forward pass (they depend on the coordinates alone: sparse_unet.
+        _UNetStages.build_rulebooks); features are neither read nor produced."""
+        if self.conv1x1:
+            return input
+        outids, _, _, out_spatial_shape = self._geometry(input)
+        out = SparseConvTensor(None, outids, out_spatial_shape, input.batch_size)
+        out.indice_dict = input.indice_dict
+        out.grid = input.grid
+        return out
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        features = input.features
+        batch_size = input.batch_size
+        if self.conv1x1:
+            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                features += self.bias
+            out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
+            out_tensor.indice_dict = input.indice_dict
+            out_tensor.grid = input.grid
+            return out_tensor
+        outids, indice_pairs, indice_pair_num, out_spatial_shape = self._geometry(input)
         if self.subm:
             out_features = indice_subm_conv(features, self.weight, indice_pairs, indice_pair_num, outids.shape[0])
         elif self.inverse:
@@ -737,7 +756,6 @@ class SparseConvolution(SparseModule):
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid
         return out_tensor
-
 
 @CONV_LAYERS.register_module()
 class SparseConv3d(SparseConvolution):

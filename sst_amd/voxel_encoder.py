@@ -260,9 +260,15 @@ class DynamicScatterVFE(DynamicVFE):
     def map_voxel_center_to_point(self, voxel_mean, voxel2point_inds):
         return voxel_mean[voxel2point_inds]
 
-    def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False):
+    def grouping_of(self, coors):
+        """the point -> voxel grouping this encoder reduces over (index work only: no parameters, no features): callers that
+        pipeline batches build it ahead and hand it to forward(..., grouping=...)"""
+        return _UniqueGrouping(coors)
+
+    def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False, grouping=None):
         features = features.float()
-        grouping = _UniqueGrouping(coors)   # one sorted-unique whether or not unique_once is set: it is never redone
+        if grouping is None:
+            grouping = _UniqueGrouping(coors)   # one sorted-unique whether or not unique_once is set: it is never redone
         x = self._decorate(features, coors, grouping, cluster_div=self.rel_dist_scaler, mean_of_xyz_only=True)
         fused_plan = UniquePlanAdapter(grouping.plan) if self.fused_stack else None
         if fused_plan is not None and fused_vfe2_ok(self, x, fused_plan):
