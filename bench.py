@@ -324,15 +324,16 @@ def cpu_reference_leg(model, frame_cpu, num_blocks, budget_s=75.0):
     vs64 = None
     if voxels_equal and same64:
         from sst_amd import dense as _dense
-        mode_now = _dense.matmul_mode()
+        mode_now = getattr(model.backbone, 'matmul', None) or _dense.matmul_mode()
         vs64 = {f'gpu, dense products {mode_now} (the timed mode)': float((out_g.double() - out64).abs().max()),
                 'cpu port, fp32': float((out_first.double() - out64).abs().max())}
         other = 'f32' if mode_now != 'f32' else 'f32x6'
+        names = {'f32': 'fp32', 'f32x6': 'f32x6', 'f32x3': 'f32x3'}      # the backbone keeps its own mode: switch it there
         try:
-            _dense.set_matmul_mode(other)
+            model.backbone.set_precision(names[other])
             vs64[f'gpu, dense products {other}'] = float((gpu_forward_sorted(model, [frame_cpu.to(dev)])[0].double() - out64).abs().max())
         finally:
-            _dense.set_matmul_mode(mode_now)
+            model.backbone.set_precision(names[mode_now])
     grad_err = None
     if voxels_equal:
         gpu_forward_sorted(model, [frame_cpu.to(dev)], upstream_sorted=up)
@@ -541,6 +542,14 @@ def main():
             tot += (t_b - t_a) + (t_d - t_c)
         return round(tot / n * 1e3, 3)
 
+    def fresh_allocator():
+        """Every leg beside the headline starts from an empty caching allocator: the legs keep differently sized tensors (one
+        512 MB slab per layer in the exact-split mode, ~25 tensors per layer in the others, half-size ones in the bf16 mode), and
+        a leg that inherited the previous one's cached blocks spent its timed steps splitting and re-requesting segments
+        (bf16 leg 94-112 frames/s behind another leg, 163 as the main loop of its own process)."""
+        sync()
+        torch.cuda.empty_cache()
+
     def step():
         if args.fwd_only:
             with torch.no_grad():
@@ -566,6 +575,13 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    # What a training script does once its model and data pipeline are built: collect, then move everything alive to the permanent
+    # generation.  A full collection of a process that has imported torch walks ~10^6 objects (60-70 ms, measured: one step of
+    # 71 ms among twenty of 6.5 ms in the reduced-precision leg; none with the collector off); frozen objects are not walked, the
+    # collector stays ON for what the steps allocate.
+    import gc
+    gc.collect()
+    gc.freeze()
     n_voxels = int(model.last_voxel_coors.size(0))
 
     def sync():
@@ -618,54 +634,77 @@ def main():
                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
                     'note': 'same pipeline under torch.no_grad(), training-mode drop/shuffle; not part of `value`'}
 
-    # Beside the exact-fp32 headline: the same step with the projections / FFN products of the encoder layers evaluated as three
-    # bf16 products of split fp32 operands with fp32 accumulation (csrc/dense_f32x3.hip; everything stays fp32 in HBM, the
-    # attention core, LayerNorm and the weight gradients stay exact fp32).  ~1e-5 relative per product - tighter than the TF32
-    # tensor-core products torch 1.8 (the reference's pinned version) uses for these layers by default on Ampere.
-    def matmul_leg(mode, dtype, what):
-        """the same step with the dense products of the encoder layers in another multiply mode (sst_amd/dense.py), beside
-        `value`: W warm-up steps, K timed; its forward output against the timed mode's on the same frame"""
+    # Order of the legs: the reduced-precision leg right behind the headline and the forward-only rate, the fp32-matrix-pipe leg
+    # last - it draws the most power of all, and on some boxes whatever ran behind it ran at lower clocks (bf16 leg 112 frames/s
+    # behind it, 163 as the main loop of the same process minutes later).
+    # Beside the fp32 headline: the same step with the encoder layers in the reduced-precision mode (bf16 storage, fp32
+    # accumulation / softmax / LayerNorm statistics, fp32 master weights: sst_amd/bf16.py) - what the reference's own
+    # fp16 training of these layers (configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82) corresponds to here.
+    bf16_leg = None
+    if not args.fwd_only and not args.no_bf16_leg:
+        fresh_allocator()
         with torch.no_grad():
             ref_out, ref_key = gpu_forward_sorted(model, frames)
-        model.backbone.set_precision(mode)
+        model.backbone.set_precision('bf16')
         try:
             with torch.no_grad():
-                alt_out, alt_key = gpu_forward_sorted(model, frames)
-            same = torch.equal(ref_key, alt_key)
-            for _ in range(3):
+                low_out, low_key = gpu_forward_sorted(model, frames)
+            diff = (low_out - ref_out).abs() if torch.equal(ref_key, low_key) else None
+            for _ in range(max(3, args.warmup)):
                 step()
+            bsink = []
+            K.EVENT_SINK = bsink
+            K.EVENT_KINDS = ('sra_fwd_bf16', 'sra_bwd_bf16')
             sync()
-            t4 = time.perf_counter()
+            t2 = time.perf_counter()
+            per_step = []
+            dev_allocs0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
             for _ in range(args.steps):
+                ts = time.perf_counter()
                 step()
+                per_step.append(time.perf_counter() - ts)
             sync()
-            el = time.perf_counter() - t4
+            el = time.perf_counter() - t2
+            if os.environ.get('SST_BENCH_DEBUG'):
+                print('bf16 leg host time per step (ms):', [round(1e3 * v, 2) for v in per_step], 'device allocations during the leg:',
+                      torch.cuda.memory_stats().get('num_device_alloc', 0) - dev_allocs0, file=sys.stderr)
+            K.EVENT_SINK = None
+            bf16_host_ms = host_ms_per_step()      # still in the bf16 mode
         finally:
             model.backbone.set_precision('f32x6' if args.matmul == 'f32x6' else 'fp32')
         if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
-                'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': dtype,
-                'max_abs_err_vs_timed_mode_forward': float((alt_out - ref_out).abs().max()) if same else None,
-                'voxels_equal': bool(same), 'what': what}
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
 
-    x3_leg = mfma_leg = None
-    if not args.fwd_only and not args.no_f32x3_leg and args.precision == 'f32':
-        x3_leg = matmul_leg('f32x3', 'f32 storage, bf16 x 3 products',
-                            'same step; q|k, v, out-proj, FFN products and their data gradients as x_hi w_hi + x_lo w_hi + x_hi w_lo '
-                            'on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (two-way split: ~1e-5 relative per product, NOT '
-                            'exact - a leg, never `value`); weight gradients on the fp32 matrix pipe')
-        if args.matmul == 'f32x6':
-            mfma_leg = matmul_leg('fp32', 'f32, fp32 matrix pipe',
-                                  'same step with every dense product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: '
-                                  'csrc/dense_f32.hip, csrc/wgrad.hip) - the arithmetic of rounds 1-3; the timed mode evaluates the '
-                                  'same products from the exact three-way bf16 split (csrc/dense_f32x6.hip, csrc/wgrad_x6.hip)')
+        def bstats(kind, bytes_per_token):
+            ev = [(e0.elapsed_time(e1), n) for k_, e0, e1, n in bsink if k_ == kind]
+            ev = [(t_, n) for t_, n in ev if t_ > 0]
+            if not ev:
+                return None
+            ms_ = sum(t_ for t_, _ in ev) / len(ev)
+            tok_ = sum(n for _, n in ev) / len(ev)
+            ach = bytes_per_token * tok_ / (ms_ * 1e-3) / 1e9
+            return {'achieved': round(ach, 1), 'frac': round(ach / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(ms_, 4),
+                    'algorithmic_bytes_per_launch': int(bytes_per_token * tok_), 'launches_timed': len(ev)}
+
+        bf16_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                    'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': 'bf16',
+                    'what': 'same step, encoder layers in bf16 storage (fp32 accumulate / softmax / LayerNorm statistics, '
+                            'fp32 master weights); voxelize, VFE and the index plan unchanged (fp32, as the reference '
+                            'forces them: voxel_encoder.py:229)',
+                    'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'sra_fwd': bstats('sra_fwd_bf16', 4 * 128 * 2 + 8),
+                                 'sra_bwd': bstats('sra_bwd_bf16', 8 * 128 * 2 + 8)},
+                    'vs_fp32_forward': None if diff is None else {'max_abs': float(diff.max()), 'mean_abs': float(diff.mean()),
+                                                                  'voxels_equal': True}}
+        bf16_leg['host_ms_per_step'] = bf16_host_ms
+        bf16_leg['host_bound'] = bool(bf16_host_ms is not None and bf16_host_ms > 0.9 * bf16_leg['ms_per_step'])
 
     # Beside the headline (uniform cloud): the same step on a LiDAR-like frame with out-of-range points and duplicates
     lidar_leg = None
     if not args.fwd_only and not args.no_lidar_leg:
+        fresh_allocator()
         lframes = [make_lidar_cloud(2000 * rank + i, dev) for i in range(args.frames_per_gpu)]
 
         def lstep():
@@ -708,61 +747,51 @@ def main():
                              '5 % box hits, 5 % of the points outside the range (clamped), 2 % exact duplicates '
                              '(SURVEY.md section 8(d) L-cloud + pathological input); not part of `value`'}
 
-    # Beside the fp32 headline: the same step with the encoder layers in the reduced-precision mode (bf16 storage, fp32
-    # accumulation / softmax / LayerNorm statistics, fp32 master weights: sst_amd/bf16.py) - what the reference's own
-    # fp16 training of these layers (configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82) corresponds to here.
-    bf16_leg = None
-    if not args.fwd_only and not args.no_bf16_leg:
+    # Beside the exact-fp32 headline: the same step with the projections / FFN products of the encoder layers evaluated as three
+    # bf16 products of split fp32 operands with fp32 accumulation (csrc/dense_f32x3.hip; everything stays fp32 in HBM, the
+    # attention core, LayerNorm and the weight gradients stay exact fp32).  ~1e-5 relative per product - tighter than the TF32
+    # tensor-core products torch 1.8 (the reference's pinned version) uses for these layers by default on Ampere.
+    def matmul_leg(mode, dtype, what):
+        """the same step with the dense products of the encoder layers in another multiply mode (sst_amd/dense.py), beside
+        `value`: W warm-up steps, K timed; its forward output against the timed mode's on the same frame"""
+        fresh_allocator()
         with torch.no_grad():
             ref_out, ref_key = gpu_forward_sorted(model, frames)
-        model.backbone.set_precision('bf16')
+        model.backbone.set_precision(mode)
         try:
             with torch.no_grad():
-                low_out, low_key = gpu_forward_sorted(model, frames)
-            diff = (low_out - ref_out).abs() if torch.equal(ref_key, low_key) else None
+                alt_out, alt_key = gpu_forward_sorted(model, frames)
+            same = torch.equal(ref_key, alt_key)
             for _ in range(3):
                 step()
-            bsink = []
-            K.EVENT_SINK = bsink
-            K.EVENT_KINDS = ('sra_fwd_bf16', 'sra_bwd_bf16')
             sync()
-            t2 = time.perf_counter()
+            t4 = time.perf_counter()
             for _ in range(args.steps):
                 step()
             sync()
-            el = time.perf_counter() - t2
-            K.EVENT_SINK = None
-            bf16_host_ms = host_ms_per_step()      # still in the bf16 mode
+            el = time.perf_counter() - t4
         finally:
             model.backbone.set_precision('f32x6' if args.matmul == 'f32x6' else 'fp32')
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': dtype,
+                'max_abs_err_vs_timed_mode_forward': float((alt_out - ref_out).abs().max()) if same else None,
+                'voxels_equal': bool(same), 'what': what}
 
-        def bstats(kind, bytes_per_token):
-            ev = [(e0.elapsed_time(e1), n) for k_, e0, e1, n in bsink if k_ == kind]
-            ev = [(t_, n) for t_, n in ev if t_ > 0]
-            if not ev:
-                return None
-            ms_ = sum(t_ for t_, _ in ev) / len(ev)
-            tok_ = sum(n for _, n in ev) / len(ev)
-            ach = bytes_per_token * tok_ / (ms_ * 1e-3) / 1e9
-            return {'achieved': round(ach, 1), 'frac': round(ach / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(ms_, 4),
-                    'algorithmic_bytes_per_launch': int(bytes_per_token * tok_), 'launches_timed': len(ev)}
-
-        bf16_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
-                    'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': 'bf16',
-                    'what': 'same step, encoder layers in bf16 storage (fp32 accumulate / softmax / LayerNorm statistics, '
-                            'fp32 master weights); voxelize, VFE and the index plan unchanged (fp32, as the reference '
-                            'forces them: voxel_encoder.py:229)',
-                    'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                 'sra_fwd': bstats('sra_fwd_bf16', 4 * 128 * 2 + 8),
-                                 'sra_bwd': bstats('sra_bwd_bf16', 8 * 128 * 2 + 8)},
-                    'vs_fp32_forward': None if diff is None else {'max_abs': float(diff.max()), 'mean_abs': float(diff.mean()),
-                                                                  'voxels_equal': True}}
-        bf16_leg['host_ms_per_step'] = bf16_host_ms
-        bf16_leg['host_bound'] = bool(bf16_host_ms is not None and bf16_host_ms > 0.9 * bf16_leg['ms_per_step'])
+    x3_leg = mfma_leg = None
+    if not args.fwd_only and not args.no_f32x3_leg and args.precision == 'f32':
+        x3_leg = matmul_leg('f32x3', 'f32 storage, bf16 x 3 products',
+                            'same step; q|k, v, out-proj, FFN products and their data gradients as x_hi w_hi + x_lo w_hi + x_hi w_lo '
+                            'on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (two-way split: ~1e-5 relative per product, NOT '
+                            'exact - a leg, never `value`); weight gradients on the fp32 matrix pipe')
+        if args.matmul == 'f32x6':
+            mfma_leg = matmul_leg('fp32', 'f32, fp32 matrix pipe',
+                                  'same step with every dense product on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: '
+                                  'csrc/dense_f32.hip, csrc/wgrad.hip) - the arithmetic of rounds 1-3; the timed mode evaluates the '
+                                  'same products from the exact three-way bf16 split (csrc/dense_f32x6.hip, csrc/wgrad_x6.hip)')
 
     # roofline of the dominant kernel group (SRA attention core, forward)
     def group_stats(kind):

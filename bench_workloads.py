@@ -650,6 +650,9 @@ def run(args, rank, world, dev, make_reducer):
 
     for _ in range(args.warmup):
         step()
+    import gc
+    gc.collect()
+    gc.freeze()      # see bench.py: a full collection of a torch process costs 60-70 ms; frozen objects are not walked
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

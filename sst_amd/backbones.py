@@ -159,7 +159,8 @@ class _WindowTransformer(nn.Module):
         # these products on Ampere.  The attention core, LayerNorm and the weight gradients stay exact fp32.
         # 'f32x6': the same fp32 tensors and results (to fp32 rounding), the products from an EXACT three-way bf16 split, six
         # products with fp32 accumulation (csrc/dense_f32x6.hip): same arithmetic class as exact fp32, 2.7 x less matrix-pipe
-        # time.  NOTE: the switch is process-global (dense.set_matmul_mode): every model of the process follows the last call.
+        # time.  The module keeps its mode (self.matmul) and runs its stack inside dense.matmul_mode_scope(); the call also sets
+        # the process-wide default, for code that multiplies outside a backbone's forward pass.
         from . import dense
         split = precision if precision in ('f32x3', 'f32x6') else None
         dense.set_matmul_mode(split or 'f32')
@@ -261,7 +262,9 @@ class SSTv2(_WindowTransformer):
         lookup = None
         if 'pos_table' in voxel_info and 'pos_index_shift0' in voxel_info:   # (table, row index) per partition
             lookup = [(voxel_info['pos_table'], voxel_info[f'pos_index_shift{i}']) for i in range(2)]
-        feats = self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks, pos_lookup=lookup)
+        from . import dense
+        with dense.matmul_mode_scope(getattr(self, 'matmul', None)):     # this module's own mode, whatever another model set
+            feats = self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks, pos_lookup=lookup)
         if not self.to_bev:
             assert self.num_attached_conv <= 0, 'the attached convolutions need the BEV canvas'
             return [{'voxel_feats': feats, 'voxel_coors': coors}]

@@ -128,7 +128,8 @@ _LDS_LINEAR_SHAPES = ((128, 128), (128, 256), (256, 128))
 #           holds (error against float64 <= 2 x the fp32 kernel's, every shape and the 12-layer stack);
 #   'f32x3' two-way split, three products (csrc/dense_f32x3.hip; ~1e-5 relative, tighter than the TF32 products of the
 #           reference's own torch 1.8 on Ampere): a leg beside the headline, never the headline.
-# SSTv2.set_precision switches it.  PROCESS-GLOBAL: models built side by side (an EMA copy, a two-stage detector) share it.
+# SSTv2.set_precision switches it: the module keeps its own mode and runs its stack inside matmul_mode_scope(); the global
+# below is the default for code outside any scope.
 _MATMUL_MODE = 'f32'
 _MATMUL_MODES = ('f32', 'f32x3', 'f32x6')
 
@@ -142,6 +143,29 @@ def set_matmul_mode(mode):
 
 def matmul_mode():
     return _MATMUL_MODE
+
+
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def matmul_mode_scope(mode):
+    """The mode for the duration of a block (None: leave it alone).  A backbone runs its encoder stack inside the scope of ITS
+    OWN mode and every fused layer node re-enters the mode of its forward pass for its backward pass, so two models of one
+    process (an EMA copy, a two-stage detector, a test beside a benchmark) no longer follow each other's set_precision()
+    (ADVICE round 3); set_matmul_mode() stays the process-wide default for code outside any scope."""
+    global _MATMUL_MODE
+    if mode is None:
+        yield
+        return
+    if mode not in _MATMUL_MODES:
+        raise ValueError(mode)
+    prev = _MATMUL_MODE
+    _MATMUL_MODE = mode
+    try:
+        yield
+    finally:
+        _MATMUL_MODE = prev
 
 
 def lds_linear_ok(x, w, trans_w=False):

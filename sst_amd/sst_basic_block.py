@@ -312,6 +312,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         ignored; pos_next = (table, row index): also return y + table[index], the next layer's xp."""
         c = x.size(1)
         x = x.contiguous()
+        from . import dense as _dense
+        ctx.matmul = _dense.matmul_mode()    # the backward pass multiplies the way the forward pass did, whatever the mode is by then
         ctx.set_materialize_grads(False)     # an output nobody differentiates (y2p when its gradient was folded into y2's) stays None
         ctx.split_input = xp is not None
         if xp is None:
@@ -372,6 +374,12 @@ class FusedEncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy2, dy2p=None):
+        from . import dense as _dense
+        with _dense.matmul_mode_scope(ctx.matmul):
+            return FusedEncoderLayerFn._backward(ctx, dy2, dy2p)
+
+    @staticmethod
+    def _backward(ctx, dy2, dy2p=None):
         if ctx.exec:
             if dy2 is None:       # only the second output was differentiated
                 dy2, dy2p = dy2p, None
@@ -446,10 +454,14 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
             enc.norm1.eps, xp, pos_next)
         return out if pos_next is not None else (out, None)
 
+    from . import dense as _dense
+    mode = _dense.matmul_mode()
+
     def block_fn(bi):
         def run(x, xp):
-            for j, enc in enumerate(blocks[bi].encoder_list):
-                x, xp = layer(enc, 2 * bi + j, x, xp)
+            with _dense.matmul_mode_scope(mode):     # also when a checkpointed block is recomputed during the backward pass
+                for j, enc in enumerate(blocks[bi].encoder_list):
+                    x, xp = layer(enc, 2 * bi + j, x, xp)
             return (x, xp) if xp is not None else (x,)
         return run
 

@@ -93,3 +93,25 @@ def test_fused_vfe_declines_what_it_is_not_built_for():
         type='DynamicVFE', in_channels=3, feat_channels=[64, 64, 128], with_cluster_center=True, with_voxel_center=True,
         voxel_size=(0.32, 0.32, 6), point_cloud_range=[-74.88, -74.88, -2, 74.88, 74.88, 4]))
     assert len(three.vfe_layers) == 3 and not fused_vfe2_ok(three, x, Plan())
+
+
+def test_precision_switch_is_scoped_to_the_module():
+    """two backbones of one process with different set_precision(): each runs its encoder stack in ITS mode, whichever call
+    came last (the switch used to be process-global), and the process-wide default is restored afterwards"""
+    import sst_amd
+    from sst_amd import dense
+    cfg = dict(type='SSTv2', d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2, output_shape=[468, 468],
+               debug=False, num_attached_conv=0, to_bev=False)
+    a, b = sst_amd.build_backbone(dict(cfg)), sst_amd.build_backbone(dict(cfg))
+    a.set_precision('f32x6')
+    b.set_precision('fp32')                      # the last call sets the process-wide default: 'f32'
+    assert dense.matmul_mode() == 'f32' and a.matmul == 'f32x6' and b.matmul == 'f32'
+    seen = {}
+    for name, model in (('a', a), ('b', b)):
+        model._window_inputs = lambda info: (None, None, None)
+        model.run_blocks = lambda feats, pos, plans, masks=None, pos_lookup=None, _n=name: seen.setdefault(_n, dense.matmul_mode()) and feats
+        model({'voxel_coors': torch.zeros((4, 4), dtype=torch.int64), 'voxel_feats': torch.zeros(4, 128)})
+    assert seen == {'a': 'f32x6', 'b': 'f32'} and dense.matmul_mode() == 'f32'
+    with pytest.raises(ValueError):
+        with dense.matmul_mode_scope('tf32'):
+            pass
