@@ -73,25 +73,22 @@ def make_lidar_cloud(seed, device, beams=64, azimuth_steps=2650, sensor_height=2
     return xyz[torch.randperm(xyz.size(0), generator=g)].contiguous().to(device)
 
 
-class Pipeline(torch.nn.Module):
-    """The SST-base hot path behind the reference's registry names (configs/sst_refactor/
-    sst_waymoD5_1x_3class_8heads_v2.py:26-79), without the dense BEV neck/head."""
-
-    def __init__(self, num_blocks=6, with_bev=False):
-        super().__init__()
-        import sst_amd
-        self.with_bev = with_bev
-        self.voxel_layer = sst_amd.Voxelization(VOXEL_SIZE, PC_RANGE, -1, (-1, -1))
-        self.voxel_encoder = sst_amd.build_voxel_encoder(dict(
+def _pipeline_config(num_blocks=6, with_bev=False):
+    """the `model` dictionary of the headline: configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:26-79 with the debug
+    checks and prints off, and without the dense BEV neck / head unless `with_bev`"""
+    return dict(
+        type='DynamicVoxelNet',
+        voxel_layer=dict(voxel_size=VOXEL_SIZE, max_num_points=-1, point_cloud_range=PC_RANGE, max_voxels=(-1, -1)),
+        voxel_encoder=dict(
             type='DynamicVFE', in_channels=3, feat_channels=[64, 128], with_distance=False, voxel_size=VOXEL_SIZE,
             with_cluster_center=True, with_voxel_center=True, point_cloud_range=PC_RANGE,
-            norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01)))
-        self.middle_encoder = sst_amd.build_middle_encoder(dict(
+            norm_cfg=dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01)),
+        middle_encoder=dict(
             type='SSTInputLayerV2', window_shape=(12, 12, 1), sparse_shape=(468, 468, 1), shuffle_voxels=True,
             window_major=True,
             debug=False, drop_info=(DROP_TRAIN, DROP_TEST), pos_temperature=10000, normalize_pos=False, mute=True,
-            reference_outputs=False))
-        self.backbone = sst_amd.build_backbone(dict(
+            reference_outputs=False),
+        backbone=dict(
             type='SSTv2', d_model=[128] * num_blocks, nhead=[8] * num_blocks, num_blocks=num_blocks,
             dim_feedforward=[256] * num_blocks, output_shape=[468, 468], debug=False,
             # --workload sst_bev: the backbone as the config builds it (sst_waymoD5_1x_3class_8heads_v2.py:64-79): BEV canvas +
@@ -101,37 +98,56 @@ class Pipeline(torch.nn.Module):
                                  dict(kernel_size=3, dilation=1, padding=1, stride=1),
                                  dict(kernel_size=3, dilation=2, padding=2, stride=1)])
                if with_bev else dict(num_attached_conv=0, to_bev=False))))
-        self.fused_index = True     # csrc/frame_plan.hip; False: the piecewise path through the module interfaces
-        self._planner = None
 
-    def prepare(self, points_list):
-        """Index work of one batch - dynamic voxelize, point->voxel grouping, window bucketing / drop / window CSR,
-        positional embeddings: depends on the point clouds only (no parameters, no features)."""
-        if self.fused_index:
-            if self._planner is None:
-                from sst_amd.frame_plan import FramePlanner
-                self._planner = FramePlanner(self.voxel_layer, self.voxel_encoder, self.middle_encoder)
-            if self._planner.supported(len(points_list)):
-                return self._planner.build(points_list)     # no host round trip; sizes are read in forward()
-        points, coors = self.voxel_layer.voxelize_batch(points_list)
-        sp = self.voxel_encoder.scatter_plan(coors)
-        wplan = self.middle_encoder.build_plan(sp.voxel_coors, len(points_list), 128, torch.float32)
-        return points, coors, sp, wplan
 
-    def forward(self, points_list, prepared=None):
-        prepared = prepared if prepared is not None else self.prepare(points_list)
-        if isinstance(prepared, tuple):     # piecewise index path (one read-back per module boundary)
-            points, coors, sp, wplan = prepared
-            voxel_feats, _ = self.voxel_encoder(points, coors, scatter_plan=sp)
-            info = self.middle_encoder.apply_plan(wplan, voxel_feats)
-        else:                               # fused index plan: the voxel encoder is queued before the sizes are read
-            voxel_feats, _ = self.voxel_encoder(prepared.points, prepared.coors, scatter_plan=prepared)
-            prepared.want_pos_rows = False   # the encoder stacks (fp32 chain and bf16) take (table, row index) instead
-            info = prepared.finalize(voxel_feats, self.middle_encoder)
-        self.last_voxel_coors = info['voxel_coors']
-        self.last_plans = [info.get('sra_plan_shift0'), info.get('sra_plan_shift1')]
-        out = self.backbone(info)[0]
-        return out if self.with_bev else out['voxel_feats']
+def Pipeline(num_blocks=6, with_bev=False, model_cfg=None, voxel_feats_only=None):
+    """The SST-base hot path as the detector that calls it: sst_amd.DynamicVoxelNet (mirror of detectors/dynamic_voxelnet.py:10-71)
+    built through the registry from a config `model` dictionary - the headline's (_pipeline_config) or, `model_cfg`, any other
+    (the shipped configs read from tests/golden/configs/).  forward(points_list, prepared=None) -> features of the kept voxels
+    [M', C] (`voxel_feats_only`, default: whenever the backbone does not go to the BEV canvas ... or is asked not to), or the
+    backbone's own output (BEV canvas behind the attached convolutions)."""
+    import sst_amd
+
+    class _Pipeline(sst_amd.DynamicVoxelNet):
+
+        def forward(self, points_list, prepared=None):
+            info = self.voxel_info(points_list, prepared)
+            self.last_voxel_coors = info['voxel_coors']
+            self.last_plans = [info.get('sra_plan_shift0'), info.get('sra_plan_shift1')]
+            if self.voxel_feats_only:
+                return self.backbone.forward_voxels(info)
+            out = self.backbone(info)[0]
+            return out if self.backbone.to_bev else out['voxel_feats']
+
+    cfg = dict(model_cfg if model_cfg is not None else _pipeline_config(num_blocks, with_bev))
+    cfg.pop('type', None)
+    model = _Pipeline(**cfg)
+    model.with_bev = bool(model.backbone.to_bev)
+    model.voxel_feats_only = (not model.with_bev) if voxel_feats_only is None else bool(voxel_feats_only)
+    return model
+
+
+class StepTimes(object):
+    """Per-step durations of a timed loop WITHOUT synchronising inside it: one event recorded on the stream behind every step,
+    the differences read after the loop's final synchronisation (device-side time between the ends of consecutive steps).  The
+    line carries median / min / max of every leg: a mean alone hides an outlier step (bf16 leg)."""
+
+    def __init__(self):
+        self.events = []
+
+    def mark(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.events.append(e)
+
+    def stats(self):
+        d = sorted(a.elapsed_time(b) for a, b in zip(self.events[:-1], self.events[1:]))
+        if not d:
+            return None
+        n = len(d)
+        med = d[n // 2] if n % 2 else 0.5 * (d[n // 2 - 1] + d[n // 2])
+        return {'median': round(med, 3), 'min': round(d[0], 3), 'max': round(d[-1], 3), 'steps': n,
+                'how': 'device-side time between the ends of consecutive steps (one event per step, read after the loop)'}
 
 
 def allreduce_grads(params, world):
@@ -370,6 +386,84 @@ def cpu_reference_leg(model, frame_cpu, num_blocks, budget_s=75.0):
     return base, parity
 
 
+def config_as_is_leg(args, dev, frames, sync):
+    """The detector a maintainer gets from INTEGRATION.md section A with the config UNTOUCHED: the
+    resolved `model` of configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py (tests/golden/configs/, checked against the
+    config text by tests/test_config_fixtures.py) through sst_amd.build_detector's class - no extra keyword (debug=True,
+    reference_outputs default, no window_major, no mute), no set_precision(), no other call after construction - on the bench
+    frame, forward + backward, each step calling the detector with the points only (no plan built ahead).  Reported:
+      value / ms_per_step           the metric's scope: voxelize -> DynamicVFE -> SSTInputLayerV2 -> 6 SRA
+                                    blocks, i.e. `det.extract_voxel_feats(points)` - comparable with the line's `value`;
+      with_plan_prefetch            the same with the next batch's index plan queued behind the backward pass, as the main loop
+                                    does (det.prepare / extract_voxel_feats(.., prepared=)): what a data-loader hook adds;
+      full_backbone                 `det.extract_feat(points)` as the config says: + BEV canvas + the three attached
+                                    convolutions with naiveSyncBN2d (MIOpen; solver search on during warm-up)."""
+    import ast
+    import contextlib
+    path = os.path.join(ROOT, 'tests', 'golden', 'configs', 'sst_waymoD5_1x_3class_8heads_v2.model.py')
+    cfg = ast.literal_eval(open(path).read())
+    torch.manual_seed(0)
+    det = Pipeline(model_cfg=cfg, voxel_feats_only=True).to(dev).train()
+    params = [p for p in det.parameters() if p.requires_grad]
+    seeds = {}
+
+    def step(prepared=None):
+        for p in params:
+            p.grad = None
+        out = det(frames, prepared)
+        g = seeds.get(out.shape)
+        if g is None:
+            g = seeds[out.shape] = torch.randn(out.shape, device=out.device, dtype=out.dtype)
+        out.backward(g)
+        return out
+
+    def timed(fn, warmup):
+        for _ in range(warmup):
+            fn()
+        sync()
+        st = StepTimes()
+        st.mark()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+            st.mark()
+        sync()
+        el = time.perf_counter() - t0
+        return {'value': round(args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'step_ms': st.stats()}
+
+    with contextlib.redirect_stdout(sys.stderr):      # mute=False as shipped: the layer prints its drop_info once
+        plain = timed(step, max(3, args.warmup))
+        ahead = []
+
+        def pstep():
+            out = step(ahead.pop() if ahead else None)
+            ahead.append(det.prepare(frames))
+            return out
+        pre = timed(pstep, 2)
+        n_vox = int(det.last_voxel_coors.size(0))
+        mode = {'matmul': det.backbone.matmul, 'precision': det.backbone.precision,
+                'window_major': bool(det.middle_encoder.window_major), 'reference_outputs': bool(det.middle_encoder.reference_outputs),
+                'debug': bool(det.middle_encoder.debug), 'fused_index_plan': det._planner is not None and det._planner is not False}
+        full = None
+        try:
+            det.voxel_feats_only = False
+            bench_flag = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = True
+            full = timed(step, 4)
+        finally:
+            det.voxel_feats_only = True
+            torch.backends.cudnn.benchmark = bench_flag
+    res = dict(plain)
+    res.update(voxels_kept_per_gpu=n_vox, with_plan_prefetch=pre, full_backbone=full, defaults_in_effect=mode,
+               config='configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py `model` (tests/golden/configs/'
+                      'sst_waymoD5_1x_3class_8heads_v2.model.py), built with no extra keyword, no call after construction',
+               what='sst_amd.DynamicVoxelNet.extract_voxel_feats(points) forward + backward per step (the metric\'s scope), the '
+                    'points handed over each step with no plan built ahead')
+    del det
+    return res
+
+
 def self_launch(n_ranks):
     """Re-run this script under torch.distributed.run with one process per GPU of this node."""
     import socket
@@ -425,7 +519,11 @@ def main():
     ap.add_argument('--matmul', default='f32x6', choices=('f32', 'f32x6'),
                     help="how the fp32 encoder layers multiply in the TIMED region: 'f32x6' = exact three-way bf16 split, six "
                          "products on the bf16 matrix pipe (csrc/dense_f32x6.hip; admissible as exact fp32: tests/"
-                         "test_gpu_dense_f32x6.py), 'f32' = the fp32 matrix pipe (csrc/dense_f32.hip)")
+                         "test_gpu_dense_f32x6.py) - the library's default, nothing is switched; 'f32' = the fp32 matrix pipe "
+                         "(csrc/dense_f32.hip), via set_precision('fp32')")
+    ap.add_argument('--no-config-as-is-leg', action='store_true',
+                    help='skip the leg that builds the detector from the shipped config (tests/golden/configs/) with no extra '
+                         'keyword and no call after construction')
     ap.add_argument('--precision', default='f32', choices=('f32', 'bf16'),
                     help="precision of the encoder layers in the TIMED region; the contract's headline is f32 (default), "
                          "bf16 makes the reduced-precision mode the measured one (profiling)")
@@ -492,8 +590,8 @@ def main():
     if args.precision == 'bf16':
         model.backbone.set_precision('bf16')
         args.no_bf16_leg = True
-    elif args.matmul == 'f32x6':
-        model.backbone.set_precision('f32x6')
+    elif args.matmul == 'f32':
+        model.backbone.set_precision('fp32')     # the opt-out: 'f32x6' (exact split) is the library's default, no call needed
     params = [p for p in model.parameters() if p.requires_grad]
     frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
     if args.cloud == 'lidar':
@@ -599,9 +697,12 @@ def main():
     if args.precision == 'bf16':
         K.EVENT_KINDS = ()
     sync()
+    main_times = StepTimes()
+    main_times.mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        main_times.mark()
     sync()
     elapsed = time.perf_counter() - t0
     K.EVENT_SINK = None
@@ -621,9 +722,12 @@ def main():
             for _ in range(2):
                 model(frames)
             sync()
+            fo_times = StepTimes()
+            fo_times.mark()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 model(frames)
+                fo_times.mark()
             sync()
             el = time.perf_counter() - t1
         if world > 1:
@@ -631,8 +735,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         fwd_only = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
-                    'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
+                    'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'step_ms': fo_times.stats(),
                     'note': 'same pipeline under torch.no_grad(), training-mode drop/shuffle; not part of `value`'}
+
+    as_is = None
+    if (world == 1 and not args.fwd_only and not args.no_config_as_is_leg and args.workload == 'sst' and args.cloud == 'uniform'
+            and args.blocks == 6 and args.precision == 'f32'):
+        fresh_allocator()
+        as_is = config_as_is_leg(args, dev, frames, sync)
+        as_is['vs_value'] = None     # filled in below
 
     # Order of the legs: the reduced-precision leg right behind the headline and the forward-only rate, the fp32-matrix-pipe leg
     # last - it draws the most power of all, and on some boxes whatever ran behind it ran at lower clocks (bf16 leg 112 frames/s
@@ -659,9 +770,12 @@ def main():
             t2 = time.perf_counter()
             per_step = []
             dev_allocs0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
+            bf_times = StepTimes()
+            bf_times.mark()
             for _ in range(args.steps):
                 ts = time.perf_counter()
                 step()
+                bf_times.mark()
                 per_step.append(time.perf_counter() - ts)
             sync()
             el = time.perf_counter() - t2
@@ -690,6 +804,7 @@ def main():
 
         bf16_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': 'bf16',
+                    'step_ms': bf_times.stats(),
                     'what': 'same step, encoder layers in bf16 storage (fp32 accumulate / softmax / LayerNorm statistics, '
                             'fp32 master weights); voxelize, VFE and the index plan unchanged (fp32, as the reference '
                             'forces them: voxel_encoder.py:229)',
@@ -722,9 +837,12 @@ def main():
         for _ in range(3):
             lo = lstep()
         sync()
+        li_times = StepTimes()
+        li_times.mark()
         t3 = time.perf_counter()
         for _ in range(args.steps):
             lstep()
+            li_times.mark()
         sync()
         el = time.perf_counter() - t3
         if world > 1:
@@ -740,7 +858,7 @@ def main():
                 sizes.append({'windows': int(pl.n_windows), 'tokens_min': int(d.min()), 'tokens_mean': round(float(d.mean()), 1),
                               'tokens_max': int(d.max())})
         lidar_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
-                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps,
+                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'step_ms': li_times.stats(),
                      'points_per_frame': int(lframes[0].size(0)), 'voxels_kept_per_gpu': int(lo.size(0)),
                      'window_sizes': sizes,
                      'what': 'same step (fwd + bwd) on a LiDAR-like frame: 64 beams x 2650 azimuth steps over a ground plane, '
@@ -765,9 +883,12 @@ def main():
             for _ in range(3):
                 step()
             sync()
+            mm_times = StepTimes()
+            mm_times.mark()
             t4 = time.perf_counter()
             for _ in range(args.steps):
                 step()
+                mm_times.mark()
             sync()
             el = time.perf_counter() - t4
         finally:
@@ -777,7 +898,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
-                'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': dtype,
+                'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'dtype': dtype, 'step_ms': mm_times.stats(),
                 'max_abs_err_vs_timed_mode_forward': float((alt_out - ref_out).abs().max()) if same else None,
                 'voxels_equal': bool(same), 'what': what}
 
@@ -855,7 +976,8 @@ def main():
             'metric': 'LiDAR frames/sec (SST backbone fwd+bwd) at Waymo 0.32m voxels' if not args.fwd_only
             else 'LiDAR frames/sec (SST backbone fwd-only) at Waymo 0.32m voxels',
             'value': round(total_frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'step_ms': main_times.stats(),
+            'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'host_ms_per_step': main_host_ms,   # interpreter + launch time of a step (forward and backward timed with the device
                                                 # idle at their start): the step is bound by the kernels while this stays below ms_per_step
@@ -887,6 +1009,9 @@ def main():
             # the exchanges of one step when nothing overlaps them; in the timed step all but the last bucket ride under the
             # backward pass of the voxel encoder / index stages
             res.update(allreduce_ms=comm['allreduce_ms'], bn_sync_ms=comm['bn_sync_ms'], communication=comm)
+        if as_is is not None:
+            as_is['vs_value'] = round(as_is['value'] / res['value'], 4)
+            res['config_as_is'] = as_is
         if fwd_only is not None:
             res['forward_only'] = fwd_only
         if lidar_leg is not None:

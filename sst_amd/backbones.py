@@ -146,26 +146,31 @@ class _WindowTransformer(nn.Module):
             width = conv_out_channel
         self.conv_layer = nn.ModuleList(stages)
 
+    # the module's own arithmetic (class defaults = what a model built from a shipped config runs, no call needed): fp32 storage,
+    # the dense products of the encoder layers from the exact three-way bf16 split (admissible as exact fp32:
+    # tests/test_gpu_dense_f32x6.py).  set_precision('fp32') is the opt-out onto the fp32 matrix pipe.
     precision = 'fp32'
+    matmul = 'f32x6'
 
     def set_precision(self, precision):
-        """'fp32' (default; the parity mode) or 'bf16': reduced-precision encoder layers (sst_amd/bf16.py) - what the
-        reference's fp16 training (Fp16OptimizerHook) corresponds to on this hardware.  Layers the bf16 kernels do not
-        cover (cosine attention, batch-norm layers, pre-norm) keep running in fp32."""
+        """How THIS module's encoder layers compute (per module: nothing process-wide changes, two models of one process keep
+        their own modes):
+          'f32x6' (default) fp32 tensors and results (to fp32 rounding); the projections / FFN products from an EXACT three-way
+                  bf16 split of both operands, six products with fp32 accumulation (csrc/dense_f32x6.hip): same arithmetic class
+                  as exact fp32 (error vs float64 <= 2 x the fp32 matrix pipe's), 2.7 x less matrix-pipe time;
+          'fp32'  every product on the fp32 matrix pipe (csrc/dense_f32.hip): the opt-out;
+          'f32x3' two-way split, three products (~1e-5 relative, tighter than the TF32 the reference's torch 1.8 used on Ampere):
+                  a measurement leg, never a default;
+          'bf16'  reduced-precision encoder layers (sst_amd/bf16.py) - what the reference's fp16 training (Fp16OptimizerHook)
+                  corresponds to on this hardware.  Layers the bf16 kernels do not cover (batch-norm layers, pre-norm) keep
+                  running in fp32 (split products)."""
         if precision not in ('fp32', 'bf16', 'f32x3', 'f32x6'):
             raise ValueError(precision)
-        # 'f32x3': fp32 storage everywhere, the projections / FFN products as three bf16 products of split operands with fp32
-        # accumulation (csrc/dense_f32x3.hip): ~1e-5 relative - tighter than the TF32 the reference's torch 1.8 used for
-        # these products on Ampere.  The attention core, LayerNorm and the weight gradients stay exact fp32.
-        # 'f32x6': the same fp32 tensors and results (to fp32 rounding), the products from an EXACT three-way bf16 split, six
-        # products with fp32 accumulation (csrc/dense_f32x6.hip): same arithmetic class as exact fp32, 2.7 x less matrix-pipe
-        # time.  The module keeps its mode (self.matmul) and runs its stack inside dense.matmul_mode_scope(); the call also sets
-        # the process-wide default, for code that multiplies outside a backbone's forward pass.
-        from . import dense
-        split = precision if precision in ('f32x3', 'f32x6') else None
-        dense.set_matmul_mode(split or 'f32')
-        self.precision = 'fp32' if split else precision
-        self.matmul = split or 'f32'
+        if precision == 'bf16':
+            self.precision = 'bf16'     # self.matmul stays: the mode of whatever falls back to the fp32-storage layers
+        else:
+            self.precision = 'fp32'
+            self.matmul = 'f32' if precision == 'fp32' else precision
         return self
 
     def run_blocks(self, feats, pos, plans, masks=None, pos_lookup=None):
@@ -248,23 +253,31 @@ class SSTv2(_WindowTransformer):
     def _window_inputs(voxel_info, shifts=2):
         """(plans, positional tensors, key masks) per partition, from either kind of voxel_info"""
         if 'sra_plan_shift0' in voxel_info:   # produced by this package's input layer / frame plan
+            # the [M, C] positional tensors are formed on demand (VoxelInfo): when the (table, row index) pair is there the
+            # encoder chains never need them, and run_blocks() gathers them itself for the per-layer path
+            lazy = hasattr(voxel_info, 'peek') and 'pos_table' in voxel_info and 'pos_index_shift0' in voxel_info
+            read = voxel_info.peek if lazy else voxel_info.get
             return ([voxel_info[f'sra_plan_shift{i}'] for i in range(shifts)],
-                    [voxel_info[f'pos_embed_shift{i}'] for i in range(shifts)], None)
+                    [read(f'pos_embed_shift{i}') for i in range(shifts)], None)
         # the reference's per-level dictionaries (flat2win indices, padded positional tensors, key masks)
         return ([voxel_info[f'flat2win_inds_shift{i}'] for i in range(shifts)],
                 [voxel_info[f'pos_dict_shift{i}'] for i in range(shifts)],
                 [voxel_info[f'key_mask_shift{i}'] for i in range(shifts)])
 
-    def forward(self, voxel_info):
-        coors = voxel_info['voxel_coors']
-        assert coors.dtype == torch.int64, 'data type of coors should be torch.int64!'
+    def forward_voxels(self, voxel_info):
+        """the shift blocks only: [M', C] features of the kept voxels (what ``forward`` returns with ``to_bev=False``)"""
         plans, pos, masks = self._window_inputs(voxel_info)
         lookup = None
         if 'pos_table' in voxel_info and 'pos_index_shift0' in voxel_info:   # (table, row index) per partition
             lookup = [(voxel_info['pos_table'], voxel_info[f'pos_index_shift{i}']) for i in range(2)]
         from . import dense
         with dense.matmul_mode_scope(getattr(self, 'matmul', None)):     # this module's own mode, whatever another model set
-            feats = self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks, pos_lookup=lookup)
+            return self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks, pos_lookup=lookup)
+
+    def forward(self, voxel_info):
+        coors = voxel_info['voxel_coors']
+        assert coors.dtype == torch.int64, 'data type of coors should be torch.int64!'
+        feats = self.forward_voxels(voxel_info)
         if not self.to_bev:
             assert self.num_attached_conv <= 0, 'the attached convolutions need the BEV canvas'
             return [{'voxel_feats': feats, 'voxel_coors': coors}]
@@ -331,7 +344,9 @@ class SSTv1(_WindowTransformer):
                                                  voxel_feat.device)
             plans.append(plan)
             pos.append(self.get_pos_embed_flat(voxel_info[f'coors_in_win_shift{i}'], voxel_feat.dtype))
-        feats = self.run_blocks(voxel_feat, pos, plans)
+        from . import dense
+        with dense.matmul_mode_scope(getattr(self, 'matmul', None)):
+            feats = self.run_blocks(voxel_feat, pos, plans)
         return [self.bev_and_attached_convs(feats, voxel_info['coors'], _batch_size_of(voxel_info, 'coors'))]
 
 

@@ -128,9 +128,12 @@ _LDS_LINEAR_SHAPES = ((128, 128), (128, 256), (256, 128))
 #           holds (error against float64 <= 2 x the fp32 kernel's, every shape and the 12-layer stack);
 #   'f32x3' two-way split, three products (csrc/dense_f32x3.hip; ~1e-5 relative, tighter than the TF32 products of the
 #           reference's own torch 1.8 on Ampere): a leg beside the headline, never the headline.
-# SSTv2.set_precision switches it: the module keeps its own mode and runs its stack inside matmul_mode_scope(); the global
-# below is the default for code outside any scope.
-_MATMUL_MODE = 'f32'
+# The DEFAULT is 'f32x6' (round 5): it is admissible as exact fp32 (tests/test_gpu_dense_f32x6.py) and it is what a model
+# built from a shipped config gets without any call; 'f32' (SSTv2.set_precision('fp32') / set_matmul_mode('f32')) is the opt-out.
+# SSTv2.set_precision switches the mode of THAT module only: it keeps its own mode and runs its stack inside
+# matmul_mode_scope(); the global below is the default for code outside any scope (set_matmul_mode changes it).
+DEFAULT_MATMUL_MODE = 'f32x6'
+_MATMUL_MODE = DEFAULT_MATMUL_MODE
 _MATMUL_MODES = ('f32', 'f32x3', 'f32x6')
 
 

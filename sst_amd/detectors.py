@@ -15,6 +15,8 @@ Reference:
   SingleStageFSD / FSD     single_stage_fsd.py:389-483 (__init__, extract_feat), two_stage_fsd.py (roi_head: config only)
   SingleStageFSDV2 / FSDV2 single_stage_fsd_v2.py:38-271, 375-433 (the stage itself: sst_amd/virtual_voxel.py),
                            two_stage_fsd_v2.py:11-60
+  DynamicVoxelNet /        mmdet3d/models/detectors/dynamic_voxelnet.py:10-71, 73-110 (__init__, extract_feat, voxelize): the
+  DynamicCenterPoint       detectors of configs/sst_refactor/*.py - the caller of the whole SST hot path
 """
 import torch
 from torch import nn
@@ -227,6 +229,96 @@ class VoteSegmentor(nn.Module):
                     batch_idx=pts_coors[:, 0], decoder_features=decoder_features)
 
     simple_test = forward
+
+
+@DETECTORS.register_module()
+class DynamicVoxelNet(nn.Module):
+    """points -> dynamic voxelisation -> DynamicVFE -> SSTInputLayerV2 -> SSTv2 (dynamic_voxelnet.py:10-71): what
+    ``model = dict(type='DynamicVoxelNet', voxel_layer=..., voxel_encoder=..., middle_encoder=..., backbone=..., neck=...,
+    bbox_head=...)`` of configs/sst_refactor/*.py constructs up to the backbone's output, with the reference's constructor
+    arguments and sub-module names (-> ``state_dict`` keys ``voxel_encoder.*``, ``backbone.*``).  The dense BEV neck (SECOND
+    FPN) and the box head are SURVEY.md section 2 OUT-OF-SCOPE: their configs are kept under ``self.unbuilt``, never run.
+
+    ``extract_feat`` has the reference's semantics (:38-47: voxelize -> voxel_encoder -> middle_encoder(.., batch_size) ->
+    backbone).  When the three index stages are the ones the fused frame plan covers (csrc/frame_plan.hip: DynamicVFE +
+    SSTInputLayerV2 on the same grid, voxels allowed to leave in window-major order - automatic with ``shuffle_voxels=True``)
+    the same results come from ONE device-side plan per batch: no host round trip until the voxel encoder's kernels are
+    queued (the reference reads ``coors[-1, 0].item()`` and three sizes back; the piecewise path of this package one size per
+    module boundary).  ``fused_index = False`` forces the piecewise path; ``prepare()`` builds the plan of a batch ahead of
+    time (it depends on the point clouds only - what a data-loader prefetch would do) for ``extract_feat(.., prepared=)``."""
+
+    def __init__(self, voxel_layer, voxel_encoder, middle_encoder, backbone, neck=None, bbox_head=None, train_cfg=None,
+                 test_cfg=None, pretrained=None, init_cfg=None):
+        super().__init__()
+        self.voxel_layer = Voxelization(**voxel_layer)
+        self.voxel_encoder = build_voxel_encoder(voxel_encoder)
+        self.middle_encoder = build_middle_encoder(middle_encoder)
+        self.backbone = build_backbone(backbone)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.unbuilt = {k: v for k, v in dict(neck=neck, bbox_head=bbox_head).items() if v is not None}
+        self.fused_index = True
+        self._planner = None
+
+    with_neck = False          # the dense neck is not built (out of scope): extract_feat ends at the backbone's output
+
+    @torch.no_grad()
+    def voxelize(self, points):
+        """list of per-sample clouds -> (all points, (b, z, y, x) int32 per point) (dynamic_voxelnet.py:49-71)"""
+        return self.voxel_layer.voxelize_batch(points)
+
+    def _frame_planner(self, batch_size):
+        from .frame_plan import FramePlanner
+        from .sst_input_layer import SSTInputLayerV2
+        from .voxel_encoder import DynamicVFE
+        if not self.fused_index:
+            return None
+        if self._planner is None:
+            ok = (type(self.voxel_encoder) is DynamicVFE and type(self.middle_encoder) is SSTInputLayerV2
+                  and hasattr(self.voxel_encoder, '_grid_zyx'))
+            self._planner = FramePlanner(self.voxel_layer, self.voxel_encoder, self.middle_encoder) if ok else False
+        planner = self._planner
+        return planner if (planner and planner.supported(batch_size)) else None
+
+    def prepare(self, points):
+        """the index work of one batch (voxelize, point -> voxel grouping, window bucketing / drop / window CSR, positional
+        rows): a FramePlan, or None when the fused plan does not cover this configuration / batch (extract_feat then runs the
+        piecewise path itself)"""
+        if len(points) == 0 or not all(p.is_cuda for p in points):
+            return None
+        planner = self._frame_planner(len(points))
+        return planner.build(points) if planner is not None else None
+
+    def voxel_info(self, points, prepared=None):
+        """everything in front of the backbone: -> the ``voxel_info`` dictionary SSTInputLayerV2 returns"""
+        plan = prepared if prepared is not None else self.prepare(points)
+        if plan is not None:     # the voxel encoder is queued before the plan's sizes are read (FramePlan.finalize)
+            voxel_features, _ = self.voxel_encoder(plan.points, plan.coors, scatter_plan=plan)
+            return plan.finalize(voxel_features, self.middle_encoder)
+        voxels, coors = self.voxelize(points)
+        voxel_features, feature_coors = self.voxel_encoder(voxels, coors)
+        return self.middle_encoder(voxel_features, feature_coors, len(points))
+
+    def extract_feat(self, points, img_metas=None, prepared=None):
+        x = self.backbone(self.voxel_info(points, prepared))
+        return x
+
+    def extract_voxel_feats(self, points, img_metas=None, prepared=None):
+        """the path up to the shift blocks' output, whatever the backbone's ``to_bev`` says: (features [M', C] of the kept
+        voxels, their (b, z, y, x)) - the part of ``extract_feat`` SURVEY.md section 8(d) defines the frames/s metric on"""
+        info = self.voxel_info(points, prepared)
+        return self.backbone.forward_voxels(info), info['voxel_coors']
+
+    forward = extract_feat
+
+    def losses(self, *args, **kwargs):
+        raise NotImplementedError('the box head, its losses and target assignment are outside the hot path (SURVEY.md section 8)')
+
+    forward_train = simple_test = aug_test = losses
+
+
+@DETECTORS.register_module()
+class DynamicCenterPoint(DynamicVoxelNet):
+    """dynamic_voxelnet.py:73-110: same feature path, CenterHead on top (not built)"""
 
 
 class _HotPathDetector(nn.Module):

@@ -68,8 +68,9 @@ class FramePlan(object):
         self.num_voxels, self.num_kept = m, m_keep
         dev = voxel_feats.device
         feat_index = self.feat_index[:m_keep]
-        info = {'voxel_feats': GatherRows.apply(voxel_feats, feat_index, self.feat_index_i32[:m_keep]),
-                'voxel_coors': self.out_coors[:m_keep], 'voxel_keep_inds': feat_index}
+        from .sst_input_layer import VoxelInfo
+        info = VoxelInfo({'voxel_feats': GatherRows.apply(voxel_feats, feat_index, self.feat_index_i32[:m_keep]),
+                          'voxel_coors': self.out_coors[:m_keep], 'voxel_keep_inds': feat_index})
         cap = self.max_tokens_cap
         tok0 = torch.arange(m_keep, dtype=torch.int32, device=dev)
         toks = (tok0, self.tok1)
@@ -80,9 +81,19 @@ class FramePlan(object):
             info[f'sra_plan_shift{i}'] = K.WindowPlan(toks[i], winoffs[i], n_win[i], m_keep,
                                                       min(cap, max(1, t_max[i])), rows_in_window_order=(i == 0))
             info[f'pos_index_shift{i}'] = (self.posidx0, self.posidx1)[i][:m_keep]
-            info[f'pos_embed_shift{i}'] = K.gather_rows(table, info[f'pos_index_shift{i}']) if self.want_pos_rows else None
         info['pos_table'] = table
         info['batch_size'] = self.batch_size
+        # the [M, C] positional tensors (only the per-layer path adds them as tensors) and the reference-style entries
+        # (flat2win dictionaries, padded positional tensors, key masks ...) are formed when somebody reads them
+        info.defer([f'pos_embed_shift{i}' for i in range(2)], lambda d: d.update(
+            {f'pos_embed_shift{i}': K.gather_rows(d['pos_table'], d[f'pos_index_shift{i}']) for i in range(2)}))
+        if input_layer.reference_outputs or input_layer.debug:
+            input_layer.defer_reference_entries_of_kept(info)
+            if input_layer.shuffle_voxels:
+                # voxel_feats_out = voxel_feats_in[shuffle_inds][voxel_keep_inds] (sst_input_layer_v2.py:93-97, 150-226): the
+                # plan's row index already maps output rows to input rows, so the shuffle part is the identity
+                info.defer(['shuffle_inds'], lambda d: d.update(
+                    shuffle_inds=torch.arange(self.num_voxels, dtype=torch.int64, device=dev)))
         self.info = info
         return info
 
@@ -113,7 +124,9 @@ class FramePlanner(object):
         self.grid_zyx = [int(g) for g in voxel_encoder._grid_zyx()]
         sx, sy, sz = input_layer.sparse_shape
         self.window = [int(w) for w in input_layer._window_shape3()]
-        self._ok = ([sz, sy, sx] == self.grid_zyx and not input_layer.reference_outputs
+        # reference_outputs no longer excludes the fused plan: those entries are formed on first access (VoxelInfo).  The
+        # plan's voxel order is window-major, which the layer must allow (automatic with shuffle_voxels: see SSTInputLayerV2)
+        self._ok = ([sz, sy, sx] == self.grid_zyx and input_layer.window_major
                     and self.window[0] * self.window[1] * self.window[2] <= 512)
 
     def supported(self, batch_size):

@@ -301,14 +301,17 @@ def _os_tile_order_enabled():
     return os.environ.get('SST_SPCONV_OS_ORDER', '1') != '0'
 
 
-_CONV_PRECISION = 'f32'
+# the exact split is the default since round 5 (what a model built from a shipped config runs without any call; the FSD / FSDv2
+# bench lines have carried it since round 4); set_conv_precision('f32') is the opt-out onto the fp32 matrix pipe
+DEFAULT_CONV_PRECISION = 'f32x6'
+_CONV_PRECISION = DEFAULT_CONV_PRECISION
 
 
 def set_conv_precision(mode):
     """How the forward contraction and the data gradient of every sparse convolution multiply (filter gradients stay on the
     fp32 matrix pipe: they are gather-bound):
-      'f32'    fp32 matrix pipe (csrc/spconv_os.hip);
-      'f32x6'  exact three-way bf16 split of both operands, six products, fp32 accumulation (csrc/spconv_os_x6.hip): the same
+      'f32'    fp32 matrix pipe (csrc/spconv_os.hip): the opt-out;
+      'f32x6'  (default) exact three-way bf16 split of both operands, six products, fp32 accumulation (csrc/spconv_os_x6.hip): the same
                arithmetic class (error vs float64 <= 2 x the fp32 kernel's, tests/test_gpu_spconv.py), 2.7 x less pipe time;
       'f32x3'  two-way split, three products (csrc/spconv_os_x3.hip; ~1e-5 of the output scale per layer): a leg only.
     PROCESS-GLOBAL, like sst_amd.dense.set_matmul_mode."""

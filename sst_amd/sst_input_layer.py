@@ -7,10 +7,11 @@ What differs underneath: the reference runs ~100 small ATen launches with a doze
 boolean-mask compaction x6, per-level unique/sort, padded pos/mask tensors).  Here two calls into
 libsst_amd.so (sst_window_coors + sst_region_batching) produce every index on the device in int32, one
 8-int readback gives the sizes, and the SRA kernels consume the resulting window CSR ("plan") directly.
-The per-level padded dictionaries of the reference API (flat2win_inds / pos_dict / key_mask) are still
-produced when ``reference_outputs=True`` (default) so reference-style consumers keep working; the SST
-backbone of this package only needs ``voxel_info['sra_plan_shift{i}']`` and
-``voxel_info['pos_embed_shift{i}']`` (flat [M, C]).
+The per-level padded dictionaries of the reference API (flat2win_inds / pos_dict / key_mask) are part of
+the returned ``voxel_info`` when ``reference_outputs=True`` (default) so reference-style consumers keep
+working, but they are formed ON FIRST ACCESS (``VoxelInfo``): the SST backbone of this package only reads
+``voxel_info['sra_plan_shift{i}']`` and the positional (table, row index) pair, so a model built from a
+shipped config never pays for them.
 
 In-window order: ascending voxel index (stable); the reference's TorchEx kernel leaves it unspecified
 (SURVEY.md §7 "hard parts").  With ``shuffle_voxels=True`` the drop is uniform, as in the reference.
@@ -24,6 +25,68 @@ from torch import nn
 from . import kernels as K
 from .registry import MIDDLE_ENCODERS
 from .sst_ops import flat2window, flat2window_v2, window2flat, window2flat_v2
+
+
+class VoxelInfo(dict):
+    """The ``voxel_info`` dictionary of SSTInputLayerV2 with its reference-style entries (per-voxel window ids and drop
+    levels, flat2win dictionaries, padded positional tensors, key masks: sst_input_layer_v2.py:99-126) formed on first
+    access.  Behaves as the plain dict the reference returns: ``in`` / ``get`` / ``[]`` see the deferred keys, and anything
+    that enumerates the dictionary (``keys``, ``items``, iteration, ``len``, ``copy`` into a plain dict) forms them first."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._deferred = {}          # key -> function(self) that stores a GROUP of keys (that one among them)
+
+    def defer(self, keys, fn):
+        for k in keys:
+            self._deferred[k] = fn
+
+    def __missing__(self, key):
+        fn = self._deferred.get(key)
+        if fn is None:
+            raise KeyError(key)
+        fn(self)
+        for k in [k for k, f in self._deferred.items() if f is fn]:
+            del self._deferred[k]
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._deferred
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def peek(self, key, default=None):
+        """the value if it is already formed (never triggers a deferred group)"""
+        return dict.get(self, key, default)
+
+    def materialize(self):
+        for key in list(self._deferred):
+            if key in self._deferred:
+                self[key]
+        return self
+
+    def __iter__(self):
+        return dict.__iter__(self.materialize())
+
+    def keys(self):
+        return dict.keys(self.materialize())
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def values(self):
+        return dict.values(self.materialize())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._deferred)
+
+    def shallow(self):
+        """a copy that shares the values and keeps the deferred groups deferred (they store into the copy they are asked from)"""
+        out = VoxelInfo()
+        dict.update(out, dict.items(self))
+        out._deferred = dict(self._deferred)
+        return out
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -57,7 +120,7 @@ class SSTInputLayerV2(nn.Module):
                  pos_temperature=10000,
                  mute=False,
                  reference_outputs=True,
-                 window_major=False,
+                 window_major=None,
                  ):
         super().__init__()
         self.fp16_enabled = False
@@ -72,10 +135,13 @@ class SSTInputLayerV2(nn.Module):
         self.reference_outputs = reference_outputs
         # window_major: emit the kept voxels ordered by their regular (shift-0) window instead of the (shuffled)
         # input order.  The order of the voxel list carries no meaning downstream (features travel with their
-        # coordinates; the reference's own order is a random permutation in training), but the attention kernels
-        # then read every window as one contiguous run of rows instead of 30-100 scattered ones.  Costs nothing:
-        # the permutation is folded into the gather that removes the dropped voxels.
-        self.window_major = window_major and not reference_outputs
+        # coordinates), but the attention kernels then read every window as one contiguous run of rows instead of
+        # 30-100 scattered ones.  Costs nothing: the permutation is folded into the gather that removes the dropped
+        # voxels, and every per-voxel entry of voxel_info (reference-style ones included) is emitted in that order.
+        # None (default) = automatic: on when shuffle_voxels is on - the reference's own output order is then a
+        # uniformly random permutation (sst_input_layer_v2.py:93-97), i.e. no consumer can depend on it - and off
+        # without the shuffle, where the reference keeps the input order and so does this layer.
+        self.window_major = bool(shuffle_voxels) if window_major is None else bool(window_major)
 
     # ---------------------------------------------------------------------------------------
     def set_drop_info(self):
@@ -151,14 +217,18 @@ class SSTInputLayerV2(nn.Module):
             batch_size = int(voxel_coors[:, 0].max().item()) + 1 if m > 0 else 1
         win_bits = max(1, int(per_sample * int(batch_size)).bit_length())
         rb = K.region_batching(win0, win1, win_bits, levels)
-        counts = rb['counts'].tolist()  # the single readback: M', W0, W1
+        sizes = rb['counts']
+        if self.debug and m > 0:    # smallest drop level among the kept voxels (-1: a population no drop_range covers)
+            lvl_min = torch.where(rb['keep'] > 0, torch.minimum(rb['level0'], rb['level1']), 0).min().reshape(1)
+            sizes = torch.cat([sizes, lvl_min.to(sizes.dtype)])
+        counts = sizes.tolist() + [0]  # the single readback: M', W0, W1, T0, T1, (spare), [8] = the level check
         m_keep, n_win = counts[0], (counts[1], counts[2])
         # upper bound on the tokens per window handed to the attention kernels: the largest surviving window of the
         # shift (read back with the other sizes) - lets them pick the smallest register / LDS class that fits
         max_tokens_cap = max(l[0] for l in levels)
         win_max = tuple(min(max_tokens_cap, max(1, int(t))) for t in (counts[3], counts[4]))
 
-        voxel_info = {}
+        voxel_info = VoxelInfo()
         keep_all = (m_keep == m)
         tok = [rb['tok0'], rb['tok1']]
         if self.window_major and m_keep > 0:
@@ -181,16 +251,8 @@ class SSTInputLayerV2(nn.Module):
             def sel(t):
                 return t.index_select(0, keep_idx)
 
-        # the per-voxel window ids / drop levels / flat2win indices are what reference-style consumers (and the
-        # debug checks) read; the SRA kernels only need the window CSR and the positional embeddings
-        full = self.reference_outputs or self.debug
         voxel_coors = sel(voxel_coors)
         ciws = (sel(ciw0), sel(ciw1))
-        if full:
-            wins = (sel(win0), sel(win1))
-            lvls = (sel(rb['level0']), sel(rb['level1']))
-            f2ws = (sel(rb['flat2win0']), sel(rb['flat2win1']))
-        identity_keys = list(level_keys) == list(range(len(level_keys)))
 
         # rows of the caller's voxel_feats that survive, in output order (shuffle and drop / re-order folded
         # into one gather); None = all rows in their own order
@@ -202,50 +264,112 @@ class SSTInputLayerV2(nn.Module):
             voxel_info['_feat_index'] = keep_idx
         voxel_info['voxel_coors'] = voxel_coors
         voxel_info['voxel_keep_inds'] = keep_idx
+        rows_in_window_order = bool(self.window_major and m_keep > 0)
         for i in range(2):
             voxel_info[f'coors_in_win_shift{i}'] = ciws[i].long()
-            if full:
-                voxel_info[f'batch_win_inds_shift{i}'] = wins[i].long()
-                lv = lvls[i].long()
-                if not identity_keys:  # drop_info keyed by something else than 0..n-1
-                    lv = torch.tensor(level_keys, device=lv.device, dtype=torch.long)[lv.clamp(min=0)]
-                voxel_info[f'voxel_drop_level_shift{i}'] = lv
-            voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep, win_max[i])
-            voxel_info[f'pos_embed_shift{i}'] = self.get_pos_embed_flat(ciws[i], feat_dim, dtype)
+            voxel_info[f'sra_plan_shift{i}'] = K.WindowPlan(tok[i], rb[f'winoff{i}'], n_win[i], m_keep, win_max[i],
+                                                            rows_in_window_order=(rows_in_window_order and i == 0))
             voxel_info[f'pos_index_shift{i}'] = self.pos_table_index(ciws[i])
         voxel_info['pos_table'] = self.pos_table_cached(feat_dim, dtype, voxel_coors.device)
         voxel_info['batch_size'] = int(batch_size)
+        # the [M, C] positional tensors: only the per-layer path adds them to x as tensors (the encoder chains take the
+        # (table, row index) pair above), so they are gathered when somebody asks
+        voxel_info.defer([f'pos_embed_shift{i}' for i in range(2)], lambda info: info.update(
+            {f'pos_embed_shift{i}': info['pos_table'].index_select(0, info[f'pos_index_shift{i}'].long()) for i in range(2)}))
 
+        # the per-voxel window ids / drop levels / flat2win indices, the padded positional tensors and the key masks are what
+        # reference-style consumers read; the SRA kernels only need the window CSR and the positional rows: deferred
         if self.debug:
-            for i in range(2):
-                assert (lvls[i] >= 0).all(), 'a window population matched no drop_range'
-
-        if self.reference_outputs:
-            for i in range(2):
-                lvl_key = voxel_info[f'voxel_drop_level_shift{i}']
-                inds_dict = {}
-                for li, dl in enumerate(level_keys):
-                    mask = lvls[i] == li
-                    if not mask.any():
-                        continue
-                    inds_dict[dl] = (f2ws[i][mask].long(), torch.where(mask))
-                inds_dict['voxel_drop_level'] = lvl_key
-                inds_dict['batching_info'] = self.drop_info
-                voxel_info[f'flat2win_inds_shift{i}'] = inds_dict
-                voxel_info[f'pos_dict_shift{i}'] = flat2window_v2(voxel_info[f'pos_embed_shift{i}'], inds_dict)
-                voxel_info[f'key_mask_shift{i}'] = self.get_key_padding_mask(inds_dict)
-            if self.debug:
-                coors_3d_dict_shift0 = flat2window_v2(voxel_coors, voxel_info['flat2win_inds_shift0'])
-                coors_2d = window2flat_v2(coors_3d_dict_shift0, voxel_info['flat2win_inds_shift0'])
-                assert (coors_2d == voxel_coors).all()
+            # "a window population matched no drop_range" (the reference's range assertions, sst_input_layer_v2.py:182-187):
+            # the smallest level of a kept voxel rode along with the sizes above - no extra host synchronisation
+            assert counts[8] >= 0, 'a window population matched no drop_range'
+        if self.reference_outputs or self.debug:
+            wins_all, lvls_all, f2ws_all = (win0, win1), (rb['level0'], rb['level1']), (rb['flat2win0'], rb['flat2win1'])
+            level_map = None
+            if list(level_keys) != list(range(len(level_keys))):   # drop_info keyed by something else than 0..n-1
+                level_map = torch.tensor(level_keys, device=voxel_coors.device, dtype=torch.long)
+            self._defer_reference_entries(voxel_info, sel, wins_all, lvls_all, f2ws_all, level_keys, level_map)
 
         if self.shuffle_voxels:
             voxel_info['shuffle_inds'] = shuffle_inds
         return voxel_info
 
+    _REFERENCE_KEYS = ('batch_win_inds', 'voxel_drop_level', 'flat2win_inds', 'pos_dict', 'key_mask')
+
+    def _reference_entries(self, info, sel, wins_all, lvls_all, f2ws_all, level_keys, level_map):
+        """The reference-style entries of ``voxel_info`` (sst_input_layer_v2.py:99-126): batch_win_inds / voxel_drop_level /
+        flat2win_inds / pos_dict / key_mask of both shifts.  ``sel`` maps a per-input-voxel tensor to the kept voxels in
+        output order."""
+        lvls = tuple(sel(t) for t in lvls_all)
+        f2ws = tuple(sel(t) for t in f2ws_all)
+        out = {}
+        for i in range(2):
+            out[f'batch_win_inds_shift{i}'] = sel(wins_all[i]).long()
+            lv = lvls[i].long()
+            if level_map is not None:
+                lv = level_map[lv.clamp(min=0)]
+            out[f'voxel_drop_level_shift{i}'] = lv
+            inds_dict = {}
+            if lvls[i].numel() > 0:
+                present = torch.stack([(lvls[i] == li).any() for li in range(len(level_keys))]).tolist()   # one read-back
+            else:
+                present = [False] * len(level_keys)
+            for li, dl in enumerate(level_keys):
+                if not present[li]:
+                    continue
+                mask = lvls[i] == li
+                inds_dict[dl] = (f2ws[i][mask].long(), torch.where(mask))
+            inds_dict['voxel_drop_level'] = lv
+            inds_dict['batching_info'] = self.drop_info
+            out[f'flat2win_inds_shift{i}'] = inds_dict
+            out[f'pos_dict_shift{i}'] = flat2window_v2(info[f'pos_embed_shift{i}'], inds_dict)
+            out[f'key_mask_shift{i}'] = self.get_key_padding_mask(inds_dict)
+        if self.debug:    # the reference's round-trip check of the index dictionaries (sst_input_layer_v2.py:119-123)
+            coors = info['voxel_coors']
+            coors_3d_dict_shift0 = flat2window_v2(coors, out['flat2win_inds_shift0'])
+            coors_2d = window2flat_v2(coors_3d_dict_shift0, out['flat2win_inds_shift0'])
+            assert (coors_2d == coors).all()
+        return out
+
+    def _defer_reference_entries(self, voxel_info, sel, wins_all, lvls_all, f2ws_all, level_keys, level_map):
+        """register them as ONE deferred group of ``voxel_info``, formed from the tensors region batching left"""
+        def form(info):
+            dict.update(info, self._reference_entries(info, sel, wins_all, lvls_all, f2ws_all, level_keys, level_map))
+
+        voxel_info.defer([f'{name}_shift{i}' for i in range(2) for name in self._REFERENCE_KEYS], form)
+
+    def defer_reference_entries_of_kept(self, voxel_info):
+        """The same group for a plan whose kernels keep no per-voxel window ids / levels (csrc/frame_plan.hip), re-derived on
+        first access from the KEPT voxels: their window ids, and region batching run on them again.  Nothing is dropped the
+        second time (a window's surviving population never exceeds the max_tokens of the level that population selects), so
+        the dictionaries describe exactly the windows the SRA plan holds; a window whose population crossed a drop_range
+        boundary when the other shift's drop thinned it sits in the (smaller) level of its surviving population - which
+        padded batch a window rides in does not enter any result.  Also forms ``coors_in_win_shift{i}``."""
+        def form(info):
+            self.set_drop_info()
+            coors = info['voxel_coors'].contiguous()
+            m = coors.size(0)
+            sx, sy, sz = self.sparse_shape
+            wx, wy, wz = self._window_shape3()
+            level_keys, levels = self._levels()
+            win0, ciw0, win1, ciw1 = K.window_coors(coors, [sx, sy, sz], [wx, wy, wz])
+            per_sample = (math.ceil(sx / wx) + 1) * (math.ceil(sy / wy) + 1) * (math.ceil(sz / wz) + 1)
+            win_bits = max(1, int(per_sample * int(info['batch_size'])).bit_length())
+            rb = K.region_batching(win0, win1, win_bits, levels)
+            if self.debug:
+                assert int(rb['counts'][0].item()) == m, 'a kept voxel did not survive its own window'
+            level_map = None
+            if list(level_keys) != list(range(len(level_keys))):
+                level_map = torch.tensor(level_keys, device=coors.device, dtype=torch.long)
+            dict.update(info, {'coors_in_win_shift0': ciw0.long(), 'coors_in_win_shift1': ciw1.long()})
+            dict.update(info, self._reference_entries(info, lambda t: t, (win0, win1), (rb['level0'], rb['level1']),
+                                                      (rb['flat2win0'], rb['flat2win1']), level_keys, level_map))
+
+        voxel_info.defer([f'{name}_shift{i}' for i in range(2) for name in self._REFERENCE_KEYS + ('coors_in_win',)], form)
+
     def apply_plan(self, plan, voxel_feats):
         """voxel_info of forward(): the plan plus the surviving voxel features in plan order (one gather)."""
-        voxel_info = dict(plan)
+        voxel_info = plan.shallow() if isinstance(plan, VoxelInfo) else dict(plan)
         idx = voxel_info.pop('_feat_index')
         voxel_info['voxel_feats'] = voxel_feats if idx is None else voxel_feats.index_select(0, idx)
         return voxel_info

@@ -19,7 +19,7 @@ def x3():
     from sst_amd import dense
     dense.set_matmul_mode('f32x3')
     yield dense
-    dense.set_matmul_mode('f32')
+    dense.set_matmul_mode(dense.DEFAULT_MATMUL_MODE)
 
 
 @pytest.mark.parametrize('m', [1, 77, 5000, 90107])

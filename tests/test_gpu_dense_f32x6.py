@@ -25,7 +25,7 @@ def _both(D, fn):
             D.set_matmul_mode(mode)
             out[mode] = fn()
     finally:
-        D.set_matmul_mode('f32')
+        D.set_matmul_mode(D.DEFAULT_MATMUL_MODE)
     return out['f32'], out['f32x6']
 
 
@@ -108,7 +108,7 @@ def test_qkv_one_launch_equals_the_two_projections(m):
         qk = D.lds_linear(xp, w[:256], b[:256])
         v = D.lds_linear(x, w[256:], b[256:])
     finally:
-        D.set_matmul_mode('f32')
+        D.set_matmul_mode(D.DEFAULT_MATMUL_MODE)
     assert torch.equal(one[:, :256], qk) and torch.equal(one[:, 256:], v)
     want = torch.cat([xp.double() @ w[:256].double().t(), x.double() @ w[256:].double().t()], 1) + b.double()
     assert float((one.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
@@ -269,9 +269,10 @@ def test_in_projection_data_gradient_as_one_product(m):
         out = ds1.clone()
         got = D.lds_linear(dqkv, w, None, D.EPI_ADD, trans_w=True, aux_in=out, out=out)
     finally:
-        D.set_matmul_mode('f32')
-    assert not D.lds_linear_dqkv_ok(dqkv, w)
-    nat = ds1.clone()
-    D.lds_linear(dqkv[:, :256].contiguous(), w[:256], None, D.EPI_ADD, trans_w=True, aux_in=nat, out=nat)
-    D.lds_linear(dqkv[:, 256:].contiguous(), w[256:], None, D.EPI_ADD, trans_w=True, aux_in=nat, out=nat)
+        D.set_matmul_mode(D.DEFAULT_MATMUL_MODE)
+    with D.matmul_mode_scope('f32'):
+        assert not D.lds_linear_dqkv_ok(dqkv, w)
+        nat = ds1.clone()
+        D.lds_linear(dqkv[:, :256].contiguous(), w[:256], None, D.EPI_ADD, trans_w=True, aux_in=nat, out=nat)
+        D.lds_linear(dqkv[:, 256:].contiguous(), w[256:], None, D.EPI_ADD, trans_w=True, aux_in=nat, out=nat)
     _admissible(nat, got, want, 'K = 384 data gradient')

@@ -160,7 +160,7 @@ def test_split_precision_convolution_kernel(cin, cout):
                               np.abs(dx.cpu().numpy() - dx_ref).max() / max(1.0, np.abs(dx_ref).max()))
             assert max(errs['f32']) < 5e-6 and max(errs['f32x3']) < 5e-5, errs
     finally:
-        spconv.set_conv_precision('f32')
+        spconv.set_conv_precision(spconv.DEFAULT_CONV_PRECISION)
 
 
 @pytest.mark.parametrize('cin,cout', [(64, 64), (16, 32), (128, 160), (192, 256), (64, 128), (256, 256)])
@@ -199,7 +199,7 @@ def test_exact_split_convolution_kernel(cin, cout):
             assert errs['f32x6'][0] <= 5e-6 * sy and errs['f32x6'][1] <= 5e-6 * sx
             assert not torch.equal(outs['f32'], outs['f32x6'])
     finally:
-        spconv.set_conv_precision('f32')
+        spconv.set_conv_precision(spconv.DEFAULT_CONV_PRECISION)
 
 
 def test_inverse_conv_matches_oracle_and_modules_chain():

@@ -56,9 +56,11 @@ def test_constants_are_cached_per_value_device_and_dtype():
 def test_conv_precision_switch_rejects_unknown_modes():
     import pytest
     from sst_amd import spconv
-    assert spconv.conv_precision() == 'f32'
+    assert spconv.conv_precision() == spconv.DEFAULT_CONV_PRECISION == 'f32x6'
     spconv.set_conv_precision('f32x3')
     assert spconv.conv_precision() == 'f32x3'
     spconv.set_conv_precision('f32')
+    assert spconv.conv_precision() == 'f32'
+    spconv.set_conv_precision(spconv.DEFAULT_CONV_PRECISION)
     with pytest.raises(ValueError):
         spconv.set_conv_precision('bf16')

@@ -97,21 +97,25 @@ def test_fused_vfe_declines_what_it_is_not_built_for():
 
 def test_precision_switch_is_scoped_to_the_module():
     """two backbones of one process with different set_precision(): each runs its encoder stack in ITS mode, whichever call
-    came last (the switch used to be process-global), and the process-wide default is restored afterwards"""
+    came last (the switch used to be process-global); set_precision() touches nothing process-wide, and a
+    backbone nobody called set_precision() on multiplies from the exact split ('f32x6', the default since round 5)"""
     import sst_amd
     from sst_amd import dense
     cfg = dict(type='SSTv2', d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2, output_shape=[468, 468],
                debug=False, num_attached_conv=0, to_bev=False)
-    a, b = sst_amd.build_backbone(dict(cfg)), sst_amd.build_backbone(dict(cfg))
-    a.set_precision('f32x6')
-    b.set_precision('fp32')                      # the last call sets the process-wide default: 'f32'
-    assert dense.matmul_mode() == 'f32' and a.matmul == 'f32x6' and b.matmul == 'f32'
+    a, b, c = sst_amd.build_backbone(dict(cfg)), sst_amd.build_backbone(dict(cfg)), sst_amd.build_backbone(dict(cfg))
+    assert dense.DEFAULT_MATMUL_MODE == 'f32x6' and dense.matmul_mode() == 'f32x6'
+    a.set_precision('f32x3')
+    b.set_precision('fp32')                      # the opt-out onto the fp32 matrix pipe: this module only
+    assert dense.matmul_mode() == 'f32x6' and a.matmul == 'f32x3' and b.matmul == 'f32' and c.matmul == 'f32x6'
+    assert c.precision == 'fp32' and b.set_precision('bf16').precision == 'bf16' and b.matmul == 'f32'
+    b.set_precision('fp32')
     seen = {}
-    for name, model in (('a', a), ('b', b)):
+    for name, model in (('a', a), ('b', b), ('c', c)):
         model._window_inputs = lambda info: (None, None, None)
         model.run_blocks = lambda feats, pos, plans, masks=None, pos_lookup=None, _n=name: seen.setdefault(_n, dense.matmul_mode()) and feats
         model({'voxel_coors': torch.zeros((4, 4), dtype=torch.int64), 'voxel_feats': torch.zeros(4, 128)})
-    assert seen == {'a': 'f32x6', 'b': 'f32'} and dense.matmul_mode() == 'f32'
+    assert seen == {'a': 'f32x3', 'b': 'f32', 'c': 'f32x6'} and dense.matmul_mode() == 'f32x6'
     with pytest.raises(ValueError):
         with dense.matmul_mode_scope('tf32'):
             pass
