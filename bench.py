@@ -38,10 +38,20 @@ SRA_BYTES_PER_TOKEN = 4 * 128 * 4 + 8   # Q,K,V read + O write (fp32, d=128) + i
 SRA_BWD_BYTES_PER_TOKEN = 8 * 128 * 4 + 8   # Q,K,V,O,dO read + dQ,dK,dV written + index
 
 
-def make_cloud(n, seed, device):
+def make_cloud(n, seed, device, channels=3):
+    """SURVEY.md section 8(d) U-cloud: uniform in the range; channels beyond xyz (intensity, elongation ...) uniform in [0, 1)"""
     g = torch.Generator().manual_seed(seed)
     xyz = torch.rand(n, 3, generator=g) * torch.tensor([149.76, 149.76, 6.0]) + torch.tensor([-74.88, -74.88, -2.0])
+    if channels > 3:
+        xyz = torch.cat([xyz, torch.rand(n, channels - 3, generator=g)], 1)
     return xyz.to(device)
+
+
+def load_config_fixture(name):
+    """resolved `model` dictionary of a shipped config (tests/golden/configs/<name>.model.py, checked against the config text
+    by tests/test_config_fixtures.py)"""
+    import ast
+    return ast.literal_eval(open(os.path.join(ROOT, 'tests', 'golden', 'configs', name + '.model.py')).read())
 
 
 def make_lidar_cloud(seed, device, beams=64, azimuth_steps=2650, sensor_height=2.0, outside_fraction=0.05,
@@ -481,14 +491,29 @@ def self_launch(n_ranks):
 
 
 def main():
+    # the contract: rank 0 prints ONE JSON line.  Modules built from a shipped config print (the input layer announces its
+    # drop_info unless `mute` is set): everything but the line goes to stderr.
+    args = parse_args()          # --help goes to the real stdout
+    line_out = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        _main(args, line_out)
+    finally:
+        sys.stdout = line_out
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--frames-per-gpu', type=int, default=1)
     ap.add_argument('--points', type=int, default=None, help='points per frame (default: 116000 for the SST workloads)')
-    ap.add_argument('--workload', default='sst', choices=('sst', 'sst_bs2', 'sst_bev', 'fsd', 'fsdv2'),
-                    help="sst = the headline (BASELINE.json configs[1]/[2] geometry, 1 frame/GPU); sst_bs2 = configs[2]'s "
+    ap.add_argument('--workload', default='sst', choices=('sst', 'sst_bs2', 'sst_bev', 'sst_center', 'fsd', 'fsdv2'),
+                    help="sst_center = configs/sst_refactor/sst_waymoD5_1x_3class_centerhead.py as shipped (4 SRA blocks with COSINE "
+                         "attention, checkpoint_blocks=[0, 1], 5-channel points; voxel features scope; beside it the same config "
+                         "with standard attention); "
+                         "sst = the headline (BASELINE.json configs[1]/[2] geometry, 1 frame/GPU); sst_bs2 = configs[2]'s "
                          "2 frames per GPU; sst_bev = sst + recover_bev + the three attached convolutions of the config; "
                          "fsd / fsdv2 = configs[3] / configs[4] hot paths (bench_workloads.py)")
     ap.add_argument('--blocks', type=int, default=6)
@@ -534,7 +559,10 @@ def main():
     ap.add_argument('--share-device', action='store_true', help='dev only: every rank uses cuda:0')
     ap.add_argument('--no-gemm-tuning', action='store_true',
                     help='do not let PyTorch TunableOp pick the hipBLASLt/rocBLAS solution of each dense GEMM shape')
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def _main(args, line_out):
     args.points_given = args.points is not None
     if args.points is None:
         args.points = 116000
@@ -580,7 +608,15 @@ def main():
         tunable.tuning_enable(True)
         tunable.set_filename(work_file)
     torch.manual_seed(0)                      # identical initial weights on every rank
-    model = Pipeline(args.blocks, with_bev=args.workload == 'sst_bev').to(dev)
+    point_channels = 3
+    if args.workload == 'sst_center':
+        center_cfg = load_config_fixture('sst_waymoD5_1x_3class_centerhead')
+        args.blocks = int(center_cfg['backbone']['num_blocks'])
+        point_channels = int(center_cfg['voxel_encoder']['in_channels'])
+        model = Pipeline(model_cfg=center_cfg, voxel_feats_only=True).to(dev)
+        args.no_bf16_leg = args.no_cpu_baseline = args.no_lidar_leg = args.no_f32x3_leg = args.no_config_as_is_leg = True
+    else:
+        model = Pipeline(args.blocks, with_bev=args.workload == 'sst_bev').to(dev)
     if args.workload == 'sst_bev':
         torch.backends.cudnn.benchmark = True    # MIOpen: search for the convolution solvers during warm-up
         args.no_bf16_leg = args.no_cpu_baseline = args.no_lidar_leg = args.no_f32x3_leg = True   # those legs cover the voxel features only
@@ -593,7 +629,7 @@ def main():
     elif args.matmul == 'f32':
         model.backbone.set_precision('fp32')     # the opt-out: 'f32x6' (exact split) is the library's default, no call needed
     params = [p for p in model.parameters() if p.requires_grad]
-    frames = [make_cloud(args.points, 1000 * rank + i, dev) for i in range(args.frames_per_gpu)]
+    frames = [make_cloud(args.points, 1000 * rank + i, dev, point_channels) for i in range(args.frames_per_gpu)]
     if args.cloud == 'lidar':
         frames = [make_lidar_cloud(2000 * rank + i, dev) for i in range(args.frames_per_gpu)]
         args.points = int(frames[0].size(0))
@@ -737,6 +773,44 @@ def main():
         fwd_only = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'step_ms': fo_times.stats(),
                     'note': 'same pipeline under torch.no_grad(), training-mode drop/shuffle; not part of `value`'}
+
+    # --workload sst_center: the same config with standard attention (layer_cfg cosine off), same frames, same loop: what the
+    # normalisation + per-head temperature inside the kernels cost per encoder layer
+    std_leg = None
+    if args.workload == 'sst_center' and not args.fwd_only and world == 1:
+        import copy
+        fresh_allocator()
+        std_cfg = copy.deepcopy(center_cfg)
+        std_cfg['backbone']['layer_cfg'] = dict(std_cfg['backbone']['layer_cfg'], cosine=False)
+        torch.manual_seed(0)
+        keep_model, keep_params = model, params
+        model = Pipeline(model_cfg=std_cfg, voxel_feats_only=True).to(dev).train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        ahead.clear()
+        try:
+            for _ in range(max(3, args.warmup)):
+                step()
+            sync()
+            sd_times = StepTimes()
+            sd_times.mark()
+            t5 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+                sd_times.mark()
+            sync()
+            el = time.perf_counter() - t5
+        finally:
+            model, params = keep_model, keep_params
+            ahead.clear()
+        n_layers = 2 * args.blocks
+        std_ms = el / args.steps * 1e3
+        cos_ms = elapsed / args.steps * 1e3
+        std_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
+                   'ms_per_step': round(std_ms, 3), 'steps': args.steps, 'step_ms': sd_times.stats(),
+                   'cosine_minus_std_ms_per_layer': round((cos_ms - std_ms) / n_layers, 4),
+                   'cosine_over_std': round(cos_ms / std_ms, 4),
+                   'what': 'the same shipped config with layer_cfg.cosine = False (standard scaled-dot-product attention), same '
+                           f'frames and loop; {n_layers} encoder layers, blocks 0-1 recomputed in the backward pass (checkpoint_blocks)'}
 
     as_is = None
     if (world == 1 and not args.fwd_only and not args.no_config_as_is_leg and args.workload == 'sst' and args.cloud == 'uniform'
@@ -990,6 +1064,10 @@ def main():
             'config': {'workload': ('NOT THE HEADLINE WORKLOAD (--cloud lidar): LiDAR-like synthetic sweep, ' if args.cloud == 'lidar'
                                     else 'SST-base Waymo training, bs=2/GPU, 0.32 m voxel: uniform synthetic cloud '
                                     if args.workload == 'sst_bs2' else
+                                    'NOT THE HEADLINE WORKLOAD (--workload sst_center): configs/sst_refactor/'
+                                    'sst_waymoD5_1x_3class_centerhead.py as shipped (cosine attention, checkpoint_blocks=[0, 1], '
+                                    '5-channel points), voxel features scope: uniform synthetic cloud '
+                                    if args.workload == 'sst_center' else
                                     'SST-base Waymo single-frame, 0.32 m voxel: uniform synthetic cloud ') +
                                    f'{args.points} points/frame -> {n_voxels // args.frames_per_gpu} non-empty '
                                    'voxels/frame; dynamic voxelize + DynamicVFE + SSTInputLayerV2 + '
@@ -1026,7 +1104,10 @@ def main():
             res['cpu_baseline'], res['parity'] = cpu_reference_leg(model, frames[0].cpu(), args.blocks)
         else:
             res['cpu_baseline'] = None
-        print(json.dumps(res))
+        if std_leg is not None:
+            res['std_attention_same_config'] = std_leg
+        print(json.dumps(res), file=line_out)
+        line_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

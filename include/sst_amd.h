@@ -295,8 +295,9 @@ int sst_window_plan_i32(const int32_t* d_vcoors, const int32_t* d_grid, int64_t 
  *       S = (Q_h * scale) K_h^T ; P = softmax_rows(S) ; O_h = P V_h
  * Replaces the per-drop-level  flat2window -> nn.MultiheadAttention bmm/softmax/bmm -> window2flat
  * of WindowAttention.forward (models/sst/sst_basic_block_v2.py:41-75); the in/out projections stay
- * GEMM-library calls in the host layer, and the cosine variant (cosine_msa.py:159-170) normalises and
- * rescales Q,K in the host layer before calling this with scale = 1.  head_dim is 16 (d_model/nhead =
+ * GEMM-library calls in the host layer; the cosine variant (cosine_msa.py:159-170) is sst_sra_attn_cos_{fwd,bwd}_f32
+ * below (normalisation and 1 / clamp(tau) inside the kernels); for layouts those do not take the host layer normalises and
+ * rescales Q,K before calling this with scale = 1.  head_dim is 16 (d_model/nhead =
  * 128/8, 192/12 in every SST config); n_heads must be a multiple of 4.
  * Q,K,V,O: [M, n_heads*16] fp32 with row strides ldq/ldk/ldv/ldo (elements, multiples of 4; base
  * pointers 16-byte aligned).  d_lse [M, n_heads] fp32: log-sum-exp of each softmax row (for backward).
@@ -341,6 +342,27 @@ int sst_sra_attn_bwd_ord_f32(const float* d_q, const float* d_k, const float* d_
                              int64_t n_tokens, int n_heads, float scale, int max_tokens, int impl, float* d_dq,
                              float* d_dk, float* d_dv, int64_t lddq, int64_t lddk, int64_t lddv, void* d_workspace,
                              void* stream);
+
+/* Scaled cosine attention (CosineMultiheadAttention, models/sst/cosine_msa.py:123-185, 449-466; layer_cfg = dict(cosine=True,
+ * tau_min=..) of configs/sst_refactor/sst_waymoD5_1x_3class_centerhead.py:75 and configs/fsd/fsd_waymoD1_1x_sst_encoder.py:70):
+ *       S = normalize(Q_h) normalize(K_h)^T * head_scale[h] ; P = softmax_rows(S) ; O_h = P V_h
+ * normalize = x / max(|x|_2, 1e-12) over the 16 channels of the head (torch.nn.functional.normalize), formed in the load
+ * prologue of the register-resident kernels (one 4-lane reduction per row fragment).  d_head_scale: [n_heads] fp32 in DEVICE
+ * memory = 1 / clamp(tau, tau_min) (a shared tau is passed expanded) - the parameter never visits the host.
+ * Backward: d_dq / d_dk are the gradients of the UN-normalised q / k (d x = (d x^ - x^ (x^ . d x^)) / |x|, taken where the
+ * row fragment is stored); d_r [n_tokens, n_heads] receives x^ . d x^ of the query side, whose column sum is the gradient of
+ * the scale: d head_scale[h] = sum_rows d_r[:, h] / head_scale[h].  Same layouts and d_tok == NULL rule as above; windows of
+ * <= 144 tokens, 16-byte aligned operands and n_heads % 4 == 0 only (else SST_ERR_UNSUPPORTED: the host layer then
+ * normalises outside). */
+int sst_sra_attn_cos_fwd_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int n_heads, const float* d_head_scale, int max_tokens, float* d_o, int64_t ldo, float* d_lse,
+                             void* stream);
+int sst_sra_attn_cos_bwd_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o, const float* d_do,
+                             const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int64_t n_tokens, int n_heads, const float* d_head_scale, int max_tokens, float* d_dq, float* d_dk,
+                             float* d_dv, int64_t lddq, int64_t lddk, int64_t lddv, float* d_r, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a12, reduced precision) The same attention core with bf16 storage: Q, K, V, O, dO, dQ, dK, dV are bf16 ([M, n_heads*16],
@@ -678,6 +700,9 @@ int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const floa
  *   backward: from dy2 (and dy2p, may be NULL) the gradients of every parameter and dx (returned in ds1: d(x) with the
  *             gradient of xp folded in, xp = x + a constant); ds2, dpre, ds1, d_o, dqkv [m, 384] are scratch outputs of the
  *             widths 128, 256, 128, 128, 384; workspace: sst_encoder_layer_bwd_workspace_bytes(m, n_heads), 256-byte aligned.
+ *   head_scale (last field of both): NULL = softmax(q k^T * scale); else scaled cosine attention (sst_sra_attn_cos_*_f32),
+ *             [n_heads] floats = 1 / clamp(tau, tau_min) in device memory, and the backward writes cos_r [m, n_heads]
+ *             (d head_scale[h] = colsum(cos_r)[h] / head_scale[h], taken by the caller).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sst_encoder_layer_fwd_args {
   int64_t m, n_windows;
@@ -689,6 +714,7 @@ typedef struct sst_encoder_layer_fwd_args {
   const float* pos_table;
   const int32_t* pos_idx;
   float *qkv, *o, *lse, *y1, *s1, *st1, *pre, *h, *s2, *y2, *st2, *y2p;
+  const float* head_scale;
 } sst_encoder_layer_fwd_args;
 typedef struct sst_encoder_layer_bwd_args {
   int64_t m, n_windows;
@@ -701,6 +727,8 @@ typedef struct sst_encoder_layer_bwd_args {
   float *ds2, *dpre, *ds1, *d_o, *dqkv;
   float *dw_in, *db_in, *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dn1w, *dn1b, *dn2w, *dn2b;
   void* workspace;
+  const float* head_scale;
+  float* cos_r;
 } sst_encoder_layer_bwd_args;
 int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads);
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* args, void* stream);

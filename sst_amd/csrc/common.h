@@ -12,6 +12,20 @@
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)
 
+// hipFuncSetAttribute (and anything else that is per DEVICE) done once per device at a call site:
+//   static unsigned long long done = 0;  if (sst_first_use_on_device(&done)) { ...; sst_mark_device(&done); }
+// bit d of the mask = device d configured (a process-wide `static bool` left a second GPU of the process
+// without the attribute).  Two threads racing on the first use both set the attribute: harmless.
+static inline unsigned long long sst_device_bit(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return 1ull << (dev & 63);
+}
+static inline bool sst_first_use_on_device(unsigned long long* mask) {
+  return (__atomic_load_n(mask, __ATOMIC_ACQUIRE) & sst_device_bit()) == 0;
+}
+static inline void sst_mark_device(unsigned long long* mask) { __atomic_fetch_or(mask, sst_device_bit(), __ATOMIC_RELEASE); }
+
 #define SST_HIP(call)                               \
   do {                                              \
     hipError_t e__ = (call);                        \

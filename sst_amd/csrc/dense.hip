@@ -423,28 +423,6 @@ __global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int
   }
 }
 
-// out[i] += sum over a 64-row slice of partials[nb][width]; grid = (ceil(width/32), ceil(nb/64)); out zeroed before
-__global__ __launch_bounds__(256) void colsum_partials2d_k(const float* __restrict__ partials, int nb, int width,
-                                                           float* __restrict__ out) {
-  __shared__ float red[8][33];
-  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cx;
-  const int b0 = blockIdx.y * 64;
-  const int b1 = b0 + 64 < nb ? b0 + 64 : nb;
-  float acc = 0.f;
-  if (i < width)
-    for (int b = b0 + gy; b < b1; b += 8) acc += partials[(int64_t)b * width + i];
-  red[gy][cx] = acc;
-  __syncthreads();
-  if (gy == 0 && i < width) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cx];
-    atomicAdd(out + i, t);
-  }
-}
-
-
 // ---- bf16 storage variants (the reduced-precision mode of the encoder layers; statistics and arithmetic in fp32) ------
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 bf4_load(const unsigned short* __restrict__ p) {

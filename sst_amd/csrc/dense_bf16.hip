@@ -734,10 +734,10 @@ int sst_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_
     next_block += blocks;
   }
   hipStream_t st = (hipStream_t)stream;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (sst_first_use_on_device(&configured)) {
     SST_HIP(hipFuncSetAttribute((const void*)wgrad_group_bf16_k, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes));
-    configured = true;
+    sst_mark_device(&configured);
   }
   hipLaunchKernelGGL(wgrad_group_bf16_k, dim3((unsigned)next_block), dim3(512), kWgLdsBytes, st, args);
   hipLaunchKernelGGL(wgrad_reduce_bf16_k, dim3((256 * 128 + 256) / 64, (unsigned)n), dim3(256), 0, st, args);

@@ -289,10 +289,10 @@ template <int K, int N, int EPI>
 int launch_x3(const float* x, int64_t ldx, const float* w, int64_t ldw, int trans_w, const float* bias, int64_t m, float* y,
               int64_t ldy, const float* aux_in, float* aux_out, int64_t ldaux, hipStream_t st, const ln_epi ln = ln_epi()) {
   constexpr int lds = 2 * N * (K * 2 + 16) + N * (EPI == kEpiAddLN ? 3 : 1) * 4;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (sst_first_use_on_device(&configured)) {
     SST_HIP(hipFuncSetAttribute((const void*)tall_linear_f32x3_k<K, N, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
+    sst_mark_device(&configured);
   }
   int64_t blocks = 256;   // one 8-wave workgroup per CU
   int64_t rpw = sst_align_up(sst_div_up(m, blocks * 8), 8);

@@ -338,10 +338,10 @@ int launch_x6(const float* x, const float* x2, int x2_from, int64_t ldx, const f
               hipStream_t st, const ln_epi ln = ln_epi()) {
   constexpr int lds = 3 * NW * (K * 2 + 16) + NW * (EPI == kEpiAddLN ? 3 : 1) * 4;
   static_assert(lds <= 160 * 1024, "three weight images of a column group must fit the CU's LDS");
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (sst_first_use_on_device(&configured)) {
     SST_HIP(hipFuncSetAttribute((const void*)tall_linear_f32x6_k<K, NW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    configured = true;
+    sst_mark_device(&configured);
   }
   const int groups = n / NW;
   // one 8-wave workgroup per CU: row blocks x column groups <= 256 workgroups, row blocks a multiple of 8 so that the groups of

@@ -59,8 +59,12 @@ int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* a, void* strea
   rc = sst_tall_linear_epi2_f32x6(a->xp, a->x, 2 * kC, kC, a->w_in, kC, 0, a->b_in, m, kC, 3 * kC, kEpiBias, nullptr, nullptr, 0,
                                   a->qkv, 3 * kC, stream);
   if (rc) return rc;
-  rc = sst_sra_attn_fwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->tok, a->winoff, a->order,
-                                a->n_windows, a->n_heads, a->scale, a->max_tokens, a->impl, a->o, kC, a->lse, stream);
+  if (a->head_scale != nullptr)   // cosine attention: normalisation and 1 / clamp(tau) inside the kernel (cosine_msa.py:159-170)
+    rc = sst_sra_attn_cos_fwd_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->tok, a->winoff, a->order,
+                                  a->n_windows, a->n_heads, a->head_scale, a->max_tokens, a->o, kC, a->lse, stream);
+  else
+    rc = sst_sra_attn_fwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->tok, a->winoff, a->order,
+                                  a->n_windows, a->n_heads, a->scale, a->max_tokens, a->impl, a->o, kC, a->lse, stream);
   if (rc) return rc;
   // out-projection + residual + LayerNorm (:113-115)
   rc = sst_tall_linear_ln_f32x6(a->o, kC, a->w_out, kC, a->b_out, m, kC, a->x, kC, a->n1w, a->n1b, a->eps, a->y1, a->s1, a->st1,
@@ -114,9 +118,14 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   if (rc) return rc;
   rc = sst_tall_linear_epi_f32x6(a->ds1, kC, a->w_out, kC, 1, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
   if (rc) return rc;
-  rc = sst_sra_attn_bwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, a->o, a->d_o, a->lse, 3 * kC, 3 * kC, 3 * kC, kC, kC, a->tok,
-                                a->winoff, a->order, a->n_windows, m, a->n_heads, a->scale, a->max_tokens, a->impl, a->dqkv,
-                                a->dqkv + kC, a->dqkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, ws_sra, stream);
+  if (a->head_scale != nullptr)
+    rc = sst_sra_attn_cos_bwd_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, a->o, a->d_o, a->lse, 3 * kC, 3 * kC, 3 * kC, kC, kC, a->tok,
+                                  a->winoff, a->order, a->n_windows, m, a->n_heads, a->head_scale, a->max_tokens, a->dqkv,
+                                  a->dqkv + kC, a->dqkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->cos_r, stream);
+  else
+    rc = sst_sra_attn_bwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, a->o, a->d_o, a->lse, 3 * kC, 3 * kC, 3 * kC, kC, kC, a->tok,
+                                  a->winoff, a->order, a->n_windows, m, a->n_heads, a->scale, a->max_tokens, a->impl, a->dqkv,
+                                  a->dqkv + kC, a->dqkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, ws_sra, stream);
   if (rc) return rc;
   sst_wgrad_problem_f32 g2[3];
   g2[0].dy = a->ds1, g2[0].x = a->o, g2[0].m = m, g2[0].ld_dy = kC, g2[0].ld_x = kC, g2[0].dw = a->dwo, g2[0].db = a->dbo;

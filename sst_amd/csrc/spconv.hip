@@ -622,7 +622,10 @@ __global__ __launch_bounds__(256) void sp_conv_seg_k(const float* __restrict__ x
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int e = vb + rb * 16 + 4 * kq + r;
-          if (e < cnt) atomicAdd(&ytile[lrow[k][e]][wave * 16 + l15], acc[rb][r]);
+          // plain read-modify-write (a float atomicAdd into LDS until round 5): a wave owns its 16 columns of the tile and the
+          // rows lrow[k][.] of one offset are distinct, so no two lanes of the workgroup ever meet on an element; successive
+          // offsets accumulate in program order - deterministic
+          if (e < cnt) ytile[lrow[k][e]][wave * 16 + l15] += acc[rb][r];
         }
         acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }

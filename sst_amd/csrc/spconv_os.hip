@@ -578,11 +578,11 @@ int sst_spconv_conv_os_f32(const float* d_x, int64_t ldx, const int32_t* d_map, 
   do {                                                                                                                 \
     constexpr int lds_max = (2 * 64 * 16 * NCT + kOsMaxK * 64 * RB + 4) * (int)sizeof(float);                          \
     const int lds = (2 * 64 * 16 * NCT + kvol * 64 * RB + 4) * (int)sizeof(float);                                     \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
+    static unsigned long long attr_set = 0;                                                                                      \
+    if (sst_first_use_on_device(&attr_set)) {                                                                                                   \
       SST_HIP(hipFuncSetAttribute((const void*)sp_conv_os_k<NCT, RB>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                   lds_max));                                                                           \
-      attr_set = true;                                                                                                 \
+      sst_mark_device(&attr_set);                                                                                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((sp_conv_os_k<NCT, RB>), grid, dim3(256), lds, st, d_x, ldx, d_map, m, kvol, wp, cin, cout,     \
                        d_bias, d_y, ldy, (int)n_units, c.n_cg, n_cc, chunk, vec_store, d_tile_order);                        \

@@ -258,20 +258,20 @@ int sst_spconv_conv_os_f32x3(const float* d_x, int64_t ldx, const int32_t* d_map
   const int vec_store = ((ldy & 3) == 0 && (((uintptr_t)d_y) & 15) == 0 && (!d_bias || (((uintptr_t)d_bias) & 15) == 0)) ? 1 : 0;
   const int lds = (2 * 64 * 16 * nct + kvol * 64 + 4) * (int)sizeof(unsigned);
   if (nct == 4) {
-    static bool attr4 = false;
-    if (!attr4) {
+    static unsigned long long attr4 = 0;
+    if (sst_first_use_on_device(&attr4)) {
       SST_HIP(hipFuncSetAttribute((const void*)sp_conv_os_x3_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (2 * 64 * 16 * 4 + kX3MaxK * 64 + 4) * (int)sizeof(unsigned)));
-      attr4 = true;
+      sst_mark_device(&attr4);
     }
     hipLaunchKernelGGL(sp_conv_os_x3_k<4>, grid, dim3(256), lds, st, d_x, ldx, d_map, m, kvol, wp, cin, cout, d_bias, d_y, ldy,
                        (int)n_units, n_cg, n_cc, chunk, vec_store, d_tile_order);
   } else {
-    static bool attr8 = false;
-    if (!attr8) {
+    static unsigned long long attr8 = 0;
+    if (sst_first_use_on_device(&attr8)) {
       SST_HIP(hipFuncSetAttribute((const void*)sp_conv_os_x3_k<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (2 * 64 * 16 * 8 + kX3MaxK * 64 + 4) * (int)sizeof(unsigned)));
-      attr8 = true;
+      sst_mark_device(&attr8);
     }
     hipLaunchKernelGGL(sp_conv_os_x3_k<8>, grid, dim3(256), lds, st, d_x, ldx, d_map, m, kvol, wp, cin, cout, d_bias, d_y, ldy,
                        (int)n_units, n_cg, n_cc, chunk, vec_store, d_tile_order);

@@ -59,6 +59,11 @@ thread_local hipEvent_t g_prof_bwd_start = nullptr, g_prof_bwd_stop = nullptr;
 // launch order of the windows of the CURRENT call (sst_sra_attn_{fwd,bwd}_ord_f32 set it around the plain entry points):
 // workgroup position p handles window order[p]; nullptr = window p
 thread_local const int32_t* g_win_order = nullptr;
+// cosine attention of the CURRENT call (sst_sra_attn_cos_{fwd,bwd}_f32 set them around the plain entry points): per-head score
+// scale 1 / clamp(tau, tau_min) in device memory (the parameter never visits the host), and the backward's per-(token, head)
+// output q^ . dq^ (the gradient of the scale is its column sum); nullptr = standard attention
+thread_local const float* g_head_scale = nullptr;
+thread_local float* g_cos_r = nullptr;
 constexpr int kWH = SST_WAVE_HEADS;  // heads (= waves) per workgroup of the register-resident kernels
 constexpr int kRS = 68;     // LDS row stride (floats)
 constexpr int kMaxTilesMfma = 9;
@@ -306,17 +311,33 @@ __device__ __forceinline__ float rows4_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// 1 / max(|x|_2, 1e-12) of the 16-channel head row whose four float4 pieces sit on lanes c, c+16, c+32, c+48
+// (torch.nn.functional.normalize(x, dim=-1), cosine_msa.py:159-160), on every lane of the column
+__device__ __forceinline__ float rowfrag_inv_norm(const float4 x) {
+  const float n2 = rows4_sum(fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, x.w * x.w))));
+  return 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+}
+__device__ __forceinline__ float4 scale4(const float4 x, const float s) {
+  return make_float4(x.x * s, x.y * s, x.z * s, x.w * s);
+}
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
-template <int NT>
+// COS: scaled cosine attention (cosine_msa.py:123-170) - q and k rows are normalised per head as they are loaded (one
+// 4-lane reduction each) and the scores are scaled by hscale[head] = 1 / clamp(tau, tau_min) instead of `scale`
+template <int NT, bool COS>
 __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, const float* __restrict__ K,
                                                   const float* __restrict__ V, uint32_t ldq, uint32_t ldk,
                                                   uint32_t ldv, const int32_t* __restrict__ tok, int beg, int t, int nt,
                                                   int hg, int H, float scale, float* __restrict__ O, uint32_t ldo,
-                                                  float* __restrict__ LSE) {
+                                                  float* __restrict__ LSE, const float* __restrict__ hscale) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kWH + (threadIdx.x >> 6);
+  if (COS) scale = hscale[head];
   const uint32_t hoff = head * kHD;
   constexpr int NTK = (NT * 16 + 63) / 64;
   // token ids, 64 window positions per register; positions past the window repeat its last token so that
@@ -337,6 +358,7 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
       // the last, partially filled tile the steps that would only see padded keys are skipped altogether.
       const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + (c >> 2) + 4 * (c & 3), 64);
       kf[j] = ldg4(K, krow * ldk + hoff + 4 * g);
+      if (COS) kf[j] = scale4(kf[j], rowfrag_inv_norm(kf[j]));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const uint32_t vrow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + g + 4 * r, 64);
@@ -361,7 +383,8 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
   // S^T tiles of one query tile: st[j][r] = S[query 16i+c][key 16j+4g+r]; k-step major so that consecutive
   // MFMAs are independent
   auto qk_tiles = [&](const float4 q, f32x4 (&st)[NT]) {
-    const float qx = q.x * qscale, qy = q.y * qscale, qz = q.z * qscale, qw = q.w * qscale;
+    const float qs = COS ? qscale * rowfrag_inv_norm(q) : qscale;
+    const float qx = q.x * qs, qy = q.y * qs, qz = q.z * qs, qw = q.w * qs;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
       if (j < nt) st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].x, qx, zero4, 0, 0, 0);
@@ -439,13 +462,14 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
 
 // One launch for every window: the tile class is picked per workgroup, so all classes run concurrently
 // (separate per-class launches serialise on the stream and the sparse classes run at very low occupancy).
-template <int NTMAX>
+template <int NTMAX, bool COS>
 __global__ __launch_bounds__(64 * kWH) void sra_fwd_wave_k(const float* __restrict__ Q, const float* __restrict__ K,
                                                       const float* __restrict__ V, int64_t ldq, int64_t ldk,
                                                       int64_t ldv, const int32_t* __restrict__ tok,
                                                       const int32_t* __restrict__ winoff, int n_groups, int H,
                                                       float scale, float* __restrict__ O, int64_t ldo,
-                                                      float* __restrict__ LSE, const int32_t* __restrict__ order) {
+                                                      float* __restrict__ LSE, const int32_t* __restrict__ order,
+                                                      const float* __restrict__ hscale) {
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
   const int wpos = bid / n_groups;
   const int hg = bid - wpos * n_groups;
@@ -456,13 +480,14 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_wave_k(const float* __restri
   if (nt < 1 || nt > NTMAX) return;  // > NTMAX: the generic kernel owns this window
   const uint32_t q_ld = (uint32_t)ldq, k_ld = (uint32_t)ldk, v_ld = (uint32_t)ldv, o_ld = (uint32_t)ldo;
   if (nt <= 2)
-    sra_fwd_wave_body<2>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
+    sra_fwd_wave_body<2, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale);
   else if (nt <= 4)
-    sra_fwd_wave_body<4>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
+    sra_fwd_wave_body<4, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale);
   else if (nt <= 7 || NTMAX <= 7)
-    sra_fwd_wave_body<(NTMAX < 7 ? NTMAX : 7)>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
+    sra_fwd_wave_body<(NTMAX < 7 ? NTMAX : 7), COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE,
+                                                    hscale);
   else
-    sra_fwd_wave_body<NTMAX>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE);
+    sra_fwd_wave_body<NTMAX, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -904,17 +929,23 @@ constexpr int kTS = 20;  // row stride (floats) of the LDS tiles
 
 __host__ __device__ constexpr int sra_fused_lds_floats_per_wave(int nt) { return (nt * 16 + 3 * 16) * kTS; }
 
-template <int NT, bool EXACT, bool NOHOIST>
+// COS (scaled cosine attention, cosine_msa.py:123-170): q and k rows are normalised per head as they are loaded, the score scale
+// is hscale[head] = 1 / clamp(tau, tau_min), and the gradients of the normalised rows are taken through the normalisation where
+// they are stored - d x = (d x^ - x^ (x^ . d x^)) / |x| - with the row fragment the lane already holds (dQ / dK leave in the
+// layout Q / K were loaded in).  q^ . dq^ = sum_k dS_qk S_qk is also what the gradient of the scale needs: written to
+// R[token][head]; d hscale[head] = colsum(R)[head] / hscale[head] (taken by the caller).
+template <int NT, bool EXACT, bool NOHOIST, bool COS>
 __device__ __forceinline__ void sra_bwd_fused_body(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t ldo,
     uint32_t lddo, const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H, float scale,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, uint32_t lddq, uint32_t lddk, uint32_t lddv,
-    float* __restrict__ lds) {
+    float* __restrict__ lds, const float* __restrict__ hscale, float* __restrict__ R) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int sig = (c >> 2) + 4 * (c & 3);  // token held by tile slot c
   const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
+  if (COS) scale = hscale[head];
   float* Kimg = lds;                 // [NT * 16][kTS]  K rows, tile slot order
   float* Qimg = Kimg + NT * 16 * kTS;  // [16][kTS]   Q rows of the current query tile
   float* Gimg = Qimg + 16 * kTS;       // [16][kTS]   dO rows of the current query tile
@@ -942,6 +973,7 @@ __device__ __forceinline__ void sra_bwd_fused_body(
     if (EXACT || j < nt) {
       const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + sig, 64);
       kf[j] = ldg4(K, krow * ldk + hoff + 4 * g);
+      if (COS) kf[j] = scale4(kf[j], rowfrag_inv_norm(kf[j]));   // k^ from here on (the K image below included)
       vf[j] = ldg4(V, krow * ldv + hoff + 4 * g);
     } else {
       kf[j] = vf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -980,7 +1012,8 @@ __device__ __forceinline__ void sra_bwd_fused_body(
     // NOHOIST: the K column fragments are re-read from the LDS image for every tile pair (4 ds_read_b32) instead of
     // being kept in 4 VGPRs per key tile across the whole loop - the price of a third wave per SIMD
     if (NOHOIST) asm volatile("" ::: "memory");
-    const float4 qf = cur.qf, gf = cur.gf;
+    const float q_inv = COS ? rowfrag_inv_norm(cur.qf) : 1.f;
+    const float4 qf = COS ? scale4(cur.qf, q_inv) : cur.qf, gf = cur.gf;   // COS: q^
     float dd = gf.x * cur.of.x + gf.y * cur.of.y + gf.z * cur.of.z + gf.w * cur.of.w;
     dd = rows4_sum(dd);                       // rowsum(dO * O) of query slot c, on every lane of the column
     const float lse_c = cur.lse * kLog2e;
@@ -1035,19 +1068,30 @@ __device__ __forceinline__ void sra_bwd_fused_body(
     // The products are formed transposed (dQ^T = K^T dS^T): in the D layout value r of lane (g, c) is
     // dQ^T[d = 4g + r][query slot c], i.e. the lane holds the ROW fragment dQ[token of slot c][4g .. 4g+3] - one
     // 16-byte store at the address pattern of the Q loads, no lane exchange.
-    if (i * 16 + sig < t) {
-      const float4 o = make_float4((dq0[0] + dq1[0]) + (dq2[0] + dq3[0]), (dq0[1] + dq1[1]) + (dq2[1] + dq3[1]),
-                                   (dq0[2] + dq1[2]) + (dq2[2] + dq3[2]), (dq0[3] + dq1[3]) + (dq2[3] + dq3[3]));
-      *(float4*)(dQ + (qrow * lddq + hoff + 4 * g)) = o;
+    float4 o = make_float4((dq0[0] + dq1[0]) + (dq2[0] + dq3[0]), (dq0[1] + dq1[1]) + (dq2[1] + dq3[1]),
+                           (dq0[2] + dq1[2]) + (dq2[2] + dq3[2]), (dq0[3] + dq1[3]) + (dq2[3] + dq3[3]));
+    if (COS) {  // through the normalisation: the lane holds q^[4g..4g+3] of the same token (every lane takes part in the sum)
+      const float rq = rows4_sum(dot4(o, qf));
+      o = make_float4((o.x - qf.x * rq) * q_inv, (o.y - qf.y * rq) * q_inv, (o.z - qf.z * rq) * q_inv,
+                      (o.w - qf.w * rq) * q_inv);
+      if (g == 0 && i * 16 + sig < t) R[qrow * (uint32_t)H + head] = rq;
     }
+    if (i * 16 + sig < t) *(float4*)(dQ + (qrow * lddq + hoff + 4 * g)) = o;
   }
   // dK^T / dV^T likewise: lane (g, c) holds d{K,V}[token of key slot c][4g .. 4g+3]
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (EXACT || j < nt) {
       const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + sig, 64);
+      float4 dkv = make_float4(dk[j][0], dk[j][1], dk[j][2], dk[j][3]);
+      if (COS) {  // kf[j] is k^; |k| comes from the row itself once more (an L2 hit) instead of a register per tile all along
+        const float k_inv = rowfrag_inv_norm(ldg4(K, krow * ldk + hoff + 4 * g));
+        const float rk = rows4_sum(dot4(dkv, kf[j]));
+        dkv = make_float4((dkv.x - kf[j].x * rk) * k_inv, (dkv.y - kf[j].y * rk) * k_inv, (dkv.z - kf[j].z * rk) * k_inv,
+                          (dkv.w - kf[j].w * rk) * k_inv);
+      }
       if (j * 16 + sig < t) {
-        *(float4*)(dK + (krow * lddk + hoff + 4 * g)) = make_float4(dk[j][0], dk[j][1], dk[j][2], dk[j][3]);
+        *(float4*)(dK + (krow * lddk + hoff + 4 * g)) = dkv;
         *(float4*)(dV + (krow * lddv + hoff + 4 * g)) = make_float4(dv[j][0], dv[j][1], dv[j][2], dv[j][3]);
       }
     }
@@ -1056,13 +1100,13 @@ __device__ __forceinline__ void sra_bwd_fused_body(
 
 // NTMAX: largest tile count the launch has to handle (the caller knows the largest window); WPS: waves per SIMD the
 // kernel is built for (2: K column fragments stay in registers, <= 256 VGPRs; 3: they are re-read from LDS, <= 168).
-template <int NTMAX, int WPS>
+template <int NTMAX, int WPS, bool COS>
 __global__ __launch_bounds__(64 * kWH, WPS) void sra_bwd_fused_k(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     int64_t lddo, const int32_t* __restrict__ tok, const int32_t* __restrict__ winoff, int n_groups, int H, float scale,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv,
-    const int32_t* __restrict__ order) {
+    const int32_t* __restrict__ order, const float* __restrict__ hscale, float* __restrict__ R) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool NH = WPS >= 3;
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
@@ -1074,17 +1118,17 @@ __global__ __launch_bounds__(64 * kWH, WPS) void sra_bwd_fused_k(
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;  // > NTMAX: the generic kernel owns this window
   float* lds = smem + (threadIdx.x >> 6) * sra_fused_lds_floats_per_wave(NTMAX);
-#define SST_FUSED_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, lds
+#define SST_FUSED_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, lds, hscale, R
   switch (nt) {
-    case 1: sra_bwd_fused_body<1, true, NH>(SST_FUSED_ARGS); break;
-    case 2: sra_bwd_fused_body<2, true, NH>(SST_FUSED_ARGS); break;
-    case 3: sra_bwd_fused_body<3, true, NH>(SST_FUSED_ARGS); break;
-    case 4: sra_bwd_fused_body<4, true, NH>(SST_FUSED_ARGS); break;
-    case 5: if constexpr (NTMAX >= 5) sra_bwd_fused_body<5, true, NH>(SST_FUSED_ARGS); break;
-    case 6: if constexpr (NTMAX >= 6) sra_bwd_fused_body<6, true, NH>(SST_FUSED_ARGS); break;
-    case 7: if constexpr (NTMAX >= 7) sra_bwd_fused_body<7, true, NH>(SST_FUSED_ARGS); break;
+    case 1: sra_bwd_fused_body<1, true, NH, COS>(SST_FUSED_ARGS); break;
+    case 2: sra_bwd_fused_body<2, true, NH, COS>(SST_FUSED_ARGS); break;
+    case 3: sra_bwd_fused_body<3, true, NH, COS>(SST_FUSED_ARGS); break;
+    case 4: sra_bwd_fused_body<4, true, NH, COS>(SST_FUSED_ARGS); break;
+    case 5: if constexpr (NTMAX >= 5) sra_bwd_fused_body<5, true, NH, COS>(SST_FUSED_ARGS); break;
+    case 6: if constexpr (NTMAX >= 6) sra_bwd_fused_body<6, true, NH, COS>(SST_FUSED_ARGS); break;
+    case 7: if constexpr (NTMAX >= 7) sra_bwd_fused_body<7, true, NH, COS>(SST_FUSED_ARGS); break;
     default:
-      if constexpr (NTMAX > 7) sra_bwd_fused_body<NTMAX, false, NH>(SST_FUSED_ARGS);
+      if constexpr (NTMAX > 7) sra_bwd_fused_body<NTMAX, false, NH, COS>(SST_FUSED_ARGS);
       break;
   }
 #undef SST_FUSED_ARGS
@@ -1097,11 +1141,19 @@ int launch_bwd_fused(const float* Q, const float* K, const float* V, const float
                      int64_t lddq, int64_t lddk, int64_t lddv, hipStream_t st) {
   const int n_groups = H / kWH;
   const size_t lds = (size_t)kWH * sra_fused_lds_floats_per_wave(NTMAX) * sizeof(float);
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    SST_HIP(hipFuncSetAttribute((const void*)sra_bwd_fused_k<NTMAX, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    configured = true;
+  const float* hs = g_head_scale;
+  float* rbuf = g_cos_r;
+  if (hs != nullptr && rbuf == nullptr) return SST_ERR_ARG;
+  auto kern = hs != nullptr ? sra_bwd_fused_k<NTMAX, WPS, true> : sra_bwd_fused_k<NTMAX, WPS, false>;
+  // the attribute is per device and per kernel: set on first use of each (device, variant)
+  static unsigned long long configured[2] = {0ull, 0ull};   // bit d of [cos]: device d done (per instantiation)
+  int dev_id = 0;
+  SST_HIP(hipGetDevice(&dev_id));
+  const unsigned long long bit = 1ull << (dev_id & 63);
+  const int slot = hs != nullptr ? 1 : 0;
+  if (!(__atomic_load_n(&configured[slot], __ATOMIC_ACQUIRE) & bit)) {
+    SST_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    __atomic_fetch_or(&configured[slot], bit, __ATOMIC_RELEASE);
   }
   const dim3 grid((unsigned)(n_windows * n_groups));
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1111,11 +1163,11 @@ int launch_bwd_fused(const float* Q, const float* K, const float* V, const float
     g_prof_bwd_start = g_prof_bwd_stop = nullptr;  // one-shot, as for the forward kernel
   }
   if (e0 != nullptr)  // kernel-exact start / stop timestamps on the launch stream
-    hipExtLaunchKernelGGL((sra_bwd_fused_k<NTMAX, WPS>), grid, dim3(64 * kWH), lds, st, e0, e1, 0, Q, K, V, O, dO, LSE, ldq,
-                          ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order);
+    hipExtLaunchKernelGGL(kern, grid, dim3(64 * kWH), lds, st, e0, e1, 0, Q, K, V, O, dO, LSE, ldq,
+                          ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order, hs, rbuf);
   else
-    hipLaunchKernelGGL((sra_bwd_fused_k<NTMAX, WPS>), grid, dim3(64 * kWH), lds, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo,
-                       lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kWH), lds, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo,
+                       lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order, hs, rbuf);
   return SST_OK;
 }
 
@@ -1151,17 +1203,19 @@ int launch_fwd_wave(const float* Q, const float* K, const float* V, int64_t ldq,
                     const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, float* O,
                     int64_t ldo, float* LSE, hipStream_t st) {
   const int n_groups = H / kWH;
+  const float* hs = g_head_scale;
+  auto kern = hs != nullptr ? sra_fwd_wave_k<NTMAX, true> : sra_fwd_wave_k<NTMAX, false>;
   if (g_prof_start != nullptr && g_prof_stop != nullptr) {
     // one-shot: kernel-exact start / stop timestamps on the launch stream (no barrier packets, no cache flush
     // between the marks and the kernel, unlike a pair of hipEventRecord calls around the launch)
-    hipExtLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st,
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st,
                           g_prof_start, g_prof_stop, 0, Q, K, V, ldq, ldk, ldv, tok, winoff, n_groups, H, scale, O, ldo,
-                          LSE, g_win_order);
+                          LSE, g_win_order, hs);
     g_prof_start = g_prof_stop = nullptr;
     return SST_OK;
   }
-  hipLaunchKernelGGL(sra_fwd_wave_k<NTMAX>, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st, Q, K, V, ldq, ldk,
-                     ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE, g_win_order);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st, Q, K, V, ldq, ldk,
+                     ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE, g_win_order, hs);
   return SST_OK;
 }
 
@@ -1359,6 +1413,50 @@ int sst_sra_attn_bwd_ord_f32(const float* d_q, const float* d_k, const float* d_
   const int rc = sst_sra_attn_bwd_f32(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
                                       n_windows, n_tokens, n_heads, scale, max_tokens, impl, d_dq, d_dk, d_dv, lddq,
                                       lddk, lddv, d_workspace, stream);
+  g_win_order = nullptr;
+  return rc;
+}
+
+// Scaled cosine attention (cosine_msa.py:123-185): softmax(normalize(q) normalize(k)^T * head_scale[h]) v inside every window,
+// head_scale[h] = 1 / clamp(tau, tau_min) in DEVICE memory ([n_heads] floats; a shared tau is passed expanded).  Only the
+// register-resident kernels carry it (impl 0, windows of <= 144 tokens, 16-byte aligned rows): anything else is
+// SST_ERR_UNSUPPORTED and the caller normalises outside (sst_amd/sst_basic_block.py WindowAttention).
+int sst_sra_attn_cos_fwd_f32(const float* d_q, const float* d_k, const float* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int n_heads, const float* d_head_scale, int max_tokens, float* d_o, int64_t ldo, float* d_lse,
+                             void* stream) {
+  if (!d_head_scale) return SST_ERR_ARG;
+  if (n_heads < 1 || n_heads % kGH != 0 || max_tokens <= 0 || max_tokens > kMaxTilesMfma * 16 || ((ldq | ldk | ldv | ldo) % 4) != 0 ||
+      !aligned16(d_q) || !aligned16(d_k) || !aligned16(d_v) || !aligned16(d_o))
+    return SST_ERR_UNSUPPORTED;
+  g_win_order = d_win_order;
+  g_head_scale = d_head_scale;
+  const int rc = sst_sra_attn_fwd_f32(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, 1.0f, max_tokens, 0, d_o,
+                                      ldo, d_lse, stream);
+  g_head_scale = nullptr;
+  g_win_order = nullptr;
+  return rc;
+}
+
+// Backward of the above.  d_dq / d_dk are the gradients of the UN-normalised q / k; d_r [n_tokens, n_heads] receives
+// normalize(q) . d normalize(q) per (token, head): d head_scale[h] = sum_tokens d_r[:, h] / head_scale[h].
+int sst_sra_attn_cos_bwd_f32(const float* d_q, const float* d_k, const float* d_v, const float* d_o, const float* d_do,
+                             const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                             const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                             int64_t n_tokens, int n_heads, const float* d_head_scale, int max_tokens, float* d_dq, float* d_dk,
+                             float* d_dv, int64_t lddq, int64_t lddk, int64_t lddv, float* d_r, void* stream) {
+  if (!d_head_scale || !d_r) return SST_ERR_ARG;
+  if (n_heads < 1 || n_heads % kGH != 0 || max_tokens <= 0 || max_tokens > kMaxTilesMfma * 16 ||
+      ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) % 4) != 0 || !aligned16(d_q) || !aligned16(d_k) || !aligned16(d_v) ||
+      !aligned16(d_o) || !aligned16(d_do) || !aligned16(d_dq) || !aligned16(d_dk) || !aligned16(d_dv))
+    return SST_ERR_UNSUPPORTED;
+  g_win_order = d_win_order;
+  g_head_scale = d_head_scale;
+  g_cos_r = d_r;
+  const int rc = sst_sra_attn_bwd_f32(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
+                                      n_tokens, n_heads, 1.0f, max_tokens, 0, d_dq, d_dk, d_dv, lddq, lddk, lddv, nullptr, stream);
+  g_cos_r = nullptr;
+  g_head_scale = nullptr;
   g_win_order = nullptr;
   return rc;
 }

@@ -289,11 +289,11 @@ template <int K, int EPI, int TRANS_W>
 int launch_n128(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int64_t m, float* Y,
                 int64_t ldy, hipStream_t st, float* aux = nullptr) {
   const size_t lds = (size_t)128 * K * sizeof(float) + (size_t)kTgWaves * kTgImage;
-  static bool configured = false;  // per instantiation; the attribute call costs tens of microseconds on the host
-  if (!configured) {
+  static unsigned long long configured = 0;  // per instantiation; the attribute call costs tens of microseconds on the host
+  if (sst_first_use_on_device(&configured)) {
     SST_HIP(hipFuncSetAttribute((const void*)tall_gemm_n128_k<K, EPI, TRANS_W>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+    sst_mark_device(&configured);
   }
   const int64_t n_tiles = sst_div_up(m, 32);
   const int grid = (int)(n_tiles < kTgGrid ? n_tiles : kTgGrid);

@@ -639,12 +639,12 @@ static int launch_partials(const float* d_dy, const float* d_x, int64_t m, int o
       const char* e = getenv("SST_WGRAD_U");
       wide_u = e ? atoi(e) : 4;
     }
-    static bool configured = false;  // once: the attribute call costs tens of microseconds on the host
-    if (!configured) {
+    static unsigned long long configured = 0;  // once: the attribute call costs tens of microseconds on the host
+    if (sst_first_use_on_device(&configured)) {
       const int lds_max = 4 * 132 * 64 * (int)sizeof(float);
       SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
       SST_HIP(hipFuncSetAttribute((const void*)wgrad_wide_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      configured = true;
+      sst_mark_device(&configured);
     }
     const int tiles_arg = tiled ? ntile : 0;
     if (wide_u == 2) {
@@ -659,10 +659,10 @@ static int launch_partials(const float* d_dy, const float* d_x, int64_t m, int o
     const int tiles = ((out + kWgTileO - 1) / kWgTileO) * ((in + kWgTileI - 1) / kWgTileI);
     constexpr int KW = 2;
     const size_t lds = (size_t)(KW - 1) * 4 * 34 * 64 * sizeof(float);
-    static bool configured_narrow = false;
-    if (!configured_narrow) {
+    static unsigned long long configured_narrow = 0;
+    if (sst_first_use_on_device(&configured_narrow)) {
       SST_HIP(hipFuncSetAttribute((const void*)wgrad_k<8, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured_narrow = true;
+      sst_mark_device(&configured_narrow);
     }
     hipLaunchKernelGGL((wgrad_k<8, KW>), dim3((unsigned)(s * tiles)), dim3(256 * KW), lds, st, d_dy, d_x, m, out, in,
                        ld_dy, ld_x, rps, part_w, part_b);

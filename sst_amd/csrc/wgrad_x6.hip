@@ -347,10 +347,10 @@ int sst_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, vo
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)d_workspace;
   float* dbp = (float*)((char*)d_workspace + plan.part_bytes);
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (sst_first_use_on_device(&configured)) {
     SST_HIP(hipFuncSetAttribute((const void*)wgrad_x6_k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    configured = true;
+    sst_mark_device(&configured);
   }
   hipLaunchKernelGGL(wgrad_x6_k, dim3((unsigned)(plan.g.tiles * plan.g.slices)), dim3(512), kLdsBytes, st, plan.g, part, dbp);
   const int64_t quads = (int64_t)plan.g.tiles * (kTile * kTile / 4);

@@ -515,6 +515,82 @@ def _sra_bwd(q, k, v, o, lse, grad_o, plan, n_heads, scale, impl, dq, dk, dv):
     _lib.check(rc, 'sst_sra_attn_bwd_ord_f32')
 
 
+def cosine_kernels_ok(plan, n_heads, impl=0):
+    """scaled cosine attention inside the register-resident kernels (sst_sra_attn_cos_{fwd,bwd}_f32): windows of <= 144 tokens,
+    heads in groups of four, the default kernel choice; anything else normalises q, k outside the kernel"""
+    return impl == 0 and n_heads % 4 == 0 and 0 < plan.max_tokens <= 144
+
+
+def _sra_cos_fwd(q, k, v, plan, n_heads, head_scale):
+    """softmax(normalize(q) normalize(k)^T * head_scale[h]) v per window; head_scale: [n_heads] fp32 on the device.
+    -> (o, lse), or None when the library does not take the layout (the caller normalises outside)"""
+    m, c = q.shape
+    o = (torch.zeros if plan.n_tokens < m else torch.empty)((m, c), dtype=torch.float32, device=q.device)
+    lse = torch.empty((m, n_heads), dtype=torch.float32, device=q.device)
+    order = plan.order
+    rc = _bracket('sra_fwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_cos_fwd_f32(
+        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _row_stride(q), _row_stride(k), _row_stride(v), plan.tok_ptr(0),
+        _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None, plan.n_windows, n_heads, _lib.ptr(head_scale),
+        plan.max_tokens, _lib.ptr(o), o.stride(0), _lib.ptr(lse), _lib.stream_ptr()))
+    if rc == _lib.SST_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, 'sst_sra_attn_cos_fwd_f32')
+    return o, lse
+
+
+def _sra_cos_bwd(q, k, v, o, lse, grad_o, plan, n_heads, head_scale, dq, dk, dv):
+    """-> r [M, n_heads] = normalize(q) . d normalize(q): d head_scale = r.sum(0) / head_scale"""
+    m = q.size(0)
+    r = (torch.zeros if plan.n_tokens < m else torch.empty)((m, n_heads), dtype=torch.float32, device=q.device)
+    order = plan.order
+    rc = _bracket('sra_bwd', plan.n_tokens, lambda: _lib.load().sst_sra_attn_cos_bwd_f32(
+        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(grad_o), _lib.ptr(lse), _row_stride(q), _row_stride(k),
+        _row_stride(v), o.stride(0), grad_o.stride(0), plan.tok_ptr(0), _lib.ptr(plan.winoff),
+        _lib.ptr(order) if order is not None else None, plan.n_windows, m, n_heads, _lib.ptr(head_scale), plan.max_tokens,
+        _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _row_stride(dq), _row_stride(dk), _row_stride(dv), _lib.ptr(r),
+        _lib.stream_ptr()))
+    _lib.check(rc, 'sst_sra_attn_cos_bwd_f32')
+    return r
+
+
+def head_scale_grad(r, head_scale):
+    """gradient of the per-head score scale from the backward kernel's r [M, H] (column sums / scale)"""
+    from .dense import colsum
+    return colsum(r) / head_scale
+
+
+class SRACosineAttentionQKV(Function):
+    """scaled cosine attention on q|k packed as [M, 2C] and v [M, C] (cosine_msa.py:123-170): normalisation and the per-head
+    scale 1 / clamp(tau) inside the kernels; differentiable in qk, v and head_scale ([H], device)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, head_scale, plan, n_heads):
+        c = v.size(1)
+        head_scale = head_scale.contiguous()
+        res = _sra_cos_fwd(qk[:, :c], qk[:, c:], v, plan, n_heads, head_scale)
+        if res is None:
+            raise RuntimeError('sst_amd: cosine attention kernels do not take this layout (check cosine_kernels_ok first)')
+        o, lse = res
+        ctx.plan, ctx.n_heads = plan, n_heads
+        ctx.save_for_backward(qk, v, o, lse, head_scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, grad_o):
+        qk, v, o, lse, head_scale = ctx.saved_tensors
+        c = v.size(1)
+        grad_o = grad_o.contiguous()
+        full = ctx.plan.n_tokens == v.size(0)
+        dqk = _grad_buf(qk.shape, qk.device, full)
+        dv = _grad_buf(v.shape, v.device, full)
+        r = _sra_cos_bwd(qk[:, :c], qk[:, c:], v, o, lse, grad_o, ctx.plan, ctx.n_heads, head_scale, dqk[:, :c], dqk[:, c:], dv)
+        return dqk, dv, head_scale_grad(r, head_scale), None, None
+
+
+def sra_cosine_attention_qk_v(qk, v, head_scale, plan, n_heads):
+    return SRACosineAttentionQKV.apply(qk, v, head_scale, plan, n_heads)
+
+
 def _grad_buf(shape, device, full):
     return (torch.empty if full else torch.zeros)(shape, dtype=torch.float32, device=device)
 

@@ -102,6 +102,14 @@ class WindowAttention(nn.Module):
         self.layer_id = layer_id
         self.impl = 0  # 0: MFMA kernels, 1: generic VALU kernels (validation)
 
+    def head_scale(self):
+        """cosine attention: the per-head score scale 1 / clamp(tau, tau_min) as a [nhead] device tensor (a shared tau expanded),
+        differentiable in tau (cosine_msa.py:162-168); None for standard attention"""
+        if not self.cosine:
+            return None
+        attn = self.self_attn
+        return (1.0 / attn.tau.float().clamp(min=attn.tau_min)).reshape(-1).expand(self.nhead).contiguous()
+
     def forward(self, feat_2d, pos_dict, ind_dict, key_padding_dict=None):
         '''
         Args:
@@ -124,7 +132,10 @@ class WindowAttention(nn.Module):
         xp = x + pos if pos is not None else x          # q = k = feat + pos ; v = feat
         qk = tall_linear(xp, w[:2 * c], b[:2 * c])
         v = tall_linear(x, w[2 * c:], b[2 * c:])
-        if self.cosine:
+        if self.cosine and not composed and K.cosine_kernels_ok(plan, self.nhead, self.impl) and qk.is_cuda:
+            # normalisation and 1 / clamp(tau) inside the attention kernels (csrc/sra_attn.hip, COS variants)
+            o = K.sra_cosine_attention_qk_v(qk, v, self.head_scale(), plan, self.nhead)
+        elif self.cosine:
             h = self.nhead
             q = F.normalize(qk[:, :c].reshape(-1, h, self.head_dim), dim=2)
             k = F.normalize(qk[:, c:].reshape(-1, h, self.head_dim), dim=2)
@@ -209,7 +220,9 @@ def _layer_exec_ok(x, xp, plan, nhead, act, params):
     for t in (x, xp) + tuple(params):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0):
             return False
-    return True
+    # the backward call must be possible too: once the forward has taken this path there is no other one to fall back to
+    from . import _lib
+    return int(_lib.load().sst_encoder_layer_bwd_workspace_bytes(m, nhead)) >= 0
 
 
 # columns (fp32 words per token) of the tensors a layer keeps for its backward pass, in the order they sit in ONE allocation
@@ -226,8 +239,8 @@ def _slab_offsets(m):
     return out, off
 
 
-def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd):
-    """-> (slab (uint8: the kept tensors at _slab_offsets), y2, y2p)"""
+def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale=None):
+    """-> (slab (uint8: the kept tensors at _slab_offsets), y2, y2p); head_scale ([nhead], device): cosine attention"""
     from . import _lib
     import ctypes
     w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b = params
@@ -247,9 +260,11 @@ def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next,
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
         S('qkv'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'), S('s2'), P(y2), S('st2'),
-        P(y2p))
+        P(y2p), P(head_scale))
     lib = _lib.load()
     rc = K._bracket('sra_fwd', plan.n_tokens, lambda: lib.sst_encoder_layer_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
+    if rc == _lib.SST_ERR_UNSUPPORTED:     # a layout one of the entry points does not take: the Python sequence has the retries
+        return None
     _lib.check(rc, 'sst_encoder_layer_fwd_f32x6')
     return slab, y2, y2p
 
@@ -257,7 +272,8 @@ def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next,
 def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     from . import _lib
     import ctypes
-    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w = saved
+    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w = saved[:9]
+    head_scale = saved[9] if len(saved) > 9 else None
     m = x.size(0)
     dev = x.device
     plan, nhead, impl = ctx.plan, ctx.nhead, ctx.impl
@@ -275,6 +291,7 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     dw_in, db_in, dwo, dbo = e(384, 128), e(384), e(128, 128), e(128)
     dw1, db1, dw2, db2 = e(256, 128), e(256), e(128, 256), e(128)
     dn = e(4, 128)
+    cos_r = e(m, nhead) if head_scale is not None else None
     lib = _lib.load()
     nbytes = lib.sst_encoder_layer_bwd_workspace_bytes(m, nhead)
     if nbytes < 0:
@@ -290,11 +307,13 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
         P(w_in), P(w_out), P(w1), P(w2), P(n1w), P(n2w),
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         p_ds2, p_dpre, P(ds1), p_do, p_dqkv,
-        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 512, dnp + 1024, dnp + 1536, P(ws))
+        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 512, dnp + 1024, dnp + 1536, P(ws),
+        P(head_scale), P(cos_r))
     rc = K._bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_encoder_layer_bwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
+    d_scale = K.head_scale_grad(cos_r, head_scale) if head_scale is not None else None
     return (ds1, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3], None, None,
-            None)
+            None, d_scale, None)
 
 
 class FusedEncoderLayerFn(torch.autograd.Function):
@@ -307,30 +326,41 @@ class FusedEncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, plan, nhead, impl, act, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps,
-                xp=None, pos_next=None):
+                xp=None, pos_next=None, head_scale=None, xp_shares_x=False):
         """xp (optional): x + positional embedding, already formed (the previous layer's second output) - ``pos`` is then
-        ignored; pos_next = (table, row index): also return y + table[index], the next layer's xp."""
+        ignored; pos_next = (table, row index): also return y + table[index], the next layer's xp; head_scale ([nhead] fp32 on
+        the device, differentiable): scaled cosine attention with the per-head scale 1 / clamp(tau) (cosine_msa.py:123-170),
+        normalisation inside the attention kernels; xp_shares_x: the caller states that the ``xp`` it hands in is x + a constant
+        (the encoder chain: x + positional rows), so d(xp) may be folded into d(x) - one K = 384 product instead of two, and the
+        producer's LayerNorm backward reads one upstream gradient.  An independent ``xp`` without the flag gets its own gradient
+        in every mode."""
         c = x.size(1)
         x = x.contiguous()
+        if head_scale is not None:
+            head_scale = head_scale.contiguous()
+        ctx.cosine = head_scale is not None
         from . import dense as _dense
         ctx.matmul = _dense.matmul_mode()    # the backward pass multiplies the way the forward pass did, whatever the mode is by then
         ctx.set_materialize_grads(False)     # an output nobody differentiates (y2p when its gradient was folded into y2's) stays None
         ctx.split_input = xp is not None
+        ctx.fold_xp = (xp is None) or bool(xp_shares_x)     # d(xp) -> d(x): only when xp = x + constant
         if xp is None:
             xp = x + pos if pos is not None else x
         params = (w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
         ctx.exec = False
-        if c == 128 and _layer_exec_ok(x, xp, plan, nhead, act, params):
+        if c == 128 and ctx.fold_xp and _layer_exec_ok(x, xp, plan, nhead, act, params):
             # the launch sequence below as ONE library call (csrc/layer_exec.hip)
             need_bwd = any(ctx.needs_input_grad)
             scale = 1.0 / math.sqrt(16.0)
-            slab, y2, y2p = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd)
-            if need_bwd:
-                ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w)
-                ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
-                ctx.exec = True
-            ctx.two = pos_next is not None
-            return (y2, y2p) if ctx.two else y2
+            done = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale)
+            if done is not None:
+                slab, y2, y2p = done
+                if need_bwd:
+                    ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w, *((head_scale,) if ctx.cosine else ()))
+                    ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
+                    ctx.exec = True
+                ctx.two = pos_next is not None
+                return (y2, y2p) if ctx.two else y2
         if _LDS_LINEAR and c == 128 and lds_linear_qkv_ok(xp, x, w_in):     # one launch, two inputs (csrc/dense_f32x6.hip)
             qkv = lds_linear_qkv(xp, x, w_in, b_in)
             qk, v = qkv[:, :2 * c], qkv[:, 2 * c:]
@@ -338,7 +368,13 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             qk = _linear_fwd(xp, w_in[:2 * c], b_in[:2 * c])
             v = _linear_fwd(x, w_in[2 * c:], b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
-        o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
+        if ctx.cosine:
+            res = K._sra_cos_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, head_scale)
+            if res is None:
+                raise RuntimeError('sst_amd: cosine attention kernels refused a layout _can_fuse admitted')
+            o, lse = res
+        else:
+            o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
         fuse_ln = _LDS_LINEAR and lds_linear_add_ln_ok(o, w_out, x, c)
         if fuse_ln:    # out-projection + residual + LayerNorm in one kernel (csrc/dense_f32.hip)
@@ -367,7 +403,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         if pos_next is not None and y2p is None:
             y2p = y2 + pos_next[0].index_select(0, pos_next[1].long())
         if need_bwd:
-            ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
+            ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w,
+                                  *((head_scale,) if ctx.cosine else ()))
             ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
         ctx.two = pos_next is not None
         return (y2, y2p) if ctx.two else y2
@@ -384,7 +421,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             if dy2 is None:       # only the second output was differentiated
                 dy2, dy2p = dy2p, None
             return _layer_exec_bwd(ctx, dy2, dy2p if ctx.two else None, ctx.saved_tensors)
-        x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
+        x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors[:19]
+        head_scale = ctx.saved_tensors[19] if ctx.cosine else None
         c = x.size(1)
         if dy2 is None:           # only the second output was differentiated
             dy2, dy2p = dy2p, None
@@ -412,15 +450,21 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         # dq | dk | dv in ONE [M, 3C] buffer: d(x) of the whole in-projection is then a single GEMM
         dqkv = torch.empty((x.size(0), 3 * c), dtype=torch.float32, device=x.device)
         dqk, dv = dqkv[:, :2 * c], dqkv[:, 2 * c:]
-        K._sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, ctx.impl, dqkv[:, :c],
-                   dqkv[:, c:2 * c], dv)
+        d_scale = None
+        if ctx.cosine:
+            r = K._sra_cos_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, head_scale, dqkv[:, :c],
+                               dqkv[:, c:2 * c], dv)
+            d_scale = K.head_scale_grad(r, head_scale)
+        else:
+            K._sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, ctx.impl, dqkv[:, :c],
+                       dqkv[:, c:2 * c], dv)
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * c, **f32)
         dwo, dbo = torch.empty_like(w_out), torch.empty(w_out.size(0), **f32)
         # second group (3 problems), before ds1 is accumulated into in place
         weight_bias_grad_group([(ds1, o, dwo, dbo), (dqk, xp, dw_in[:2 * c], db_in[:2 * c]), (dv, x, dw_in[2 * c:], db_in[2 * c:])])
         dxp = None
-        if _LDS_LINEAR and c == 128 and lds_linear_dqkv_ok(dqkv, w_in):
+        if ctx.fold_xp and _LDS_LINEAR and c == 128 and lds_linear_dqkv_ok(dqkv, w_in):
             # xp = x + pos with a constant pos: d(x) += d(xp), so the residual branch and all three projections leave as ONE
             # product over K = 384 with the residual in the epilogue; the gradient of xp is folded in (None): the producer's
             # LayerNorm backward then reads one upstream gradient instead of two
@@ -433,7 +477,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         else:
             dx = ds1.addmm_(dqkv, w_in)                               # residual + q,k,v branches (in place)
         return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
-                None, dxp, None)
+                None, dxp, None, d_scale, None)
 
 
 def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()):
@@ -451,7 +495,7 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
             x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
             attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
             enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
-            enc.norm1.eps, xp, pos_next)
+            enc.norm1.eps, xp, pos_next, enc.win_attn.head_scale(), True)     # xp = x + positional rows: a constant offset
         return out if pos_next is not None else (out, None)
 
     from . import dense as _dense
@@ -510,7 +554,8 @@ class EncoderLayer(nn.Module):
         wa = self.win_attn
         return (self.fused and self.post_norm and isinstance(ind_dict, K.WindowPlan)
                 and ind_dict.n_tokens == src.size(0)
-                and (pos_dict is None or torch.is_tensor(pos_dict)) and not wa.cosine and wa.head_dim == 16
+                and (pos_dict is None or torch.is_tensor(pos_dict)) and wa.head_dim == 16
+                and (not wa.cosine or K.cosine_kernels_ok(ind_dict, wa.nhead, wa.impl))
                 and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
                 and self.act_name in ('gelu', 'relu') and src.dtype == torch.float32 and src.is_cuda
                 and src.size(1) % 32 == 0 and self.linear1.out_features % 32 == 0
@@ -523,7 +568,7 @@ class EncoderLayer(nn.Module):
                 src, pos_dict, ind_dict, self.win_attn.nhead, self.win_attn.impl, self.act_name, attn.in_proj_weight,
                 attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, self.linear1.weight, self.linear1.bias,
                 self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias, self.norm2.weight,
-                self.norm2.bias, self.norm1.eps, None, None)
+                self.norm2.bias, self.norm1.eps, None, None, self.win_attn.head_scale())
         if self.post_norm:
             src2 = self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)  # [N, d_model]
             src = add_layer_norm(src, self.dropout1(src2), self.norm1)     # norm1(src + src2), one kernel

@@ -112,7 +112,8 @@ def test_qkv_one_launch_equals_the_two_projections(m):
     assert torch.equal(one[:, :256], qk) and torch.equal(one[:, 256:], v)
     want = torch.cat([xp.double() @ w[:256].double().t(), x.double() @ w[256:].double().t()], 1) + b.double()
     assert float((one.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
-    assert not D.lds_linear_qkv_ok(xp, x, w)           # outside the mode: the caller keeps its two launches
+    with D.matmul_mode_scope('f32'):
+        assert not D.lds_linear_qkv_ok(xp, x, w)       # outside the mode: the caller keeps its two launches
 
 
 def _stack_case(n_voxels, seed):
