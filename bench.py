@@ -541,6 +541,8 @@ def parse_args():
                          'that frame; the line then names it in config.workload and is not the headline)')
     ap.add_argument('--no-lidar-leg', action='store_true', help='skip the LiDAR-like / pathological frame beside the headline')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the reduced-precision (bf16) measurement')
+    ap.add_argument('--no-bf16-own-process', action='store_true',
+                    help='do not repeat the reduced-precision leg as the main loop of a process of its own')
     ap.add_argument('--matmul', default='f32x6', choices=('f32', 'f32x6'),
                     help="how the fp32 encoder layers multiply in the TIMED region: 'f32x6' = exact three-way bf16 split, six "
                          "products on the bf16 matrix pipe (csrc/dense_f32x6.hip; admissible as exact fp32: tests/"
@@ -742,10 +744,16 @@ def _main(args, line_out):
     sync()
     elapsed = time.perf_counter() - t0
     K.EVENT_SINK = None
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own clock around the same K steps (the line's time is their maximum), so that a scaling run describes
+        # itself: a straggler rank shows up here, not as an unexplained loss of efficiency
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        ms = [float(v.item()) / args.steps * 1e3 for v in every]
+        per_rank = {'ms_per_step': [round(v, 3) for v in ms], 'min': round(min(ms), 3), 'max': round(max(ms), 3)}
+        elapsed = max(float(v.item()) for v in every)
 
     comm = collective_costs(reducer, dev) if reducer is not None else None   # every rank takes part
     main_host_ms = host_ms_per_step() if world == 1 else None                 # outside the timed region
@@ -889,6 +897,22 @@ def _main(args, line_out):
                                                                   'voxels_equal': True}}
         bf16_leg['host_ms_per_step'] = bf16_host_ms
         bf16_leg['host_bound'] = bool(bf16_host_ms is not None and bf16_host_ms > 0.9 * bf16_leg['ms_per_step'])
+        # The same leg as the MAIN loop of a process of its own (fresh interpreter, allocator and clocks; this process idle
+        # meanwhile): if the two disagree, state inherited from the legs in front of it is the cause, if they agree and the
+        # driver's box still differs from the builder's, it is the box.  Both are in the line.
+        if world == 1 and not args.no_bf16_own_process:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), '--precision', 'bf16', '--steps', str(args.steps), '--warmup',
+                   str(max(3, args.warmup)), '--points', str(args.points), '--blocks', str(args.blocks), '--no-cpu-baseline',
+                   '--no-lidar-leg', '--no-forward-only-leg', '--no-config-as-is-leg', '--no-traffic-remeasure', '--no-f32x3-leg',
+                   '--no-time-sra-bwd']
+            try:
+                sub = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+                own = json.loads(sub.stdout.strip().splitlines()[-1])
+                bf16_leg['own_process'] = {k: own.get(k) for k in ('value', 'ms_per_step', 'step_ms', 'host_ms_per_step')}
+                bf16_leg['own_process']['vs_in_process'] = round(own['value'] / bf16_leg['value'], 4)
+            except Exception as e:     # the leg beside the headline must never take the line down
+                bf16_leg['own_process'] = {'error': repr(e)[:200]}
 
     # Beside the headline (uniform cloud): the same step on a LiDAR-like frame with out-of-range points and duplicates
     lidar_leg = None
@@ -1087,6 +1111,15 @@ def _main(args, line_out):
             # the exchanges of one step when nothing overlaps them; in the timed step all but the last bucket ride under the
             # backward pass of the voxel encoder / index stages
             res.update(allreduce_ms=comm['allreduce_ms'], bn_sync_ms=comm['bn_sync_ms'], communication=comm)
+        if world > 1:
+            try:
+                lib_version = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                lib_version = None
+            res['ranks'] = {'world_size': world, 'backend': args.backend, 'collective_library':
+                            ('RCCL ' + lib_version) if (args.backend == 'nccl' and lib_version) else args.backend,
+                            'reduce_op_avg': bool(reducer is not None and reducer._avg), 'per_rank': per_rank,
+                            'devices_visible': torch.cuda.device_count()}
         if as_is is not None:
             as_is['vs_value'] = round(as_is['value'] / res['value'], 4)
             res['config_as_is'] = as_is

@@ -734,6 +734,55 @@ int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads);
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* args, void* stream);
 int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* args, void* stream);
 
+/* The same layer in the reduced-precision mode (bf16 storage, fp32 accumulation / softmax / LayerNorm statistics, fp32 master
+ * weights: what the reference's fp16 training of these layers - configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82 -
+ * corresponds to), one call per direction: the launch sequence of sst_amd/bf16.py EncoderLayerBF16Fn issued from C (6 launches
+ * forward, 10 + the grouped weight gradients backward; same kernels, same order, same bits).  d_model 128, feed-forward 256,
+ * 8 heads.  Activations are bf16 [m, *]; wqk [256][128], wv / wout [128][128], w1 [256][128], w2 [128][256] are the bf16 copies
+ * of the fp32 parameters (sst_cast_group_bf16), the *_t ones their transposes; biases, LayerNorm parameters, statistics
+ * (st1, st2 [m, 2]) and lse [m, 8] are fp32.  Backward: dx / dxp (bf16) are the gradients of x and of xp = x + positional rows;
+ * ds2, dpre, dy1, ds1, d_o, dqkv are scratch of widths 128, 256, 128, 128, 128, 384; parameter gradients fp32; workspace:
+ * sst_encoder_layer_bwd_bf16_workspace_bytes(m), 256-byte aligned. */
+typedef struct sst_encoder_layer_fwd_bf16_args {
+  int64_t m, n_windows;
+  int32_t n_heads, act, max_tokens, reserved;
+  float eps, scale;
+  const void *x, *xp;
+  const void *wqk, *wv, *wout, *w1, *w2;
+  const float *b_in, *b_out, *b1, *b2, *n1w, *n1b, *n2w, *n2b;
+  const int32_t *tok, *winoff, *order;
+  const float* pos_table;
+  const int32_t* pos_idx;
+  void *qk, *v, *o;
+  float* lse;
+  void *y1, *s1;
+  float* st1;
+  void *pre, *h, *s2;
+  float* st2;
+  void *y2, *y2p;
+} sst_encoder_layer_fwd_bf16_args;
+typedef struct sst_encoder_layer_bwd_bf16_args {
+  int64_t m, n_windows;
+  int32_t n_heads, act, max_tokens, reserved;
+  float eps, scale;
+  const void *dy2, *dy2p;
+  const void *x, *xp, *qk, *v, *o;
+  const float* lse;
+  const void* s1;
+  const float* st1;
+  const void *y1, *pre, *h, *s2;
+  const float* st2;
+  const void *wqk_t, *wv_t, *wout_t, *w1_t, *w2_t;
+  const float *n1w, *n2w;
+  const int32_t *tok, *winoff, *order;
+  void *ds2, *dpre, *dy1, *ds1, *d_o, *dqkv, *dxp, *dx;
+  float *dw_in, *db_in, *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dn1w, *dn1b, *dn2w, *dn2b;
+  void* workspace;
+} sst_encoder_layer_bwd_bf16_args;
+int64_t sst_encoder_layer_bwd_bf16_workspace_bytes(int64_t m);
+int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* args, void* stream);
+int sst_encoder_layer_bwd_bf16(const sst_encoder_layer_bwd_bf16_args* args, void* stream);
+
 /* sst_tall_linear_epi_f32 (csrc/dense_f32.hip): y[m, n] = epilogue(x[m, k] W^T + bias), exact fp32 (v_mfma_f32_16x16x4_f32),
  * the whole weight matrix resident in LDS; (k, n) in {(128,128), (128,256), (256,128)}.  trans_w = 0: d_w holds W as [n][k]
  * rows (F.linear's weight); trans_w = 1: d_w holds [k][n] rows - the data gradient dy[m, out] w[out, in] of a layer with

@@ -63,6 +63,22 @@ EncoderLayerBwdArgs = _struct('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args
                          'workspace', 'head_scale', 'cos_r')]))
 
 
+EncoderLayerFwdBF16Args = _struct('EncoderLayerFwdBF16Args', 'sst_encoder_layer_fwd_bf16_args of include/sst_amd.h', (
+    [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'reserved')]
+    + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
+    + [(k, _P) for k in ('x', 'xp', 'wqk', 'wv', 'wout', 'w1', 'w2', 'b_in', 'b_out', 'b1', 'b2', 'n1w', 'n1b', 'n2w', 'n2b',
+                         'tok', 'winoff', 'order', 'pos_table', 'pos_idx',
+                         'qk', 'v', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p')]))
+EncoderLayerBwdBF16Args = _struct('EncoderLayerBwdBF16Args', 'sst_encoder_layer_bwd_bf16_args of include/sst_amd.h', (
+    [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'reserved')]
+    + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
+    + [(k, _P) for k in ('dy2', 'dy2p', 'x', 'xp', 'qk', 'v', 'o', 'lse', 's1', 'st1', 'y1', 'pre', 'h', 's2', 'st2',
+                         'wqk_t', 'wv_t', 'wout_t', 'w1_t', 'w2_t', 'n1w', 'n2w', 'tok', 'winoff', 'order',
+                         'ds2', 'dpre', 'dy1', 'ds1', 'd_o', 'dqkv', 'dxp', 'dx',
+                         'dw_in', 'db_in', 'dwo', 'dbo', 'dw1', 'db1', 'dw2', 'db2', 'dn1w', 'dn1b', 'dn2w', 'dn2b',
+                         'workspace')]))
+
+
 # name -> (restype, argtypes); mirrors include/sst_amd.h one to one
 _SIGNATURES = {
     'sst_version': (ctypes.c_char_p, []),
@@ -81,6 +97,9 @@ _SIGNATURES = {
     'sst_encoder_layer_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_encoder_layer_fwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),
+    'sst_encoder_layer_bwd_bf16_workspace_bytes': (c_i64, [c_i64]),
+    'sst_encoder_layer_fwd_bf16': (c_i32, [c_ptr, c_ptr]),
+    'sst_encoder_layer_bwd_bf16': (c_i32, [c_ptr, c_ptr]),
     'sst_segment_reduce_work_words': (c_i64, [c_i64, c_i64, c_i32]),
     'sst_segment_reduce_fwd_work_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                                 c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),

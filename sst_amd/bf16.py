@@ -332,6 +332,104 @@ class _CastIn(Function):
         return dx.float() + dxp.float(), None, None
 
 
+# The whole layer as ONE library call per direction (csrc/layer_exec.hip, sst_encoder_layer_{fwd,bwd}_bf16: the launch sequence
+# of EncoderLayerBF16Fn below issued from C).  The Python side of that sequence is 6 + 10 foreign calls per layer with their
+# argument marshalling and ~25 tensor allocations: 4.7-5.1 ms of host time per step against 6.0 ms of kernels - on a slower or
+# busier host the reduced-precision step was bound by the interpreter (driver-run 8.1 ms against 6.1 ms here).
+# SST_AMD_LAYER_EXEC_BF16=0: the Python sequence (same kernels, same order, same bits: tests/test_gpu_bf16.py).
+_LAYER_EXEC = int(__import__('os').environ.get('SST_AMD_LAYER_EXEC_BF16', '1'))
+# what a layer keeps for its backward pass, in ONE allocation: (name, columns, bytes per element); pieces padded to 256 bytes
+_SLAB = (('qk', 256, 2), ('v', 128, 2), ('o', 128, 2), ('lse', 8, 4), ('s1', 128, 2), ('st1', 2, 4), ('y1', 128, 2),
+         ('pre', 256, 2), ('h', 256, 2), ('s2', 128, 2), ('st2', 2, 4))
+# scratch of the backward call (bf16 columns), one allocation: ds2 | dpre | dy1 | ds1 | d_o | dqkv
+_SCRATCH = (('ds2', 128), ('dpre', 256), ('dy1', 128), ('ds1', 128), ('d_o', 128), ('dqkv', 384))
+
+
+def _slab_offsets(m):
+    off, out = 0, {}
+    for name, cols, size in _SLAB:
+        out[name] = off
+        off += (m * cols * size + 255) // 256 * 256
+    return out, off
+
+
+def _exec_ok(x, xp, plan, nhead, act, w_in, w1, w2):
+    m, c = x.shape
+    return (_LAYER_EXEC and _FUSED_LN and c == 128 and nhead == 8 and act in ('gelu', 'relu') and m > 0
+            and w_in.shape == (384, 128) and w1.shape == (256, 128) and w2.shape == (128, 256) and plan.n_tokens == m
+            and 0 < plan.max_tokens <= 144 and x.is_contiguous() and xp.is_contiguous() and x.dtype == BF16 and xp.dtype == BF16
+            and x.data_ptr() % 16 == 0 and xp.data_ptr() % 16 == 0)
+
+
+def _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next, params, need_bwd):
+    """-> (slab, y2, y2p)"""
+    import ctypes
+    w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b = params
+    m, c = x.shape
+    dev = x.device
+    offs, total = _slab_offsets(m)
+    slab = torch.empty(total, dtype=torch.uint8, device=dev)
+    base = slab.data_ptr()
+    y2 = torch.empty((m, c), dtype=BF16, device=dev)
+    y2p = torch.empty((m, c), dtype=BF16, device=dev) if pos_next is not None else None
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    S = lambda name: base + offs[name]                   # noqa: E731
+    order = plan.order
+    args = _lib.EncoderLayerFwdBF16Args(
+        m, plan.n_windows, nhead, 1 if act == 'gelu' else 2, plan.max_tokens, 0, float(eps), float(scale),
+        P(x), P(xp), P(shadow(w_in, (0, 2 * c))), P(shadow(w_in, (2 * c, 3 * c))), P(shadow(w_out)), P(shadow(w1)), P(shadow(w2)),
+        P(b_in), P(b_out), P(b1), P(b2), P(n1w), P(n1b), P(n2w), P(n2b), P(plan.tok), P(plan.winoff), P(order),
+        P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
+        S('qk'), S('v'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'),
+        S('s2') if need_bwd else None, S('st2'), P(y2), P(y2p))
+    lib = _lib.load()
+    rc = _timed('sra_fwd_bf16', plan.n_tokens, 0, lambda: lib.sst_encoder_layer_fwd_bf16(ctypes.byref(args), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_encoder_layer_fwd_bf16')
+    return slab, y2, y2p
+
+
+def _exec_bwd(ctx, dy2, dy2p):
+    import ctypes
+    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
+    m, c = x.shape
+    dev = x.device
+    plan = ctx.plan
+    offs, _ = _slab_offsets(m)
+    base = slab.data_ptr()
+    scratch = torch.empty((m, sum(cols for _, cols in _SCRATCH)), dtype=BF16, device=dev)
+    sp, so = {}, scratch.data_ptr()
+    for name, cols in _SCRATCH:
+        sp[name] = so
+        so += 2 * m * cols
+    dx = torch.empty((m, c), dtype=BF16, device=dev)
+    dxp = torch.empty((m, c), dtype=BF16, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    dw_in, db_in = torch.empty((3 * c, c), **f32), torch.empty(3 * c, **f32)
+    dwo, dbo = torch.empty((c, c), **f32), torch.empty(c, **f32)
+    dw1, db1 = torch.empty((256, c), **f32), torch.empty(256, **f32)
+    dw2, db2 = torch.empty((c, 256), **f32), torch.empty(c, **f32)
+    dn = torch.empty((4, c), **f32)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_encoder_layer_bwd_bf16_workspace_bytes(m), dev)
+    dy2 = dy2.contiguous()
+    dy2p = dy2p.contiguous() if dy2p is not None else None
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    S = lambda name: base + offs[name]                   # noqa: E731
+    dnp = dn.data_ptr()
+    order = plan.order
+    args = _lib.EncoderLayerBwdBF16Args(
+        m, plan.n_windows, ctx.nhead, 1 if ctx.act == 'gelu' else 2, plan.max_tokens, 0, 0.0, float(ctx.scale),
+        P(dy2), P(dy2p), P(x), P(xp), S('qk'), S('v'), S('o'), S('lse'), S('s1'), S('st1'), S('y1'), S('pre'), S('h'), S('s2'),
+        S('st2'), P(shadow(w_in, (0, 2 * c), transposed=True)), P(shadow(w_in, (2 * c, 3 * c), transposed=True)),
+        P(shadow(w_out, transposed=True)), P(shadow(w1, transposed=True)), P(shadow(w2, transposed=True)), P(n1w), P(n2w),
+        P(plan.tok), P(plan.winoff), P(order),
+        sp['ds2'], sp['dpre'], sp['dy1'], sp['ds1'], sp['d_o'], sp['dqkv'], P(dxp), P(dx),
+        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 4 * c, dnp + 8 * c, dnp + 12 * c, P(ws))
+    rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_encoder_layer_bwd_bf16(ctypes.byref(args), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_encoder_layer_bwd_bf16')
+    return (dx, dxp, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3])
+
+
 class EncoderLayerBF16Fn(Function):
     """One post-norm SRA encoder layer (sst_basic_block_v2.py:104-119) in the reduced-precision mode, as one autograd node.
     Inputs x and xp = x + positional embedding (bf16); outputs the layer result and (when ``pos_next`` is given) the
@@ -342,6 +440,17 @@ class EncoderLayerBF16Fn(Function):
     @staticmethod
     def forward(ctx, x, xp, plan, nhead, act, eps, pos_next, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b):
         c = x.size(1)
+        ctx.exec = False
+        if _exec_ok(x, xp, plan, nhead, act, w_in, w1, w2):
+            need_bwd = any(ctx.needs_input_grad)
+            scale = 1.0 / math.sqrt(16.0)
+            slab, y2, y2p = _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next,
+                                      (w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b), need_bwd)
+            if need_bwd:
+                ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w)
+                ctx.plan, ctx.nhead, ctx.act, ctx.scale, ctx.two = plan, nhead, act, scale, y2p is not None
+                ctx.exec = True
+            return y2 if y2p is None else (y2, y2p)
         # q | k from x + pos, v from x (sst_basic_block_v2.py:58-63); written side by side for the core
         qk = tall_linear(xp, shadow(w_in, (0, 2 * c)), b_in[:2 * c])
         v = tall_linear(x, shadow(w_in, (2 * c, 3 * c)), b_in[2 * c:])
@@ -368,6 +477,8 @@ class EncoderLayerBF16Fn(Function):
 
     @staticmethod
     def backward(ctx, dy2, dy2p=None):
+        if ctx.exec:
+            return _exec_bwd(ctx, dy2, dy2p if ctx.two else None)
         x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
         c = x.size(1)
         dev = x.device

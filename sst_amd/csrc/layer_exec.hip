@@ -35,6 +35,13 @@ int64_t wg_ws(int64_t m, int which) {   // workspace of the two weight-gradient 
   return sst_weight_grad_group_f32x6_workspace_bytes(p, 3);
 }
 
+int64_t wg_ws_bf16(int64_t m) {
+  sst_wgrad_problem_bf16 p[5];
+  for (auto& q : p) q.m = m;
+  p[0].p = 2 * kC, p[1].p = kC, p[2].p = kC, p[3].p = kFF, p[4].p = kFF;
+  return sst_wgrad_group_workspace_bytes(p, 5);
+}
+
 }  // namespace
 
 extern "C" {
@@ -139,6 +146,96 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   // d(x) of the residual branch and of all three projections: one product over K = 384 (xp = x + constant: d(x) += d(xp))
   return sst_tall_linear_epi_f32x6(a->dqkv, 3 * kC, a->w_in, kC, 1, nullptr, m, 3 * kC, kC, kEpiAdd, a->ds1, nullptr, kC, a->ds1, kC,
                                    stream);
+}
+
+// ---- the reduced-precision layer (sst_amd/bf16.py EncoderLayerBF16Fn, its fused-LayerNorm sequence) ------------------------
+int64_t sst_encoder_layer_bwd_bf16_workspace_bytes(int64_t m) {
+  if (m < 0) return SST_ERR_ARG;
+  const int64_t a = sst_add_layernorm_bwd_workspace_bytes(m, kC), b = wg_ws_bf16(m);
+  if (a < 0 || b < 0) return SST_ERR_UNSUPPORTED;
+  return sst_align_up(a, 256) + sst_align_up(b, 256) + 256;
+}
+
+int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* a, void* stream) {
+  if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
+  if (a->m == 0) return SST_OK;
+  if (!a->x || !a->xp || !a->wqk || !a->wv || !a->wout || !a->w1 || !a->w2 || !a->qk || !a->v || !a->o || !a->lse || !a->y1 ||
+      !a->st1 || !a->pre || !a->h || !a->y2 || !a->st2)
+    return SST_ERR_ARG;
+  const int64_t m = a->m;
+  const unsigned short* qk = (const unsigned short*)a->qk;
+  int rc;
+  // q | k from x + pos, v from x (sst_basic_block_v2.py:58-63)
+  rc = sst_tall_linear_bf16(a->xp, kC, a->wqk, a->b_in, m, kC, 2 * kC, kEpiBias, nullptr, nullptr, 0, a->qk, 2 * kC, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_bf16(a->x, kC, a->wv, a->b_in ? a->b_in + 2 * kC : nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->v,
+                            kC, stream);
+  if (rc) return rc;
+  rc = sst_sra_attn_fwd_ord_bf16(qk, qk + kC, a->v, 2 * kC, 2 * kC, kC, a->tok, a->winoff, a->order, a->n_windows, a->n_heads,
+                                 a->scale, a->max_tokens, a->o, kC, a->lse, stream);
+  if (rc) return rc;
+  // out-projection + residual + LayerNorm; linear1 + activation; linear2 + residual + LayerNorm (+ the next layer's x + pos)
+  rc = sst_tall_linear_ln_bf16(a->o, kC, a->wout, a->b_out, m, kC, a->x, kC, a->n1w, a->n1b, a->eps, a->y1, a->s1, a->st1, nullptr,
+                               nullptr, nullptr, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_bf16(a->y1, kC, a->w1, a->b1, m, kC, kFF, a->act == 1 ? kEpiGelu : kEpiRelu, nullptr, a->pre, kFF, a->h, kFF,
+                            stream);
+  if (rc) return rc;
+  return sst_tall_linear_ln_bf16(a->h, kFF, a->w2, a->b2, m, kFF, a->y1, kC, a->n2w, a->n2b, a->eps, a->y2, a->s2, a->st2,
+                                 a->pos_table, a->pos_idx, a->pos_table ? a->y2p : nullptr, stream);
+}
+
+int sst_encoder_layer_bwd_bf16(const sst_encoder_layer_bwd_bf16_args* a, void* stream) {
+  if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
+  if (a->m == 0) return SST_OK;
+  if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->dy1 || !a->ds1 || !a->d_o || !a->dqkv || !a->dxp || !a->dx ||
+      !a->s1 || !a->s2)
+    return SST_ERR_ARG;
+  const int64_t m = a->m;
+  char* ws = (char*)a->workspace;
+  void* ws_ln = ws;
+  ws += sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
+  void* ws_wg = ws;
+  const unsigned short* qk = (const unsigned short*)a->qk;
+  unsigned short* dqkv = (unsigned short*)a->dqkv;
+  int rc;
+  rc = sst_add_layernorm_bwd_bf16(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, a->dn2w, a->dn2b, ws_ln, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_bf16(a->ds2, kC, a->w2_t, nullptr, m, kC, kFF, a->act == 1 ? kEpiMulGeluGrad : kEpiMulReluGrad, a->pre,
+                            nullptr, kFF, a->dpre, kFF, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_bf16(a->dpre, kFF, a->w1_t, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, a->dy1, kC, stream);
+  if (rc) return rc;
+  rc = sst_add_layernorm_bwd_bf16(a->dy1, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, a->dn1w, a->dn1b, ws_ln, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_bf16(a->ds1, kC, a->wout_t, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
+  if (rc) return rc;
+  rc = sst_sra_attn_bwd_ord_bf16(qk, qk + kC, a->v, a->o, a->d_o, a->lse, 2 * kC, 2 * kC, kC, kC, kC, a->tok, a->winoff, a->order,
+                                 a->n_windows, a->n_heads, a->scale, a->max_tokens, dqkv, dqkv + kC, dqkv + 2 * kC, 3 * kC, 3 * kC,
+                                 3 * kC, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_bf16(dqkv, 3 * kC, a->wqk_t, nullptr, m, 2 * kC, kC, kEpiBias, nullptr, nullptr, 0, a->dxp, kC, stream);
+  if (rc) return rc;
+  rc = sst_tall_linear_bf16(dqkv + 2 * kC, 3 * kC, a->wv_t, nullptr, m, kC, kC, kEpiAdd, a->ds1, nullptr, kC, a->dx, kC, stream);
+  if (rc) return rc;
+  // every parameter gradient of the layer in one launch (+ its reduction)
+  sst_wgrad_problem_bf16 g[5];
+  for (auto& q : g) {
+    q.m = m;
+    q.ldb = kC;
+    q.bias_side = 1;
+    q.transpose_out = 0;
+    q.reserved = 0;
+  }
+  g[0].a = dqkv, g[0].lda = 3 * kC, g[0].b = a->xp, g[0].out_w = a->dw_in, g[0].out_b = a->db_in, g[0].p = 2 * kC;
+  g[1].a = dqkv + 2 * kC, g[1].lda = 3 * kC, g[1].b = a->x, g[1].out_w = a->dw_in + 2 * kC * kC, g[1].out_b = a->db_in + 2 * kC;
+  g[1].p = kC;
+  g[2].a = a->ds1, g[2].lda = kC, g[2].b = a->o, g[2].out_w = a->dwo, g[2].out_b = a->dbo, g[2].p = kC;
+  g[3].a = a->dpre, g[3].lda = kFF, g[3].b = a->y1, g[3].out_w = a->dw1, g[3].out_b = a->db1, g[3].p = kFF;
+  // dW2 [128][256] = ds2^T h: operands swapped, stored transposed; its bias gradient = column sums of the b side (ds2)
+  g[4].a = a->h, g[4].lda = kFF, g[4].b = a->ds2, g[4].out_w = a->dw2, g[4].out_b = a->db2, g[4].p = kFF;
+  g[4].bias_side = 2, g[4].transpose_out = 1;
+  return sst_wgrad_group_bf16(g, 5, ws_wg, stream);
 }
 
 }  // extern "C"

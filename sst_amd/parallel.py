@@ -20,6 +20,16 @@ network and for point-to-point xGMI links (7 x ~153 GB/s per GPU: a ring is per-
     world size inside the same pass (``ReduceOp.AVG`` where the backend has it);
   * one backward pass per ``finish()``: a hook that fires for a bucket already on the wire raises instead of losing the
     gradient (gradient accumulation over several backward passes needs ``overlap=False``);
+  * the bucket communicator is created ONCE per process and shared by every reducer (``dist.new_group`` is collective over
+    all ranks and communicators are never freed by ``remove()``: one per reducer leaked them - ADVICE round 4);
+    ``ReduceOp.AVG`` support is decided at construction by a blocking one-element probe on that communicator (an
+    asynchronous refusal mid-step could not be caught), not on the first bucket of a step;
+  * ``static_graph`` (default True) is the caller's statement that EVERY rank produces the same set of gradients every step
+    (true for SST / FSD training steps on any frame).  Only then may a bucket leave mid-backward: with per-rank sets of unused
+    parameters rank A would send bucket b before, rank B after one of naiveSyncBN's blocking all-reduces of the same backward
+    pass (default communicator), and two collectives issued in different relative order on different ranks may deadlock when
+    their kernels cannot co-run.  ``static_graph=False``: every bucket leaves in ``finish()`` - after the backward pass and all
+    its norm-layer collectives - in index order on every rank;
   * the copy into the flat buffer (one ``_foreach_copy_`` per bucket, 8.4 MB for SST-base: ~10 us per step) is skipped for a
     gradient that already IS its slot (``p.grad`` left pointing at the view and accumulated into in place).  Pre-pointing
     every gradient is not the default: autograd then accumulates in place, one small ``add_`` launch per parameter
@@ -29,21 +39,51 @@ import torch
 import torch.distributed as dist
 
 
+_BUCKET_GROUP = {}      # default-group id -> the process-wide bucket communicator
+_AVG_SUPPORT = {}       # (backend, group id) -> bool
+
+
+def bucket_group():
+    """the communicator the gradient buckets travel on: created on first use (collective: every rank builds its first reducer
+    at the same point of the program), then shared by every reducer of the process"""
+    key = id(dist.group.WORLD)
+    if key not in _BUCKET_GROUP:
+        _BUCKET_GROUP[key] = dist.new_group()
+    return _BUCKET_GROUP[key]
+
+
+def avg_supported(group, device):
+    """does the backend of ``group`` reduce with ReduceOp.AVG?  One blocking one-element all-reduce, once per communicator
+    (collective).  RCCL builds that follow NCCL >= 2.10 do; gloo refuses at the call (-> sum and divide)."""
+    key = (dist.get_backend(group), id(group))
+    if key not in _AVG_SUPPORT:
+        try:
+            probe = torch.ones(1, dtype=torch.float32, device=device)
+            dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+            if probe.is_cuda:
+                torch.cuda.current_stream(device).synchronize()
+            _AVG_SUPPORT[key] = bool(abs(float(probe.item()) - 1.0) < 1e-6)
+        except (RuntimeError, ValueError, TypeError, NotImplementedError):
+            _AVG_SUPPORT[key] = False
+    return _AVG_SUPPORT[key]
+
+
 class GradBucketReducer(object):
     """reducer = GradBucketReducer(params, n_buckets=2); per step: ``p.grad = None`` for all -> backward (hooks fire) ->
     ``reducer.finish()`` -> every ``p.grad`` is a view of the averaged flat buffer."""
 
-    def __init__(self, params, n_buckets=2, group=None, overlap=True):
+    def __init__(self, params, n_buckets=2, group=None, overlap=True, static_graph=True):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('GradBucketReducer: no parameters')
         dev, dtype = self.params[0].device, self.params[0].dtype
         if any(p.device != dev or p.dtype != dtype for p in self.params):
             raise ValueError('GradBucketReducer: parameters must share one device and dtype')
-        self.overlap = overlap
+        self.overlap = bool(overlap) and bool(static_graph)   # per-rank gradient sets: nothing leaves before finish()
+        self.static_graph = bool(static_graph)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if group is None and self.world > 1:
-            group = dist.new_group()          # collective: every rank constructs its reducer at the same point of the program
+            group = bucket_group()
         self.group = group
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
@@ -69,7 +109,7 @@ class GradBucketReducer(object):
         self._sent = [False] * len(self.buckets)
         self._next = 0                        # buckets [0, _next) are on the wire
         self._work = []
-        self._avg = dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
+        self._avg = self.world > 1 and avg_supported(self.group, dev)     # decided once, by a blocking probe
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
 
     def _make_hook(self, i):
@@ -101,14 +141,6 @@ class GradBucketReducer(object):
         self._next = b + 1
         if self.world > 1:
             chunk = self.flat[start:end]
-            if self._avg and b == 0:
-                # ReduceOp.AVG exists in RCCL builds that follow NCCL >= 2.10; one that lacks it refuses at the call: sum and
-                # divide instead (decided on the FIRST bucket of a step, so every bucket of the step is treated alike)
-                try:
-                    self._work.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-                    return
-                except (RuntimeError, ValueError, TypeError):
-                    self._avg = False
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self._work.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
 

@@ -148,3 +148,107 @@ def test_sync_bn_and_flat_grad_allreduce_world2():
         assert torch.allclose(ret[r]['y'], lin(ref), atol=1e-5)
     assert torch.allclose(ret[0]['mean'], 0.01 * mean, atol=1e-6)
     assert torch.isfinite(ret[0]['gx']).all() and ret[0]['gx'].shape == (40, 8)
+
+
+def _worker4(rank, world, port, ret):
+    """world 4: every rank lacks the gradients of a DIFFERENT head, a naiveSyncBN layer puts blocking
+    collectives of the default communicator into the same backward pass, and both ReduceOp.AVG branches are driven."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sst_amd import parallel
+        from sst_amd.norm import NaiveSyncBatchNorm1d
+        from sst_amd.parallel import GradBucketReducer
+        torch.manual_seed(0)
+        full = torch.randn(4 * 24, 8)
+        xin = full[24 * rank:24 * rank + 12 + 3 * rank]              # different numbers of rows per rank
+        torch.manual_seed(3)
+        trunk = torch.nn.Sequential(torch.nn.Linear(8, 8), NaiveSyncBatchNorm1d(8, eps=1e-3, momentum=0.01)).train()
+        heads = torch.nn.ModuleList([torch.nn.Linear(8, 4) for _ in range(world)])
+        ps = list(trunk.parameters()) + list(heads.parameters())
+
+        def step(red):
+            for p in ps:
+                p.grad = None
+            feat = trunk(xin)
+            sum((heads[k](feat) ** 2).sum() for k in range(world) if k != rank).backward()     # rank r never uses head r
+            local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in ps]
+            assert heads[rank].weight.grad is None
+            red.finish()
+            for p, g_local in zip(ps, local):
+                every = [torch.zeros_like(g_local) for _ in range(world)]
+                dist.all_gather(every, g_local)
+                assert torch.allclose(p.grad, sum(every) / world, atol=1e-6)
+            return red.flat.clone()
+
+        outs, orders = {}, {}
+        groups = set()
+        for tag, kw in (('in_finish', dict(static_graph=False)), ('overlap', dict(static_graph=True))):
+            red = GradBucketReducer(ps, n_buckets=4, overlap=True, **kw)
+            groups.add(id(red.group))
+            natural_avg = red._avg                       # whatever this build's gloo answers to the ReduceOp.AVG probe
+            assert red.overlap == (tag == 'overlap')
+            sent = []
+            orig = red._send
+            red._send = lambda b, _o=orig, _s=sent: (_s.append((b, torch.is_grad_enabled())), _o(b))[1]
+            outs[tag] = step(red)
+            orders[tag] = [b for b, _ in sent]
+            n_buckets = len(red.buckets)
+            red.remove()
+        assert len(groups) == 1, 'one bucket communicator per process, shared by the reducers'
+        assert n_buckets >= 3 and orders['in_finish'] == orders['overlap'] == list(range(n_buckets))
+        assert torch.allclose(outs['in_finish'], outs['overlap'], atol=1e-7)
+        # both ReduceOp.AVG branches, whatever the build does by itself: a backend that REFUSES the op at the call (the probe must
+        # catch it and the reducer sum + divide), and one that HAS it (RCCL following NCCL >= 2.10), emulated by sum + divide on wait
+        real = dist.all_reduce
+
+        class _Avg(object):
+            def __init__(self, work, t):
+                self.work, self.t = work, t
+
+            def wait(self):
+                self.work.wait()
+                self.t.div_(world)
+
+        def with_avg(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            if op == dist.ReduceOp.AVG:
+                w = _Avg(real(t, op=dist.ReduceOp.SUM, group=group, async_op=True), t)
+                if async_op:
+                    return w
+                w.wait()
+                return None
+            return real(t, op=op, group=group, async_op=async_op)
+
+        def refusing(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            if op == dist.ReduceOp.AVG:
+                raise RuntimeError('this backend does not reduce with AVG')
+            return real(t, op=op, group=group, async_op=async_op)
+
+        for tag, fake, want in (('avg', with_avg, True), ('no_avg', refusing, False)):
+            parallel._AVG_SUPPORT.clear()
+            dist.all_reduce = fake
+            try:
+                red = GradBucketReducer(ps, n_buckets=4, overlap=True)
+                assert red._avg is want
+                outs[tag] = step(red)
+                red.remove()
+            finally:
+                dist.all_reduce = real
+                parallel._AVG_SUPPORT.clear()
+        assert isinstance(natural_avg, bool)
+        assert torch.allclose(outs['no_avg'], outs['overlap'], atol=1e-7)
+        assert torch.allclose(outs['avg'], outs['overlap'], atol=1e-7)
+        ret[rank] = outs['overlap']
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unequal_gradient_sets_world4_with_sync_bn_and_both_avg_branches():
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker4, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert sorted(ret.keys()) == [0, 1, 2, 3]
+    for r in range(1, world):
+        assert torch.equal(ret[0], ret[r])

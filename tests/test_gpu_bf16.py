@@ -295,3 +295,52 @@ def test_bf16_shadow_weights_follow_every_kind_of_parameter_update():
     odd = torch.nn.Parameter(torch.randn(45, 70, device=DEV))
     assert torch.equal(bf16.shadow(odd, (3, 40), transposed=True), odd.detach()[3:40].t().to(BF).contiguous())
     assert torch.equal(bf16.shadow(odd), odd.detach().to(BF))
+
+
+@pytest.mark.parametrize('n_points,blocks,act', [(20000, 2, 'gelu'), (116000, 1, 'gelu'), (3000, 1, 'relu')])
+def test_bf16_layer_executor_equals_the_python_sequence(n_points, blocks, act):
+    """the reduced-precision encoder layer as ONE library call per direction (csrc/layer_exec.hip,
+    sst_encoder_layer_{fwd,bwd}_bf16) against the same launch sequence issued from Python (sst_amd/bf16.py EncoderLayerBF16Fn):
+    same kernels in the same order, so outputs and every gradient agree BIT FOR BIT through the whole pipeline"""
+    import bench
+    from sst_amd import bf16 as B
+    torch.manual_seed(0)
+    model = bench.Pipeline(blocks).to(DEV).train()
+    model.backbone.set_precision('bf16')
+    if act == 'relu':
+        for blk in model.backbone.block_list:
+            for enc in blk.encoder_list:
+                enc.act_name, enc.activation = 'relu', torch.nn.functional.relu
+    frames = [bench.make_cloud(n_points, 5, DEV)]
+    calls = []
+    orig = B._exec_fwd
+
+    def run(exec_on, grad=True):
+        B._LAYER_EXEC = 1 if exec_on else 0
+        try:
+            torch.manual_seed(11)                    # voxel shuffle / drop
+            for p in model.parameters():
+                p.grad = None
+            if not grad:
+                with torch.no_grad():
+                    return model(frames).clone(), None
+            out = model(frames)
+            gen = torch.Generator(device=DEV).manual_seed(3)
+            out.backward(torch.randn(out.shape, device=DEV, generator=gen))
+            return out.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            B._LAYER_EXEC = 1
+
+    B._exec_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out_e, grads_e = run(True)
+    finally:
+        B._exec_fwd = orig
+    assert len(calls) == 2 * blocks, 'the executor did not take the layers'
+    out_p, grads_p = run(False)
+    assert torch.equal(out_e, out_p)
+    assert grads_e.keys() == grads_p.keys() and len(grads_e) > 10
+    for n in grads_e:
+        assert torch.equal(grads_e[n], grads_p[n]), n
+    out_ne, _ = run(True, grad=False)
+    assert torch.equal(out_ne, out_e)

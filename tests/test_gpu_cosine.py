@@ -84,6 +84,8 @@ def _cosine_backbone(blocks, layer_cfg, seed=5):
     net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128] * blocks, nhead=[8] * blocks, num_blocks=blocks,
                                       dim_feedforward=[256] * blocks, output_shape=[468, 468], num_attached_conv=0, to_bev=False,
                                       debug=False, layer_cfg=layer_cfg)).to(DEV).train()
+    if not layer_cfg.get('cosine', False):
+        return net
     with torch.no_grad():           # temperatures away from their initial 1 (and one below tau_min: the clamp must cut its gradient)
         for i, blk in enumerate(net.block_list):
             for j, enc in enumerate(blk.encoder_list):

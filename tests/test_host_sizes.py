@@ -58,7 +58,9 @@ def test_encoder_layer_backward_workspace_and_slab():
 
 
 @pytest.mark.parametrize('struct,cname', [('EncoderLayerFwdArgs', 'sst_encoder_layer_fwd_args'),
-                                          ('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args')])
+                                          ('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args'),
+                                          ('EncoderLayerFwdBF16Args', 'sst_encoder_layer_fwd_bf16_args'),
+                                          ('EncoderLayerBwdBF16Args', 'sst_encoder_layer_bwd_bf16_args')])
 def test_layer_argument_structs_match_the_header(struct, cname):
     """field names and order of the ctypes structures == the typedefs of include/sst_amd.h"""
     from sst_amd import _lib
