@@ -92,8 +92,10 @@ class FramePlan(object):
             if input_layer.shuffle_voxels:
                 # voxel_feats_out = voxel_feats_in[shuffle_inds][voxel_keep_inds] (sst_input_layer_v2.py:93-97, 150-226): the
                 # plan's row index already maps output rows to input rows, so the shuffle part is the identity
-                info.defer(['shuffle_inds'], lambda d: d.update(
-                    shuffle_inds=torch.arange(self.num_voxels, dtype=torch.int64, device=dev)))
+                # (the closure must not hold the plan: plan -> info -> closure -> plan would be a reference cycle, and every
+                # step's plan - ~65 MB of index buffers - would wait for the cyclic collector instead of dying with the step)
+                info.defer(['shuffle_inds'], lambda d, _m=m, _dev=dev: d.update(
+                    shuffle_inds=torch.arange(_m, dtype=torch.int64, device=_dev)))
         self.info = info
         return info
 
@@ -188,8 +190,25 @@ class FramePlanner(object):
                                      _lib.ptr(plan.winoff0), _lib.ptr(plan.winoff1), _lib.ptr(plan.posidx0),
                                      _lib.ptr(plan.posidx1), _lib.ptr(plan.d_counts), _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, 'sst_window_plan_i32')
-        plan.h_counts = torch.empty(8, dtype=torch.int32, pin_memory=True)
+        # the sizes travel to PINNED host memory behind the plan's kernels.  The pinned words come from a ring the planner owns
+        # (16 slots, an event per slot): allocating them per plan went through the pinned-memory cache, which now and then had no
+        # free block and called hipHostMalloc - a 40-55 ms host stall in ONE step of a run (bench.py's reduced-precision leg:
+        # 129 instead of 160 frames/s with one such step among twenty; profiles/r05)
+        plan.h_counts, plan.counts_ready = self._count_slot()
         plan.h_counts.copy_(plan.d_counts, non_blocking=True)
-        plan.counts_ready = torch.cuda.Event()
         plan.counts_ready.record()
         return plan
+
+    def _count_slot(self):
+        ring = self.__dict__.get('_count_ring')
+        if ring is None:
+            ring = self._count_ring = {'host': torch.empty((16, 8), dtype=torch.int32, pin_memory=True),
+                                       'events': [None] * 16, 'next': 0}
+        i = ring['next']
+        ring['next'] = (i + 1) % 16
+        ev = ring['events'][i]
+        if ev is None:
+            ev = ring['events'][i] = torch.cuda.Event()
+        else:
+            ev.synchronize()      # the copy of the plan that used this slot 16 plans ago: long done (a plan is read once, at finalize)
+        return ring['host'][i], ev

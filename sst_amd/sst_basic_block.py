@@ -480,6 +480,60 @@ class FusedEncoderLayerFn(torch.autograd.Function):
                 None, dxp, None, d_scale, None)
 
 
+class _StackHeadScales(torch.autograd.Function):
+    """1 / clamp(tau, tau_min) of EVERY cosine layer of a stack in one pass (cosine_msa.py:162-168): -> [L, nhead], row l = the
+    per-head score scale of layer l (a shared tau expanded).  Three small launches for the whole stack instead of three per
+    layer, and the backward pass - d tau = -d scale * scale^2 where tau >= tau_min, summed over the heads for a shared tau -
+    once for all layers: the per-layer version was ~100 tiny launches per training step."""
+
+    @staticmethod
+    def forward(ctx, nhead, tau_mins, *taus):
+        flat = torch.cat([t.reshape(-1).expand(nhead) if t.numel() == 1 else t.reshape(-1) for t in taus]).view(len(taus), nhead)
+        mins = K.const_tensor(tau_mins, flat.device).view(-1, 1)
+        scales = 1.0 / torch.maximum(flat.float(), mins)
+        ctx.save_for_backward(flat, scales, mins)
+        ctx.shapes = [tuple(t.shape) for t in taus]
+        return scales
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, scales, mins = ctx.saved_tensors
+        d = torch.where(flat >= mins, -(g * scales * scales), torch.zeros((), dtype=g.dtype, device=g.device))   # [L, H]
+        per_layer_sum = None
+        out = []
+        for l, shape in enumerate(ctx.shapes):
+            n = 1
+            for v in shape:
+                n *= v
+            if n == 1:
+                if per_layer_sum is None:
+                    per_layer_sum = d.sum(1)
+                out.append(per_layer_sum[l].reshape(shape))
+            else:
+                out.append(d[l].reshape(shape))
+        return (None, None) + tuple(out)
+
+
+def stack_head_scales(layers):
+    """per-layer head scales of a stack: list aligned with ``layers`` (None for standard attention); cosine layers get rows of
+    ONE [L, nhead] tensor (row views: contiguous, 32-byte aligned for 8 heads)"""
+    cos = [(i, enc.win_attn) for i, enc in enumerate(layers) if enc.win_attn.cosine]
+    out = [None] * len(layers)
+    if not cos:
+        return out
+    heads = {wa.nhead for _, wa in cos}
+    if len(heads) != 1:              # mixed widths: every layer on its own
+        for i, wa in cos:
+            out[i] = wa.head_scale()
+        return out
+    nhead = heads.pop()
+    rows = _StackHeadScales.apply(nhead, tuple(float(wa.self_attn.tau_min) for _, wa in cos),
+                                  *[wa.self_attn.tau for _, wa in cos]).unbind(0)
+    for (i, _), row in zip(cos, rows):
+        out[i] = row
+    return out
+
+
 def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()):
     """All encoder layers of the shift blocks as a chain of FusedEncoderLayerFn nodes that hand (x, x + positional embedding)
     to each other: "+ positional embedding" of layer i + 1 is the second output of layer i's last kernel, so no add pass and
@@ -488,6 +542,8 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
     (the reference's torch.utils.checkpoint per block, sst_v2.py:131-133 / sst_basic_block_v2.py:164-165)."""
     n_layers = 2 * len(blocks)
 
+    scales = stack_head_scales([enc for block in blocks for enc in block.encoder_list])
+
     def layer(enc, li, x, xp):
         attn = enc.win_attn.self_attn
         pos_next = pos_specs[(li + 1) % 2] if li + 1 < n_layers else None
@@ -495,7 +551,7 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
             x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
             attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
             enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
-            enc.norm1.eps, xp, pos_next, enc.win_attn.head_scale(), True)     # xp = x + positional rows: a constant offset
+            enc.norm1.eps, xp, pos_next, scales[li], True)                    # xp = x + positional rows: a constant offset
         return out if pos_next is not None else (out, None)
 
     from . import dense as _dense

@@ -143,3 +143,33 @@ def test_fused_plan_random_drop_invariants():
             assert np.array_equal(wid_tok, wid_tok[starts][seg]), 'a window of the CSR mixes voxels of two windows'
             assert np.all(np.diff(wid_tok[starts]) > 0), 'windows not in ascending id order'
     assert kept_sets[0] != kept_sets[1]
+
+
+def test_a_steps_index_plan_dies_with_the_step_without_the_cyclic_collector():
+    """plan -> voxel_info -> (deferred entries) must not lead back to the plan: with a reference cycle every step's plan (~65 MB of
+    index buffers at the bench size) waited for Python's cyclic collector, the caching allocator grew by a few segments per step
+    and device memory in use by 65 MB per step (round 5: found by bench.py's allocation trace)"""
+    import gc
+    import weakref
+    import bench
+    torch.manual_seed(0)
+    model = bench.Pipeline(model_cfg=bench.load_config_fixture('sst_waymoD5_1x_3class_8heads_v2'), voxel_feats_only=True).to(DEV).train()
+    model.middle_encoder.mute = True
+    frames = [bench.make_cloud(20000, 5, DEV)]
+    gc.collect()
+    gc.disable()
+    try:
+        plan = model.prepare(frames)
+        assert plan is not None
+        out = model(frames, plan)
+        out.sum().backward()
+        ref = weakref.ref(plan)
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        del plan, out
+        model.last_voxel_coors = model.last_plans = None
+        model.zero_grad(set_to_none=True)
+        assert ref() is None, 'the frame plan is kept alive by a reference cycle'
+        assert torch.cuda.memory_allocated() < before
+    finally:
+        gc.enable()
