@@ -22,7 +22,9 @@ from . import kernels as K
 class FramePlan(object):
 
     def __init__(self):
-        self.info = None
+        # (the plan does NOT keep the voxel_info it hands out: info['voxel_feats'] carries the autograd graph of the voxel encoder,
+        # whose nodes hold this plan - plan -> info -> graph -> plan was a reference cycle, and every step's plan, index buffers
+        # and gathered features, ~65 MB at the bench size, waited for Python's cyclic collector instead of dying with the step)
         self.want_pos_rows = True   # materialise the [M, C] positional tensors (the fp32 encoder layers add them to x)
 
     # -- the interface DynamicVFE.forward uses of a scatter plan ------------------------------------------------
@@ -96,7 +98,6 @@ class FramePlan(object):
                 # step's plan - ~65 MB of index buffers - would wait for the cyclic collector instead of dying with the step)
                 info.defer(['shuffle_inds'], lambda d, _m=m, _dev=dev: d.update(
                     shuffle_inds=torch.arange(_m, dtype=torch.int64, device=_dev)))
-        self.info = info
         return info
 
 
