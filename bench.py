@@ -643,7 +643,7 @@ def _main(args, line_out):
 
     if args.workload in ('fsd', 'fsdv2'):
         import bench_workloads
-        bench_workloads.run(args, rank, world, dev, make_reducer)
+        bench_workloads.run(args, rank, world, dev, make_reducer, line_out=line_out, step_times_cls=StepTimes)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -1119,8 +1119,10 @@ def _main(args, line_out):
     if fwd is not None:
         ms, tokens, launches = fwd
         achieved = SRA_BYTES_PER_TOKEN * tokens / (ms * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': 'sra_fwd_wave_k<NTMAX> (one launch per sst_sra_attn_fwd_f32 call; HIP events bound to the launch, '
-                              'hipExtLaunchKernelGGL start/stop)',
+        roofline = {'bound': 'hbm', 'kernel': ('sra_fwd_wave_k<NTMAX, true> (scaled cosine attention; one launch per sst_sra_attn_cos_fwd_f32 call'
+                                               if args.workload == 'sst_center' else
+                                               'sra_fwd_wave_k<NTMAX, false> (one launch per sst_sra_attn_fwd_f32 call') +
+                              '; HIP events bound to the launch, hipExtLaunchKernelGGL start/stop)',
                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
                     'algorithmic_bytes_per_launch': int(SRA_BYTES_PER_TOKEN * tokens),
@@ -1148,10 +1150,11 @@ def _main(args, line_out):
         if os.path.exists(tpath) and args.points == 116000 and args.frames_per_gpu == 1:
             try:
                 tj = json.load(open(tpath))
-                roofline['traffic'] = int(tj['sra_fwd_wave_k']['hbm_bytes_per_launch'])
+                suffix = '_cosine' if args.workload == 'sst_center' else ''     # the <.., true> variants of the kernels
+                roofline['traffic'] = int(tj['sra_fwd_wave_k' + suffix]['hbm_bytes_per_launch'])
                 roofline['traffic_source'] = source
-                if 'sra_bwd' in roofline and 'sra_bwd_fused_k' in tj:
-                    roofline['sra_bwd']['traffic'] = int(tj['sra_bwd_fused_k']['hbm_bytes_per_launch'])
+                if 'sra_bwd' in roofline and 'sra_bwd_fused_k' + suffix in tj:
+                    roofline['sra_bwd']['traffic'] = int(tj['sra_bwd_fused_k' + suffix]['hbm_bytes_per_launch'])
                 if bf16_leg is not None:
                     for key, kern in (('sra_fwd', 'sra_fwd_bf16_k'), ('sra_bwd', 'sra_bwd_bf16_k')):
                         if bf16_leg['roofline'].get(key) and kern in tj:

@@ -596,9 +596,11 @@ def _conv_precision_leg(mode, timed_mode, model, clouds, step, sync, args, world
             'max_err_vs_timed_mode_forward_rel_to_output_scale': errs}
 
 
-def run(args, rank, world, dev, make_reducer):
+def run(args, rank, world, dev, make_reducer, line_out=None, step_times_cls=None):
     """bench.py's contract for --workload fsd | fsdv2: W warm-up steps, K timed steps between barriers, max over ranks,
-    one JSON line from rank 0."""
+    one JSON line from rank 0 (to `line_out`: bench.py keeps everything else off its stdout)."""
+    import sys
+    line_out = line_out if line_out is not None else sys.stdout
     spec = WORKLOADS[args.workload]
     if not getattr(args, 'no_gemm_tuning', False):
         # the point-wise linears (VFE / SIR layers, the stand-in heads: tall and very narrow products) are library GEMMs:
@@ -654,11 +656,36 @@ def run(args, rank, world, dev, make_reducer):
     gc.collect()
     gc.freeze()      # see bench.py: a full collection of a torch process costs 60-70 ms; frozen objects are not walked
     sync()
+    times = step_times_cls() if step_times_cls is not None else None
+    if times is not None:
+        times.mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if times is not None:
+            times.mark()
     sync()
     elapsed = time.perf_counter() - t0
+    step_ms = times.close().stats() if times is not None else None
+    # interpreter + launch time of a step: forward and backward timed on the host with the device idle at their start
+    host_ms = None
+    if world == 1:
+        tot = 0.0
+        for _ in range(2):
+            for p in params:
+                p.grad = None
+            sync()
+            ta = time.perf_counter()
+            loss, _st = model(clouds, prepared=None)
+            tb = time.perf_counter()
+            sync()
+            tc = time.perf_counter()
+            loss.backward()
+            td = time.perf_counter()
+            sync()
+            tot += (tb - ta) + (td - tc)
+        host_ms = round(tot / 2 * 1e3, 3)
+        ahead.clear()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -676,6 +703,7 @@ def run(args, rank, world, dev, make_reducer):
         frames = world * args.frames_per_gpu * args.steps
         res = {'metric': spec['metric'], 'value': round(frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+               'step_ms': step_ms, 'host_ms_per_step': host_ms,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': {'f32': 'f32',
                          'f32x6': 'f32 (storage, accumulation, norms, reductions, filter gradients: fp32; the sparse convolutions\' '
@@ -699,4 +727,5 @@ def run(args, rank, world, dev, make_reducer):
             res['precision_f32x3'] = x3
         if mfma_leg is not None:
             res['precision_f32_mfma'] = mfma_leg
-        print(json.dumps(res))
+        print(json.dumps(res), file=line_out)
+        line_out.flush()

@@ -349,6 +349,28 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+FP16_MESSAGE = ("sst_amd: float16 {what} - this library has no fp16 path.  The reference's half-precision training "
+                "(`fp16 = dict(loss_scale=32.0)`, mmcv wrap_fp16_model / Fp16OptimizerHook: sst_waymoD5_1x_3class_8heads_v2.py:82) "
+                "corresponds here to bf16 storage with fp32 master weights and no loss scaling: leave the model in fp32, do not wrap "
+                "it, and call `backbone.set_precision('bf16')` (INTEGRATION.md section A.1)")
+
+
+def refuse_fp16(module=None, *tensors, what=None):
+    """The fp16 / auto_fp16 contract (sst_basic_block_v2.py:104, sst_input_layer_v2.py:79, voxel_encoder.py:229): a model that
+    went through mmcv's ``wrap_fp16_model`` has half parameters, and its decorated forwards would hand half tensors on.  Instead
+    of failing somewhere inside a kernel wrapper with a dtype message, the entry modules say what to do (loudly, before any
+    launch)."""
+    import torch
+    if module is not None:
+        for p in module.parameters():
+            if p.dtype == torch.float16:
+                raise RuntimeError(FP16_MESSAGE.format(what=what or f'parameters in {type(module).__name__}'))
+            break     # wrap_fp16_model converts all of them: the first one tells
+    for t in tensors:
+        if t is not None and torch.is_tensor(t) and t.dtype == torch.float16:
+            raise RuntimeError(FP16_MESSAGE.format(what=what or 'input tensor'))
+
+
 def require_cuda(*tensors):
     """CHECK_INPUT of the reference (scatter_points_cuda.cu:9-15): device + contiguous, else RuntimeError."""
     for t in tensors:

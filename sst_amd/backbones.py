@@ -266,6 +266,7 @@ class SSTv2(_WindowTransformer):
 
     def forward_voxels(self, voxel_info):
         """the shift blocks only: [M', C] features of the kept voxels (what ``forward`` returns with ``to_bev=False``)"""
+        _lib.refuse_fp16(self, voxel_info['voxel_feats'])
         plans, pos, masks = self._window_inputs(voxel_info)
         lookup = None
         if 'pos_table' in voxel_info and 'pos_index_shift0' in voxel_info:   # (table, row index) per partition
@@ -334,6 +335,7 @@ class SSTv1(_WindowTransformer):
 
     def forward(self, input_tuple):
         voxel_feat, ind_dict_list, voxel_info = input_tuple
+        _lib.refuse_fp16(self, voxel_feat)
         assert voxel_info['coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'
         self.set_drop_info()
         plans, pos = [], []
@@ -372,6 +374,7 @@ class SIR(nn.Module):
 
     def forward(self, points, features, coors, f_cluster=None):
         """-> (point features of the last block, per-cluster features of all blocks side by side, cluster coordinates)."""
+        _lib.refuse_fp16(self, features)
         grouping = dict(new_coors_once=None, unq_inv_once=None)
         if self.unique_once:   # one sorted-unique of the cluster ids for the whole stack (its CSR rides on unq_inv)
             grouping['new_coors_once'], grouping['unq_inv_once'] = unique_with_plan(coors)

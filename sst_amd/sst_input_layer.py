@@ -179,6 +179,8 @@ class SSTInputLayerV2(nn.Module):
             voxel_info: dict, same keys as the reference (sst_input_layer_v2.py:99-126) plus
                         'sra_plan_shift{i}', 'pos_embed_shift{i}'.
         '''
+        from . import _lib
+        _lib.refuse_fp16(None, voxel_feats)
         return self.apply_plan(self.build_plan(voxel_coors, batch_size, voxel_feats.size(1), voxel_feats.dtype),
                                voxel_feats)
 

@@ -22,9 +22,16 @@ def avg(path, counter, pat):
             if r['Counter_Name'] == counter and re.search(pat, r['Kernel_Name'])]
     return sum(vals) / len(vals), len(vals)
 res = {}
-for kern in ('sra_fwd_wave_k', 'sra_bwd_fused_k', 'sra_fwd_bf16_k', 'sra_bwd_bf16_k'):
-    f, nf = avg(out + '/fetch_counter_collection.csv', 'FETCH_SIZE', kern)
-    w, nw = avg(out + '/write_counter_collection.csv', 'WRITE_SIZE', kern)
+# the fp32 kernels exist in two variants since round 5: <.., false> standard attention, <.., true> scaled cosine attention
+pats = {'sra_fwd_wave_k': r'sra_fwd_wave_k<\d+, false>', 'sra_bwd_fused_k': r'sra_bwd_fused_k<\d+, \d+, false>',
+        'sra_fwd_wave_k_cosine': r'sra_fwd_wave_k<\d+, true>', 'sra_bwd_fused_k_cosine': r'sra_bwd_fused_k<\d+, \d+, true>',
+        'sra_fwd_bf16_k': 'sra_fwd_bf16_k', 'sra_bwd_bf16_k': 'sra_bwd_bf16_k'}
+for kern, pat in pats.items():
+    try:
+        f, nf = avg(out + '/fetch_counter_collection.csv', 'FETCH_SIZE', pat)
+        w, nw = avg(out + '/write_counter_collection.csv', 'WRITE_SIZE', pat)
+    except ZeroDivisionError:
+        continue
     res[kern] = {'FETCH_SIZE_KB_raw': f, 'WRITE_SIZE_KB_raw': w, 'launches_averaged': nf,
                  'hbm_read_bytes': 2 * f * 1024, 'hbm_write_bytes': w * 1024,
                  'hbm_bytes_per_launch': 2 * f * 1024 + w * 1024,

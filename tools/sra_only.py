@@ -26,6 +26,12 @@ q, k, v = qkv[:, :128], qkv[:, 128:256], qkv[:, 256:]
 for _ in range(iters):
     o, lse = K._sra_fwd(q, k, v, plan, 8, 0.25, 0)
     K._sra_bwd(q, k, v, o, lse, do, plan, 8, 0.25, 0, dqkv[:, :128], dqkv[:, 128:256], dqkv[:, 256:])
+# scaled cosine attention inside the same kernels (normalisation in the load prologue, per-head 1 / clamp(tau) from device memory)
+hs = torch.full((8,), 4.0, device=mb.DEV)
+if K.cosine_kernels_ok(plan, 8):
+    for _ in range(iters):
+        oc, lsec = K._sra_cos_fwd(q, k, v, plan, 8, hs)
+        K._sra_cos_bwd(q, k, v, oc, lsec, do, plan, 8, hs, dqkv[:, :128], dqkv[:, 128:256], dqkv[:, 256:])
 # the reduced-precision kernels on the same plan (bf16 storage)
 from sst_amd import bf16  # noqa: E402
 qb, kb, vb, dob = (t.to(torch.bfloat16).contiguous() for t in (q, k, v, do))
