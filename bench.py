@@ -591,6 +591,8 @@ def parse_args():
                          'that frame; the line then names it in config.workload and is not the headline)')
     ap.add_argument('--no-lidar-leg', action='store_true', help='skip the LiDAR-like / pathological frame beside the headline')
     ap.add_argument('--no-bf16-leg', action='store_true', help='skip the reduced-precision (bf16) measurement')
+    ap.add_argument('--no-std-attention-leg', action='store_true',
+                    help='--workload sst_center: skip the same config with standard attention beside it')
     ap.add_argument('--no-bf16-own-process', action='store_true',
                     help='do not repeat the reduced-precision leg as the main loop of a process of its own')
     ap.add_argument('--matmul', default='f32x6', choices=('f32', 'f32x6'),
@@ -872,7 +874,7 @@ def _main(args, line_out):
     # --workload sst_center: the same config with standard attention (layer_cfg cosine off), same frames, same loop: what the
     # normalisation + per-head temperature inside the kernels cost per encoder layer
     std_leg = None
-    if args.workload == 'sst_center' and not args.fwd_only and world == 1:
+    if args.workload == 'sst_center' and not args.fwd_only and world == 1 and not args.no_std_attention_leg:
         import copy
         fresh_allocator()
         std_cfg = copy.deepcopy(center_cfg)

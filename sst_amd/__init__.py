@@ -31,12 +31,13 @@ from .sparse_unet import (SimpleSparseUNet, SparseBasicBlock, SparseUNet, Virtua
 from .virtual_voxel import VirtualVoxelExtractor  # noqa: F401
 from . import detectors  # noqa: F401
 from .detectors import (DETECTORS, HEADS, NECKS, FSD, FSDV2, DynamicCenterPoint, DynamicVoxelNet, SingleStageFSD, SingleStageFSDV2, VoteSegHead,  # noqa: F401
-                        VoteSegmentor, Voxel2PointScatterNeck, build_detector, build_head, build_model, build_neck)
+                        VoteSegmentor, Voxel2PointScatterNeck, build_detector, build_head, build_model, build_neck,
+                        install_fused_extract_feat)
 
 __version__ = '0.1.0'
 
 __all__ = [
-    'VirtualVoxelExtractor', 'detectors', 'DynamicVoxelNet', 'DynamicCenterPoint', 'DETECTORS', 'HEADS', 'NECKS', 'FSD', 'FSDV2', 'SingleStageFSD', 'SingleStageFSDV2',
+    'VirtualVoxelExtractor', 'detectors', 'DynamicVoxelNet', 'DynamicCenterPoint', 'install_fused_extract_feat', 'DETECTORS', 'HEADS', 'NECKS', 'FSD', 'FSDV2', 'SingleStageFSD', 'SingleStageFSDV2',
     'VoteSegHead', 'VoteSegmentor', 'Voxel2PointScatterNeck', 'build_detector', 'build_head', 'build_model', 'build_neck',
     'Voxelization', 'voxelization', 'DynamicScatter', 'dynamic_scatter', 'dynamic_voxelize',
     'dynamic_point_to_voxel_forward', 'build_scatter_plan', 'flat2window', 'window2flat', 'get_flat2win_inds',

@@ -267,16 +267,19 @@ class DynamicVoxelNet(nn.Module):
         return self.voxel_layer.voxelize_batch(points)
 
     def _frame_planner(self, batch_size):
+        # (written against `self` = ANY detector object with voxel_layer / voxel_encoder / middle_encoder sub-modules: the
+        # reference's own DynamicVoxelNet instance after install_fused_extract_feat(), whose class never set these attributes)
         from .frame_plan import FramePlanner
         from .sst_input_layer import SSTInputLayerV2
         from .voxel_encoder import DynamicVFE
-        if not self.fused_index:
+        if not getattr(self, 'fused_index', True):
             return None
-        if self._planner is None:
+        planner = self.__dict__.get('_planner')
+        if planner is None:
             ok = (type(self.voxel_encoder) is DynamicVFE and type(self.middle_encoder) is SSTInputLayerV2
-                  and hasattr(self.voxel_encoder, '_grid_zyx'))
-            self._planner = FramePlanner(self.voxel_layer, self.voxel_encoder, self.middle_encoder) if ok else False
-        planner = self._planner
+                  and isinstance(self.voxel_layer, Voxelization) and hasattr(self.voxel_encoder, '_grid_zyx'))
+            planner = FramePlanner(self.voxel_layer, self.voxel_encoder, self.middle_encoder) if ok else False
+            self.__dict__['_planner'] = planner
         return planner if (planner and planner.supported(batch_size)) else None
 
     def prepare(self, points):
@@ -285,16 +288,16 @@ class DynamicVoxelNet(nn.Module):
         piecewise path itself)"""
         if len(points) == 0 or not all(p.is_cuda for p in points):
             return None
-        planner = self._frame_planner(len(points))
+        planner = DynamicVoxelNet._frame_planner(self, len(points))
         return planner.build(points) if planner is not None else None
 
     def voxel_info(self, points, prepared=None):
         """everything in front of the backbone: -> the ``voxel_info`` dictionary SSTInputLayerV2 returns"""
-        plan = prepared if prepared is not None else self.prepare(points)
+        plan = prepared if prepared is not None else DynamicVoxelNet.prepare(self, points)
         if plan is not None:     # the voxel encoder is queued before the plan's sizes are read (FramePlan.finalize)
             voxel_features, _ = self.voxel_encoder(plan.points, plan.coors, scatter_plan=plan)
             return plan.finalize(voxel_features, self.middle_encoder)
-        voxels, coors = self.voxelize(points)
+        voxels, coors = self.voxelize(points)          # the detector's own voxelize(): the reference's per-sample loop works too
         voxel_features, feature_coors = self.voxel_encoder(voxels, coors)
         return self.middle_encoder(voxel_features, feature_coors, len(points))
 
@@ -319,6 +322,26 @@ class DynamicVoxelNet(nn.Module):
 @DETECTORS.register_module()
 class DynamicCenterPoint(DynamicVoxelNet):
     """dynamic_voxelnet.py:73-110: same feature path, CenterHead on top (not built)"""
+
+
+def install_fused_extract_feat(detector_cls):
+    """Reference-side hook: give the REFERENCE's own detector class - mmdet3d's DynamicVoxelNet /
+    DynamicCenterPoint, which keeps its neck, heads, losses and test-time code - the ``extract_feat`` of this module: same
+    semantics as detectors/dynamic_voxelnet.py:38-47 (voxelize -> voxel_encoder -> middle_encoder(.., batch_size) -> backbone
+    -> neck), with the three index stages as ONE device-side plan when the sub-modules are this library's.
+
+        from mmdet3d.models.detectors import DynamicVoxelNet, DynamicCenterPoint
+        sst_amd.detectors.install_fused_extract_feat(DynamicVoxelNet)        # DynamicCenterPoint inherits it
+    """
+    def extract_feat(self, points, img_metas=None):
+        x = self.backbone(DynamicVoxelNet.voxel_info(self, points))
+        if getattr(self, 'with_neck', False):
+            x = self.neck(x)
+        return x
+
+    extract_feat.__doc__ = 'Extract features from points (sst_amd: fused index plan in front of the backbone).'
+    detector_cls.extract_feat = extract_feat
+    return detector_cls
 
 
 class _HotPathDetector(nn.Module):

@@ -68,3 +68,35 @@ def test_voxel_info_defers_the_reference_entries():
     with pytest.raises(KeyError):
         info['missing']
     assert sorted(info.keys()) == ['flat2win_inds_shift0', 'key_mask_shift0', 'voxel_feats']
+
+
+class _ReferenceLikeDetector(torch.nn.Module):
+    """what the reference's DynamicVoxelNet instance looks like after the registry swap of INTEGRATION.md section A: the four
+    sub-modules are this library's, the class itself (voxelize loop, neck, heads) is the reference's"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        import sst_amd
+        self.voxel_layer = sst_amd.Voxelization(**cfg['voxel_layer'])
+        self.voxel_encoder = sst_amd.build_voxel_encoder(cfg['voxel_encoder'])
+        self.middle_encoder = sst_amd.build_middle_encoder(cfg['middle_encoder'])
+        self.backbone = sst_amd.build_backbone(cfg['backbone'])
+        self.neck, self.with_neck = torch.nn.Identity(), True
+
+    @torch.no_grad()
+    def voxelize(self, points):            # dynamic_voxelnet.py:49-71, verbatim semantics: per-sample loop, pad, concatenate
+        coors = [torch.nn.functional.pad(self.voxel_layer(p), (1, 0), mode='constant', value=i) for i, p in enumerate(points)]
+        return torch.cat(points, dim=0), torch.cat(coors, dim=0)
+
+
+def test_install_fused_extract_feat_on_a_reference_like_class():
+    import sst_amd
+    cfg = load_fixture(FIXTURES[0])
+    cls = sst_amd.install_fused_extract_feat(type('Det', (_ReferenceLikeDetector,), {}))
+    det = cls(cfg)
+    assert 'fused index plan' in cls.extract_feat.__doc__
+    planner = sst_amd.DynamicVoxelNet._frame_planner(det, 1)
+    assert planner is not None and det.__dict__['_planner'] is planner and planner.supported(2) and not planner.supported(65)
+    det.fused_index = False
+    assert sst_amd.DynamicVoxelNet._frame_planner(det, 1) is None
+    assert sst_amd.DynamicVoxelNet.prepare(det, [torch.zeros(5, 3)]) is None         # CPU clouds: the piecewise path

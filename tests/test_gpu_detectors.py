@@ -97,3 +97,34 @@ def test_fsdv2_detector_hot_path_forward_backward():
                  'segmentor.backbone.upsample_layer4.0.weight', 'segmentor.voxel_encoder.vfe_layers.0.linear.weight',
                  'backbone.conv_out.0.weight'):
         assert grads[name] is not None and torch.isfinite(grads[name]).all() and float(grads[name].abs().max()) > 0, name
+
+
+def test_reference_detector_with_the_fused_extract_feat_hook():
+    """the reference's own DynamicVoxelNet class (its voxelize loop, its neck) over this library's
+    sub-modules, with `install_fused_extract_feat`: same features as sst_amd.DynamicVoxelNet built from the same shipped config,
+    and as the piecewise (module by module) path"""
+    import bench
+    import sst_amd
+    from test_config_fixtures import _ReferenceLikeDetector
+    cfg = bench.load_config_fixture('sst_waymoD5_1x_3class_8heads_v2')
+    cfg['middle_encoder'] = dict(cfg['middle_encoder'], shuffle_voxels=False, window_major=True)   # deterministic voxel order
+    cfg['backbone'] = dict(cfg['backbone'], to_bev=False, num_attached_conv=0)
+    frames = [bench.make_cloud(30000, 3, 'cuda:0'), bench.make_cloud(20000, 4, 'cuda:0')]
+    torch.manual_seed(0)
+    a = sst_amd.build_detector(cfg).to('cuda:0').train()
+    cls = sst_amd.install_fused_extract_feat(type('Det', (_ReferenceLikeDetector,), {}))
+    torch.manual_seed(0)
+    b = cls(cfg).to('cuda:0').train()
+    b.load_state_dict(a.state_dict(), strict=True)
+    a.middle_encoder.mute = b.middle_encoder.mute = True
+    outs = []
+    for det, fused in ((a, True), (b, True), (b, False)):
+        det.fused_index = fused
+        with torch.no_grad():
+            x = det.extract_feat(frames, None)[0]
+        outs.append((x['voxel_coors'], x['voxel_feats']))
+    assert b.__dict__['_planner'] is not None and b.__dict__['_planner'] is not False
+    for coors, feats in outs[1:]:
+        assert torch.equal(coors, outs[0][0])
+        assert float((feats - outs[0][1]).abs().max()) <= 1e-5
+    assert torch.equal(outs[1][1], outs[0][1])

@@ -420,3 +420,36 @@ def test_window_ordered_rows_need_no_token_list(cap):
         outs.append((o, lse, dqkv))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_d_model_192_twelve_heads_against_float64(fused):
+    """configs/sst/sst_waymoD5_1x_3class_12heads.py:56-80 (d_model 192, 12 heads, feed-forward 384): the attention kernels take any
+    multiple of four heads of width 16; the projections of that width run on the library / LDS-resident fp32 kernels.  Forward of
+    one shift block against the float64 restatement (oracle/sst_oracle.encoder_layer), and its gradients finite."""
+    import sst_amd
+    from oracle import sst_oracle
+    torch.manual_seed(4)
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[192], nhead=[12], num_blocks=1, dim_feedforward=[384],
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=False)).to(DEV).train()
+    net.set_fused(fused)
+    g = torch.Generator().manual_seed(5)
+    side, n = 80, 2600
+    cells = torch.randperm(side * side, generator=g)[:n].sort()[0]
+    coors = torch.stack([torch.zeros_like(cells), torch.zeros_like(cells), cells // side + 30, cells % side + 30], 1).to(DEV)
+    feats = torch.randn(n, 192, generator=g).to(DEV).requires_grad_(True)
+    layer = sst_amd.SSTInputLayerV2((DROP_TEST, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False, debug=False,
+                                    mute=True).eval()
+    info = layer(feats, coors, 1)
+    out = net(info)[0]['voxel_feats']
+    x = info['voxel_feats'].detach().double().cpu().numpy()
+    for li, enc in enumerate(net.block_list[0].encoder_list):
+        plan = info[f'sra_plan_shift{li}']
+        pos = info[f'pos_embed_shift{li}'].double().cpu().numpy()
+        params = {k: v.detach().double().cpu().numpy() for k, v in enc.state_dict().items()}
+        x = sst_oracle.encoder_layer(x, pos, plan.tok.cpu().numpy(), plan.winoff[:plan.n_windows + 1].cpu().numpy(), params, 12)
+    err = float(np.abs(out.detach().double().cpu().numpy() - x).max())
+    assert err < 2e-5, err
+    out.square().sum().backward()
+    assert torch.isfinite(feats.grad).all() and float(feats.grad.abs().max()) > 0
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-5 evidence set (GPU box): the bench line with all its legs (config_as_is, reduced precision in and out of process),
+# the shipped cosine-attention config (--workload sst_center) beside its standard-attention twin, the other workloads, rocprofv3
+# kernel statistics + steady-state reports of the same commands without the side legs, SRA traffic (PMC passes) of the standard,
+# cosine and bf16 kernels.
+# Usage: bash tools/collect_r05.sh <tag>   -> gpurun_out/<tag>/   (copy into profiles/r05/)
+TAG=${1:-r05/a}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --workload sst_center > $OUT/bench_workload_sst_center.json 2> $OUT/bench_center.err
+python bench.py --workload sst_bs2 --no-cpu-baseline > $OUT/bench_workload_sst_bs2.json 2> /dev/null
+python bench.py --workload sst_bev > $OUT/bench_workload_sst_bev.json 2> /dev/null
+python bench.py --cloud lidar --no-bf16-leg --no-f32x3-leg --no-forward-only-leg --no-traffic-remeasure > $OUT/bench_cloud_lidar.json 2> /dev/null
+if [ "$2" != "nofsd" ]; then
+  python bench.py --workload fsd > $OUT/bench_workload_fsd.json 2> $OUT/bench_fsd.err
+  python bench.py --workload fsdv2 > $OUT/bench_workload_fsdv2.json 2> $OUT/bench_fsdv2.err
+fi
+cd /tmp && export TMPDIR=/tmp
+prof() {  # name, command...
+  local name=$1; shift
+  rm -rf /tmp/pp_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_$name -o p -- "$@" > $OUT/${name}_under_rocprof.log 2>&1
+  cp /tmp/pp_$name/p_kernel_stats.csv $OUT/${name}_kernel_stats.csv
+  python $R/tools/gap_report.py /tmp/pp_$name/p_kernel_trace.csv 0.65 70 > $OUT/${name}_steady_state_trace_report.txt 2>&1
+}
+SIDE="--no-cpu-baseline --no-forward-only-leg --no-lidar-leg --no-f32x3-leg --no-traffic-remeasure --no-config-as-is-leg --no-bf16-own-process"
+prof sst python $R/bench.py --steps 16 --warmup 6 $SIDE --no-bf16-leg
+python $R/tools/front_of_step.py /tmp/pp_sst/p_kernel_trace.csv > $OUT/sst_front_of_step.txt 2>&1
+prof sst_bf16 python $R/bench.py --precision bf16 --steps 16 --warmup 6 $SIDE
+prof sst_center python $R/bench.py --workload sst_center --steps 16 --warmup 6 --no-forward-only-leg --no-traffic-remeasure --no-std-attention-leg
+prof sst_lidar python $R/bench.py --cloud lidar --steps 16 --warmup 6 $SIDE --no-bf16-leg
+cd $R
+bash tools/collect_sra_traffic.sh gpurun_out/$TAG/traffic > $OUT/traffic.log 2>&1
+ls -la $OUT | head -60
