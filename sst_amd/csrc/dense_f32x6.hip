@@ -271,7 +271,9 @@ __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
     *(f32x4*)(Y + row * ldy + n0 + 4) = v1;
   };
 
-  constexpr bool PREFETCH = K <= 128;   // K = 256: no room for a second X tile beside three weight fragment sets
+  // the next X tile is requested before this one is multiplied while a second tile fits the 256 VGPRs a wave has here (two waves
+  // per SIMD: the three weight images leave LDS for one workgroup per CU): K <= 256 (K = 256: 160 + 64 registers; K = 384 is at 248)
+  constexpr bool PREFETCH = K <= 256;
   for (; r0 < r1; r0 += 16) {
     asm volatile("" ::: "memory");  // W fragments are re-read from LDS per row tile (never hoisted into registers)
     const bool more = r0 + 16 < r1;

@@ -99,6 +99,7 @@ def test_fsdv2_detector_hot_path_forward_backward():
         assert grads[name] is not None and torch.isfinite(grads[name]).all() and float(grads[name].abs().max()) > 0, name
 
 
+@pytest.mark.gpu
 def test_reference_detector_with_the_fused_extract_feat_hook():
     """the reference's own DynamicVoxelNet class (its voxelize loop, its neck) over this library's
     sub-modules, with `install_fused_extract_feat`: same features as sst_amd.DynamicVoxelNet built from the same shipped config,
