@@ -163,6 +163,11 @@ class GcWatch(object):
 GC_WATCH = None
 
 
+def note(msg):
+    """progress marker on stderr (the line itself goes to stdout): which leg a run was in when something went wrong"""
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
 class StepTimes(object):
     """Per-step durations of a timed loop WITHOUT synchronising inside it: one event recorded on the stream behind every step,
     the differences read after the loop's final synchronisation (device-side time between the ends of consecutive steps).  The
@@ -772,8 +777,10 @@ def _main(args, line_out):
             reducer.finish()
         return out
 
+    note(f'warm-up: {args.warmup} steps')
     for _ in range(args.warmup):
         out = step()
+    note('timed loop')
     # What a training script does once its model and data pipeline are built: collect, then move everything alive to the permanent
     # generation.  A full collection of a process that has imported torch walks ~10^6 objects (60-70 ms, measured: one step of
     # 71 ms among twenty of 6.5 ms in the reduced-precision leg; none with the collector off); frozen objects are not walked, the
@@ -849,7 +856,9 @@ def _main(args, line_out):
     # Outside the timed region: the forward-only rate of the same workload (BASELINE.json configs[1] is quoted
     # forward-only, the metric forward + backward; `value` is the harder one, this is reported beside it).
     fwd_only = None
+    note('main loop done; side legs')
     if not args.fwd_only and not args.no_forward_only_leg:
+        note('leg: forward only')
         with torch.no_grad():
             for _ in range(2):
                 model(frames)
@@ -914,6 +923,7 @@ def _main(args, line_out):
     if (world == 1 and not args.fwd_only and not args.no_config_as_is_leg and args.workload == 'sst' and args.cloud == 'uniform'
             and args.blocks == 6 and args.precision == 'f32'):
         fresh_allocator()
+        note('leg: config_as_is')
         as_is = config_as_is_leg(args, dev, frames, sync)
         as_is['vs_value'] = None     # filled in below
 
@@ -925,6 +935,7 @@ def _main(args, line_out):
     # fp16 training of these layers (configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82) corresponds to here.
     bf16_leg = None
     if not args.fwd_only and not args.no_bf16_leg:
+        note('leg: reduced precision (bf16)')
         fresh_allocator()
         with torch.no_grad():
             ref_out, ref_key = gpu_forward_sorted(model, frames)
@@ -992,6 +1003,7 @@ def _main(args, line_out):
         # meanwhile): if the two disagree, state inherited from the legs in front of it is the cause, if they agree and the
         # driver's box still differs from the builder's, it is the box.  Both are in the line.
         if world == 1 and not args.no_bf16_own_process:
+            note('leg: reduced precision, own process')
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--precision', 'bf16', '--steps', str(args.steps), '--warmup',
                    str(max(3, args.warmup)), '--points', str(args.points), '--blocks', str(args.blocks), '--no-cpu-baseline',
@@ -1008,6 +1020,7 @@ def _main(args, line_out):
     # Beside the headline (uniform cloud): the same step on a LiDAR-like frame with out-of-range points and duplicates
     lidar_leg = None
     if not args.fwd_only and not args.no_lidar_leg:
+        note('leg: LiDAR-like cloud')
         fresh_allocator()
         lframes = [make_lidar_cloud(2000 * rank + i, dev) for i in range(args.frames_per_gpu)]
 
@@ -1062,6 +1075,7 @@ def _main(args, line_out):
     def matmul_leg(mode, dtype, what):
         """the same step with the dense products of the encoder layers in another multiply mode (sst_amd/dense.py), beside
         `value`: W warm-up steps, K timed; its forward output against the timed mode's on the same frame"""
+        note(f'leg: matmul mode {mode}')
         fresh_allocator()
         with torch.no_grad():
             ref_out, ref_key = gpu_forward_sorted(model, frames)
@@ -1230,6 +1244,7 @@ def _main(args, line_out):
         if bf16_leg is not None:
             res['reduced_precision'] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
+            note('leg: cpu_baseline + parity')
             res['cpu_baseline'], res['parity'] = cpu_reference_leg(model, frames[0].cpu(), args.blocks)
         else:
             res['cpu_baseline'] = None

@@ -56,6 +56,21 @@ class FramePlan(object):
     def voxel_coors(self):
         return self.vcoors
 
+    def _release_count_slot(self):
+        """hand the pinned size words back to the planner's free list (their values have been read, or nobody will)"""
+        home, slot = self.__dict__.pop('_slot_home', None), (self.__dict__.pop('h_counts', None), self.__dict__.pop('counts_ready', None))
+        if home is not None and slot[0] is not None and len(home) < 64:
+            home.append(slot)
+
+    def __del__(self):
+        try:
+            if '_slot_home' in self.__dict__:
+                # unread plan (built ahead and dropped): its copy may still be in flight - wait for it before the words are reused
+                self.counts_ready.synchronize()
+                self._release_count_slot()
+        except Exception:
+            pass
+
     # -----------------------------------------------------------------------------------------------------------
     def finalize(self, voxel_feats, input_layer, feat_dim=None):
         """Read the sizes (the only host synchronisation of the plan) and return the ``voxel_info`` dictionary the
@@ -66,6 +81,7 @@ class FramePlan(object):
         # the previous step's backward pass - nothing at all)
         self.counts_ready.synchronize()
         counts = self.h_counts.tolist()
+        self._release_count_slot()
         m, m_keep, n_win, t_max = counts[0], counts[1], (counts[2], counts[3]), (counts[4], counts[5])
         self.num_voxels, self.num_kept = m, m_keep
         dev = voxel_feats.device
@@ -191,25 +207,22 @@ class FramePlanner(object):
                                      _lib.ptr(plan.winoff0), _lib.ptr(plan.winoff1), _lib.ptr(plan.posidx0),
                                      _lib.ptr(plan.posidx1), _lib.ptr(plan.d_counts), _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, 'sst_window_plan_i32')
-        # the sizes travel to PINNED host memory behind the plan's kernels.  The pinned words come from a ring the planner owns
-        # (16 slots, an event per slot): allocating them per plan went through the pinned-memory cache, which now and then had no
-        # free block and called hipHostMalloc - a 40-55 ms host stall in ONE step of a run (bench.py's reduced-precision leg:
-        # 129 instead of 160 frames/s with one such step among twenty; profiles/r05)
-        plan.h_counts, plan.counts_ready = self._count_slot()
+        # the sizes travel to PINNED host memory behind the plan's kernels.  The pinned words (and the event that says they have
+        # arrived) come from a free list the planner owns: a plan takes a slot here and hands it back when finalize() has read it
+        # (or when the plan dies unread) - in steady state nothing is allocated.  Allocating them per plan went through the
+        # pinned-memory cache, which now and then had no free block and called hipHostMalloc: a 40-55 ms host stall in ONE step
+        # of a run (bench.py's reduced-precision leg: 129 instead of 160 frames/s with one such step among twenty; profiles/r05).
+        # A slot belongs to ONE plan until that plan gives it up: a plan built ahead may wait arbitrarily long for its finalize()
+        # (a first version recycled slots round-robin after 16 builds and handed a waiting plan the sizes of another frame).
+        plan._slot_home = self._free_count_slots()
+        plan.h_counts, plan.counts_ready = plan._slot_home.pop() if plan._slot_home else (
+            torch.empty(8, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
         plan.h_counts.copy_(plan.d_counts, non_blocking=True)
         plan.counts_ready.record()
         return plan
 
-    def _count_slot(self):
-        ring = self.__dict__.get('_count_ring')
-        if ring is None:
-            ring = self._count_ring = {'host': torch.empty((16, 8), dtype=torch.int32, pin_memory=True),
-                                       'events': [None] * 16, 'next': 0}
-        i = ring['next']
-        ring['next'] = (i + 1) % 16
-        ev = ring['events'][i]
-        if ev is None:
-            ev = ring['events'][i] = torch.cuda.Event()
-        else:
-            ev.synchronize()      # the copy of the plan that used this slot 16 plans ago: long done (a plan is read once, at finalize)
-        return ring['host'][i], ev
+    def _free_count_slots(self):
+        slots = self.__dict__.get('_count_slots')
+        if slots is None:
+            slots = self._count_slots = []
+        return slots

@@ -173,3 +173,23 @@ def test_a_steps_index_plan_dies_with_the_step_without_the_cyclic_collector():
         assert torch.cuda.memory_allocated() < before
     finally:
         gc.enable()
+
+
+def test_a_plan_built_ahead_keeps_its_own_sizes_however_long_it_waits():
+    """the pinned size words of a plan belong to it until finalize() has read them: a plan built ahead (bench.py keeps one across
+    its legs) and finalized after MANY other plans were built must still describe its own frame.  (Round 5: a first version of
+    the pinned free list recycled slots round-robin after 16 builds - a plan that waited got another frame's sizes and the
+    attention kernels read out of bounds.)"""
+    import bench
+    torch.manual_seed(0)
+    model = bench.Pipeline(1).to(DEV).train()
+    big = [bench.make_cloud(40000, 5, DEV)]
+    small = [bench.make_cloud(3000, 6, DEV)]
+    with torch.no_grad():
+        want = model(big).size(0)
+        waiting = model.prepare(big)
+        for _ in range(40):
+            assert model(small).size(0) < want
+        out = model(big, waiting)
+    assert out.size(0) == want
+    assert len(model._planner._count_slots) <= 4, 'slots are handed back: the free list stays small'
