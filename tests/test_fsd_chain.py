@@ -48,13 +48,26 @@ def _check_against_golden(tag, net, g, dev, feat_tol, grad_tol):
     params = dict(net.named_parameters())
     grad_keys = [k[6:] for k in g if k.startswith('grad::')]
     assert len(grad_keys) >= 8
+    report = {}
     for key in grad_keys:
         # against the float64 evaluation stored beside the reference's fp32 gradient; the bar is the tolerance or the
         # reference's own fp32 deviation from float64 on that parameter, whichever is larger
         ref32, exact = g['grad::' + key].astype(np.float64), g['grad64::' + key]
         scale = max(1.0, float(np.abs(exact).max()))
         err = float(np.abs(params[key].grad.cpu().numpy().astype(np.float64) - exact).max())
-        assert err <= max(grad_tol * scale, 4.0 * float(np.abs(ref32 - exact).max())), (key, err / scale)
+        noise_ref = float(np.abs(ref32 - exact).max())
+        report[key] = (err / scale, noise_ref / scale)
+        # per parameter: a parameter the reference's own fp32 backward holds to 2.5e-4 of float64 is not
+        # decision-sensitive on this fixture - it keeps the 1e-3 bar whatever `grad_tol` says; the looser floor is for the
+        # parameters that are already noisy in the reference's fp32 evaluation
+        floor = min(grad_tol, 1e-3) if noise_ref <= 2.5e-4 * scale else grad_tol
+        assert err <= max(floor * scale, 4.0 * noise_ref), (key, err / scale, noise_ref / scale)
+    import json
+    import os
+    log_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(log_dir) and dev != 'cpu':
+        with open(os.path.join(log_dir, f'chain_grad_errs_{tag}.json'), 'w') as f:
+            json.dump({k: {'err_over_scale': a, 'reference_fp32_noise_over_scale': b} for k, (a, b) in report.items()}, f, indent=1)
 
 
 @pytest.mark.parametrize('tag', ['fsd', 'fsdv2'])
@@ -111,24 +124,30 @@ def test_cpu_port_chain_matches_live_reference(tag, train):
         port64.train(train)
         port64([c.double() for c in clouds])[0].backward()
         theirs, ours, exact = dict(ref.named_parameters()), dict(port.named_parameters()), dict(port64.named_parameters())
-        checked, loose = 0, []
+        checked, report = 0, []
         for name, p in theirs.items():
             if p.grad is None:
                 assert ours[name].grad is None, name
                 continue
             scale = max(1.0, float(p.grad.abs().max()))
-            noise = float((ours[name].grad.double() - exact[name].grad).abs().max())
+            noise_port = float((ours[name].grad.double() - exact[name].grad).abs().max())     # fp32 port vs the exact gradient
+            noise_ref = float((p.grad.double() - exact[name].grad).abs().max())               # fp32 REFERENCE vs the exact gradient
             err = float((p.grad - ours[name].grad).abs().max())
-            # forward outputs agree to 1e-6 (above); for the gradients the float64 run is the adjudicator, and it says the
-            # REFERENCE's fp32 backward is the noisier of the two (naiveSyncBN differentiates var = E[x^2] - mean^2 in fp32:
-            # up to 7e-3 from the float64 gradient at this size, the port's F.batch_norm 1e-3).  A defect of the port would
-            # show as O(scale); rounding shows as a tail of a few 1e-3.
-            assert err <= 2e-2 * scale, (name, err / scale)
-            if err > max(1e-4 * scale, 8.0 * noise):
-                loose.append((name, err / scale))
+            # PER PARAMETER: forward outputs agree to 1e-6 (above); two correct fp32 evaluations of one gradient
+            # differ by at most the sum of their distances from the exact one, and the float64 run measures both distances for
+            # THIS parameter.  The reference is the noisier of the two (naiveSyncBN differentiates var = E[x^2] - mean^2 in fp32:
+            # up to 7e-3 from float64 on the batch-norm-fed parameters, the port's F.batch_norm 1e-3); a defect of the port - a
+            # mis-routed bias or norm gradient - is O(scale) on a parameter whose measured noise is 1e-6..1e-4 and fails here,
+            # where the blanket 2e-2 / "15 % may miss" of round 4 let it pass.  Floor 2e-4 of the gradient's scale.
+            bar = max(2e-4 * scale, 2.0 * (noise_port + noise_ref))
+            report.append((name, err / scale, noise_port / scale, noise_ref / scale))
+            assert err <= bar, (name, err / scale, noise_port / scale, noise_ref / scale)
+            assert err <= 2e-2 * scale, (name, err / scale)        # and never the O(scale) of a wrong formula, whatever the noise
             checked += 1
-        assert checked > 40 and len(loose) <= 0.15 * checked, loose
         assert checked > 40
+        # the well-conditioned half of the parameters is held to the tight bar by construction: say how many there are
+        tight = sum(1 for _, e, a, b in report if 2.0 * (a + b) <= 2e-4)
+        assert tight >= 0.2 * checked, (tight, checked)       # measured: 34 of 149 (FSDv2 chain), more on FSD's
 
 
 @pytest.mark.gpu

@@ -102,9 +102,15 @@ def test_pipeline_matches_cpu_port_of_the_reference_flow(n_points, blocks, fused
     assert flips <= max(8, n_rows // 2000), f'{flips} point rows with a different pooling decision'
     # the fused node keeps no per-point activations to count decisions on (that is its point): its bound is the one a flipped
     # decision gives; its routing is pinned bit for bit by tests/test_gpu_vfe_fused.py::test_fused_stack_routes_gradients_exactly
-    tol = 1e-3 if (flips == 0 and not fused_vfe) else GRAD_TOL_VFE
+    # PER PARAMETER: only the two linear weights sit in front of a max-pooling decision AND only on a frame that
+    # has flipped decisions - counted above on the layer-wise path; the fused node pools the same values, so the frame known to
+    # flip (6 000 points: 2 rows, errors 2.8e-3 / 6.5e-3 measured on both paths) is named.  Everything else - the norm weight
+    # (measured 5e-7 .. 1.4e-6 on every frame and path), both linears on the 30 000-point frame (2.3e-6) - holds the 1e-3 bar.
+    flipping_frame = flips > 0 or (fused_vfe and n_points == 6000)
+    sensitive = {'vfe0.linear', 'vfe1.linear'} if flipping_frame else set()
     for name in ('vfe0.linear', 'vfe1.linear', 'vfe1.norm'):
-        assert errs[name] < tol, f'relative parameter gradient errors {errs} ({flips} flipped pooling decisions)'
+        tol = GRAD_TOL_VFE if name in sensitive else 1e-3
+        assert errs[name] < tol, f'{name}: relative parameter gradient errors {errs} ({flips} flipped pooling decisions)'
 
 
 @pytest.mark.parametrize('fused_index', [True, False])
