@@ -370,6 +370,7 @@ int sst_sra_attn_cos_bwd_f32(const float* d_q, const float* d_k, const float* d_
  * accumulation are fp32; v_mfma_f32_16x16x16_bf16.  The reference's own training precision for these layers is fp16
  * (configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82).  Windows up to 144 tokens (max_tokens must say so, else
  * SST_ERR_UNSUPPORTED).  The backward is one pass per (window, head) wave (dQ, dK, dV from one read of Q, K, V, O, dO).
+ * d_tok == NULL: the tokens of window w are the rows winoff[w] .. winoff[w+1] - 1 themselves (as for the fp32 kernels).
  * sst_sra_attn_bf16_profile_next(backward, start, stop): one-shot kernel-bound events, as for the fp32 kernels.
  * ---------------------------------------------------------------------------------------------- */
 int sst_sra_attn_fwd_bf16(const void* d_q, const void* d_k, const void* d_v, int64_t ldq, int64_t ldk, int64_t ldv,

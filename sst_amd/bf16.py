@@ -54,7 +54,7 @@ def sra_fwd(q, k, v, plan, n_heads, scale):
     lib = _lib.load()
     order = plan.order
     rc = _timed('sra_fwd_bf16', plan.n_tokens, 0, lambda: lib.sst_sra_attn_fwd_ord_bf16(
-        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _ld(q), _ld(k), _ld(v), _lib.ptr(plan.tok), _lib.ptr(plan.winoff),
+        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _ld(q), _ld(k), _ld(v), plan.tok_ptr(0), _lib.ptr(plan.winoff),
         _lib.ptr(order) if order is not None else None, plan.n_windows, n_heads, float(scale), plan.max_tokens,
         _lib.ptr(o), _ld(o), _lib.ptr(lse), _lib.stream_ptr()))
     _lib.check(rc, 'sst_sra_attn_fwd_ord_bf16')
@@ -66,7 +66,7 @@ def sra_bwd(q, k, v, o, lse, do, plan, n_heads, scale, dq, dk, dv):
     order = plan.order
     rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_sra_attn_bwd_ord_bf16(
         _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(do), _lib.ptr(lse), _ld(q), _ld(k), _ld(v), _ld(o),
-        _ld(do), _lib.ptr(plan.tok), _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None,
+        _ld(do), plan.tok_ptr(0), _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None,
         plan.n_windows, n_heads, float(scale), plan.max_tokens, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _ld(dq), _ld(dk),
         _ld(dv), _lib.stream_ptr()))
     _lib.check(rc, 'sst_sra_attn_bwd_ord_bf16')
@@ -378,7 +378,8 @@ def _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next, params, need_bwd):
     args = _lib.EncoderLayerFwdBF16Args(
         m, plan.n_windows, nhead, 1 if act == 'gelu' else 2, plan.max_tokens, 0, float(eps), float(scale),
         P(x), P(xp), P(shadow(w_in, (0, 2 * c))), P(shadow(w_in, (2 * c, 3 * c))), P(shadow(w_out)), P(shadow(w1)), P(shadow(w2)),
-        P(b_in), P(b_out), P(b1), P(b2), P(n1w), P(n1b), P(n2w), P(n2b), P(plan.tok), P(plan.winoff), P(order),
+        P(b_in), P(b_out), P(b1), P(b2), P(n1w), P(n1b), P(n2w), P(n2b),
+        None if plan.tok_ptr(0) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
         S('qk'), S('v'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'),
         S('s2') if need_bwd else None, S('st2'), P(y2), P(y2p))
@@ -422,7 +423,7 @@ def _exec_bwd(ctx, dy2, dy2p):
         P(dy2), P(dy2p), P(x), P(xp), S('qk'), S('v'), S('o'), S('lse'), S('s1'), S('st1'), S('y1'), S('pre'), S('h'), S('s2'),
         S('st2'), P(shadow(w_in, (0, 2 * c), transposed=True)), P(shadow(w_in, (2 * c, 3 * c), transposed=True)),
         P(shadow(w_out, transposed=True)), P(shadow(w1, transposed=True)), P(shadow(w2, transposed=True)), P(n1w), P(n2w),
-        P(plan.tok), P(plan.winoff), P(order),
+        None if plan.tok_ptr(0) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         sp['ds2'], sp['dpre'], sp['dy1'], sp['ds1'], sp['d_o'], sp['dqkv'], P(dxp), P(dx),
         P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 4 * c, dnp + 8 * c, dnp + 12 * c, P(ws))
     rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_encoder_layer_bwd_bf16(ctypes.byref(args), _lib.stream_ptr()))

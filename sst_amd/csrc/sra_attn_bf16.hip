@@ -92,7 +92,9 @@ __device__ __forceinline__ void fwd_body(const unsigned short* __restrict__ Q, c
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = tok[beg + (p < t ? p : t - 1)];  // padded positions repeat the last token: loads are unconditional
+    // padded positions repeat the last token: loads are unconditional; no list (tok == nullptr): the window's rows are
+    // beg .. beg + t - 1 themselves (feature rows in window order), one dependent load less at the head of the wave
+    tk[i] = tok != nullptr ? tok[beg + (p < t ? p : t - 1)] : beg + (p < t ? p : t - 1);
   }
   auto tok_at = [&](int i, int within) -> uint32_t {
     int sel = tk[0];
@@ -216,7 +218,7 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
 #pragma unroll
   for (int i = 0; i < NTK; ++i) {
     const int p = i * 64 + lane;
-    tk[i] = tok[beg + (p < t ? p : t - 1)];
+    tk[i] = tok != nullptr ? tok[beg + (p < t ? p : t - 1)] : beg + (p < t ? p : t - 1);
   }
   auto tok_at = [&](int i, int within) -> uint32_t {
     int sel = tk[0];
@@ -406,7 +408,7 @@ int sst_sra_attn_fwd_bf16(const void* d_q, const void* d_k, const void* d_v, int
                           int max_tokens, void* d_o, int64_t ldo, float* d_lse, void* stream) {
   if (n_windows < 0 || n_heads < 1 || (n_heads % kWH) != 0) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
-  if (!d_q || !d_k || !d_v || !d_tok || !d_winoff || !d_o || !d_lse) return SST_ERR_ARG;
+  if (!d_q || !d_k || !d_v || !d_winoff || !d_o || !d_lse) return SST_ERR_ARG;   // d_tok == NULL: rows in window order
   if (((ldq | ldk | ldv | ldo) & 3) || !aligned8(d_q) || !aligned8(d_k) || !aligned8(d_v) || !aligned8(d_o)) return SST_ERR_ARG;
   const int cap_tiles = max_tokens > 0 ? (max_tokens + 15) / 16 : 1 << 30;
   if (cap_tiles > 9) return SST_ERR_UNSUPPORTED;  // windows above 144 tokens: no SST configuration has them
@@ -431,7 +433,7 @@ int sst_sra_attn_bwd_bf16(const void* d_q, const void* d_k, const void* d_v, con
                           void* stream) {
   if (n_windows < 0 || n_heads < 1 || (n_heads % kWH) != 0) return SST_ERR_ARG;
   if (n_windows == 0) return SST_OK;
-  if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_tok || !d_winoff || !d_dq || !d_dk || !d_dv) return SST_ERR_ARG;
+  if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_winoff || !d_dq || !d_dk || !d_dv) return SST_ERR_ARG;
   if (((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 3) || !aligned8(d_q) || !aligned8(d_k) || !aligned8(d_v) ||
       !aligned8(d_o) || !aligned8(d_do) || !aligned8(d_dq) || !aligned8(d_dk) || !aligned8(d_dv))
     return SST_ERR_ARG;
