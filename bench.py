@@ -1024,18 +1024,14 @@ def _main(args, line_out):
         fresh_allocator()
         lframes = [make_lidar_cloud(2000 * rank + i, dev) for i in range(args.frames_per_gpu)]
 
-        lahead = []     # the next batch's index plan, queued behind this step's backward pass - exactly as in the main loop
-
         def lstep():
             for p in params:
                 p.grad = None
-            o = model(lframes, lahead.pop() if lahead else None)
+            o = model(lframes)
             gg = seed_grad.get(o.shape)
             if gg is None:
                 gg = seed_grad[o.shape] = torch.randn(o.shape, device=o.device, dtype=o.dtype)
             o.backward(gg)
-            if not args.no_plan_prefetch:
-                lahead.append(model.prepare(lframes))
             if reducer is not None:
                 reducer.finish()
             return o
