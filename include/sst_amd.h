@@ -392,6 +392,18 @@ int sst_sra_attn_bwd_ord_bf16(const void* d_q, const void* d_k, const void* d_v,
                               const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
                               int n_heads, float scale, int max_tokens, void* d_dq, void* d_dk, void* d_dv, int64_t lddq,
                               int64_t lddk, int64_t lddv, void* stream);
+/* scaled cosine attention (cosine_msa.py:123-185) with bf16 storage: as sst_sra_attn_cos_{fwd,bwd}_f32 - normalisation in the
+ * load prologue (the normalised rows rounded to bf16 before the products), d_head_scale [n_heads] fp32 in device memory =
+ * 1 / clamp(tau, tau_min), gradients through the normalisation at the store, d_r [n_tokens, n_heads] fp32 = q^ . dq^ */
+int sst_sra_attn_cos_fwd_bf16(const void* d_q, const void* d_k, const void* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, const float* d_head_scale, int max_tokens, void* d_o, int64_t ldo, float* d_lse,
+                              void* stream);
+int sst_sra_attn_cos_bwd_bf16(const void* d_q, const void* d_k, const void* d_v, const void* d_o, const void* d_do,
+                              const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, const float* d_head_scale, int max_tokens, void* d_dq, void* d_dk, void* d_dv,
+                              int64_t lddq, int64_t lddk, int64_t lddv, float* d_r, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels of the reduced-precision encoder layer: bf16 storage, fp32 parameters / statistics / arithmetic.
@@ -743,7 +755,8 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* args, void* st
  * of the fp32 parameters (sst_cast_group_bf16), the *_t ones their transposes; biases, LayerNorm parameters, statistics
  * (st1, st2 [m, 2]) and lse [m, 8] are fp32.  Backward: dx / dxp (bf16) are the gradients of x and of xp = x + positional rows;
  * ds2, dpre, dy1, ds1, d_o, dqkv are scratch of widths 128, 256, 128, 128, 128, 384; parameter gradients fp32; workspace:
- * sst_encoder_layer_bwd_bf16_workspace_bytes(m), 256-byte aligned. */
+ * sst_encoder_layer_bwd_bf16_workspace_bytes(m), 256-byte aligned.  head_scale (last fields): NULL = standard attention, else
+ * scaled cosine attention (sst_sra_attn_cos_*_bf16) and the backward writes cos_r [m, 8] fp32. */
 typedef struct sst_encoder_layer_fwd_bf16_args {
   int64_t m, n_windows;
   int32_t n_heads, act, max_tokens, reserved;
@@ -761,6 +774,7 @@ typedef struct sst_encoder_layer_fwd_bf16_args {
   void *pre, *h, *s2;
   float* st2;
   void *y2, *y2p;
+  const float* head_scale;
 } sst_encoder_layer_fwd_bf16_args;
 typedef struct sst_encoder_layer_bwd_bf16_args {
   int64_t m, n_windows;
@@ -779,6 +793,8 @@ typedef struct sst_encoder_layer_bwd_bf16_args {
   void *ds2, *dpre, *dy1, *ds1, *d_o, *dqkv, *dxp, *dx;
   float *dw_in, *db_in, *dwo, *dbo, *dw1, *db1, *dw2, *db2, *dn1w, *dn1b, *dn2w, *dn2b;
   void* workspace;
+  const float* head_scale;
+  float* cos_r;
 } sst_encoder_layer_bwd_bf16_args;
 int64_t sst_encoder_layer_bwd_bf16_workspace_bytes(int64_t m);
 int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* args, void* stream);

@@ -68,7 +68,7 @@ EncoderLayerFwdBF16Args = _struct('EncoderLayerFwdBF16Args', 'sst_encoder_layer_
     + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
     + [(k, _P) for k in ('x', 'xp', 'wqk', 'wv', 'wout', 'w1', 'w2', 'b_in', 'b_out', 'b1', 'b2', 'n1w', 'n1b', 'n2w', 'n2b',
                          'tok', 'winoff', 'order', 'pos_table', 'pos_idx',
-                         'qk', 'v', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p')]))
+                         'qk', 'v', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p', 'head_scale')]))
 EncoderLayerBwdBF16Args = _struct('EncoderLayerBwdBF16Args', 'sst_encoder_layer_bwd_bf16_args of include/sst_amd.h', (
     [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'reserved')]
     + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
@@ -76,7 +76,7 @@ EncoderLayerBwdBF16Args = _struct('EncoderLayerBwdBF16Args', 'sst_encoder_layer_
                          'wqk_t', 'wv_t', 'wout_t', 'w1_t', 'w2_t', 'n1w', 'n2w', 'tok', 'winoff', 'order',
                          'ds2', 'dpre', 'dy1', 'ds1', 'd_o', 'dqkv', 'dxp', 'dx',
                          'dw_in', 'db_in', 'dwo', 'dbo', 'dw1', 'db1', 'dw2', 'db2', 'dn1w', 'dn1b', 'dn2w', 'dn2b',
-                         'workspace')]))
+                         'workspace', 'head_scale', 'cos_r')]))
 
 
 # name -> (restype, argtypes); mirrors include/sst_amd.h one to one
@@ -154,6 +154,10 @@ _SIGNATURES = {
                                           c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     'sst_sra_attn_bwd_ord_bf16': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_i32, c_ptr,
                                                                       c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr]),
+    'sst_sra_attn_cos_fwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr,
+                                          c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sst_sra_attn_cos_bwd_bf16': (c_i32, [c_ptr] * 6 + [c_i64] * 5 + [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32, c_ptr,
+                                                                      c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sst_add_layernorm_fwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_ptr, c_ptr, c_ptr]),
     'sst_add_layernorm_bwd_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,

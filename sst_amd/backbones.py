@@ -162,7 +162,7 @@ class _WindowTransformer(nn.Module):
           'f32x3' two-way split, three products (~1e-5 relative, tighter than the TF32 the reference's torch 1.8 used on Ampere):
                   a measurement leg, never a default;
           'bf16'  reduced-precision encoder layers (sst_amd/bf16.py) - what the reference's fp16 training (Fp16OptimizerHook)
-                  corresponds to on this hardware.  Layers the bf16 kernels do not cover (batch-norm layers, pre-norm) keep
+                  corresponds to on this hardware (cosine-attention layers included).  Layers the bf16 kernels do not cover (batch-norm layers, pre-norm, widths other than 128 / 256) keep
                   running in fp32 (split products)."""
         if precision not in ('fp32', 'bf16', 'f32x3', 'f32x6'):
             raise ValueError(precision)

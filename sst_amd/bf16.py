@@ -72,6 +72,37 @@ def sra_bwd(q, k, v, o, lse, do, plan, n_heads, scale, dq, dk, dv):
     _lib.check(rc, 'sst_sra_attn_bwd_ord_bf16')
 
 
+def sra_cos_fwd(q, k, v, plan, n_heads, head_scale):
+    """scaled cosine attention on bf16 tensors (sst_sra_attn_cos_fwd_bf16): head_scale [n_heads] fp32 on the device"""
+    m, c = q.shape
+    alloc = torch.empty if plan.n_tokens == m else torch.zeros
+    o = alloc((m, c), dtype=BF16, device=q.device)
+    lse = torch.empty((m, n_heads), dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    order = plan.order
+    rc = _timed('sra_fwd_bf16', plan.n_tokens, 0, lambda: lib.sst_sra_attn_cos_fwd_bf16(
+        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _ld(q), _ld(k), _ld(v), plan.tok_ptr(0), _lib.ptr(plan.winoff),
+        _lib.ptr(order) if order is not None else None, plan.n_windows, n_heads, _lib.ptr(head_scale), plan.max_tokens,
+        _lib.ptr(o), _ld(o), _lib.ptr(lse), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_sra_attn_cos_fwd_bf16')
+    return o, lse
+
+
+def sra_cos_bwd(q, k, v, o, lse, do, plan, n_heads, head_scale, dq, dk, dv):
+    """-> r [M, n_heads] fp32 (normalize(q) . d normalize(q)): d head_scale = colsum(r) / head_scale"""
+    m = q.size(0)
+    r = (torch.empty if plan.n_tokens == m else torch.zeros)((m, n_heads), dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    order = plan.order
+    rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_sra_attn_cos_bwd_bf16(
+        _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(do), _lib.ptr(lse), _ld(q), _ld(k), _ld(v), _ld(o),
+        _ld(do), plan.tok_ptr(0), _lib.ptr(plan.winoff), _lib.ptr(order) if order is not None else None,
+        plan.n_windows, n_heads, _lib.ptr(head_scale), plan.max_tokens, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _ld(dq),
+        _ld(dk), _ld(dv), _lib.ptr(r), _lib.stream_ptr()))
+    _lib.check(rc, 'sst_sra_attn_cos_bwd_bf16')
+    return r
+
+
 def _timed(kind, n_tokens, backward, fn):
     """bench.py hook: kernel-bound HIP events on every kernels.EVENT_STRIDE-th launch (same scheme as the fp32 kernels)"""
     if K.EVENT_SINK is None or kind not in K.EVENT_KINDS:
@@ -361,8 +392,8 @@ def _exec_ok(x, xp, plan, nhead, act, w_in, w1, w2):
             and x.data_ptr() % 16 == 0 and xp.data_ptr() % 16 == 0)
 
 
-def _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next, params, need_bwd):
-    """-> (slab, y2, y2p)"""
+def _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next, params, need_bwd, head_scale=None):
+    """-> (slab, y2, y2p); head_scale ([nhead] fp32, device): scaled cosine attention"""
     import ctypes
     w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b = params
     m, c = x.shape
@@ -382,7 +413,7 @@ def _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next, params, need_bwd):
         None if plan.tok_ptr(0) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
         S('qk'), S('v'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'),
-        S('s2') if need_bwd else None, S('st2'), P(y2), P(y2p))
+        S('s2') if need_bwd else None, S('st2'), P(y2), P(y2p), P(head_scale))
     lib = _lib.load()
     rc = _timed('sra_fwd_bf16', plan.n_tokens, 0, lambda: lib.sst_encoder_layer_fwd_bf16(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_fwd_bf16')
@@ -391,11 +422,13 @@ def _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next, params, need_bwd):
 
 def _exec_bwd(ctx, dy2, dy2p):
     import ctypes
-    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
+    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors[:9]
+    head_scale = ctx.saved_tensors[9] if ctx.cosine else None
     m, c = x.shape
     dev = x.device
     plan = ctx.plan
     offs, _ = _slab_offsets(m)
+    cos_r = torch.empty((m, ctx.nhead), dtype=torch.float32, device=dev) if ctx.cosine else None
     base = slab.data_ptr()
     scratch = torch.empty((m, sum(cols for _, cols in _SCRATCH)), dtype=BF16, device=dev)
     sp, so = {}, scratch.data_ptr()
@@ -425,10 +458,12 @@ def _exec_bwd(ctx, dy2, dy2p):
         P(shadow(w_out, transposed=True)), P(shadow(w1, transposed=True)), P(shadow(w2, transposed=True)), P(n1w), P(n2w),
         None if plan.tok_ptr(0) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         sp['ds2'], sp['dpre'], sp['dy1'], sp['ds1'], sp['d_o'], sp['dqkv'], P(dxp), P(dx),
-        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 4 * c, dnp + 8 * c, dnp + 12 * c, P(ws))
+        P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 4 * c, dnp + 8 * c, dnp + 12 * c, P(ws),
+        P(head_scale), P(cos_r))
     rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_encoder_layer_bwd_bf16(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_bwd_bf16')
-    return (dx, dxp, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3])
+    d_scale = K.head_scale_grad(cos_r, head_scale) if ctx.cosine else None
+    return (dx, dxp, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3], d_scale)
 
 
 class EncoderLayerBF16Fn(Function):
@@ -439,16 +474,21 @@ class EncoderLayerBF16Fn(Function):
     gradients, attention core, ONE grouped weight-gradient launch + its reduction (10 launches)."""
 
     @staticmethod
-    def forward(ctx, x, xp, plan, nhead, act, eps, pos_next, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b):
+    def forward(ctx, x, xp, plan, nhead, act, eps, pos_next, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b,
+                head_scale=None):
+        """head_scale ([nhead] fp32 on the device, differentiable): scaled cosine attention, normalisation inside the kernels"""
         c = x.size(1)
         ctx.exec = False
+        ctx.cosine = head_scale is not None
+        if ctx.cosine:
+            head_scale = head_scale.float().contiguous()
         if _exec_ok(x, xp, plan, nhead, act, w_in, w1, w2):
             need_bwd = any(ctx.needs_input_grad)
             scale = 1.0 / math.sqrt(16.0)
             slab, y2, y2p = _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next,
-                                      (w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b), need_bwd)
+                                      (w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b), need_bwd, head_scale)
             if need_bwd:
-                ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w)
+                ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w, *((head_scale,) if ctx.cosine else ()))
                 ctx.plan, ctx.nhead, ctx.act, ctx.scale, ctx.two = plan, nhead, act, scale, y2p is not None
                 ctx.exec = True
             return y2 if y2p is None else (y2, y2p)
@@ -456,7 +496,10 @@ class EncoderLayerBF16Fn(Function):
         qk = tall_linear(xp, shadow(w_in, (0, 2 * c)), b_in[:2 * c])
         v = tall_linear(x, shadow(w_in, (2 * c, 3 * c)), b_in[2 * c:])
         scale = 1.0 / math.sqrt(16.0)
-        o, lse = sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale)
+        if ctx.cosine:
+            o, lse = sra_cos_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, head_scale)
+        else:
+            o, lse = sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale)
         need_bwd = any(ctx.needs_input_grad)
         if _FUSED_LN:
             # out-projection + residual + LayerNorm, linear1 + activation, linear2 + residual + LayerNorm: three launches
@@ -470,7 +513,8 @@ class EncoderLayerBF16Fn(Function):
             f = tall_linear(h, shadow(w2), b2)
             y2, s2, st2, y2p = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd, pos=pos_next)
         if need_bwd:
-            ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w)
+            ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w,
+                                  *((head_scale,) if ctx.cosine else ()))
             ctx.plan, ctx.nhead, ctx.act, ctx.scale, ctx.two = plan, nhead, act, scale, y2p is not None
         if y2p is None:
             return y2
@@ -480,7 +524,8 @@ class EncoderLayerBF16Fn(Function):
     def backward(ctx, dy2, dy2p=None):
         if ctx.exec:
             return _exec_bwd(ctx, dy2, dy2p if ctx.two else None)
-        x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors
+        x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors[:19]
+        head_scale = ctx.saved_tensors[19] if ctx.cosine else None
         c = x.size(1)
         dev = x.device
         ds2, dn2w, dn2b = add_ln_bwd(dy2, dy2p if ctx.two else None, s2, st2, n2w)   # = d(y1 residual) = d(f)
@@ -490,8 +535,14 @@ class EncoderLayerBF16Fn(Function):
         ds1, dn1w, dn1b = add_ln_bwd(dy1, None, s1, st1, n1w)                             # = d(x residual) = d(a)
         do = tall_linear(ds1, shadow(w_out, transposed=True))
         dqkv = torch.empty((x.size(0), 3 * c), dtype=BF16, device=dev)
-        sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, dqkv[:, :c], dqkv[:, c:2 * c],
-                dqkv[:, 2 * c:])
+        d_scale = None
+        if ctx.cosine:
+            r = sra_cos_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, head_scale, dqkv[:, :c], dqkv[:, c:2 * c],
+                            dqkv[:, 2 * c:])
+            d_scale = K.head_scale_grad(r, head_scale)
+        else:
+            sra_bwd(qk[:, :c], qk[:, c:], v, o, lse, do, ctx.plan, ctx.nhead, ctx.scale, dqkv[:, :c], dqkv[:, c:2 * c],
+                    dqkv[:, 2 * c:])
         dxp = tall_linear(dqkv[:, :2 * c], shadow(w_in, (0, 2 * c), transposed=True))
         dx = tall_linear(dqkv[:, 2 * c:], shadow(w_in, (2 * c, 3 * c), transposed=True), None, EPI_ADD, aux_in=ds1)
         # every parameter gradient of the layer in one launch
@@ -505,12 +556,13 @@ class EncoderLayerBF16Fn(Function):
                      (ds1, o, dwo, dbo, 1, 0),
                      (dpre, y1, dw1, db1, 1, 0),
                      (h, ds2, dw2, db2, 2, 1)])     # dW2 [128][256] = ds2^T h: operands swapped, stored transposed
-        return (dx, dxp, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b)
+        return (dx, dxp, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
+                d_scale)
 
 
 def layer_supported(enc, plan, m):
     wa = enc.win_attn
-    return (enc.post_norm and not wa.cosine and isinstance(enc.norm1, torch.nn.LayerNorm)
+    return (enc.post_norm and isinstance(enc.norm1, torch.nn.LayerNorm)
             and isinstance(enc.norm2, torch.nn.LayerNorm) and enc.act_name in ('gelu', 'relu')
             and isinstance(plan, K.WindowPlan) and plan.n_tokens == m and plan.max_tokens <= 144
             and wa.d_model == 128 and wa.head_dim == 16 and enc.linear1.out_features == 256      # the shapes csrc/dense_bf16.hip is built for
@@ -522,6 +574,8 @@ def run_encoder_stack(blocks, feats, plans, pos_specs):
     pos_specs: per partition (positional table fp32 [P, C], row index int32 [M])."""
     layers = [enc for block in blocks for enc in block.encoder_list]
     _refresh_stack_shadows(layers, torch.is_grad_enabled())   # one launch, every forward
+    from .sst_basic_block import stack_head_scales
+    scales = stack_head_scales(layers)      # cosine layers: 1 / clamp(tau) of the whole stack in one pass (None: standard attention)
     x, xp = _CastIn.apply(feats, pos_specs[0][0], pos_specs[0][1])
     for li, enc in enumerate(layers):
         attn = enc.win_attn.self_attn
@@ -529,6 +583,6 @@ def run_encoder_stack(blocks, feats, plans, pos_specs):
         out = EncoderLayerBF16Fn.apply(
             x, xp, plans[li % 2], enc.win_attn.nhead, enc.act_name, enc.norm1.eps, pos_next, attn.in_proj_weight,
             attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
-            enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias)
+            enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias, scales[li])
         x, xp = out if pos_next is not None else (out, None)
     return x.float()

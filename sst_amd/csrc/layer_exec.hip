@@ -171,8 +171,12 @@ int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* a, void* s
   rc = sst_tall_linear_bf16(a->x, kC, a->wv, a->b_in ? a->b_in + 2 * kC : nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->v,
                             kC, stream);
   if (rc) return rc;
-  rc = sst_sra_attn_fwd_ord_bf16(qk, qk + kC, a->v, 2 * kC, 2 * kC, kC, a->tok, a->winoff, a->order, a->n_windows, a->n_heads,
-                                 a->scale, a->max_tokens, a->o, kC, a->lse, stream);
+  if (a->head_scale != nullptr)
+    rc = sst_sra_attn_cos_fwd_bf16(qk, qk + kC, a->v, 2 * kC, 2 * kC, kC, a->tok, a->winoff, a->order, a->n_windows, a->n_heads,
+                                   a->head_scale, a->max_tokens, a->o, kC, a->lse, stream);
+  else
+    rc = sst_sra_attn_fwd_ord_bf16(qk, qk + kC, a->v, 2 * kC, 2 * kC, kC, a->tok, a->winoff, a->order, a->n_windows, a->n_heads,
+                                   a->scale, a->max_tokens, a->o, kC, a->lse, stream);
   if (rc) return rc;
   // out-projection + residual + LayerNorm; linear1 + activation; linear2 + residual + LayerNorm (+ the next layer's x + pos)
   rc = sst_tall_linear_ln_bf16(a->o, kC, a->wout, a->b_out, m, kC, a->x, kC, a->n1w, a->n1b, a->eps, a->y1, a->s1, a->st1, nullptr,
@@ -210,9 +214,14 @@ int sst_encoder_layer_bwd_bf16(const sst_encoder_layer_bwd_bf16_args* a, void* s
   if (rc) return rc;
   rc = sst_tall_linear_bf16(a->ds1, kC, a->wout_t, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
   if (rc) return rc;
-  rc = sst_sra_attn_bwd_ord_bf16(qk, qk + kC, a->v, a->o, a->d_o, a->lse, 2 * kC, 2 * kC, kC, kC, kC, a->tok, a->winoff, a->order,
-                                 a->n_windows, a->n_heads, a->scale, a->max_tokens, dqkv, dqkv + kC, dqkv + 2 * kC, 3 * kC, 3 * kC,
-                                 3 * kC, stream);
+  if (a->head_scale != nullptr)
+    rc = sst_sra_attn_cos_bwd_bf16(qk, qk + kC, a->v, a->o, a->d_o, a->lse, 2 * kC, 2 * kC, kC, kC, kC, a->tok, a->winoff,
+                                   a->order, a->n_windows, a->n_heads, a->head_scale, a->max_tokens, dqkv, dqkv + kC,
+                                   dqkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->cos_r, stream);
+  else
+    rc = sst_sra_attn_bwd_ord_bf16(qk, qk + kC, a->v, a->o, a->d_o, a->lse, 2 * kC, 2 * kC, kC, kC, kC, a->tok, a->winoff,
+                                   a->order, a->n_windows, a->n_heads, a->scale, a->max_tokens, dqkv, dqkv + kC, dqkv + 2 * kC,
+                                   3 * kC, 3 * kC, 3 * kC, stream);
   if (rc) return rc;
   rc = sst_tall_linear_bf16(dqkv, 3 * kC, a->wqk_t, nullptr, m, 2 * kC, kC, kEpiBias, nullptr, nullptr, 0, a->dxp, kC, stream);
   if (rc) return rc;

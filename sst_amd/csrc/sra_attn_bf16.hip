@@ -75,18 +75,32 @@ __device__ __forceinline__ float rows4_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// scaled cosine attention (cosine_msa.py:123-170; see csrc/sra_attn.hip): a bf16 row fragment (token c, channels 4g .. 4g+3 of the
+// head) normalised over the head's 16 channels - the four lanes c, c+16, c+32, c+48 hold one row - and rounded back to bf16
+__device__ __forceinline__ float rowfrag_inv_norm(const s16x4 x) {
+  const f32x4 u = unpack4(x);
+  const float n2 = rows4_sum(fmaf(u[0], u[0], fmaf(u[1], u[1], fmaf(u[2], u[2], u[3] * u[3]))));
+  return __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));      // 1 / max(|x|, 1e-12)
+}
+__device__ __forceinline__ s16x4 scaled(const s16x4 x, const float sc) {
+  const f32x4 u = unpack4(x);
+  return pack4(u[0] * sc, u[1] * sc, u[2] * sc, u[3] * sc);
+}
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return fmaf(a[0], b[0], fmaf(a[1], b[1], fmaf(a[2], b[2], a[3] * b[3]))); }
+
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool COS>
 __device__ __forceinline__ void fwd_body(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                          const unsigned short* __restrict__ V, uint32_t ldq, uint32_t ldk, uint32_t ldv,
                                          const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H,
                                          float scale, unsigned short* __restrict__ O, uint32_t ldo,
-                                         float* __restrict__ LSE) {
+                                         float* __restrict__ LSE, const float* __restrict__ hscale) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
+  if (COS) scale = hscale[head];
   constexpr int NTK = (NT * 16 + 63) / 64;
   int tk[NTK];
 #pragma unroll
@@ -108,6 +122,7 @@ __device__ __forceinline__ void fwd_body(const unsigned short* __restrict__ Q, c
     if (j < nt) {
       const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
       kf[j] = ld_row(K, krow * ldk + hoff + 4 * g);
+      if (COS) kf[j] = scaled(kf[j], rowfrag_inv_norm(kf[j]));
       unsigned short v4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -127,6 +142,7 @@ __device__ __forceinline__ void fwd_body(const unsigned short* __restrict__ Q, c
   for (int i = 0; i < nt; ++i) {
     const uint32_t qrow_next = tok_at(i + 1 < nt ? i + 1 : i, c);
     const s16x4 qf_next = ld_row(Q, qrow_next * ldq + hoff + 4 * g);  // prefetch
+    if (COS) qf = scaled(qf, rowfrag_inv_norm(qf));
     f32x4 st[NT];
     float mx = -INFINITY;
 #pragma unroll
@@ -168,14 +184,15 @@ __device__ __forceinline__ void fwd_body(const unsigned short* __restrict__ Q, c
   }
 }
 
-template <int NTMAX>
+template <int NTMAX, bool COS>
 __global__ __launch_bounds__(64 * kWH) void sra_fwd_bf16_k(const unsigned short* __restrict__ Q,
                                                            const unsigned short* __restrict__ K,
                                                            const unsigned short* __restrict__ V, int64_t ldq, int64_t ldk,
                                                            int64_t ldv, const int32_t* __restrict__ tok,
                                                            const int32_t* __restrict__ winoff, int n_groups, int H,
                                                            float scale, unsigned short* __restrict__ O, int64_t ldo,
-                                                           float* __restrict__ LSE, const int32_t* __restrict__ order) {
+                                                           float* __restrict__ LSE, const int32_t* __restrict__ order,
+                                                           const float* __restrict__ hscale) {
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
   const int wpos = bid / n_groups;
   const int hg = bid - wpos * n_groups;
@@ -184,13 +201,13 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_bf16_k(const unsigned short*
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;
-#define SST_F_ARGS Q, K, V, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, tok, beg, t, nt, hg, H, scale, O, (uint32_t)ldo, LSE
+#define SST_F_ARGS Q, K, V, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, tok, beg, t, nt, hg, H, scale, O, (uint32_t)ldo, LSE, hscale
   if (nt <= 2)
-    fwd_body<2>(SST_F_ARGS);
+    fwd_body<2, COS>(SST_F_ARGS);
   else if (nt <= 4)
-    fwd_body<4>(SST_F_ARGS);
+    fwd_body<4, COS>(SST_F_ARGS);
   else
-    fwd_body<NTMAX>(SST_F_ARGS);
+    fwd_body<NTMAX, COS>(SST_F_ARGS);
 #undef SST_F_ARGS
 }
 
@@ -202,17 +219,21 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_bf16_k(const unsigned short*
 // (lane = d, registers = 4 consecutive tokens), which packed to bf16 is the operand wanted - exact (a selection of bf16
 // values accumulated in fp32).  The same product turns the dS tile (D layout: lane = key, registers = queries, read as
 // the A operand of dS^T) into the B operand of dQ^T += K^T dS^T.  No LDS, no barrier, no wave-private tiles.
-template <int NT, bool EXACT>
+// COS: q / k normalised as they are loaded, score scale hscale[head], the gradients taken through the normalisation where they are
+// stored (d x = (d x^ - x^ (x^ . d x^)) / |x|: dQ / dK leave in the row-fragment layout Q / K were loaded in), q^ . dq^ -> R
+template <int NT, bool EXACT, bool COS>
 __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K,
                                          const unsigned short* __restrict__ V, const unsigned short* __restrict__ O,
                                          const unsigned short* __restrict__ dO, const float* __restrict__ LSE,
                                          uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t ldo, uint32_t lddo,
                                          const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H,
                                          float scale, unsigned short* __restrict__ dQ, unsigned short* __restrict__ dK,
-                                         unsigned short* __restrict__ dV, uint32_t lddq, uint32_t lddk, uint32_t lddv) {
+                                         unsigned short* __restrict__ dV, uint32_t lddq, uint32_t lddk, uint32_t lddv,
+                                         const float* __restrict__ hscale, float* __restrict__ R) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
+  if (COS) scale = hscale[head];
   constexpr int NTK = (NT * 16 + 63) / 64;
   int tk[NTK];
 #pragma unroll
@@ -243,6 +264,7 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
     if (EXACT || j < nt) {
       const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
       kf[j] = ld_row(K, krow * ldk + hoff + 4 * g);
+      if (COS) kf[j] = scaled(kf[j], rowfrag_inv_norm(kf[j]));   // k^ (bf16) from here on
       vf[j] = ld_row(V, krow * ldv + hoff + 4 * g);
     } else {
       kf[j] = vf[j] = (s16x4){0, 0, 0, 0};
@@ -269,7 +291,8 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
   const float s2 = scale * kLog2e;
 
   for (int i = 0; i < nt; ++i) {
-    const s16x4 qf = cur.qf, gf = cur.gf;
+    const float q_inv = COS ? rowfrag_inv_norm(cur.qf) : 1.f;
+    const s16x4 qf = COS ? scaled(cur.qf, q_inv) : cur.qf, gf = cur.gf;   // COS: q^
     const f32x4 gq = unpack4(gf), oq = unpack4(cur.of);
     float dd = gq[0] * oq[0] + gq[1] * oq[1] + gq[2] * oq[2] + gq[3] * oq[3];
     dd = rows4_sum(dd);
@@ -307,6 +330,13 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
         dq = mma(kcf[j], transposed(dsp), dq);                        // dQ^T[d][query] += K^T dS^T
       }
     }
+    if (COS) {   // lane (g, c) holds dq^[query c][4g .. 4g+3] and q^ of the same row fragment; every lane takes part in the sum
+      const f32x4 qh = unpack4(qf);
+      const float rq = rows4_sum(dot4(dq, qh));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dq[r] = (dq[r] - qh[r] * rq) * q_inv;
+      if (g == 0 && i * 16 + c < t) R[qrow * (uint32_t)H + head] = rq;
+    }
     if (i * 16 + c < t) {
       const u32x2 o = {pack2(dq[0], dq[1]), pack2(dq[2], dq[3])};  // lane (g, c): dQ[query c][4g .. 4g+3]
       *(u32x2*)(dQ + (qrow * lddq + hoff + 4 * g)) = o;
@@ -316,6 +346,13 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
   for (int j = 0; j < NT; ++j) {
     if (EXACT || j < nt) {
       const uint32_t krow = (uint32_t)__shfl(tk[j >> 2], (j & 3) * 16 + c, 64);
+      if (COS) {   // kf[j] is k^; |k| from the row itself once more (an L2 hit)
+        const float k_inv = rowfrag_inv_norm(ld_row(K, krow * ldk + hoff + 4 * g));
+        const f32x4 kh = unpack4(kf[j]);
+        const float rk = rows4_sum(dot4(dk[j], kh));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dk[j][r] = (dk[j][r] - kh[r] * rk) * k_inv;
+      }
       if (j * 16 + c < t) {
         const u32x2 a = {pack2(dk[j][0], dk[j][1]), pack2(dk[j][2], dk[j][3])};
         const u32x2 b = {pack2(dv[j][0], dv[j][1]), pack2(dv[j][2], dv[j][3])};
@@ -326,14 +363,14 @@ __device__ __forceinline__ void bwd_body(const unsigned short* __restrict__ Q, c
   }
 }
 
-template <int NTMAX>
+template <int NTMAX, bool COS>
 __global__ __launch_bounds__(64 * kWH, (NTMAX > 7 ? 2 : 3)) void sra_bwd_bf16_k(
     const unsigned short* __restrict__ Q, const unsigned short* __restrict__ K, const unsigned short* __restrict__ V,
     const unsigned short* __restrict__ O, const unsigned short* __restrict__ dO, const float* __restrict__ LSE,
     int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, const int32_t* __restrict__ tok,
     const int32_t* __restrict__ winoff, int n_groups, int H, float scale, unsigned short* __restrict__ dQ,
     unsigned short* __restrict__ dK, unsigned short* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv,
-    const int32_t* __restrict__ order) {
+    const int32_t* __restrict__ order, const float* __restrict__ hscale, float* __restrict__ R) {
   const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
   const int wpos = bid / n_groups;
   const int hg = bid - wpos * n_groups;
@@ -342,17 +379,17 @@ __global__ __launch_bounds__(64 * kWH, (NTMAX > 7 ? 2 : 3)) void sra_bwd_bf16_k(
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;
-#define SST_B_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv
+#define SST_B_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, hscale, R
   switch (nt) {
-    case 1: bwd_body<1, true>(SST_B_ARGS); break;
-    case 2: bwd_body<2, true>(SST_B_ARGS); break;
-    case 3: bwd_body<3, true>(SST_B_ARGS); break;
-    case 4: bwd_body<4, true>(SST_B_ARGS); break;
-    case 5: if constexpr (NTMAX >= 5) bwd_body<5, true>(SST_B_ARGS); break;
-    case 6: if constexpr (NTMAX >= 6) bwd_body<6, true>(SST_B_ARGS); break;
-    case 7: if constexpr (NTMAX >= 7) bwd_body<7, true>(SST_B_ARGS); break;
+    case 1: bwd_body<1, true, COS>(SST_B_ARGS); break;
+    case 2: bwd_body<2, true, COS>(SST_B_ARGS); break;
+    case 3: bwd_body<3, true, COS>(SST_B_ARGS); break;
+    case 4: bwd_body<4, true, COS>(SST_B_ARGS); break;
+    case 5: if constexpr (NTMAX >= 5) bwd_body<5, true, COS>(SST_B_ARGS); break;
+    case 6: if constexpr (NTMAX >= 6) bwd_body<6, true, COS>(SST_B_ARGS); break;
+    case 7: if constexpr (NTMAX >= 7) bwd_body<7, true, COS>(SST_B_ARGS); break;
     default:
-      if constexpr (NTMAX > 7) bwd_body<NTMAX, false>(SST_B_ARGS);
+      if constexpr (NTMAX > 7) bwd_body<NTMAX, false, COS>(SST_B_ARGS);
       break;
   }
 #undef SST_B_ARGS
@@ -360,6 +397,8 @@ __global__ __launch_bounds__(64 * kWH, (NTMAX > 7 ? 2 : 3)) void sra_bwd_bf16_k(
 
 thread_local hipEvent_t g_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // one-shot hooks: [fwd|bwd][start|stop]
 thread_local const int32_t* g_win_order = nullptr;   // launch order of the current call (the *_ord_* entries set it)
+thread_local const float* g_head_scale = nullptr;    // cosine attention of the current call (sst_sra_attn_cos_*_bf16 set them)
+thread_local float* g_cos_r = nullptr;
 
 bool aligned8(const void* p) { return ((uintptr_t)p & 7) == 0; }
 
@@ -371,12 +410,14 @@ int launch_fwd(const unsigned short* q, const unsigned short* k, const unsigned 
   const dim3 grid((unsigned)(n_windows * n_groups));
   hipEvent_t e0 = g_ev[0][0], e1 = g_ev[0][1];
   g_ev[0][0] = g_ev[0][1] = nullptr;
+  const float* hs = g_head_scale;
+  auto kern = hs != nullptr ? sra_fwd_bf16_k<NTMAX, true> : sra_fwd_bf16_k<NTMAX, false>;
   if (e0 != nullptr && e1 != nullptr)
-    hipExtLaunchKernelGGL(sra_fwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), 0, st, e0, e1, 0, q, k, v, ldq, ldk, ldv, tok, winoff,
-                          n_groups, H, scale, o, ldo, lse, g_win_order);
+    hipExtLaunchKernelGGL(kern, grid, dim3(64 * kWH), 0, st, e0, e1, 0, q, k, v, ldq, ldk, ldv, tok, winoff,
+                          n_groups, H, scale, o, ldo, lse, g_win_order, hs);
   else
-    hipLaunchKernelGGL(sra_fwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), 0, st, q, k, v, ldq, ldk, ldv, tok, winoff, n_groups, H,
-                       scale, o, ldo, lse, g_win_order);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kWH), 0, st, q, k, v, ldq, ldk, ldv, tok, winoff, n_groups, H,
+                       scale, o, ldo, lse, g_win_order, hs);
   return SST_OK;
 }
 
@@ -390,12 +431,16 @@ int launch_bwd(const unsigned short* q, const unsigned short* k, const unsigned 
   const dim3 grid((unsigned)(n_windows * n_groups));
   hipEvent_t e0 = g_ev[1][0], e1 = g_ev[1][1];
   g_ev[1][0] = g_ev[1][1] = nullptr;
+  const float* hs = g_head_scale;
+  float* rbuf = g_cos_r;
+  if (hs != nullptr && rbuf == nullptr) return SST_ERR_ARG;
+  auto kern = hs != nullptr ? sra_bwd_bf16_k<NTMAX, true> : sra_bwd_bf16_k<NTMAX, false>;
   if (e0 != nullptr && e1 != nullptr)
-    hipExtLaunchKernelGGL(sra_bwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), lds, st, e0, e1, 0, q, k, v, o, g, lse, ldq, ldk, ldv,
-                          ldo, ldg, tok, winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv, g_win_order);
+    hipExtLaunchKernelGGL(kern, grid, dim3(64 * kWH), lds, st, e0, e1, 0, q, k, v, o, g, lse, ldq, ldk, ldv,
+                          ldo, ldg, tok, winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv, g_win_order, hs, rbuf);
   else
-    hipLaunchKernelGGL(sra_bwd_bf16_k<NTMAX>, grid, dim3(64 * kWH), lds, st, q, k, v, o, g, lse, ldq, ldk, ldv, ldo, ldg, tok,
-                       winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv, g_win_order);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kWH), lds, st, q, k, v, o, g, lse, ldq, ldk, ldv, ldo, ldg, tok,
+                       winoff, n_groups, H, scale, dq, dk, dv, lddq, lddk, lddv, g_win_order, hs, rbuf);
   return SST_OK;
 }
 
@@ -477,6 +522,41 @@ int sst_sra_attn_bwd_ord_bf16(const void* d_q, const void* d_k, const void* d_v,
   g_win_order = d_win_order;
   const int rc = sst_sra_attn_bwd_bf16(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff,
                                        n_windows, n_heads, scale, max_tokens, d_dq, d_dk, d_dv, lddq, lddk, lddv, stream);
+  g_win_order = nullptr;
+  return rc;
+}
+
+// Scaled cosine attention with bf16 storage (see sst_sra_attn_cos_{fwd,bwd}_f32): normalize(q) normalize(k)^T * head_scale[h],
+// head_scale [n_heads] fp32 in DEVICE memory; the normalised rows are rounded to bf16 before the products (bf16 resolution, as
+// every operand of this mode).  Backward: d_dq / d_dk = gradients of the UN-normalised rows, d_r [n_tokens, n_heads] fp32 =
+// normalize(q) . d normalize(q) (column sums / head_scale = gradient of the scale).
+int sst_sra_attn_cos_fwd_bf16(const void* d_q, const void* d_k, const void* d_v, int64_t ldq, int64_t ldk, int64_t ldv,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, const float* d_head_scale, int max_tokens, void* d_o, int64_t ldo, float* d_lse,
+                              void* stream) {
+  if (!d_head_scale) return SST_ERR_ARG;
+  g_win_order = d_win_order;
+  g_head_scale = d_head_scale;
+  const int rc = sst_sra_attn_fwd_bf16(d_q, d_k, d_v, ldq, ldk, ldv, d_tok, d_winoff, n_windows, n_heads, 1.0f, max_tokens, d_o,
+                                       ldo, d_lse, stream);
+  g_head_scale = nullptr;
+  g_win_order = nullptr;
+  return rc;
+}
+
+int sst_sra_attn_cos_bwd_bf16(const void* d_q, const void* d_k, const void* d_v, const void* d_o, const void* d_do,
+                              const float* d_lse, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                              const int32_t* d_tok, const int32_t* d_winoff, const int32_t* d_win_order, int64_t n_windows,
+                              int n_heads, const float* d_head_scale, int max_tokens, void* d_dq, void* d_dk, void* d_dv,
+                              int64_t lddq, int64_t lddk, int64_t lddv, float* d_r, void* stream) {
+  if (!d_head_scale || !d_r) return SST_ERR_ARG;
+  g_win_order = d_win_order;
+  g_head_scale = d_head_scale;
+  g_cos_r = d_r;
+  const int rc = sst_sra_attn_bwd_bf16(d_q, d_k, d_v, d_o, d_do, d_lse, ldq, ldk, ldv, ldo, lddo, d_tok, d_winoff, n_windows,
+                                       n_heads, 1.0f, max_tokens, d_dq, d_dk, d_dv, lddq, lddk, lddv, stream);
+  g_cos_r = nullptr;
+  g_head_scale = nullptr;
   g_win_order = nullptr;
   return rc;
 }

@@ -215,14 +215,14 @@ def test_sst_block_bf16_matches_reference_autocast_golden():
 
 
 def test_bf16_mode_leaves_unsupported_layers_in_fp32():
-    """cosine attention / batch-norm layers are not covered by the bf16 kernels: set_precision('bf16') must then give
-    the fp32 result bit for bit"""
+    """batch-norm layers (and widths other than 128 / 256) are not covered by the bf16 kernels: set_precision('bf16') must then
+    give the fp32 result bit for bit"""
     import sst_amd
-    g = load_golden('sst_block_cosine.npz')
+    g = load_golden('sst_block_bn_cosine.npz')
     d, h, ffn = int(g['cfg::d_model']), int(g['cfg::nhead']), int(g['cfg::ffn'])
     net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[d], nhead=[h], num_blocks=1, dim_feedforward=[ffn],
                                       output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=True,
-                                      layer_cfg=dict(cosine=True, tau_min=0.01)))
+                                      layer_cfg=dict(use_bn=True, cosine=True, tau_min=0.01)))
     net.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w::')}, strict=True)
     net = net.to(DEV).train()
     layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False,
@@ -344,3 +344,65 @@ def test_bf16_layer_executor_equals_the_python_sequence(n_points, blocks, act):
         assert torch.equal(grads_e[n], grads_p[n]), n
     out_ne, _ = run(True, grad=False)
     assert torch.equal(out_ne, out_e)
+
+
+@pytest.mark.parametrize('layer_cfg', [dict(cosine=True, tau_min=0.01), dict(cosine=True, tau_min=0.01, non_shared_tau=True)])
+@pytest.mark.parametrize('n_voxels', [2500, 9000])
+def test_bf16_cosine_layers(layer_cfg, n_voxels):
+    """scaled cosine attention in the reduced-precision mode (sst_sra_attn_cos_{fwd,bwd}_bf16: normalisation and 1 / clamp(tau)
+    inside the bf16 kernels): the stack runs in bf16 (not the fp32 fallback), agrees with the fp32 cosine stack at bf16
+    resolution - outputs, input gradient, every parameter gradient incl. tau - and the one-call layer executor reproduces the
+    Python launch sequence bit for bit"""
+    import math
+    import sst_amd
+    from sst_amd import bf16 as B
+    torch.manual_seed(5)
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2,
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=False,
+                                      layer_cfg=layer_cfg)).to(DEV).train()
+    with torch.no_grad():
+        for i, blk in enumerate(net.block_list):
+            for j, enc in enumerate(blk.encoder_list):
+                enc.win_attn.self_attn.tau.fill_(0.3 + 0.2 * j)
+    g = torch.Generator().manual_seed(3)
+    side = int(math.ceil(math.sqrt(n_voxels * 2.2)))
+    cells = torch.randperm(side * side, generator=g)[:n_voxels].sort()[0]
+    coors = torch.stack([torch.zeros_like(cells), torch.zeros_like(cells), cells // side + 20, cells % side + 20], 1).to(DEV)
+    feats0 = torch.randn(n_voxels, 128, generator=g).to(DEV)
+    up = torch.randn(n_voxels, 128, generator=g).to(DEV)
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False, debug=False,
+                                    mute=True).eval()
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        feats = feats0.clone().requires_grad_(True)
+        out = net(layer(feats, coors, 1))[0]['voxel_feats']
+        (out * up[:out.size(0)]).sum().backward()
+        return out.detach().clone(), feats.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    ref = step()                       # fp32 storage (exact-split products), cosine inside the fp32 kernels
+    net.set_precision('bf16')
+    calls = []
+    orig = B.run_encoder_stack
+    B.run_encoder_stack = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        low = step()
+        B._LAYER_EXEC = 0
+        seq = step()
+    finally:
+        B.run_encoder_stack = orig
+        B._LAYER_EXEC = 1
+        net.set_precision('f32x6')
+    assert len(calls) == 2, 'the cosine stack did not run in the reduced-precision mode'
+    assert torch.equal(low[0], seq[0]) and torch.equal(low[1], seq[1])
+    for n in low[2]:
+        assert torch.equal(low[2][n], seq[2][n]), n
+    d = (low[0] - ref[0]).abs()
+    assert float(d.max()) < 8e-2 and float(d.mean()) < 8e-3, (float(d.max()), float(d.mean()))
+    sc = max(1.0, float(ref[1].abs().max()))
+    e = (low[1] - ref[1]).abs()
+    assert float(e.max()) < 8e-2 * sc and float(e.mean()) < 8e-3 * sc
+    assert low[2].keys() == ref[2].keys() and any(n.endswith('tau') for n in low[2])
+    for n in low[2]:
+        s_ = max(1.0, float(ref[2][n].abs().max()))
+        assert float((low[2][n] - ref[2][n]).abs().max()) < 6e-2 * s_, n
