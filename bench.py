@@ -675,7 +675,8 @@ def _main(args, line_out):
         args.blocks = int(center_cfg['backbone']['num_blocks'])
         point_channels = int(center_cfg['voxel_encoder']['in_channels'])
         model = Pipeline(model_cfg=center_cfg, voxel_feats_only=True).to(dev)
-        args.no_bf16_leg = args.no_cpu_baseline = args.no_lidar_leg = args.no_f32x3_leg = args.no_config_as_is_leg = True
+        args.no_cpu_baseline = args.no_lidar_leg = args.no_f32x3_leg = args.no_config_as_is_leg = True
+        args.no_bf16_own_process = True      # the reduced-precision leg stays: cosine attention inside the bf16 kernels too
     else:
         model = Pipeline(args.blocks, with_bev=args.workload == 'sst_bev').to(dev)
     if args.workload == 'sst_bev':
