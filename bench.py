@@ -503,7 +503,7 @@ def config_as_is_leg(args, dev, frames, sync):
 
         def pstep():
             out = step(ahead.pop() if ahead else None)
-            ahead.append(det.prepare(frames))
+            ahead.append(det.prepare(frames, overlap=args.plan_overlap))
             return out
         pre = timed(pstep, 2)
         n_vox = int(det.last_voxel_coors.size(0))
@@ -577,6 +577,11 @@ def parse_args():
     ap.add_argument('--no-plan-prefetch', action='store_true',
                     help='build the index plan of a batch at the head of its own step (round-2 behaviour) instead of behind '
                          'the previous step\'s backward pass')
+    ap.add_argument('--plan-overlap', action='store_true',
+                    help='build the next batch\'s index plan on the planner\'s own stream beside the backward pass '
+                         '(FramePlanner.build_overlapped) instead of on the same stream behind it.  Measured without a profiler '
+                         '(tools/step_segments.py, profiles/r05): 11.50 -> 11.47 ms on the bench frame, 5.07 -> 4.97 ms on the '
+                         'LiDAR-like frame - the head of a step is NOT where the time goes; off by default')
     ap.add_argument('--grad-sync', default='overlap', choices=('overlap', 'flat'),
                     help='N > 1: overlap = buckets sent from autograd hooks during the backward pass (default); flat = one '
                          'blocking all-reduce of the whole buffer after it')
@@ -709,7 +714,7 @@ def _main(args, line_out):
         at the host's launch rate at the head of the next step.  Every timed step still builds exactly one plan."""
         if args.no_plan_prefetch:
             return None
-        return ahead.pop() if ahead else model.prepare(frames)
+        return ahead.pop() if ahead else model.prepare(frames, overlap=args.plan_overlap)
 
     def host_ms_per_step(n=3):
         """Interpreter + launch time of one step: forward and backward each timed on the host with the device idle at their
@@ -760,7 +765,7 @@ def _main(args, line_out):
             with torch.no_grad():
                 out = model(frames, next_plan())
                 if not args.no_plan_prefetch:
-                    ahead.append(model.prepare(frames))
+                    ahead.append(model.prepare(frames, overlap=args.plan_overlap))
                 return out
         for p in params:
             p.grad = None
@@ -773,7 +778,7 @@ def _main(args, line_out):
             g = seed_grad[out.shape] = torch.randn(out.shape, device=out.device, dtype=out.dtype)
         out.backward(g)                       # the reducer's hooks send a bucket as soon as its gradients exist
         if not args.no_plan_prefetch:
-            ahead.append(model.prepare(frames))
+            ahead.append(model.prepare(frames, overlap=args.plan_overlap))
         if reducer is not None:
             reducer.finish()
         return out
@@ -1211,7 +1216,9 @@ def _main(args, line_out):
                        'frames_per_gpu': args.frames_per_gpu, 'points_per_frame': args.points,
                        'voxels_per_gpu': n_voxels, 'parallelism': f'dp{world}',
                        'index_plan': 'built at the head of its step' if args.no_plan_prefetch else
-                                     'one plan per step, queued behind the previous step\'s backward pass (same stream)',
+                                     ('one plan per step, built on the planner\'s own stream beside the previous step\'s backward '
+                                      'pass (DynamicVoxelNet.prepare(.., overlap=True))' if args.plan_overlap else
+                                      'one plan per step, queued behind the previous step\'s backward pass (same stream)'),
                        'grad_sync': ('one flat persistent fp32 buffer, ' + (f'{len(reducer.buckets)} bucket(s) sent from autograd '
                                      'hooks during the backward pass' if args.grad_sync == 'overlap' else
                                      'one blocking all-reduce after the backward pass') + ', over '

@@ -282,14 +282,25 @@ class DynamicVoxelNet(nn.Module):
             self.__dict__['_planner'] = planner
         return planner if (planner and planner.supported(batch_size)) else None
 
-    def prepare(self, points):
+    def prepare(self, points, overlap=False, ready_event=None):
         """the index work of one batch (voxelize, point -> voxel grouping, window bucketing / drop / window CSR, positional
         rows): a FramePlan, or None when the fused plan does not cover this configuration / batch (extract_feat then runs the
-        piecewise path itself)"""
-        if len(points) == 0 or not all(p.is_cuda for p in points):
+        piecewise path itself).
+
+        ``overlap=True`` (a data-loader hook's mode): the plan is built on a stream of its own, concurrently with the step the
+        caller's stream is still working on; the point clouds must be complete, or complete once ``ready_event`` has happened
+        (FramePlanner.build_overlapped).  Host tensors (the data loader's pinned batch) are copied to the device on that
+        stream first - then nothing has to be promised."""
+        if len(points) == 0:
             return None
         planner = DynamicVoxelNet._frame_planner(self, len(points))
-        return planner.build(points) if planner is not None else None
+        if planner is None:
+            return None
+        if overlap and not any(p.is_cuda for p in points):
+            return planner.build_overlapped_from_host(points, next(self.parameters()).device)
+        if not all(p.is_cuda for p in points):
+            return None
+        return planner.build_overlapped(points, ready_event) if overlap else planner.build(points)
 
     def voxel_info(self, points, prepared=None):
         """everything in front of the backbone: -> the ``voxel_info`` dictionary SSTInputLayerV2 returns"""

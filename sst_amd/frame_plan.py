@@ -152,6 +152,67 @@ class FramePlanner(object):
         cells = batch_size * self.grid_zyx[0] * self.grid_zyx[1] * self.grid_zyx[2]
         return self._ok and 1 <= batch_size <= 64 and cells <= (1 << 28)
 
+    def build_overlapped(self, points_list, ready_event=None):
+        """build() on the planner's OWN stream, concurrently with whatever the caller's stream still has queued (the previous
+        step's backward pass): the plan depends on the point clouds only, its ~50 short launches fit between the waves of the
+        dense kernels, and its sizes are on the host long before finalize() asks for them - the host never falls behind the
+        device at the head of a step (with everything on one stream it waited there for the previous step to drain, and the
+        device then idled while the host woke up and issued the voxel encoder).
+
+        The caller's promise: the point clouds are COMPLETE, or complete once `ready_event` (recorded behind their producer,
+        e.g. the host-to-device copy of a data-loader hook) has happened - the side stream waits for that event and nothing else.
+        Memory: everything the plan keeps is allocated from the side stream's pool and marked as used by the caller's stream
+        (`record_stream`), which waits for the plan before its first consumer."""
+        dev = points_list[0].device
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.get('_side_stream')
+        if side is None or side.device != dev:
+            side = self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
+        if ready_event is not None:
+            side.wait_event(ready_event)
+        with torch.cuda.stream(side):
+            plan = self.build(points_list)
+            done = torch.cuda.Event()
+            done.record(side)
+        seen = set()
+
+        def mark(v, depth=0):
+            if isinstance(v, torch.Tensor):
+                if v.is_cuda and v.untyped_storage().data_ptr() not in seen:
+                    seen.add(v.untyped_storage().data_ptr())
+                    v.record_stream(main)
+            elif isinstance(v, (list, tuple)):
+                for u in v:
+                    mark(u, depth + 1)
+            elif isinstance(v, dict):
+                for u in v.values():
+                    mark(u, depth + 1)
+            elif depth < 3 and not isinstance(v, (torch.cuda.Event, torch.cuda.Stream, type, str, int, float)) and v is not None:
+                for u in list(getattr(v, '__dict__', {}).values()) + [getattr(v, a, None) for a in getattr(type(v), '__slots__', ())]:
+                    mark(u, depth + 1)
+        mark(plan)
+        main.wait_event(done)
+        plan.overlapped = True
+        return plan
+
+    def build_overlapped_from_host(self, host_points, device):
+        """the data loader's batch (host tensors, ideally pinned) -> device copies on the side stream -> build_overlapped: the
+        copy, the plan and the size read-back all run beside the step in flight, and the copies belong to the plan
+        (`plan.points_list`: what extract_feat would have been handed)"""
+        side = self.__dict__.get('_side_stream')
+        if side is None or side.device != torch.device(device):
+            side = self._side_stream = torch.cuda.Stream(device=device, priority=-1)
+        main = torch.cuda.current_stream(device)
+        with torch.cuda.stream(side):
+            dev_points = [p.to(device, non_blocking=True) for p in host_points]
+            copied = torch.cuda.Event()
+            copied.record(side)
+        for p in dev_points:
+            p.record_stream(main)
+        plan = self.build_overlapped(dev_points, copied)
+        plan.points_list = dev_points
+        return plan
+
     @torch.no_grad()
     def build(self, points_list):
         lib = _lib.load()

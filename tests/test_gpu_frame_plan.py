@@ -193,3 +193,88 @@ def test_a_plan_built_ahead_keeps_its_own_sizes_however_long_it_waits():
         out = model(big, waiting)
     assert out.size(0) == want
     assert len(model._planner._count_slots) <= 4, 'slots are handed back: the free list stays small'
+
+
+def _plan_tensors(plan):
+    out = {k: v for k, v in vars(plan).items() if isinstance(v, torch.Tensor) and v.is_cuda}
+    out.update({'groups.' + a: getattr(plan.groups, a) for a in ('perm', 'inverse', 'offsets', 'ukeys', 'num')})
+    return out
+
+
+@pytest.mark.parametrize('kind', ['uniform', 'crowded2'])
+def test_a_plan_built_beside_the_step_in_flight_equals_the_plan_built_in_line(kind):
+    """FramePlanner.build_overlapped (the planner's own stream, while the caller's stream is busy) == build(): every index
+    tensor and every size, with a long queue of work on the caller's stream in front of it; the pinned host batch of a data
+    loader (DynamicVoxelNet.prepare(host tensors, overlap=True)) gives the same plan again."""
+    from sst_amd.frame_plan import FramePlanner
+    vox, vfe, layer = _modules()
+    host = _clouds(kind)
+    clouds = [c.to(DEV) for c in host]
+    planner = FramePlanner(vox, vfe, layer)
+    want = planner.build(clouds)
+    torch.cuda.synchronize()
+    a = torch.randn(4096, 4096, device=DEV)
+    for _ in range(20):                      # the step in flight: ~tens of ms on the caller's stream
+        a = torch.tanh(a @ a * 1e-2)
+    got = planner.build_overlapped(clouds)
+    assert got.overlapped
+    got.counts_ready.synchronize()
+    sizes_w, sizes_g = want.h_counts.tolist()[:6], got.h_counts.tolist()[:6]
+    assert sizes_w == sizes_g
+    wt, gt = _plan_tensors(want), _plan_tensors(got)
+    assert set(wt) == set(gt)
+    m, m_keep = sizes_w[0], sizes_w[1]
+    n_groups = int(want.groups.num.item())
+    assert n_groups == int(got.groups.num.item())
+    for k in wt:
+        n = {'vcoors': m, 'gidx': None, 'feat_index': m_keep, 'feat_index_i32': m_keep, 'out_coors': m_keep, 'tok1': m_keep,
+             'posidx0': m_keep, 'posidx1': m_keep, 'groups.ukeys': n_groups, 'groups.offsets': n_groups + 1}.get(k)
+        x, y = (wt[k], gt[k]) if n is None else (wt[k][:n], gt[k][:n])
+        if k in ('winoff0', 'winoff1'):
+            nw = sizes_w[2 + int(k[-1])]
+            x, y = x[:nw + 1], y[:nw + 1]
+        if k == 'd_counts':
+            x, y = x[:6], y[:6]
+        if k == 'gidx':
+            continue                         # rows of dropped groups are unspecified beyond the counts
+        assert torch.equal(x, y), k
+    pinned = [c.pin_memory() for c in host]
+    plan_h = planner.build_overlapped_from_host(pinned, torch.device(DEV))
+    plan_h.counts_ready.synchronize()
+    assert plan_h.h_counts.tolist()[:6] == sizes_w
+    for k in ('feat_index_i32', 'tok1', 'posidx0', 'posidx1'):
+        assert torch.equal(_plan_tensors(plan_h)[k][:m_keep], wt[k][:m_keep]), k
+    assert all(torch.equal(p.cpu(), h) for p, h in zip(plan_h.points_list, host))
+
+
+def test_training_steps_with_the_plan_built_beside_the_backward_pass_are_the_same_steps():
+    """twelve forward + backward steps of the pipeline, the next step's plan built (a) in line, (b) ahead on the same stream,
+    (c) ahead on the planner's own stream beside the backward pass: outputs and parameter gradients bit for bit equal
+    (shuffle off: the drop is deterministic) - the overlapped plan's buffers are never reused while the step still reads them"""
+    import bench
+    outs = {}
+    clouds = [[bench.make_cloud(30000 + 1500 * i, 40 + i, DEV)] for i in range(4)]
+    for mode in ('inline', 'same_stream', 'overlap'):
+        torch.manual_seed(0)
+        cfg = bench._pipeline_config(2)
+        cfg['middle_encoder'] = dict(cfg['middle_encoder'], shuffle_voxels=False)
+        model = bench.Pipeline(model_cfg=cfg, voxel_feats_only=True).to(DEV).train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        ahead, rec = [], []
+        for step in range(12):
+            frames = clouds[step % 4]
+            for p in params:
+                p.grad = None
+            out = model(frames, ahead.pop() if ahead else None)
+            g = torch.Generator(device=DEV).manual_seed(step)
+            out.backward(torch.randn(out.shape, device=DEV, generator=g))
+            if mode != 'inline':
+                ahead.append(model.prepare(clouds[(step + 1) % 4], overlap=(mode == 'overlap')))
+            rec.append((out.detach().clone(), [p.grad.clone() for p in params]))
+            del out
+        torch.cuda.synchronize()
+        outs[mode] = rec
+    for mode in ('same_stream', 'overlap'):
+        for (oa, ga), (ob, gb) in zip(outs['inline'], outs[mode]):
+            assert torch.equal(oa, ob), mode
+            assert all(torch.equal(x, y) for x, y in zip(ga, gb)), mode
