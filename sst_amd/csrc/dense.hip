@@ -735,7 +735,8 @@ int64_t sst_add_layernorm_bwd_workspace_bytes(int64_t m, int c) {
 
 static int add_layernorm_bwd_any(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
                                  const float* d_weight, const float* d_bias, int act, int64_t m, int c, float* d_dx,
-                                 float* d_dweight, float* d_dbias, void* d_workspace, void* stream) {
+                                 float* d_dweight, float* d_dbias, void* d_workspace, void* stream,
+                                 int* partial_rows = nullptr) {
   if (m < 0 || c < 1 || c > 128 * kLnMaxVec || act < 0 || act > 2) return SST_ERR_UNSUPPORTED;
   if (act && (!d_bias || d_dy2)) return SST_ERR_ARG;
   if (!d_dweight || !d_dbias) return SST_ERR_ARG;
@@ -762,11 +763,30 @@ static int add_layernorm_bwd_any(const float* d_dy, const float* d_dy2, const fl
   else
     hipLaunchKernelGGL(add_ln_bwd_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st, d_dy, d_sum,
                        (const float2*)d_stats, d_weight, d_bias, act, m, c, d_dx, partials);
-  hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
-                     d_dbias, c);
+  if (partial_rows != nullptr)     // the caller finishes the column sums itself (a rider on its next reduction launch)
+    *partial_rows = grid;
+  else
+    hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
+                       d_dbias, c);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
+
+}  // extern "C"
+
+// sst_add_layernorm_bwd2_f32 without its finishing launch: the block partials of d(gamma) | d(beta) stay in the workspace as
+// [*partial_rows][2 c] and the caller sums their columns (csrc/layer_exec.hip hands them to the weight-gradient reduction as a
+// rider, csrc/wgrad_x6.hip).  m must be > 0.
+int sst_internal_add_layernorm_bwd2_partials_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
+                                                 const float* d_weight, int64_t m, int c, float* d_dx, void* d_workspace,
+                                                 int* partial_rows, void* stream) {
+  float dummy;
+  if (m <= 0 || !partial_rows) return SST_ERR_ARG;
+  return add_layernorm_bwd_any(d_dy, d_dy2, d_sum, d_stats, d_weight, nullptr, 0, m, c, d_dx, &dummy, &dummy, d_workspace, stream,
+                               partial_rows);
+}
+
+extern "C" {
 
 int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
                                const float* d_weight, int64_t m, int c, float* d_dx, float* d_dweight, float* d_dbias,
@@ -804,9 +824,9 @@ int sst_add_layernorm_fwd_bf16(const void* d_x, const void* d_res, const float* 
   return SST_OK;
 }
 
-int sst_add_layernorm_bwd_bf16(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
-                               const float* d_weight, int64_t m, int c, void* d_dx, float* d_dweight, float* d_dbias,
-                               void* d_workspace, void* stream) {
+static int add_layernorm_bwd_bf16_any(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
+                                      const float* d_weight, int64_t m, int c, void* d_dx, float* d_dweight, float* d_dbias,
+                                      void* d_workspace, void* stream, int* partial_rows) {
   // 4-wide bf16 row accesses (col = k * 128 + lane * 4 under a `col < c` check): c must be a multiple of 4, like the forward
   if (m < 0 || c < 4 || (c & 3) || c > 128 * kLnMaxVec) return SST_ERR_UNSUPPORTED;
   if (!d_dweight || !d_dbias) return SST_ERR_ARG;
@@ -828,11 +848,35 @@ int sst_add_layernorm_bwd_bf16(const void* d_dy, const void* d_dy2, const void* 
     hipLaunchKernelGGL(add_ln_bwd_bf16_k, dim3(grid), dim3(kLnThreads), 2 * c * sizeof(float), st,
                        (const unsigned short*)d_dy, (const unsigned short*)d_dy2, (const unsigned short*)d_sum,
                        (const float2*)d_stats, d_weight, m, c, (unsigned short*)d_dx, partials);
-  hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
-                     d_dbias, c);
+  if (partial_rows != nullptr)     // the caller finishes the column sums itself (a rider on its reduction launch)
+    *partial_rows = grid;
+  else
+    hipLaunchKernelGGL(colsum_partials_k, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, grid, 2 * c, d_dweight,
+                       d_dbias, c);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
+
+int sst_add_layernorm_bwd_bf16(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
+                               const float* d_weight, int64_t m, int c, void* d_dx, float* d_dweight, float* d_dbias,
+                               void* d_workspace, void* stream) {
+  return add_layernorm_bwd_bf16_any(d_dy, d_dy2, d_sum, d_stats, d_weight, m, c, d_dx, d_dweight, d_dbias, d_workspace, stream,
+                                    nullptr);
+}
+
+}  // extern "C"
+
+// sst_add_layernorm_bwd_bf16 without its finishing launch (see sst_internal_add_layernorm_bwd2_partials_f32).  m > 0.
+int sst_internal_add_layernorm_bwd_bf16_partials(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
+                                                 const float* d_weight, int64_t m, int c, void* d_dx, void* d_workspace,
+                                                 int* partial_rows, void* stream) {
+  float dummy;
+  if (m <= 0 || !partial_rows) return SST_ERR_ARG;
+  return add_layernorm_bwd_bf16_any(d_dy, d_dy2, d_sum, d_stats, d_weight, m, c, d_dx, &dummy, &dummy, d_workspace, stream,
+                                    partial_rows);
+}
+
+extern "C" {
 
 int sst_cast_add_pos_bf16(const void* d_x, int x_is_bf16, int64_t m, int c, const float* d_pos_table,
                           const int32_t* d_pos_idx, void* d_out, void* stream) {

@@ -352,6 +352,8 @@ constexpr int kWgMaxProblems = 8;
 struct wg_args {
   wg_problem pr[kWgMaxProblems];
   int n;
+  int n_riders;                 // riders of the reduction launch (csrc/common.h): blockIdx.y < n_riders
+  sst_colsum_rider riders[2];
 };
 
 // k-slot (g, x) of the packed operand = token 4 g + x (x < 4) / 16 + 4 g + x - 4 (x >= 4) of the 32-token step, on both
@@ -516,7 +518,48 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_bf16_k(const wg_args args)
 // 64 output elements per workgroup; the four waves take every fourth slice, combined in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_bf16_k(const wg_args args) {
   __shared__ float red[4][64];
-  const wg_problem& pr = args.pr[blockIdx.y];
+  if ((int)blockIdx.y < args.n_riders) {
+    // a rider (the FIRST rows of the grid: they start with the launch): column sums of another kernel's block partials - the
+    // LayerNorm backward's d(gamma) | d(beta) partials - in the arithmetic of colsum_partials_k (csrc/dense.hip: 32 strided
+    // partial sums per column, added in order).  Workgroup = 32 columns; thread (cx, gq) forms the sums gy = gq + 8 j.
+    // The partials are cold by now: all 64 loads are requested before the first is added.
+    __shared__ float fr[32 * 33];
+    const sst_colsum_rider& J = args.riders[blockIdx.y];
+    if ((int)blockIdx.x * 32 >= J.width) return;
+    const int cx = threadIdx.x & 31, gq = threadIdx.x >> 5;
+    const int i = (int)blockIdx.x * 32 + cx;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < J.width) {
+      const float* src = J.partials + i;
+      float v[16][4];
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int b = 32 * it + gq + 8 * j;
+          v[it][j] = src[(int64_t)(b < J.nb ? b : J.nb - 1) * J.width];
+        }
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (32 * it + gq + 8 * j < J.nb) acc[j] += v[it][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fr[(gq + 8 * j) * 33 + cx] = acc[j];
+    __syncthreads();
+    if (gq == 0 && i < J.width) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) t += fr[k * 33 + cx];
+      if (i < J.split)
+        J.out0[i] = t;
+      else
+        J.out1[i - J.split] = t;
+    }
+    return;
+  }
+  const wg_problem& pr = args.pr[blockIdx.y - args.n_riders];
   const int total_w = pr.p * 128;
   const int total_b = pr.bias_side == 1 ? pr.p : (pr.bias_side == 2 ? 128 : 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -691,9 +734,24 @@ int64_t sst_wgrad_group_workspace_bytes(const sst_wgrad_problem_bf16* problems, 
 }
 
 int sst_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_workspace, void* stream) {
+  return sst_internal_wgrad_group_bf16(problems, n, d_workspace, nullptr, 0, stream);
+}
+
+}  // extern "C"
+
+int sst_internal_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_workspace, const sst_colsum_rider* riders,
+                                  int n_riders, void* stream) {
   if (n < 1 || n > kWgMaxProblems || !problems || !d_workspace) return SST_ERR_ARG;
+  if (n_riders < 0 || n_riders > 2 || (n_riders > 0 && !riders)) return SST_ERR_ARG;
   wg_args args;
   args.n = n;
+  args.n_riders = n_riders;
+  for (int i = 0; i < n_riders; ++i) {
+    if (!riders[i].partials || riders[i].nb < 1 || riders[i].nb > 512 || riders[i].width < 1 || riders[i].width > 516 * 32 ||
+        !riders[i].out0 || !riders[i].out1)
+      return SST_ERR_ARG;
+    args.riders[i] = riders[i];
+  }
   // cost of a problem in wave-steps: tokens x (P / 256); 256 workgroups in total, shared in proportion
   double cost = 0;
   for (int i = 0; i < n; ++i) {
@@ -740,9 +798,7 @@ int sst_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_
     sst_mark_device(&configured);
   }
   hipLaunchKernelGGL(wgrad_group_bf16_k, dim3((unsigned)next_block), dim3(512), kWgLdsBytes, st, args);
-  hipLaunchKernelGGL(wgrad_reduce_bf16_k, dim3((256 * 128 + 256) / 64, (unsigned)n), dim3(256), 0, st, args);
+  hipLaunchKernelGGL(wgrad_reduce_bf16_k, dim3((256 * 128 + 256) / 64, (unsigned)(n + n_riders)), dim3(256), 0, st, args);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
-
-}  // extern "C"

@@ -105,7 +105,11 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   void* ws_sra = ws;
   int rc;
   // norm2 backward: d(y1 residual) = d(FFN output); the next layer's x + pos output arrives as a second gradient
-  rc = sst_add_layernorm_bwd2_f32(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, a->dn2w, a->dn2b, ws_ln, stream);
+  // (d(gamma) | d(beta): the block partials stay in ws_ln, their columns are summed by the reduction launch of the next
+  // weight-gradient group - one finishing launch less per LayerNorm)
+  if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
+  int ln_rows = 0;
+  rc = sst_internal_add_layernorm_bwd2_partials_f32(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, ws_ln, &ln_rows, stream);
   if (rc) return rc;
   // linear2's data gradient with the activation's derivative in the epilogue
   rc = sst_tall_linear_epi_f32x6(a->ds2, kC, a->w2, kFF, 1, nullptr, m, kC, kFF, a->act == 1 ? kEpiMulGeluGrad : kEpiMulReluGrad,
@@ -116,12 +120,13 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   g1[0].out = kC, g1[0].in = kFF;
   g1[1].dy = a->dpre, g1[1].x = a->y1, g1[1].m = m, g1[1].ld_dy = kFF, g1[1].ld_x = kC, g1[1].dw = a->dw1, g1[1].db = a->db1;
   g1[1].out = kFF, g1[1].in = kC;
-  rc = sst_weight_grad_group_f32x6(g1, 2, ws_g1, stream);   // before ds2 is accumulated into
+  // before ds2 is accumulated into
+  rc = sst_internal_weight_grad_group_f32x6(g1, 2, ws_g1, (const float*)ws_ln, ln_rows, 2 * kC, kC, a->dn2w, a->dn2b, stream);
   if (rc) return rc;
   // residual + FFN branch: dy1 = ds2 + dpre W1 (in place)
   rc = sst_tall_linear_epi_f32x6(a->dpre, kFF, a->w1, kC, 1, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, a->ds2, kC, stream);
   if (rc) return rc;
-  rc = sst_add_layernorm_bwd2_f32(a->ds2, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, a->dn1w, a->dn1b, ws_ln, stream);
+  rc = sst_internal_add_layernorm_bwd2_partials_f32(a->ds2, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, ws_ln, &ln_rows, stream);
   if (rc) return rc;
   rc = sst_tall_linear_epi_f32x6(a->ds1, kC, a->w_out, kC, 1, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
   if (rc) return rc;
@@ -141,7 +146,8 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   g2[1].out = 2 * kC, g2[1].in = kC;
   g2[2].dy = a->dqkv + 2 * kC, g2[2].x = a->x, g2[2].m = m, g2[2].ld_dy = 3 * kC, g2[2].ld_x = kC;
   g2[2].dw = a->dw_in + 2 * kC * kC, g2[2].db = a->db_in + 2 * kC, g2[2].out = kC, g2[2].in = kC;
-  rc = sst_weight_grad_group_f32x6(g2, 3, ws_g2, stream);   // before ds1 is accumulated into
+  // before ds1 is accumulated into
+  rc = sst_internal_weight_grad_group_f32x6(g2, 3, ws_g2, (const float*)ws_ln, ln_rows, 2 * kC, kC, a->dn1w, a->dn1b, stream);
   if (rc) return rc;
   // d(x) of the residual branch and of all three projections: one product over K = 384 (xp = x + constant: d(x) += d(xp))
   return sst_tall_linear_epi_f32x6(a->dqkv, 3 * kC, a->w_in, kC, 1, nullptr, m, 3 * kC, kC, kEpiAdd, a->ds1, nullptr, kC, a->ds1, kC,
@@ -153,7 +159,7 @@ int64_t sst_encoder_layer_bwd_bf16_workspace_bytes(int64_t m) {
   if (m < 0) return SST_ERR_ARG;
   const int64_t a = sst_add_layernorm_bwd_workspace_bytes(m, kC), b = wg_ws_bf16(m);
   if (a < 0 || b < 0) return SST_ERR_UNSUPPORTED;
-  return sst_align_up(a, 256) + sst_align_up(b, 256) + 256;
+  return 2 * sst_align_up(a, 256) + sst_align_up(b, 256) + 256;    // the partials of BOTH LayerNorms live until the reduction
 }
 
 int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* a, void* stream) {
@@ -199,19 +205,31 @@ int sst_encoder_layer_bwd_bf16(const sst_encoder_layer_bwd_bf16_args* a, void* s
   char* ws = (char*)a->workspace;
   void* ws_ln = ws;
   ws += sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
+  void* ws_ln1 = ws;
+  ws += sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
   void* ws_wg = ws;
+  if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
+  // d(gamma) | d(beta) of both LayerNorms: the block partials wait in the workspace, the reduction launch of the
+  // parameter-gradient group sums their columns (two finishing launches less per layer)
+  sst_colsum_rider riders[2];
   const unsigned short* qk = (const unsigned short*)a->qk;
   unsigned short* dqkv = (unsigned short*)a->dqkv;
   int rc;
-  rc = sst_add_layernorm_bwd_bf16(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, a->dn2w, a->dn2b, ws_ln, stream);
+  rc = sst_internal_add_layernorm_bwd_bf16_partials(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, ws_ln, &riders[0].nb,
+                                                    stream);
   if (rc) return rc;
+  riders[0].partials = (const float*)ws_ln, riders[0].width = 2 * kC, riders[0].split = kC;
+  riders[0].out0 = a->dn2w, riders[0].out1 = a->dn2b;
   rc = sst_tall_linear_bf16(a->ds2, kC, a->w2_t, nullptr, m, kC, kFF, a->act == 1 ? kEpiMulGeluGrad : kEpiMulReluGrad, a->pre,
                             nullptr, kFF, a->dpre, kFF, stream);
   if (rc) return rc;
   rc = sst_tall_linear_bf16(a->dpre, kFF, a->w1_t, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, a->dy1, kC, stream);
   if (rc) return rc;
-  rc = sst_add_layernorm_bwd_bf16(a->dy1, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, a->dn1w, a->dn1b, ws_ln, stream);
+  rc = sst_internal_add_layernorm_bwd_bf16_partials(a->dy1, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, ws_ln1, &riders[1].nb,
+                                                    stream);
   if (rc) return rc;
+  riders[1].partials = (const float*)ws_ln1, riders[1].width = 2 * kC, riders[1].split = kC;
+  riders[1].out0 = a->dn1w, riders[1].out1 = a->dn1b;
   rc = sst_tall_linear_bf16(a->ds1, kC, a->wout_t, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
   if (rc) return rc;
   if (a->head_scale != nullptr)
@@ -244,7 +262,7 @@ int sst_encoder_layer_bwd_bf16(const sst_encoder_layer_bwd_bf16_args* a, void* s
   // dW2 [128][256] = ds2^T h: operands swapped, stored transposed; its bias gradient = column sums of the b side (ds2)
   g[4].a = a->h, g[4].lda = kFF, g[4].b = a->ds2, g[4].out_w = a->dw2, g[4].out_b = a->db2, g[4].p = kFF;
   g[4].bias_side = 2, g[4].transpose_out = 1;
-  return sst_wgrad_group_bf16(g, 5, ws_wg, stream);
+  return sst_internal_wgrad_group_bf16(g, 5, ws_wg, riders, 2, stream);
 }
 
 }  // extern "C"

@@ -235,21 +235,78 @@ __global__ __launch_bounds__(512, 2) void wgrad_x6_k(const x6_group G, float* __
 }
 
 // dW[problem][n][k] = sum over slices of the partial tiles, in float64 (one rounding at the end; slice order fixed:
-// deterministic).  Workgroup = 64 output quads (16 bytes each) x 4 slice groups: thread (quad, group) sums the slices group,
-// group + 4, ... with every load independent (the first version - one thread walking all slices of its quad, 64 workgroups in
-// all - took 26 us for 17 MB), the four groups meet in LDS.
+// deterministic).  Workgroup = 32 output quads (16 bytes each) x 8 slice groups: thread (quad, group) sums the slices group,
+// group + 8, ... with every load independent, the groups meet in LDS.  (First version: one thread walking all slices of its
+// quad, 64 workgroups - 26 us for 17 MB; second: 64 quads x 4 groups, 256 workgroups - 14 us; 16 quads x 16 groups with
+// 4-byte stores: 256-byte runs per wave and load, 30 us.)
+//
+// A second, optional job rides on the launch (extra workgroups behind the tile ones): the column sums of another kernel's block
+// partials - the LayerNorm backward's d(gamma) | d(beta) partials [nb][2 c] (csrc/dense.hip add_ln_bwd_*), in the arithmetic of
+// colsum_partials_k (32 strided partial sums per column, added in order), so that the one-call layer executor needs no
+// finishing launch of its own for them.
+struct x6_colsum_job {
+  const float* partials;   // [nb][width], NULL: no job
+  int nb, width, split;
+  float* out0;             // columns [0, split)
+  float* out1;             // columns [split, width)
+};
+
+constexpr int kRedQuads = 32, kRedGroups = 8;
+
 __global__ __launch_bounds__(256) void wgrad_x6_reduce_k(const x6_group G, const float* __restrict__ part,
-                                                         const float* __restrict__ dbp) {
-  __shared__ double red[4][64][4];
-  const int ql = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int64_t quad = (int64_t)blockIdx.x * 64 + ql;          // over tiles x 128 x 32
+                                                         const float* __restrict__ dbp, int rider_blocks,
+                                                         const x6_colsum_job J) {
+  __shared__ double red[kRedGroups][kRedQuads][4];
+  if ((int)blockIdx.x < rider_blocks) {
+    // column sums of the rider (the FIRST workgroups: they start with the launch and end inside it): this workgroup = 32
+    // columns; thread (cx, gq) forms the four strided sums gy = gq + 8 j side by side, each in colsum_partials_k's order
+    float* fr = (float*)&red[0][0][0];                       // [32][33] floats
+    const int cx = threadIdx.x & 31, gq = threadIdx.x >> 5;
+    const int i = (int)blockIdx.x * 32 + cx;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < J.width) {
+      // the partials were written several kernels ago (600 MB of operands have passed through the caches since): every load
+      // is an HBM round trip.  All 64 of them are requested before the first is added (row clamped, value masked): a loop that
+      // waited per step took 30 us.  nb <= 512 (the LayerNorm backward's grid cap; checked by the host).
+      const float* src = J.partials + i;
+      float v[16][4];
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int b = 32 * it + gq + 8 * j;
+          v[it][j] = src[(int64_t)(b < J.nb ? b : J.nb - 1) * J.width];
+        }
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (32 * it + gq + 8 * j < J.nb) acc[j] += v[it][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fr[(gq + 8 * j) * 33 + cx] = acc[j];
+    __syncthreads();
+    if (gq == 0 && i < J.width) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) t += fr[k * 33 + cx];
+      if (i < J.split)
+        J.out0[i] = t;
+      else
+        J.out1[i - J.split] = t;
+    }
+    return;
+  }
+  const int blk = (int)blockIdx.x - rider_blocks;
+  const int ql = threadIdx.x & (kRedQuads - 1), sg = threadIdx.x / kRedQuads;
+  const int64_t quad = (int64_t)blk * kRedQuads + ql;          // over tiles x 128 x 32
   const int64_t tile = quad / (kTile * kTile / 4);
   const int e4 = (int)(quad - tile * (kTile * kTile / 4));
   double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
   if (tile < G.tiles) {
     const float* src = part + tile * G.slices * (int64_t)(kTile * kTile) + 4 * e4;
 #pragma unroll 8
-    for (int q = sg; q < G.slices; q += 4) {
+    for (int q = sg; q < G.slices; q += kRedGroups) {
       const f32x4 v = *(const f32x4*)(src + (int64_t)q * (kTile * kTile));
       d0 += v[0], d1 += v[1], d2 += v[2], d3 += v[3];
     }
@@ -259,7 +316,12 @@ __global__ __launch_bounds__(256) void wgrad_x6_reduce_k(const x6_group G, const
   if (sg == 0 && tile < G.tiles) {
     f32x4 s;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = (float)(((red[0][ql][r] + red[1][ql][r]) + red[2][ql][r]) + red[3][ql][r]);
+    for (int r = 0; r < 4; ++r) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < kRedGroups; ++k) t += red[k][ql][r];
+      s[r] = (float)t;
+    }
     int pi = 0;
 #pragma unroll
     for (int q = 1; q < kMaxProblems; ++q)
@@ -270,7 +332,7 @@ __global__ __launch_bounds__(256) void wgrad_x6_reduce_k(const x6_group G, const
     *(f32x4*)(G.p[pi].dw + (int64_t)n * G.p[pi].in + k) = s;
   }
   // bias gradients ride on the first blocks: one thread per output column
-  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t col = (int64_t)blk * 256 + threadIdx.x;
   int base = 0;
   for (int q = 0; q < G.n; ++q) {
     if (G.p[q].db_off < 0) continue;
@@ -340,7 +402,13 @@ int64_t sst_weight_grad_group_f32x6_workspace_bytes(const sst_wgrad_problem_f32*
   return plan.part_bytes + plan.db_bytes;
 }
 
-int sst_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream) {
+}  // extern "C"
+
+// the group launch with a rider for the reduction kernel (csrc/layer_exec.hip: the LayerNorm backward's parameter-gradient
+// partials): partials [nb][width] -> out0 (columns < split) | out1
+int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, const float* rider,
+                                         int rider_nb, int rider_width, int rider_split, float* rider_out0, float* rider_out1,
+                                         void* stream) {
   x6_plan plan;
   if (!make_plan(problems, n, &plan)) return SST_ERR_UNSUPPORTED;
   if (!d_workspace || !aligned16(d_workspace)) return SST_ERR_ARG;
@@ -354,9 +422,22 @@ int sst_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, vo
   }
   hipLaunchKernelGGL(wgrad_x6_k, dim3((unsigned)(plan.g.tiles * plan.g.slices)), dim3(512), kLdsBytes, st, plan.g, part, dbp);
   const int64_t quads = (int64_t)plan.g.tiles * (kTile * kTile / 4);
-  hipLaunchKernelGGL(wgrad_x6_reduce_k, dim3((unsigned)sst_div_up(quads, (int64_t)64)), dim3(256), 0, st, plan.g, part, dbp);
+  const int tile_blocks = (int)sst_div_up(quads, (int64_t)kRedQuads);
+  x6_colsum_job job;
+  job.partials = rider;
+  job.nb = rider_nb, job.width = rider_width, job.split = rider_split;
+  job.out0 = rider_out0, job.out1 = rider_out1;
+  if (rider && (rider_nb < 1 || rider_nb > 512 || rider_width < 1 || !rider_out0 || !rider_out1)) return SST_ERR_ARG;
+  const int extra = rider ? (rider_width + 31) / 32 : 0;
+  hipLaunchKernelGGL(wgrad_x6_reduce_k, dim3((unsigned)(tile_blocks + extra)), dim3(256), 0, st, plan.g, part, dbp, extra, job);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+extern "C" {
+
+int sst_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream) {
+  return sst_internal_weight_grad_group_f32x6(problems, n, d_workspace, nullptr, 0, 0, 0, nullptr, nullptr, stream);
 }
 
 }  // extern "C"
