@@ -716,6 +716,11 @@ int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const floa
  *   head_scale (last field of both): NULL = softmax(q k^T * scale); else scaled cosine attention (sst_sra_attn_cos_*_f32),
  *             [n_heads] floats = 1 / clamp(tau, tau_min) in device memory, and the backward writes cos_r [m, n_heads]
  *             (d head_scale[h] = colsum(cos_r)[h] / head_scale[h], taken by the caller).
+ *   dy1 (last field of the backward arguments): scratch [m, 128] or NULL.  With it the gradient of y1 gets a buffer of its own
+ *             instead of being accumulated into ds2, all five parameter gradients of the layer leave in ONE grouped launch
+ *             (+ its reduction, which also finishes the LayerNorm parameter gradients) at the end of the layer: 9 launches
+ *             instead of 11.  NULL: two groups, each before the buffer it reads is accumulated into (the same gradients up to
+ *             the order of the fp32 partial sums: the token slices of a group differ).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sst_encoder_layer_fwd_args {
   int64_t m, n_windows;
@@ -742,6 +747,7 @@ typedef struct sst_encoder_layer_bwd_args {
   void* workspace;
   const float* head_scale;
   float* cos_r;
+  float* dy1;
 } sst_encoder_layer_bwd_args;
 int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads);
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* args, void* stream);

@@ -60,7 +60,7 @@ EncoderLayerBwdArgs = _struct('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args
                          'w_in', 'w_out', 'w1', 'w2', 'n1w', 'n2w', 'tok', 'winoff', 'order',
                          'ds2', 'dpre', 'ds1', 'd_o', 'dqkv',
                          'dw_in', 'db_in', 'dwo', 'dbo', 'dw1', 'db1', 'dw2', 'db2', 'dn1w', 'dn1b', 'dn2w', 'dn2b',
-                         'workspace', 'head_scale', 'cos_r')]))
+                         'workspace', 'head_scale', 'cos_r', 'dy1')]))
 
 
 EncoderLayerFwdBF16Args = _struct('EncoderLayerFwdBF16Args', 'sst_encoder_layer_fwd_bf16_args of include/sst_amd.h', (

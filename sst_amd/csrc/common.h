@@ -58,23 +58,22 @@ __device__ __forceinline__ int sst_wave_incl_scan(int v) {
 
 // Cross-file internals of the one-call layer executor (csrc/layer_exec.hip): the LayerNorm backward without its finishing launch
 // (csrc/dense.hip) and the weight-gradient group whose reduction launch also sums those partials' columns (csrc/wgrad_x6.hip).
-int sst_internal_add_layernorm_bwd2_partials_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
-                                                 const float* d_weight, int64_t m, int c, float* d_dx, void* d_workspace,
-                                                 int* partial_rows, void* stream);
 struct sst_colsum_rider {      // column sums of block partials [nb][width] -> out0 (columns < split) | out1; nb <= 512
   const float* partials;
   int nb, width, split;
   float* out0;
   float* out1;
 };
+int sst_internal_add_layernorm_bwd2_partials_f32(const float* d_dy, const float* d_dy2, const float* d_sum, const float* d_stats,
+                                                 const float* d_weight, int64_t m, int c, float* d_dx, void* d_workspace,
+                                                 int* partial_rows, void* stream);
 int sst_internal_add_layernorm_bwd_bf16_partials(const void* d_dy, const void* d_dy2, const void* d_sum, const float* d_stats,
                                                  const float* d_weight, int64_t m, int c, void* d_dx, void* d_workspace,
                                                  int* partial_rows, void* stream);
 int sst_internal_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_workspace, const sst_colsum_rider* riders,
                                   int n_riders, void* stream);
-int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, const float* rider,
-                                         int rider_nb, int rider_width, int rider_split, float* rider_out0, float* rider_out1,
-                                         void* stream);
+int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace,
+                                         const sst_colsum_rider* riders, int n_riders, void* stream);
 
 // Workspace carving on the host side (256-byte aligned slices of one caller-owned buffer).
 struct sst_carver {

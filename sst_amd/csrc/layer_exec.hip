@@ -16,18 +16,22 @@ namespace {
 enum { kEpiBias = 0, kEpiGelu = 1, kEpiRelu = 2, kEpiMulGeluGrad = 3, kEpiMulReluGrad = 4, kEpiAdd = 5 };
 constexpr int kC = 128, kFF = 256;
 
-int64_t wg_ws(int64_t m, int which) {   // workspace of the two weight-gradient groups of a layer
-  sst_wgrad_problem_f32 p[3];
+int64_t wg_ws(int64_t m, int which) {   // workspace of the two weight-gradient groups of a layer (which = 2: all five in one)
+  sst_wgrad_problem_f32 p[5];
   float* const any = (float*)(uintptr_t)256;   // the size query looks at shapes and alignment only; it wants non-null operands
   for (auto& q : p) {
     q.dy = q.x = any;
     q.dw = q.db = any;
     q.m = m;
   }
-  if (which == 0) {
+  if (which == 0 || which == 2) {
     p[0].ld_dy = kC, p[0].ld_x = kFF, p[0].out = kC, p[0].in = kFF;    // dW2 = ds2^T h
     p[1].ld_dy = kFF, p[1].ld_x = kC, p[1].out = kFF, p[1].in = kC;    // dW1 = dpre^T y1
-    return sst_weight_grad_group_f32x6_workspace_bytes(p, 2);
+    if (which == 0) return sst_weight_grad_group_f32x6_workspace_bytes(p, 2);
+    p[2].ld_dy = kC, p[2].ld_x = kC, p[2].out = kC, p[2].in = kC;
+    p[3].ld_dy = 3 * kC, p[3].ld_x = kC, p[3].out = 2 * kC, p[3].in = kC;
+    p[4].ld_dy = 3 * kC, p[4].ld_x = kC, p[4].out = kC, p[4].in = kC;
+    return sst_weight_grad_group_f32x6_workspace_bytes(p, 5);
   }
   p[0].ld_dy = kC, p[0].ld_x = kC, p[0].out = kC, p[0].in = kC;              // dWo = ds1^T o
   p[1].ld_dy = 3 * kC, p[1].ld_x = kC, p[1].out = 2 * kC, p[1].in = kC;      // dWq | dWk = [dq | dk]^T xp
@@ -49,10 +53,13 @@ extern "C" {
 int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads) {
   if (m < 0 || n_heads < 1) return SST_ERR_ARG;
   const int64_t a = sst_add_layernorm_bwd_workspace_bytes(m, kC), b = wg_ws(m, 0), c = wg_ws(m, 1),
-                d = sst_sra_attn_bwd_workspace_bytes(m, n_heads);
-  if (a < 0 || b < 0 || c < 0 || d < 0) return SST_ERR_UNSUPPORTED;
-  // the four users never overlap in time on the stream, but a kernel of one may still run when the next is queued: own pieces
-  return sst_align_up(a, 256) + sst_align_up(b, 256) + sst_align_up(c, 256) + sst_align_up(d, 256) + 256;
+                d = sst_sra_attn_bwd_workspace_bytes(m, n_heads), e = wg_ws(m, 2);
+  if (a < 0 || b < 0 || c < 0 || d < 0 || e < 0) return SST_ERR_UNSUPPORTED;
+  // the users never overlap in time on the stream, but a kernel of one may still run when the next is queued: own pieces.
+  // Two groups (dy1 == NULL): a | b | c | d.  One group: a | a (both LayerNorms' partials wait for the reduction) | e | d.
+  const int64_t two = sst_align_up(a, 256) + sst_align_up(b, 256) + sst_align_up(c, 256),
+                one = 2 * sst_align_up(a, 256) + sst_align_up(e, 256);
+  return (two > one ? two : one) + sst_align_up(d, 256) + 256;
 }
 
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* a, void* stream) {
@@ -94,40 +101,52 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
   if (a->m == 0) return SST_OK;
   if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->ds1 || !a->d_o || !a->dqkv) return SST_ERR_ARG;
+  if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
   const int64_t m = a->m;
+  const bool one_group = a->dy1 != nullptr;   // the gradient of y1 in a buffer of its own: ds2 stays what dW2 needs until the end
+  const int64_t ln_bytes = sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
   char* ws = (char*)a->workspace;
-  void* ws_ln = ws;
-  ws += sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
+  void* ws_ln2 = ws;                           // partials of norm2's parameter gradients
+  ws += ln_bytes;
+  void* ws_ln1 = one_group ? (void*)ws : ws_ln2;   // ... of norm1's: the same piece again when norm2's have been summed by then
+  if (one_group) ws += ln_bytes;
   void* ws_g1 = ws;
-  ws += sst_align_up(wg_ws(m, 0), 256);
+  ws += sst_align_up(wg_ws(m, one_group ? 2 : 0), 256);
   void* ws_g2 = ws;
-  ws += sst_align_up(wg_ws(m, 1), 256);
+  if (!one_group) ws += sst_align_up(wg_ws(m, 1), 256);
   void* ws_sra = ws;
   int rc;
-  // norm2 backward: d(y1 residual) = d(FFN output); the next layer's x + pos output arrives as a second gradient
-  // (d(gamma) | d(beta): the block partials stay in ws_ln, their columns are summed by the reduction launch of the next
+  sst_colsum_rider riders[2];
+  // norm2 backward: d(y1 residual) = d(FFN output); the next layer's x + pos output arrives as a second gradient.
+  // (d(gamma) | d(beta): the block partials stay in the workspace, their columns are summed by the reduction launch of the next
   // weight-gradient group - one finishing launch less per LayerNorm)
-  if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
-  int ln_rows = 0;
-  rc = sst_internal_add_layernorm_bwd2_partials_f32(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, ws_ln, &ln_rows, stream);
+  rc = sst_internal_add_layernorm_bwd2_partials_f32(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, ws_ln2, &riders[0].nb,
+                                                    stream);
   if (rc) return rc;
+  riders[0].partials = (const float*)ws_ln2, riders[0].width = 2 * kC, riders[0].split = kC;
+  riders[0].out0 = a->dn2w, riders[0].out1 = a->dn2b;
   // linear2's data gradient with the activation's derivative in the epilogue
   rc = sst_tall_linear_epi_f32x6(a->ds2, kC, a->w2, kFF, 1, nullptr, m, kC, kFF, a->act == 1 ? kEpiMulGeluGrad : kEpiMulReluGrad,
                                  a->pre, nullptr, kFF, a->dpre, kFF, stream);
   if (rc) return rc;
-  sst_wgrad_problem_f32 g1[2];
-  g1[0].dy = a->ds2, g1[0].x = a->h, g1[0].m = m, g1[0].ld_dy = kC, g1[0].ld_x = kFF, g1[0].dw = a->dw2, g1[0].db = a->db2;
-  g1[0].out = kC, g1[0].in = kFF;
-  g1[1].dy = a->dpre, g1[1].x = a->y1, g1[1].m = m, g1[1].ld_dy = kFF, g1[1].ld_x = kC, g1[1].dw = a->dw1, g1[1].db = a->db1;
-  g1[1].out = kFF, g1[1].in = kC;
-  // before ds2 is accumulated into
-  rc = sst_internal_weight_grad_group_f32x6(g1, 2, ws_g1, (const float*)ws_ln, ln_rows, 2 * kC, kC, a->dn2w, a->dn2b, stream);
+  sst_wgrad_problem_f32 g[5];
+  g[0].dy = a->ds2, g[0].x = a->h, g[0].m = m, g[0].ld_dy = kC, g[0].ld_x = kFF, g[0].dw = a->dw2, g[0].db = a->db2;
+  g[0].out = kC, g[0].in = kFF;
+  g[1].dy = a->dpre, g[1].x = a->y1, g[1].m = m, g[1].ld_dy = kFF, g[1].ld_x = kC, g[1].dw = a->dw1, g[1].db = a->db1;
+  g[1].out = kFF, g[1].in = kC;
+  if (!one_group) {   // before ds2 is accumulated into
+    rc = sst_internal_weight_grad_group_f32x6(g, 2, ws_g1, riders, 1, stream);
+    if (rc) return rc;
+  }
+  // residual + FFN branch: dy1 = ds2 + dpre W1 (in place unless dy1 has a buffer of its own)
+  float* dy1 = one_group ? a->dy1 : a->ds2;
+  rc = sst_tall_linear_epi_f32x6(a->dpre, kFF, a->w1, kC, 1, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, dy1, kC, stream);
   if (rc) return rc;
-  // residual + FFN branch: dy1 = ds2 + dpre W1 (in place)
-  rc = sst_tall_linear_epi_f32x6(a->dpre, kFF, a->w1, kC, 1, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, a->ds2, kC, stream);
+  sst_colsum_rider& r1 = riders[one_group ? 1 : 0];
+  rc = sst_internal_add_layernorm_bwd2_partials_f32(dy1, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, ws_ln1, &r1.nb, stream);
   if (rc) return rc;
-  rc = sst_internal_add_layernorm_bwd2_partials_f32(a->ds2, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, ws_ln, &ln_rows, stream);
-  if (rc) return rc;
+  r1.partials = (const float*)ws_ln1, r1.width = 2 * kC, r1.split = kC;
+  r1.out0 = a->dn1w, r1.out1 = a->dn1b;
   rc = sst_tall_linear_epi_f32x6(a->ds1, kC, a->w_out, kC, 1, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
   if (rc) return rc;
   if (a->head_scale != nullptr)
@@ -139,15 +158,16 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
                                   a->winoff, a->order, a->n_windows, m, a->n_heads, a->scale, a->max_tokens, a->impl, a->dqkv,
                                   a->dqkv + kC, a->dqkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, ws_sra, stream);
   if (rc) return rc;
-  sst_wgrad_problem_f32 g2[3];
+  sst_wgrad_problem_f32* g2 = g + 2;
   g2[0].dy = a->ds1, g2[0].x = a->o, g2[0].m = m, g2[0].ld_dy = kC, g2[0].ld_x = kC, g2[0].dw = a->dwo, g2[0].db = a->dbo;
   g2[0].out = kC, g2[0].in = kC;
   g2[1].dy = a->dqkv, g2[1].x = a->xp, g2[1].m = m, g2[1].ld_dy = 3 * kC, g2[1].ld_x = kC, g2[1].dw = a->dw_in, g2[1].db = a->db_in;
   g2[1].out = 2 * kC, g2[1].in = kC;
   g2[2].dy = a->dqkv + 2 * kC, g2[2].x = a->x, g2[2].m = m, g2[2].ld_dy = 3 * kC, g2[2].ld_x = kC;
   g2[2].dw = a->dw_in + 2 * kC * kC, g2[2].db = a->db_in + 2 * kC, g2[2].out = kC, g2[2].in = kC;
-  // before ds1 is accumulated into
-  rc = sst_internal_weight_grad_group_f32x6(g2, 3, ws_g2, (const float*)ws_ln, ln_rows, 2 * kC, kC, a->dn1w, a->dn1b, stream);
+  // before ds1 is accumulated into: the three gradients that read it and dqkv - or, with dy1, all five of the layer
+  rc = one_group ? sst_internal_weight_grad_group_f32x6(g, 5, ws_g1, riders, 2, stream)
+                 : sst_internal_weight_grad_group_f32x6(g2, 3, ws_g2, riders, 1, stream);
   if (rc) return rc;
   // d(x) of the residual branch and of all three projections: one product over K = 384 (xp = x + constant: d(x) += d(xp))
   return sst_tall_linear_epi_f32x6(a->dqkv, 3 * kC, a->w_in, kC, 1, nullptr, m, 3 * kC, kC, kEpiAdd, a->ds1, nullptr, kC, a->ds1, kC,

@@ -240,29 +240,30 @@ __global__ __launch_bounds__(512, 2) void wgrad_x6_k(const x6_group G, float* __
 // quad, 64 workgroups - 26 us for 17 MB; second: 64 quads x 4 groups, 256 workgroups - 14 us; 16 quads x 16 groups with
 // 4-byte stores: 256-byte runs per wave and load, 30 us.)
 //
-// A second, optional job rides on the launch (extra workgroups behind the tile ones): the column sums of another kernel's block
-// partials - the LayerNorm backward's d(gamma) | d(beta) partials [nb][2 c] (csrc/dense.hip add_ln_bwd_*), in the arithmetic of
-// colsum_partials_k (32 strided partial sums per column, added in order), so that the one-call layer executor needs no
-// finishing launch of its own for them.
-struct x6_colsum_job {
-  const float* partials;   // [nb][width], NULL: no job
-  int nb, width, split;
-  float* out0;             // columns [0, split)
-  float* out1;             // columns [split, width)
+// Optional riders (sst_colsum_rider, csrc/common.h; the FIRST workgroups of the launch): the column sums of another kernel's
+// block partials - the LayerNorm backward's d(gamma) | d(beta) partials [nb][2 c] (csrc/dense.hip add_ln_bwd_*), in the
+// arithmetic of colsum_partials_k (32 strided partial sums per column, added in order), so that the one-call layer executor
+// needs no finishing launch of its own for them.
+struct x6_riders {
+  sst_colsum_rider r[2];
+  int n, blocks0;          // blocks0: workgroups of rider 0 (the rest of the rider blocks belong to rider 1)
 };
 
 constexpr int kRedQuads = 32, kRedGroups = 8;
 
 __global__ __launch_bounds__(256) void wgrad_x6_reduce_k(const x6_group G, const float* __restrict__ part,
                                                          const float* __restrict__ dbp, int rider_blocks,
-                                                         const x6_colsum_job J) {
+                                                         const x6_riders R) {
   __shared__ double red[kRedGroups][kRedQuads][4];
   if ((int)blockIdx.x < rider_blocks) {
+    const int second = (int)blockIdx.x >= R.blocks0 ? 1 : 0;
+    const sst_colsum_rider& J = R.r[second];
+    const int rblk = (int)blockIdx.x - (second ? R.blocks0 : 0);
     // column sums of the rider (the FIRST workgroups: they start with the launch and end inside it): this workgroup = 32
     // columns; thread (cx, gq) forms the four strided sums gy = gq + 8 j side by side, each in colsum_partials_k's order
     float* fr = (float*)&red[0][0][0];                       // [32][33] floats
     const int cx = threadIdx.x & 31, gq = threadIdx.x >> 5;
-    const int i = (int)blockIdx.x * 32 + cx;
+    const int i = rblk * 32 + cx;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < J.width) {
       // the partials were written several kernels ago (600 MB of operands have passed through the caches since): every load
@@ -406,9 +407,8 @@ int64_t sst_weight_grad_group_f32x6_workspace_bytes(const sst_wgrad_problem_f32*
 
 // the group launch with a rider for the reduction kernel (csrc/layer_exec.hip: the LayerNorm backward's parameter-gradient
 // partials): partials [nb][width] -> out0 (columns < split) | out1
-int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, const float* rider,
-                                         int rider_nb, int rider_width, int rider_split, float* rider_out0, float* rider_out1,
-                                         void* stream) {
+int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace,
+                                         const sst_colsum_rider* riders, int n_riders, void* stream) {
   x6_plan plan;
   if (!make_plan(problems, n, &plan)) return SST_ERR_UNSUPPORTED;
   if (!d_workspace || !aligned16(d_workspace)) return SST_ERR_ARG;
@@ -423,13 +423,18 @@ int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, 
   hipLaunchKernelGGL(wgrad_x6_k, dim3((unsigned)(plan.g.tiles * plan.g.slices)), dim3(512), kLdsBytes, st, plan.g, part, dbp);
   const int64_t quads = (int64_t)plan.g.tiles * (kTile * kTile / 4);
   const int tile_blocks = (int)sst_div_up(quads, (int64_t)kRedQuads);
-  x6_colsum_job job;
-  job.partials = rider;
-  job.nb = rider_nb, job.width = rider_width, job.split = rider_split;
-  job.out0 = rider_out0, job.out1 = rider_out1;
-  if (rider && (rider_nb < 1 || rider_nb > 512 || rider_width < 1 || !rider_out0 || !rider_out1)) return SST_ERR_ARG;
-  const int extra = rider ? (rider_width + 31) / 32 : 0;
-  hipLaunchKernelGGL(wgrad_x6_reduce_k, dim3((unsigned)(tile_blocks + extra)), dim3(256), 0, st, plan.g, part, dbp, extra, job);
+  if (n_riders < 0 || n_riders > 2 || (n_riders > 0 && !riders)) return SST_ERR_ARG;
+  x6_riders R;
+  R.n = n_riders, R.blocks0 = 0;
+  int extra = 0;
+  for (int i = 0; i < n_riders; ++i) {
+    const sst_colsum_rider& q = riders[i];
+    if (!q.partials || q.nb < 1 || q.nb > 512 || q.width < 1 || !q.out0 || !q.out1) return SST_ERR_ARG;
+    R.r[i] = q;
+    if (i == 0) R.blocks0 = (q.width + 31) / 32;
+    extra += (q.width + 31) / 32;
+  }
+  hipLaunchKernelGGL(wgrad_x6_reduce_k, dim3((unsigned)(tile_blocks + extra)), dim3(256), 0, st, plan.g, part, dbp, extra, R);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }
@@ -437,7 +442,7 @@ int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, 
 extern "C" {
 
 int sst_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream) {
-  return sst_internal_weight_grad_group_f32x6(problems, n, d_workspace, nullptr, 0, 0, 0, nullptr, nullptr, stream);
+  return sst_internal_weight_grad_group_f32x6(problems, n, d_workspace, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -183,12 +183,15 @@ def _linear_fwd(x, w, b):
     return torch.addmm(b, x, w.t())
 
 
-def _linear_dgrad(dy, w, out=None):
-    """dy @ w (w: [out_features, in_features]); ``out`` given: out += dy @ w in place."""
+def _linear_dgrad(dy, w, out=None, add=None):
+    """dy @ w (w: [out_features, in_features]); ``out`` given: out += dy @ w in place; ``add`` given as well: out = add + dy @ w
+    (``add`` untouched)."""
     if _LDS_LINEAR and lds_linear_ok(dy, w, trans_w=True):
         if out is not None:
-            return lds_linear(dy, w, None, EPI_ADD, trans_w=True, aux_in=out, out=out)
+            return lds_linear(dy, w, None, EPI_ADD, trans_w=True, aux_in=out if add is None else add, out=out)
         return lds_linear(dy, w, None, trans_w=True)
+    if out is not None and add is not None:
+        out.copy_(add)
     if _TALL_GEMM and w.size(1) == 128 and (w.size(0) == 128 or _TALL_GEMM > 1):
         y = tall_gemm(dy, w, None, trans_w=True, out=out, accumulate=out is not None)
         if y is not None:
@@ -285,9 +288,9 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     dy2 = dy2.contiguous()
     dy2p = dy2p.contiguous() if dy2p is not None else None
     ds1 = e(m, 128)                                    # leaves as d(x)
-    scratch = e(m, 128 + 256 + 128 + 384)              # ds2 | dpre | d_o | dqkv, one after the other (not interleaved)
+    scratch = e(m, 128 + 256 + 128 + 384 + 128)        # ds2 | dpre | d_o | dqkv | dy1, one after the other (not interleaved)
     sb = scratch.data_ptr()
-    p_ds2, p_dpre, p_do, p_dqkv = sb, sb + 4 * m * 128, sb + 4 * m * 384, sb + 4 * m * 512
+    p_ds2, p_dpre, p_do, p_dqkv, p_dy1 = sb, sb + 4 * m * 128, sb + 4 * m * 384, sb + 4 * m * 512, sb + 4 * m * 896
     dw_in, db_in, dwo, dbo = e(384, 128), e(384), e(128, 128), e(128)
     dw1, db1, dw2, db2 = e(256, 128), e(256), e(128, 256), e(128)
     dn = e(4, 128)
@@ -308,7 +311,7 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         p_ds2, p_dpre, P(ds1), p_do, p_dqkv,
         P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 512, dnp + 1024, dnp + 1536, P(ws),
-        P(head_scale), P(cos_r))
+        P(head_scale), P(cos_r), p_dy1)
     rc = K._bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_encoder_layer_bwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
     d_scale = K.head_scale_grad(cos_r, head_scale) if head_scale is not None else None
@@ -442,9 +445,9 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=x.device)
         dw2, db2 = torch.empty_like(w2), torch.empty(w2.size(0), **f32)
         dw1, db1 = torch.empty_like(w1), torch.empty(w1.size(0), **f32)
-        # dW2 must be taken BEFORE the next GEMM accumulates into ds2 in place: first group (2 problems) here
-        weight_bias_grad_group([(ds2_for_w2, h, dw2, db2), (dpre, y1, dw1, db1)])
-        dy1 = _linear_dgrad(dpre, w1, out=ds2)                        # residual + FFN branch: GEMM with beta = 1
+        # residual + FFN branch: GEMM with beta = 1 into a buffer of its OWN - ds2 stays what dW2 needs, and all five parameter
+        # gradients of the layer leave in one grouped launch at the end (csrc/layer_exec.hip does the same: 9 launches, not 11)
+        dy1 = _linear_dgrad(dpre, w1, out=torch.empty_like(ds2), add=ds2)
         ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
         do = _linear_dgrad(ds1, w_out)
         # dq | dk | dv in ONE [M, 3C] buffer: d(x) of the whole in-projection is then a single GEMM
@@ -461,8 +464,9 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * c, **f32)
         dwo, dbo = torch.empty_like(w_out), torch.empty(w_out.size(0), **f32)
-        # second group (3 problems), before ds1 is accumulated into in place
-        weight_bias_grad_group([(ds1, o, dwo, dbo), (dqk, xp, dw_in[:2 * c], db_in[:2 * c]), (dv, x, dw_in[2 * c:], db_in[2 * c:])])
+        # all five, before ds1 is accumulated into in place
+        weight_bias_grad_group([(ds2_for_w2, h, dw2, db2), (dpre, y1, dw1, db1), (ds1, o, dwo, dbo),
+                                (dqk, xp, dw_in[:2 * c], db_in[:2 * c]), (dv, x, dw_in[2 * c:], db_in[2 * c:])])
         dxp = None
         if ctx.fold_xp and _LDS_LINEAR and c == 128 and lds_linear_dqkv_ok(dqkv, w_in):
             # xp = x + pos with a constant pos: d(x) += d(xp), so the residual branch and all three projections leave as ONE
