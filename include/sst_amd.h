@@ -988,6 +988,12 @@ int64_t sst_spconv_wgrad_os_workspace_bytes(int kvol, int64_t pair_ld, int64_t t
 int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                             int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
                             int cout, float* d_dw, void* d_workspace, void* stream);
+/*   sst_spconv_wgrad_os_f32x6: the same gradient from the exact three-way bf16 split of both gathered operands (six products on the
+ *   bf16 matrix pipe, fp32 accumulation, two accumulator sets; csrc/spconv_os.hip sp_wgrad_os_x6_k): the filter-gradient half of
+ *   the 'f32x6' convolution precision.  Same arguments and workspace as sst_spconv_wgrad_os_f32. */
+int sst_spconv_wgrad_os_f32x6(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+                            int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
+                            int cout, float* d_dw, void* d_workspace, void* stream);
 int64_t sst_spconv_wgrad_workspace_bytes(int kvol, int64_t pair_ld, int64_t total_pairs, int cin, int cout);
 int sst_spconv_wgrad_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                          int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,

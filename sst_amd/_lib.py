@@ -248,6 +248,8 @@ _SIGNATURES = {
     'sst_spconv_wgrad_os_workspace_bytes': (c_i64, [c_i32, c_i64, c_i64, c_i32, c_i32]),
     'sst_spconv_wgrad_os_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32,
                                         c_ptr, c_ptr, c_ptr]),
+    'sst_spconv_wgrad_os_f32x6': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32,
+                                        c_ptr, c_ptr, c_ptr]),
     'sst_spconv_wgrad_workspace_bytes': (c_i64, [c_i32, c_i64, c_i64, c_i32, c_i32]),
     'sst_spconv_wgrad_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_i32, c_i32,
                                      c_ptr, c_ptr, c_ptr]),

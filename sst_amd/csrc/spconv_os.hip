@@ -485,6 +485,173 @@ __global__ __launch_bounds__(256) void sp_wgrad_os_reduce_k(const float* __restr
   dw[(int64_t)k * per_k + e] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same filter gradient from the EXACT three-way bf16 split of both gathered operands (csrc/dense_f32x6.hip, csrc/wgrad_x6.hip,
+// csrc/spconv_os_x6.hip: x = x0 + x1 + x2, dy = d0 + d1 + d2, the six products with i + j <= 2 on v_mfma_f32_16x16x32_bf16, fp32
+// accumulation, two accumulator sets): 48 bf16 instructions = 768 matrix-pipe cycles per wave and 64-pair stage against
+// 64 x v_mfma_f32_16x16x4_f32 = 2 048 for sp_wgrad_os_k, which that pipe bounds (4.8 of 25.5 ms of an FSD step, 10.1 of 49 ms
+// of an FSDv2 step).  Same decomposition (64 x 64 block of dW[k], chunk of pairs, wave = 32 x 32 quadrant, stage = 64 pairs,
+// rows global -> registers -> LDS transposed, indices two stages ahead), different LDS image: per operand three bf16 images
+// [64 channels][64 pairs] of 128-byte rows, written as 8-byte groups of 4 consecutive pairs (a thread stages 4 consecutive
+// pairs x 4 channels: its split yields the three parts of 4 pairs per channel), read as the 16-byte fragments the
+// instruction wants (lane (l15, g): 8 consecutive pairs 32 ks + 8 g .. of channel row l15).  16-byte unit G of row r sits at
+// G ^ f(r), f(r) = ((r >> 1) & 7) ^ ((r >> 3) & 7): the sixteen rows of a fragment read cover all 64 banks once, the sixteen
+// channel blocks of a write land two per 8-byte slot.  One buffer (48 KB, three workgroups per CU): the stage in registers
+// waits for a barrier behind the products of the stage in LDS.
+__device__ __forceinline__ unsigned wx6_pack2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void wx6_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = wx6_pack2(a, b);
+  const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+  p1 = wx6_pack2(ra, rb);
+  p2 = wx6_pack2(ra - __uint_as_float(p1 << 16), rb - __uint_as_float(p1 & 0xffff0000u));
+}
+typedef unsigned wx6_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wx6_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 wx6_mma(wx6_u32x4 a, wx6_u32x4 b, f32x4 c) {
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int wx6_unit(int row, int G) { return (G ^ ((row >> 1) & 7) ^ ((row >> 3) & 7)) & 7; }
+
+__global__ __launch_bounds__(256) void sp_wgrad_os_x6_k(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ dy, int64_t lddy,
+                                                        const int32_t* __restrict__ pairs, int64_t pair_ld, int x_side,
+                                                        const int32_t* __restrict__ num, int kvol, int cin, int cout,
+                                                        int n_bj, int csize, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[6][64 * 128];   // X parts 0..2, dY parts 0..2
+  int k, first;
+  if (!os_find_chunk(num, kvol, blockIdx.x, csize, k, first)) return;  // uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int bi = blockIdx.y / n_bj, bj = blockIdx.y - bi * n_bj;
+  const int ci0 = bi * 64, co0 = bj * 64;
+  const int np = num[k];
+  const int p0 = (blockIdx.x - first) * csize;
+  const int p1 = p0 + csize < np ? p0 + csize : np;
+  const int32_t* pa = pairs + ((int64_t)k * 2 + x_side) * pair_ld;
+  const int32_t* pb = pairs + ((int64_t)k * 2 + (1 - x_side)) * pair_ld;
+  // staging role of this thread: pairs 4 pq + u (u < 4) of the stage, channels 4 ch4 .. + 3 of the block
+  const int ch4 = tid & 15, pq = tid >> 4;
+  int ca = ci0 + 4 * ch4, cb = co0 + 4 * ch4;
+  ca = ca < cin - 4 ? ca : cin - 4;      // channel tails: a clamped (finite) piece whose products are never stored
+  cb = cb < cout - 4 ? cb : cout - 4;
+  int ia[4], ib[4];
+  f32x4 ra[4], rb[4];
+  bool live[4];
+  auto load_idx = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int pp = p + 4 * pq + u;
+      pp = pp < p1 ? pp : p1 - 1;
+      ia[u] = pa[pp];
+      ib[u] = pb[pp];
+    }
+  };
+  auto load_rows = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      live[u] = p + 4 * pq + u < p1;
+      ra[u] = *(const f32x4*)(x + (int64_t)ia[u] * ldx + ca);
+      rb[u] = *(const f32x4*)(dy + (int64_t)ib[u] * lddy + cb);
+    }
+  };
+  auto store_rows = [&]() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 4 * ch4 + e;
+      const int off = row * 128 + wx6_unit(row, pq >> 1) * 16 + (pq & 1) * 8;
+      unsigned a0[2], a1[2], a2[2], b0[2], b1[2], b2[2];
+      wx6_split2(live[0] ? ra[0][e] : 0.f, live[1] ? ra[1][e] : 0.f, a0[0], a1[0], a2[0]);
+      wx6_split2(live[2] ? ra[2][e] : 0.f, live[3] ? ra[3][e] : 0.f, a0[1], a1[1], a2[1]);
+      wx6_split2(rb[0][e], rb[1][e], b0[0], b1[0], b2[0]);
+      wx6_split2(rb[2][e], rb[3][e], b0[1], b1[1], b2[1]);
+      *(wx6_u32x2*)(img[0] + off) = (wx6_u32x2){a0[0], a0[1]};
+      *(wx6_u32x2*)(img[1] + off) = (wx6_u32x2){a1[0], a1[1]};
+      *(wx6_u32x2*)(img[2] + off) = (wx6_u32x2){a2[0], a2[1]};
+      *(wx6_u32x2*)(img[3] + off) = (wx6_u32x2){b0[0], b0[1]};
+      *(wx6_u32x2*)(img[4] + off) = (wx6_u32x2){b1[0], b1[1]};
+      *(wx6_u32x2*)(img[5] + off) = (wx6_u32x2){b2[0], b2[1]};
+    }
+  };
+  f32x4 acc[2][2], cor[2][2];   // leading product | the five corrections
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = cor[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;   // this wave's quadrant of the 64 x 64 block
+  load_idx(p0);
+  load_rows(p0);
+  load_idx(p0 + kWgStage);
+  store_rows();
+  __syncthreads();
+  for (int p = p0; p < p1; p += kWgStage) {
+    load_rows(p + kWgStage);        // rows of the next stage (their indices were requested a stage ago)
+    load_idx(p + 2 * kWgStage);     // indices of the stage after it
+    __builtin_amdgcn_sched_barrier(0);   // the loads are issued HERE, in front of the products that hide their latency
+#pragma unroll
+    for (int ks = 0; ks < kWgStage / 32; ++ks) {
+      wx6_u32x4 af[2][3], bf[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ra_ = wi + 16 * h + l15, rb_ = wj + 16 * h + l15;
+        const int oa = ra_ * 128 + wx6_unit(ra_, 4 * ks + g) * 16, ob = rb_ * 128 + wx6_unit(rb_, 4 * ks + g) * 16;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          af[h][q] = *(const wx6_u32x4*)(img[q] + oa);
+          bf[h][q] = *(const wx6_u32x4*)(img[3 + q] + ob);
+        }
+      }
+      // smallest products first (x2 d0, x0 d2, x1 d1 ~ 2^-16; x1 d0, x0 d1 ~ 2^-8), product by product over the four tiles
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cor[a][b] = wx6_mma(af[a][2], bf[b][0], cor[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cor[a][b] = wx6_mma(af[a][0], bf[b][2], cor[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cor[a][b] = wx6_mma(af[a][1], bf[b][1], cor[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cor[a][b] = wx6_mma(af[a][1], bf[b][0], cor[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cor[a][b] = wx6_mma(af[a][0], bf[b][1], cor[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = wx6_mma(af[a][0], bf[b][0], acc[a][b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                // every wave has read this stage's images
+    store_rows();
+    __syncthreads();
+  }
+  // D[i][j]: lane = (j = l15, rows i = 4 g + r): dW[k][ci0 + wi + 16 a + 4 g + r][co0 + wj + 16 b + l15]
+  float* dst = part + (int64_t)blockIdx.x * cin * cout;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int n = co0 + wj + 16 * b + l15;
+      if (n >= cout) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = ci0 + wi + 16 * a + 4 * g + r;
+        if (c < cin) dst[(int64_t)c * cout + n] = acc[a][b][r] + cor[a][b][r];
+      }
+    }
+}
+
 // pairs per workgroup: 2048 when that still gives every CU a few workgroups, down to 512 for the thin levels (a level with
 // 5 partners per voxel has 330 chunks of 2048 pairs for 256 CUs)
 int os_wgrad_chunk_size(int kvol, int64_t pair_ld, int64_t total_pairs, int n_blocks) {
@@ -632,7 +799,7 @@ int64_t sst_spconv_wgrad_os_workspace_bytes(int kvol, int64_t pair_ld, int64_t t
   return os_wgrad_chunks(kvol, pair_ld, total_pairs, csize) * cin * cout * (int64_t)sizeof(float) + 256;
 }
 
-int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+static int wgrad_os_any(int split, const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
                             int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
                             int cout, float* d_dw, void* d_workspace, void* stream) {
   if (kvol < 1 || cin < 1 || cout < 1 || ldx < cin || lddy < cout || pair_ld < 0 || (x_side != 0 && x_side != 1))
@@ -651,12 +818,30 @@ int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, in
   const int64_t chunks = os_wgrad_chunks(kvol, pair_ld, total_pairs, csize);
   if (kvol > 65535 || chunks > 0x7fffffff || n_bi * n_bj > 65535) return SST_ERR_UNSUPPORTED;
   float* part = (float*)d_workspace;
-  hipLaunchKernelGGL(sp_wgrad_os_k, dim3((unsigned)chunks, (unsigned)(n_bi * n_bj)), dim3(256), 0, st, d_x, ldx, d_dy, lddy,
-                     d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, n_bj, csize, part);
+  if (split)
+    hipLaunchKernelGGL(sp_wgrad_os_x6_k, dim3((unsigned)chunks, (unsigned)(n_bi * n_bj)), dim3(256), 0, st, d_x, ldx, d_dy, lddy,
+                       d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, n_bj, csize, part);
+  else
+    hipLaunchKernelGGL(sp_wgrad_os_k, dim3((unsigned)chunks, (unsigned)(n_bi * n_bj)), dim3(256), 0, st, d_x, ldx, d_dy, lddy,
+                       d_pairs, pair_ld, x_side, d_num, kvol, cin, cout, n_bj, csize, part);
   hipLaunchKernelGGL(sp_wgrad_os_reduce_k, dim3((unsigned)sst_div_up(per_k, 256), (unsigned)kvol), dim3(256), 0, st, part,
                      d_num, kvol, per_k, csize, d_dw);
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_spconv_wgrad_os_f32(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+                            int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
+                            int cout, float* d_dw, void* d_workspace, void* stream) {
+  return wgrad_os_any(0, d_x, ldx, d_dy, lddy, d_pairs, pair_ld, total_pairs, x_side, d_num, kvol, cin, cout, d_dw, d_workspace,
+                      stream);
+}
+
+int sst_spconv_wgrad_os_f32x6(const float* d_x, int64_t ldx, const float* d_dy, int64_t lddy, const int32_t* d_pairs,
+                              int64_t pair_ld, int64_t total_pairs, int x_side, const int32_t* d_num, int kvol, int cin,
+                              int cout, float* d_dw, void* d_workspace, void* stream) {
+  return wgrad_os_any(1, d_x, ldx, d_dy, lddy, d_pairs, pair_ld, total_pairs, x_side, d_num, kvol, cin, cout, d_dw, d_workspace,
+                      stream);
 }
 
 }  // extern "C"

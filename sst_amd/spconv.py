@@ -388,9 +388,13 @@ def _wgrad(x, dy, rb, pairs, x_side, shape):
     if (_conv_kernel_choice() == 'os' and cin % 4 == 0 and cout % 4 == 0 and ldx % 4 == 0 and lddy % 4 == 0
             and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0):
         ws = _lib.workspace(lib.sst_spconv_wgrad_os_workspace_bytes(kvol, rb.n, total, cin, cout), x.device)
-        rc = lib.sst_spconv_wgrad_os_f32(_lib.ptr(x), ldx, _lib.ptr(dy), lddy, _lib.ptr(pairs), rb.n, total, x_side,
-                                         _lib.ptr(rb.num), kvol, cin, cout, _lib.ptr(dw), _lib.ptr(ws), _lib.stream_ptr())
-        _lib.check(rc, 'sst_spconv_wgrad_os_f32')
+        # the filter gradient multiplies the way the convolution does: exact three-way bf16 split ('f32x6', the default) or the
+        # fp32 matrix pipe ('f32'; 'f32x3' has no filter-gradient kernel of its own and takes the fp32 one)
+        name = ('sst_spconv_wgrad_os_f32x6' if (_CONV_PRECISION == 'f32x6' and os.environ.get('SST_SPCONV_WGRAD_X6', '1') != '0')
+                else 'sst_spconv_wgrad_os_f32')     # SST_SPCONV_WGRAD_X6=0: A/B against the fp32-pipe kernel
+        rc = getattr(lib, name)(_lib.ptr(x), ldx, _lib.ptr(dy), lddy, _lib.ptr(pairs), rb.n, total, x_side,
+                                _lib.ptr(rb.num), kvol, cin, cout, _lib.ptr(dw), _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, name)
         return dw.view(shape)
     ws = _lib.workspace(lib.sst_spconv_wgrad_workspace_bytes(kvol, rb.n, total, cin, cout), x.device)
     rc = lib.sst_spconv_wgrad_f32(_lib.ptr(x), ldx, _lib.ptr(dy), lddy, _lib.ptr(pairs), rb.n, total, x_side,

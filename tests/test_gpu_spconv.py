@@ -185,19 +185,24 @@ def test_exact_split_convolution_kernel(cin, cout):
             gy = torch.randn(m, cout, generator=gen)
             p_np, n_np = pairs.cpu().numpy(), num.cpu().numpy()
             y_ref = O.indice_conv(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), p_np, n_np, m)
-            dx_ref, _ = O.indice_conv_backward(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), gy.numpy(), p_np, n_np)
+            dx_ref, dw_ref = O.indice_conv_backward(x.numpy(), w.numpy().reshape(3, 3, 3, cin, cout), gy.numpy(), p_np, n_np)
+            dw_ref = np.asarray(dw_ref).reshape(27, cin, cout)
             errs, outs = {}, {}
             for mode in ('f32', 'f32x6'):
                 spconv.set_conv_precision(mode)
                 y = spconv._gather_gemm(x.to(DEV), rb.out2in, m, w.to(DEV), False, cout, rb)
                 dx = spconv._gather_gemm(gy.to(DEV), rb.in2out, n, w.to(DEV), True, cin, rb)
-                outs[mode] = y
-                errs[mode] = (np.abs(y.cpu().numpy() - y_ref).max(), np.abs(dx.cpu().numpy() - dx_ref).max())
-            sy, sx = max(1.0, np.abs(y_ref).max()), max(1.0, np.abs(dx_ref).max())
+                # the filter gradient (csrc/spconv_os.hip sp_wgrad_os_x6_k beside sp_wgrad_os_k): same bar
+                dw = spconv._wgrad(x.to(DEV), gy.to(DEV), rb, pairs, 0, (27, cin, cout))
+                outs[mode] = (y, dw)
+                errs[mode] = (np.abs(y.cpu().numpy() - y_ref).max(), np.abs(dx.cpu().numpy() - dx_ref).max(),
+                              np.abs(dw.cpu().numpy() - dw_ref).max())
+            sy, sx, sw = max(1.0, np.abs(y_ref).max()), max(1.0, np.abs(dx_ref).max()), max(1.0, np.abs(dw_ref).max())
             assert errs['f32x6'][0] <= max(2.0 * errs['f32'][0], 2e-7 * sy), (errs, sy)
             assert errs['f32x6'][1] <= max(2.0 * errs['f32'][1], 2e-7 * sx), (errs, sx)
-            assert errs['f32x6'][0] <= 5e-6 * sy and errs['f32x6'][1] <= 5e-6 * sx
-            assert not torch.equal(outs['f32'], outs['f32x6'])
+            assert errs['f32x6'][2] <= max(2.0 * errs['f32'][2], 2e-7 * sw), (errs, sw)
+            assert errs['f32x6'][0] <= 5e-6 * sy and errs['f32x6'][1] <= 5e-6 * sx and errs['f32x6'][2] <= 5e-6 * sw
+            assert not torch.equal(outs['f32'][0], outs['f32x6'][0]) and not torch.equal(outs['f32'][1], outs['f32x6'][1])
     finally:
         spconv.set_conv_precision(spconv.DEFAULT_CONV_PRECISION)
 
