@@ -529,7 +529,7 @@ def config_as_is_leg(args, dev, frames, sync):
     return res
 
 
-def self_launch(n_ranks):
+def self_launch(n_ranks, line_out=None):
     """Re-run this script under torch.distributed.run with one process per GPU of this node."""
     import socket
     import subprocess
@@ -542,19 +542,32 @@ def self_launch(n_ranks):
     env.setdefault('OMP_NUM_THREADS', '8')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_ranks}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # the ranks inherit the ORIGINAL stdout (this process's fd 1 is a copy of stderr by now: main())
+    if line_out is not None:
+        line_out.flush()
+    return subprocess.call(cmd, env=env, stdout=line_out if line_out is not None else None)
 
 
 def main():
     # the contract: rank 0 prints ONE JSON line.  Modules built from a shipped config print (the input layer announces its
     # drop_info unless `mute` is set): everything but the line goes to stderr.
+    # ... at the level of the file descriptor too: native libraries write to fd 1 themselves (gloo announces its peers there when a
+    # process group is created; RCCL's diagnostics go there when NCCL_DEBUG is set) - fd 1 becomes a copy of stderr, the line is
+    # written to a private duplicate of the original stdout.
     args = parse_args()          # --help goes to the real stdout
-    line_out = sys.stdout
+    python_stdout = sys.stdout
+    sys.stdout.flush()
+    try:
+        line_out = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+    except OSError:              # no usable descriptors (embedded interpreter): the Python-level redirection alone
+        line_out = python_stdout
     sys.stdout = sys.stderr
     try:
         _main(args, line_out)
     finally:
-        sys.stdout = line_out
+        line_out.flush()
+        sys.stdout = python_stdout
 
 
 def parse_args():
@@ -638,7 +651,7 @@ def _main(args, line_out):
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # launched as plain `python bench.py --gpus N`: start one rank per GPU ourselves, the way the reference's
         # tools/dist_train.sh:7-9 does (torch.distributed.launch --nproc_per_node=$GPUS); rank 0 prints the JSON line
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, line_out))
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
