@@ -297,8 +297,12 @@ int launch_linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const float* bi
   if (nth == 0) {
     const char* e = getenv("SST_AMD_BF16_LINEAR_WAVES");
     nth = (e != nullptr && atoi(e) == 8) ? 512 : 256;
+  }
+  static unsigned long long configured = 0;     // the attribute belongs to a (kernel, device) pair
+  if (sst_first_use_on_device(&configured)) {
     SST_HIP(hipFuncSetAttribute((const void*)tall_linear_bf16_k<K, N, EPI, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     SST_HIP(hipFuncSetAttribute((const void*)tall_linear_bf16_k<K, N, EPI, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    sst_mark_device(&configured);
   }
   // persistent shape: every wave a contiguous row range (multiple of 16 rows)
   const int wpb = nth / 64;
