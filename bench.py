@@ -548,6 +548,20 @@ def self_launch(n_ranks, line_out=None):
     return subprocess.call(cmd, env=env, stdout=line_out if line_out is not None else None)
 
 
+def claim_stdout():
+    """-> a file object on a private duplicate of the process's stdout; fd 1 itself and sys.stdout become copies of stderr, so
+    that nothing but what is written to the returned object - the JSON line - reaches the caller's stdout, whoever prints
+    (Python code, native libraries, child processes that inherit fd 1).  tests/test_bench_contract.py."""
+    sys.stdout.flush()
+    try:
+        line_out = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+    except OSError:              # no usable descriptors (embedded interpreter): the Python-level redirection alone
+        line_out = sys.stdout
+    sys.stdout = sys.stderr
+    return line_out
+
+
 def main():
     # the contract: rank 0 prints ONE JSON line.  Modules built from a shipped config print (the input layer announces its
     # drop_info unless `mute` is set): everything but the line goes to stderr.
@@ -556,13 +570,7 @@ def main():
     # written to a private duplicate of the original stdout.
     args = parse_args()          # --help goes to the real stdout
     python_stdout = sys.stdout
-    sys.stdout.flush()
-    try:
-        line_out = os.fdopen(os.dup(1), 'w')
-        os.dup2(2, 1)
-    except OSError:              # no usable descriptors (embedded interpreter): the Python-level redirection alone
-        line_out = python_stdout
-    sys.stdout = sys.stderr
+    line_out = claim_stdout()
     try:
         _main(args, line_out)
     finally:
