@@ -1,5 +1,9 @@
 #!/bin/bash
-# same-box A/B of two builds of the library: SST_AMD_LIB=<base .so> against the in-tree one
+# same-box A/B of two builds of the library: SST_AMD_LIB=<base .so> against the in-tree one.
+# The base build is made by hand before the call (it travels with the snapshot, *.so is git-ignored):
+#   mkdir -p sst_amd/csrc/ab && git show HEAD:sst_amd/csrc/<file>.hip > sst_amd/csrc/ab/<file>_base.hip   (+ a copy of common.h with
+#   the include path one level deeper), hipcc -c it with the Makefile's flags, link it with the other in-tree objects into
+#   sst_amd/csrc/ab/libsst_amd_base.so; remove sst_amd/csrc/ab afterwards.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 BASE=$R/sst_amd/csrc/ab/libsst_amd_base.so
