@@ -248,6 +248,11 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
                         int32_t* d_tok0, int32_t* d_tok1, int32_t* d_winoff0, int32_t* d_winoff1,
                         int32_t* d_winlevel0, int32_t* d_winlevel1, int32_t* d_counts,
                         void* d_workspace, void* stream);
+/* Launch order of the windows of a CSR for the register-resident attention kernels: d_order [n_windows] = window ids by ascending
+ * token count (winoff[w + 1] - winoff[w] <= max_tokens), ties in id order - torch.sort(sizes, stable=True)[1] of the host layer
+ * (the kernels dispatch from the end: largest windows first).  One launch.  SST_ERR_UNSUPPORTED: max_tokens >= 512. */
+int sst_window_order_i32(const int32_t* d_winoff, int n_windows, int max_tokens, int32_t* d_order, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * (a2-a9 in one piece) Index plan of a frame batch without host round trips (csrc/frame_plan.hip): the same voxel

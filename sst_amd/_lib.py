@@ -122,6 +122,7 @@ _SIGNATURES = {
     'sst_ingroup_rank_workspace_bytes': (c_i64, [c_i64]),
     'sst_ingroup_rank_i64': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr]),
     'sst_window_coors': (c_i32, [c_ptr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_window_order_i32': (c_i32, [c_ptr, c_i32, c_i32, c_ptr, c_ptr]),
     'sst_region_batching_workspace_bytes': (c_i64, [c_i64]),
     'sst_region_batching': (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i32] + [c_ptr] * 15 + [c_ptr, c_ptr]),
     'sst_frame_windows_per_sample': (c_i64, [c_ptr, c_ptr]),

@@ -211,6 +211,76 @@ __global__ void plan_fill_k(const int32_t* __restrict__ keep, const int32_t* __r
 
 }  // namespace
 
+// Launch order of the windows for the register-resident attention kernels (sst_amd/kernels.py WindowPlan.order): window ids by
+// ascending token count, ties in id order = torch.sort(sizes, stable=True)[1].  One workgroup: wave q owns the q-th contiguous
+// slice of the ids; per (wave, size) counts -> exclusive positions in (size, wave) order -> every wave places its ids chunk by
+// chunk, the lanes of one size taking consecutive places by their rank in the ballot.  Replaces four small launches per
+// partition and step (difference, sort, index cast ...) by one.
+constexpr int kOrdWaves = 16, kOrdBins = 512;
+
+__global__ __launch_bounds__(1024) void window_order_k(const int32_t* __restrict__ winoff, int n, int nbins,
+                                                       int32_t* __restrict__ order) {
+  __shared__ int hist[kOrdWaves][kOrdBins];   // counts, then next free position, per (wave, size)
+  __shared__ int tot[kOrdBins];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < kOrdWaves * kOrdBins; i += 1024) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  const int per = (n + kOrdWaves - 1) / kOrdWaves;
+  const int w0 = wave * per, w1 = (w0 + per < n) ? w0 + per : n;
+  for (int w = w0 + lane; w < w1; w += 64) {
+    int s = winoff[w + 1] - winoff[w];
+    s = s < 0 ? 0 : (s < nbins ? s : nbins - 1);
+    atomicAdd(&hist[wave][s], 1);           // integer counts: the totals do not depend on the order of the adds
+  }
+  __syncthreads();
+  for (int s = tid; s < nbins; s += 1024) {
+    int t = 0;
+    for (int q = 0; q < kOrdWaves; ++q) t += hist[q][s];
+    tot[s] = t;
+  }
+  __syncthreads();
+  if (wave == 0) {                          // exclusive scan of the per-size totals: 64 sizes at a time
+    int carry = 0;
+    for (int b = 0; b < nbins; b += 64) {
+      const int s = b + lane;
+      const int v = s < nbins ? tot[s] : 0;
+      const int inc = sst_wave_incl_scan(v);
+      if (s < nbins) tot[s] = carry + inc - v;
+      carry += __shfl(inc, 63, 64);
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < nbins; s += 1024) {
+    int run = tot[s];
+    for (int q = 0; q < kOrdWaves; ++q) {
+      const int c = hist[q][s];
+      hist[q][s] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  volatile int* next = hist[wave];
+  for (int c0 = w0; c0 < w1; c0 += 64) {
+    const int w = c0 + lane;
+    const bool valid = w < w1;
+    int s = -1;
+    if (valid) {
+      s = winoff[w + 1] - winoff[w];
+      s = s < 0 ? 0 : (s < nbins ? s : nbins - 1);
+    }
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int sl = __shfl(s, leader, 64);
+      const unsigned long long same = __ballot(valid && s == sl);
+      const int first = next[sl];
+      if (valid && s == sl) order[first + __popcll(same & ((1ull << lane) - 1ull))] = w;
+      if (lane == leader) next[sl] = first + __popcll(same);
+      todo &= ~same;
+    }
+  }
+}
+
 extern "C" {
 
 int sst_window_coors(const void* d_coors, int coor_is_i64, int64_t m, const int32_t sparse_shape[3],
@@ -358,6 +428,17 @@ int sst_region_batching(const int32_t* d_win0, const int32_t* d_win1, int64_t m,
     hipLaunchKernelGGL(plan_fill_k, dim3(grid), dim3(256), 0, st, d_keep, inv[s], inner[s], level[s], d_newidx,
                        tokbase, cwl, lt, m, tok[s], flat2win[s]);
   }
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+
+int sst_window_order_i32(const int32_t* d_winoff, int n_windows, int max_tokens, int32_t* d_order, void* stream) {
+  if (n_windows < 0 || max_tokens < 0) return SST_ERR_ARG;
+  if (n_windows == 0) return SST_OK;
+  if (!d_winoff || !d_order) return SST_ERR_ARG;
+  if (max_tokens >= kOrdBins || n_windows > (1 << 20)) return SST_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(window_order_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_winoff, n_windows, max_tokens + 1, d_order);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

@@ -406,8 +406,17 @@ class WindowPlan(object):
         end: largest windows first).  Two small launches, once per plan - a plan serves every encoder layer of its shift,
         forward and backward.  None for small plans, where every workgroup is resident at once anyway."""
         if self._order is None and self.n_windows >= WINDOW_ORDER_MIN:
-            off = self.winoff[:self.n_windows + 1]
-            self._order = torch.sort(off[1:] - off[:-1], stable=True)[1].to(torch.int32)
+            order = torch.empty(self.n_windows, dtype=torch.int32, device=self.winoff.device)
+            rc = _lib.load().sst_window_order_i32(_lib.ptr(self.winoff), self.n_windows, self.max_tokens, _lib.ptr(order),
+                                                  _lib.stream_ptr()) if (self.winoff.is_cuda and self.winoff.dtype == torch.int32
+                                                                         and not os.environ.get('SST_AMD_WINDOW_ORDER_TORCH')) \
+                else _lib.SST_ERR_UNSUPPORTED
+            if rc == _lib.SST_ERR_UNSUPPORTED:       # windows of 512 tokens and more: the library sort
+                off = self.winoff[:self.n_windows + 1]
+                order = torch.sort(off[1:] - off[:-1], stable=True)[1].to(torch.int32)
+            else:
+                _lib.check(rc, 'sst_window_order_i32')
+            self._order = order
         return self._order
 
 

@@ -207,3 +207,24 @@ def test_voxel_grouping_with_a_few_huge_voxels(c, subset, monkeypatch):
     val, arg = K.segment_argmax(feats, plan)
     assert torch.equal(val, ref)
     assert torch.equal(feats.gather(0, arg.long()), ref)
+
+
+@pytest.mark.parametrize('n,cap', [(1, 5), (600, 100), (1521, 100), (5000, 37), (70000, 100), (3000, 511), (900, 700)])
+def test_window_launch_order_equals_the_stable_sort(n, cap):
+    """WindowPlan.order (csrc/window.hip window_order_k: one launch) == torch.sort(sizes, stable=True)[1]; windows of 512 tokens
+    and more take the library sort"""
+    from sst_amd import kernels as K
+    g = torch.Generator().manual_seed(n + cap)
+    sizes = torch.randint(0, cap + 1, (n,), generator=g)
+    sizes[torch.randint(0, n, (max(1, n // 7),), generator=g)] = cap          # many ties at the cap, as after the drop
+    winoff = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)]).to(torch.int32).to(_dev())
+    total = int(sizes.sum())
+    plan = K.WindowPlan(torch.arange(max(total, 1), dtype=torch.int32, device=_dev()), winoff, n, total, cap)
+    old = K.WINDOW_ORDER_MIN
+    K.WINDOW_ORDER_MIN = 1
+    try:
+        order = plan.order
+    finally:
+        K.WINDOW_ORDER_MIN = old
+    ref = torch.sort(sizes, stable=True)[1].to(torch.int32)
+    assert order.dtype == torch.int32 and torch.equal(order.cpu(), ref)
