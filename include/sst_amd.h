@@ -484,6 +484,11 @@ int sst_cast_group_bf16(const sst_cast_problem_bf16* problems, int n, void* stre
  * ---------------------------------------------------------------------------------------------- */
 int sst_gather_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_idx, int64_t n_out, int c,
                         float fill, float* d_out, int64_t ld_out, void* stream);
+/* out[i, :] = x[i, :] + table[idx[i], :]: q = k = feat + pos_embed of the first encoder layer (sst_basic_block_v2.py:62-66) with the
+ * positional embedding kept as a table of the distinct in-window positions + a row index (sst_input_layer_v2.py:196-226 builds
+ * the [M, C] tensor).  c % 4 == 0, 16-byte aligned rows. */
+int sst_add_table_rows_f32(const float* d_x, int64_t ldx, const float* d_table, int64_t ld_table, const int32_t* d_idx, int64_t m,
+                           int c, float* d_out, int64_t ld_out, void* stream);
 int sst_scatter_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_idx, int64_t n_src, int c,
                          float* d_out, int64_t ld_out, void* stream);
 

@@ -191,6 +191,7 @@ _SIGNATURES = {
     'sst_wgrad_group_bf16': (c_i32, [c_ptr, c_i32, c_ptr, c_ptr]),
     'sst_cast_group_bf16': (c_i32, [c_ptr, c_i32, c_ptr]),
     'sst_gather_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_i64, c_ptr]),
+    'sst_add_table_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_scatter_rows_f32': (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     'sst_add_layernorm_fwd_f32': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_f32, c_ptr, c_ptr, c_ptr,
                                           c_ptr]),

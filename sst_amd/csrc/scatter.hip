@@ -756,6 +756,22 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* __restrict__ s
   }
 }
 
+// out[i, :] = x[i, :] + table[idx[i], :] (c % 4 == 0): the first encoder layer's q / k input, feat + pos_embed
+// (sst_basic_block_v2.py:62-66), as one pass instead of index cast + index_select + add
+__global__ __launch_bounds__(256) void add_table_rows_k(const float* __restrict__ x, int64_t ldx, const float* __restrict__ table,
+                                                        int64_t ldt, const int32_t* __restrict__ idx, int64_t m, int c4,
+                                                        float* __restrict__ out, int64_t ldo) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int64_t total = m * c4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / c4;
+    const int q = (int)(e - i * c4);
+    const f4 a = *(const f4*)(x + i * ldx + 4 * q);
+    const f4 b = *(const f4*)(table + (int64_t)idx[i] * ldt + 4 * q);
+    *(f4*)(out + i * ldo + 4 * q) = a + b;
+  }
+}
+
 __global__ __launch_bounds__(256) void scatter_rows_k(const float* __restrict__ src, int64_t ld_src,
                                                       const int32_t* __restrict__ idx, int64_t n_src, int c,
                                                       float* __restrict__ out, int64_t ld_out) {
@@ -1202,6 +1218,20 @@ int sst_gather_rows_f32(const float* d_src, int64_t ld_src, const int32_t* d_idx
   const int grid = sst_grid_1d(n_out * c, 256);
   hipLaunchKernelGGL(gather_rows_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_src, ld_src, d_idx, n_out, c,
                      fill, d_out, ld_out);
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+int sst_add_table_rows_f32(const float* d_x, int64_t ldx, const float* d_table, int64_t ld_table, const int32_t* d_idx, int64_t m,
+                           int c, float* d_out, int64_t ld_out, void* stream) {
+  if (m < 0 || c < 4 || (c & 3)) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_table || !d_idx || !d_out || (ldx & 3) || (ld_table & 3) || (ld_out & 3) ||
+      (((uintptr_t)d_x | (uintptr_t)d_table | (uintptr_t)d_out) & 15))
+    return SST_ERR_ARG;
+  const int grid = sst_grid_1d(m * (c >> 2), 256);
+  hipLaunchKernelGGL(add_table_rows_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_x, ldx, d_table, ld_table, d_idx, m, c >> 2,
+                     d_out, ld_out);
   SST_LAUNCH_CHECK();
   return SST_OK;
 }

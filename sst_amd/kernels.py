@@ -679,6 +679,38 @@ def gather_rows(src, idx, fill=0.0):
     return out
 
 
+class _AddTableRows(torch.autograd.Function):
+    """x + table[idx] with the gradient of x passed through (the table rows are constants here: positional embedding)"""
+
+    @staticmethod
+    def forward(ctx, x, table, idx):
+        return _add_table_rows(x, table, idx)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None, None
+
+
+def add_table_rows(x, table, idx):
+    """x + table[idx] (x [M, C] fp32, idx int32 [M]) in one launch (index cast + index_select + add otherwise); differentiable
+    with respect to x"""
+    return _AddTableRows.apply(x, table, idx)
+
+
+def _add_table_rows(x, table, idx):
+    _lib.require_cuda(x, table, idx)
+    m, c = x.shape
+    if not (x.dtype == torch.float32 and table.dtype == torch.float32 and idx.dtype == torch.int32 and c % 4 == 0
+            and x.stride(1) == 1 and table.stride(1) == 1 and x.stride(0) % 4 == 0 and table.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and table.data_ptr() % 16 == 0 and idx.numel() == m and table.size(1) == c):
+        return x + table.index_select(0, idx.long())
+    out = torch.empty((m, c), dtype=torch.float32, device=x.device)
+    rc = _lib.load().sst_add_table_rows_f32(_lib.ptr(x), x.stride(0), _lib.ptr(table), table.stride(0), _lib.ptr(idx), m, c,
+                                            _lib.ptr(out), c, _lib.stream_ptr())
+    _lib.check(rc, 'sst_add_table_rows_f32')
+    return out
+
+
 def scatter_rows(src, idx, out):
     _lib.require_cuda(src, idx, out)
     assert src.dtype == torch.float32 and idx.dtype == torch.int32 and src.dim() == 2

@@ -570,7 +570,8 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
         return run
 
     x = feats.contiguous()
-    xp = x + pos_specs[0][0].index_select(0, pos_specs[0][1].long())
+    # x + positional rows of the first layer: one pass (csrc/scatter.hip add_table_rows_k)
+    xp = K.add_table_rows(x, pos_specs[0][0], pos_specs[0][1])
     for bi in range(len(blocks)):
         if bi in checkpoint_blocks and torch.is_grad_enabled():
             out = checkpoint(block_fn(bi), x, xp, use_reentrant=False)

@@ -228,3 +228,16 @@ def test_window_launch_order_equals_the_stable_sort(n, cap):
         K.WINDOW_ORDER_MIN = old
     ref = torch.sort(sizes, stable=True)[1].to(torch.int32)
     assert order.dtype == torch.int32 and torch.equal(order.cpu(), ref)
+
+
+def test_add_table_rows_equals_index_select_plus_add():
+    from sst_amd import kernels as K
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(5003, 128, generator=g).to(_dev()).requires_grad_(True)
+    table = torch.randn(144, 128, generator=g).to(_dev())
+    idx = torch.randint(0, 144, (5003,), generator=g, dtype=torch.int32).to(_dev())
+    y = K.add_table_rows(x, table, idx)
+    assert torch.equal(y, x + table.index_select(0, idx.long()))
+    w = torch.randn(y.shape, generator=g).to(_dev())
+    (y * w).sum().backward()
+    assert torch.equal(x.grad, w)
