@@ -763,6 +763,50 @@ int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads);
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* args, void* stream);
 int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* args, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The part of that layer behind the attention core as ONE kernel per direction (csrc/layer_tail_x6.hip), exact-split
+ * arithmetic, d_model 128, feed-forward 256 (sst_basic_block_v2.py:113-118 and their autograd): a wave carries 16 tokens
+ * through out-projection -> + x -> norm1 -> linear1 -> act -> linear2 -> + y1 -> norm2 in registers; the weights pass
+ * through LDS in 10 chunks.  All tensors fp32, contiguous, 16-byte aligned; widths: o, x, s1, y1, s2, y2, y2p, ds2, ds1,
+ * d_o, dy2, dy2p 128; pre, h, dpre 256; st1, st2 [m, 2] (mean, rstd); w_out [128][128], w1 [256][128], w2 [128][256].
+ *   pack    : `packed` (sst_encoder_tail_pack_bytes() bytes, device) = the three bf16 parts of the three weight matrices as the
+ *             chunk images both kernels fetch with LDS-DMA; formed once per layer call (the weights of THIS forward pass: the
+ *             backward pass must see the same buffer).
+ *   forward : s1 = x + o W_o^T + b_o (s1 may be NULL), y1 = LN1(s1), pre = y1 W_1^T + b_1, h = act(pre) (act 1 = GELU(erf),
+ *             2 = ReLU), s2 = y1 + h W_2^T + b_2 (s2 may be NULL), y2 = LN2(s2), y2p = y2 + pos_table[pos_idx] (all three NULL
+ *             or all three given); biases may be NULL.
+ *   backward: ds2 = LN2'(dy2 (+ dy2p, may be NULL)), dpre = (ds2 W_2) act'(pre), ds1 = LN1'(ds2 + dpre W_1), d_o = ds1 W_o;
+ *             dn2w | dn2b | dn1w | dn1b [128] = the LayerNorm parameter gradients (m == 0: zeros).  workspace:
+ *             sst_encoder_tail_bwd_workspace_bytes(m), 256-byte aligned.
+ * The weight gradients of the three linears are the caller's (sst_weight_grad_group_f32x6 on (ds2, h), (dpre, y1), (ds1, o)).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sst_encoder_tail_fwd_args {
+  int64_t m;
+  int32_t act, reserved;
+  float eps, reserved_f;
+  const float *o, *x;
+  const void* packed;
+  const float *b_out, *b1, *b2, *n1w, *n1b, *n2w, *n2b;
+  const float* pos_table;
+  const int32_t* pos_idx;
+  float *s1, *st1, *y1, *pre, *h, *s2, *st2, *y2, *y2p;
+} sst_encoder_tail_fwd_args;
+typedef struct sst_encoder_tail_bwd_args {
+  int64_t m;
+  int32_t act, reserved;
+  const float *dy2, *dy2p, *s2, *st2, *pre, *s1, *st1;
+  const void* packed;
+  const float *n1w, *n2w;
+  float *ds2, *dpre, *ds1, *d_o;
+  float *dn2w, *dn2b, *dn1w, *dn1b;
+  void* workspace;
+} sst_encoder_tail_bwd_args;
+int64_t sst_encoder_tail_pack_bytes(void);
+int sst_encoder_tail_pack_f32x6(const float* d_w_out, const float* d_w1, const float* d_w2, void* d_packed, void* stream);
+int64_t sst_encoder_tail_bwd_workspace_bytes(int64_t m);
+int sst_encoder_tail_fwd_f32x6(const sst_encoder_tail_fwd_args* args, void* stream);
+int sst_encoder_tail_bwd_f32x6(const sst_encoder_tail_bwd_args* args, void* stream);
+
 /* The same layer in the reduced-precision mode (bf16 storage, fp32 accumulation / softmax / LayerNorm statistics, fp32 master
  * weights: what the reference's fp16 training of these layers - configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82 -
  * corresponds to), one call per direction: the launch sequence of sst_amd/bf16.py EncoderLayerBF16Fn issued from C (6 launches

@@ -63,6 +63,16 @@ EncoderLayerBwdArgs = _struct('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args
                          'workspace', 'head_scale', 'cos_r', 'dy1')]))
 
 
+EncoderTailFwdArgs = _struct('EncoderTailFwdArgs', 'sst_encoder_tail_fwd_args of include/sst_amd.h', (
+    [('m', c_i64), ('act', ctypes.c_int32), ('reserved', ctypes.c_int32), ('eps', ctypes.c_float), ('reserved_f', ctypes.c_float)]
+    + [(k, _P) for k in ('o', 'x', 'packed', 'b_out', 'b1', 'b2', 'n1w', 'n1b', 'n2w', 'n2b', 'pos_table', 'pos_idx',
+                         's1', 'st1', 'y1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p')]))
+EncoderTailBwdArgs = _struct('EncoderTailBwdArgs', 'sst_encoder_tail_bwd_args of include/sst_amd.h', (
+    [('m', c_i64), ('act', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+    + [(k, _P) for k in ('dy2', 'dy2p', 's2', 'st2', 'pre', 's1', 'st1', 'packed', 'n1w', 'n2w',
+                         'ds2', 'dpre', 'ds1', 'd_o', 'dn2w', 'dn2b', 'dn1w', 'dn1b', 'workspace')]))
+
+
 EncoderLayerFwdBF16Args = _struct('EncoderLayerFwdBF16Args', 'sst_encoder_layer_fwd_bf16_args of include/sst_amd.h', (
     [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'reserved')]
     + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
@@ -97,6 +107,11 @@ _SIGNATURES = {
     'sst_encoder_layer_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'sst_encoder_layer_fwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),
+    'sst_encoder_tail_pack_bytes': (c_i64, []),
+    'sst_encoder_tail_pack_f32x6': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_encoder_tail_bwd_workspace_bytes': (c_i64, [c_i64]),
+    'sst_encoder_tail_fwd_f32x6': (c_i32, [c_ptr, c_ptr]),
+    'sst_encoder_tail_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_bf16_workspace_bytes': (c_i64, [c_i64]),
     'sst_encoder_layer_fwd_bf16': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_bf16': (c_i32, [c_ptr, c_ptr]),

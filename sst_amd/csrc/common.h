@@ -72,6 +72,10 @@ int sst_internal_add_layernorm_bwd_bf16_partials(const void* d_dy, const void* d
                                                  int* partial_rows, void* stream);
 int sst_internal_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n, void* d_workspace, const sst_colsum_rider* riders,
                                   int n_riders, void* stream);
+// csrc/layer_tail_x6.hip without the finishing launches of the LayerNorm parameter gradients: their per-workgroup partials stay
+// in args->workspace as [*partial_rows][256] at *part2 (norm2) and *part1 (norm1); the dn* fields of args are not read.
+int sst_internal_encoder_tail_bwd_f32x6(const sst_encoder_tail_bwd_args* args, float** part2, float** part1, int* partial_rows,
+                                        void* stream);
 int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace,
                                          const sst_colsum_rider* riders, int n_riders, void* stream);
 

@@ -393,6 +393,76 @@ def lds_linear_add_ln(x, w, bias, res, ln_weight, ln_bias, eps, save_sum=True, p
     return y, s, stats, yp
 
 
+def encoder_tail_ok(o, x, w_out, w1, w2):
+    """the one-kernel tail of an encoder layer (csrc/layer_tail_x6.hip): exact-split mode, d_model 128, feed-forward 256"""
+    if _MATMUL_MODE != 'f32x6':
+        return False
+    if not (o.shape == x.shape and x.dim() == 2 and x.size(1) == 128 and w_out.shape == (128, 128) and w1.shape == (256, 128)
+            and w2.shape == (128, 256)):
+        return False
+    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0
+               for t in (o, x, w_out, w1, w2))
+
+
+def encoder_tail_pack(w_out, w1, w2, out=None):
+    """the chunk images (three bf16 parts, LDS layout) of a layer's out-projection / linear1 / linear2 weights that
+    encoder_tail_fwd / _bwd fetch with LDS-DMA: one small launch per layer call (uint8 tensor, ~1.1 MB)"""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(int(lib.sst_encoder_tail_pack_bytes()), dtype=torch.uint8, device=w_out.device)
+    _lib.check(lib.sst_encoder_tail_pack_f32x6(_lib.ptr(w_out), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(out), _lib.stream_ptr()),
+               'sst_encoder_tail_pack_f32x6')
+    return out
+
+
+def encoder_tail_fwd(o, x, packed, b_out, b1, b2, n1w, n1b, n2w, n2b, eps, act, save=True, pos=None, out=None):
+    """y1 = LN1(x + o W_o^T + b_o); pre = y1 W_1^T + b_1; h = act(pre); s2 = y1 + h W_2^T + b_2; y2 = LN2(s2) as ONE kernel
+    (sst_basic_block_v2.py:113-118); packed = encoder_tail_pack(W_o, W_1, W_2).  -> dict(s1 (None unless save), st1, y1, pre,
+    h, s2, st2, y2, y2p (pos = (table, index))); ``out``: optional dict of preallocated tensors by the same names."""
+    m = x.size(0)
+    dev = x.device
+    out = dict(out) if out else {}
+
+    def e(name, cols):
+        if name not in out or out[name] is None:
+            out[name] = torch.empty((m, cols), dtype=torch.float32, device=dev)
+        return out[name]
+    s1 = e('s1', 128) if save else None
+    out['s1'] = s1
+    st1, y1, pre, h, s2, st2, y2 = e('st1', 2), e('y1', 128), e('pre', 256), e('h', 256), e('s2', 128), e('st2', 2), e('y2', 128)
+    y2p = e('y2p', 128) if pos is not None else None
+    out['y2p'] = y2p
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    args = _lib.EncoderTailFwdArgs(
+        m, 1 if act == 'gelu' else 2, 0, float(eps), 0.0, P(o), P(x), P(packed), P(b_out), P(b1), P(b2), P(n1w), P(n1b),
+        P(n2w), P(n2b), P(pos[0]) if pos is not None else None, P(pos[1]) if pos is not None else None,
+        P(s1), P(st1), P(y1), P(pre), P(h), P(s2), P(st2), P(y2), P(y2p))
+    import ctypes
+    _lib.check(_lib.load().sst_encoder_tail_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()), 'sst_encoder_tail_fwd_f32x6')
+    return out
+
+
+def encoder_tail_bwd(dy2, dy2p, s2, st2, pre, s1, st1, packed, n1w, n2w, act):
+    """the backward of encoder_tail_fwd up to the attention output: -> (ds2, dpre, ds1, d_o, dn [4, 128] = dn2w | dn2b | dn1w | dn1b);
+    the weight gradients of the three linears are left to the caller (ds2 with h, dpre with y1, ds1 with o)."""
+    m = dy2.size(0)
+    dev = dy2.device
+
+    def e(cols):
+        return torch.empty((m, cols), dtype=torch.float32, device=dev)
+    ds2, dpre, ds1, d_o = e(128), e(256), e(128), e(128)
+    dn = torch.empty((4, 128), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_encoder_tail_bwd_workspace_bytes(m), dev)
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    d0 = dn.data_ptr()
+    args = _lib.EncoderTailBwdArgs(m, 1 if act == 'gelu' else 2, 0, P(dy2), P(dy2p), P(s2), P(st2), P(pre), P(s1), P(st1), P(packed),
+                                   P(n1w), P(n2w), P(ds2), P(dpre), P(ds1), P(d_o), d0, d0 + 512, d0 + 1024, d0 + 1536, P(ws))
+    import ctypes
+    _lib.check(lib.sst_encoder_tail_bwd_f32x6(ctypes.byref(args), _lib.stream_ptr()), 'sst_encoder_tail_bwd_f32x6')
+    return ds2, dpre, ds1, d_o, dn
+
+
 class AddLayerNorm(Function):
     """y = act(LayerNorm(x + res)) (act None | 'gelu' | 'relu'); the gradient w.r.t. x and res is the same tensor."""
 

@@ -1,0 +1,126 @@
+"""GPU: the one-kernel tail of an encoder layer (csrc/layer_tail_x6.hip, sst_encoder_tail_{fwd,bwd}_f32x6) - out-projection ->
++ x -> norm1 -> linear1 -> act -> linear2 -> + y1 -> norm2 (mmdet3d/models/sst/sst_basic_block_v2.py:113-118) and its autograd -
+against the same chain in float64 (torch, on the device) and against the launch-per-product kernels it replaces
+(csrc/dense_f32x6.hip + csrc/dense.hip): tolerance = the admissibility bar of tests/test_gpu_dense_f32x6.py - the error against
+float64 may not exceed twice that of the unfused exact-split kernels, and every output is within 1e-5 relative of float64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _params(seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+
+    def r(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g) * s).to(DEV)
+    return dict(w_out=r(128, 128, s=0.09 * scale), b_out=r(128, s=0.1), w1=r(256, 128, s=0.09 * scale), b1=r(256, s=0.1),
+                w2=r(128, 256, s=0.06 * scale), b2=r(128, s=0.1), n1w=1 + r(128, s=0.2), n1b=r(128, s=0.1),
+                n2w=1 + r(128, s=0.2), n2b=r(128, s=0.1))
+
+
+def _ref64(o, x, p, act, eps, pos=None):
+    """the chain in float64 under autograd: returns the dict of forward tensors (leaf inputs keep .grad)"""
+    d = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    o64, x64 = o.double().requires_grad_(True), x.double().requires_grad_(True)
+    s1 = x64 + o64 @ d['w_out'].t() + d['b_out']
+    y1 = torch.nn.functional.layer_norm(s1, (128,), d['n1w'], d['n1b'], eps)
+    pre = y1 @ d['w1'].t() + d['b1']
+    h = torch.nn.functional.gelu(pre) if act == 'gelu' else torch.relu(pre)
+    s2 = y1 + h @ d['w2'].t() + d['b2']
+    y2 = torch.nn.functional.layer_norm(s2, (128,), d['n2w'], d['n2b'], eps)
+    out = dict(s1=s1, y1=y1, pre=pre, h=h, s2=s2, y2=y2, o=o64, x=x64, params=d)
+    if pos is not None:
+        out['y2p'] = y2 + pos[0].double()[pos[1].long()]
+    return out
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('m,act,with_pos', [(1, 'gelu', False), (17, 'relu', True), (128, 'gelu', True), (1000, 'gelu', False),
+                                            (4099, 'relu', False), (20011, 'gelu', True)])
+def test_tail_forward_and_backward_match_float64(m, act, with_pos):
+    from sst_amd import dense as D
+    eps = 1e-5
+    g = torch.Generator().manual_seed(m)
+    o, x = torch.randn(m, 128, generator=g).to(DEV), torch.randn(m, 128, generator=g).to(DEV)
+    p = _params(3)
+    pos = None
+    if with_pos:
+        pos = (torch.randn(144, 128, generator=g).to(DEV), torch.randint(0, 144, (m,), generator=g, dtype=torch.int32).to(DEV))
+    with D.matmul_mode_scope('f32x6'):
+        assert D.encoder_tail_ok(o, x, p['w_out'], p['w1'], p['w2'])
+        packed = D.encoder_tail_pack(p['w_out'], p['w1'], p['w2'])
+        out = D.encoder_tail_fwd(o, x, packed, p['b_out'], p['b1'], p['b2'], p['n1w'], p['n1b'], p['n2w'], p['n2b'], eps, act,
+                                 save=True, pos=pos)
+    ref = _ref64(o, x, p, act, eps, pos)
+    for k in ('s1', 'y1', 'pre', 'h', 's2', 'y2') + (('y2p',) if with_pos else ()):
+        assert _rel(out[k], ref[k].detach()) < 1e-5, k
+    # statistics: mean | rstd of the two LayerNorm inputs
+    for st, s in ((out['st1'], ref['s1']), (out['st2'], ref['s2'])):
+        mean = s.detach().mean(1)
+        rstd = 1.0 / torch.sqrt(s.detach().var(1, unbiased=False) + eps)
+        assert _rel(st[:, 0], mean) < 1e-5 and _rel(st[:, 1], rstd) < 1e-5
+
+    dy2 = torch.randn(m, 128, generator=g).to(DEV)
+    dy2p = torch.randn(m, 128, generator=g).to(DEV) if with_pos else None
+    loss = (ref['y2'] * dy2.double()).sum()
+    if with_pos:
+        loss = loss + (ref['y2p'] * dy2p.double()).sum()
+    # gradients of the intermediate tensors the kernel hands out: ds2 = d(s2), dpre = d(pre), ds1 = d(s1), d_o = d(o)
+    grads = torch.autograd.grad(loss, [ref['s2'], ref['pre'], ref['s1'], ref['o'], ref['params']['n2w'], ref['params']['n2b'],
+                                       ref['params']['n1w'], ref['params']['n1b']])
+    with D.matmul_mode_scope('f32x6'):
+        ds2, dpre, ds1, d_o, dn = D.encoder_tail_bwd(dy2, dy2p, out['s2'], out['st2'], out['pre'], out['s1'], out['st1'], packed,
+                                                     p['n1w'], p['n2w'], act)
+    tol = 2e-5
+    assert _rel(ds2, grads[0]) < tol
+    assert _rel(dpre, grads[1]) < tol
+    assert _rel(ds1, grads[2]) < tol
+    assert _rel(d_o, grads[3]) < tol
+    for i in range(4):
+        assert _rel(dn[i], grads[4 + i]) < 5e-5, i
+
+
+def test_tail_is_as_exact_as_the_kernels_it_replaces():
+    """error against float64 <= 2 x the error of the launch-per-product sequence (the bar of tests/test_gpu_dense_f32x6.py)"""
+    from sst_amd import dense as D
+    m, act, eps = 30000, 'gelu', 1e-5
+    g = torch.Generator().manual_seed(5)
+    o, x = torch.randn(m, 128, generator=g).to(DEV), torch.randn(m, 128, generator=g).to(DEV)
+    p = _params(7)
+    ref = _ref64(o, x, p, act, eps)
+    with D.matmul_mode_scope('f32x6'):
+        packed = D.encoder_tail_pack(p['w_out'], p['w1'], p['w2'])
+        out = D.encoder_tail_fwd(o, x, packed, p['b_out'], p['b1'], p['b2'], p['n1w'], p['n1b'], p['n2w'], p['n2b'], eps, act)
+        y1, s1, st1, _ = D.lds_linear_add_ln(o, p['w_out'], p['b_out'], x, p['n1w'], p['n1b'], eps)
+        h, pre = D.lds_linear(y1, p['w1'], p['b1'], D.EPI_GELU, want_pre=True)
+        s2 = D.lds_linear(h, p['w2'], p['b2'], D.EPI_ADD, aux_in=y1)
+        y2 = D.add_ln_fwd(s2, None, p['n2w'], p['n2b'], eps)[0]
+    for k, unf in (('y1', y1), ('pre', pre), ('h', h), ('s2', s2), ('y2', y2)):
+        e_f = float((out[k].double() - ref[k].detach()).abs().max())
+        e_u = float((unf.double() - ref[k].detach()).abs().max())
+        assert e_f <= 2.0 * e_u + 1e-7, (k, e_f, e_u)
+
+
+def test_tail_refuses_bad_arguments():
+    from sst_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    args = _lib.EncoderTailFwdArgs()
+    args.m = 16
+    args.act = 1
+    assert lib.sst_encoder_tail_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()) == _lib.SST_ERR_ARG
+    args.act = 3
+    assert lib.sst_encoder_tail_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()) == _lib.SST_ERR_ARG
+    b = _lib.EncoderTailBwdArgs()
+    b.m = 16
+    b.act = 1
+    assert lib.sst_encoder_tail_bwd_f32x6(ctypes.byref(b), _lib.stream_ptr()) == _lib.SST_ERR_ARG
+    assert lib.sst_encoder_tail_bwd_workspace_bytes(-1) == _lib.SST_ERR_ARG
+    assert lib.sst_encoder_tail_bwd_workspace_bytes(1000) >= 2 * 8 * 256 * 4
+    assert lib.sst_encoder_tail_pack_bytes() == 2 * 10 * 48 * 1024
+    assert lib.sst_encoder_tail_pack_f32x6(None, None, None, None, _lib.stream_ptr()) == _lib.SST_ERR_ARG
