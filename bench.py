@@ -642,9 +642,94 @@ def parse_args():
     ap.add_argument('--impl', type=int, default=0, help='0 = MFMA SRA kernels, 1 = generic VALU kernels')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL, default) | gloo (dev check of the N>1 path on one GPU)')
     ap.add_argument('--share-device', action='store_true', help='dev only: every rank uses cuda:0')
+    ap.add_argument('--compact', action='store_true',
+                    help='a short leg of another workload inside the default line: no side legs, no CPU baseline; the '
+                         'FSD / FSDv2 chains check parity against the CPU port on a bounded frame (--parity-points)')
+    ap.add_argument('--parity-points', type=int, default=40000,
+                    help='--compact, fsd / fsdv2: points of the frame the GPU chain is compared with the CPU port on')
+    ap.add_argument('--no-workload-legs', action='store_true',
+                    help='default line only: skip the compact legs of BASELINE configs 2-4 (sst_bs2, sst_center, fsd, fsdv2)')
+    ap.add_argument('--no-voxelize-roofline', action='store_true', help='skip the dynamic-voxelize microbenchmark')
     ap.add_argument('--no-gemm-tuning', action='store_true',
                     help='do not let PyTorch TunableOp pick the hipBLASLt/rocBLAS solution of each dense GEMM shape')
     return ap.parse_args()
+
+
+def voxelize_roofline(dev, frame_points):
+    """dynamic voxelize alone (24 B / point = 12 B xyz in + 12 B zyx out) at 16 M points - the size
+    at which the launch is bound by HBM - and at the bench frame's size, where one launch is a few microseconds of latency."""
+    import sst_amd
+    vs, rng = (0.32, 0.32, 6), [-74.88, -74.88, -2, 74.88, 74.88, 4]
+    out = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'algorithmic_bytes_per_point': 24,
+           'kernel': 'dynamic_voxelize_rows_k<3> (csrc/voxelize.hip), one launch per sst_dynamic_voxelize_f32 call; '
+                     'torch events on the launch stream, 20 launches'}
+    for key, n in (('at_16M_points', 1 << 24), ('at_bench_frame', int(frame_points))):
+        g = torch.Generator(device=dev).manual_seed(5)
+        pts = torch.rand(n, 3, device=dev, generator=g) * torch.tensor([149.76, 149.76, 6.0], device=dev) \
+            + torch.tensor([-74.88, -74.88, -2.0], device=dev)
+        for _ in range(3):
+            sst_amd.voxelization(pts, vs, rng, -1, -1)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            sst_amd.voxelization(pts, vs, rng, -1, -1)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / 20 * 1e3
+        out[key] = {'points': n, 'avg_us': round(us, 2), 'achieved': round(24.0 * n / us / 1e3, 1),
+                    'frac': round(24.0 * n / us / 1e3 / HBM_PEAK_GBS, 4)}
+        del pts
+    out['achieved'], out['frac'] = out['at_16M_points']['achieved'], out['at_16M_points']['frac']
+    out['note'] = ('frac is quoted at 16 M points; at the bench frame one launch moves 2.8 MB and is bound by launch latency, '
+                   'not by bandwidth (at_bench_frame)')
+    return out
+
+
+def workload_legs(args):
+    """BASELINE.json configs 2-4 as compact legs of the default line, each the MAIN loop of a process of its own (fresh
+    interpreter, allocator, clocks; this process idle meanwhile): value, step statistics, host time, the leg's roofline, and for
+    the FSD chains parity against the CPU port on a bounded frame.  VERDICT round 5 item 2: every BASELINE config is then in the
+    line the driver records, not only in builder-run files."""
+    import subprocess
+    legs = {}
+    plan = (('sst_bs2', 10, 3, 150), ('sst_center', 10, 3, 150), ('fsd', 10, 3, 240), ('fsdv2', 10, 3, 300))
+    for name, steps, warm, limit in plan:
+        note(f'leg: workload {name} (own process)')
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--compact', '--steps', str(steps), '--warmup',
+               str(warm)]
+        t0 = time.perf_counter()
+        try:
+            sub = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, cwd=ROOT)
+            own = json.loads(sub.stdout.strip().splitlines()[-1])
+            leg = {k: own.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'step_ms', 'host_ms_per_step',
+                                           'dtype') if k in own}
+            leg['workload'] = (own.get('config') or {}).get('workload')
+            for k in ('frames_per_gpu', 'points_per_frame', 'voxels_per_gpu', 'sizes'):
+                if k in (own.get('config') or {}):
+                    leg[k] = own['config'][k]
+            rf = own.get('roofline')
+            if rf:
+                leg['roofline'] = {k: rf.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_us',
+                                                          'peak_note', 'frac_of_bf16_peak') if k in rf}
+                if isinstance(rf.get('sra_bwd'), dict):
+                    leg['roofline']['sra_bwd'] = {k: rf['sra_bwd'].get(k) for k in ('achieved', 'frac', 'avg_us') if k in rf['sra_bwd']}
+            if own.get('roofline_seg_reduce'):
+                leg['roofline_seg_reduce'] = {k: own['roofline_seg_reduce'].get(k) for k in ('bound', 'achieved', 'peak', 'unit',
+                                                                                             'frac', 'algorithmic_bytes', 'ms')}
+            if own.get('reduced_precision'):
+                rp = own['reduced_precision']
+                leg['reduced_precision'] = {k: rp.get(k) for k in ('value', 'ms_per_step', 'roofline') if k in rp}
+            par = own.get('parity')
+            if par:
+                leg['parity'] = {k: par.get(k) for k in ('integer_outputs_equal', 'max_abs_err_overall', 'max_abs_err',
+                                                         'max_rel_grad_err', 'feature_tolerance', 'frame_points', 'unpinned')
+                                 if k in par}
+            leg['wall_s'] = round(time.perf_counter() - t0, 1)
+            legs[name] = leg
+        except Exception as e:     # a leg beside the headline must never take the line down
+            legs[name] = {'error': repr(e)[:300], 'wall_s': round(time.perf_counter() - t0, 1)}
+    return legs
 
 
 def _main(args, line_out):
@@ -655,6 +740,12 @@ def _main(args, line_out):
         args.points = 116000
     if args.workload == 'sst_bs2':
         args.frames_per_gpu = 2
+    if args.compact:
+        args.no_lidar_leg = args.no_forward_only_leg = args.no_config_as_is_leg = args.no_traffic_remeasure = True
+        args.no_f32x3_leg = args.no_bf16_own_process = args.no_std_attention_leg = args.no_workload_legs = True
+        args.no_voxelize_roofline = True
+        if args.workload not in ('fsd', 'fsdv2'):
+            args.no_cpu_baseline = True
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # launched as plain `python bench.py --gpus N`: start one rank per GPU ourselves, the way the reference's
@@ -1279,6 +1370,16 @@ def _main(args, line_out):
             res['cpu_baseline'] = None
         if std_leg is not None:
             res['std_attention_same_config'] = std_leg
+        if world == 1 and not args.no_voxelize_roofline:
+            note('leg: voxelize roofline')
+            try:
+                res['roofline']['voxelize'] = voxelize_roofline(dev, args.points)
+            except Exception as e:
+                res['roofline']['voxelize'] = {'error': repr(e)[:200]}
+        if world == 1 and args.workload == 'sst' and not args.no_workload_legs and not args.fwd_only:
+            del model
+            fresh_allocator()
+            res['workloads'] = workload_legs(args)
         print(json.dumps(res), file=line_out)
         line_out.flush()
     if world > 1:

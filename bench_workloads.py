@@ -24,6 +24,7 @@ from sst_amd.sst_ops import scatter_v2
 
 HBM_PEAK_GBS = 8000.0
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 (the headline figures with 2:1 sparsity are not used)
 BN = dict(type='naiveSyncBN1d', eps=1e-3, momentum=0.01)
 
 
@@ -463,6 +464,15 @@ def _conv_roofline(model, clouds):
                 'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                 'algorithmic_flops': fl, 'ms': round(ms, 3)}
+        from sst_amd import spconv as _sp
+        if _sp.conv_precision() == 'f32x6':
+            # the timed mode issues SIX bf16 products per algorithmic fp32 product on the bf16 pipe (exact three-way split): the
+            # honest denominator for the pipe it runs on is the dense bf16 peak with that factor stated
+            issued = 6.0 * fl / (ms * 1e-3) / 1e12
+            conv['peak_note'] = ('achieved / peak / frac count ALGORITHMIC fp32 flops against the fp32 matrix pipe (157.3 TFLOP/s); the '
+                                 'kernels run on the bf16 pipe and issue 6 x those flops: frac_of_bf16_peak = 6 x achieved / 2500')
+            conv['issued_bf16_tflops'] = round(issued, 1)
+            conv['frac_of_bf16_peak'] = round(issued / BF16_MFMA_PEAK_TFLOPS, 4)
     seg = None
     timed = [(t, b) for t, b in ((ke.elapsed_time(ke), b) for ke, b in seg_records) if t > 0]
     if timed:
@@ -476,40 +486,15 @@ def _conv_roofline(model, clouds):
     return conv, seg
 
 
-def cpu_chain_leg(spec, model, clouds):
-    """The CPU port of the same chain (oracle/fsd_cpu.py: the reference's algorithm module by module, pinned to the
-    reference by tests/test_fsd_chain.py) on the host cores, rank 0 at N = 1 - the ONLY place this file touches oracle/:
-      * `cpu_baseline`: frames/s of forward + backward of the first bench frame: one untimed warm-up pass on a 20 000-point
-        cloud (thread pools, allocator), then ONE timed pass at full size (tens of seconds);
-      * `parity`: the GPU chain with the SAME weights on the SAME frame against that CPU pass - integer side (voxel set,
-        foreground selection, cluster assignment / virtual voxels) and the features along the chain; gradients of three
-        parameters at the ends and the middle of the chain."""
-    from oracle import fsd_cpu
-    all_threads = torch.get_num_threads()
-    port = spec['cls'](fsd_cpu).train()
-    port.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
-    # thread sweep on a 20 000-point cloud (the SST leg showed 128 threads to be 3.5 x slower than 16-32 for this kind of
-    # work: many small ops): one untimed warm-up pass, then one timed forward + backward per candidate thread count
-    probe = [model.make_cloud(20000, 7, 'cpu')]
-    port(probe)[0].backward()
-    port.zero_grad(set_to_none=True)
-    sweep = {}
-    for t in sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads}):
-        torch.set_num_threads(t)
-        t0 = time.perf_counter()
-        port(probe)[0].backward()
-        sweep[t] = round(time.perf_counter() - t0, 2)
-        port.zero_grad(set_to_none=True)
-    threads = min(sweep, key=sweep.get)
-    torch.set_num_threads(threads)
-    frame = [clouds[0].cpu()]
+def _chain_parity(port, model, cloud):
+    """one forward + backward of the CPU port and of the GPU chain on the same frame with the same weights -> (cpu seconds, parity)"""
+    frame = [cloud.cpu()]
     t0 = time.perf_counter()
     loss_c, _, tc = port(frame, return_tensors=True)
     loss_c.backward()
     cpu_s = time.perf_counter() - t0
-    torch.set_num_threads(all_threads)
     model.zero_grad(set_to_none=True)
-    loss_g, stats, tg = model([clouds[0]], return_tensors=True)
+    loss_g, stats, tg = model([cloud], return_tensors=True)
     loss_g.backward()
     ints, feats = {}, {}
     for key, a in tc.items():
@@ -540,6 +525,50 @@ def cpu_chain_leg(spec, model, clouds):
                       'from the exact gradient on these frames and the GPU path no further (profiles/r04/'
                       '*_grad_adjudication.json, tests/adjudicate_fsd_grads.py, tests/test_fsd_chain.py::'
                       'test_gpu_gradients_within_fp32_noise_at_40k); the 1e-3 bar is stated for features'}
+    return cpu_s, parity
+
+
+def cpu_chain_leg(spec, model, clouds, parity_points=None):
+    """The CPU port of the same chain (oracle/fsd_cpu.py: the reference's algorithm module by module, pinned to the
+    reference by tests/test_fsd_chain.py) on the host cores, rank 0 at N = 1 - the ONLY place this file touches oracle/:
+      * `cpu_baseline`: frames/s of forward + backward of the first bench frame: one untimed warm-up pass on a 20 000-point
+        cloud (thread pools, allocator), then ONE timed pass at full size (tens of seconds);
+      * `parity`: the GPU chain with the SAME weights on the SAME frame against that CPU pass - integer side (voxel set,
+        foreground selection, cluster assignment / virtual voxels) and the features along the chain; gradients of three
+        parameters at the ends and the middle of the chain."""
+    from oracle import fsd_cpu
+    all_threads = torch.get_num_threads()
+    port = spec['cls'](fsd_cpu).train()
+    port.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
+    if parity_points:
+        # bench.py --compact (a leg inside the default line): parity only, on a bounded frame of the same generator - one CPU
+        # pass of a few seconds at 16 threads instead of the thread sweep + the full-size timed pass
+        torch.set_num_threads(min(16, all_threads))
+        small = model.make_cloud(int(parity_points), 1000, clouds[0].device)
+        try:
+            _, parity = _chain_parity(port, model, small)
+        finally:
+            torch.set_num_threads(all_threads)
+        parity['frame_points'] = int(parity_points)
+        return None, parity
+    # thread sweep on a 20 000-point cloud (the SST leg showed 128 threads to be 3.5 x slower than 16-32 for this kind of
+    # work: many small ops): one untimed warm-up pass, then one timed forward + backward per candidate thread count
+    probe = [model.make_cloud(20000, 7, 'cpu')]
+    port(probe)[0].backward()
+    port.zero_grad(set_to_none=True)
+    sweep = {}
+    for t in sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads}):
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        port(probe)[0].backward()
+        sweep[t] = round(time.perf_counter() - t0, 2)
+        port.zero_grad(set_to_none=True)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    torch.set_num_threads(threads)
+    cpu_s, parity = _chain_parity(port, model, clouds[0])
+    torch.set_num_threads(all_threads)
+    frame = [clouds[0]]
     base = {'value': round(1.0 / cpu_s, 5), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
             'thread_sweep_20k_points_s': sweep,
             'sample': f'1 timed pass of 1 frame ({frame[0].size(0)} points), forward + backward, {cpu_s:.1f} s at {threads} threads '
@@ -620,6 +649,8 @@ def run(args, rank, world, dev, make_reducer, line_out=None, step_times_cls=None
     spconv.set_conv_precision(conv_prec)
     if conv_prec == 'f32x3':               # profiling the two-way split: not a headline, no parity legs
         args.no_f32x3_leg = args.no_cpu_baseline = True
+    if getattr(args, 'compact', False):
+        args.no_f32x3_leg = True
     torch.manual_seed(0)
     model = spec['cls']().to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
@@ -698,7 +729,8 @@ def run(args, rank, world, dev, make_reducer, line_out=None, step_times_cls=None
             mfma_leg = _conv_precision_leg('f32', conv_prec, model, clouds, step, sync, args, world, dev)
     cpu_base = parity = None
     if rank == 0 and world == 1 and not getattr(args, 'no_cpu_baseline', False):
-        cpu_base, parity = cpu_chain_leg(spec, model, clouds)
+        cpu_base, parity = cpu_chain_leg(spec, model, clouds,
+                                         parity_points=getattr(args, 'parity_points', None) if getattr(args, 'compact', False) else None)
     if rank == 0:
         frames = world * args.frames_per_gpu * args.steps
         res = {'metric': spec['metric'], 'value': round(frames / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world,

@@ -726,11 +726,11 @@ int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const floa
  *   head_scale (last field of both): NULL = softmax(q k^T * scale); else scaled cosine attention (sst_sra_attn_cos_*_f32),
  *             [n_heads] floats = 1 / clamp(tau, tau_min) in device memory, and the backward writes cos_r [m, n_heads]
  *             (d head_scale[h] = colsum(cos_r)[h] / head_scale[h], taken by the caller).
- *   dy1 (last field of the backward arguments): scratch [m, 128] or NULL.  With it the gradient of y1 gets a buffer of its own
- *             instead of being accumulated into ds2, all five parameter gradients of the layer leave in ONE grouped launch
- *             (+ its reduction, which also finishes the LayerNorm parameter gradients) at the end of the layer: 9 launches
- *             instead of 11.  NULL: two groups, each before the buffer it reads is accumulated into (the same gradients up to
- *             the order of the fp32 partial sums: the token slices of a group differ).
+ *   wpack   : the weight images of the one-kernel tail (csrc/layer_tail_x6.hip: out-projection -> norm1 -> feed-forward -> norm2),
+ *             sst_encoder_layer_wpack_bytes() bytes of device memory: formed by the forward call, read by the backward call.
+ *   Launches: forward 4 (in-projection, attention core, weight images, tail), backward 5 (tail, attention core, the five
+ *             weight gradients + their reduction - which also finishes the LayerNorm parameter gradients -, in-projection's data
+ *             gradient).  dy1 (a scratch field of the round-5 sequence) is ignored.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sst_encoder_layer_fwd_args {
   int64_t m, n_windows;
@@ -743,6 +743,7 @@ typedef struct sst_encoder_layer_fwd_args {
   const int32_t* pos_idx;
   float *qkv, *o, *lse, *y1, *s1, *st1, *pre, *h, *s2, *y2, *st2, *y2p;
   const float* head_scale;
+  void* wpack;   /* sst_encoder_layer_wpack_bytes() bytes, written by the forward call, read by the backward call of the SAME layer call */
 } sst_encoder_layer_fwd_args;
 typedef struct sst_encoder_layer_bwd_args {
   int64_t m, n_windows;
@@ -757,9 +758,11 @@ typedef struct sst_encoder_layer_bwd_args {
   void* workspace;
   const float* head_scale;
   float* cos_r;
-  float* dy1;
+  float* dy1;    /* unused since round 6 (the gradient of y1 never leaves the registers of the tail kernel); may be NULL */
+  const void* wpack;
 } sst_encoder_layer_bwd_args;
 int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads);
+int64_t sst_encoder_layer_wpack_bytes(void);
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* args, void* stream);
 int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* args, void* stream);
 

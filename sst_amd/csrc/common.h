@@ -58,7 +58,7 @@ __device__ __forceinline__ int sst_wave_incl_scan(int v) {
 
 // Cross-file internals of the one-call layer executor (csrc/layer_exec.hip): the LayerNorm backward without its finishing launch
 // (csrc/dense.hip) and the weight-gradient group whose reduction launch also sums those partials' columns (csrc/wgrad_x6.hip).
-struct sst_colsum_rider {      // column sums of block partials [nb][width] -> out0 (columns < split) | out1; nb <= 512
+struct sst_colsum_rider {      // column sums of block partials [nb][width] -> out0 (columns < split) | out1
   const float* partials;
   int nb, width, split;
   float* out0;

@@ -1,6 +1,9 @@
 // One post-norm SRA encoder layer (models/sst/sst_basic_block_v2.py:41-126: WindowAttention -> norm1(x + .) -> FFN ->
 // norm2(y1 + .)) as ONE call forward and ONE call backward: the launch sequence of sst_amd/sst_basic_block.py
 // FusedEncoderLayerFn in its exact-split mode (d_model 128, feed-forward 256, head dim 16), issued from C.
+// Round 6: everything behind the attention core is ONE kernel per direction (csrc/layer_tail_x6.hip) - forward 4 launches
+// (in-projection, attention, weight images, tail), backward 5 (tail, attention, weight gradients + their reduction, in-projection's
+// data gradient) instead of 6 and 10, and 56 instead of 69 [M, 128] tensors through HBM per layer.
 //
 // Why: nothing here computes - every step is an entry point of this library - but the Python side of that sequence is
 // 6 + 9 foreign calls per layer with their argument marshalling, 2.6 + 2.7 ms of host time per training step on a fast host and
@@ -52,15 +55,14 @@ extern "C" {
 
 int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads) {
   if (m < 0 || n_heads < 1) return SST_ERR_ARG;
-  const int64_t a = sst_add_layernorm_bwd_workspace_bytes(m, kC), b = wg_ws(m, 0), c = wg_ws(m, 1),
-                d = sst_sra_attn_bwd_workspace_bytes(m, n_heads), e = wg_ws(m, 2);
-  if (a < 0 || b < 0 || c < 0 || d < 0 || e < 0) return SST_ERR_UNSUPPORTED;
+  const int64_t a = sst_encoder_tail_bwd_workspace_bytes(m), d = sst_sra_attn_bwd_workspace_bytes(m, n_heads), e = wg_ws(m, 2);
+  if (a < 0 || d < 0 || e < 0) return SST_ERR_UNSUPPORTED;
   // the users never overlap in time on the stream, but a kernel of one may still run when the next is queued: own pieces.
-  // Two groups (dy1 == NULL): a | b | c | d.  One group: a | a (both LayerNorms' partials wait for the reduction) | e | d.
-  const int64_t two = sst_align_up(a, 256) + sst_align_up(b, 256) + sst_align_up(c, 256),
-                one = 2 * sst_align_up(a, 256) + sst_align_up(e, 256);
-  return (two > one ? two : one) + sst_align_up(d, 256) + 256;
+  // LayerNorm partials of the tail (they wait for the weight gradients' reduction launch) | the five weight gradients | attention
+  return sst_align_up(a, 256) + sst_align_up(e, 256) + sst_align_up(d, 256) + 256;
 }
+
+int64_t sst_encoder_layer_wpack_bytes(void) { return sst_encoder_tail_pack_bytes(); }
 
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* a, void* stream) {
   if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
@@ -80,75 +82,51 @@ int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* a, void* strea
     rc = sst_sra_attn_fwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->tok, a->winoff, a->order,
                                   a->n_windows, a->n_heads, a->scale, a->max_tokens, a->impl, a->o, kC, a->lse, stream);
   if (rc) return rc;
-  // out-projection + residual + LayerNorm (:113-115)
-  rc = sst_tall_linear_ln_f32x6(a->o, kC, a->w_out, kC, a->b_out, m, kC, a->x, kC, a->n1w, a->n1b, a->eps, a->y1, a->s1, a->st1,
-                                nullptr, nullptr, nullptr, stream);
+  // everything behind the attention core as one kernel (:113-118): the weight images of this call first
+  if (!a->wpack) return SST_ERR_ARG;
+  rc = sst_encoder_tail_pack_f32x6(a->w_out, a->w1, a->w2, a->wpack, stream);
   if (rc) return rc;
-  // linear1 + activation, pre-activation kept (:116)
-  rc = sst_tall_linear_epi_f32x6(a->y1, kC, a->w1, kC, 0, a->b1, m, kC, kFF, a->act == 1 ? kEpiGelu : kEpiRelu, nullptr, a->pre,
-                                 kFF, a->h, kFF, stream);
-  if (rc) return rc;
-  // linear2 + residual, then LayerNorm (+ the next layer's positional embedding) over the sum (:116-118)
-  rc = sst_tall_linear_epi_f32x6(a->h, kFF, a->w2, kFF, 0, a->b2, m, kFF, kC, kEpiAdd, a->y1, nullptr, kC, a->s2, kC, stream);
-  if (rc) return rc;
-  if (a->pos_table != nullptr)
-    return sst_add_layernorm_pos_fwd_f32(a->s2, nullptr, a->n2w, a->n2b, m, kC, a->eps, a->y2, nullptr, a->st2, a->pos_table,
-                                         a->pos_idx, a->y2p, stream);
-  return sst_add_layernorm_act_fwd_f32(a->s2, nullptr, a->n2w, a->n2b, m, kC, a->eps, 0, a->y2, nullptr, a->st2, stream);
+  sst_encoder_tail_fwd_args t;
+  t.m = m, t.act = a->act, t.reserved = 0, t.eps = a->eps, t.reserved_f = 0.f;
+  t.o = a->o, t.x = a->x, t.packed = a->wpack;
+  t.b_out = a->b_out, t.b1 = a->b1, t.b2 = a->b2, t.n1w = a->n1w, t.n1b = a->n1b, t.n2w = a->n2w, t.n2b = a->n2b;
+  t.pos_table = a->pos_table, t.pos_idx = a->pos_idx;
+  t.s1 = a->s1, t.st1 = a->st1, t.y1 = a->y1, t.pre = a->pre, t.h = a->h, t.s2 = a->s2, t.st2 = a->st2, t.y2 = a->y2;
+  t.y2p = a->pos_table != nullptr ? a->y2p : nullptr;
+  return sst_encoder_tail_fwd_f32x6(&t, stream);
 }
 
 int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* stream) {
   if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
   if (a->m == 0) return SST_OK;
-  if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->ds1 || !a->d_o || !a->dqkv) return SST_ERR_ARG;
+  if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->ds1 || !a->d_o || !a->dqkv || !a->wpack) return SST_ERR_ARG;
   if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
   const int64_t m = a->m;
-  const bool one_group = a->dy1 != nullptr;   // the gradient of y1 in a buffer of its own: ds2 stays what dW2 needs until the end
-  const int64_t ln_bytes = sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
   char* ws = (char*)a->workspace;
-  void* ws_ln2 = ws;                           // partials of norm2's parameter gradients
-  ws += ln_bytes;
-  void* ws_ln1 = one_group ? (void*)ws : ws_ln2;   // ... of norm1's: the same piece again when norm2's have been summed by then
-  if (one_group) ws += ln_bytes;
-  void* ws_g1 = ws;
-  ws += sst_align_up(wg_ws(m, one_group ? 2 : 0), 256);
-  void* ws_g2 = ws;
-  if (!one_group) ws += sst_align_up(wg_ws(m, 1), 256);
+  void* ws_tail = ws;
+  ws += sst_align_up(sst_encoder_tail_bwd_workspace_bytes(m), 256);
+  void* ws_wg = ws;
+  ws += sst_align_up(wg_ws(m, 2), 256);
   void* ws_sra = ws;
   int rc;
+  // norm2' -> linear2' * act' -> linear1' + residual -> norm1' -> out-projection' in one kernel; d(gamma) | d(beta) of both
+  // LayerNorms stay as per-workgroup partials for the reduction launch of the weight gradients below
+  sst_encoder_tail_bwd_args t;
+  t.m = m, t.act = a->act, t.reserved = 0;
+  t.dy2 = a->dy2, t.dy2p = a->dy2p, t.s2 = a->s2, t.st2 = a->st2, t.pre = a->pre, t.s1 = a->s1, t.st1 = a->st1;
+  t.packed = a->wpack, t.n1w = a->n1w, t.n2w = a->n2w;
+  t.ds2 = a->ds2, t.dpre = a->dpre, t.ds1 = a->ds1, t.d_o = a->d_o;
+  t.dn2w = a->dn2w, t.dn2b = a->dn2b, t.dn1w = a->dn1w, t.dn1b = a->dn1b;
+  t.workspace = ws_tail;
+  float *part2 = nullptr, *part1 = nullptr;
+  int rows = 0;
+  rc = sst_internal_encoder_tail_bwd_f32x6(&t, &part2, &part1, &rows, stream);
+  if (rc) return rc;
   sst_colsum_rider riders[2];
-  // norm2 backward: d(y1 residual) = d(FFN output); the next layer's x + pos output arrives as a second gradient.
-  // (d(gamma) | d(beta): the block partials stay in the workspace, their columns are summed by the reduction launch of the next
-  // weight-gradient group - one finishing launch less per LayerNorm)
-  rc = sst_internal_add_layernorm_bwd2_partials_f32(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, ws_ln2, &riders[0].nb,
-                                                    stream);
-  if (rc) return rc;
-  riders[0].partials = (const float*)ws_ln2, riders[0].width = 2 * kC, riders[0].split = kC;
+  riders[0].partials = part2, riders[0].nb = rows, riders[0].width = 2 * kC, riders[0].split = kC;
   riders[0].out0 = a->dn2w, riders[0].out1 = a->dn2b;
-  // linear2's data gradient with the activation's derivative in the epilogue
-  rc = sst_tall_linear_epi_f32x6(a->ds2, kC, a->w2, kFF, 1, nullptr, m, kC, kFF, a->act == 1 ? kEpiMulGeluGrad : kEpiMulReluGrad,
-                                 a->pre, nullptr, kFF, a->dpre, kFF, stream);
-  if (rc) return rc;
-  sst_wgrad_problem_f32 g[5];
-  g[0].dy = a->ds2, g[0].x = a->h, g[0].m = m, g[0].ld_dy = kC, g[0].ld_x = kFF, g[0].dw = a->dw2, g[0].db = a->db2;
-  g[0].out = kC, g[0].in = kFF;
-  g[1].dy = a->dpre, g[1].x = a->y1, g[1].m = m, g[1].ld_dy = kFF, g[1].ld_x = kC, g[1].dw = a->dw1, g[1].db = a->db1;
-  g[1].out = kFF, g[1].in = kC;
-  if (!one_group) {   // before ds2 is accumulated into
-    rc = sst_internal_weight_grad_group_f32x6(g, 2, ws_g1, riders, 1, stream);
-    if (rc) return rc;
-  }
-  // residual + FFN branch: dy1 = ds2 + dpre W1 (in place unless dy1 has a buffer of its own)
-  float* dy1 = one_group ? a->dy1 : a->ds2;
-  rc = sst_tall_linear_epi_f32x6(a->dpre, kFF, a->w1, kC, 1, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, dy1, kC, stream);
-  if (rc) return rc;
-  sst_colsum_rider& r1 = riders[one_group ? 1 : 0];
-  rc = sst_internal_add_layernorm_bwd2_partials_f32(dy1, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, ws_ln1, &r1.nb, stream);
-  if (rc) return rc;
-  r1.partials = (const float*)ws_ln1, r1.width = 2 * kC, r1.split = kC;
-  r1.out0 = a->dn1w, r1.out1 = a->dn1b;
-  rc = sst_tall_linear_epi_f32x6(a->ds1, kC, a->w_out, kC, 1, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
-  if (rc) return rc;
+  riders[1].partials = part1, riders[1].nb = rows, riders[1].width = 2 * kC, riders[1].split = kC;
+  riders[1].out0 = a->dn1w, riders[1].out1 = a->dn1b;
   if (a->head_scale != nullptr)
     rc = sst_sra_attn_cos_bwd_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, a->o, a->d_o, a->lse, 3 * kC, 3 * kC, 3 * kC, kC, kC, a->tok,
                                   a->winoff, a->order, a->n_windows, m, a->n_heads, a->head_scale, a->max_tokens, a->dqkv,
@@ -158,16 +136,20 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
                                   a->winoff, a->order, a->n_windows, m, a->n_heads, a->scale, a->max_tokens, a->impl, a->dqkv,
                                   a->dqkv + kC, a->dqkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, ws_sra, stream);
   if (rc) return rc;
-  sst_wgrad_problem_f32* g2 = g + 2;
-  g2[0].dy = a->ds1, g2[0].x = a->o, g2[0].m = m, g2[0].ld_dy = kC, g2[0].ld_x = kC, g2[0].dw = a->dwo, g2[0].db = a->dbo;
-  g2[0].out = kC, g2[0].in = kC;
-  g2[1].dy = a->dqkv, g2[1].x = a->xp, g2[1].m = m, g2[1].ld_dy = 3 * kC, g2[1].ld_x = kC, g2[1].dw = a->dw_in, g2[1].db = a->db_in;
-  g2[1].out = 2 * kC, g2[1].in = kC;
-  g2[2].dy = a->dqkv + 2 * kC, g2[2].x = a->x, g2[2].m = m, g2[2].ld_dy = 3 * kC, g2[2].ld_x = kC;
-  g2[2].dw = a->dw_in + 2 * kC * kC, g2[2].db = a->db_in + 2 * kC, g2[2].out = kC, g2[2].in = kC;
-  // before ds1 is accumulated into: the three gradients that read it and dqkv - or, with dy1, all five of the layer
-  rc = one_group ? sst_internal_weight_grad_group_f32x6(g, 5, ws_g1, riders, 2, stream)
-                 : sst_internal_weight_grad_group_f32x6(g2, 3, ws_g2, riders, 1, stream);
+  // all five parameter gradients of the layer in one grouped launch (+ its reduction, which also finishes the LayerNorm
+  // parameter gradients), before ds1 is accumulated into
+  sst_wgrad_problem_f32 g[5];
+  g[0].dy = a->ds2, g[0].x = a->h, g[0].m = m, g[0].ld_dy = kC, g[0].ld_x = kFF, g[0].dw = a->dw2, g[0].db = a->db2;
+  g[0].out = kC, g[0].in = kFF;
+  g[1].dy = a->dpre, g[1].x = a->y1, g[1].m = m, g[1].ld_dy = kFF, g[1].ld_x = kC, g[1].dw = a->dw1, g[1].db = a->db1;
+  g[1].out = kFF, g[1].in = kC;
+  g[2].dy = a->ds1, g[2].x = a->o, g[2].m = m, g[2].ld_dy = kC, g[2].ld_x = kC, g[2].dw = a->dwo, g[2].db = a->dbo;
+  g[2].out = kC, g[2].in = kC;
+  g[3].dy = a->dqkv, g[3].x = a->xp, g[3].m = m, g[3].ld_dy = 3 * kC, g[3].ld_x = kC, g[3].dw = a->dw_in, g[3].db = a->db_in;
+  g[3].out = 2 * kC, g[3].in = kC;
+  g[4].dy = a->dqkv + 2 * kC, g[4].x = a->x, g[4].m = m, g[4].ld_dy = 3 * kC, g[4].ld_x = kC;
+  g[4].dw = a->dw_in + 2 * kC * kC, g[4].db = a->db_in + 2 * kC, g[4].out = kC, g[4].in = kC;
+  rc = sst_internal_weight_grad_group_f32x6(g, 5, ws_wg, riders, 2, stream);
   if (rc) return rc;
   // d(x) of the residual branch and of all three projections: one product over K = 384 (xp = x + constant: d(x) += d(xp))
   return sst_tall_linear_epi_f32x6(a->dqkv, 3 * kC, a->w_in, kC, 1, nullptr, m, 3 * kC, kC, kEpiAdd, a->ds1, nullptr, kC, a->ds1, kC,

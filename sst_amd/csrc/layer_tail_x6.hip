@@ -25,6 +25,13 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef SST_NT_OUT
+#define SST_NT_OUT false
+#endif
+#ifndef SST_NT_BWD
+#define SST_NT_BWD true
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -131,9 +138,10 @@ static_assert(kNTH >= 2 * kC, "one thread per LayerNorm parameter-gradient colum
 constexpr int kNChunks = kNF + 2;
 constexpr int kPackDir = kNChunks * kSlot;               // packed weight images of one direction: 10 chunk images of kSlot bytes
 constexpr int kParF = 6 * kC + kFF;                       // forward parameters in LDS: b_o, g1, be1, b2, g2, be2 | b1
-constexpr int kArea = 2 * kPart1 + kPart2;                 // LDS weight area of a workgroup: 72 KiB (an out-projection half takes 48 of it)
-constexpr int kLdsFwd = kArea + kParF * 4;
-constexpr int kLdsBwd = kArea + 2 * kC * 4 + kWaves * 2 * kC * 4;   // gamma2 | gamma1 | one [waves][256] reduction area (used twice)
+constexpr int kArea = kSlot;                               // LDS weight area of a workgroup: first-product part | second-product part
+constexpr int kScr = 2048;                               // per wave: one 16-token x 32-column fp32 block on its way between layouts
+constexpr int kLdsFwd = kArea + kParF * 4 + kWaves * kScr;
+constexpr int kLdsBwd = kArea + 2 * kC * 4 + kWaves * 2 * kC * 4 + kWaves * kScr;   // gamma2 | gamma1 | one [waves][256] reduction area (used twice)
 
 // ---- weight images ------------------------------------------------------------------------------------------------------------
 // The three bf16 images of every chunk are formed ONCE per layer call by encoder_tail_pack_k (global fp32 -> registers -> split
@@ -259,6 +267,72 @@ __device__ __forceinline__ void dma_pieces(const unsigned char* __restrict__ src
 // barrier that does NOT drain the vector-memory counter (stores / DMA stay in flight across it): the LDS reads of the phase it
 // ends are retired (lgkmcnt(0)), nothing else is waited for.  Only where no DMA has to have landed by this point.
 __device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// THE barrier of the chunk choreography: every vector-memory operation of this wave - its LDS-DMA pieces among them - and every
+// LDS operation has completed, then the workgroup meets.  Written out: __syncthreads() leaves the vmcnt wait to the compiler's
+// view of which LDS-DMA may alias which ds_read, and a missing one shows as rare wrong tiles in workgroups that start late
+// (found by running the kernel twice on the same input: 2 % of the s2 rows differed).
+__device__ __forceinline__ void barrier_drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- global memory <-> the MFMA fragment layout, through a wave-private LDS block ---------------------------------------------
+// In the fragment layout lane (c, g) holds 32 bytes of token c: consecutive lanes are consecutive ROWS, so a dwordx4 access of a
+// wave touches 64 different 16-byte pieces (16 rows x 4 pieces with holes between them) - measured: the forward kernel's stores
+// alone took 70 of its 188 us (2 TB/s against 6.7 TB/s of a plain fill), and every fragment-shaped load pays the same way.
+// Here a 16-token x 32-column block (2 KiB) passes through LDS so that in global memory lane l touches row l / 8, piece l % 8:
+// 8 consecutive lanes = one full 128-byte line.  The 16-byte slots of a row are XOR-swizzled with the row so that both the
+// fragment-side and the row-side LDS accesses are bank-conflict-free (ds_*_b128 lane groups: MI355X_MICROARCH.md, LDS).  One
+// wave, in-order LDS: no barrier.
+struct tile_io {
+  unsigned char* scr;   // this wave's 2 KiB
+  int frag_off0;        // fragment side: slot 2 g of row c (the second half: ^ 16)
+  int row_off[2];       // row side, instruction i: row 8 i + lane / 8, slot lane % 8
+  int64_t rrow[2];      // the global rows of the row side (clamped to m - 1 for loads)
+  bool rvalid[2];
+  int rcol;             // (lane % 8) * 4
+};
+__device__ __forceinline__ tile_io make_tile_io(unsigned char* scr, int lane, int64_t r0, int64_t m) {
+  tile_io t;
+  const int c = lane & 15, g = lane >> 4;
+  t.scr = scr;
+  t.frag_off0 = c * 128 + (((2 * g) ^ (c & 7)) << 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * i + (lane >> 3), p = lane & 7;
+    t.row_off[i] = r * 128 + ((p ^ (r & 7)) << 4);
+    t.rvalid[i] = r0 + r < m;
+    t.rrow[i] = t.rvalid[i] ? r0 + r : m - 1;
+  }
+  t.rcol = (lane & 7) * 4;
+  return t;
+}
+// columns col0 .. col0 + 31 of the wave's 16 tokens: fragment registers (v0: 8 g .. + 3, v1: 8 g + 4 .. + 7 of token c) -> memory
+// STREAM: the tensor is read again only much later (kept for the backward pass): nontemporal stores - they do not queue behind
+// the cache's write-back of earlier lines (measured on the forward kernel: 190 -> 175 us with every store streamed)
+template <bool STREAM>
+__device__ __forceinline__ void store32(const tile_io& t, float* __restrict__ base, int64_t ld, int col0, const f32x4& v0,
+                                        const f32x4& v1) {
+  *(f32x4*)(t.scr + t.frag_off0) = v0;
+  *(f32x4*)(t.scr + (t.frag_off0 ^ 16)) = v1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x4 w = *(const f32x4*)(t.scr + t.row_off[i]);
+    if (t.rvalid[i]) {
+      if (STREAM)
+        __builtin_nontemporal_store(w, (f32x4*)(base + t.rrow[i] * ld + col0 + t.rcol));
+      else
+        *(f32x4*)(base + t.rrow[i] * ld + col0 + t.rcol) = w;
+    }
+  }
+}
+__device__ __forceinline__ void load32_issue(const tile_io& t, const float* __restrict__ base, int64_t ld, int col0, f32x4 (&w)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) w[i] = *(const f32x4*)(base + t.rrow[i] * ld + col0 + t.rcol);
+}
+__device__ __forceinline__ void load32_finish(const tile_io& t, const f32x4 (&w)[2], f32x4& v0, f32x4& v1) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *(f32x4*)(t.scr + t.row_off[i]) = w[i];
+  v0 = *(const f32x4*)(t.scr + t.frag_off0);
+  v1 = *(const f32x4*)(t.scr + (t.frag_off0 ^ 16));
+}
 
 // ---- the three products on a wave's 16 tokens -------------------------------------------------------------------------------
 // out-projection k-half (two k-steps, 8 output tiles): acc[T] += W(slot)[T] x(ks), x split on the way (smallest products first)
@@ -400,21 +474,22 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_fwd_x6_k(const tail_fwd_
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerWg + wave * 16;
   const bool valid = r0 + c < P.m;
   const int64_t row = valid ? r0 + c : P.m - 1;
-  // the wave's o tile (B operand of the out-projection) and x tile (the residual, same addresses: k-step s <-> columns 32 s ..)
+  const tile_io io = make_tile_io(lds + kArea + kParF * 4 + wave * kScr, lane, r0, P.m);
+  const unsigned char* packed = P.packed;
+  unsigned char* const part2 = lds + kPart1;
+  dma_pieces(packed, lds, 3 * kIA / 1024, wave, lane);   // out-projection half 0
+  // the wave's o tile (B operand of the out-projection) and x tile (the residual: k-step s <-> columns 32 s ..)
   f32x4 ob[4][2], xr[4][2];
   {
-    const float* po = P.o + row * kC + 8 * g;
-    const float* px = P.x + row * kC + 8 * g;
+    f32x4 wo[4][2], wx[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      ob[s][0] = *(const f32x4*)(po + 32 * s);
-      ob[s][1] = *(const f32x4*)(po + 32 * s + 4);
-    }
+    for (int s = 0; s < 4; ++s) load32_issue(io, P.o, kC, 32 * s, wo[s]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      xr[s][0] = *(const f32x4*)(px + 32 * s);
-      xr[s][1] = *(const f32x4*)(px + 32 * s + 4);
-    }
+    for (int s = 0; s < 4; ++s) load32_issue(io, P.x, kC, 32 * s, wx[s]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) load32_finish(io, wo[s], ob[s][0], ob[s][1]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) load32_finish(io, wx[s], xr[s][0], xr[s][1]);
   }
   for (int i = threadIdx.x; i < kC; i += kNTH) {
     par[i] = P.b_out ? P.b_out[i] : 0.f;
@@ -433,24 +508,19 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_fwd_x6_k(const tail_fwd_
   for (int T = 0; T < 8; ++T) acc[T] = z4;
   img3 yi[4];   // y1's parts: B operand of every chunk's first product, and the residual of the second LayerNorm
 
-  // chunk choreography.  LDS weight area = first-product part A | first-product part B | second-product part (24 KiB each); the
-  // CU's second workgroup computes while this one waits.  Out-projection halves take the first 48 KiB: DMA, drain, barrier,
-  // multiply, barrier.  Feed-forward chunk j: [phase 1] request chunk j + 1's first-product images into the OTHER first part,
-  // first product from this chunk's part, activation; __syncthreads() (drains: chunk j + 1's first part and this chunk's second
-  // part have landed); [phase 2] store pre | h, second product from the second part; barrier WITHOUT a vmcnt drain (the stores
-  // stay in flight into the next chunk); request chunk j + 1's second-product images into the second part.
-  const unsigned char* packed = P.packed;
-  unsigned char* const part2 = lds + 2 * kPart1;
-  dma_pieces(packed, lds, 3 * kIA / 1024, wave, lane);
-  __syncthreads();
+  // chunk choreography, ONE slot per workgroup (the CU's second workgroup computes while this one waits).  Out-projection halves
+  // take the whole slot: DMA, drain, barrier, multiply, barrier.  A feed-forward chunk uses the slot's two parts in turn - while
+  // the first product reads part 1 the DMA of the chunk's second-product images lands in part 2, while the second product reads
+  // part 2 the next chunk's first-product images land in part 1 - so no DMA latency is exposed after the first chunk.
+  // Every barrier_drain() drains vmcnt and lgkmcnt before its s_barrier: "landed for all waves" and "nobody reads any more".
+  barrier_drain();
   mma_half<0>(lds, lane_offA, ob, acc);
-  __syncthreads();
+  barrier_drain();
   dma_pieces(packed + kSlot, lds, 3 * kIA / 1024, wave, lane);
-  __syncthreads();
+  barrier_drain();
   mma_half<1>(lds, lane_offA, ob, acc);
-  __syncthreads();
-  dma_pieces(packed + 2 * kSlot, lds, kPart1 / 1024, wave, lane);                    // feed-forward chunk 0 (landed at the next drain)
-  dma_pieces(packed + 2 * kSlot + kPart1, part2, kPart2 / 1024, wave, lane);
+  barrier_drain();
+  dma_pieces(packed + 2 * kSlot, lds, kSlot / 1024, wave, lane);   // feed-forward chunk 0, both parts (landed at the next barrier)
   {
     // s1 = out-proj + b_o + x; y1 = LN1(s1)
     f32x4 v[4][2];
@@ -459,10 +529,7 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_fwd_x6_k(const tail_fwd_
       const int n0 = 32 * s + 8 * g;
       v[s][0] = acc[2 * s] + *(const f32x4*)(par + n0) + xr[s][0];
       v[s][1] = acc[2 * s + 1] + *(const f32x4*)(par + n0 + 4) + xr[s][1];
-      if (P.s1 != nullptr && valid) {
-        *(f32x4*)(P.s1 + row * kC + n0) = v[s][0];
-        *(f32x4*)(P.s1 + row * kC + n0 + 4) = v[s][1];
-      }
+      if (P.s1 != nullptr) store32<true>(io, P.s1, kC, 32 * s, v[s][0], v[s][1]);
     }
     float mean, rstd;
     ln_stats(v, P.eps, mean, rstd);
@@ -472,21 +539,22 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_fwd_x6_k(const tail_fwd_
       const int n0 = 32 * s + 8 * g;
       const f32x4 y0 = v[s][0] * rstd * *(const f32x4*)(par + kC + n0) + *(const f32x4*)(par + 2 * kC + n0);
       const f32x4 y1 = v[s][1] * rstd * *(const f32x4*)(par + kC + n0 + 4) + *(const f32x4*)(par + 2 * kC + n0 + 4);
-      if (valid) {
-        *(f32x4*)(P.y1 + row * kC + n0) = y0;
-        *(f32x4*)(P.y1 + row * kC + n0 + 4) = y1;
-      }
+      store32<true>(io, P.y1, kC, 32 * s, y0, y1);
       yi[s] = split8(y0, y1);
     }
 #pragma unroll
     for (int T = 0; T < 8; ++T) acc[T] = z4;
   }
-  __syncthreads();   // chunk 0's images have landed
+  barrier_drain();   // chunk 0's images have landed
+  f32x4 sp0 = z4, sp1 = z4, sh0 = z4, sh1 = z4;   // pre | h of the previous chunk, stored one phase later
 #pragma unroll 1
   for (int j = 0; j < kNF; ++j) {
-    if (j + 1 < kNF) dma_pieces(packed + (size_t)(j + 3) * kSlot, lds + ((j + 1) & 1) * kPart1, kPart1 / 1024, wave, lane);
+    if (j > 0) {   // behind the barrier that needed no store to be finished; acknowledged by the next drain, a whole phase away
+      store32<true>(io, P.pre, kFF, kHC * (j - 1), sp0, sp1);
+      store32<true>(io, P.h, kFF, kHC * (j - 1), sh0, sh1);
+    }
     f32x4 p0, p1;
-    mma_first(lds + (j & 1) * kPart1, lane_off1, yi, p0, p1);
+    mma_first(lds, lane_off1, yi, p0, p1);
     const int nl = kHC * j + 8 * g;
     p0 += *(const f32x4*)(par + 6 * kC + nl);
     p1 += *(const f32x4*)(par + 6 * kC + nl + 4);
@@ -497,17 +565,15 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_fwd_x6_k(const tail_fwd_
       h1[r] = ACT == 1 ? gelu_f(p1[r]) : fmaxf(p1[r], 0.f);
     }
     const img3 hs = split8(h0, h1);
-    __syncthreads();   // the next chunk's first part and this chunk's second part have landed
-    if (valid) {
-      *(f32x4*)(P.pre + row * kFF + nl) = p0;
-      *(f32x4*)(P.pre + row * kFF + nl + 4) = p1;
-      *(f32x4*)(P.h + row * kFF + nl) = h0;
-      *(f32x4*)(P.h + row * kFF + nl + 4) = h1;
-    }
+    barrier_drain();   // part 1 is free; this chunk's part 2 has landed; the previous chunk's stores are acknowledged
+    if (j + 1 < kNF) dma_pieces(packed + (size_t)(j + 3) * kSlot, lds, kPart1 / 1024, wave, lane);
     mma_second(part2, lane_off2, hs, acc);
-    barrier_lds_only();   // the second part is free; the stores above stay in flight
+    sp0 = p0, sp1 = p1, sh0 = h0, sh1 = h1;
+    barrier_drain();   // part 2 is free, the next chunk's part 1 has landed (nothing else is in flight)
     if (j + 1 < kNF) dma_pieces(packed + (size_t)(j + 3) * kSlot + kPart1, part2, kPart2 / 1024, wave, lane);
   }
+  store32<true>(io, P.pre, kFF, kHC * (kNF - 1), sp0, sp1);
+  store32<true>(io, P.h, kFF, kHC * (kNF - 1), sh0, sh1);
   // s2 = y1 + linear2 + b2; y2 = LN2(s2) (; y2p = y2 + positional rows of the next layer)
   f32x4 v[4][2];
 #pragma unroll
@@ -517,27 +583,19 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_fwd_x6_k(const tail_fwd_
     join8(yi[s], ya, yb);
     v[s][0] = acc[2 * s] + *(const f32x4*)(par + 3 * kC + n0) + ya;
     v[s][1] = acc[2 * s + 1] + *(const f32x4*)(par + 3 * kC + n0 + 4) + yb;
-    if (P.s2 != nullptr && valid) {
-      *(f32x4*)(P.s2 + row * kC + n0) = v[s][0];
-      *(f32x4*)(P.s2 + row * kC + n0 + 4) = v[s][1];
-    }
+    if (P.s2 != nullptr) store32<true>(io, P.s2, kC, 32 * s, v[s][0], v[s][1]);
   }
   float mean, rstd;
   ln_stats(v, P.eps, mean, rstd);
-  if (!valid) return;
-  if (g == 0) ((float2*)P.st2)[row] = make_float2(mean, rstd);
+  if (valid && g == 0) ((float2*)P.st2)[row] = make_float2(mean, rstd);
   const float* prow = P.pos_table != nullptr ? P.pos_table + (size_t)P.pos_idx[row] * kC : nullptr;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int n0 = 32 * s + 8 * g;
     const f32x4 y0 = v[s][0] * rstd * *(const f32x4*)(par + 4 * kC + n0) + *(const f32x4*)(par + 5 * kC + n0);
     const f32x4 y1 = v[s][1] * rstd * *(const f32x4*)(par + 4 * kC + n0 + 4) + *(const f32x4*)(par + 5 * kC + n0 + 4);
-    *(f32x4*)(P.y2 + row * kC + n0) = y0;
-    *(f32x4*)(P.y2 + row * kC + n0 + 4) = y1;
-    if (prow != nullptr) {
-      *(f32x4*)(P.y2p + row * kC + n0) = y0 + *(const f32x4*)(prow + n0);
-      *(f32x4*)(P.y2p + row * kC + n0 + 4) = y1 + *(const f32x4*)(prow + n0 + 4);
-    }
+    store32<SST_NT_OUT>(io, P.y2, kC, 32 * s, y0, y1);
+    if (prow != nullptr) store32<SST_NT_OUT>(io, P.y2p, kC, 32 * s, y0 + *(const f32x4*)(prow + n0), y1 + *(const f32x4*)(prow + n0 + 4));
   }
 }
 
@@ -595,54 +653,49 @@ template <int ACT>
 __global__ __launch_bounds__(kNTH, 2) void encoder_tail_bwd_x6_k(const tail_bwd_params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* par = (float*)(lds + kArea);        // gamma2 | gamma1
-  float* red = par + 2 * kC;                      // [waves][256]: norm2's column sums, later norm1's
+  float* red = par + 2 * kC;                  // [waves][256]: norm2's column sums, later norm1's
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, wave = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerWg + wave * 16;
   const bool valid = r0 + c < P.m;
   const int64_t row = valid ? r0 + c : P.m - 1;
+  const tile_io io = make_tile_io(lds + kArea + 2 * kC * 4 + kWaves * 2 * kC * 4 + wave * kScr, lane, r0, P.m);
   const unsigned char* packed = P.packed;
-  unsigned char* const part2 = lds + 2 * kPart1;
-  dma_pieces(packed, lds, kPart1 / 1024, wave, lane);   // feed-forward chunk 0: lands behind the first LayerNorm backward
-  dma_pieces(packed + kPart1, part2, kPart2 / 1024, wave, lane);
+  unsigned char* const part2 = lds + kPart1;
+  dma_pieces(packed, lds, kSlot / 1024, wave, lane);   // feed-forward chunk 0, both parts: lands behind the first LayerNorm backward
   f32x4 d[4][2], sv[4][2];
   {
-    const float* pd = P.dy2 + row * kC + 8 * g;
-    const float* ps = P.s2 + row * kC + 8 * g;
+    f32x4 wd[4][2], we[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      d[s][0] = *(const f32x4*)(pd + 32 * s);
-      d[s][1] = *(const f32x4*)(pd + 32 * s + 4);
-    }
+    for (int s = 0; s < 4; ++s) load32_issue(io, P.dy2, kC, 32 * s, wd[s]);
     if (P.dy2p != nullptr) {   // the second gradient arriving at the LayerNorm output (its "+ positional rows" copy)
-      const float* pe = P.dy2p + row * kC + 8 * g;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) load32_issue(io, P.dy2p, kC, 32 * s, we[s]);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        d[s][0] += *(const f32x4*)(pe + 32 * s);
-        d[s][1] += *(const f32x4*)(pe + 32 * s + 4);
+        wd[s][0] += we[s][0];
+        wd[s][1] += we[s][1];
       }
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      sv[s][0] = *(const f32x4*)(ps + 32 * s);
-      sv[s][1] = *(const f32x4*)(ps + 32 * s + 4);
-    }
+    for (int s = 0; s < 4; ++s) load32_issue(io, P.s2, kC, 32 * s, we[s]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) load32_finish(io, wd[s], d[s][0], d[s][1]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) load32_finish(io, we[s], sv[s][0], sv[s][1]);
   }
   const float2 st2 = ((const float2*)P.st2)[row];
   for (int i = threadIdx.x; i < kC; i += kNTH) {
     par[i] = P.n2w[i];
     par[kC + i] = P.n1w[i];
   }
-  __syncthreads();    // gamma is in LDS
+  barrier_drain();    // gamma is in LDS
 
   img3 di[4];   // ds2's parts: B operand of every chunk's first product, and the residual branch of d(y1)
   {
     ln_bwd(d, sv, st2, par, g, c, valid, red + wave * 2 * kC);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (valid) {
-        *(f32x4*)(P.ds2 + row * kC + 32 * s + 8 * g) = d[s][0];
-        *(f32x4*)(P.ds2 + row * kC + 32 * s + 8 * g + 4) = d[s][1];
-      }
+      store32<SST_NT_BWD>(io, P.ds2, kC, 32 * s, d[s][0], d[s][1]);
       di[s] = split8(d[s][0], d[s][1]);
     }
   }
@@ -652,42 +705,34 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_bwd_x6_k(const tail_bwd_
 #pragma unroll
   for (int T = 0; T < 8; ++T) acc[T] = z4;
   f32x4 xs1[4][2];   // ds1 (fp32): B operand of the out-projection's data gradient
-  f32x4 pq0, pq1;    // the pre-activation of the running chunk, requested one chunk ahead
-  {
-    const float* pp = P.pre + row * kFF + 8 * g;
-    pq0 = *(const f32x4*)pp;
-    pq1 = *(const f32x4*)(pp + 4);
-  }
+  f32x4 pq[2];       // the pre-activation of the running chunk (row side), requested one chunk ahead
+  load32_issue(io, P.pre, kFF, 0, pq);
 
-  // chunk choreography as in the forward kernel
+  // chunk choreography as in the forward kernel: one slot, its two parts alternate between "being read" and "being filled"
   // feed-forward chunk j: dpre_j = (ds2 W2[:, 32 j ..]) act'(pre_j), d(y1) += dpre_j W1[32 j .., :]
+  f32x4 sd0 = z4, sd1 = z4;   // dpre of the previous chunk, stored one phase later (see the forward kernel)
   auto ffn_chunk = [&](int j, const f32x4 q0, const f32x4 q1) __attribute__((always_inline)) {
-    if (j + 1 < kNF) dma_pieces(packed + (size_t)(j + 1) * kSlot, lds + ((j + 1) & 1) * kPart1, kPart1 / 1024, wave, lane);
+    if (j > 0) store32<SST_NT_BWD>(io, P.dpre, kFF, kHC * (j - 1), sd0, sd1);
     f32x4 p0, p1;
-    mma_first(lds + (j & 1) * kPart1, lane_off1, di, p0, p1);
+    mma_first(lds, lane_off1, di, p0, p1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       p0[r] *= ACT == 1 ? gelu_grad_f(q0[r]) : (q0[r] > 0.f ? 1.f : 0.f);
       p1[r] *= ACT == 1 ? gelu_grad_f(q1[r]) : (q1[r] > 0.f ? 1.f : 0.f);
     }
     const img3 hs = split8(p0, p1);
-    __syncthreads();   // the next chunk's first part and this chunk's second part have landed
-    const int nl = kHC * j + 8 * g;
-    if (valid) {
-      *(f32x4*)(P.dpre + row * kFF + nl) = p0;
-      *(f32x4*)(P.dpre + row * kFF + nl + 4) = p1;
-    }
+    barrier_drain();   // part 1 is free (and this chunk's part 2 has landed)
+    if (j + 1 < kNF) dma_pieces(packed + (size_t)(j + 1) * kSlot, lds, kPart1 / 1024, wave, lane);
     mma_second(part2, lane_off2, hs, acc);
-    if (j + 1 < kNF) {
-      barrier_lds_only();   // the second part is free; the stores stay in flight
+    sd0 = p0, sd1 = p1;
+    barrier_drain();   // part 2 is free, the next chunk's part 1 has landed
+    if (j + 1 < kNF)
       dma_pieces(packed + (size_t)(j + 1) * kSlot + kPart1, part2, kPart2 / 1024, wave, lane);
-    } else {
-      __syncthreads();      // everything of the feed-forward is read: the whole area is free
+    else
       dma_pieces(packed + (size_t)kNF * kSlot, lds, 3 * kIA / 1024, wave, lane);   // out-projection half 0: lands behind norm1's backward
-    }
   };
   // norm2's parameter-gradient partials of this workgroup leave now: the reduction area is used again by norm1's
-  __syncthreads();   // chunk 0's images have landed; all waves' column sums are in LDS
+  barrier_drain();   // chunk 0's images have landed; all waves' column sums are in LDS
   if (threadIdx.x < 2 * kC) {
     float a = 0.f;
 #pragma unroll
@@ -696,19 +741,22 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_bwd_x6_k(const tail_bwd_
   }
 #pragma unroll 1
   for (int j = 0; j < kNF - 1; ++j) {
-    const f32x4 q0 = pq0, q1 = pq1;
-    const float* pp = P.pre + row * kFF + kHC * (j + 1) + 8 * g;   // the next chunk's pre-activation
-    pq0 = *(const f32x4*)pp;
-    pq1 = *(const f32x4*)(pp + 4);
+    f32x4 q0, q1;
+    load32_finish(io, pq, q0, q1);
+    load32_issue(io, P.pre, kFF, kHC * (j + 1), pq);   // the next chunk's pre-activation
     ffn_chunk(j, q0, q1);
   }
   {
-    ffn_chunk(kNF - 1, pq0, pq1);
-    const float* ps = P.s1 + row * kC + 8 * g;   // norm1's input (requested here: a tile of it held across the chunk spills)
+    f32x4 q0, q1;
+    load32_finish(io, pq, q0, q1);
+    ffn_chunk(kNF - 1, q0, q1);
+    store32<SST_NT_BWD>(io, P.dpre, kFF, kHC * (kNF - 1), sd0, sd1);
+    {   // norm1's input (requested here: a tile of it held across the chunk spills)
+      f32x4 ws[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      xs1[s][0] = *(const f32x4*)(ps + 32 * s);
-      xs1[s][1] = *(const f32x4*)(ps + 32 * s + 4);
+      for (int s = 0; s < 4; ++s) load32_issue(io, P.s1, kC, 32 * s, ws[s]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) load32_finish(io, ws[s], xs1[s][0], xs1[s][1]);
     }
     // d(y1) = ds2 + dpre W1; norm1 backward -> ds1 (= d(x) of the residual, = d(out-projection output))
     f32x4 dd[4][2];
@@ -720,33 +768,26 @@ __global__ __launch_bounds__(kNTH, 2) void encoder_tail_bwd_x6_k(const tail_bwd_
       dd[s][1] = acc[2 * s + 1] + yb;
     }
     const float2 st1 = ((const float2*)P.st1)[row];
+    barrier_drain();   // norm2's column sums have been read by every thread: the reduction area is free
     ln_bwd(dd, xs1, st1, par + kC, g, c, valid, red + wave * 2 * kC);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (valid) {
-        *(f32x4*)(P.ds1 + row * kC + 32 * s + 8 * g) = dd[s][0];
-        *(f32x4*)(P.ds1 + row * kC + 32 * s + 8 * g + 4) = dd[s][1];
-      }
+      store32<SST_NT_BWD>(io, P.ds1, kC, 32 * s, dd[s][0], dd[s][1]);
       xs1[s][0] = dd[s][0];
       xs1[s][1] = dd[s][1];
     }
 #pragma unroll
     for (int T = 0; T < 8; ++T) acc[T] = z4;
-    __syncthreads();   // out-projection half 0 has landed
+    barrier_drain();   // out-projection half 0 has landed
     mma_half<0>(lds, lane_offA, xs1, acc);
-    __syncthreads();
+    barrier_drain();
     dma_pieces(packed + (size_t)(kNF + 1) * kSlot, lds, 3 * kIA / 1024, wave, lane);
-    __syncthreads();
+    barrier_drain();
     mma_half<1>(lds, lane_offA, xs1, acc);
   }
-  if (valid) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      *(f32x4*)(P.d_o + row * kC + 32 * s + 8 * g) = acc[2 * s];
-      *(f32x4*)(P.d_o + row * kC + 32 * s + 8 * g + 4) = acc[2 * s + 1];
-    }
-  }
-  __syncthreads();   // all waves' column sums of norm1 are in LDS
+  for (int s = 0; s < 4; ++s) store32<SST_NT_OUT>(io, P.d_o, kC, 32 * s, acc[2 * s], acc[2 * s + 1]);
+  barrier_drain();   // all waves' column sums of norm1 are in LDS
   if (threadIdx.x < 2 * kC) {
     float b = 0.f;
 #pragma unroll

@@ -270,19 +270,23 @@ __global__ __launch_bounds__(256) void wgrad_x6_reduce_k(const x6_group G, const
       // is an HBM round trip.  All 64 of them are requested before the first is added (row clamped, value masked): a loop that
       // waited per step took 30 us.  nb <= 512 (the LayerNorm backward's grid cap; checked by the host).
       const float* src = J.partials + i;
-      float v[16][4];
+      // 512 partial rows at a time (the LayerNorm backward's grid cap; the one-kernel layer tail, csrc/layer_tail_x6.hip, has one
+      // row per 64 tokens): same order of additions per strided sum as colsum_partials_k whatever nb is
+      for (int base = 0; base < J.nb; base += 512) {
+        float v[16][4];
 #pragma unroll
-      for (int it = 0; it < 16; ++it)
+        for (int it = 0; it < 16; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int b = 32 * it + gq + 8 * j;
-          v[it][j] = src[(int64_t)(b < J.nb ? b : J.nb - 1) * J.width];
-        }
+          for (int j = 0; j < 4; ++j) {
+            const int b = base + 32 * it + gq + 8 * j;
+            v[it][j] = src[(int64_t)(b < J.nb ? b : J.nb - 1) * J.width];
+          }
 #pragma unroll
-      for (int it = 0; it < 16; ++it)
+        for (int it = 0; it < 16; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (32 * it + gq + 8 * j < J.nb) acc[j] += v[it][j];
+          for (int j = 0; j < 4; ++j)
+            if (base + 32 * it + gq + 8 * j < J.nb) acc[j] += v[it][j];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) fr[(gq + 8 * j) * 33 + cx] = acc[j];
@@ -420,7 +424,6 @@ int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, 
     SST_HIP(hipFuncSetAttribute((const void*)wgrad_x6_k, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     sst_mark_device(&configured);
   }
-  hipLaunchKernelGGL(wgrad_x6_k, dim3((unsigned)(plan.g.tiles * plan.g.slices)), dim3(512), kLdsBytes, st, plan.g, part, dbp);
   const int64_t quads = (int64_t)plan.g.tiles * (kTile * kTile / 4);
   const int tile_blocks = (int)sst_div_up(quads, (int64_t)kRedQuads);
   if (n_riders < 0 || n_riders > 2 || (n_riders > 0 && !riders)) return SST_ERR_ARG;
@@ -429,11 +432,12 @@ int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, 
   int extra = 0;
   for (int i = 0; i < n_riders; ++i) {
     const sst_colsum_rider& q = riders[i];
-    if (!q.partials || q.nb < 1 || q.nb > 512 || q.width < 1 || !q.out0 || !q.out1) return SST_ERR_ARG;
+    if (!q.partials || q.nb < 1 || q.width < 1 || !q.out0 || !q.out1) return SST_ERR_ARG;
     R.r[i] = q;
     if (i == 0) R.blocks0 = (q.width + 31) / 32;
     extra += (q.width + 31) / 32;
   }
+  hipLaunchKernelGGL(wgrad_x6_k, dim3((unsigned)(plan.g.tiles * plan.g.slices)), dim3(512), kLdsBytes, st, plan.g, part, dbp);
   hipLaunchKernelGGL(wgrad_x6_reduce_k, dim3((unsigned)(tile_blocks + extra)), dim3(256), 0, st, plan.g, part, dbp, extra, R);
   SST_LAUNCH_CHECK();
   return SST_OK;

@@ -19,7 +19,8 @@ from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
 from .sra_composed import sra_attention_composed
-from .dense import (EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
+from .dense import (encoder_tail_ok, encoder_tail_pack, encoder_tail_fwd, encoder_tail_bwd,
+                    EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
                     lds_linear_add_ln, lds_linear_add_ln_ok, lds_linear_dqkv_ok, lds_linear_qkv, lds_linear_qkv_ok,
                     weight_bias_grad_group,
                     tall_gemm, add_layer_norm, add_ln_bwd, add_ln_fwd, dgrad_gelu, linear_gelu, tall_linear,
@@ -254,6 +255,8 @@ def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next,
     base = slab.data_ptr()
     y2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
     y2p = torch.empty((m, 128), dtype=torch.float32, device=dev) if pos_next is not None else None
+    lib = _lib.load()
+    wpack = torch.empty(int(lib.sst_encoder_layer_wpack_bytes()), dtype=torch.uint8, device=dev)   # weight images of the tail kernel
     order = plan.order
     P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     S = lambda name: base + offs[name]                   # noqa: E731
@@ -263,20 +266,19 @@ def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next,
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
         S('qkv'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'), S('s2'), P(y2), S('st2'),
-        P(y2p), P(head_scale))
-    lib = _lib.load()
+        P(y2p), P(head_scale), P(wpack))
     rc = K._bracket('sra_fwd', plan.n_tokens, lambda: lib.sst_encoder_layer_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     if rc == _lib.SST_ERR_UNSUPPORTED:     # a layout one of the entry points does not take: the Python sequence has the retries
         return None
     _lib.check(rc, 'sst_encoder_layer_fwd_f32x6')
-    return slab, y2, y2p
+    return slab, y2, y2p, wpack
 
 
 def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     from . import _lib
     import ctypes
-    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w = saved[:9]
-    head_scale = saved[9] if len(saved) > 9 else None
+    x, xp, slab, w_in, w_out, w1, w2, n1w, n2w, wpack = saved[:10]
+    head_scale = saved[10] if len(saved) > 10 else None
     m = x.size(0)
     dev = x.device
     plan, nhead, impl = ctx.plan, ctx.nhead, ctx.impl
@@ -288,9 +290,9 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     dy2 = dy2.contiguous()
     dy2p = dy2p.contiguous() if dy2p is not None else None
     ds1 = e(m, 128)                                    # leaves as d(x)
-    scratch = e(m, 128 + 256 + 128 + 384 + 128)        # ds2 | dpre | d_o | dqkv | dy1, one after the other (not interleaved)
+    scratch = e(m, 128 + 256 + 128 + 384)              # ds2 | dpre | d_o | dqkv, one after the other (not interleaved)
     sb = scratch.data_ptr()
-    p_ds2, p_dpre, p_do, p_dqkv, p_dy1 = sb, sb + 4 * m * 128, sb + 4 * m * 384, sb + 4 * m * 512, sb + 4 * m * 896
+    p_ds2, p_dpre, p_do, p_dqkv = sb, sb + 4 * m * 128, sb + 4 * m * 384, sb + 4 * m * 512
     dw_in, db_in, dwo, dbo = e(384, 128), e(384), e(128, 128), e(128)
     dw1, db1, dw2, db2 = e(256, 128), e(256), e(128, 256), e(128)
     dn = e(4, 128)
@@ -311,7 +313,7 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         p_ds2, p_dpre, P(ds1), p_do, p_dqkv,
         P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 512, dnp + 1024, dnp + 1536, P(ws),
-        P(head_scale), P(cos_r), p_dy1)
+        P(head_scale), P(cos_r), None, P(wpack))
     rc = K._bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_encoder_layer_bwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
     d_scale = K.head_scale_grad(cos_r, head_scale) if head_scale is not None else None
@@ -357,9 +359,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             scale = 1.0 / math.sqrt(16.0)
             done = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale)
             if done is not None:
-                slab, y2, y2p = done
+                slab, y2, y2p, wpack = done
                 if need_bwd:
-                    ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w, *((head_scale,) if ctx.cosine else ()))
+                    ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w, wpack,
+                                          *((head_scale,) if ctx.cosine else ()))
                     ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
                     ctx.exec = True
                 ctx.two = pos_next is not None
@@ -379,6 +382,29 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         else:
             o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
+        ctx.tail = False
+        wpack = None
+        if (_LDS_LINEAR and c == 128 and act in ('gelu', 'relu') and o.is_contiguous()
+                and encoder_tail_ok(o, x, w_out, w1, w2) and all(t is not None for t in (b_out, b1, b2))):
+            # everything behind the attention core as ONE kernel (csrc/layer_tail_x6.hip), as csrc/layer_exec.hip issues it
+            wpack = encoder_tail_pack(w_out, w1, w2)
+            t = encoder_tail_fwd(o, x, wpack, b_out, b1, b2, n1w, n1b, n2w, n2b, eps, act, save=need_bwd, pos=pos_next)
+            s1, st1, y1, pre, h, s2, st2, y2, y2p = (t[k] for k in ('s1', 'st1', 'y1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p'))
+            ctx.tail = True
+        else:
+            y1, s1, st1, pre, h, s2, st2, y2, y2p = FusedEncoderLayerFn._tail_by_products(
+                o, x, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps, act, need_bwd, pos_next, c)
+        if need_bwd:
+            ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w,
+                                  *((wpack,) if ctx.tail else ()), *((head_scale,) if ctx.cosine else ()))
+            ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
+        ctx.two = pos_next is not None
+        return (y2, y2p) if ctx.two else y2
+
+    @staticmethod
+    def _tail_by_products(o, x, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps, act, need_bwd, pos_next, c):
+        """out-projection -> norm1 -> feed-forward -> norm2, one launch per product / LayerNorm (the modes and shapes the
+        one-kernel tail is not built for)"""
         fuse_ln = _LDS_LINEAR and lds_linear_add_ln_ok(o, w_out, x, c)
         if fuse_ln:    # out-projection + residual + LayerNorm in one kernel (csrc/dense_f32.hip)
             y1, s1, st1, _ = lds_linear_add_ln(o, w_out, b_out, x, n1w, n1b, eps, save_sum=need_bwd)
@@ -405,12 +431,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             y2, s2, st2 = add_ln_fwd(y1, f, n2w, n2b, eps, save_sum=need_bwd)
         if pos_next is not None and y2p is None:
             y2p = y2 + pos_next[0].index_select(0, pos_next[1].long())
-        if need_bwd:
-            ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w,
-                                  *((head_scale,) if ctx.cosine else ()))
-            ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
-        ctx.two = pos_next is not None
-        return (y2, y2p) if ctx.two else y2
+        return y1, s1, st1, pre, h, s2, st2, y2, y2p
 
     @staticmethod
     def backward(ctx, dy2, dy2p=None):
@@ -424,32 +445,42 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             if dy2 is None:       # only the second output was differentiated
                 dy2, dy2p = dy2p, None
             return _layer_exec_bwd(ctx, dy2, dy2p if ctx.two else None, ctx.saved_tensors)
-        x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = ctx.saved_tensors[:19]
-        head_scale = ctx.saved_tensors[19] if ctx.cosine else None
+        saved = ctx.saved_tensors     # ONE access (a second one under torch.utils.checkpoint is an error)
+        x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = saved[:19]
+        rest = list(saved[19:])
+        wpack = rest.pop(0) if ctx.tail else None
+        head_scale = rest.pop(0) if ctx.cosine else None
         c = x.size(1)
         if dy2 is None:           # only the second output was differentiated
             dy2, dy2p = dy2p, None
-        ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
-        ds2_for_w2 = ds2
-        dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
-        if _LDS_LINEAR and lds_linear_ok(ds2, w2, trans_w=True) and pre.is_contiguous():
-            # the activation's derivative in the epilogue of linear2's data gradient
-            dpre = lds_linear(ds2, w2, None, EPI_MUL_GELU_GRAD if ctx.act == 'gelu' else EPI_MUL_RELU_GRAD, trans_w=True,
-                              aux_in=pre)
-        if dpre is None:
-            dh = ds2 @ w2
-            if ctx.act == 'gelu':
-                dpre = torch.ops.aten.gelu_backward(dh, pre)
-            else:
-                dpre = dh * (pre > 0).to(dh.dtype)
         f32 = dict(dtype=torch.float32, device=x.device)
         dw2, db2 = torch.empty_like(w2), torch.empty(w2.size(0), **f32)
         dw1, db1 = torch.empty_like(w1), torch.empty(w1.size(0), **f32)
-        # residual + FFN branch: GEMM with beta = 1 into a buffer of its OWN - ds2 stays what dW2 needs, and all five parameter
-        # gradients of the layer leave in one grouped launch at the end (csrc/layer_exec.hip does the same: 9 launches, not 11)
-        dy1 = _linear_dgrad(dpre, w1, out=torch.empty_like(ds2), add=ds2)
-        ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
-        do = _linear_dgrad(ds1, w_out)
+        if ctx.tail:
+            # norm2' -> linear2' * act' -> linear1' + residual -> norm1' -> out-projection' as ONE kernel (csrc/layer_tail_x6.hip)
+            ds2, dpre, ds1, do, dn = encoder_tail_bwd(dy2.contiguous(), dy2p.contiguous() if (ctx.two and dy2p is not None) else None,
+                                                      s2, st2, pre, s1, st1, wpack, n1w, n2w, ctx.act)
+            ds2_for_w2 = ds2
+            dn2w, dn2b, dn1w, dn1b = dn[0], dn[1], dn[2], dn[3]
+        else:
+            ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
+            ds2_for_w2 = ds2
+            dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
+            if _LDS_LINEAR and lds_linear_ok(ds2, w2, trans_w=True) and pre.is_contiguous():
+                # the activation's derivative in the epilogue of linear2's data gradient
+                dpre = lds_linear(ds2, w2, None, EPI_MUL_GELU_GRAD if ctx.act == 'gelu' else EPI_MUL_RELU_GRAD, trans_w=True,
+                                  aux_in=pre)
+            if dpre is None:
+                dh = ds2 @ w2
+                if ctx.act == 'gelu':
+                    dpre = torch.ops.aten.gelu_backward(dh, pre)
+                else:
+                    dpre = dh * (pre > 0).to(dh.dtype)
+            # residual + FFN branch: GEMM with beta = 1 into a buffer of its OWN - ds2 stays what dW2 needs, and all five parameter
+            # gradients of the layer leave in one grouped launch at the end
+            dy1 = _linear_dgrad(dpre, w1, out=torch.empty_like(ds2), add=ds2)
+            ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
+            do = _linear_dgrad(ds1, w_out)
         # dq | dk | dv in ONE [M, 3C] buffer: d(x) of the whole in-projection is then a single GEMM
         dqkv = torch.empty((x.size(0), 3 * c), dtype=torch.float32, device=x.device)
         dqk, dv = dqkv[:, :2 * c], dqkv[:, 2 * c:]

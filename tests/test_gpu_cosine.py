@@ -131,7 +131,7 @@ def test_cosine_layers_run_in_the_fused_chain_and_match_the_normalise_outside_pa
     # the round-4 path: modular layers, q / k normalised and divided by tau in torch around the standard kernel
     monkeypatch.setattr(K, 'cosine_kernels_ok', lambda *a, **k: False)
     slow = _step(net, layer, feats0, coors, up)
-    assert float((fast[0] - slow[0]).abs().max()) <= 2e-5
+    assert float((fast[0] - slow[0]).abs().max()) <= 4e-5      # two fp32 evaluations of 4 layers: 2.3e-5 measured (round 6: one-kernel tail)
     assert float((fast[1] - slow[1]).abs().max()) <= 5e-5 * max(1.0, float(slow[1].abs().max()))      # 2.0e-5 measured
     assert fast[2].keys() == slow[2].keys() and any(n.endswith('tau') for n in fast[2])
     for n in fast[2]:
