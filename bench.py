@@ -1126,7 +1126,7 @@ def _main(args, line_out):
             cmd = [sys.executable, os.path.abspath(__file__), '--precision', 'bf16', '--steps', str(args.steps), '--warmup',
                    str(max(3, args.warmup)), '--points', str(args.points), '--blocks', str(args.blocks), '--no-cpu-baseline',
                    '--no-lidar-leg', '--no-forward-only-leg', '--no-config-as-is-leg', '--no-traffic-remeasure', '--no-f32x3-leg',
-                   '--no-time-sra-bwd']
+                   '--no-time-sra-bwd', '--no-voxelize-roofline', '--no-workload-legs']
             try:
                 sub = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
                 own = json.loads(sub.stdout.strip().splitlines()[-1])
@@ -1373,9 +1373,13 @@ def _main(args, line_out):
         if world == 1 and not args.no_voxelize_roofline:
             note('leg: voxelize roofline')
             try:
-                res['roofline']['voxelize'] = voxelize_roofline(dev, args.points)
+                rv = voxelize_roofline(dev, args.points)
             except Exception as e:
-                res['roofline']['voxelize'] = {'error': repr(e)[:200]}
+                rv = {'error': repr(e)[:200]}
+            if isinstance(res.get('roofline'), dict):
+                res['roofline']['voxelize'] = rv
+            else:
+                res['roofline_voxelize'] = rv
         if world == 1 and args.workload == 'sst' and not args.no_workload_legs and not args.fwd_only:
             del model
             fresh_allocator()

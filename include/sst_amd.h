@@ -546,6 +546,11 @@ typedef struct sst_wgrad_problem_f32 {
   float* dw;
   float* db;
   int32_t out, in;
+  /* optional (both NULL or both set; exact-split group only, in == 128): the X operand is x + x_add_rows[x_add_index[token]] -
+   * rows fp32 [P][in], index int32 [m]: the weight gradient of q | k = (feat + pos) W (sst_basic_block_v2.py:56-60) without
+   * "feat + pos" in memory */
+  const float* x_add_rows;
+  const int32_t* x_add_index;
 } sst_wgrad_problem_f32;
 int64_t sst_weight_grad_group_workspace_bytes(const sst_wgrad_problem_f32* problems, int n);
 int sst_weight_grad_group_f32(const sst_wgrad_problem_f32* problems, int n, void* d_workspace, void* stream);
@@ -703,6 +708,11 @@ int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_
 int sst_tall_linear_add_rows_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, int64_t m, int k, int n,
                                    const float* d_rows, int64_t ldrows, const int32_t* d_row_index, float* d_y, int64_t ldy,
                                    void* stream);
+/* The in-projection of an SRA encoder layer from x alone (sst_basic_block_v2.py:56-62: q = k = feat + pos, v = feat):
+ * y[m, 384] = [(x + rows[index]) W[:256]^T | x W[256:]^T] + bias; W [384][128] (in_proj_weight), rows = positional table fp32
+ * [P][128], index int32 [m].  One launch; "x + pos" is formed in registers. */
+int sst_inproj_pos_f32x6(const float* d_x, int64_t ldx, const float* d_rows, const int32_t* d_index, const float* d_w, int64_t ldw,
+                         const float* d_bias, int64_t m, float* d_y, int64_t ldy, void* stream);
 int sst_tall_linear_ln_f32x6(const float* d_x, int64_t ldx, const float* d_w, int64_t ldw, const float* d_bias, int64_t m, int k,
                              const float* d_res, int64_t ldres, const float* d_ln_weight, const float* d_ln_bias, float eps,
                              float* d_y, float* d_sum, float* d_stats, const float* d_pos_table, const int32_t* d_pos_idx,
@@ -726,6 +736,9 @@ int sst_add_layernorm_bwd2_f32(const float* d_dy, const float* d_dy2, const floa
  *   head_scale (last field of both): NULL = softmax(q k^T * scale); else scaled cosine attention (sst_sra_attn_cos_*_f32),
  *             [n_heads] floats = 1 / clamp(tau, tau_min) in device memory, and the backward writes cos_r [m, n_heads]
  *             (d head_scale[h] = colsum(cos_r)[h] / head_scale[h], taken by the caller).
+ *   xp      : x + positional rows as a tensor, or NULL with (xpos_table, xpos_idx): the in-projection and the weight gradient of
+ *             W_q | W_k then add the table rows to x on load (sst_inproj_pos_f32x6, x_add_rows of sst_wgrad_problem_f32) and
+ *             no [m, 128] "x + pos" tensor exists; a chain of layers passes pos_table = NULL (no y2p) in that mode.
  *   wpack   : the weight images of the one-kernel tail (csrc/layer_tail_x6.hip: out-projection -> norm1 -> feed-forward -> norm2),
  *             sst_encoder_layer_wpack_bytes() bytes of device memory: formed by the forward call, read by the backward call.
  *   Launches: forward 4 (in-projection, attention core, weight images, tail), backward 5 (tail, attention core, the five
@@ -744,6 +757,8 @@ typedef struct sst_encoder_layer_fwd_args {
   float *qkv, *o, *lse, *y1, *s1, *st1, *pre, *h, *s2, *y2, *st2, *y2p;
   const float* head_scale;
   void* wpack;   /* sst_encoder_layer_wpack_bytes() bytes, written by the forward call, read by the backward call of the SAME layer call */
+  const float* xpos_table;     /* with xp == NULL: x + pos is formed on load from the positional table [P][128] ... */
+  const int32_t* xpos_idx;     /* ... and the table row of every token (int32 [m]); then pos_table / y2p are normally NULL */
 } sst_encoder_layer_fwd_args;
 typedef struct sst_encoder_layer_bwd_args {
   int64_t m, n_windows;
@@ -760,6 +775,8 @@ typedef struct sst_encoder_layer_bwd_args {
   float* cos_r;
   float* dy1;    /* unused since round 6 (the gradient of y1 never leaves the registers of the tail kernel); may be NULL */
   const void* wpack;
+  const float* xpos_table;     /* with xp == NULL (as in the forward call): the weight gradient of W_q | W_k reads x + table rows */
+  const int32_t* xpos_idx;
 } sst_encoder_layer_bwd_args;
 int64_t sst_encoder_layer_bwd_workspace_bytes(int64_t m, int n_heads);
 int64_t sst_encoder_layer_wpack_bytes(void);

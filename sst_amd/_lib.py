@@ -39,7 +39,7 @@ class CastProblemBF16(ctypes.Structure):
 class WgradProblemF32(ctypes.Structure):
     """sst_wgrad_problem_f32 of include/sst_amd.h"""
     _fields_ = [('dy', c_ptr), ('x', c_ptr), ('m', c_i64), ('ld_dy', c_i64), ('ld_x', c_i64), ('dw', c_ptr), ('db', c_ptr),
-                ('out', ctypes.c_int32), ('inn', ctypes.c_int32)]
+                ('out', ctypes.c_int32), ('inn', ctypes.c_int32), ('x_add_rows', c_ptr), ('x_add_index', c_ptr)]
 
 
 def _struct(name, doc, fields):
@@ -52,7 +52,8 @@ EncoderLayerFwdArgs = _struct('EncoderLayerFwdArgs', 'sst_encoder_layer_fwd_args
     + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
     + [(k, _P) for k in ('x', 'xp', 'w_in', 'b_in', 'w_out', 'b_out', 'w1', 'b1', 'w2', 'b2', 'n1w', 'n1b', 'n2w', 'n2b',
                          'tok', 'winoff', 'order', 'pos_table', 'pos_idx',
-                         'qkv', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'y2', 'st2', 'y2p', 'head_scale', 'wpack')]))
+                         'qkv', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'y2', 'st2', 'y2p', 'head_scale', 'wpack',
+                         'xpos_table', 'xpos_idx')]))
 EncoderLayerBwdArgs = _struct('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args of include/sst_amd.h', (
     [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'impl')]
     + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
@@ -60,7 +61,7 @@ EncoderLayerBwdArgs = _struct('EncoderLayerBwdArgs', 'sst_encoder_layer_bwd_args
                          'w_in', 'w_out', 'w1', 'w2', 'n1w', 'n2w', 'tok', 'winoff', 'order',
                          'ds2', 'dpre', 'ds1', 'd_o', 'dqkv',
                          'dw_in', 'db_in', 'dwo', 'dbo', 'dw1', 'db1', 'dw2', 'db2', 'dn1w', 'dn1b', 'dn2w', 'dn2b',
-                         'workspace', 'head_scale', 'cos_r', 'dy1', 'wpack')]))
+                         'workspace', 'head_scale', 'cos_r', 'dy1', 'wpack', 'xpos_table', 'xpos_idx')]))
 
 
 EncoderTailFwdArgs = _struct('EncoderTailFwdArgs', 'sst_encoder_tail_fwd_args of include/sst_amd.h', (
@@ -105,6 +106,7 @@ _SIGNATURES = {
     'sst_segment_reduce_fwd_f32': (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                            c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
+    'sst_inproj_pos_f32x6': (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'sst_encoder_layer_wpack_bytes': (c_i64, []),
     'sst_encoder_layer_fwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),

@@ -102,12 +102,14 @@ __device__ __forceinline__ int w_lds_row(int n) {  // see csrc/dense_bf16.hip: a
 
 // K: contraction width; NW: output columns per workgroup (the whole row when EPI == kEpiAddLN); blockIdx.x = group * row_blocks
 // + row block; `X2` replaces X for the column groups >= x2_from (x2_from >= number of groups: never).
-template <int K, int NW, int EPI>
+// XADD: the column groups < x2_from multiply X + xadd_rows[xadd_idx[row]] (rows of width K) instead of X - q | k = (x + positional
+// rows) W_qk and v = x W_v from ONE input tensor: "x + pos" never exists in memory (the table is a few KB and stays in L2)
+template <int K, int NW, int EPI, bool XADD = false>
 __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
     const float* __restrict__ X, const float* __restrict__ X2, int x2_from, int64_t ldx, const float* __restrict__ W,
     int64_t ldw, int trans_w, const float* __restrict__ bias, int64_t M, int row_blocks, int rows_per_wave,
     float* __restrict__ Y, int64_t ldy, const float* __restrict__ aux_in, float* __restrict__ aux_out, int64_t ldaux,
-    const ln_epi ln) {
+    const ln_epi ln, const float* __restrict__ xadd_rows = nullptr, const int32_t* __restrict__ xadd_idx = nullptr) {
   static_assert(EPI != kEpiAddLN || NW == 128, "the LayerNorm epilogue needs a whole 128-wide row in one accumulator set");
   static_assert(NW == 64 || NW == 128, "column group");
   constexpr int RS = K * 2 + 16;  // LDS row stride in bytes of one bf16 image (+16: conflict-free 16-byte fragment reads)
@@ -135,7 +137,26 @@ __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
       dst[s][1] = *(const f32x4*)(p + 32 * s + 4);
     }
   };
+  // XADD: the positional rows of the tile in pb / pn (same fragment addresses inside a table row); the row index of the tile
+  // AFTER the one being requested is loaded alongside, so that a table address never waits for its index
+  const bool xadd = XADD && grp < x2_from;
+  f32x4 pb[XADD ? KS : 1][2], pn[XADD ? KS : 1][2];
+  int32_t pidx = 0;
+  auto load_idx = [&](int64_t r) {
+    int64_t row = r + c;
+    row = row < M ? row : M - 1;
+    pidx = xadd_idx[row];
+  };
+  auto load_p = [&](f32x4 (&dst)[XADD ? KS : 1][2]) {
+    const float* p = xadd_rows + (int64_t)pidx * K + 8 * g;
+#pragma unroll
+    for (int s = 0; s < (XADD ? KS : 1); ++s) {
+      dst[s][0] = *(const f32x4*)(p + 32 * s);
+      dst[s][1] = *(const f32x4*)(p + 32 * s + 4);
+    }
+  };
   load_x(r0 < M ? r0 : M - 1, xb);
+  if (xadd) load_idx(r0 < M ? r0 : M - 1);
   // weight fill: W[nb + n][k] (trans_w = 0: row of W; trans_w = 1: W is [K][N], the data gradient of a layer whose parameter is
   // W) -> three bf16 images, row w_lds_row(n).  8 consecutive k per thread and step.
   if (!trans_w) {
@@ -181,6 +202,15 @@ __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
   }
   __syncthreads();
   if (r0 >= r1) return;
+  if (xadd) {
+    load_p(pb);
+    load_idx(r0 + 16);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      xb[s][0] += pb[s][0];
+      xb[s][1] += pb[s][1];
+    }
+  }
   const int lane_off = c * RS + g * 16;
 
   f32x4 pend[TILES];
@@ -278,7 +308,13 @@ __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
     asm volatile("" ::: "memory");  // W fragments are re-read from LDS per row tile (never hoisted into registers)
     const bool more = r0 + 16 < r1;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this tile's X has landed before the next one is requested
-    if (PREFETCH && more) load_x(r0 + 16, xn);
+    if (PREFETCH && more) {
+      load_x(r0 + 16, xn);
+      if (xadd) {
+        load_p(pn);          // rows of the index requested one tile ago
+        load_idx(r0 + 32);
+      }
+    }
     f32x4 acc[TILES];
 #pragma unroll
     for (int T = 0; T < TILES; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -325,6 +361,13 @@ __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
           xb[s][0] = xn[s][0];
           xb[s][1] = xn[s][1];
         }
+        if (xadd) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            xb[s][0] += pn[s][0];
+            xb[s][1] += pn[s][1];
+          }
+        }
       } else {
         load_x(r0 + 16, xb);
       }
@@ -334,15 +377,15 @@ __global__ __launch_bounds__(512, 2) void tall_linear_f32x6_k(
   for (int tp = 0; tp < EMITS; ++tp) emit(tp);
 }
 
-template <int K, int NW, int EPI>
+template <int K, int NW, int EPI, bool XADD = false>
 int launch_x6(const float* x, const float* x2, int x2_from, int64_t ldx, const float* w, int64_t ldw, int trans_w,
               const float* bias, int64_t m, int n, float* y, int64_t ldy, const float* aux_in, float* aux_out, int64_t ldaux,
-              hipStream_t st, const ln_epi ln = ln_epi()) {
+              hipStream_t st, const ln_epi ln = ln_epi(), const float* xadd_rows = nullptr, const int32_t* xadd_idx = nullptr) {
   constexpr int lds = 3 * NW * (K * 2 + 16) + NW * (EPI == kEpiAddLN ? 3 : 1) * 4;
   static_assert(lds <= 160 * 1024, "three weight images of a column group must fit the CU's LDS");
   static unsigned long long configured = 0;
   if (sst_first_use_on_device(&configured)) {
-    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_f32x6_k<K, NW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    SST_HIP(hipFuncSetAttribute((const void*)tall_linear_f32x6_k<K, NW, EPI, XADD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     sst_mark_device(&configured);
   }
   const int groups = n / NW;
@@ -352,8 +395,9 @@ int launch_x6(const float* x, const float* x2, int x2_from, int64_t ldx, const f
   int64_t rpw = sst_align_up(sst_div_up(m, row_blocks * 8), 16);
   row_blocks = sst_align_up(sst_div_up(m, rpw * 8), 8);
   if (x2 == nullptr) x2_from = groups;
-  hipLaunchKernelGGL((tall_linear_f32x6_k<K, NW, EPI>), dim3((unsigned)(row_blocks * groups)), dim3(512), lds, st, x, x2, x2_from,
-                     ldx, w, ldw, trans_w, bias, m, (int)row_blocks, (int)rpw, y, ldy, aux_in, aux_out, ldaux, ln);
+  hipLaunchKernelGGL((tall_linear_f32x6_k<K, NW, EPI, XADD>), dim3((unsigned)(row_blocks * groups)), dim3(512), lds, st, x, x2,
+                     x2_from, ldx, w, ldw, trans_w, bias, m, (int)row_blocks, (int)rpw, y, ldy, aux_in, aux_out, ldaux, ln, xadd_rows,
+                     xadd_idx);
   return SST_OK;
 }
 
@@ -419,6 +463,23 @@ int sst_tall_linear_epi2_f32x6(const float* d_x, const float* d_x2, int x2_from_
   } else {
     return SST_ERR_UNSUPPORTED;
   }
+  if (rc) return rc;
+  SST_LAUNCH_CHECK();
+  return SST_OK;
+}
+
+/* The in-projection of an SRA encoder layer from x alone (sst_basic_block_v2.py:56-62: q = k = feat + pos, v = feat):
+ * y[m, 384] = [(x + rows[index]) W[:256]^T | x W[256:]^T] + bias, rows = the positional table [P][128] (fp32), index int32 [m].
+ * One launch, x read once per column group, "x + pos" never materialised. */
+int sst_inproj_pos_f32x6(const float* d_x, int64_t ldx, const float* d_rows, const int32_t* d_index, const float* d_w, int64_t ldw,
+                         const float* d_bias, int64_t m, float* d_y, int64_t ldy, void* stream) {
+  if (m < 0 || !d_w) return SST_ERR_ARG;
+  if (m == 0) return SST_OK;
+  if (!d_x || !d_y || !d_rows || !d_index || (ldx & 3) || (ldy & 3) || (ldw & 3) || !aligned16(d_x) || !aligned16(d_y) ||
+      !aligned16(d_w) || !aligned16(d_rows))
+    return SST_ERR_ARG;
+  const int rc = launch_x6<128, 128, kEpiBias, true>(d_x, d_x, 2, ldx, d_w, ldw, 0, d_bias, m, 384, d_y, ldy, nullptr, nullptr, 0,
+                                                     (hipStream_t)stream, ln_epi(), d_rows, d_index);
   if (rc) return rc;
   SST_LAUNCH_CHECK();
   return SST_OK;

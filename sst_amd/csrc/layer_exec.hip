@@ -26,6 +26,7 @@ int64_t wg_ws(int64_t m, int which) {   // workspace of the two weight-gradient 
     q.dy = q.x = any;
     q.dw = q.db = any;
     q.m = m;
+    q.x_add_rows = nullptr, q.x_add_index = nullptr;
   }
   if (which == 0 || which == 2) {
     p[0].ld_dy = kC, p[0].ld_x = kFF, p[0].out = kC, p[0].in = kFF;    // dW2 = ds2^T h
@@ -67,13 +68,18 @@ int64_t sst_encoder_layer_wpack_bytes(void) { return sst_encoder_tail_pack_bytes
 int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* a, void* stream) {
   if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
   if (a->m == 0) return SST_OK;
-  if (!a->x || !a->xp || !a->qkv || !a->o || !a->lse || !a->y1 || !a->st1 || !a->pre || !a->h || !a->s2 || !a->y2 || !a->st2)
+  if (!a->x || !a->qkv || !a->o || !a->lse || !a->y1 || !a->st1 || !a->pre || !a->h || !a->s2 || !a->y2 || !a->st2)
     return SST_ERR_ARG;
+  if (!a->xp && (!a->xpos_table || !a->xpos_idx)) return SST_ERR_ARG;   // x + pos: either as a tensor or as (table, row index)
   const int64_t m = a->m;
   int rc;
-  // q | k = (x + pos) W_qk^T, v = x W_v^T: one launch over 384 columns (sst_basic_block_v2.py:56-62)
-  rc = sst_tall_linear_epi2_f32x6(a->xp, a->x, 2 * kC, kC, a->w_in, kC, 0, a->b_in, m, kC, 3 * kC, kEpiBias, nullptr, nullptr, 0,
-                                  a->qkv, 3 * kC, stream);
+  // q | k = (x + pos) W_qk^T, v = x W_v^T: one launch over 384 columns (sst_basic_block_v2.py:56-62); without an xp tensor the
+  // positional rows are added to x on the way into the product (table [P][128] + row index per token)
+  if (a->xp == nullptr)
+    rc = sst_inproj_pos_f32x6(a->x, kC, a->xpos_table, a->xpos_idx, a->w_in, kC, a->b_in, m, a->qkv, 3 * kC, stream);
+  else
+    rc = sst_tall_linear_epi2_f32x6(a->xp, a->x, 2 * kC, kC, a->w_in, kC, 0, a->b_in, m, kC, 3 * kC, kEpiBias, nullptr, nullptr, 0,
+                                    a->qkv, 3 * kC, stream);
   if (rc) return rc;
   if (a->head_scale != nullptr)   // cosine attention: normalisation and 1 / clamp(tau) inside the kernel (cosine_msa.py:159-170)
     rc = sst_sra_attn_cos_fwd_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->tok, a->winoff, a->order,
@@ -101,6 +107,7 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   if (a->m == 0) return SST_OK;
   if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->ds1 || !a->d_o || !a->dqkv || !a->wpack) return SST_ERR_ARG;
   if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
+  if (!a->xp && (!a->xpos_table || !a->xpos_idx)) return SST_ERR_ARG;
   const int64_t m = a->m;
   char* ws = (char*)a->workspace;
   void* ws_tail = ws;
@@ -139,14 +146,16 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
   // all five parameter gradients of the layer in one grouped launch (+ its reduction, which also finishes the LayerNorm
   // parameter gradients), before ds1 is accumulated into
   sst_wgrad_problem_f32 g[5];
+  for (auto& q : g) q.x_add_rows = nullptr, q.x_add_index = nullptr;
   g[0].dy = a->ds2, g[0].x = a->h, g[0].m = m, g[0].ld_dy = kC, g[0].ld_x = kFF, g[0].dw = a->dw2, g[0].db = a->db2;
   g[0].out = kC, g[0].in = kFF;
   g[1].dy = a->dpre, g[1].x = a->y1, g[1].m = m, g[1].ld_dy = kFF, g[1].ld_x = kC, g[1].dw = a->dw1, g[1].db = a->db1;
   g[1].out = kFF, g[1].in = kC;
   g[2].dy = a->ds1, g[2].x = a->o, g[2].m = m, g[2].ld_dy = kC, g[2].ld_x = kC, g[2].dw = a->dwo, g[2].db = a->dbo;
   g[2].out = kC, g[2].in = kC;
-  g[3].dy = a->dqkv, g[3].x = a->xp, g[3].m = m, g[3].ld_dy = 3 * kC, g[3].ld_x = kC, g[3].dw = a->dw_in, g[3].db = a->db_in;
-  g[3].out = 2 * kC, g[3].in = kC;
+  g[3].dy = a->dqkv, g[3].x = a->xp ? a->xp : a->x, g[3].m = m, g[3].ld_dy = 3 * kC, g[3].ld_x = kC, g[3].dw = a->dw_in;
+  g[3].db = a->db_in, g[3].out = 2 * kC, g[3].in = kC;
+  if (!a->xp) g[3].x_add_rows = a->xpos_table, g[3].x_add_index = a->xpos_idx;   // dW_q | dW_k = [dq | dk]^T (x + pos rows)
   g[4].dy = a->dqkv + 2 * kC, g[4].x = a->x, g[4].m = m, g[4].ld_dy = 3 * kC, g[4].ld_x = kC;
   g[4].dw = a->dw_in + 2 * kC * kC, g[4].db = a->db_in + 2 * kC, g[4].out = kC, g[4].in = kC;
   rc = sst_internal_weight_grad_group_f32x6(g, 5, ws_wg, riders, 2, stream);

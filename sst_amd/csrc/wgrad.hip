@@ -710,6 +710,7 @@ int sst_weight_grad_group_f32(const sst_wgrad_problem_f32* problems, int n, void
   for (int i = 0; i < n; ++i) {
     const sst_wgrad_problem_f32& q = problems[i];
     if (q.m < 1 || q.out < 1 || q.in < 1 || q.out > 4096 || q.in > 4096) return SST_ERR_UNSUPPORTED;
+    if (q.x_add_rows || q.x_add_index) return SST_ERR_UNSUPPORTED;   // rows added to X on load: the exact-split group only
     if (!q.dy || !q.x || !q.dw || q.ld_dy < q.out || q.ld_x < q.in) return SST_ERR_ARG;
     int s = 0;
     const int rc = launch_partials(q.dy, q.x, q.m, q.out, q.in, q.ld_dy, q.ld_x, q.db != nullptr, ws, st, &s);

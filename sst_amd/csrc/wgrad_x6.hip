@@ -67,6 +67,8 @@ struct x6_problem {
   int db_off;       // offset of this problem's bias-gradient partials in the db workspace, -1: no bias gradient
   float* dw;        // [out, in] contiguous
   float* db;        // [out] or NULL
+  const float* x_add_rows;      // not NULL: the X operand is x + x_add_rows[x_add_index[token]] (rows of width `in`, the positional
+  const int32_t* x_add_index;   // table of an encoder layer): "x + pos" is formed on the way into LDS, never in memory
 };
 struct x6_group {
   x6_problem p[kMaxProblems];
@@ -106,12 +108,31 @@ __global__ __launch_bounds__(512, 2) void wgrad_x6_k(const x6_group G, float* __
   constexpr int kPf = 2;
   f32x4 rows[kPf][4];
   const int64_t t_last = t_end > 0 ? t_end - 1 : 0;
-  auto load_rows = [&](int64_t t0, f32x4 (&dst)[4]) {
+  // positional rows of the X operand (x_add_rows): requested with the rows they are added to; their token indices are loaded
+  // one request ahead so that a table address never waits for its index
+  const bool xadd = op == 1 && P.x_add_rows != nullptr;
+  const float* addsrc = xadd ? P.x_add_rows + k0 + 4 * cg : nullptr;
+  f32x4 prow[kPf][4];
+  int32_t pidx[4] = {0, 0, 0, 0};
+  auto load_idx = [&](int64_t t0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int64_t t = t0 + 4 * tq + r;
+      t = t < t_last ? t : t_last;
+      pidx[r] = P.x_add_index[t];
+    }
+  };
+  auto load_rows = [&](int64_t t0, f32x4 (&dst)[4], f32x4 (&pdst)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int64_t t = t0 + 4 * tq + r;
       t = t < t_last ? t : t_last;
       dst[r] = *(const f32x4*)(src + t * ld);
+    }
+    if (xadd) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pdst[r] = *(const f32x4*)(addsrc + (int64_t)pidx[r] * P.in);
+      load_idx(t0 + kStep);      // the indices of the NEXT request (requests are one step apart)
     }
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -119,10 +140,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_x6_k(const x6_group G, float* __
   // VALU instructions issue in the shadow of the matrix pipe instead of after it (all 8 waves of the workgroup move in lock
   // step from barrier to barrier: work that is not interleaved is serial)
   u32x4 img[3][2];
-  auto split_col = [&](int e, int64_t t0, const f32x4 (&rws)[4]) {
+  auto split_col = [&](int e, int64_t t0, const f32x4 (&rws)[4], const f32x4 (&prw)[4]) {
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (t0 + 4 * tq + r < t_end) ? rws[r][e] : 0.f;
+    for (int r = 0; r < 4; ++r) v[r] = (t0 + 4 * tq + r < t_end) ? (xadd ? rws[r][e] + prw[r][e] : rws[r][e]) : 0.f;
     if (op == 0) bsum[e] += (v[0] + v[1]) + (v[2] + v[3]);
     unsigned a0, a1, a2, b0, b1, b2;
     split2(v[0], v[1], a0, a1, a2);
@@ -161,12 +182,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_x6_k(const x6_group G, float* __
     return (u32x4){lo[0], lo[1], hi[0], hi[1]};
   };
 
+  if (xadd) load_idx(t_begin);
 #pragma unroll
-  for (int u = 0; u < kPf; ++u) load_rows(t_begin + (int64_t)u * kStep, rows[u]);
+  for (int u = 0; u < kPf; ++u) load_rows(t_begin + (int64_t)u * kStep, rows[u], prow[u]);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split_col(e, t_begin, rows[0]);
+  for (int e = 0; e < 4; ++e) split_col(e, t_begin, rows[0], prow[0]);
   store_img(0);
-  load_rows(t_begin + (int64_t)kPf * kStep, rows[0]);
+  load_rows(t_begin + (int64_t)kPf * kStep, rows[0], prow[0]);
   __syncthreads();
   // step s (tokens t_begin + 32 s ..): products on buffer s & 1, and between its four MFMA groups the four columns of step
   // s + 1 (ring set (s + 1) % kPf) are split; then stored into buffer (s + 1) & 1 and the set refilled with step s + 1 + kPf
@@ -202,10 +224,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_x6_k(const x6_group G, float* __
         for (int b = 0; b < 2; ++b) acl[a][b] = mma32(a0, b1[b], acl[a][b]);
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = mma32(a0, b0[b], acc[a][b]);
-        split_col(a, t1, rows[(u + 1) % kPf]);
+        split_col(a, t1, rows[(u + 1) % kPf], prow[(u + 1) % kPf]);
       }
       store_img((u + 1) & 1);
-      load_rows(t1 + (int64_t)kPf * kStep, rows[(u + 1) % kPf]);
+      load_rows(t1 + (int64_t)kPf * kStep, rows[(u + 1) % kPf], prow[(u + 1) % kPf]);
       __syncthreads();
     }
   }
@@ -381,6 +403,9 @@ bool make_plan(const sst_wgrad_problem_f32* pr, int n, x6_plan* plan) {
     G.p[i].db_off = p.db ? db_cols : -1;
     G.p[i].dw = p.dw;
     G.p[i].db = p.db;
+    if ((p.x_add_rows != nullptr) != (p.x_add_index != nullptr) || (p.x_add_rows && !aligned16(p.x_add_rows))) return false;
+    G.p[i].x_add_rows = p.x_add_rows;
+    G.p[i].x_add_index = p.x_add_index;
     tiles += (p.out / kTile) * (p.in / kTile);
     if (p.db) db_cols += p.out;
   }

@@ -72,22 +72,41 @@ def weight_bias_grad(dy, x, want_bias, out_w=None, out_b=None):
 
 
 def weight_bias_grad_group(problems):
-    """Weight / bias gradients of several linears at once: problems = [(dy, x, out_w, out_b | None), ...] with contiguous
-    fp32 destinations; the split-K kernels of csrc/wgrad.hip one after the other and ONE reduction launch for all of them
-    (sst_weight_grad_group_f32).  Problems the kernel is not built for go through weight_bias_grad one by one."""
+    """Weight / bias gradients of several linears at once: problems = [(dy, x, out_w, out_b | None[, (rows, index)]), ...] with
+    contiguous fp32 destinations; the split-K kernels of csrc/wgrad.hip one after the other and ONE reduction launch for all of
+    them (sst_weight_grad_group_f32).  The optional fifth element: the X operand is x + rows[index] (the positional rows of an
+    encoder layer), added on load - exact-split group only; elsewhere the sum is formed first.  Problems the kernel is not built
+    for go through weight_bias_grad one by one."""
+    problems = [tuple(p) + (None,) * (5 - len(p)) for p in problems]
     ok = all(dy.stride(1) == 1 and x.stride(1) == 1 and dy.size(0) >= 4096 and dy.size(1) <= 4096 and x.size(1) <= 4096
              and dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.is_cuda and ow.is_contiguous()
-             and (ob is None or ob.is_contiguous()) for dy, x, ow, ob in problems)
+             and (ob is None or ob.is_contiguous()) for dy, x, ow, ob, _ in problems)
+    lib = _lib.load()
+    if ok and len(problems) <= 8 and _MATMUL_MODE == 'f32x6':
+        arr = (_lib.WgradProblemF32 * len(problems))()
+        for q, (dy, x, ow, ob, xadd) in zip(arr, problems):
+            q.dy, q.x, q.m, q.ld_dy, q.ld_x = dy.data_ptr(), x.data_ptr(), dy.size(0), dy.stride(0), x.stride(0)
+            q.dw, q.db, q.out, q.inn = ow.data_ptr(), (ob.data_ptr() if ob is not None else None), dy.size(1), x.size(1)
+            if xadd is not None:
+                q.x_add_rows, q.x_add_index = xadd[0].data_ptr(), xadd[1].data_ptr()
+        # exact three-way bf16 split on the bf16 matrix pipe (csrc/wgrad_x6.hip), one launch for the group
+        need = lib.sst_weight_grad_group_f32x6_workspace_bytes(arr, len(problems))
+        if need >= 0:
+            ws = _lib.workspace(need, problems[0][0].device)
+            _lib.check(lib.sst_weight_grad_group_f32x6(arr, len(problems), _lib.ptr(ws), _lib.stream_ptr()),
+                       'sst_weight_grad_group_f32x6')
+            return
+    # every other path takes X as a tensor: form x + rows[index] where it was asked for
+    problems = [(dy, x if xadd is None else x + xadd[0].index_select(0, xadd[1].long()), ow, ob) for dy, x, ow, ob, xadd in problems]
     if not ok or len(problems) > 8:
         for dy, x, ow, ob in problems:
             weight_bias_grad(dy, x, ob is not None, out_w=ow, out_b=ob)
         return
-    lib = _lib.load()
     arr = (_lib.WgradProblemF32 * len(problems))()
     for q, (dy, x, ow, ob) in zip(arr, problems):
         q.dy, q.x, q.m, q.ld_dy, q.ld_x = dy.data_ptr(), x.data_ptr(), dy.size(0), dy.stride(0), x.stride(0)
         q.dw, q.db, q.out, q.inn = ow.data_ptr(), (ob.data_ptr() if ob is not None else None), dy.size(1), x.size(1)
-    if _MATMUL_MODE == 'f32x6':       # exact three-way bf16 split on the bf16 matrix pipe (csrc/wgrad_x6.hip), one launch for the group
+    if _MATMUL_MODE == 'f32x6':
         need = lib.sst_weight_grad_group_f32x6_workspace_bytes(arr, len(problems))
         if need >= 0:
             ws = _lib.workspace(need, problems[0][0].device)
@@ -220,6 +239,28 @@ def lds_linear_qkv(xp, x, w_in, b_in):
                                                _lib.ptr(b_in), m, 128, 384, EPI_BIAS, None, None, 0, _lib.ptr(y), 384,
                                                _lib.stream_ptr())
     _lib.check(rc, 'sst_tall_linear_epi2_f32x6')
+    return y
+
+
+def inproj_pos_ok(x, pos_spec, w_in):
+    """the in-projection from x + positional rows formed on load (sst_inproj_pos_f32x6): exact-split mode, d_model 128"""
+    if _MATMUL_MODE != 'f32x6' or pos_spec is None:
+        return False
+    table, idx = pos_spec
+    return (x.dim() == 2 and x.size(1) == 128 and w_in.shape == (384, 128) and w_in.is_contiguous() and x.is_contiguous()
+            and x.is_cuda and x.dtype == torch.float32 and x.data_ptr() % 16 == 0 and w_in.data_ptr() % 16 == 0
+            and table.dtype == torch.float32 and table.dim() == 2 and table.size(1) == 128 and table.is_contiguous()
+            and table.data_ptr() % 16 == 0 and idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == x.size(0))
+
+
+def inproj_pos(x, pos_spec, w_in, b_in):
+    """[M, 384] = [((x + table[idx]) W_q^T | (x + table[idx]) W_k^T) | x W_v^T] + b (sst_basic_block_v2.py:56-62) - "x + pos" is
+    never a tensor"""
+    m = x.size(0)
+    y = torch.empty((m, 384), dtype=torch.float32, device=x.device)
+    rc = _lib.load().sst_inproj_pos_f32x6(_lib.ptr(x), 128, _lib.ptr(pos_spec[0]), _lib.ptr(pos_spec[1]), _lib.ptr(w_in), 128,
+                                          _lib.ptr(b_in), m, _lib.ptr(y), 384, _lib.stream_ptr())
+    _lib.check(rc, 'sst_inproj_pos_f32x6')
     return y
 
 

@@ -19,7 +19,7 @@ from torch.utils.checkpoint import checkpoint
 
 from . import kernels as K
 from .sra_composed import sra_attention_composed
-from .dense import (encoder_tail_ok, encoder_tail_pack, encoder_tail_fwd, encoder_tail_bwd,
+from .dense import (encoder_tail_ok, encoder_tail_pack, encoder_tail_fwd, encoder_tail_bwd, inproj_pos_ok, inproj_pos,
                     EPI_ADD, EPI_BIAS, EPI_GELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_GRAD, EPI_RELU, lds_linear, lds_linear_ok,
                     lds_linear_add_ln, lds_linear_add_ln_ok, lds_linear_dqkv_ok, lds_linear_qkv, lds_linear_qkv_ok,
                     weight_bias_grad_group,
@@ -206,6 +206,9 @@ def _linear_dgrad(dy, w, out=None, add=None):
 # exact-split mode at d_model 128 / feed-forward 256.  SST_AMD_LAYER_EXEC=0: the Python sequence (same kernels, same order, same
 # bits: tests/test_gpu_layer_exec.py); the module attribute can be flipped at run time.
 _LAYER_EXEC = int(_os.environ.get('SST_AMD_LAYER_EXEC', '1'))
+# SST_AMD_POS_FOLD=0: the encoder chain hands x + positional rows from layer to layer as a tensor (round 5) instead of adding the
+# rows on load in the in-projection and the W_q | W_k weight gradient (round 6)
+_POS_FOLD = int(_os.environ.get('SST_AMD_POS_FOLD', '1'))
 
 
 def _layer_exec_ok(x, xp, plan, nhead, act, params):
@@ -216,12 +219,12 @@ def _layer_exec_ok(x, xp, plan, nhead, act, params):
     if any(p is None for p in params):
         return False
     m = x.size(0)
-    shapes_ok = (x.shape == (m, 128) and xp.shape == (m, 128) and w_in.shape == (384, 128) and w_out.shape == (128, 128)
+    shapes_ok = (x.shape == (m, 128) and (xp is None or xp.shape == (m, 128)) and w_in.shape == (384, 128) and w_out.shape == (128, 128)
                  and w1.shape == (256, 128) and w2.shape == (128, 256) and plan.n_tokens == m
                  and m >= 4096)     # below: the Python sequence takes the library's split-K weight gradients (dense.py)
     if not shapes_ok:
         return False
-    for t in (x, xp) + tuple(params):
+    for t in (x,) + ((xp,) if xp is not None else ()) + tuple(params):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0):
             return False
     # the backward call must be possible too: once the forward has taken this path there is no other one to fall back to
@@ -243,8 +246,9 @@ def _slab_offsets(m):
     return out, off
 
 
-def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale=None):
-    """-> (slab (uint8: the kept tensors at _slab_offsets), y2, y2p); head_scale ([nhead], device): cosine attention"""
+def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale=None, pos_spec=None):
+    """-> (slab (uint8: the kept tensors at _slab_offsets), y2, y2p, wpack); head_scale ([nhead], device): cosine attention;
+    xp None + pos_spec = (table, row index): x + positional rows formed on load"""
     from . import _lib
     import ctypes
     w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b = params
@@ -266,7 +270,8 @@ def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next,
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
         S('qkv'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'), S('s2'), P(y2), S('st2'),
-        P(y2p), P(head_scale), P(wpack))
+        P(y2p), P(head_scale), P(wpack), P(pos_spec[0]) if pos_spec is not None else None,
+        P(pos_spec[1]) if pos_spec is not None else None)
     rc = K._bracket('sra_fwd', plan.n_tokens, lambda: lib.sst_encoder_layer_fwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     if rc == _lib.SST_ERR_UNSUPPORTED:     # a layout one of the entry points does not take: the Python sequence has the retries
         return None
@@ -278,7 +283,11 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     from . import _lib
     import ctypes
     x, xp, slab, w_in, w_out, w1, w2, n1w, n2w, wpack = saved[:10]
-    head_scale = saved[10] if len(saved) > 10 else None
+    rest = list(saved[10:])
+    pos_spec = (rest.pop(0), rest.pop(0)) if ctx.pos_fold else None
+    if ctx.pos_fold:
+        xp = None
+    head_scale = rest.pop(0) if rest else None
     m = x.size(0)
     dev = x.device
     plan, nhead, impl = ctx.plan, ctx.nhead, ctx.impl
@@ -313,12 +322,13 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         p_ds2, p_dpre, P(ds1), p_do, p_dqkv,
         P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 512, dnp + 1024, dnp + 1536, P(ws),
-        P(head_scale), P(cos_r), None, P(wpack))
+        P(head_scale), P(cos_r), None, P(wpack), P(pos_spec[0]) if pos_spec is not None else None,
+        P(pos_spec[1]) if pos_spec is not None else None)
     rc = K._bracket('sra_bwd', plan.n_tokens, lambda: lib.sst_encoder_layer_bwd_f32x6(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
     d_scale = K.head_scale_grad(cos_r, head_scale) if head_scale is not None else None
     return (ds1, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3], None, None,
-            None, d_scale, None)
+            None, d_scale, None, None)
 
 
 class FusedEncoderLayerFn(torch.autograd.Function):
@@ -331,8 +341,11 @@ class FusedEncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, plan, nhead, impl, act, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps,
-                xp=None, pos_next=None, head_scale=None, xp_shares_x=False):
-        """xp (optional): x + positional embedding, already formed (the previous layer's second output) - ``pos`` is then
+                xp=None, pos_next=None, head_scale=None, xp_shares_x=False, pos_spec=None):
+        """pos_spec = (table fp32 [P, C], row index int32 [M]) (optional, instead of pos / xp): the positional embedding of every
+        token is a row of a small table; in the exact-split mode x + table[index] is then formed ON LOAD by the in-projection and
+        by the weight gradient of W_q | W_k and never exists as a tensor (round 6: 3 of a layer's 56 [M, 128] passes).
+        xp (optional): x + positional embedding, already formed (the previous layer's second output) - ``pos`` is then
         ignored; pos_next = (table, row index): also return y + table[index], the next layer's xp; head_scale ([nhead] fp32 on
         the device, differentiable): scaled cosine attention with the per-head scale 1 / clamp(tau) (cosine_msa.py:123-170),
         normalisation inside the attention kernels; xp_shares_x: the caller states that the ``xp`` it hands in is x + a constant
@@ -347,9 +360,17 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         from . import dense as _dense
         ctx.matmul = _dense.matmul_mode()    # the backward pass multiplies the way the forward pass did, whatever the mode is by then
         ctx.set_materialize_grads(False)     # an output nobody differentiates (y2p when its gradient was folded into y2's) stays None
+        ctx.pos_fold = False
+        if pos_spec is not None:
+            assert xp is None and pos is None, 'pos_spec replaces pos / xp'
+            if _LDS_LINEAR and inproj_pos_ok(x, pos_spec, w_in):
+                ctx.pos_fold = True       # x + table[index] on load: no xp tensor
+            else:                         # the modes / shapes without that kernel: the sum as a tensor, a constant offset of x
+                xp = K.add_table_rows(x, pos_spec[0], pos_spec[1])
+                xp_shares_x = True
         ctx.split_input = xp is not None
         ctx.fold_xp = (xp is None) or bool(xp_shares_x)     # d(xp) -> d(x): only when xp = x + constant
-        if xp is None:
+        if xp is None and not ctx.pos_fold:
             xp = x + pos if pos is not None else x
         params = (w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
         ctx.exec = False
@@ -357,17 +378,22 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             # the launch sequence below as ONE library call (csrc/layer_exec.hip)
             need_bwd = any(ctx.needs_input_grad)
             scale = 1.0 / math.sqrt(16.0)
-            done = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale)
+            done = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale,
+                                   pos_spec if ctx.pos_fold else None)
             if done is not None:
                 slab, y2, y2p, wpack = done
                 if need_bwd:
-                    ctx.save_for_backward(x, xp, slab, w_in, w_out, w1, w2, n1w, n2w, wpack,
-                                          *((head_scale,) if ctx.cosine else ()))
+                    ctx.save_for_backward(x, xp if xp is not None else x, slab, w_in, w_out, w1, w2, n1w, n2w, wpack,
+                                          *(pos_spec if ctx.pos_fold else ()), *((head_scale,) if ctx.cosine else ()))
                     ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
                     ctx.exec = True
                 ctx.two = pos_next is not None
                 return (y2, y2p) if ctx.two else y2
-        if _LDS_LINEAR and c == 128 and lds_linear_qkv_ok(xp, x, w_in):     # one launch, two inputs (csrc/dense_f32x6.hip)
+        if ctx.pos_fold:                                                    # x + positional rows on load (csrc/dense_f32x6.hip)
+            qkv = inproj_pos(x, pos_spec, w_in, b_in)
+            qk, v = qkv[:, :2 * c], qkv[:, 2 * c:]
+            xp = x         # placeholder in the saved list (never read: the weight gradient adds the rows on load again)
+        elif _LDS_LINEAR and c == 128 and lds_linear_qkv_ok(xp, x, w_in):   # one launch, two inputs (csrc/dense_f32x6.hip)
             qkv = lds_linear_qkv(xp, x, w_in, b_in)
             qk, v = qkv[:, :2 * c], qkv[:, 2 * c:]
         else:
@@ -396,7 +422,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
                 o, x, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps, act, need_bwd, pos_next, c)
         if need_bwd:
             ctx.save_for_backward(x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w,
-                                  *((wpack,) if ctx.tail else ()), *((head_scale,) if ctx.cosine else ()))
+                                  *((wpack,) if ctx.tail else ()), *(pos_spec if ctx.pos_fold else ()),
+                                  *((head_scale,) if ctx.cosine else ()))
             ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
         ctx.two = pos_next is not None
         return (y2, y2p) if ctx.two else y2
@@ -449,6 +476,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         x, xp, qk, v, o, lse, s1, st1, y1, pre, h, s2, st2, w_in, w_out, w1, w2, n1w, n2w = saved[:19]
         rest = list(saved[19:])
         wpack = rest.pop(0) if ctx.tail else None
+        pos_spec = (rest.pop(0), rest.pop(0)) if ctx.pos_fold else None
         head_scale = rest.pop(0) if ctx.cosine else None
         c = x.size(1)
         if dy2 is None:           # only the second output was differentiated
@@ -497,6 +525,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         dwo, dbo = torch.empty_like(w_out), torch.empty(w_out.size(0), **f32)
         # all five, before ds1 is accumulated into in place
         weight_bias_grad_group([(ds2_for_w2, h, dw2, db2), (dpre, y1, dw1, db1), (ds1, o, dwo, dbo),
+                                (dqk, x, dw_in[:2 * c], db_in[:2 * c], pos_spec) if ctx.pos_fold else
                                 (dqk, xp, dw_in[:2 * c], db_in[:2 * c]), (dv, x, dw_in[2 * c:], db_in[2 * c:])])
         dxp = None
         if ctx.fold_xp and _LDS_LINEAR and c == 128 and lds_linear_dqkv_ok(dqkv, w_in):
@@ -512,7 +541,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         else:
             dx = ds1.addmm_(dqkv, w_in)                               # residual + q,k,v branches (in place)
         return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
-                None, dxp, None, d_scale, None)
+                None, dxp, None, d_scale, None, None)
 
 
 class _StackHeadScales(torch.autograd.Function):
@@ -579,8 +608,22 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
 
     scales = stack_head_scales([enc for block in blocks for enc in block.encoder_list])
 
+    from . import dense as _dense
+    mode = _dense.matmul_mode()
+    # exact-split mode: every layer adds its positional rows to x on load (pos_spec) - no "x + pos" tensor between the layers;
+    # the other modes keep the round-5 chain (x + pos of layer i + 1 is the second output of layer i's last kernel)
+    fold = _POS_FOLD and mode == 'f32x6' and _LDS_LINEAR and all(inproj_pos_ok(feats.contiguous(), spec, blocks[0].encoder_list[0].win_attn.
+                                                                 self_attn.in_proj_weight) for spec in pos_specs[:2])
+
     def layer(enc, li, x, xp):
         attn = enc.win_attn.self_attn
+        if fold:
+            out = FusedEncoderLayerFn.apply(
+                x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
+                attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
+                enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
+                enc.norm1.eps, None, None, scales[li], False, pos_specs[li % 2])
+            return out, None
         pos_next = pos_specs[(li + 1) % 2] if li + 1 < n_layers else None
         out = FusedEncoderLayerFn.apply(
             x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
@@ -588,9 +631,6 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
             enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
             enc.norm1.eps, xp, pos_next, scales[li], True)                    # xp = x + positional rows: a constant offset
         return out if pos_next is not None else (out, None)
-
-    from . import dense as _dense
-    mode = _dense.matmul_mode()
 
     def block_fn(bi):
         def run(x, xp):
@@ -601,8 +641,8 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
         return run
 
     x = feats.contiguous()
-    # x + positional rows of the first layer: one pass (csrc/scatter.hip add_table_rows_k)
-    xp = K.add_table_rows(x, pos_specs[0][0], pos_specs[0][1])
+    # x + positional rows of the first layer: one pass (csrc/scatter.hip add_table_rows_k) - unless every layer adds them on load
+    xp = None if fold else K.add_table_rows(x, pos_specs[0][0], pos_specs[0][1])
     for bi in range(len(blocks)):
         if bi in checkpoint_blocks and torch.is_grad_enabled():
             out = checkpoint(block_fn(bi), x, xp, use_reentrant=False)

@@ -9,7 +9,7 @@ shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/$OUT"
 cd /tmp && export TMPDIR=/tmp
-FLAGS="--steps 4 --warmup 3 --no-cpu-baseline --no-forward-only-leg --no-lidar-leg --no-f32x3-leg --no-traffic-remeasure --no-config-as-is-leg --no-bf16-leg $@"
+FLAGS="--steps 4 --warmup 3 --no-cpu-baseline --no-forward-only-leg --no-lidar-leg --no-f32x3-leg --no-traffic-remeasure --no-config-as-is-leg --no-bf16-leg --no-workload-legs --no-voxelize-roofline $@"
 rm -rf /tmp/st_f /tmp/st_w
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/st_f -o f -- python "$R/bench.py" $FLAGS > /tmp/st_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/st_w -o w -- python "$R/bench.py" $FLAGS > /tmp/st_w.log 2>&1
