@@ -773,18 +773,9 @@ def _main(args, line_out):
         return
 
     from sst_amd import kernels as K
-    if not args.no_gemm_tuning:
-        # the dense projections / FFN are library GEMMs (plumbing): let TunableOp choose the fastest
-        # hipBLASLt / rocBLAS solution per shape during warm-up (seeded from the committed results file)
-        import shutil
-        import torch.cuda.tunable as tunable
-        seed_file = os.path.join(ROOT, 'sst_amd', 'tunableop_gfx950_fp32.csv')
-        work_file = f'/tmp/sst_amd_tunableop_rank{rank}.csv'
-        if os.path.exists(seed_file):
-            shutil.copyfile(seed_file, work_file)
-        tunable.enable(True)
-        tunable.tuning_enable(True)
-        tunable.set_filename(work_file)
+    # (no TunableOp here since round 6: the SST step has had no library GEMM in it since round 4 - every dense product is a
+    # kernel of csrc/ - so there was nothing for it to tune; the FSD workloads, whose stand-in heads are library GEMMs, enable
+    # it in bench_workloads.run)
     torch.manual_seed(0)                      # identical initial weights on every rank
     point_channels = 3
     if args.workload == 'sst_center':
@@ -1312,7 +1303,7 @@ def _main(args, line_out):
                       'accumulation - error vs float64 <= 2 x the fp32 matrix pipe\'s: tests/test_gpu_dense_f32x6.py)'
                       if (args.precision == 'f32' and args.matmul == 'f32x6') else args.precision),
             'data': 'synthetic',
-            'gemm_tuning': 'off' if args.no_gemm_tuning else 'torch TunableOp (hipBLASLt/rocBLAS solution per shape)',
+            'gemm_tuning': 'none (no library GEMM in this step)',
             'config': {'workload': ('NOT THE HEADLINE WORKLOAD (--cloud lidar): LiDAR-like synthetic sweep, ' if args.cloud == 'lidar'
                                     else 'SST-base Waymo training, bs=2/GPU, 0.32 m voxel: uniform synthetic cloud '
                                     if args.workload == 'sst_bs2' else

@@ -92,11 +92,13 @@ __global__ __launch_bounds__(NTH, (NTH == 512 ? 2 : (K * N <= 128 * 128 ? 3 : 2)
                                                              int64_t ldy, const bf16_t* __restrict__ aux_in,
                                                              bf16_t* __restrict__ aux_out, int64_t ldaux, const ln_epi ln) {
   static_assert(EPI != kEpiAddLN || N == 128, "the LayerNorm epilogue needs a whole row in one accumulator set");
-  constexpr int RS = K * 2 + 16;  // LDS row stride in bytes: 16-byte lanes of one ds_read_b128 phase on distinct banks
+  // the LDS image is FRAGMENT-contiguous (round 6, see csrc/dense_f32x6.hip): the 16 rows x 32 k of an MFMA A operand are one
+  // 1 KiB block in lane order, a fragment read is base + 16 * lane - no bank conflicts under the real ds_read_b128 lane groups
+  // (the row-major image with a K * 2 + 16 byte row stride had two lanes of every group on the same banks), no padding
   constexpr int KS = K / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wimg = smem;
-  float* bimg = (float*)(smem + N * RS);  // [N] bias, then (kEpiAddLN) [N] LayerNorm weight, [N] LayerNorm bias
+  float* bimg = (float*)(smem + N * K * 2);  // [N] bias, then (kEpiAddLN) [N] LayerNorm weight, [N] LayerNorm bias
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t wave = (int64_t)blockIdx.x * (NTH / 64) + (threadIdx.x >> 6);
   int64_t r0 = wave * rows_per_wave;
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(NTH, (NTH == 512 ? 2 : (K * N <= 128 * 128 ? 3 : 2)
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
       const int idx = base + u * NTH, n = idx / (K / 8), ch = idx - n * (K / 8);
-      *(u32x4*)(wimg + w_lds_row(n) * RS + ch * 16) = v[u];
+      const int lr = w_lds_row(n);    // ch = 8-k chunk: k-step ch >> 2, k group ch & 3
+      *(u32x4*)(wimg + ((lr >> 4) * KS + (ch >> 2)) * 1024 + (16 * (ch & 3) + (lr & 15)) * 16) = v[u];
     }
   }
   for (int n = threadIdx.x; n < N; n += NTH) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(NTH, (NTH == 512 ? 2 : (K * N <= 128 * 128 ? 3 : 2)
   }
   __syncthreads();
   if (r0 >= r1) return;
-  const unsigned char* wlane = wimg + c * RS + g * 16;
+  const unsigned char* wlane = wimg + lane * 16;
   for (; r0 < r1; r0 += 32) {
     asm volatile("" ::: "memory");  // W fragments are re-read from LDS per row tile (never hoisted into registers)
     const bool more = r0 + 32 < r1;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(NTH, (NTH == 512 ? 2 : (K * N <= 128 * 128 ? 3 : 2)
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
       for (int T = 0; T < HT; ++T) {
-        const u32x4 wf = *(const u32x4*)(wlane + (nh * HT + T) * 16 * RS + s * 64);
+        const u32x4 wf = *(const u32x4*)(wlane + ((nh * HT + T) * KS + s) * 1024);
         acc[0][T] = mma32(wf, xb[0][s], acc[0][T]);
         acc[1][T] = mma32(wf, xb[1][s], acc[1][T]);
       }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(NTH, (NTH == 512 ? 2 : (K * N <= 128 * 128 ? 3 : 2)
 template <int K, int N, int EPI>
 int launch_linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const float* bias, int64_t m, bf16_t* y, int64_t ldy,
                   const bf16_t* aux_in, bf16_t* aux_out, int64_t ldaux, hipStream_t st, const ln_epi ln = ln_epi()) {
-  constexpr int lds = N * (K * 2 + 16) + N * 4 * (EPI == kEpiAddLN ? 3 : 1);
+  constexpr int lds = N * K * 2 + N * 4 * (EPI == kEpiAddLN ? 3 : 1);
   // SST_AMD_BF16_LINEAR_WAVES = 8: one 8-wave workgroup per CU (the weights are copied to LDS once per CU, not 2-3 times)
   static int nth = 0;
   if (nth == 0) {

@@ -79,9 +79,11 @@ class FramePlan(object):
         # the sizes were copied to pinned host memory right behind the plan's kernels (build()): waiting for THAT copy does
         # not wait for anything queued after it (the voxel encoder of this step, or - when the plan was built ahead, behind
         # the previous step's backward pass - nothing at all)
-        self.counts_ready.synchronize()
-        counts = self.h_counts.tolist()
-        self._release_count_slot()
+        counts = self.__dict__.get('_counts')
+        if counts is None:               # a second finalize() of the same plan (activation checkpointing around voxel_info,
+            self.counts_ready.synchronize()   # extract_feat after extract_voxel_feats) reuses what the first one read
+            counts = self._counts = self.h_counts.tolist()
+            self._release_count_slot()
         m, m_keep, n_win, t_max = counts[0], counts[1], (counts[2], counts[3]), (counts[4], counts[5])
         self.num_voxels, self.num_kept = m, m_keep
         dev = voxel_feats.device
@@ -152,15 +154,18 @@ class FramePlanner(object):
         cells = batch_size * self.grid_zyx[0] * self.grid_zyx[1] * self.grid_zyx[2]
         return self._ok and 1 <= batch_size <= 64 and cells <= (1 << 28)
 
-    def build_overlapped(self, points_list, ready_event=None):
+    def build_overlapped(self, points_list, ready_event=None, points_complete=False):
         """build() on the planner's OWN stream, concurrently with whatever the caller's stream still has queued (the previous
         step's backward pass): the plan depends on the point clouds only, its ~50 short launches fit between the waves of the
         dense kernels, and its sizes are on the host long before finalize() asks for them - the host never falls behind the
         device at the head of a step (with everything on one stream it waited there for the previous step to drain, and the
         device then idled while the host woke up and issued the voxel encoder).
 
-        The caller's promise: the point clouds are COMPLETE, or complete once `ready_event` (recorded behind their producer,
-        e.g. the host-to-device copy of a data-loader hook) has happened - the side stream waits for that event and nothing else.
+        The side stream waits for `ready_event` (recorded behind the producer of the point clouds, e.g. the host-to-device copy
+        of a data-loader hook) and nothing else; WITHOUT one it waits for everything the caller's current stream has queued up
+        to this call (an event recorded here): a cloud still being produced there - `p.cuda(non_blocking=True)`, a device-side
+        augmentation - is complete before the plan reads it (a docstring promise was the only guard).
+        `points_complete=True` states that the clouds need no wait at all (the round-5 behaviour).
         Memory: everything the plan keeps is allocated from the side stream's pool and marked as used by the caller's stream
         (`record_stream`), which waits for the plan before its first consumer."""
         dev = points_list[0].device
@@ -168,6 +173,9 @@ class FramePlanner(object):
         side = self.__dict__.get('_side_stream')
         if side is None or side.device != dev:
             side = self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
+        if ready_event is None and not points_complete:
+            ready_event = torch.cuda.Event()
+            ready_event.record(main)     # the producer work queued so far - not what the caller queues after this call
         if ready_event is not None:
             side.wait_event(ready_event)
         with torch.cuda.stream(side):
@@ -199,8 +207,11 @@ class FramePlanner(object):
         """the data loader's batch (host tensors, ideally pinned) -> device copies on the side stream -> build_overlapped: the
         copy, the plan and the size read-back all run beside the step in flight, and the copies belong to the plan
         (`plan.points_list`: what extract_feat would have been handed)"""
+        device = torch.device(device)
+        if device.index is None:          # 'cuda' never equals a stream's 'cuda:0': a new stream per call otherwise
+            device = torch.device('cuda', torch.cuda.current_device())
         side = self.__dict__.get('_side_stream')
-        if side is None or side.device != torch.device(device):
+        if side is None or side.device != device:
             side = self._side_stream = torch.cuda.Stream(device=device, priority=-1)
         main = torch.cuda.current_stream(device)
         with torch.cuda.stream(side):

@@ -39,33 +39,41 @@ import torch
 import torch.distributed as dist
 
 
-_BUCKET_GROUP = {}      # default-group id -> the process-wide bucket communicator
-_AVG_SUPPORT = {}       # (backend, group id) -> bool
+# keyed by id(group) WITH the group object kept in the entry: a bare id() can be reused after destroy_process_group() +
+# init_process_group() in one process (test harnesses, elastic restarts) and would hand back a destroyed communicator or a stale
+# AVG decision; an entry that holds its group keeps that id taken (ProcessGroup objects take no weak references)
+_BUCKET_GROUP = {}      # id(default group) -> (default group, the process-wide bucket communicator)
+_AVG_SUPPORT = {}       # id(group) -> (group, {backend: bool})
 
 
 def bucket_group():
     """the communicator the gradient buckets travel on: created on first use (collective: every rank builds its first reducer
     at the same point of the program), then shared by every reducer of the process"""
-    key = id(dist.group.WORLD)
-    if key not in _BUCKET_GROUP:
-        _BUCKET_GROUP[key] = dist.new_group()
-    return _BUCKET_GROUP[key]
+    world = dist.group.WORLD
+    entry = _BUCKET_GROUP.get(id(world))
+    if entry is None or entry[0] is not world:
+        entry = _BUCKET_GROUP[id(world)] = (world, dist.new_group())
+    return entry[1]
 
 
 def avg_supported(group, device):
     """does the backend of ``group`` reduce with ReduceOp.AVG?  One blocking one-element all-reduce, once per communicator
     (collective).  RCCL builds that follow NCCL >= 2.10 do; gloo refuses at the call (-> sum and divide)."""
-    key = (dist.get_backend(group), id(group))
-    if key not in _AVG_SUPPORT:
+    entry = _AVG_SUPPORT.get(id(group))
+    if entry is None or entry[0] is not group:
+        entry = _AVG_SUPPORT[id(group)] = (group, {})
+    per_group = entry[1]
+    key = dist.get_backend(group)
+    if key not in per_group:
         try:
             probe = torch.ones(1, dtype=torch.float32, device=device)
             dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
             if probe.is_cuda:
                 torch.cuda.current_stream(device).synchronize()
-            _AVG_SUPPORT[key] = bool(abs(float(probe.item()) - 1.0) < 1e-6)
+            per_group[key] = bool(abs(float(probe.item()) - 1.0) < 1e-6)
         except (RuntimeError, ValueError, TypeError, NotImplementedError):
-            _AVG_SUPPORT[key] = False
-    return _AVG_SUPPORT[key]
+            per_group[key] = False
+    return per_group[key]
 
 
 class GradBucketReducer(object):
@@ -145,7 +153,10 @@ class GradBucketReducer(object):
             self._work.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
 
     def finish(self):
-        """send what is left, wait for every bucket, average, point every ``p.grad`` at its slot"""
+        """send what is left, wait for every bucket, average, point every ``p.grad`` at its slot.  A parameter that produced no
+        gradient this step travels as zeros and ends with a ZERO gradient (not None): an optimizer with weight decay / momentum
+        then updates it, unlike torch DDP with find_unused_parameters (which leaves None) - the models of this package use every
+        parameter in every step; a caller with conditional branches should drop those parameters from the reducer."""
         for b in range(self._next, len(self.buckets)):
             self._send(b)
         for w in self._work:

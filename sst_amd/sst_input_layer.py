@@ -45,9 +45,15 @@ class VoxelInfo(dict):
         fn = self._deferred.get(key)
         if fn is None:
             raise KeyError(key)
-        fn(self)
-        for k in [k for k, f in self._deferred.items() if f is fn]:
+        group = [k for k, f in self._deferred.items() if f is fn]
+        for k in group:                  # before the call: fn stores the group's keys through __setitem__ / update
             del self._deferred[k]
+        try:
+            fn(self)
+        except BaseException:
+            for k in group:
+                self._deferred[k] = fn
+            raise
         return dict.__getitem__(self, key)
 
     def __contains__(self, key):
@@ -87,6 +93,45 @@ class VoxelInfo(dict):
         dict.update(out, dict.items(self))
         out._deferred = dict(self._deferred)
         return out
+
+    # the rest of the dict protocol on deferred keys: a write or a removal settles the key first, copies get
+    # their own table of deferred groups
+    def __copy__(self):
+        return self.shallow()
+
+    def copy(self):
+        return self.shallow()
+
+    def __reduce__(self):                     # pickling / deepcopy: the formed dictionary
+        return (dict, (dict(dict.items(self.materialize())),))
+
+    def _drop_deferred(self, key):
+        """``key`` is about to be overwritten or removed: form its group first (the other keys of the group stay valid), so that
+        no stale deferred entry is left to overwrite the user's value or to be counted twice"""
+        if key in self._deferred:
+            self[key]
+
+    def __setitem__(self, key, value):
+        self._drop_deferred(key)
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self._drop_deferred(key)
+        dict.__delitem__(self, key)
+
+    def pop(self, key, *default):
+        self._drop_deferred(key)
+        return dict.pop(self, key, *default)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        dict.__setitem__(self, key, default)
+        return default
+
+    def update(self, *args, **kwargs):
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = v
 
 
 @MIDDLE_ENCODERS.register_module()

@@ -141,3 +141,22 @@ def test_bench_launches_its_own_ranks():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['parallelism'] == 'dp2' and res['value'] > 0
     assert res['config']['grad_sync'].startswith('one flat')
+
+
+def test_bench_preflight_eight_ranks_on_one_device():
+    """The launch plumbing of the driver's N = 8 run without eight GPUs: eight ranks, all on cuda:0,
+    gloo - rendezvous, per-rank frames, SyncBN exchange, bucketed gradient all-reduce, max-over-ranks timing, ONE JSON line
+    from rank 0 with its `ranks` block."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--share-device', '--backend',
+                        'gloo', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--points', '20000', '--blocks', '2'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 8 and res['config']['parallelism'] == 'dp8' and res['value'] > 0 and res['scaling'] == 'weak'
+    ranks = res['ranks']
+    assert ranks['world_size'] == 8 and ranks['backend'] == 'gloo' and len(ranks['per_rank']) == 8
+    assert res['config']['grad_sync'].startswith('one flat') and res['cpu_baseline'] is None
+    assert 'workloads' not in res           # the single-GPU legs stay out of a multi-rank line

@@ -66,6 +66,7 @@ def test_layer_argument_structs_match_the_header(struct, cname):
     from sst_amd import _lib
     text = open(os.path.join(ROOT, 'include', 'sst_amd.h')).read()
     body = re.search(r'typedef struct ' + cname + r' \{(.*?)\} ' + cname + ';', text, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)      # field comments
     fields = []
     for decl in body.split(';'):
         decl = decl.strip()
