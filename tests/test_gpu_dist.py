@@ -157,6 +157,6 @@ def test_bench_preflight_eight_ranks_on_one_device():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 8 and res['config']['parallelism'] == 'dp8' and res['value'] > 0 and res['scaling'] == 'weak'
     ranks = res['ranks']
-    assert ranks['world_size'] == 8 and ranks['backend'] == 'gloo' and len(ranks['per_rank']) == 8
+    assert ranks['world_size'] == 8 and ranks['backend'] == 'gloo' and len(ranks['per_rank']['ms_per_step']) == 8
     assert res['config']['grad_sync'].startswith('one flat') and res['cpu_baseline'] is None
     assert 'workloads' not in res           # the single-GPU legs stay out of a multi-rank line
