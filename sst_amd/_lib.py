@@ -375,26 +375,57 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-FP16_MESSAGE = ("sst_amd: float16 {what} - this library has no fp16 path.  The reference's half-precision training "
-                "(`fp16 = dict(loss_scale=32.0)`, mmcv wrap_fp16_model / Fp16OptimizerHook: sst_waymoD5_1x_3class_8heads_v2.py:82) "
-                "corresponds here to bf16 storage with fp32 master weights and no loss scaling: leave the model in fp32, do not wrap "
-                "it, and call `backbone.set_precision('bf16')` (INTEGRATION.md section A.1)")
+class Fp32Master(object):
+    """Mix-in of the entry modules (voxel encoders, input layers, backbones): what ``model.half()`` means for them.
+
+    The reference's half-precision training (``fp16 = dict(loss_scale=32.0)``, configs/sst_refactor/
+    sst_waymoD5_1x_3class_8heads_v2.py:82) goes through mmcv's ``wrap_fp16_model`` - ``model.half()`` plus
+    ``fp16_enabled = True`` on every module that has the attribute - and ``Fp16OptimizerHook``, which keeps fp32 master copies
+    of the weights and scales the loss.  On this hardware the encoder layers' reduced-precision mode is bf16 storage with fp32
+    accumulation (sst_amd/bf16.py) and the parameters of these modules ARE the fp32 masters: a conversion of the module to
+    float16 is therefore remembered (``half_requested``) and NOT applied - parameters and buffers stay fp32, the encoder stack
+    switches to its bf16 mode where the reference's ``auto_fp16`` (sst_basic_block_v2.py:102-104) would cast to half, and
+    outputs are handed on as float16 where the reference's layers would (the modules behind - neck, heads - are half).  The
+    hook's bookkeeping (copy_grads_to_fp32 / copy_params_to_fp16) works unchanged on fp32 parameters.  bf16 has fp32's
+    exponent range: the loss scale is harmless (and not needed)."""
+
+    half_requested = False
+
+    def _apply(self, fn, *args, **kwargs):
+        try:
+            to_half = fn(torch.zeros(1, dtype=torch.float32)).dtype == torch.float16
+        except Exception:
+            to_half = False
+        if to_half:
+            for m in self.modules():
+                if isinstance(m, Fp32Master):
+                    m.half_requested = True
+            return self
+        return super()._apply(fn, *args, **kwargs)
+
+
+def wants_half(module):
+    """did the caller ask for the reference's fp16 mode: ``model.half()`` (remembered by Fp32Master) or ``fp16_enabled`` set on
+    one of the module's encoder layers / the module itself by mmcv's wrap_fp16_model"""
+    if getattr(module, 'half_requested', False) or getattr(module, 'fp16_enabled', False):
+        return True
+    return any(getattr(m, 'fp16_enabled', False) for m in module.modules())
+
+
+def as_fp32(*tensors):
+    """the reference's force_fp32 on inputs (voxel_encoder.py:229, dynamic_voxelnet.py:50): half tensors are cast, others pass"""
+    out = tuple(t.float() if (t is not None and torch.is_tensor(t) and t.dtype in (torch.float16, torch.bfloat16)) else t
+                for t in tensors)
+    return out if len(out) != 1 else out[0]
 
 
 def refuse_fp16(module=None, *tensors, what=None):
-    """The fp16 / auto_fp16 contract (sst_basic_block_v2.py:104, sst_input_layer_v2.py:79, voxel_encoder.py:229): a model that
-    went through mmcv's ``wrap_fp16_model`` has half parameters, and its decorated forwards would hand half tensors on.  Instead
-    of failing somewhere inside a kernel wrapper with a dtype message, the entry modules say what to do (loudly, before any
-    launch)."""
-    import torch
-    if module is not None:
-        for p in module.parameters():
-            if p.dtype == torch.float16:
-                raise RuntimeError(FP16_MESSAGE.format(what=what or f'parameters in {type(module).__name__}'))
-            break     # wrap_fp16_model converts all of them: the first one tells
+    """kept for callers outside the entry modules: half PARAMETERS cannot occur in an Fp32Master module; a half tensor handed to
+    a kernel wrapper directly is a usage error there (the entry modules cast with as_fp32 instead)"""
     for t in tensors:
         if t is not None and torch.is_tensor(t) and t.dtype == torch.float16:
-            raise RuntimeError(FP16_MESSAGE.format(what=what or 'input tensor'))
+            raise RuntimeError(what or 'sst_amd: float16 tensor handed to an fp32 kernel wrapper - cast it (the entry modules do: '
+                                       'sst_amd._lib.as_fp32), or use the bf16 mode of the encoder stack (set_precision)')
 
 
 def require_cuda(*tensors):

@@ -112,7 +112,7 @@ def _batch_size_of(info, coors_key):
     return int(coors[:, 0].max().item()) + 1 if coors.size(0) > 0 else 1
 
 
-class _WindowTransformer(nn.Module):
+class _WindowTransformer(_lib.Fp32Master, nn.Module):
     """What SSTv1 and SSTv2 have in common: optional input projection, the shift blocks, the attached convolutions."""
 
     def _build_stem(self, d_model, nhead, num_blocks, dim_feedforward, dropout, activation, in_channel, layer_cfg,
@@ -266,23 +266,37 @@ class SSTv2(_WindowTransformer):
 
     def forward_voxels(self, voxel_info):
         """the shift blocks only: [M', C] features of the kept voxels (what ``forward`` returns with ``to_bev=False``)"""
-        _lib.refuse_fp16(self, voxel_info['voxel_feats'])
+        feats_in = _lib.as_fp32(voxel_info['voxel_feats'])
         plans, pos, masks = self._window_inputs(voxel_info)
         lookup = None
         if 'pos_table' in voxel_info and 'pos_index_shift0' in voxel_info:   # (table, row index) per partition
             lookup = [(voxel_info['pos_table'], voxel_info[f'pos_index_shift{i}']) for i in range(2)]
         from . import dense
-        with dense.matmul_mode_scope(getattr(self, 'matmul', None)):     # this module's own mode, whatever another model set
-            return self.run_blocks(voxel_info['voxel_feats'], pos, plans, masks, pos_lookup=lookup)
+        # the reference's fp16 mode (wrap_fp16_model: model.half() + fp16_enabled on the encoder layers, whose auto_fp16 casts
+        # their input to half: sst_basic_block_v2.py:102-104) = this stack's bf16 mode for the call; the features leave as
+        # float16, as the reference's half layers hand them on (_lib.Fp32Master)
+        half = _lib.wants_half(self)
+        keep = self.precision
+        if half:
+            self.precision = 'bf16'
+        try:
+            with dense.matmul_mode_scope(getattr(self, 'matmul', None)):     # this module's own mode, whatever another model set
+                out = self.run_blocks(feats_in, pos, plans, masks, pos_lookup=lookup)
+        finally:
+            self.precision = keep
+        return out.half() if half else out
 
     def forward(self, voxel_info):
         coors = voxel_info['voxel_coors']
         assert coors.dtype == torch.int64, 'data type of coors should be torch.int64!'
         feats = self.forward_voxels(voxel_info)
+        half = _lib.wants_half(self)
         if not self.to_bev:
             assert self.num_attached_conv <= 0, 'the attached convolutions need the BEV canvas'
             return [{'voxel_feats': feats, 'voxel_coors': coors}]
-        return [self.bev_and_attached_convs(feats, coors, _batch_size_of(voxel_info, 'voxel_coors'), self.conv_shortcut)]
+        # the canvas and the attached convolutions compute in fp32 (their parameters are the fp32 masters)
+        bev = self.bev_and_attached_convs(_lib.as_fp32(feats), coors, _batch_size_of(voxel_info, 'voxel_coors'), self.conv_shortcut)
+        return [bev.half() if half else bev]      # fp16 mode: the neck / heads behind are half modules
 
     def recover_bev(self, voxel_feat, coors, batch_size):
         return recover_bev(voxel_feat, coors, batch_size, self.output_shape)
@@ -335,7 +349,7 @@ class SSTv1(_WindowTransformer):
 
     def forward(self, input_tuple):
         voxel_feat, ind_dict_list, voxel_info = input_tuple
-        _lib.refuse_fp16(self, voxel_feat)
+        voxel_feat = _lib.as_fp32(voxel_feat)
         assert voxel_info['coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'
         self.set_drop_info()
         plans, pos = [], []
@@ -374,7 +388,7 @@ class SIR(nn.Module):
 
     def forward(self, points, features, coors, f_cluster=None):
         """-> (point features of the last block, per-cluster features of all blocks side by side, cluster coordinates)."""
-        _lib.refuse_fp16(self, features)
+        features = _lib.as_fp32(features)
         grouping = dict(new_coors_once=None, unq_inv_once=None)
         if self.unique_once:   # one sorted-unique of the cluster ids for the whole stack (its CSR rides on unq_inv)
             grouping['new_coors_once'], grouping['unq_inv_once'] = unique_with_plan(coors)

@@ -225,7 +225,7 @@ class SSTInputLayerV2(nn.Module):
                         'sra_plan_shift{i}', 'pos_embed_shift{i}'.
         '''
         from . import _lib
-        _lib.refuse_fp16(None, voxel_feats)
+        voxel_feats = _lib.as_fp32(voxel_feats)    # auto_fp16 of the reference names a non-existent argument (sst_input_layer_v2.py:79): fp32 passes
         return self.apply_plan(self.build_plan(voxel_coors, batch_size, voxel_feats.size(1), voxel_feats.dtype),
                                voxel_feats)
 

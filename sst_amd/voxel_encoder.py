@@ -113,7 +113,7 @@ class _UniqueGrouping(object):
 # ------------------------------------------------------------------------------------------------------------------
 # shared implementation
 # ------------------------------------------------------------------------------------------------------------------
-class _PointGroupEncoder(nn.Module):
+class _PointGroupEncoder(_lib.Fp32Master, nn.Module):
 
     def _init_common(self, in_channels, feat_channels, with_distance, with_cluster_center, with_voxel_center,
                      voxel_size, point_cloud_range, mode, return_point_feats, fusion_layer):
@@ -228,7 +228,6 @@ class DynamicVFE(_PointGroupEncoder):
         return voxel_mean[plan.coors_map.long().clamp(min=0), ...]
 
     def forward(self, features, coors, points=None, img_feats=None, img_metas=None, scatter_plan=None):
-        _lib.refuse_fp16(self)        # half parameters (a wrapped model); half INPUTS are cast, as the reference's force_fp32 does
         features = features.float()   # @force_fp32 (voxel_encoder.py:229)
         coors = coors.contiguous()
         grouping = _VoxelGrouping(scatter_plan if scatter_plan is not None else self.scatter_plan(coors))
@@ -268,7 +267,6 @@ class DynamicScatterVFE(DynamicVFE):
         return _UniqueGrouping(coors)
 
     def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False, grouping=None):
-        _lib.refuse_fp16(self)
         features = features.float()
         if grouping is None:
             grouping = _UniqueGrouping(coors)   # one sorted-unique whether or not unique_once is set: it is never redone
@@ -321,7 +319,6 @@ class SIRLayer(_PointGroupEncoder):
 
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None, return_inv=False,
                 return_both=False, unq_inv_once=None, new_coors_once=None):
-        _lib.refuse_fp16(self)
         features = features.float()
         grouping = _UniqueGrouping(coors, new_coors_once, unq_inv_once)
         xyz, rest = features[:, :3], features[:, 3:]
