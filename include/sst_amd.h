@@ -827,6 +827,47 @@ int64_t sst_encoder_tail_bwd_workspace_bytes(int64_t m);
 int sst_encoder_tail_fwd_f32x6(const sst_encoder_tail_fwd_args* args, void* stream);
 int sst_encoder_tail_bwd_f32x6(const sst_encoder_tail_bwd_args* args, void* stream);
 
+/* The same one-kernel tail in the reduced-precision mode (csrc/layer_tail_bf16.hip): activations bf16 (o, x, s1, y1, s2, y2, y2p,
+ * ds2, ds1, d_o, dy2, dy2p [m, 128]; pre, h, dpre [m, 256]), statistics / biases / LayerNorm parameters / their gradients fp32;
+ * `packed` = sst_encoder_tail_pack_bf16_bytes() bytes written by sst_encoder_tail_pack_bf16 from the fp32 master weights
+ * (w_out [128][128], w1 [256][128], w2 [128][256]): the bf16 images of both directions.  Field meaning as sst_encoder_tail_*_args. */
+typedef struct sst_encoder_tail_fwd_bf16_args {
+  int64_t m;
+  int32_t act, reserved;
+  float eps, reserved_f;
+  const void *o, *x;
+  const void* packed;
+  const float *b_out, *b1, *b2, *n1w, *n1b, *n2w, *n2b;
+  const float* pos_table;
+  const int32_t* pos_idx;
+  void* s1;
+  float* st1;
+  void *y1, *pre, *h, *s2;
+  float* st2;
+  void *y2, *y2p;
+} sst_encoder_tail_fwd_bf16_args;
+typedef struct sst_encoder_tail_bwd_bf16_args {
+  int64_t m;
+  int32_t act, reserved;
+  const void *dy2, *dy2p, *s2;
+  const float* st2;
+  const void *pre, *s1;
+  const float* st1;
+  const void* packed;
+  const float *n1w, *n2w;
+  void *ds2, *dpre, *ds1, *d_o;
+  float *dn2w, *dn2b, *dn1w, *dn1b;
+  void* workspace;
+} sst_encoder_tail_bwd_bf16_args;
+int64_t sst_encoder_tail_pack_bf16_bytes(void);
+int sst_encoder_tail_pack_bf16(const float* d_w_out, const float* d_w1, const float* d_w2, void* d_packed, void* stream);
+/* the images of n layers in one launch: host arrays of device pointers (a whole encoder stack per forward pass) */
+int sst_encoder_tail_pack_bf16_many(const float* const* d_w_out, const float* const* d_w1, const float* const* d_w2,
+                                    void* const* d_packed, int n, void* stream);
+int64_t sst_encoder_tail_bwd_bf16_workspace_bytes(int64_t m);
+int sst_encoder_tail_fwd_bf16(const sst_encoder_tail_fwd_bf16_args* args, void* stream);
+int sst_encoder_tail_bwd_bf16(const sst_encoder_tail_bwd_bf16_args* args, void* stream);
+
 /* The same layer in the reduced-precision mode (bf16 storage, fp32 accumulation / softmax / LayerNorm statistics, fp32 master
  * weights: what the reference's fp16 training of these layers - configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:82 -
  * corresponds to), one call per direction: the launch sequence of sst_amd/bf16.py EncoderLayerBF16Fn issued from C (6 launches
@@ -855,6 +896,7 @@ typedef struct sst_encoder_layer_fwd_bf16_args {
   float* st2;
   void *y2, *y2p;
   const float* head_scale;
+  const void* wpack;   /* sst_encoder_tail_pack_bf16 images of this layer's out_proj / linear1 / linear2 (fp32 masters) */
 } sst_encoder_layer_fwd_bf16_args;
 typedef struct sst_encoder_layer_bwd_bf16_args {
   int64_t m, n_windows;
@@ -875,6 +917,7 @@ typedef struct sst_encoder_layer_bwd_bf16_args {
   void* workspace;
   const float* head_scale;
   float* cos_r;
+  const void* wpack;   /* as in the forward arguments */
 } sst_encoder_layer_bwd_bf16_args;
 int64_t sst_encoder_layer_bwd_bf16_workspace_bytes(int64_t m);
 int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* args, void* stream);

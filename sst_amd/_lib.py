@@ -73,13 +73,22 @@ EncoderTailBwdArgs = _struct('EncoderTailBwdArgs', 'sst_encoder_tail_bwd_args of
     + [(k, _P) for k in ('dy2', 'dy2p', 's2', 'st2', 'pre', 's1', 'st1', 'packed', 'n1w', 'n2w',
                          'ds2', 'dpre', 'ds1', 'd_o', 'dn2w', 'dn2b', 'dn1w', 'dn1b', 'workspace')]))
 
+EncoderTailFwdBF16Args = _struct('EncoderTailFwdBF16Args', 'sst_encoder_tail_fwd_bf16_args of include/sst_amd.h', (
+    [('m', c_i64), ('act', ctypes.c_int32), ('reserved', ctypes.c_int32), ('eps', ctypes.c_float), ('reserved_f', ctypes.c_float)]
+    + [(k, _P) for k in ('o', 'x', 'packed', 'b_out', 'b1', 'b2', 'n1w', 'n1b', 'n2w', 'n2b', 'pos_table', 'pos_idx',
+                         's1', 'st1', 'y1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p')]))
+EncoderTailBwdBF16Args = _struct('EncoderTailBwdBF16Args', 'sst_encoder_tail_bwd_bf16_args of include/sst_amd.h', (
+    [('m', c_i64), ('act', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+    + [(k, _P) for k in ('dy2', 'dy2p', 's2', 'st2', 'pre', 's1', 'st1', 'packed', 'n1w', 'n2w',
+                         'ds2', 'dpre', 'ds1', 'd_o', 'dn2w', 'dn2b', 'dn1w', 'dn1b', 'workspace')]))
+
 
 EncoderLayerFwdBF16Args = _struct('EncoderLayerFwdBF16Args', 'sst_encoder_layer_fwd_bf16_args of include/sst_amd.h', (
     [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'reserved')]
     + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
     + [(k, _P) for k in ('x', 'xp', 'wqk', 'wv', 'wout', 'w1', 'w2', 'b_in', 'b_out', 'b1', 'b2', 'n1w', 'n1b', 'n2w', 'n2b',
                          'tok', 'winoff', 'order', 'pos_table', 'pos_idx',
-                         'qk', 'v', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p', 'head_scale')]))
+                         'qk', 'v', 'o', 'lse', 'y1', 's1', 'st1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p', 'head_scale', 'wpack')]))
 EncoderLayerBwdBF16Args = _struct('EncoderLayerBwdBF16Args', 'sst_encoder_layer_bwd_bf16_args of include/sst_amd.h', (
     [('m', c_i64), ('n_windows', c_i64)] + [(k, ctypes.c_int32) for k in ('n_heads', 'act', 'max_tokens', 'reserved')]
     + [('eps', ctypes.c_float), ('scale', ctypes.c_float)]
@@ -87,7 +96,7 @@ EncoderLayerBwdBF16Args = _struct('EncoderLayerBwdBF16Args', 'sst_encoder_layer_
                          'wqk_t', 'wv_t', 'wout_t', 'w1_t', 'w2_t', 'n1w', 'n2w', 'tok', 'winoff', 'order',
                          'ds2', 'dpre', 'dy1', 'ds1', 'd_o', 'dqkv', 'dxp', 'dx',
                          'dw_in', 'db_in', 'dwo', 'dbo', 'dw1', 'db1', 'dw2', 'db2', 'dn1w', 'dn1b', 'dn2w', 'dn2b',
-                         'workspace', 'head_scale', 'cos_r')]))
+                         'workspace', 'head_scale', 'cos_r', 'wpack')]))
 
 
 # name -> (restype, argtypes); mirrors include/sst_amd.h one to one
@@ -115,6 +124,12 @@ _SIGNATURES = {
     'sst_encoder_tail_bwd_workspace_bytes': (c_i64, [c_i64]),
     'sst_encoder_tail_fwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_tail_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),
+    'sst_encoder_tail_pack_bf16_bytes': (c_i64, []),
+    'sst_encoder_tail_pack_bf16': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_encoder_tail_pack_bf16_many': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr]),
+    'sst_encoder_tail_bwd_bf16_workspace_bytes': (c_i64, [c_i64]),
+    'sst_encoder_tail_fwd_bf16': (c_i32, [c_ptr, c_ptr]),
+    'sst_encoder_tail_bwd_bf16': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_bf16_workspace_bytes': (c_i64, [c_i64]),
     'sst_encoder_layer_fwd_bf16': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_layer_bwd_bf16': (c_i32, [c_ptr, c_ptr]),

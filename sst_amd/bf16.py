@@ -332,6 +332,111 @@ def layer_shadow_specs(enc, with_grad):
     return specs
 
 
+def tail_pack(w_out, w1, w2, out=None):
+    """bf16 chunk images (LDS layout) of a layer's out-projection / linear1 / linear2 weights for tail_fwd / tail_bwd, from the
+    fp32 masters: one small launch per layer call (uint8 tensor, 320 KB)"""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(int(lib.sst_encoder_tail_pack_bf16_bytes()), dtype=torch.uint8, device=w_out.device)
+    _lib.check(lib.sst_encoder_tail_pack_bf16(_lib.ptr(w_out), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(out), _lib.stream_ptr()),
+               'sst_encoder_tail_pack_bf16')
+    return out
+
+
+def tail_weights_ok(w_out, w1, w2):
+    return (w_out.shape == (128, 128) and w1.shape == (256, 128) and w2.shape == (128, 256)
+            and all(w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda for w in (w_out, w1, w2)))
+
+
+def tail_ok(o, x, w_out, w1, w2):
+    return (o.shape == x.shape and x.dim() == 2 and x.size(1) == 128 and w_out.shape == (128, 128) and w1.shape == (256, 128)
+            and w2.shape == (128, 256) and o.dtype == BF16 and x.dtype == BF16 and o.is_contiguous() and x.is_contiguous()
+            and o.is_cuda and o.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+            and all(w.dtype == torch.float32 and w.is_contiguous() for w in (w_out, w1, w2)))
+
+
+def tail_fwd(o, x, packed, b_out, b1, b2, n1w, n1b, n2w, n2b, eps, act, save=True, pos=None, out=None):
+    """out-projection -> + x -> norm1 -> linear1 -> act -> linear2 -> + y1 -> norm2 (sst_basic_block_v2.py:113-118) as ONE kernel,
+    bf16 storage (csrc/layer_tail_bf16.hip) -> dict(s1, st1, y1, pre, h, s2, st2, y2, y2p)"""
+    import ctypes
+    m = x.size(0)
+    dev = x.device
+    out = dict(out) if out else {}
+
+    def e(name, cols, dtype=BF16):
+        if name not in out or out[name] is None:
+            out[name] = torch.empty((m, cols), dtype=dtype, device=dev)
+        return out[name]
+    s1 = e('s1', 128) if save else None
+    s2 = e('s2', 128) if save else None
+    out['s1'], out['s2'] = s1, s2
+    st1, st2 = e('st1', 2, torch.float32), e('st2', 2, torch.float32)
+    y1, pre, h, y2 = e('y1', 128), e('pre', 256), e('h', 256), e('y2', 128)
+    y2p = e('y2p', 128) if pos is not None else None
+    out['y2p'] = y2p
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    args = _lib.EncoderTailFwdBF16Args(
+        m, 1 if act == 'gelu' else 2, 0, float(eps), 0.0, P(o), P(x), P(packed), P(b_out), P(b1), P(b2), P(n1w), P(n1b),
+        P(n2w), P(n2b), P(pos[0]) if pos is not None else None, P(pos[1]) if pos is not None else None,
+        P(s1), P(st1), P(y1), P(pre), P(h), P(s2), P(st2), P(y2), P(y2p))
+    _lib.check(_lib.load().sst_encoder_tail_fwd_bf16(ctypes.byref(args), _lib.stream_ptr()), 'sst_encoder_tail_fwd_bf16')
+    return out
+
+
+def tail_bwd(dy2, dy2p, s2, st2, pre, s1, st1, packed, n1w, n2w, act):
+    """-> (ds2, dpre, ds1, d_o (bf16), dn fp32 [4, 128] = dn2w | dn2b | dn1w | dn1b)"""
+    import ctypes
+    m = dy2.size(0)
+    dev = dy2.device
+
+    def e(cols):
+        return torch.empty((m, cols), dtype=BF16, device=dev)
+    ds2, dpre, ds1, d_o = e(128), e(256), e(128), e(128)
+    dn = torch.empty((4, 128), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws = _lib.workspace(lib.sst_encoder_tail_bwd_bf16_workspace_bytes(m), dev)
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    d0 = dn.data_ptr()
+    args = _lib.EncoderTailBwdBF16Args(m, 1 if act == 'gelu' else 2, 0, P(dy2), P(dy2p), P(s2), P(st2), P(pre), P(s1), P(st1),
+                                       P(packed), P(n1w), P(n2w), P(ds2), P(dpre), P(ds1), P(d_o), d0, d0 + 512, d0 + 1024,
+                                       d0 + 1536, P(ws))
+    _lib.check(lib.sst_encoder_tail_bwd_bf16(ctypes.byref(args), _lib.stream_ptr()), 'sst_encoder_tail_bwd_bf16')
+    return ds2, dpre, ds1, d_o, dn
+
+
+def tail_images(w_out, w1, w2, refresh=False):
+    """the layer's tail weight images (tail_pack), kept with the out-projection parameter like its bf16 copies; refreshed by
+    run_encoder_stack at every forward (one launch for the whole stack), made on the spot when missing"""
+    slot = _shadow_slot(w_out)
+    t = slot.get('tail')
+    if t is None or t.device != w_out.device:
+        t = slot['tail'] = tail_pack(w_out, w1, w2)
+    elif refresh:
+        tail_pack(w_out, w1, w2, out=t)
+    return t
+
+
+def _refresh_stack_tail_images(layers):
+    """tail images of every layer of a stack in ONE launch (sst_encoder_tail_pack_bf16_many), every forward: they follow the fp32
+    masters whatever wrote them (see refresh_shadows)"""
+    import ctypes
+    lib = _lib.load()
+    nbytes = int(lib.sst_encoder_tail_pack_bf16_bytes())
+    triples = [(enc.win_attn.self_attn.out_proj.weight, enc.linear1.weight, enc.linear2.weight) for enc in layers]
+    bufs = []
+    for wo, w1, w2 in triples:
+        slot = _shadow_slot(wo)
+        t = slot.get('tail')
+        if t is None or t.device != wo.device or t.numel() != nbytes:
+            t = slot['tail'] = torch.empty(nbytes, dtype=torch.uint8, device=wo.device)
+        bufs.append(t)
+    n = len(triples)
+    P = ctypes.c_void_p * n
+    a = P(*[t[0].data_ptr() for t in triples]), P(*[t[1].data_ptr() for t in triples]), P(*[t[2].data_ptr() for t in triples])
+    d = P(*[b.data_ptr() for b in bufs])
+    _lib.check(lib.sst_encoder_tail_pack_bf16_many(a[0], a[1], a[2], d, n, _lib.stream_ptr()), 'sst_encoder_tail_pack_bf16_many')
+
+
 def weight_grad(dy, x, chunk=2048):
     """dW [out, in] (fp32) = dy^T x for tall bf16 operands: batched split-K product over row chunks (each chunk a full
     MFMA-shaped GEMM for the library), partials reduced in fp32; bias gradient = fp32 column sum."""
@@ -413,7 +518,7 @@ def _exec_fwd(x, xp, plan, nhead, act, eps, scale, pos_next, params, need_bwd, h
         None if plan.tok_ptr(0) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
         S('qk'), S('v'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'),
-        S('s2') if need_bwd else None, S('st2'), P(y2), P(y2p), P(head_scale))
+        S('s2') if need_bwd else None, S('st2'), P(y2), P(y2p), P(head_scale), P(tail_images(w_out, w1, w2)))
     lib = _lib.load()
     rc = _timed('sra_fwd_bf16', plan.n_tokens, 0, lambda: lib.sst_encoder_layer_fwd_bf16(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_fwd_bf16')
@@ -459,7 +564,7 @@ def _exec_bwd(ctx, dy2, dy2p):
         None if plan.tok_ptr(0) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         sp['ds2'], sp['dpre'], sp['dy1'], sp['ds1'], sp['d_o'], sp['dqkv'], P(dxp), P(dx),
         P(dw_in), P(db_in), P(dwo), P(dbo), P(dw1), P(db1), P(dw2), P(db2), dnp, dnp + 4 * c, dnp + 8 * c, dnp + 12 * c, P(ws),
-        P(head_scale), P(cos_r))
+        P(head_scale), P(cos_r), P(tail_images(w_out, w1, w2)))
     rc = _timed('sra_bwd_bf16', plan.n_tokens, 1, lambda: lib.sst_encoder_layer_bwd_bf16(ctypes.byref(args), _lib.stream_ptr()))
     _lib.check(rc, 'sst_encoder_layer_bwd_bf16')
     d_scale = K.head_scale_grad(cos_r, head_scale) if ctx.cosine else None
@@ -501,7 +606,13 @@ class EncoderLayerBF16Fn(Function):
         else:
             o, lse = sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale)
         need_bwd = any(ctx.needs_input_grad)
-        if _FUSED_LN:
+        ctx.tail = False
+        if _FUSED_LN and c == 128 and tail_ok(o, x, w_out, w1, w2) and act in ('gelu', 'relu'):
+            # everything behind the attention core as ONE kernel (csrc/layer_tail_bf16.hip), as csrc/layer_exec.hip issues it
+            t = tail_fwd(o, x, tail_images(w_out, w1, w2), b_out, b1, b2, n1w, n1b, n2w, n2b, eps, act, save=True, pos=pos_next)
+            s1, st1, y1, pre, h, s2, st2, y2, y2p = (t[k] for k in ('s1', 'st1', 'y1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p'))
+            ctx.tail = True
+        elif _FUSED_LN:
             # out-projection + residual + LayerNorm, linear1 + activation, linear2 + residual + LayerNorm: three launches
             y1, s1, st1, _ = linear_add_ln(o, shadow(w_out), b_out, x, n1w, n1b, eps, save_sum=need_bwd)
             h, pre = tall_linear(y1, shadow(w1), b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
@@ -528,12 +639,17 @@ class EncoderLayerBF16Fn(Function):
         head_scale = ctx.saved_tensors[19] if ctx.cosine else None
         c = x.size(1)
         dev = x.device
-        ds2, dn2w, dn2b = add_ln_bwd(dy2, dy2p if ctx.two else None, s2, st2, n2w)   # = d(y1 residual) = d(f)
-        dpre = tall_linear(ds2, shadow(w2, transposed=True), None,
-                           EPI_MUL_GELU_GRAD if ctx.act == 'gelu' else EPI_MUL_RELU_GRAD, aux_in=pre)
-        dy1 = tall_linear(dpre, shadow(w1, transposed=True), None, EPI_ADD, aux_in=ds2)   # residual + FFN branch
-        ds1, dn1w, dn1b = add_ln_bwd(dy1, None, s1, st1, n1w)                             # = d(x residual) = d(a)
-        do = tall_linear(ds1, shadow(w_out, transposed=True))
+        if ctx.tail:
+            ds2, dpre, ds1, do, dn = tail_bwd(dy2.contiguous(), dy2p.contiguous() if (ctx.two and dy2p is not None) else None,
+                                              s2, st2, pre, s1, st1, tail_images(w_out, w1, w2), n1w, n2w, ctx.act)
+            dn2w, dn2b, dn1w, dn1b = dn[0], dn[1], dn[2], dn[3]
+        else:
+            ds2, dn2w, dn2b = add_ln_bwd(dy2, dy2p if ctx.two else None, s2, st2, n2w)   # = d(y1 residual) = d(f)
+            dpre = tall_linear(ds2, shadow(w2, transposed=True), None,
+                               EPI_MUL_GELU_GRAD if ctx.act == 'gelu' else EPI_MUL_RELU_GRAD, aux_in=pre)
+            dy1 = tall_linear(dpre, shadow(w1, transposed=True), None, EPI_ADD, aux_in=ds2)   # residual + FFN branch
+            ds1, dn1w, dn1b = add_ln_bwd(dy1, None, s1, st1, n1w)                             # = d(x residual) = d(a)
+            do = tall_linear(ds1, shadow(w_out, transposed=True))
         dqkv = torch.empty((x.size(0), 3 * c), dtype=BF16, device=dev)
         d_scale = None
         if ctx.cosine:
@@ -574,6 +690,9 @@ def run_encoder_stack(blocks, feats, plans, pos_specs):
     pos_specs: per partition (positional table fp32 [P, C], row index int32 [M])."""
     layers = [enc for block in blocks for enc in block.encoder_list]
     _refresh_stack_shadows(layers, torch.is_grad_enabled())   # one launch, every forward
+    if _FUSED_LN and all(tail_weights_ok(enc.win_attn.self_attn.out_proj.weight, enc.linear1.weight, enc.linear2.weight)
+                         for enc in layers):
+        _refresh_stack_tail_images(layers)                    # ... and one for the tail kernels' weight images
     from .sst_basic_block import stack_head_scales
     scales = stack_head_scales(layers)      # cosine layers: 1 / clamp(tau) of the whole stack in one pass (None: standard attention)
     x, xp = _CastIn.apply(feats, pos_specs[0][0], pos_specs[0][1])

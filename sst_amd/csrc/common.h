@@ -76,6 +76,8 @@ int sst_internal_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n,
 // in args->workspace as [*partial_rows][256] at *part2 (norm2) and *part1 (norm1); the dn* fields of args are not read.
 int sst_internal_encoder_tail_bwd_f32x6(const sst_encoder_tail_bwd_args* args, float** part2, float** part1, int* partial_rows,
                                         void* stream);
+int sst_internal_encoder_tail_bwd_bf16(const sst_encoder_tail_bwd_bf16_args* args, float** part2, float** part1, int* partial_rows,
+                                       void* stream);
 int sst_internal_weight_grad_group_f32x6(const sst_wgrad_problem_f32* problems, int n, void* d_workspace,
                                          const sst_colsum_rider* riders, int n_riders, void* stream);
 

@@ -538,19 +538,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_bf16_k(const wg_args args) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < J.width) {
       const float* src = J.partials + i;
-      float v[16][4];
+      for (int base = 0; base < J.nb; base += 512) {   // 512 partial rows at a time (any nb: csrc/layer_tail_bf16.hip has one per 128 tokens)
+        float v[16][4];
 #pragma unroll
-      for (int it = 0; it < 16; ++it)
+        for (int it = 0; it < 16; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int b = 32 * it + gq + 8 * j;
-          v[it][j] = src[(int64_t)(b < J.nb ? b : J.nb - 1) * J.width];
-        }
+          for (int j = 0; j < 4; ++j) {
+            const int b = base + 32 * it + gq + 8 * j;
+            v[it][j] = src[(int64_t)(b < J.nb ? b : J.nb - 1) * J.width];
+          }
 #pragma unroll
-      for (int it = 0; it < 16; ++it)
+        for (int it = 0; it < 16; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (32 * it + gq + 8 * j < J.nb) acc[j] += v[it][j];
+          for (int j = 0; j < 4; ++j)
+            if (base + 32 * it + gq + 8 * j < J.nb) acc[j] += v[it][j];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) fr[(gq + 8 * j) * 33 + cx] = acc[j];
@@ -754,7 +756,7 @@ int sst_internal_wgrad_group_bf16(const sst_wgrad_problem_bf16* problems, int n,
   args.n = n;
   args.n_riders = n_riders;
   for (int i = 0; i < n_riders; ++i) {
-    if (!riders[i].partials || riders[i].nb < 1 || riders[i].nb > 512 || riders[i].width < 1 || riders[i].width > 516 * 32 ||
+    if (!riders[i].partials || riders[i].nb < 1 || riders[i].width < 1 || riders[i].width > 516 * 32 ||
         !riders[i].out0 || !riders[i].out1)
       return SST_ERR_ARG;
     args.riders[i] = riders[i];

@@ -168,9 +168,9 @@ int sst_encoder_layer_bwd_f32x6(const sst_encoder_layer_bwd_args* a, void* strea
 // ---- the reduced-precision layer (sst_amd/bf16.py EncoderLayerBF16Fn, its fused-LayerNorm sequence) ------------------------
 int64_t sst_encoder_layer_bwd_bf16_workspace_bytes(int64_t m) {
   if (m < 0) return SST_ERR_ARG;
-  const int64_t a = sst_add_layernorm_bwd_workspace_bytes(m, kC), b = wg_ws_bf16(m);
+  const int64_t a = sst_encoder_tail_bwd_bf16_workspace_bytes(m), b = wg_ws_bf16(m);
   if (a < 0 || b < 0) return SST_ERR_UNSUPPORTED;
-  return 2 * sst_align_up(a, 256) + sst_align_up(b, 256) + 256;    // the partials of BOTH LayerNorms live until the reduction
+  return sst_align_up(a, 256) + sst_align_up(b, 256) + 256;    // the tail's LayerNorm partials (both norms) live until the reduction
 }
 
 int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* a, void* stream) {
@@ -195,54 +195,51 @@ int sst_encoder_layer_fwd_bf16(const sst_encoder_layer_fwd_bf16_args* a, void* s
     rc = sst_sra_attn_fwd_ord_bf16(qk, qk + kC, a->v, 2 * kC, 2 * kC, kC, a->tok, a->winoff, a->order, a->n_windows, a->n_heads,
                                    a->scale, a->max_tokens, a->o, kC, a->lse, stream);
   if (rc) return rc;
-  // out-projection + residual + LayerNorm; linear1 + activation; linear2 + residual + LayerNorm (+ the next layer's x + pos)
-  rc = sst_tall_linear_ln_bf16(a->o, kC, a->wout, a->b_out, m, kC, a->x, kC, a->n1w, a->n1b, a->eps, a->y1, a->s1, a->st1, nullptr,
-                               nullptr, nullptr, stream);
-  if (rc) return rc;
-  rc = sst_tall_linear_bf16(a->y1, kC, a->w1, a->b1, m, kC, kFF, a->act == 1 ? kEpiGelu : kEpiRelu, nullptr, a->pre, kFF, a->h, kFF,
-                            stream);
-  if (rc) return rc;
-  return sst_tall_linear_ln_bf16(a->h, kFF, a->w2, a->b2, m, kFF, a->y1, kC, a->n2w, a->n2b, a->eps, a->y2, a->s2, a->st2,
-                                 a->pos_table, a->pos_idx, a->pos_table ? a->y2p : nullptr, stream);
+  // everything behind the attention core as ONE kernel (csrc/layer_tail_bf16.hip; sst_basic_block_v2.py:113-118)
+  if (!a->wpack) return SST_ERR_ARG;
+  sst_encoder_tail_fwd_bf16_args t;
+  t.m = m, t.act = a->act, t.reserved = 0, t.eps = a->eps, t.reserved_f = 0.f;
+  t.o = a->o, t.x = a->x, t.packed = a->wpack;
+  t.b_out = a->b_out, t.b1 = a->b1, t.b2 = a->b2, t.n1w = a->n1w, t.n1b = a->n1b, t.n2w = a->n2w, t.n2b = a->n2b;
+  t.pos_table = a->pos_table, t.pos_idx = a->pos_idx;
+  t.s1 = a->s1, t.st1 = a->st1, t.y1 = a->y1, t.pre = a->pre, t.h = a->h, t.s2 = a->s2, t.st2 = a->st2, t.y2 = a->y2;
+  t.y2p = a->pos_table ? a->y2p : nullptr;
+  return sst_encoder_tail_fwd_bf16(&t, stream);
 }
 
 int sst_encoder_layer_bwd_bf16(const sst_encoder_layer_bwd_bf16_args* a, void* stream) {
   if (!a || a->m < 0 || a->n_heads * 16 != kC || (a->act != 1 && a->act != 2)) return SST_ERR_ARG;
   if (a->m == 0) return SST_OK;
-  if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->dy1 || !a->ds1 || !a->d_o || !a->dqkv || !a->dxp || !a->dx ||
-      !a->s1 || !a->s2)
+  if (!a->dy2 || !a->workspace || !a->ds2 || !a->dpre || !a->ds1 || !a->d_o || !a->dqkv || !a->dxp || !a->dx ||
+      !a->s1 || !a->s2 || !a->wpack)
     return SST_ERR_ARG;
+  if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
   const int64_t m = a->m;
   char* ws = (char*)a->workspace;
-  void* ws_ln = ws;
-  ws += sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
-  void* ws_ln1 = ws;
-  ws += sst_align_up(sst_add_layernorm_bwd_workspace_bytes(m, kC), 256);
+  void* ws_tail = ws;
+  ws += sst_align_up(sst_encoder_tail_bwd_bf16_workspace_bytes(m), 256);
   void* ws_wg = ws;
-  if (!a->dn2w || !a->dn2b || !a->dn1w || !a->dn1b) return SST_ERR_ARG;
-  // d(gamma) | d(beta) of both LayerNorms: the block partials wait in the workspace, the reduction launch of the
-  // parameter-gradient group sums their columns (two finishing launches less per layer)
-  sst_colsum_rider riders[2];
   const unsigned short* qk = (const unsigned short*)a->qk;
   unsigned short* dqkv = (unsigned short*)a->dqkv;
   int rc;
-  rc = sst_internal_add_layernorm_bwd_bf16_partials(a->dy2, a->dy2p, a->s2, a->st2, a->n2w, m, kC, a->ds2, ws_ln, &riders[0].nb,
-                                                    stream);
+  // norm2' -> linear2' * act' -> linear1' + residual -> norm1' -> out-projection' in one kernel; d(gamma) | d(beta) of both
+  // LayerNorms stay as per-workgroup partials for the reduction launch of the parameter-gradient group
+  sst_encoder_tail_bwd_bf16_args t;
+  t.m = m, t.act = a->act, t.reserved = 0;
+  t.dy2 = a->dy2, t.dy2p = a->dy2p, t.s2 = a->s2, t.st2 = a->st2, t.pre = a->pre, t.s1 = a->s1, t.st1 = a->st1;
+  t.packed = a->wpack, t.n1w = a->n1w, t.n2w = a->n2w;
+  t.ds2 = a->ds2, t.dpre = a->dpre, t.ds1 = a->ds1, t.d_o = a->d_o;
+  t.dn2w = a->dn2w, t.dn2b = a->dn2b, t.dn1w = a->dn1w, t.dn1b = a->dn1b;
+  t.workspace = ws_tail;
+  float *part2 = nullptr, *part1 = nullptr;
+  int rows = 0;
+  rc = sst_internal_encoder_tail_bwd_bf16(&t, &part2, &part1, &rows, stream);
   if (rc) return rc;
-  riders[0].partials = (const float*)ws_ln, riders[0].width = 2 * kC, riders[0].split = kC;
+  sst_colsum_rider riders[2];
+  riders[0].partials = part2, riders[0].nb = rows, riders[0].width = 2 * kC, riders[0].split = kC;
   riders[0].out0 = a->dn2w, riders[0].out1 = a->dn2b;
-  rc = sst_tall_linear_bf16(a->ds2, kC, a->w2_t, nullptr, m, kC, kFF, a->act == 1 ? kEpiMulGeluGrad : kEpiMulReluGrad, a->pre,
-                            nullptr, kFF, a->dpre, kFF, stream);
-  if (rc) return rc;
-  rc = sst_tall_linear_bf16(a->dpre, kFF, a->w1_t, nullptr, m, kFF, kC, kEpiAdd, a->ds2, nullptr, kC, a->dy1, kC, stream);
-  if (rc) return rc;
-  rc = sst_internal_add_layernorm_bwd_bf16_partials(a->dy1, nullptr, a->s1, a->st1, a->n1w, m, kC, a->ds1, ws_ln1, &riders[1].nb,
-                                                    stream);
-  if (rc) return rc;
-  riders[1].partials = (const float*)ws_ln1, riders[1].width = 2 * kC, riders[1].split = kC;
+  riders[1].partials = part1, riders[1].nb = rows, riders[1].width = 2 * kC, riders[1].split = kC;
   riders[1].out0 = a->dn1w, riders[1].out1 = a->dn1b;
-  rc = sst_tall_linear_bf16(a->ds1, kC, a->wout_t, nullptr, m, kC, kC, kEpiBias, nullptr, nullptr, 0, a->d_o, kC, stream);
-  if (rc) return rc;
   if (a->head_scale != nullptr)
     rc = sst_sra_attn_cos_bwd_bf16(qk, qk + kC, a->v, a->o, a->d_o, a->lse, 2 * kC, 2 * kC, kC, kC, kC, a->tok, a->winoff,
                                    a->order, a->n_windows, a->n_heads, a->head_scale, a->max_tokens, dqkv, dqkv + kC,

@@ -22,7 +22,55 @@ def timed(fn, iters=30, warm=5):
     return a.elapsed_time(b) / iters * 1e3
 
 
+def main_bf16(m):
+    from sst_amd import bf16 as B
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(0)
+
+    def r(*s, sc=1.0):
+        return (torch.randn(*s, generator=g) * sc).to(dev)
+    o, x = r(m, 128).bfloat16(), r(m, 128).bfloat16()
+    w_out, b_out, w1, b1, w2, b2 = r(128, 128, sc=.09), r(128, sc=.1), r(256, 128, sc=.09), r(256, sc=.1), r(128, 256, sc=.06), r(128, sc=.1)
+    n1w, n1b, n2w, n2b = 1 + r(128, sc=.2), r(128, sc=.1), 1 + r(128, sc=.2), r(128, sc=.1)
+    pos = (r(144, 128), torch.randint(0, 144, (m,), generator=g, dtype=torch.int32).to(dev))
+    eps, act = 1e-5, 'gelu'
+    keep = {}
+    packed = B.tail_pack(w_out, w1, w2)
+    t_pack = timed(lambda: B.tail_pack(w_out, w1, w2, out=packed))
+    wo, w1s, w2s = B.shadow(w_out), B.shadow(w1), B.shadow(w2)
+    w2t, w1t, wot = (B.shadow(w, transposed=True) for w in (w2, w1, w_out))
+
+    def fused_fwd():
+        keep['out'] = B.tail_fwd(o, x, packed, b_out, b1, b2, n1w, n1b, n2w, n2b, eps, act, pos=pos, out=keep.get('out'))
+
+    def unfused_fwd():
+        y1, s1, st1, _ = B.linear_add_ln(o, wo, b_out, x, n1w, n1b, eps)
+        h, pre = B.tall_linear(y1, w1s, b1, B.EPI_GELU, want_pre=True)
+        keep['u'] = B.linear_add_ln(h, w2s, b2, y1, n2w, n2b, eps, pos=pos)
+    t_f, t_u = timed(fused_fwd), timed(unfused_fwd)
+    out = keep['out']
+    dy2 = r(m, 128).bfloat16()
+
+    def fused_bwd():
+        keep['b'] = B.tail_bwd(dy2, None, out['s2'], out['st2'], out['pre'], out['s1'], out['st1'], packed, n1w, n2w, act)
+
+    def unfused_bwd():
+        ds2, _, _ = B.add_ln_bwd(dy2, None, out['s2'], out['st2'], n2w)
+        dpre = B.tall_linear(ds2, w2t, None, B.EPI_MUL_GELU_GRAD, aux_in=out['pre'])
+        dy1 = B.tall_linear(dpre, w1t, None, B.EPI_ADD, aux_in=ds2)
+        ds1, _, _ = B.add_ln_bwd(dy1, None, out['s1'], out['st1'], n1w)
+        keep['ub'] = B.tall_linear(ds1, wot)
+    tb_f, tb_u = timed(fused_bwd), timed(unfused_bwd)
+    unit = m * 256 / 1e9
+    print(json.dumps({'mode': 'bf16', 'm': m, 'pack_us': round(t_pack, 1),
+                      'fwd_us': {'one_kernel': round(t_f, 1), 'launch_per_product': round(t_u, 1)},
+                      'bwd_us': {'one_kernel': round(tb_f, 1), 'launch_per_product': round(tb_u, 1)},
+                      'fwd_algorithmic_GBps': round(11 * unit / (t_f * 1e-6), 0), 'bwd_algorithmic_GBps': round(10 * unit / (tb_f * 1e-6), 0)}))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == 'bf16':
+        return main_bf16(int(sys.argv[1]))
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 90107
     dev = 'cuda:0'
     g = torch.Generator().manual_seed(0)
