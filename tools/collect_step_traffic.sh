@@ -43,5 +43,10 @@ with open(out + '/step_traffic.txt', 'w') as fh:
     for r in rows[:60]:
         fh.write('%-82s %8d %14.2f %14.2f %14.1f\n' % (r['kernel'], r['launches'], r['read_MB_per_launch'], r['write_MB_per_launch'],
                                                       r['total_MB_all_launches']))
-print(open(out + '/step_traffic.txt').read()[:6000])
+total = sum(r['total_MB_all_launches'] for r in rows)
+nbwd = sum(r['launches'] for r in rows if r['kernel'].startswith('sra_bwd'))
+with open(out + '/step_traffic.txt', 'a') as fh:
+    fh.write('TOTAL %.1f MB over all launches; %d attention-backward launches = %.1f training steps of 12 encoder layers -> %.2f GB per step\n'
+             % (total, nbwd, nbwd / 12.0, total / max(nbwd / 12.0, 1e-9) / 1e3))
+print(open(out + '/step_traffic.txt').read()[:6500])
 PY
