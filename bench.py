@@ -1130,52 +1130,92 @@ def _main(args, line_out):
     lidar_leg = None
     if not args.fwd_only and not args.no_lidar_leg:
         note('leg: LiDAR-like cloud')
-        fresh_allocator()
-        lframes = [make_lidar_cloud(2000 * rank + i, dev) for i in range(args.frames_per_gpu)]
 
-        def lstep():
-            for p in params:
-                p.grad = None
-            o = model(lframes)
-            gg = seed_grad.get(o.shape)
-            if gg is None:
-                gg = seed_grad[o.shape] = torch.randn(o.shape, device=o.device, dtype=o.dtype)
-            o.backward(gg)
-            if reducer is not None:
-                reducer.finish()
-            return o
+        def lidar_run(nframes):
+            """W warm-up + K timed steps on `nframes` LiDAR-like frames per GPU; the attention kernels' own launch times (events
+            bound to every 5th launch) against their algorithmic bytes, as for the headline"""
+            fresh_allocator()
+            lframes = [make_lidar_cloud(2000 * rank + i, dev) for i in range(nframes)]
 
-        for _ in range(3):
-            lo = lstep()
-        sync()
-        li_times = StepTimes()
-        li_times.mark()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            lstep()
+            def lstep():
+                for p in params:
+                    p.grad = None
+                o = model(lframes)
+                gg = seed_grad.get(o.shape)
+                if gg is None:
+                    gg = seed_grad[o.shape] = torch.randn(o.shape, device=o.device, dtype=o.dtype)
+                o.backward(gg)
+                if reducer is not None:
+                    reducer.finish()
+                return o
+
+            for _ in range(3):
+                lo = lstep()
+            lsink = []
+            K.EVENT_SINK = lsink
+            K.EVENT_STRIDE = 5
+            K.EVENT_KINDS = ('sra_fwd', 'sra_bwd')
+            sync()
+            li_times = StepTimes()
             li_times.mark()
-        sync()
-        el = time.perf_counter() - t3
-        li_times.close()
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        sizes = []
-        for sft in range(2):
-            pl = model.last_plans[sft]
-            if pl is not None:
-                off = pl.winoff[:pl.n_windows + 1].cpu()
-                d = (off[1:] - off[:-1]).float()
-                sizes.append({'windows': int(pl.n_windows), 'tokens_min': int(d.min()), 'tokens_mean': round(float(d.mean()), 1),
-                              'tokens_max': int(d.max())})
-        lidar_leg = {'value': round(world * args.frames_per_gpu * args.steps / el, 3), 'unit': 'frames/s',
-                     'ms_per_step': round(el / args.steps * 1e3, 3), 'steps': args.steps, 'step_ms': li_times.stats(),
-                     'points_per_frame': int(lframes[0].size(0)), 'voxels_kept_per_gpu': int(lo.size(0)),
-                     'window_sizes': sizes,
-                     'what': 'same step (fwd + bwd) on a LiDAR-like frame: 64 beams x 2650 azimuth steps over a ground plane, '
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                lstep()
+                li_times.mark()
+            sync()
+            el = time.perf_counter() - t3
+            li_times.close()
+            K.EVENT_SINK = None
+            if world > 1:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            sizes = []
+            for sft in range(2):
+                pl = model.last_plans[sft]
+                if pl is not None:
+                    off = pl.winoff[:pl.n_windows + 1].cpu()
+                    d = (off[1:] - off[:-1]).float()
+                    sizes.append({'windows': int(pl.n_windows), 'tokens_min': int(d.min()), 'tokens_mean': round(float(d.mean()), 1),
+                                  'tokens_max': int(d.max())})
+
+            def lstats(kind, bytes_per_token):
+                ev = [(e0.elapsed_time(e1), n) for k_, e0, e1, n in lsink if k_ == kind]
+                ev = [(t_, n) for t_, n in ev if t_ > 0]
+                if not ev:
+                    return None
+                ms_ = sum(t_ for t_, _ in ev) / len(ev)
+                tok_ = sum(n for _, n in ev) / len(ev)
+                ach = bytes_per_token * tok_ / (ms_ * 1e-3) / 1e9
+                return {'achieved': round(ach, 1), 'frac': round(ach / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(ms_, 4),
+                        'algorithmic_bytes_per_launch': int(bytes_per_token * tok_), 'launches_timed': len(ev)}
+
+            return {'value': round(world * nframes * args.steps / el, 3), 'unit': 'frames/s', 'frames_per_gpu': nframes,
+                    'ms_per_step': round(el / args.steps * 1e3, 3), 'ms_per_frame': round(el / args.steps / nframes * 1e3, 3),
+                    'steps': args.steps, 'step_ms': li_times.stats(),
+                    'points_per_frame': int(lframes[0].size(0)), 'voxels_kept_per_gpu': int(lo.size(0)),
+                    'window_sizes': sizes,
+                    'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'kernel': 'sra_fwd_wave_k / sra_bwd_fused_k, events bound to every 5th launch of the timed steps',
+                                 'sra_fwd': lstats('sra_fwd', SRA_BYTES_PER_TOKEN), 'sra_bwd': lstats('sra_bwd', SRA_BWD_BYTES_PER_TOKEN)}}
+
+        lidar_leg = lidar_run(args.frames_per_gpu)
+        lidar_leg['what'] = ('same step (fwd + bwd) on a LiDAR-like frame: 64 beams x 2650 azimuth steps over a ground plane, '
                              '5 % box hits, 5 % of the points outside the range (clamped), 2 % exact duplicates '
-                             '(SURVEY.md section 8(d) L-cloud + pathological input); not part of `value`'}
+                             '(SURVEY.md section 8(d) L-cloud + pathological input); not part of `value`.  A sweep keeps 18 k voxels in '
+                             '~800 windows of 23 tokens: one frame does not fill the chip (a launch of the attention core is bound by '
+                             'the wave of its largest window, not by HBM) - the reference trains at 2 frames per GPU '
+                             '(BASELINE.json configs[2]); `more_frames_per_gpu` = the same leg at 2 and 4')
+        if args.frames_per_gpu == 1 and not os.environ.get('SST_BENCH_NO_LIDAR_BATCHES'):
+            lidar_leg['more_frames_per_gpu'] = {}
+            for nf in (2, 4):
+                try:
+                    r = lidar_run(nf)
+                    for k_ in ('unit', 'steps', 'points_per_frame'):
+                        r.pop(k_, None)
+                    lidar_leg['more_frames_per_gpu'][str(nf)] = r
+                except Exception as e:     # a side leg must never take the line down
+                    lidar_leg['more_frames_per_gpu'][str(nf)] = {'error': repr(e)[:200]}
 
     # Beside the exact-fp32 headline: the same step with the projections / FFN products of the encoder layers evaluated as three
     # bf16 products of split fp32 operands with fp32 accumulation (csrc/dense_f32x3.hip; everything stays fp32 in HBM, the

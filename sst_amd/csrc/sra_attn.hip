@@ -327,6 +327,7 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 }
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kSplitTiles = 4;    // windows of this many 16-token tiles and more are dealt out over several workgroups in small launches
 constexpr float kLn2 = 0.6931471805599453f;
 
 // COS: scaled cosine attention (cosine_msa.py:123-170) - q and k rows are normalised per head as they are loaded (one
@@ -336,7 +337,10 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
                                                   const float* __restrict__ V, uint32_t ldq, uint32_t ldk,
                                                   uint32_t ldv, const int32_t* __restrict__ tok, int beg, int t, int nt,
                                                   int hg, int H, float scale, float* __restrict__ O, uint32_t ldo,
-                                                  float* __restrict__ LSE, const float* __restrict__ hscale) {
+                                                  float* __restrict__ LSE, const float* __restrict__ hscale,
+                                                  int part = 0, int parts = 1) {
+  // part / parts: the query tiles part, part + parts, ... of the window (a large window of a SMALL launch is dealt out over
+  // several workgroups: its one wave per head is otherwise the critical path of the whole launch - see sra_fwd_wave_k)
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int head = hg * kWH + (threadIdx.x >> 6);
   if (COS) scale = hscale[head];
@@ -450,10 +454,11 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
   // (A two-deep software pipeline over query tiles — QK^T of tile i+1 issued ahead of the softmax of tile i —
   // was measured slower: +34 VGPRs drop the occupancy from 4 to 3 waves/SIMD, 61.8 vs 56.2 us.)
   f32x4 st[NT];
-  uint32_t qrow = q_row(0);
+  if (part >= nt) return;
+  uint32_t qrow = q_row(part);
   float4 qf = ldg4(Q, qrow * ldq + hoff + 4 * g);
-  for (int i = 0; i < nt; ++i) {
-    const uint32_t qrow_next = q_row(i + 1 < nt ? i + 1 : i);
+  for (int i = part; i < nt; i += parts) {
+    const uint32_t qrow_next = q_row(i + parts < nt ? i + parts : i);
     const float4 qf_next = ldg4(Q, qrow_next * ldq + hoff + 4 * g);  // prefetch
     qk_tiles(qf, st);
     finish_tile(st, i, qrow);
@@ -471,25 +476,46 @@ __global__ __launch_bounds__(64 * kWH) void sra_fwd_wave_k(const float* __restri
                                                       const int32_t* __restrict__ winoff, int n_groups, int H,
                                                       float scale, float* __restrict__ O, int64_t ldo,
                                                       float* __restrict__ LSE, const int32_t* __restrict__ order,
-                                                      const float* __restrict__ hscale) {
-  const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
-  const int wpos = bid / n_groups;
-  const int hg = bid - wpos * n_groups;
+                                                      const float* __restrict__ hscale, int n_win, int qs) {
+  // Small launches (qs > 1): the grid carries (qs - 1) * n_groups further workgroups per
+  // window IN FRONT of the regular ones; those of a window of kSplitTiles tiles and more take the query tiles
+  // part, part + qs, ... of it, the others leave at once.  Why: a 100-token window is 7 dependent query tiles on ONE wave per
+  // head, ~11 us - on a LiDAR sweep (18 k voxels, 23 tokens per window on average, a few at the cap) the whole launch waited
+  // for those waves (19 us for 38 MB; tools/sra_sizes.py).
+  const int n_main = n_win * n_groups;
+  const int n_extra = (int)gridDim.x - n_main;
+  int part = 0, wpos, hg;
+  if ((int)blockIdx.x < n_extra) {
+    const int per = n_groups * (qs - 1);
+    const int from_end = (int)blockIdx.x / per, r = (int)blockIdx.x - from_end * per;
+    part = 1 + r / n_groups;
+    hg = r % n_groups;
+    wpos = n_win - 1 - from_end;      // with a launch order (ascending) the largest windows sit at the end: first to go
+  } else {
+    const int bid = SST_SRA_BLOCK((int)blockIdx.x - n_extra, n_main);
+    wpos = bid / n_groups;
+    hg = bid - wpos * n_groups;
+  }
   const int w = order != nullptr ? order[wpos] : wpos;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;  // > NTMAX: the generic kernel owns this window
+  int parts = 1;
+  if (qs > 1) {
+    if (nt >= kSplitTiles) parts = qs;
+    else if (part > 0) return;
+  }
   const uint32_t q_ld = (uint32_t)ldq, k_ld = (uint32_t)ldk, v_ld = (uint32_t)ldv, o_ld = (uint32_t)ldo;
   if (nt <= 2)
     sra_fwd_wave_body<2, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale);
   else if (nt <= 4)
-    sra_fwd_wave_body<4, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale);
+    sra_fwd_wave_body<4, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale, part, parts);
   else if (nt <= 7 || NTMAX <= 7)
     sra_fwd_wave_body<(NTMAX < 7 ? NTMAX : 7), COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE,
-                                                    hscale);
+                                                    hscale, part, parts);
   else
-    sra_fwd_wave_body<NTMAX, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale);
+    sra_fwd_wave_body<NTMAX, COS>(Q, K, V, q_ld, k_ld, v_ld, tok, beg, t, nt, hg, H, scale, O, o_ld, LSE, hscale, part, parts);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1200,6 +1226,21 @@ int launch_fwd_variant(const float* Q, const float* K, const float* V, int64_t l
   return SST_OK;
 }
 
+// parts a large window is dealt out over, by the size of the launch (workgroups before the split).  A launch that fills the chip
+// several times over hides a long wave behind the others; below that the long waves ARE the launch.
+// SST_SRA_SPLIT=<parts> / SST_SRA_SPLIT_MAX_WG=<workgroups> override (A/B runs).
+int sra_split_parts(int64_t n_workgroups) {
+  static int parts_env = -1, max_wg = 0;
+  if (parts_env < 0) {
+    const char* e = getenv("SST_SRA_SPLIT");
+    const char* m = getenv("SST_SRA_SPLIT_MAX_WG");
+    max_wg = m ? atoi(m) : 2048;     // measured (tools/sra_sizes.py, kernel-exact events): 10 x 100 tokens 12.8 -> 8.5 us, LiDAR-like
+    parts_env = e ? atoi(e) : 2;     // frame (1 620 workgroups) 18.0 -> 17.4 us with 2 parts; 4 parts and larger launches lose to the empty workgroups
+  }
+  if (parts_env <= 1 || n_workgroups > max_wg) return 1;
+  return parts_env;
+}
+
 template <int NTMAX>
 int launch_fwd_wave(const float* Q, const float* K, const float* V, int64_t ldq, int64_t ldk, int64_t ldv,
                     const int32_t* tok, const int32_t* winoff, int64_t n_windows, int H, float scale, float* O,
@@ -1207,17 +1248,19 @@ int launch_fwd_wave(const float* Q, const float* K, const float* V, int64_t ldq,
   const int n_groups = H / kWH;
   const float* hs = g_head_scale;
   auto kern = hs != nullptr ? sra_fwd_wave_k<NTMAX, true> : sra_fwd_wave_k<NTMAX, false>;
+  const int qs = NTMAX >= kSplitTiles ? sra_split_parts(n_windows * n_groups) : 1;
+  const dim3 grid((unsigned)(n_windows * n_groups * qs));
   if (g_prof_start != nullptr && g_prof_stop != nullptr) {
     // one-shot: kernel-exact start / stop timestamps on the launch stream (no barrier packets, no cache flush
     // between the marks and the kernel, unlike a pair of hipEventRecord calls around the launch)
-    hipExtLaunchKernelGGL(kern, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st,
+    hipExtLaunchKernelGGL(kern, grid, dim3(64 * kWH), 0, st,
                           g_prof_start, g_prof_stop, 0, Q, K, V, ldq, ldk, ldv, tok, winoff, n_groups, H, scale, O, ldo,
-                          LSE, g_win_order, hs);
+                          LSE, g_win_order, hs, (int)n_windows, qs);
     g_prof_start = g_prof_stop = nullptr;
     return SST_OK;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n_windows * n_groups)), dim3(64 * kWH), 0, st, Q, K, V, ldq, ldk,
-                     ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE, g_win_order, hs);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * kWH), 0, st, Q, K, V, ldq, ldk,
+                     ldv, tok, winoff, n_groups, H, scale, O, ldo, LSE, g_win_order, hs, (int)n_windows, qs);
   return SST_OK;
 }
 
