@@ -174,7 +174,7 @@ class StepTimes(object):
     line carries median / min / max of every leg: a mean alone hides an outlier step (bf16 leg)."""
 
     def __init__(self):
-        self.events, self.host = [], []
+        self.events, self.host, self.allocs = [], [], []
         self.t_begin = time.perf_counter()
         self.allocs0 = torch.cuda.memory_stats().get('num_device_alloc', 0) if torch.cuda.is_available() else 0
 
@@ -195,6 +195,7 @@ class StepTimes(object):
         e.record()
         self.events.append(e)
         self.host.append(time.perf_counter())
+        self.allocs.append(torch.cuda.memory_stats().get('num_device_alloc', 0))
 
     def stats(self):
         self.close()
@@ -209,7 +210,9 @@ class StepTimes(object):
         return {'median': round(med, 3), 'min': round(d[0], 3), 'max': round(d[-1], 3), 'steps': n,
                 'slowest_step': {'index': worst, 'device_ms': round(raw[worst], 3), 'host_ms_of_that_step': round(host[worst], 3),
                                  'host_ms_median': round(sorted(host)[len(host) // 2], 3)},
+                'per_step_ms': [round(v, 2) for v in raw],
                 'device_allocations_inside_the_loop': int(self.allocs1 - self.allocs0),
+                'steps_with_a_device_allocation': [i for i, (a, b) in enumerate(zip(self.allocs[:-1], self.allocs[1:])) if b > a],
                 'python_gc_inside_the_loop': self.gc(),
                 'how': 'device-side time between the ends of consecutive steps (one event per step, read after the loop)'}
 
@@ -693,11 +696,16 @@ def workload_legs(args):
     line the driver records, not only in builder-run files."""
     import subprocess
     legs = {}
-    plan = (('sst_bs2', 10, 3, 150), ('sst_center', 10, 3, 150), ('fsd', 10, 3, 240), ('fsdv2', 10, 3, 300))
-    for name, steps, warm, limit in plan:
+    # fsd_bs2: the FSD chain at 2 frames per GPU, the batch its config trains at (configs/fsd/fsd_waymoD1_1x.py: samples_per_gpu=2):
+    # the segmented reduce of the SIR layers, launch-bound at one frame (18 k foreground points), is quoted there too; no CPU pass
+    plan = (('sst_bs2', 10, 3, 150, ()), ('sst_center', 10, 3, 150, ()), ('fsd', 10, 3, 240, ()),
+            ('fsd_bs2', 10, 3, 240, ('--workload', 'fsd', '--frames-per-gpu', '2', '--no-cpu-baseline')), ('fsdv2', 10, 3, 300, ()))
+    for name, steps, warm, limit, extra in plan:
         note(f'leg: workload {name} (own process)')
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--compact', '--steps', str(steps), '--warmup',
                str(warm)]
+        if extra:
+            cmd = [sys.executable, os.path.abspath(__file__), *extra, '--compact', '--steps', str(steps), '--warmup', str(warm)]
         t0 = time.perf_counter()
         try:
             sub = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, cwd=ROOT)
@@ -887,16 +895,21 @@ def _main(args, line_out):
         return out
 
     note(f'warm-up: {args.warmup} steps')
-    for _ in range(args.warmup):
-        out = step()
-    note('timed loop')
     # What a training script does once its model and data pipeline are built: collect, then move everything alive to the permanent
     # generation.  A full collection of a process that has imported torch walks ~10^6 objects (60-70 ms, measured: one step of
     # 71 ms among twenty of 6.5 ms in the reduced-precision leg; none with the collector off); frozen objects are not walked, the
-    # collector stays ON for what the steps allocate.
+    # collector stays ON for what the steps allocate.  It happens INSIDE the warm-up (before its last two steps), not between the
+    # warm-up and the timed loop: the device idles for those 60-70 ms and drops its clocks, and the first timed step then ran
+    # 2.5 ms longer than the other nineteen (step_ms.slowest_step.index = 0 in every round-5 / early round-6 line).
     import gc
+    tail_steps = min(2, max(args.warmup - 1, 0))
+    for _ in range(args.warmup - tail_steps):
+        out = step()
     gc.collect()
     gc.freeze()
+    for _ in range(tail_steps):
+        out = step()
+    note('timed loop')
     n_voxels = int(model.last_voxel_coors.size(0))
 
     def sync():
@@ -913,6 +926,8 @@ def _main(args, line_out):
     K.EVENT_KINDS = ('sra_fwd',) if (args.fwd_only or args.no_time_sra_bwd) else ('sra_fwd', 'sra_bwd')
     if args.precision == 'bf16':
         K.EVENT_KINDS = ()
+    if os.environ.get('SST_BENCH_ALLOC_TRACE_TIMED'):     # diagnostic: who calls hipMalloc inside the timed loop
+        torch.cuda.memory._record_memory_history(enabled='all', context=None, stacks='python', max_entries=200000)
     sync()
     main_times = StepTimes()
     main_times.mark()
@@ -923,6 +938,12 @@ def _main(args, line_out):
     sync()
     elapsed = time.perf_counter() - t0
     main_times.close()
+    if os.environ.get('SST_BENCH_ALLOC_TRACE_TIMED'):
+        snap = torch.cuda.memory._snapshot()
+        for e in [e for tr in snap.get('device_traces', []) for e in tr if e.get('action') in ('segment_alloc', 'segment_free')][:20]:
+            fr = [f"{f['filename'].split('/')[-1]}:{f['line']}:{f['name']}" for f in (e.get('frames') or [])[:12]]
+            print('timed-loop', e['action'], e['size'], 'B', fr, file=sys.stderr)
+        torch.cuda.memory._record_memory_history(enabled=None)
     K.EVENT_SINK = None
     per_rank = None
     if world > 1:

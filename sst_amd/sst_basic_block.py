@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
+from . import _lib
 from . import kernels as K
 from .sra_composed import sra_attention_composed
 from .dense import (encoder_tail_ok, encoder_tail_pack, encoder_tail_fwd, encoder_tail_bwd, inproj_pos_ok, inproj_pos,
@@ -328,7 +329,53 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
     d_scale = K.head_scale_grad(cos_r, head_scale) if head_scale is not None else None
     return (ds1, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3], None, None,
-            None, d_scale, None, None)
+            None, d_scale, None, None, None)
+
+
+def _bn_rows_fwd(bn, s):
+    """y = bn(s) for a BatchNorm1d-family module on the rows of s [M, C] (layer_cfg use_bn=True: norm1 / norm2 of an encoder layer
+    are naiveSyncBN1d modules, sst_basic_block_v2.py:92-99): the statistics pass with the module's bookkeeping (running statistics,
+    the cross-rank average of naiveSyncBN: sst_amd/norm.py bn_prepare) and the apply pass of csrc/bn.hip.
+    -> (y, prep [4, C] = mean, invstd, scale, shift, (batch_stats, count, sync))"""
+    from .norm import bn_prepare
+    prep, batch_stats, count, sync = bn_prepare(bn, s)
+    m, c = s.shape
+    y = torch.empty((m, c), dtype=torch.float32, device=s.device)
+    _lib.check(_lib.load().sst_bn_act_res_fwd_f32(_lib.ptr(s), m, c, s.stride(0), None, 0, _lib.ptr(prep[2]), _lib.ptr(prep[3]), 0,
+                                                  _lib.ptr(y), y.stride(0), _lib.stream_ptr()), 'sst_bn_act_res_fwd_f32')
+    return y, prep, (bool(batch_stats), float(count), bool(sync))
+
+
+def _bn_rows_bwd(dy, s, prep, cfg):
+    """gradient of _bn_rows_fwd: -> (ds, d weight, d bias).  Batch statistics: ds = scale * (g - (G1 + xhat G2) / count) with
+    G1 = sum g, G2 = sum g xhat over every rank when the statistics were averaged across ranks (ops/norm.py:20-24, 53-58: one
+    all-reduce of 2 C floats between the two passes); the parameter gradients stay the local sums."""
+    from torch import distributed as dist
+    batch_stats, count, sync = cfg
+    m, c = s.shape
+    dy = dy.contiguous()
+    lib = _lib.load()
+    sums = torch.empty((2, c), dtype=torch.float32, device=s.device)
+    ws = _lib.workspace(lib.sst_bn_workspace_bytes(m, c), s.device)
+    _lib.check(lib.sst_bn_act_res_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(s), None, m, c, dy.stride(0), s.stride(0), 0, _lib.ptr(prep[0]),
+                                                 _lib.ptr(prep[1]), _lib.ptr(prep[2]), _lib.ptr(prep[3]), 0, _lib.ptr(sums[0]),
+                                                 _lib.ptr(sums[1]), _lib.ptr(ws), _lib.stream_ptr()), 'sst_bn_act_res_bwd_reduce_f32')
+    total = sums
+    if sync and batch_stats:
+        total = sums.clone()
+        dist.all_reduce(total, async_op=False)
+    ds = torch.empty((m, c), dtype=torch.float32, device=s.device)
+    _lib.check(lib.sst_bn_act_res_bwd_apply_f32(_lib.ptr(dy), _lib.ptr(s), None, m, c, dy.stride(0), s.stride(0), 0, _lib.ptr(prep[0]),
+                                                _lib.ptr(prep[1]), _lib.ptr(prep[2]), _lib.ptr(prep[3]), _lib.ptr(total[0]),
+                                                _lib.ptr(total[1]), (1.0 / count) if batch_stats else 0.0, 0, None, 0, _lib.ptr(ds),
+                                                ds.stride(0), _lib.stream_ptr()), 'sst_bn_act_res_bwd_apply_f32')
+    return ds, sums[1], sums[0]
+
+
+def _bn_layer_ok(norm, c):
+    """a batch-norm module the chain's row kernels take (csrc/bn.hip): affine BatchNorm1d family over c channels"""
+    return (isinstance(norm, nn.BatchNorm1d) and norm.weight is not None and norm.bias is not None and norm.num_features == c
+            and c % 4 == 0 and c <= 1024)
 
 
 class FusedEncoderLayerFn(torch.autograd.Function):
@@ -341,8 +388,11 @@ class FusedEncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, plan, nhead, impl, act, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps,
-                xp=None, pos_next=None, head_scale=None, xp_shares_x=False, pos_spec=None):
-        """pos_spec = (table fp32 [P, C], row index int32 [M]) (optional, instead of pos / xp): the positional embedding of every
+                xp=None, pos_next=None, head_scale=None, xp_shares_x=False, pos_spec=None, bn=None):
+        """bn = (norm1, norm2) modules (optional): batch-norm layers (layer_cfg use_bn=True, sst_basic_block_v2.py:92-99,
+        configs/fsd/fsd_waymoD1_1x_sst_encoder.py:70) - the same node with the two LayerNorm passes replaced by statistics + apply
+        passes over the sums the projections' epilogues leave (n1w .. n2b are then the modules' weight / bias).
+        pos_spec = (table fp32 [P, C], row index int32 [M]) (optional, instead of pos / xp): the positional embedding of every
         token is a row of a small table; in the exact-split mode x + table[index] is then formed ON LOAD by the in-projection and
         by the weight gradient of W_q | W_k and never exists as a tensor (round 6: 3 of a layer's 56 [M, 128] passes).
         xp (optional): x + positional embedding, already formed (the previous layer's second output) - ``pos`` is then
@@ -374,7 +424,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             xp = x + pos if pos is not None else x
         params = (w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
         ctx.exec = False
-        if c == 128 and ctx.fold_xp and _layer_exec_ok(x, xp, plan, nhead, act, params):
+        ctx.bn = bn is not None
+        if bn is None and c == 128 and ctx.fold_xp and _layer_exec_ok(x, xp, plan, nhead, act, params):
             # the launch sequence below as ONE library call (csrc/layer_exec.hip)
             need_bwd = any(ctx.needs_input_grad)
             scale = 1.0 / math.sqrt(16.0)
@@ -410,7 +461,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
         ctx.tail = False
         wpack = None
-        if (_LDS_LINEAR and c == 128 and act in ('gelu', 'relu') and o.is_contiguous()
+        if bn is not None:
+            y1, s1, st1, pre, h, s2, st2, y2, y2p, ctx.bn_cfg = FusedEncoderLayerFn._tail_batch_norm(
+                o, x, w_out, b_out, w1, b1, w2, b2, bn, act, pos_next)
+        elif (_LDS_LINEAR and c == 128 and act in ('gelu', 'relu') and o.is_contiguous()
                 and encoder_tail_ok(o, x, w_out, w1, w2) and all(t is not None for t in (b_out, b1, b2))):
             # everything behind the attention core as ONE kernel (csrc/layer_tail_x6.hip), as csrc/layer_exec.hip issues it
             wpack = encoder_tail_pack(w_out, w1, w2)
@@ -427,6 +481,30 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             ctx.plan, ctx.nhead, ctx.impl, ctx.act, ctx.scale = plan, nhead, impl, act, scale
         ctx.two = pos_next is not None
         return (y2, y2p) if ctx.two else y2
+
+    @staticmethod
+    def _tail_batch_norm(o, x, w_out, b_out, w1, b1, w2, b2, bn, act, pos_next):
+        """out-projection + residual -> bn1 -> linear1 + activation -> linear2 + residual -> bn2: the residual sums leave the
+        projections' epilogues, each batch norm is its statistics pass + its apply pass (training mode needs the whole batch
+        before a value can be normalised; naiveSyncBN's collective sits between the two).  st1 / st2 of the saved list = the
+        [4, C] statistic rows."""
+        if _LDS_LINEAR and lds_linear_ok(o, w_out) and x.is_contiguous():
+            s1 = lds_linear(o, w_out, b_out, EPI_ADD, aux_in=x)
+        else:
+            s1 = torch.addmm(b_out, o, w_out.t()).add_(x)
+        y1, prep1, cfg1 = _bn_rows_fwd(bn[0], s1)
+        if _LDS_LINEAR and lds_linear_ok(y1, w1) and act in ('gelu', 'relu'):
+            h, pre = lds_linear(y1, w1, b1, EPI_GELU if act == 'gelu' else EPI_RELU, want_pre=True)
+        else:
+            pre = torch.addmm(b1, y1, w1.t())
+            h = F.gelu(pre) if act == 'gelu' else F.relu(pre)
+        if _LDS_LINEAR and lds_linear_ok(h, w2):
+            s2 = lds_linear(h, w2, b2, EPI_ADD, aux_in=y1)
+        else:
+            s2 = torch.addmm(b2, h, w2.t()).add_(y1)
+        y2, prep2, cfg2 = _bn_rows_fwd(bn[1], s2)
+        y2p = y2 + pos_next[0].index_select(0, pos_next[1].long()) if pos_next is not None else None
+        return y1, s1, prep1, pre, h, s2, prep2, y2, y2p, (cfg1, cfg2)
 
     @staticmethod
     def _tail_by_products(o, x, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps, act, need_bwd, pos_next, c):
@@ -491,7 +569,12 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             ds2_for_w2 = ds2
             dn2w, dn2b, dn1w, dn1b = dn[0], dn[1], dn[2], dn[3]
         else:
-            ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
+            if ctx.bn:
+                if ctx.two and dy2p is not None:
+                    dy2 = dy2 + dy2p
+                ds2, dn2w, dn2b = _bn_rows_bwd(dy2, s2, st2, ctx.bn_cfg[1])
+            else:
+                ds2, dn2w, dn2b = add_ln_bwd(dy2, s2, st2, n2w, dy2=dy2p if ctx.two else None)   # = d(y1 residual) = d(f)
             ds2_for_w2 = ds2
             dpre = dgrad_gelu(ds2, w2, pre) if (ctx.act == 'gelu' and _FUSED_GELU) else None
             if _LDS_LINEAR and lds_linear_ok(ds2, w2, trans_w=True) and pre.is_contiguous():
@@ -507,7 +590,10 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             # residual + FFN branch: GEMM with beta = 1 into a buffer of its OWN - ds2 stays what dW2 needs, and all five parameter
             # gradients of the layer leave in one grouped launch at the end
             dy1 = _linear_dgrad(dpre, w1, out=torch.empty_like(ds2), add=ds2)
-            ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
+            if ctx.bn:
+                ds1, dn1w, dn1b = _bn_rows_bwd(dy1, s1, st1, ctx.bn_cfg[0])
+            else:
+                ds1, dn1w, dn1b = add_ln_bwd(dy1, s1, st1, n1w)               # = d(x residual) = d(attention output)
             do = _linear_dgrad(ds1, w_out)
         # dq | dk | dv in ONE [M, 3C] buffer: d(x) of the whole in-projection is then a single GEMM
         dqkv = torch.empty((x.size(0), 3 * c), dtype=torch.float32, device=x.device)
@@ -541,7 +627,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         else:
             dx = ds1.addmm_(dqkv, w_in)                               # residual + q,k,v branches (in place)
         return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
-                None, dxp, None, d_scale, None, None)
+                None, dxp, None, d_scale, None, None, None)
 
 
 class _StackHeadScales(torch.autograd.Function):
@@ -622,14 +708,14 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
                 x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
                 attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
                 enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
-                enc.norm1.eps, None, None, scales[li], False, pos_specs[li % 2])
+                enc.norm1.eps, None, None, scales[li], False, pos_specs[li % 2], enc.bn_modules())
             return out, None
         pos_next = pos_specs[(li + 1) % 2] if li + 1 < n_layers else None
         out = FusedEncoderLayerFn.apply(
             x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
             attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
             enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
-            enc.norm1.eps, xp, pos_next, scales[li], True)                    # xp = x + positional rows: a constant offset
+            enc.norm1.eps, xp, pos_next, scales[li], True, None, enc.bn_modules())   # xp = x + positional rows: a constant offset
         return out if pos_next is not None else (out, None)
 
     def block_fn(bi):
@@ -678,6 +764,11 @@ class EncoderLayer(nn.Module):
         self.post_norm = layer_cfg.get('post_norm', True)
         self.fp16_enabled = False
 
+    def bn_modules(self):
+        """(norm1, norm2) when they are batch-norm modules (layer_cfg use_bn=True), else None: the argument FusedEncoderLayerFn
+        takes for its batch-norm tail"""
+        return (self.norm1, self.norm2) if isinstance(self.norm1, nn.BatchNorm1d) else None
+
     def _ffn(self, x):
         h = self.activation(tall_linear(x, self.linear1.weight, self.linear1.bias))
         return tall_linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
@@ -688,7 +779,8 @@ class EncoderLayer(nn.Module):
                 and ind_dict.n_tokens == src.size(0)
                 and (pos_dict is None or torch.is_tensor(pos_dict)) and wa.head_dim == 16
                 and (not wa.cosine or K.cosine_kernels_ok(ind_dict, wa.nhead, wa.impl))
-                and isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm)
+                and ((isinstance(self.norm1, nn.LayerNorm) and isinstance(self.norm2, nn.LayerNorm))
+                     or (_bn_layer_ok(self.norm1, src.size(1)) and _bn_layer_ok(self.norm2, src.size(1))))
                 and self.act_name in ('gelu', 'relu') and src.dtype == torch.float32 and src.is_cuda
                 and src.size(1) % 32 == 0 and self.linear1.out_features % 32 == 0
                 and not (self.training and (wa.attn_dropout > 0 or self.dropout.p > 0 or self.dropout1.p > 0)))
@@ -700,7 +792,7 @@ class EncoderLayer(nn.Module):
                 src, pos_dict, ind_dict, self.win_attn.nhead, self.win_attn.impl, self.act_name, attn.in_proj_weight,
                 attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, self.linear1.weight, self.linear1.bias,
                 self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias, self.norm2.weight,
-                self.norm2.bias, self.norm1.eps, None, None, self.win_attn.head_scale())
+                self.norm2.bias, self.norm1.eps, None, None, self.win_attn.head_scale(), False, None, self.bn_modules())
         if self.post_norm:
             src2 = self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)  # [N, d_model]
             src = add_layer_norm(src, self.dropout1(src2), self.norm1)     # norm1(src + src2), one kernel
