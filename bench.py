@@ -1227,7 +1227,7 @@ def _main(args, line_out):
                              '~800 windows of 23 tokens: one frame does not fill the chip (a launch of the attention core is bound by '
                              'the wave of its largest window, not by HBM) - the reference trains at 2 frames per GPU '
                              '(BASELINE.json configs[2]); `more_frames_per_gpu` = the same leg at 2 and 4')
-        if args.frames_per_gpu == 1 and not os.environ.get('SST_BENCH_NO_LIDAR_BATCHES'):
+        if args.frames_per_gpu == 1 and world == 1 and not os.environ.get('SST_BENCH_NO_LIDAR_BATCHES'):
             lidar_leg['more_frames_per_gpu'] = {}
             for nf in (2, 4):
                 try:
