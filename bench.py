@@ -1158,14 +1158,18 @@ def _main(args, line_out):
             fresh_allocator()
             lframes = [make_lidar_cloud(2000 * rank + i, dev) for i in range(nframes)]
 
+            lahead = []     # the next step's index plan queued behind this step's backward pass, exactly as the main loop does it
+
             def lstep():
                 for p in params:
                     p.grad = None
-                o = model(lframes)
+                o = model(lframes, None if args.no_plan_prefetch else (lahead.pop() if lahead else model.prepare(lframes)))
                 gg = seed_grad.get(o.shape)
                 if gg is None:
                     gg = seed_grad[o.shape] = torch.randn(o.shape, device=o.device, dtype=o.dtype)
                 o.backward(gg)
+                if not args.no_plan_prefetch:
+                    lahead.append(model.prepare(lframes))
                 if reducer is not None:
                     reducer.finish()
                 return o

@@ -756,7 +756,8 @@ typedef struct sst_encoder_layer_fwd_args {
   const int32_t* pos_idx;
   float *qkv, *o, *lse, *y1, *s1, *st1, *pre, *h, *s2, *y2, *st2, *y2p;
   const float* head_scale;
-  void* wpack;   /* sst_encoder_layer_wpack_bytes() bytes, written by the forward call, read by the backward call of the SAME layer call */
+  void* wpack;   /* sst_encoder_layer_wpack_bytes() bytes, written by the forward call, read by the backward call of the SAME layer call;
+                    with w_out = w1 = w2 = NULL: already formed by sst_encoder_tail_pack_f32x6_many, only read */
   const float* xpos_table;     /* with xp == NULL: x + pos is formed on load from the positional table [P][128] ... */
   const int32_t* xpos_idx;     /* ... and the table row of every token (int32 [m]); then pos_table / y2p are normally NULL */
 } sst_encoder_layer_fwd_args;
@@ -823,6 +824,11 @@ typedef struct sst_encoder_tail_bwd_args {
 } sst_encoder_tail_bwd_args;
 int64_t sst_encoder_tail_pack_bytes(void);
 int sst_encoder_tail_pack_f32x6(const float* d_w_out, const float* d_w1, const float* d_w2, void* d_packed, void* stream);
+/* the images of n layers in ONE launch (arrays of n device pointers in HOST memory; d_packed[i]: sst_encoder_tail_pack_bytes()
+ * bytes each): what a stack of layers does once per forward pass (sst_v2.py:118-133 runs its blocks back to back);
+ * sst_encoder_layer_fwd_f32x6 takes such images with w_out = w1 = w2 = NULL in its arguments */
+int sst_encoder_tail_pack_f32x6_many(const float* const* d_w_out, const float* const* d_w1, const float* const* d_w2,
+                                     void* const* d_packed, int n, void* stream);
 int64_t sst_encoder_tail_bwd_workspace_bytes(int64_t m);
 int sst_encoder_tail_fwd_f32x6(const sst_encoder_tail_fwd_args* args, void* stream);
 int sst_encoder_tail_bwd_f32x6(const sst_encoder_tail_bwd_args* args, void* stream);

@@ -121,6 +121,7 @@ _SIGNATURES = {
     'sst_encoder_layer_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_tail_pack_bytes': (c_i64, []),
     'sst_encoder_tail_pack_f32x6': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sst_encoder_tail_pack_f32x6_many': (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr]),
     'sst_encoder_tail_bwd_workspace_bytes': (c_i64, [c_i64]),
     'sst_encoder_tail_fwd_f32x6': (c_i32, [c_ptr, c_ptr]),
     'sst_encoder_tail_bwd_f32x6': (c_i32, [c_ptr, c_ptr]),

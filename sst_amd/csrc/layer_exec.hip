@@ -88,10 +88,13 @@ int sst_encoder_layer_fwd_f32x6(const sst_encoder_layer_fwd_args* a, void* strea
     rc = sst_sra_attn_fwd_ord_f32(a->qkv, a->qkv + kC, a->qkv + 2 * kC, 3 * kC, 3 * kC, 3 * kC, a->tok, a->winoff, a->order,
                                   a->n_windows, a->n_heads, a->scale, a->max_tokens, a->impl, a->o, kC, a->lse, stream);
   if (rc) return rc;
-  // everything behind the attention core as one kernel (:113-118): the weight images of this call first
+  // everything behind the attention core as one kernel (:113-118): the weight images of this call first - unless the caller has
+  // formed them already (w_out = w1 = w2 = NULL: sst_encoder_tail_pack_f32x6_many, one launch for the whole stack)
   if (!a->wpack) return SST_ERR_ARG;
-  rc = sst_encoder_tail_pack_f32x6(a->w_out, a->w1, a->w2, a->wpack, stream);
-  if (rc) return rc;
+  if (a->w_out || a->w1 || a->w2) {
+    rc = sst_encoder_tail_pack_f32x6(a->w_out, a->w1, a->w2, a->wpack, stream);
+    if (rc) return rc;
+  }
   sst_encoder_tail_fwd_args t;
   t.m = m, t.act = a->act, t.reserved = 0, t.eps = a->eps, t.reserved_f = 0.f;
   t.o = a->o, t.x = a->x, t.packed = a->wpack;

@@ -239,10 +239,19 @@ __device__ __forceinline__ void stage_store(unsigned char* slot, int chunk, int 
   }
 }
 
-// the chunk images of both directions: packed[dir][chunk][kSlot bytes], dir 0 = forward, 1 = backward.  One workgroup per image.
-__global__ __launch_bounds__(512) void encoder_tail_pack_k(const tail_weights W, unsigned char* __restrict__ packed) {
+// the chunk images of both directions: packed[dir][chunk][kSlot bytes], dir 0 = forward, 1 = backward.  One workgroup per image;
+// a launch takes the weights of up to 16 layers (a whole encoder stack: one launch per forward pass instead of one per layer -
+// twelve 5 us launches of a 10.4 ms step)
+constexpr int kPackMany = 16;
+struct pack_batch {
+  tail_weights w[kPackMany];
+  unsigned char* dst[kPackMany];
+};
+__global__ __launch_bounds__(512) void encoder_tail_pack_k(const pack_batch B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int chunk = blockIdx.x % kNChunks, dir = blockIdx.x / kNChunks;
+  const int layer = blockIdx.x / (2 * kNChunks), blk = blockIdx.x % (2 * kNChunks);
+  const tail_weights W = B.w[layer];
+  const int chunk = blk % kNChunks, dir = blk / kNChunks;
   float r[16];
   if (dir == 0) {
     stage_load<false>(W, chunk, threadIdx.x, r);
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(512) void encoder_tail_pack_k(const tail_weights W,
     stage_store<true>(lds, chunk, threadIdx.x, r);
   }
   __syncthreads();
-  unsigned char* dst = packed + (size_t)blockIdx.x * kSlot;
+  unsigned char* dst = B.dst[layer] + (size_t)blk * kSlot;
   for (int i = threadIdx.x; i < kSlot / 16; i += 512) *(u32x4*)(dst + 16 * i) = *(const u32x4*)(lds + 16 * i);   // pads: whatever
 }
 
@@ -872,17 +881,30 @@ extern "C" {
 
 int64_t sst_encoder_tail_pack_bytes(void) { return 2 * (int64_t)kPackDir; }
 
-int sst_encoder_tail_pack_f32x6(const float* d_w_out, const float* d_w1, const float* d_w2, void* d_packed, void* stream) {
-  if (!d_w_out || !d_w1 || !d_w2 || !d_packed || !aligned16(d_w_out) || !aligned16(d_w1) || !aligned16(d_w2) || !aligned16(d_packed))
-    return SST_ERR_ARG;
+int sst_encoder_tail_pack_f32x6_many(const float* const* d_w_out, const float* const* d_w1, const float* const* d_w2,
+                                     void* const* d_packed, int n, void* stream) {
+  if (n < 0 || (n > 0 && (!d_w_out || !d_w1 || !d_w2 || !d_packed))) return SST_ERR_ARG;
   static unsigned long long cfg = 0;
   const int rc = configure(encoder_tail_pack_k, kSlot, &cfg);
   if (rc) return rc;
-  tail_weights W;
-  W.wo = d_w_out, W.w1 = d_w1, W.w2 = d_w2;
-  hipLaunchKernelGGL(encoder_tail_pack_k, dim3(2 * kNChunks), dim3(512), kSlot, (hipStream_t)stream, W, (unsigned char*)d_packed);
+  for (int base = 0; base < n; base += kPackMany) {
+    pack_batch B;
+    const int cnt = n - base < kPackMany ? n - base : kPackMany;
+    for (int i = 0; i < cnt; ++i) {
+      const float *wo = d_w_out[base + i], *w1 = d_w1[base + i], *w2 = d_w2[base + i];
+      void* dst = d_packed[base + i];
+      if (!wo || !w1 || !w2 || !dst || !aligned16(wo) || !aligned16(w1) || !aligned16(w2) || !aligned16(dst)) return SST_ERR_ARG;
+      B.w[i].wo = wo, B.w[i].w1 = w1, B.w[i].w2 = w2;
+      B.dst[i] = (unsigned char*)dst;
+    }
+    hipLaunchKernelGGL(encoder_tail_pack_k, dim3(cnt * 2 * kNChunks), dim3(512), kSlot, (hipStream_t)stream, B);
+  }
   SST_LAUNCH_CHECK();
   return SST_OK;
+}
+
+int sst_encoder_tail_pack_f32x6(const float* d_w_out, const float* d_w1, const float* d_w2, void* d_packed, void* stream) {
+  return sst_encoder_tail_pack_f32x6_many(&d_w_out, &d_w1, &d_w2, &d_packed, 1, stream);
 }
 
 int64_t sst_encoder_tail_bwd_workspace_bytes(int64_t m) {

@@ -247,7 +247,8 @@ def _slab_offsets(m):
     return out, off
 
 
-def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale=None, pos_spec=None):
+def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale=None, pos_spec=None,
+                    wpack=None):
     """-> (slab (uint8: the kept tensors at _slab_offsets), y2, y2p, wpack); head_scale ([nhead], device): cosine attention;
     xp None + pos_spec = (table, row index): x + positional rows formed on load"""
     from . import _lib
@@ -261,13 +262,16 @@ def _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next,
     y2 = torch.empty((m, 128), dtype=torch.float32, device=dev)
     y2p = torch.empty((m, 128), dtype=torch.float32, device=dev) if pos_next is not None else None
     lib = _lib.load()
-    wpack = torch.empty(int(lib.sst_encoder_layer_wpack_bytes()), dtype=torch.uint8, device=dev)   # weight images of the tail kernel
+    packed = wpack is not None     # the stack has formed this layer's weight images already (stack_tail_images: one launch for all)
+    if not packed:
+        wpack = torch.empty(int(lib.sst_encoder_layer_wpack_bytes()), dtype=torch.uint8, device=dev)   # weight images of the tail kernel
     order = plan.order
     P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     S = lambda name: base + offs[name]                   # noqa: E731
     args = _lib.EncoderLayerFwdArgs(
         m, plan.n_windows, nhead, 1 if act == 'gelu' else 2, plan.max_tokens, impl, float(eps), float(scale),
-        P(x), P(xp), P(w_in), P(b_in), P(w_out), P(b_out), P(w1), P(b1), P(w2), P(b2), P(n1w), P(n1b), P(n2w), P(n2b),
+        P(x), P(xp), P(w_in), P(b_in), None if packed else P(w_out), P(b_out), None if packed else P(w1), P(b1),
+        None if packed else P(w2), P(b2), P(n1w), P(n1b), P(n2w), P(n2b),
         None if plan.tok_ptr(impl) is None else plan.tok.data_ptr(), P(plan.winoff), P(order),
         P(pos_next[0]) if pos_next is not None else None, P(pos_next[1]) if pos_next is not None else None,
         S('qkv'), S('o'), S('lse'), S('y1'), S('s1') if need_bwd else None, S('st1'), S('pre'), S('h'), S('s2'), P(y2), S('st2'),
@@ -329,7 +333,7 @@ def _layer_exec_bwd(ctx, dy2, dy2p, saved):
     _lib.check(rc, 'sst_encoder_layer_bwd_f32x6')
     d_scale = K.head_scale_grad(cos_r, head_scale) if head_scale is not None else None
     return (ds1, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn[0], dn[1], dn[2], dn[3], None, None,
-            None, d_scale, None, None, None)
+            None, d_scale, None, None, None, None)
 
 
 def _bn_rows_fwd(bn, s):
@@ -388,8 +392,8 @@ class FusedEncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, plan, nhead, impl, act, w_in, b_in, w_out, b_out, w1, b1, w2, b2, n1w, n1b, n2w, n2b, eps,
-                xp=None, pos_next=None, head_scale=None, xp_shares_x=False, pos_spec=None, bn=None):
-        """bn = (norm1, norm2) modules (optional): batch-norm layers (layer_cfg use_bn=True, sst_basic_block_v2.py:92-99,
+                xp=None, pos_next=None, head_scale=None, xp_shares_x=False, pos_spec=None, bn=None, wpack=None):
+        """wpack (optional): this layer's tail weight images, already formed (stack_tail_images); bn = (norm1, norm2) modules (optional): batch-norm layers (layer_cfg use_bn=True, sst_basic_block_v2.py:92-99,
         configs/fsd/fsd_waymoD1_1x_sst_encoder.py:70) - the same node with the two LayerNorm passes replaced by statistics + apply
         passes over the sums the projections' epilogues leave (n1w .. n2b are then the modules' weight / bias).
         pos_spec = (table fp32 [P, C], row index int32 [M]) (optional, instead of pos / xp): the positional embedding of every
@@ -430,7 +434,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             need_bwd = any(ctx.needs_input_grad)
             scale = 1.0 / math.sqrt(16.0)
             done = _layer_exec_fwd(x, xp, plan, nhead, impl, act, params, eps, scale, pos_next, need_bwd, head_scale,
-                                   pos_spec if ctx.pos_fold else None)
+                                   pos_spec if ctx.pos_fold else None, wpack)
             if done is not None:
                 slab, y2, y2p, wpack = done
                 if need_bwd:
@@ -460,14 +464,14 @@ class FusedEncoderLayerFn(torch.autograd.Function):
             o, lse = K._sra_fwd(qk[:, :c], qk[:, c:], v, plan, nhead, scale, impl)
         need_bwd = any(ctx.needs_input_grad)  # False under torch.no_grad(): nothing is kept for a backward pass
         ctx.tail = False
-        wpack = None
         if bn is not None:
             y1, s1, st1, pre, h, s2, st2, y2, y2p, ctx.bn_cfg = FusedEncoderLayerFn._tail_batch_norm(
                 o, x, w_out, b_out, w1, b1, w2, b2, bn, act, pos_next)
         elif (_LDS_LINEAR and c == 128 and act in ('gelu', 'relu') and o.is_contiguous()
                 and encoder_tail_ok(o, x, w_out, w1, w2) and all(t is not None for t in (b_out, b1, b2))):
             # everything behind the attention core as ONE kernel (csrc/layer_tail_x6.hip), as csrc/layer_exec.hip issues it
-            wpack = encoder_tail_pack(w_out, w1, w2)
+            if wpack is None:
+                wpack = encoder_tail_pack(w_out, w1, w2)
             t = encoder_tail_fwd(o, x, wpack, b_out, b1, b2, n1w, n1b, n2w, n2b, eps, act, save=need_bwd, pos=pos_next)
             s1, st1, y1, pre, h, s2, st2, y2, y2p = (t[k] for k in ('s1', 'st1', 'y1', 'pre', 'h', 's2', 'st2', 'y2', 'y2p'))
             ctx.tail = True
@@ -627,7 +631,7 @@ class FusedEncoderLayerFn(torch.autograd.Function):
         else:
             dx = ds1.addmm_(dqkv, w_in)                               # residual + q,k,v branches (in place)
         return (dx, None, None, None, None, None, dw_in, db_in, dwo, dbo, dw1, db1, dw2, db2, dn1w, dn1b, dn2w, dn2b,
-                None, dxp, None, d_scale, None, None, None)
+                None, dxp, None, d_scale, None, None, None, None)
 
 
 class _StackHeadScales(torch.autograd.Function):
@@ -684,6 +688,39 @@ def stack_head_scales(layers):
     return out
 
 
+def stack_tail_images(layers, like):
+    """The tail weight images (csrc/layer_tail_x6.hip) of every LayerNorm layer of a stack in ONE launch
+    (sst_encoder_tail_pack_f32x6_many) - a list aligned with ``layers``: a byte tensor per layer the one-kernel tail can serve,
+    None for the others (batch-norm layers, other widths).  Fresh memory per forward pass (the images are kept for the backward
+    pass of THIS forward; ~1 MB per layer)."""
+    import ctypes
+    out = [None] * len(layers)
+    take = []
+    for i, enc in enumerate(layers):
+        attn = enc.win_attn.self_attn
+        wo, w1, w2 = attn.out_proj.weight, enc.linear1.weight, enc.linear2.weight
+        if (enc.bn_modules() is None and wo.is_cuda and wo.shape == (128, 128) and w1.shape == (256, 128) and w2.shape == (128, 256)
+                and all(w.dtype == torch.float32 and w.is_contiguous() and w.data_ptr() % 16 == 0 for w in (wo, w1, w2))
+                and enc.act_name in ('gelu', 'relu') and all(b is not None for b in (attn.out_proj.bias, enc.linear1.bias,
+                                                                                     enc.linear2.bias))):
+            take.append((i, wo, w1, w2))
+    if not take or not like.is_cuda:
+        return out
+    lib = _lib.load()
+    nbytes = (int(lib.sst_encoder_tail_pack_bytes()) + 255) // 256 * 256
+    buf = torch.empty(len(take) * nbytes, dtype=torch.uint8, device=like.device)
+    n = len(take)
+    P = ctypes.c_void_p * n
+    d = [buf[j * nbytes:(j + 1) * nbytes] for j in range(n)]
+    with torch.no_grad():
+        _lib.check(lib.sst_encoder_tail_pack_f32x6_many(P(*[t[1].data_ptr() for t in take]), P(*[t[2].data_ptr() for t in take]),
+                                                        P(*[t[3].data_ptr() for t in take]), P(*[v.data_ptr() for v in d]), n,
+                                                        _lib.stream_ptr()), 'sst_encoder_tail_pack_f32x6_many')
+    for (i, _, _, _), v in zip(take, d):
+        out[i] = v
+    return out
+
+
 def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()):
     """All encoder layers of the shift blocks as a chain of FusedEncoderLayerFn nodes that hand (x, x + positional embedding)
     to each other: "+ positional embedding" of layer i + 1 is the second output of layer i's last kernel, so no add pass and
@@ -701,6 +738,9 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
     fold = _POS_FOLD and mode == 'f32x6' and _LDS_LINEAR and all(inproj_pos_ok(feats.contiguous(), spec, blocks[0].encoder_list[0].win_attn.
                                                                  self_attn.in_proj_weight) for spec in pos_specs[:2])
 
+    layers = [enc for block in blocks for enc in block.encoder_list]
+    wpacks = stack_tail_images(layers, feats) if (mode == 'f32x6' and _LDS_LINEAR) else [None] * n_layers
+
     def layer(enc, li, x, xp):
         attn = enc.win_attn.self_attn
         if fold:
@@ -708,14 +748,14 @@ def run_encoder_stack_fp32(blocks, feats, plans, pos_specs, checkpoint_blocks=()
                 x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
                 attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
                 enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
-                enc.norm1.eps, None, None, scales[li], False, pos_specs[li % 2], enc.bn_modules())
+                enc.norm1.eps, None, None, scales[li], False, pos_specs[li % 2], enc.bn_modules(), wpacks[li])
             return out, None
         pos_next = pos_specs[(li + 1) % 2] if li + 1 < n_layers else None
         out = FusedEncoderLayerFn.apply(
             x, None, plans[li % 2], enc.win_attn.nhead, enc.win_attn.impl, enc.act_name, attn.in_proj_weight,
             attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias, enc.linear1.weight, enc.linear1.bias,
             enc.linear2.weight, enc.linear2.bias, enc.norm1.weight, enc.norm1.bias, enc.norm2.weight, enc.norm2.bias,
-            enc.norm1.eps, xp, pos_next, scales[li], True, None, enc.bn_modules())   # xp = x + positional rows: a constant offset
+            enc.norm1.eps, xp, pos_next, scales[li], True, None, enc.bn_modules(), wpacks[li])   # xp = x + positional rows: a constant offset
         return out if pos_next is not None else (out, None)
 
     def block_fn(bi):
