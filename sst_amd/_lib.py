@@ -425,7 +425,16 @@ def wants_half(module):
     one of the module's encoder layers / the module itself by mmcv's wrap_fp16_model"""
     if getattr(module, 'half_requested', False) or getattr(module, 'fp16_enabled', False):
         return True
-    return any(getattr(m, 'fp16_enabled', False) for m in module.modules())
+    # the submodules that carry the flag at all (the reference's auto_fp16 modules: encoder layers, norms, the input layer): found
+    # once per module object - walking module.modules() on every forward call was 7 x ~150 modules per step, 0.4 ms of a 3.4 ms
+    # host step (tools/host_profile.py).  A module added later is seen after `del module.__dict__['_sst_fp16_watch']`.
+    watch = module.__dict__.get('_sst_fp16_watch')
+    if watch is None:
+        watch = module.__dict__['_sst_fp16_watch'] = [m for m in module.modules() if hasattr(m, 'fp16_enabled')]
+    for m in watch:
+        if m.fp16_enabled:
+            return True
+    return False
 
 
 def as_fp32(*tensors):
