@@ -150,3 +150,68 @@ def test_tail_refuses_bad_arguments():
     assert lib.sst_encoder_tail_bwd_workspace_bytes(1000) >= 2 * 8 * 256 * 4
     assert lib.sst_encoder_tail_pack_bytes() == 2 * 10 * 48 * 1024
     assert lib.sst_encoder_tail_pack_f32x6(None, None, None, None, _lib.stream_ptr()) == _lib.SST_ERR_ARG
+
+
+def test_stack_pack_equals_per_layer_pack():
+    """sst_encoder_tail_pack_f32x6_many (one launch for the images of a whole stack; 20 layers = two launches of <= 16) writes
+    byte for byte what the per-layer call writes; the stack helper of sst_amd/sst_basic_block.py skips the layers the one-kernel
+    tail cannot serve"""
+    import ctypes
+    from sst_amd import _lib, dense as D
+    lib = _lib.load()
+    n = 20
+    ps = [_params(100 + i) for i in range(n)]
+    nbytes = int(lib.sst_encoder_tail_pack_bytes())
+    singles = [D.encoder_tail_pack(p['w_out'], p['w1'], p['w2']) for p in ps]
+    many = [torch.zeros(nbytes, dtype=torch.uint8, device=DEV) for _ in range(n)]
+    P = ctypes.c_void_p * n
+    rc = lib.sst_encoder_tail_pack_f32x6_many(P(*[p['w_out'].data_ptr() for p in ps]), P(*[p['w1'].data_ptr() for p in ps]),
+                                              P(*[p['w2'].data_ptr() for p in ps]), P(*[t.data_ptr() for t in many]), n,
+                                              _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    for a, b in zip(singles, many):
+        assert torch.equal(a, b)
+    assert lib.sst_encoder_tail_pack_f32x6_many(None, None, None, None, 3, _lib.stream_ptr()) == _lib.SST_ERR_ARG
+    assert lib.sst_encoder_tail_pack_f32x6_many(None, None, None, None, 0, _lib.stream_ptr()) == 0
+
+
+def test_stack_images_feed_the_layer_call():
+    """a stack of LayerNorm layers: forward + backward with the stack-level weight images is bit-identical to the per-layer
+    images (SST_AMD-independent: the helper is switched off by handing the layers None)"""
+    import sst_amd
+    from sst_amd import sst_basic_block as B
+    from conftest import DROP_TEST, DROP_TRAIN
+    torch.manual_seed(5)
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2,
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=False)).to(DEV).train()
+    g = torch.Generator().manual_seed(0)
+    coors = torch.unique(torch.stack([torch.randint(0, 2, (5000,), generator=g), torch.zeros(5000, dtype=torch.long),
+                                      torch.randint(0, 468, (5000,), generator=g), torch.randint(0, 468, (5000,), generator=g)], 1),
+                         dim=0).int().to(DEV)
+    feats = torch.randn(coors.size(0), 128, generator=g).to(DEV)
+    layer = sst_amd.SSTInputLayerV2((DROP_TRAIN, DROP_TEST), (12, 12, 1), (468, 468, 1), shuffle_voxels=False, debug=False, mute=True)
+    layer.eval()
+    gout = torch.randn(feats.shape, generator=g).to(DEV)
+
+    def run():
+        x = feats.clone().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        out = net(layer(x, coors, 2))[0]['voxel_feats']
+        (out * gout).sum().backward()
+        return out.detach(), x.grad.detach(), [p.grad.detach().clone() for p in net.parameters()]
+
+    calls = []
+    orig = B.stack_tail_images
+    try:
+        B.stack_tail_images = lambda layers, like: (calls.append(1), orig(layers, like))[1]
+        a = run()
+        assert calls, 'the chain must ask for the stack-level images'
+        B.stack_tail_images = lambda layers, like: [None] * len(layers)
+        b = run()
+    finally:
+        B.stack_tail_images = orig
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for u, v in zip(a[2], b[2]):
+        assert torch.equal(u, v)

@@ -2,6 +2,8 @@
 oracle; encoder layers / SSTv2 block against golden tensors from the reference's own Python.
 Tolerance: 1e-3 absolute on fp32 features (BASELINE.json north_star), in practice ~1e-5."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,7 @@ from conftest import DROP_TEST, DROP_TRAIN, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-3
 
 
@@ -453,3 +456,45 @@ def test_d_model_192_twelve_heads_against_float64(fused):
     out.square().sum().backward()
     assert torch.isfinite(feats.grad).all() and float(feats.grad.abs().max()) > 0
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def _run_split_probe(split):
+    """forward of the attention core on 12 windows of 49..100 tokens (a SMALL launch: the query-tile split is on by default) in a
+    process of its own with SST_SRA_SPLIT=<split> (the switch is read once per process) -> output tensors on the host"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from sst_amd import kernels as K
+sizes = np.array([100, 97, 81, 80, 65, 64, 49, 52, 33, 16, 7, 100], dtype=np.int64)
+off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+m = int(off[-1])
+g = torch.Generator().manual_seed(11)
+qkv = torch.randn(m, 384, generator=g).cuda()
+perm = torch.randperm(m, generator=g).int().cuda()
+for tag, plan in (('rows', K.WindowPlan(torch.arange(m, dtype=torch.int32).cuda(), torch.from_numpy(off).cuda(), len(sizes), m, 100, rows_in_window_order=True)),
+                  ('list', K.WindowPlan(perm, torch.from_numpy(off).cuda(), len(sizes), m, 100))):
+    o, lse = K._sra_fwd(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], plan, 8, 0.25, 0)
+    hs = torch.linspace(2.0, 6.0, 8).cuda()
+    oc, lsec = K._sra_cos_fwd(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], plan, 8, hs)
+    np.savez(sys.argv[1] + tag + '.npz', o=o.cpu().numpy(), lse=lse.cpu().numpy(), oc=oc.cpu().numpy(), lsec=lsec.cpu().numpy())
+''' % (ROOT,)
+    d = tempfile.mkdtemp()
+    env = dict(os.environ, SST_SRA_SPLIT=str(split))
+    subprocess.run([sys.executable, '-c', code, d + '/'], check=True, env=env, timeout=300)
+    return {t: dict(np.load(f'{d}/{t}.npz')) for t in ('rows', 'list')}
+
+
+def test_query_tile_split_of_small_launches_is_bit_identical():
+    """sra_fwd_wave_k deals windows of >= 4 tiles out over two (or four) workgroups when the launch is small: every query row is
+    still computed by one wave from the same K / V fragments in the same order - the outputs must not differ in a single bit from
+    the unsplit launch (standard and cosine attention, rows in window order and through a token list)"""
+    base = _run_split_probe(1)
+    for parts in (2, 4):
+        got = _run_split_probe(parts)
+        for t in base:
+            for k in base[t]:
+                assert np.array_equal(base[t][k], got[t][k]), (parts, t, k)
