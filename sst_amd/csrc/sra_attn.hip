@@ -966,12 +966,15 @@ template <int NT, bool EXACT, bool NOHOIST, bool COS>
 __device__ __forceinline__ void sra_bwd_fused_body(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, uint32_t ldq, uint32_t ldk, uint32_t ldv, uint32_t ldo,
-    uint32_t lddo, const int32_t* __restrict__ tok, int beg, int t, int nt, int hg, int H, float scale,
+    uint32_t lddo, const int32_t* __restrict__ tok, int beg, int t, int nt, int head, int H, float scale,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, uint32_t lddq, uint32_t lddk, uint32_t lddv,
-    float* __restrict__ lds, const float* __restrict__ hscale, float* __restrict__ R) {
+    float* __restrict__ lds, const float* __restrict__ hscale, float* __restrict__ R, int part = 0, int parts = 1,
+    float* __restrict__ partner_lds = nullptr) {
+  // part / parts (small launches, sra_bwd_fused_k): this wave takes the query tiles part, part + 2, ... of the window; the wave
+  // next to it in the workgroup (same head, partner_lds = its LDS block) takes the others.  dQ rows belong to one of the two;
+  // dK / dV are partial sums over each wave's query tiles: wave 1 hands its partials to wave 0 through its LDS block at the end.
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int sig = (c >> 2) + 4 * (c & 3);  // token held by tile slot c
-  const int head = hg * kWH + (threadIdx.x >> 6);
   const uint32_t hoff = head * kHD;
   if (COS) scale = hscale[head];
   float* Kimg = lds;                 // [NT * 16][kTS]  K rows, tile slot order
@@ -1023,7 +1026,7 @@ __device__ __forceinline__ void sra_bwd_fused_body(
     q.lse = LSE[row * (uint32_t)H + head];
     return q;
   };
-  qtile cur = load_tile(0);
+  qtile cur = load_tile(part < nt ? part : 0);
   // K image (column fragments of K for dQ += dS K)
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -1036,7 +1039,7 @@ __device__ __forceinline__ void sra_bwd_fused_body(
   float* drow = Dimg + c * kTS + 4 * g;                  // write: [key slot c][query slots 4g .. 4g+3]
   const float* dcol = Dimg + (4 * g) * kTS + c;          // read:  [key slot 4g + r][query slot c]
 
-  for (int i = 0; i < nt; ++i) {
+  for (int i = part; i < nt; i += parts) {
     // NOHOIST: the K column fragments are re-read from the LDS image for every tile pair (4 ds_read_b32) instead of
     // being kept in 4 VGPRs per key tile across the whole loop - the price of a third wave per SIMD
     if (NOHOIST) asm volatile("" ::: "memory");
@@ -1048,7 +1051,7 @@ __device__ __forceinline__ void sra_bwd_fused_body(
     const uint32_t qrow = cur.row;
     *(float4*)(Qimg + c * kTS + 4 * g) = qf;
     *(float4*)(Gimg + c * kTS + 4 * g) = gf;
-    cur = load_tile(i + 1 < nt ? i + 1 : i);  // prefetch of the next query tile
+    cur = load_tile(i + parts < nt ? i + parts : i);  // prefetch of this wave's next query tile
     float qc[4], gc[4], lse2[4], dd4[4], rmask[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1106,6 +1109,32 @@ __device__ __forceinline__ void sra_bwd_fused_body(
     }
     if (i * 16 + sig < t) *(float4*)(dQ + (qrow * lddq + hoff + 4 * g)) = o;
   }
+  if (parts == 2) {
+    // the two waves of a head meet: wave 1 leaves its dK (then its dV) partial tiles in ITS LDS block (its K image is dead: its
+    // query loop is over), wave 0 adds them to its own in a fixed order (own + partner: deterministic) and stores.  Workgroup
+    // barriers: all four waves of a split workgroup belong to the same window and run the same number of rounds.
+    f32x4* mine = (f32x4*)lds;
+    const f32x4* theirs = (const f32x4*)partner_lds;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      if (part == 1) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (EXACT || j < nt) mine[j * 64 + lane] = round == 0 ? dk[j] : dv[j];
+      }
+      __syncthreads();
+      if (part == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (EXACT || j < nt) {
+            if (round == 0) dk[j] += theirs[j * 64 + lane];
+            else dv[j] += theirs[j * 64 + lane];
+          }
+      }
+      __syncthreads();
+    }
+    if (part == 1) return;
+  }
   // dK^T / dV^T likewise: lane (g, c) holds d{K,V}[token of key slot c][4g .. 4g+3]
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -1134,19 +1163,46 @@ __global__ __launch_bounds__(64 * kWH, WPS) void sra_bwd_fused_k(
     const float* __restrict__ dO, const float* __restrict__ LSE, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
     int64_t lddo, const int32_t* __restrict__ tok, const int32_t* __restrict__ winoff, int n_groups, int H, float scale,
     float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int64_t lddq, int64_t lddk, int64_t lddv,
-    const int32_t* __restrict__ order, const float* __restrict__ hscale, float* __restrict__ R) {
+    const int32_t* __restrict__ order, const float* __restrict__ hscale, float* __restrict__ R, int n_win, int qs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool NH = WPS >= 3;
-  const int bid = SST_SRA_BLOCK(blockIdx.x, gridDim.x);
-  const int wpos = bid / n_groups;
-  const int hg = bid - wpos * n_groups;
+  // Small launches (qs == 2): the grid carries one further workgroup per (window, head group) IN FRONT of the regular ones.  A
+  // window of kSplitTiles tiles and more is then served by both: each takes two of the group's four heads, and the two waves of a
+  // head share the window's query tiles (part 0: tiles 0, 2, .., part 1: tiles 1, 3, ..) - the 7 x 7 dependent tile pairs of a
+  // 100-token window on ONE wave per head (27.6 us alone) were the whole launch on a sweep-sized frame (34 us for 75 MB).
+  const int n_main = n_win * n_groups;
+  const int n_extra = (int)gridDim.x - n_main;
+  int sub = 0, wpos, hg;
+  if ((int)blockIdx.x < n_extra) {
+    sub = 1;
+    const int from_end = (int)blockIdx.x / n_groups;
+    hg = (int)blockIdx.x - from_end * n_groups;
+    wpos = n_win - 1 - from_end;
+  } else {
+    const int bid = SST_SRA_BLOCK((int)blockIdx.x - n_extra, n_main);
+    wpos = bid / n_groups;
+    hg = bid - wpos * n_groups;
+  }
   const int w = order != nullptr ? order[wpos] : wpos;
   const int beg = winoff[w];
   const int t = winoff[w + 1] - beg;
   const int nt = (t + 15) >> 4;
   if (nt < 1 || nt > NTMAX) return;  // > NTMAX: the generic kernel owns this window
-  float* lds = smem + (threadIdx.x >> 6) * sra_fused_lds_floats_per_wave(NTMAX);
-#define SST_FUSED_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, hg, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, lds, hscale, R
+  const int wave = threadIdx.x >> 6;
+  int head = hg * kWH + wave, part = 0, parts = 1;
+  if (qs == 2) {
+    if (nt >= kSplitTiles) {
+      static_assert(kWH % 2 == 0, "the split pairs the waves of a workgroup");
+      head = hg * kWH + sub * (kWH / 2) + (wave >> 1);
+      part = wave & 1;
+      parts = 2;
+    } else if (sub) {
+      return;
+    }
+  }
+  float* lds = smem + wave * sra_fused_lds_floats_per_wave(NTMAX);
+  float* plds = smem + (wave ^ 1) * sra_fused_lds_floats_per_wave(NTMAX);
+#define SST_FUSED_ARGS Q, K, V, O, dO, LSE, (uint32_t)ldq, (uint32_t)ldk, (uint32_t)ldv, (uint32_t)ldo, (uint32_t)lddo, tok, beg, t, nt, head, H, scale, dQ, dK, dV, (uint32_t)lddq, (uint32_t)lddk, (uint32_t)lddv, lds, hscale, R, part, parts, plds
   switch (nt) {
     case 1: sra_bwd_fused_body<1, true, NH, COS>(SST_FUSED_ARGS); break;
     case 2: sra_bwd_fused_body<2, true, NH, COS>(SST_FUSED_ARGS); break;
@@ -1160,6 +1216,21 @@ __global__ __launch_bounds__(64 * kWH, WPS) void sra_bwd_fused_k(
       break;
   }
 #undef SST_FUSED_ARGS
+}
+
+// parts a large window is dealt out over, by the size of the launch (workgroups before the split).  A launch that fills the chip
+// several times over hides a long wave behind the others; below that the long waves ARE the launch.
+// SST_SRA_SPLIT=<parts> / SST_SRA_SPLIT_MAX_WG=<workgroups> override (A/B runs).
+int sra_split_parts(int64_t n_workgroups) {
+  static int parts_env = -1, max_wg = 0;
+  if (parts_env < 0) {
+    const char* e = getenv("SST_SRA_SPLIT");
+    const char* m = getenv("SST_SRA_SPLIT_MAX_WG");
+    max_wg = m ? atoi(m) : 2048;     // measured (tools/sra_sizes.py, kernel-exact events): 10 x 100 tokens 12.8 -> 8.5 us, LiDAR-like
+    parts_env = e ? atoi(e) : 2;     // frame (1 620 workgroups) 18.0 -> 17.4 us with 2 parts; 4 parts and larger launches lose to the empty workgroups
+  }
+  if (parts_env <= 1 || n_workgroups > max_wg) return 1;
+  return parts_env;
 }
 
 template <int NTMAX, int WPS>
@@ -1183,7 +1254,8 @@ int launch_bwd_fused(const float* Q, const float* K, const float* V, const float
     SST_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     __atomic_fetch_or(&configured[slot], bit, __ATOMIC_RELEASE);
   }
-  const dim3 grid((unsigned)(n_windows * n_groups));
+  const int qs = (NTMAX >= kSplitTiles && sra_split_parts(n_windows * n_groups) > 1) ? 2 : 1;
+  const dim3 grid((unsigned)(n_windows * n_groups * qs));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof_bwd_start != nullptr && g_prof_bwd_stop != nullptr) {
     e0 = g_prof_bwd_start;
@@ -1192,10 +1264,11 @@ int launch_bwd_fused(const float* Q, const float* K, const float* V, const float
   }
   if (e0 != nullptr)  // kernel-exact start / stop timestamps on the launch stream
     hipExtLaunchKernelGGL(kern, grid, dim3(64 * kWH), lds, st, e0, e1, 0, Q, K, V, O, dO, LSE, ldq,
-                          ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order, hs, rbuf);
+                          ldk, ldv, ldo, lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order, hs, rbuf,
+                          (int)n_windows, qs);
   else
     hipLaunchKernelGGL(kern, grid, dim3(64 * kWH), lds, st, Q, K, V, O, dO, LSE, ldq, ldk, ldv, ldo,
-                       lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order, hs, rbuf);
+                       lddo, tok, winoff, n_groups, H, scale, dQ, dK, dV, lddq, lddk, lddv, g_win_order, hs, rbuf, (int)n_windows, qs);
   return SST_OK;
 }
 
@@ -1224,21 +1297,6 @@ int launch_fwd_variant(const float* Q, const float* K, const float* V, int64_t l
   hipLaunchKernelGGL(sra_fwd_mfma_k<NT>, dim3((unsigned)(n_windows * n_groups)), dim3(256), lds, st, Q, K, V, ldq, ldk,
                      ldv, tok, winoff, n_groups, H, scale, nt_lo, O, ldo, LSE);
   return SST_OK;
-}
-
-// parts a large window is dealt out over, by the size of the launch (workgroups before the split).  A launch that fills the chip
-// several times over hides a long wave behind the others; below that the long waves ARE the launch.
-// SST_SRA_SPLIT=<parts> / SST_SRA_SPLIT_MAX_WG=<workgroups> override (A/B runs).
-int sra_split_parts(int64_t n_workgroups) {
-  static int parts_env = -1, max_wg = 0;
-  if (parts_env < 0) {
-    const char* e = getenv("SST_SRA_SPLIT");
-    const char* m = getenv("SST_SRA_SPLIT_MAX_WG");
-    max_wg = m ? atoi(m) : 2048;     // measured (tools/sra_sizes.py, kernel-exact events): 10 x 100 tokens 12.8 -> 8.5 us, LiDAR-like
-    parts_env = e ? atoi(e) : 2;     // frame (1 620 workgroups) 18.0 -> 17.4 us with 2 parts; 4 parts and larger launches lose to the empty workgroups
-  }
-  if (parts_env <= 1 || n_workgroups > max_wg) return 1;
-  return parts_env;
 }
 
 template <int NTMAX>

@@ -480,7 +480,15 @@ for tag, plan in (('rows', K.WindowPlan(torch.arange(m, dtype=torch.int32).cuda(
     o, lse = K._sra_fwd(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], plan, 8, 0.25, 0)
     hs = torch.linspace(2.0, 6.0, 8).cuda()
     oc, lsec = K._sra_cos_fwd(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], plan, 8, hs)
-    np.savez(sys.argv[1] + tag + '.npz', o=o.cpu().numpy(), lse=lse.cpu().numpy(), oc=oc.cpu().numpy(), lsec=lsec.cpu().numpy())
+    do = torch.randn(m, 128, generator=torch.Generator().manual_seed(12)).cuda()
+    out = dict(o=o.cpu().numpy(), lse=lse.cpu().numpy(), oc=oc.cpu().numpy(), lsec=lsec.cpu().numpy())
+    for rep in range(2):      # twice: the hand-over of the partial dK / dV tiles must not depend on which wave arrives first
+        d = torch.empty_like(qkv)
+        K._sra_bwd(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], o, lse, do, plan, 8, 0.25, 0, d[:, :128], d[:, 128:256], d[:, 256:])
+        dc = torch.empty_like(qkv)
+        K._sra_cos_bwd(qkv[:, :128], qkv[:, 128:256], qkv[:, 256:], oc, lsec, do, plan, 8, hs, dc[:, :128], dc[:, 128:256], dc[:, 256:])
+        out['d' + str(rep)], out['dc' + str(rep)] = d.cpu().numpy(), dc.cpu().numpy()
+    np.savez(sys.argv[1] + tag + '.npz', **out)
 ''' % (ROOT,)
     d = tempfile.mkdtemp()
     env = dict(os.environ, SST_SRA_SPLIT=str(split))
@@ -488,7 +496,7 @@ for tag, plan in (('rows', K.WindowPlan(torch.arange(m, dtype=torch.int32).cuda(
     return {t: dict(np.load(f'{d}/{t}.npz')) for t in ('rows', 'list')}
 
 
-def test_query_tile_split_of_small_launches_is_bit_identical():
+def test_query_tile_split_of_small_launches():
     """sra_fwd_wave_k deals windows of >= 4 tiles out over two (or four) workgroups when the launch is small: every query row is
     still computed by one wave from the same K / V fragments in the same order - the outputs must not differ in a single bit from
     the unsplit launch (standard and cosine attention, rows in window order and through a token list)"""
@@ -496,5 +504,12 @@ def test_query_tile_split_of_small_launches_is_bit_identical():
     for parts in (2, 4):
         got = _run_split_probe(parts)
         for t in base:
-            for k in base[t]:
+            for k in ('o', 'lse', 'oc', 'lsec'):
                 assert np.array_equal(base[t][k], got[t][k]), (parts, t, k)
+            # backward (two parts whatever SST_SRA_SPLIT > 1 says): dQ rows belong to one wave - bit-identical; dK / dV are the
+            # sum of two partial sums over the query tiles instead of one running sum - equal to fp32 rounding, and reproducible
+            for k in ('d', 'dc'):
+                assert np.array_equal(got[t][k + '0'], got[t][k + '1']), (parts, t, k, 'run-to-run')
+                assert np.array_equal(base[t][k + '0'][:, :128], got[t][k + '0'][:, :128]), (parts, t, k, 'dQ')
+                scale = np.abs(base[t][k + '0']).max()
+                assert np.abs(base[t][k + '0'] - got[t][k + '0']).max() <= 2e-6 * scale, (parts, t, k)
