@@ -470,7 +470,10 @@ __device__ __forceinline__ void sra_fwd_wave_body(const float* __restrict__ Q, c
 // One launch for every window: the tile class is picked per workgroup, so all classes run concurrently
 // (separate per-class launches serialise on the stream and the sparse classes run at very low occupancy).
 template <int NTMAX, bool COS>
-__global__ __launch_bounds__(64 * kWH) void sra_fwd_wave_k(const float* __restrict__ Q, const float* __restrict__ K,
+// (second launch bound = waves per SIMD the register allocation aims at: the 5-tile classes and the standard 4-tile class fit 95-96
+// VGPRs without a spill when asked to - five waves per SIMD instead of four at 100; same-box A/B on the bench frame: 50.9 -> 50.2 us
+// per launch.  The cosine 4-tile class would spill 12 bytes per lane: left alone.)
+__global__ __launch_bounds__(64 * kWH, ((NTMAX == 5 || (NTMAX <= 4 && !COS)) ? 5 : 1)) void sra_fwd_wave_k(const float* __restrict__ Q, const float* __restrict__ K,
                                                       const float* __restrict__ V, int64_t ldq, int64_t ldk,
                                                       int64_t ldv, const int32_t* __restrict__ tok,
                                                       const int32_t* __restrict__ winoff, int n_groups, int H,
