@@ -97,3 +97,31 @@ def test_half_keeps_the_fp32_master_weights():
     assert _lib.as_fp32(torch.zeros(2, dtype=torch.float16)).dtype == torch.float32
     x = torch.zeros(2)
     assert _lib.as_fp32(x) is x
+
+
+def test_round6_host_logic_without_a_gpu():
+    """host side of the round-6 additions: the stack-level weight-image helper declines CPU layers (the per-layer call then packs
+    for itself), batch-norm encoder layers are recognised as chain material by shape alone, and the fp16-flag watch list of
+    _lib.wants_half follows flags that are set after its first use"""
+    import sst_amd
+    from sst_amd import _lib
+    from sst_amd import sst_basic_block as B
+    net = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128], nhead=[8], num_blocks=1, dim_feedforward=[256],
+                                      output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=False,
+                                      layer_cfg=dict(use_bn=True)))
+    layers = [enc for block in net.block_list for enc in block.encoder_list]
+    assert all(enc.bn_modules() is not None and B._bn_layer_ok(enc.norm1, 128) and B._bn_layer_ok(enc.norm2, 128) for enc in layers)
+    assert not B._bn_layer_ok(layers[0].norm1, 64) and not B._bn_layer_ok(torch.nn.LayerNorm(128), 128)
+    assert B.stack_tail_images(layers, torch.zeros(1)) == [None, None]          # batch-norm layers: never the one-kernel tail
+    ln = sst_amd.build_backbone(dict(type='SSTv2', d_model=[128], nhead=[8], num_blocks=1, dim_feedforward=[256],
+                                     output_shape=[468, 468], num_attached_conv=0, to_bev=False, debug=False))
+    ln_layers = [enc for block in ln.block_list for enc in block.encoder_list]
+    assert ln_layers[0].bn_modules() is None
+    assert B.stack_tail_images(ln_layers, torch.zeros(1)) == [None, None]       # CPU parameters: nothing to launch
+    assert not _lib.wants_half(ln)
+    assert '_sst_fp16_watch' in ln.__dict__ and len(ln.__dict__['_sst_fp16_watch']) >= 2
+    ln_layers[1].fp16_enabled = True                                            # what mmcv's wrap_fp16_model does, later
+    assert _lib.wants_half(ln)
+    ln_layers[1].fp16_enabled = False
+    assert not _lib.wants_half(ln)
+    assert all(k.count('_sst_fp16_watch') == 0 for k in ln.state_dict())
